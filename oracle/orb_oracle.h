@@ -1,0 +1,125 @@
+/*
+ * orb_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the reference's per-frame ORB front-end
+ * (fabrizioromanelli/ORBSLAM2: src/ORBextractor.cc, src/Frame.cc:464-666,
+ * src/ORBmatcher.cc) plus the OpenCV 4.5.5 routines that path calls
+ * (cv::FAST, cv::resize INTER_LINEAR 8U, cv::GaussianBlur 8U fixed point,
+ * cv::fastAtan2, cvRound).  Every function cites the reference file:line it
+ * follows.
+ *
+ * PARITY UNPINNED: the reference ships no tests / golden vectors for this path
+ * and OpenCV is not available in the authoring container, so this oracle is
+ * pinned only by first-principles known-answer tests (tests/test_oracle_*.py)
+ * and the committed fixtures generated from it (tests/golden/).  Routines that
+ * restate OpenCV behaviour from knowledge of the 4.5.5 sources carry the tag
+ * OPENCV-4.5.5-SEMANTICS.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product (orbslam2_amd/csrc) never links it.
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Layout-identical to cv::KeyPoint (28 bytes). */
+typedef struct orc_keypoint {
+    float x, y;      /* pt */
+    float size;      /* patch diameter at level scale */
+    float angle;     /* degrees [0,360) */
+    float response;  /* FAST score */
+    int32_t octave;
+    int32_t class_id;
+} orc_keypoint;
+
+typedef struct orc_params {
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t nlevels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+    int32_t patch_size;
+    int32_t half_patch_size;
+    int32_t edge_threshold;
+} orc_params;
+
+typedef struct orc_extractor orc_extractor;
+
+/* ---- scalar helpers (OpenCV semantics) ---- */
+int orc_cv_round_f(float v);            /* cvRound(float): round-half-even */
+int orc_cv_round_d(double v);           /* cvRound(double) */
+float orc_fast_atan2(float y, float x); /* cv::fastAtan2, degrees */
+void orc_sincos_det(float rad, float *s, float *c); /* contract Q4 routine */
+int orc_border_reflect101(int p, int len);
+int orc_hamming256(const uint8_t *a, const uint8_t *b); /* ORBmatcher::DescriptorDistance */
+const int32_t *orc_bit_pattern(void);   /* 1024 ints */
+void orc_gaussian_taps_q8(int ksize, double sigma, int32_t *taps); /* fixed-point 8.8 taps */
+
+/* ---- image primitives ---- */
+void orc_resize_linear_u8(const uint8_t *src, int sw, int sh, size_t sstride,
+                          uint8_t *dst, int dw, int dh, size_t dstride);
+void orc_gaussian7_u8(const uint8_t *src, int w, int h, size_t sstride,
+                      uint8_t *dst, size_t dstride);
+/* cv::FAST(img, kps, threshold, nonmax=true), type 9_16.  Returns count; xs/ys/scores hold up to cap. */
+int orc_fast9_16(const uint8_t *img, int w, int h, size_t stride, int threshold,
+                 int nonmax, int32_t *xs, int32_t *ys, int32_t *scores, int cap);
+/* cornerScore<16> at one pixel (needs 3-px margin). */
+int orc_fast_corner_score(const uint8_t *ptr, size_t stride, int threshold);
+/* closed-form score: max(t, max_arc min(v-p), max_arc min(p-v)) - 1 */
+int orc_fast_score_closed_form(const uint8_t *ptr, size_t stride, int threshold);
+
+/* ---- extractor ---- */
+orc_extractor *orc_extractor_create(const orc_params *p);
+void orc_extractor_destroy(orc_extractor *ex);
+int orc_extractor_nlevels(const orc_extractor *ex);
+const float *orc_extractor_scale_factors(const orc_extractor *ex);
+const float *orc_extractor_inv_scale_factors(const orc_extractor *ex);
+const float *orc_extractor_sigma2(const orc_extractor *ex);
+const float *orc_extractor_inv_sigma2(const orc_extractor *ex);
+const int32_t *orc_extractor_features_per_level(const orc_extractor *ex);
+const int32_t *orc_extractor_umax(const orc_extractor *ex);
+void orc_level_size(const orc_extractor *ex, int w, int h, int level, int *lw, int *lh);
+
+/* ORBextractor::operator().  Returns number of keypoints (may exceed cap: then
+ * only cap entries were written), or -1 on bad args.  Empty image -> 0. */
+int orc_extract(orc_extractor *ex, const uint8_t *img, int w, int h, size_t stride,
+                orc_keypoint *kps, uint8_t *desc, int cap);
+/* pyramid of the latest orc_extract call (unblurred), as mvImagePyramid */
+const uint8_t *orc_pyramid_level(const orc_extractor *ex, int level, int *w, int *h, size_t *stride);
+/* candidates (pre-quadtree) of the latest call at one level: returns count; coords are region-relative */
+int orc_level_candidates(const orc_extractor *ex, int level, const int32_t **xs, const int32_t **ys,
+                         const int32_t **scores);
+
+/* DistributeOctTree on integer candidates (region-relative coords).  Writes the
+ * indices of the retained candidates in output order; returns their count. */
+int orc_distribute_octtree(const int32_t *xs, const int32_t *ys, const int32_t *scores, int n,
+                           int min_x, int max_x, int min_y, int max_y, int n_features,
+                           int32_t *out_idx, int cap);
+
+float orc_ic_angle(const uint8_t *img, size_t stride, int cx, int cy, const int32_t *umax, int half_patch);
+void orc_orb_descriptor(const uint8_t *img, size_t stride, int cx, int cy, float angle_deg, uint8_t *desc32);
+
+/* ---- Frame::ComputeStereoMatches ---- */
+/* Uses the pyramids held by exL/exR (latest orc_extract calls).  mb := bf/fx (Q1). */
+int orc_stereo_matches(const orc_extractor *exL, const orc_extractor *exR,
+                       const orc_keypoint *kL, const uint8_t *dL, int nL,
+                       const orc_keypoint *kR, const uint8_t *dR, int nR,
+                       float bf, float fx, float *u_right, float *depth,
+                       int32_t *best_idx_r /* optional, -1 when no coarse match */,
+                       int32_t *best_sad /* optional */);
+
+/* Frame::ComputeStereoFromRGBD */
+void orc_stereo_from_rgbd(const orc_keypoint *k, const orc_keypoint *k_un, int n,
+                          const float *depth, int w, int h, size_t stride_floats,
+                          float bf, float *u_right, float *out_depth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
