@@ -1,0 +1,147 @@
+/*
+ * orbfe.h -- C ABI of the MI355X (gfx950) ORB front-end.
+ *
+ * Drop-in boundary for the per-frame front-end of fabrizioromanelli/ORBSLAM2.
+ * Every entry point names the reference interface it replaces (file:line under
+ * the reference tree).  Plain pointers and sizes only; no C++/torch types; no
+ * exceptions cross this boundary.  All functions return ORBFE_OK (0) or a
+ * negative error code; orbfe_last_error() gives a message.
+ *
+ * Threading: a context is not re-entrant (the reference never re-enters one
+ * ORBextractor, src/Frame.cc:78-81); different contexts may be used from
+ * different threads concurrently.
+ *
+ * There is NO CPU fallback: if no HIP device is present orbfe_create fails
+ * with ORBFE_ERR_NO_DEVICE.
+ */
+#ifndef ORBFE_H
+#define ORBFE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBFE_ABI_VERSION 1
+
+enum {
+    ORBFE_OK = 0,
+    ORBFE_ERR_INVALID = -1,    /* bad argument */
+    ORBFE_ERR_NO_DEVICE = -2,  /* no HIP device / HIP runtime failure at create */
+    ORBFE_ERR_HIP = -3,        /* HIP runtime error during a call */
+    ORBFE_ERR_CAPACITY = -4,   /* caller buffer or context capacity too small */
+    ORBFE_ERR_UNSUPPORTED = -5 /* image type / size outside what the context was built for */
+};
+
+/* Layout-identical to cv::KeyPoint (28 bytes) so compat shims can memcpy. */
+typedef struct orbfe_keypoint {
+    float x, y;      /* pt, level-0 pixel coordinates */
+    float size;      /* int(patchSize * scale[octave]) */
+    float angle;     /* degrees, [0,360) */
+    float response;  /* FAST score */
+    int32_t octave;
+    int32_t class_id; /* -1 */
+} orbfe_keypoint;
+
+/* The 8 ORBextractor constructor arguments (include/ORBextractor.h:51,
+ * src/ORBextractor.cc:405) + the camera numbers Frame needs (src/Frame.cc:104-114)
+ * + sizing of the device context. */
+typedef struct orbfe_params {
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t nlevels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+    int32_t patch_size;
+    int32_t half_patch_size;
+    int32_t edge_threshold;
+    float fx, fy, cx, cy;
+    float bf;             /* baseline * fx (Frame::mbf) */
+    int32_t device;       /* HIP device ordinal */
+    int32_t width, height;/* image size the context is built for (one camera model per context) */
+    int32_t max_images;   /* images in flight per batched call (2 per stereo pair) */
+} orbfe_params;
+
+typedef struct orbfe_context orbfe_context;
+
+int orbfe_abi_version(void);
+const char *orbfe_last_error(const orbfe_context *ctx);
+
+/* Replaces `new ORBextractor(...)` (src/Tracking.cc:125-131, src/ORBextractor.cc:405-464). */
+int orbfe_create(const orbfe_params *params, orbfe_context **out);
+void orbfe_destroy(orbfe_context *ctx);
+
+/* Getters of include/ORBextractor.h:61-82 (GetLevels/GetScaleFactors/...), plus
+ * mnFeaturesPerLevel and umax for tests.  Arrays hold nlevels entries (umax: half_patch+1). */
+int orbfe_levels(const orbfe_context *ctx);
+int orbfe_keypoint_capacity(const orbfe_context *ctx); /* max keypoints one image can yield */
+int orbfe_get_tables(const orbfe_context *ctx, float *scale, float *inv_scale, float *sigma2,
+                     float *inv_sigma2, int32_t *features_per_level, int32_t *umax);
+int orbfe_level_size(const orbfe_context *ctx, int level, int *w, int *h);
+
+/* ORBextractor::operator() (src/ORBextractor.cc:858-919): host image in, host
+ * keypoints (level-major, quadtree-leaf order) + 32-byte descriptors out.
+ * `cap` entries are available in kps/desc; *n receives the count.  An empty image
+ * (img==NULL or w/h<=0) returns ORBFE_OK with *n = 0 and outputs untouched. */
+int orbfe_extract(orbfe_context *ctx, const uint8_t *img, int w, int h, size_t stride,
+                  orbfe_keypoint *kps, uint8_t *desc, int cap, int *n);
+
+/* Frame::Frame(stereo) body (src/Frame.cc:61-117): ExtractORB(left) + ExtractORB(right)
+ * + ComputeStereoMatches (src/Frame.cc:464-642).  u_right/depth have cap entries and
+ * are filled for the first *n_left (-1 where unmatched).  mb := bf/fx. */
+int orbfe_stereo_frame(orbfe_context *ctx, const uint8_t *left, const uint8_t *right,
+                       int w, int h, size_t stride,
+                       orbfe_keypoint *kps_left, uint8_t *desc_left, int *n_left,
+                       orbfe_keypoint *kps_right, uint8_t *desc_right, int *n_right,
+                       float *u_right, float *depth, int cap);
+
+/* Frame::Frame(rgbd) body (src/Frame.cc:120-172) for an undistorted camera:
+ * ExtractORB + ComputeStereoFromRGBD (src/Frame.cc:645-666).  depth_img is CV_32F
+ * metres, row stride in bytes; kps_un may be NULL (then kps are used: k1 == 0). */
+int orbfe_rgbd_frame(orbfe_context *ctx, const uint8_t *gray, const float *depth_img,
+                     int w, int h, size_t gray_stride, size_t depth_stride,
+                     orbfe_keypoint *kps, uint8_t *desc, int *n,
+                     float *u_right, float *depth, int cap);
+
+/* mvImagePyramid[level] of image slot `image` of the latest call (include/ORBextractor.h:84;
+ * read by src/Frame.cc:471,565,577,582).  blurred!=0 returns the Gaussian-blurred
+ * working copy (src/ORBextractor.cc:899-900).  Copies w*h bytes into dst (row stride dst_stride). */
+int orbfe_fetch_pyramid(orbfe_context *ctx, int image, int level, int blurred,
+                        uint8_t *dst, size_t dst_stride);
+
+/* ---- batched / device-resident path (no reference counterpart: SURVEY.md §8e) ----
+ * d_images: device pointer to n_images contiguous 8UC1 images (w*h bytes each, row
+ * stride w; stereo pairs as L0,R0,L1,R1,...).  Work is enqueued on `stream`
+ * (a hipStream_t; NULL = the context's own stream) and NOT synchronised.  Results
+ * stay in context-owned device buffers until fetched. */
+int orbfe_enqueue_extract(orbfe_context *ctx, const uint8_t *d_images, int n_images, void *stream);
+int orbfe_enqueue_stereo(orbfe_context *ctx, const uint8_t *d_images, int n_pairs, void *stream);
+int orbfe_synchronize(orbfe_context *ctx, void *stream);
+/* Copy the results of image slot `image` to host.  u_right/depth may be NULL. */
+int orbfe_fetch_image(orbfe_context *ctx, int image, orbfe_keypoint *kps, uint8_t *desc,
+                      float *u_right, float *depth, int cap, int *n);
+/* Per-image keypoint counts of the latest batch (n_images ints). */
+int orbfe_fetch_counts(orbfe_context *ctx, int32_t *counts, int n_images);
+/* Device pointers to the result buffers (for consumers that stay on the GPU):
+ * keypoints [max_images][capacity], descriptors [max_images][capacity][32],
+ * counts [max_images], u_right/depth [max_images][capacity]. */
+int orbfe_device_buffers(orbfe_context *ctx, void **kps, void **desc, void **counts,
+                         void **u_right, void **depth);
+
+/* ---- stage taps for parity tests (results of the latest call) ---- */
+/* FAST+NMS candidates of (image, level) in the reference's emission order
+ * (src/ORBextractor.cc:783-823); coordinates relative to (minBorderX, minBorderY). */
+int orbfe_fetch_candidates(orbfe_context *ctx, int image, int level, int32_t *xs, int32_t *ys,
+                           int32_t *scores, int cap, int *n);
+
+/* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1643-1659) for every (a_i, b_j):
+ * host descriptors in, host int32 matrix [na][nb] out. */
+int orbfe_hamming_matrix(orbfe_context *ctx, const uint8_t *desc_a, int na,
+                         const uint8_t *desc_b, int nb, int32_t *dist);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,225 @@
+"""ctypes binding of the C ABI (include/orbfe.h) -- plumbing for tests and bench.py.
+
+The product is liborbfe.so (HIP, gfx950).  This module never computes anything
+itself and has no CPU fallback: if the library is missing or no GPU is present
+the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liborbfe.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+
+EXPORTS = [
+    "orbfe_abi_version", "orbfe_last_error", "orbfe_create", "orbfe_destroy", "orbfe_levels",
+    "orbfe_keypoint_capacity", "orbfe_get_tables", "orbfe_level_size", "orbfe_extract",
+    "orbfe_stereo_frame", "orbfe_rgbd_frame", "orbfe_fetch_pyramid", "orbfe_enqueue_extract",
+    "orbfe_enqueue_stereo", "orbfe_synchronize", "orbfe_fetch_image", "orbfe_fetch_counts",
+    "orbfe_device_buffers", "orbfe_fetch_candidates", "orbfe_hamming_matrix",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("patch_size", C.c_int32),
+                ("half_patch_size", C.c_int32), ("edge_threshold", C.c_int32),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("bf", C.c_float), ("device", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("max_images", C.c_int32)]
+
+
+class OrbfeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("orbfe error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load liborbfe.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("liborbfe.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "or `make -C orbslam2_amd/csrc`")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.orbfe_abi_version.restype = C.c_int
+    L.orbfe_last_error.restype = C.c_char_p; L.orbfe_last_error.argtypes = [vp]
+    L.orbfe_create.restype = C.c_int; L.orbfe_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    L.orbfe_destroy.restype = None; L.orbfe_destroy.argtypes = [vp]
+    L.orbfe_levels.restype = C.c_int; L.orbfe_levels.argtypes = [vp]
+    L.orbfe_keypoint_capacity.restype = C.c_int; L.orbfe_keypoint_capacity.argtypes = [vp]
+    L.orbfe_get_tables.restype = C.c_int; L.orbfe_get_tables.argtypes = [vp] + [vp] * 6
+    L.orbfe_level_size.restype = C.c_int; L.orbfe_level_size.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.orbfe_extract.restype = C.c_int
+    L.orbfe_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, vp, C.c_int, C.POINTER(C.c_int)]
+    L.orbfe_stereo_frame.restype = C.c_int
+    L.orbfe_stereo_frame.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, vp, vp, C.POINTER(C.c_int),
+                                     vp, vp, C.POINTER(C.c_int), vp, vp, C.c_int]
+    L.orbfe_rgbd_frame.restype = C.c_int
+    L.orbfe_rgbd_frame.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, vp, vp, C.POINTER(C.c_int), vp, vp, C.c_int]
+    L.orbfe_fetch_pyramid.restype = C.c_int
+    L.orbfe_fetch_pyramid.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
+    L.orbfe_enqueue_extract.restype = C.c_int; L.orbfe_enqueue_extract.argtypes = [vp, vp, C.c_int, vp]
+    L.orbfe_enqueue_stereo.restype = C.c_int; L.orbfe_enqueue_stereo.argtypes = [vp, vp, C.c_int, vp]
+    L.orbfe_synchronize.restype = C.c_int; L.orbfe_synchronize.argtypes = [vp, vp]
+    L.orbfe_fetch_image.restype = C.c_int
+    L.orbfe_fetch_image.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int)]
+    L.orbfe_fetch_counts.restype = C.c_int; L.orbfe_fetch_counts.argtypes = [vp, vp, C.c_int]
+    L.orbfe_device_buffers.restype = C.c_int; L.orbfe_device_buffers.argtypes = [vp] + [C.POINTER(vp)] * 5
+    L.orbfe_fetch_candidates.restype = C.c_int
+    L.orbfe_fetch_candidates.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_int)]
+    L.orbfe_hamming_matrix.restype = C.c_int
+    L.orbfe_hamming_matrix.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One device context = one ORBextractor pair / one camera model (include/orbfe.h)."""
+
+    def __init__(self, width, height, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th_fast=20,
+                 min_th_fast=7, patch_size=31, half_patch_size=15, edge_threshold=19,
+                 fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, bf=386.1448, device=0, max_images=2):
+        self.L = load()
+        self.params = Params(nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast, patch_size,
+                             half_patch_size, edge_threshold, fx, fy, cx, cy, bf, device, width, height, max_images)
+        h = C.c_void_p()
+        rc = self.L.orbfe_create(C.byref(self.params), C.byref(h))
+        if rc != OK:
+            raise OrbfeError(rc, self.L.orbfe_last_error(None).decode())
+        self.h = h
+        self.width, self.height = width, height
+        self.nlevels = nlevels
+        self.capacity = self.L.orbfe_keypoint_capacity(self.h)
+        self.max_images = max_images
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.orbfe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != OK:
+            raise OrbfeError(rc, self.L.orbfe_last_error(self.h).decode())
+
+    # ---- tables (ORBextractor getters) ----
+    def tables(self):
+        n = self.nlevels
+        sc, isc, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        feats = np.zeros(n, np.int32)
+        umax = np.zeros(self.params.half_patch_size + 1, np.int32)
+        self._check(self.L.orbfe_get_tables(self.h, _p(sc), _p(isc), _p(s2), _p(is2), _p(feats), _p(umax)))
+        return dict(scale=sc, inv_scale=isc, sigma2=s2, inv_sigma2=is2, features_per_level=feats, umax=umax)
+
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        self._check(self.L.orbfe_level_size(self.h, level, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    # ---- host-image entry points ----
+    def extract(self, img: np.ndarray):
+        img = np.ascontiguousarray(img, np.uint8)
+        cap = self.capacity
+        kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int()
+        self._check(self.L.orbfe_extract(self.h, _p(img), img.shape[1], img.shape[0], img.strides[0], _p(kps), _p(desc), cap, C.byref(n)))
+        return kps[: n.value].copy(), desc[: n.value].copy()
+
+    def stereo_frame(self, left: np.ndarray, right: np.ndarray):
+        left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
+        assert left.shape == right.shape
+        cap = self.capacity
+        kl = np.zeros(cap, KP_DTYPE); dl = np.zeros((cap, 32), np.uint8)
+        kr = np.zeros(cap, KP_DTYPE); dr = np.zeros((cap, 32), np.uint8)
+        ur = np.zeros(cap, np.float32); dp = np.zeros(cap, np.float32)
+        nl, nr = C.c_int(), C.c_int()
+        self._check(self.L.orbfe_stereo_frame(self.h, _p(left), _p(right), left.shape[1], left.shape[0], left.strides[0],
+                                              _p(kl), _p(dl), C.byref(nl), _p(kr), _p(dr), C.byref(nr), _p(ur), _p(dp), cap))
+        a, b = nl.value, nr.value
+        return dict(kps_left=kl[:a].copy(), desc_left=dl[:a].copy(), kps_right=kr[:b].copy(), desc_right=dr[:b].copy(),
+                    u_right=ur[:a].copy(), depth=dp[:a].copy())
+
+    def rgbd_frame(self, gray: np.ndarray, depth_img: np.ndarray):
+        gray = np.ascontiguousarray(gray, np.uint8); depth_img = np.ascontiguousarray(depth_img, np.float32)
+        cap = self.capacity
+        k = np.zeros(cap, KP_DTYPE); d = np.zeros((cap, 32), np.uint8)
+        ur = np.zeros(cap, np.float32); dp = np.zeros(cap, np.float32)
+        n = C.c_int()
+        self._check(self.L.orbfe_rgbd_frame(self.h, _p(gray), _p(depth_img), gray.shape[1], gray.shape[0], gray.strides[0],
+                                            depth_img.strides[0], _p(k), _p(d), C.byref(n), _p(ur), _p(dp), cap))
+        m = n.value
+        return dict(kps=k[:m].copy(), desc=d[:m].copy(), u_right=ur[:m].copy(), depth=dp[:m].copy())
+
+    # ---- taps ----
+    def fetch_pyramid(self, image, level, blurred=False):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        self._check(self.L.orbfe_fetch_pyramid(self.h, image, level, int(blurred), _p(out), out.strides[0]))
+        return out
+
+    def fetch_candidates(self, image, level):
+        w, h = self.level_size(level)
+        cap = max(16, (w * h) // 4 + 16)
+        xs, ys, sc = (np.zeros(cap, np.int32) for _ in range(3))
+        n = C.c_int()
+        self._check(self.L.orbfe_fetch_candidates(self.h, image, level, _p(xs), _p(ys), _p(sc), cap, C.byref(n)))
+        return xs[: n.value].copy(), ys[: n.value].copy(), sc[: n.value].copy()
+
+    # ---- device-resident batched path ----
+    def enqueue_extract(self, d_ptr: int, n_images: int, stream: int = 0):
+        self._check(self.L.orbfe_enqueue_extract(self.h, C.c_void_p(d_ptr), n_images, C.c_void_p(stream)))
+
+    def enqueue_stereo(self, d_ptr: int, n_pairs: int, stream: int = 0):
+        self._check(self.L.orbfe_enqueue_stereo(self.h, C.c_void_p(d_ptr), n_pairs, C.c_void_p(stream)))
+
+    def synchronize(self, stream: int = 0):
+        self._check(self.L.orbfe_synchronize(self.h, C.c_void_p(stream)))
+
+    def fetch_counts(self, n_images):
+        c = np.zeros(n_images, np.int32)
+        self._check(self.L.orbfe_fetch_counts(self.h, _p(c), n_images))
+        return c
+
+    def fetch_image(self, image, stereo=False):
+        cap = self.capacity
+        k = np.zeros(cap, KP_DTYPE); d = np.zeros((cap, 32), np.uint8)
+        ur = np.zeros(cap, np.float32); dp = np.zeros(cap, np.float32)
+        n = C.c_int()
+        self._check(self.L.orbfe_fetch_image(self.h, image, _p(k), _p(d), _p(ur) if stereo else None,
+                                             _p(dp) if stereo else None, cap, C.byref(n)))
+        m = n.value
+        out = dict(kps=k[:m].copy(), desc=d[:m].copy())
+        if stereo:
+            out.update(u_right=ur[:m].copy(), depth=dp[:m].copy())
+        return out
+
+    def hamming_matrix(self, a: np.ndarray, b: np.ndarray):
+        a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+        out = np.zeros((len(a), len(b)), np.int32)
+        self._check(self.L.orbfe_hamming_matrix(self.h, _p(a), len(a), _p(b), len(b), _p(out)))
+        return out

@@ -1,0 +1,517 @@
+// orbfe_api.hip -- host side of the C ABI declared in include/orbfe.h.
+//
+// Builds the level / cell / quota tables exactly as ORBextractor::ORBextractor and
+// ComputePyramid do (reference src/ORBextractor.cc:405-464,921-946), owns the HBM
+// buffers of one batch of images, and enqueues the kernels of orbfe_kernels.hip.
+// There is no CPU compute path here: without a HIP device orbfe_create fails.
+#include "../../include/orbfe.h"
+#include "orbfe_device.h"
+
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+size_t orbfe_octree_lds_bytes(const DeviceConfig &cfg);
+
+struct orbfe_context {
+    orbfe_params params;
+    DeviceConfig cfg;
+    DeviceBuffers buf;
+    hipStream_t stream = nullptr;
+    uint8_t *d_in = nullptr;      // staging for host-image entry points [max_images][w*h]
+    float *d_depth_in = nullptr;  // staging for RGB-D depth
+    uint8_t *d_ham = nullptr;     // scratch for orbfe_hamming_matrix
+    size_t d_ham_bytes = 0;
+    int last_images = 0;
+    float scale[ORBFE_MAX_LEVELS], inv_scale[ORBFE_MAX_LEVELS], sigma2[ORBFE_MAX_LEVELS], inv_sigma2[ORBFE_MAX_LEVELS];
+    int32_t feats[ORBFE_MAX_LEVELS];
+    std::vector<void *> allocs;
+    char err[512];
+};
+
+static thread_local char g_err[512] = "";
+
+static int fail(orbfe_context *ctx, int code, const char *fmt, ...)
+{
+    char msg[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(msg, sizeof(msg), fmt, ap);
+    va_end(ap);
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s", msg);
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail(ctx, ORBFE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" int orbfe_abi_version(void) { return ORBFE_ABI_VERSION; }
+extern "C" const char *orbfe_last_error(const orbfe_context *ctx) { return ctx ? ctx->err : g_err; }
+
+static int cv_round_f(float v) { return (int)lrintf(v); }
+
+// OpenCV 4.5.5 getGaussianKernelBitExact + getGaussianKernelFixedPoint_ED (see oracle for provenance)
+static void gaussian_taps_q8(int ksize, double sigma, int *taps)
+{
+    double g[64];
+    double scale2x = -0.5 / (sigma * sigma);
+    double sum = 0.0;
+    for (int i = 0; i < ksize; i++) {
+        double x = (double)i - (double)(ksize - 1) * 0.5;
+        g[i] = exp(scale2x * x * x);
+        sum += g[i];
+    }
+    sum = 1.0 / sum;
+    for (int i = 0; i < ksize; i++) g[i] *= sum;
+    int n2 = ksize / 2;
+    double err = 0.0;
+    long acc = 0;
+    for (int i = 0; i < n2; i++) {
+        double adj = g[i] * 256.0 + err;
+        long v0 = lrint(adj);
+        err = adj - (double)v0;
+        taps[i] = (int)v0;
+        taps[ksize - 1 - i] = (int)v0;
+        acc += 2 * v0;
+    }
+    taps[n2] = (int)(256 - acc);
+}
+
+template <typename T>
+static int dev_alloc(orbfe_context *ctx, T **p, size_t count)
+{
+    void *q = nullptr;
+    size_t bytes = sizeof(T) * (count ? count : 1);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(ctx, ORBFE_ERR_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    ctx->allocs.push_back(q);
+    *p = (T *)q;
+    return ORBFE_OK;
+}
+
+// Tables of ORBextractor::ORBextractor (src/ORBextractor.cc:405-464) and the per-level
+// geometry of ComputePyramid / ComputeKeyPointsOctTree / DistributeOctTree.
+static int build_config(orbfe_context *ctx)
+{
+    const orbfe_params &p = ctx->params;
+    DeviceConfig &c = ctx->cfg;
+    memset(&c, 0, sizeof(c));
+    c.nlevels = p.nlevels;
+    c.width = p.width; c.height = p.height;
+    c.edge_threshold = p.edge_threshold;
+    c.min_border = p.edge_threshold - 3;
+    c.ini_th = p.ini_th_fast; c.min_th = p.min_th_fast;
+    c.half_patch = p.half_patch_size;
+    c.bf = p.bf; c.fx = p.fx;
+    c.mb = p.fx != 0.f ? p.bf / p.fx : 0.f; // mb := mbf / fx
+
+    const double sf_d = (double)p.scale_factor; // member is double, initialised from float
+    ctx->scale[0] = 1.0f; ctx->sigma2[0] = 1.0f;
+    for (int i = 1; i < p.nlevels; i++) {
+        ctx->scale[i] = (float)((double)ctx->scale[i - 1] * sf_d);
+        ctx->sigma2[i] = ctx->scale[i] * ctx->scale[i];
+    }
+    for (int i = 0; i < p.nlevels; i++) {
+        ctx->inv_scale[i] = 1.0f / ctx->scale[i];
+        ctx->inv_sigma2[i] = 1.0f / ctx->sigma2[i];
+    }
+    const float factor = (float)(1.0 / sf_d);
+    float n_desired = (float)p.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)p.nlevels));
+    int sum = 0;
+    for (int l = 0; l < p.nlevels - 1; l++) {
+        ctx->feats[l] = cv_round_f(n_desired);
+        sum += ctx->feats[l];
+        n_desired *= factor;
+    }
+    ctx->feats[p.nlevels - 1] = p.nfeatures - sum > 0 ? p.nfeatures - sum : 0;
+
+    const int hp = p.half_patch_size;
+    const int vmax = (int)floor((double)((float)hp * sqrtf(2.f) / 2 + 1));
+    const int vmin = (int)ceil((double)((float)hp * sqrtf(2.f) / 2));
+    const double hp2 = (double)(hp * hp);
+    for (int v = 0; v <= vmax; ++v) c.umax[v] = (int)lrint(sqrt(hp2 - (double)(v * v)));
+    for (int v = hp, v0 = 0; v >= vmin; --v) {
+        while (c.umax[v0] == c.umax[v0 + 1]) ++v0;
+        c.umax[v] = v0;
+        ++v0;
+    }
+    gaussian_taps_q8(7, 2.0, c.taps);
+
+    size_t pyr_off = 0;
+    int cell_off = 0, cand_off = 0, sel_off = 0, tile_off = 0, cell_cap = 1, max_nodes = 8;
+    for (int l = 0; l < p.nlevels; l++) {
+        LevelInfo &L = c.lv[l];
+        L.scale = ctx->scale[l]; L.inv_scale = ctx->inv_scale[l];
+        L.w = cv_round_f((float)p.width * L.inv_scale);
+        L.h = cv_round_f((float)p.height * L.inv_scale);
+        if (L.w < 1 || L.h < 1) return fail(ctx, ORBFE_ERR_UNSUPPORTED, "level %d is empty (%dx%d)", l, L.w, L.h);
+        L.pitch = (L.w + 63) & ~63;
+        L.pyr_off = (int)pyr_off;
+        pyr_off += ((size_t)L.pitch * L.h + 255) & ~(size_t)255;
+        if (l > 0) {
+            L.rs_scale_x = 1.0 / ((double)L.w / (double)c.lv[l - 1].w);
+            L.rs_scale_y = 1.0 / ((double)L.h / (double)c.lv[l - 1].h);
+        }
+        L.scaled_patch = (int)((float)p.patch_size * L.scale);
+        L.quota = ctx->feats[l];
+        const int min_b = c.min_border;
+        const int max_bx = L.w - p.edge_threshold + 3, max_by = L.h - p.edge_threshold + 3;
+        const float width = (float)(max_bx - min_b), height = (float)(max_by - min_b);
+        L.n_cols = (int)(width / 30.f);
+        L.n_rows = (int)(height / 30.f);
+        L.cell_off = cell_off; L.cand_off = cand_off;
+        int cand_cap = 0;
+        if (L.n_cols >= 1 && L.n_rows >= 1 && max_bx > min_b && max_by > min_b) {
+            L.w_cell = (int)ceilf(width / (float)L.n_cols);
+            L.h_cell = (int)ceilf(height / (float)L.n_rows);
+            L.n_cells = L.n_cols * L.n_rows;
+            for (int i = 0; i < L.n_rows; i++) {
+                const int ini_y = min_b + i * L.h_cell;
+                int my = ini_y + L.h_cell + 6;
+                if (ini_y >= max_by - 3) continue;
+                if (my > max_by) my = max_by;
+                for (int j = 0; j < L.n_cols; j++) {
+                    const int ini_x = min_b + j * L.w_cell;
+                    int mx = ini_x + L.w_cell + 6;
+                    if (ini_x >= max_bx - 6) continue;
+                    if (mx > max_bx) mx = max_bx;
+                    const int iw = mx - ini_x - 6, ih = my - ini_y - 6;
+                    if (iw <= 0 || ih <= 0) continue;
+                    const int cc = ((iw + 1) / 2) * ((ih + 1) / 2); // 3x3 strict NMS survivors bound
+                    cand_cap += cc;
+                    if (cc > cell_cap) cell_cap = cc;
+                }
+            }
+            L.n_ini = (int)roundf(width / height);
+            if (L.n_ini < 1) L.n_ini = 1; // reference would index an empty vector; documented guard
+            L.hx = width / (float)L.n_ini;
+        } else {
+            L.n_cols = L.n_rows = 0; L.w_cell = L.h_cell = 0; L.n_cells = 0;
+            L.n_ini = 1; L.hx = 1.f;
+        }
+        L.cand_cap = cand_cap;
+        cell_off += L.n_cells;
+        cand_off += (cand_cap + 3) & ~3;
+        L.sel_off = sel_off;
+        L.sel_cap = (L.quota + 3 > 4 * L.n_ini ? L.quota + 3 : 4 * L.n_ini) + 1;
+        sel_off += L.sel_cap;
+        if (L.sel_cap + 1 > max_nodes) max_nodes = L.sel_cap + 1;
+        L.blur_tile_off = tile_off;
+        L.blur_tiles_x = (L.w + 63) / 64;
+        L.blur_tiles_y = (L.h + 15) / 16;
+        tile_off += L.blur_tiles_x * L.blur_tiles_y;
+    }
+    c.pyr_bytes = pyr_off;
+    c.cells_total = cell_off > 0 ? cell_off : 1;
+    c.cand_total = cand_off > 0 ? cand_off : 4;
+    c.sel_total = sel_off;
+    c.cell_cap = cell_cap;
+    c.blur_tiles_total = tile_off;
+    c.max_nodes = max_nodes;
+    if (p.width > 32767 || p.height > 32767) return fail(ctx, ORBFE_ERR_UNSUPPORTED, "image larger than 32767 px");
+    if (c.sel_total > 65535) return fail(ctx, ORBFE_ERR_UNSUPPORTED, "nfeatures too large (keypoint capacity %d > 65535)", c.sel_total);
+    if (orbfe_octree_lds_bytes(c) > 64 * 1024) return fail(ctx, ORBFE_ERR_UNSUPPORTED, "nfeatures too large for the quadtree LDS budget");
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
+{
+    if (!params || !out) return fail(nullptr, ORBFE_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const orbfe_params &p = *params;
+    if (p.nlevels < 1 || p.nlevels > ORBFE_MAX_LEVELS || p.nfeatures < 1 || !(p.scale_factor > 1.0f) ||
+        p.half_patch_size < 1 || p.half_patch_size > 62 || p.edge_threshold < p.half_patch_size + 4 ||
+        p.width < 1 || p.height < 1 || p.max_images < 1 || p.min_th_fast < 1 || p.ini_th_fast < p.min_th_fast ||
+        p.ini_th_fast > 254)
+        return fail(nullptr, ORBFE_ERR_INVALID, "invalid orbfe_params");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, ORBFE_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (p.device < 0 || p.device >= ndev) return fail(nullptr, ORBFE_ERR_INVALID, "device %d out of range (%d)", p.device, ndev);
+    orbfe_context *ctx = new (std::nothrow) orbfe_context();
+    if (!ctx) return fail(nullptr, ORBFE_ERR_INVALID, "out of host memory");
+    ctx->err[0] = 0;
+    ctx->params = p;
+    int rc = build_config(ctx);
+    if (rc != ORBFE_OK) { snprintf(g_err, sizeof(g_err), "%s", ctx->err); delete ctx; return rc; }
+    // edge threshold must cover the descriptor reach (pattern radius 18.4 + rounding) and the patch
+    if (hipSetDevice(p.device) != hipSuccess) { delete ctx; return fail(nullptr, ORBFE_ERR_NO_DEVICE, "hipSetDevice failed"); }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return fail(nullptr, ORBFE_ERR_NO_DEVICE, "hipStreamCreate failed"); }
+    const DeviceConfig &c = ctx->cfg;
+    const size_t B = (size_t)p.max_images;
+    DeviceBuffers &b = ctx->buf;
+    KeyPointPOD *kps = nullptr;
+#define A(ptr, count) do { rc = dev_alloc(ctx, &(ptr), (count)); if (rc != ORBFE_OK) { orbfe_destroy(ctx); return rc; } } while (0)
+    A(b.pyr, B * c.pyr_bytes);
+    A(b.blur, B * c.pyr_bytes);
+    A(b.cell_cnt, B * c.cells_total);
+    A(b.cell_xy, B * c.cells_total * c.cell_cap);
+    A(b.cell_sc, B * c.cells_total * c.cell_cap);
+    A(b.cell_base, B * c.cells_total);
+    A(b.cand_xy, B * c.cand_total);
+    A(b.cand_sc, B * c.cand_total);
+    A(b.idx0, B * c.cand_total);
+    A(b.idx1, B * c.cand_total);
+    A(b.lvl_ncand, B * c.nlevels);
+    A(b.sel_cnt, B * c.nlevels);
+    A(b.sel_xy, B * c.sel_total);
+    A(b.sel_sc, B * c.sel_total);
+    A(kps, B * c.sel_total);
+    b.kps = kps;
+    A(b.desc, B * c.sel_total * 32);
+    A(b.kp_cnt, B);
+    A(b.u_right, B * c.sel_total);
+    A(b.depth, B * c.sel_total);
+    A(b.sad, B * c.sel_total);
+    A(b.status, B);
+    A(ctx->d_in, B * (size_t)p.width * p.height);
+#undef A
+    hipMemset(b.kp_cnt, 0, sizeof(int) * B);
+    hipMemset(b.sel_cnt, 0, sizeof(int) * B * c.nlevels);
+    hipMemset(b.status, 0, sizeof(int) * B);
+    *out = ctx;
+    return ORBFE_OK;
+}
+
+extern "C" void orbfe_destroy(orbfe_context *ctx)
+{
+    if (!ctx) return;
+    if (ctx->stream) { hipStreamSynchronize(ctx->stream); }
+    for (void *q : ctx->allocs) hipFree(q);
+    if (ctx->d_depth_in) hipFree(ctx->d_depth_in);
+    if (ctx->d_ham) hipFree(ctx->d_ham);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int orbfe_levels(const orbfe_context *ctx) { return ctx ? ctx->cfg.nlevels : ORBFE_ERR_INVALID; }
+extern "C" int orbfe_keypoint_capacity(const orbfe_context *ctx) { return ctx ? ctx->cfg.sel_total : ORBFE_ERR_INVALID; }
+
+extern "C" int orbfe_get_tables(const orbfe_context *ctx, float *scale, float *inv_scale, float *sigma2,
+                                float *inv_sigma2, int32_t *features_per_level, int32_t *umax)
+{
+    if (!ctx) return ORBFE_ERR_INVALID;
+    const int n = ctx->cfg.nlevels;
+    if (scale) memcpy(scale, ctx->scale, sizeof(float) * n);
+    if (inv_scale) memcpy(inv_scale, ctx->inv_scale, sizeof(float) * n);
+    if (sigma2) memcpy(sigma2, ctx->sigma2, sizeof(float) * n);
+    if (inv_sigma2) memcpy(inv_sigma2, ctx->inv_sigma2, sizeof(float) * n);
+    if (features_per_level) memcpy(features_per_level, ctx->feats, sizeof(int32_t) * n);
+    if (umax) memcpy(umax, ctx->cfg.umax, sizeof(int32_t) * (ctx->cfg.half_patch + 1));
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_level_size(const orbfe_context *ctx, int level, int *w, int *h)
+{
+    if (!ctx || level < 0 || level >= ctx->cfg.nlevels) return ORBFE_ERR_INVALID;
+    if (w) *w = ctx->cfg.lv[level].w;
+    if (h) *h = ctx->cfg.lv[level].h;
+    return ORBFE_OK;
+}
+
+static hipStream_t pick_stream(orbfe_context *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
+
+extern "C" int orbfe_enqueue_extract(orbfe_context *ctx, const uint8_t *d_images, int n_images, void *stream)
+{
+    if (!ctx || !d_images) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    if (n_images < 1 || n_images > ctx->params.max_images)
+        return fail(ctx, ORBFE_ERR_CAPACITY, "n_images %d outside [1, %d]", n_images, ctx->params.max_images);
+    hipStream_t s = pick_stream(ctx, stream);
+    HIP_TRY(ctx, hipSetDevice(ctx->params.device));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->buf.status, 0, sizeof(int) * n_images, s));
+    orbfe_launch_ingest(ctx->cfg, ctx->buf, d_images, n_images, s);
+    orbfe_launch_pyramid(ctx->cfg, ctx->buf, n_images, s);
+    orbfe_launch_blur(ctx->cfg, ctx->buf, n_images, s);
+    orbfe_launch_fast(ctx->cfg, ctx->buf, n_images, s);
+    orbfe_launch_octree(ctx->cfg, ctx->buf, n_images, s);
+    orbfe_launch_describe(ctx->cfg, ctx->buf, n_images, s);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->last_images = n_images;
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_enqueue_stereo(orbfe_context *ctx, const uint8_t *d_images, int n_pairs, void *stream)
+{
+    if (!ctx) return fail(ctx, ORBFE_ERR_INVALID, "null context");
+    if (n_pairs < 1 || 2 * n_pairs > ctx->params.max_images)
+        return fail(ctx, ORBFE_ERR_CAPACITY, "n_pairs %d needs max_images >= %d", n_pairs, 2 * n_pairs);
+    int rc = orbfe_enqueue_extract(ctx, d_images, 2 * n_pairs, stream);
+    if (rc != ORBFE_OK) return rc;
+    orbfe_launch_stereo(ctx->cfg, ctx->buf, n_pairs, pick_stream(ctx, stream));
+    HIP_TRY(ctx, hipGetLastError());
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_synchronize(orbfe_context *ctx, void *stream)
+{
+    if (!ctx) return ORBFE_ERR_INVALID;
+    HIP_TRY(ctx, hipStreamSynchronize(pick_stream(ctx, stream)));
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_fetch_counts(orbfe_context *ctx, int32_t *counts, int n_images)
+{
+    if (!ctx || !counts || n_images < 1 || n_images > ctx->params.max_images) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
+    HIP_TRY(ctx, hipMemcpy(counts, ctx->buf.kp_cnt, sizeof(int32_t) * n_images, hipMemcpyDeviceToHost));
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_fetch_image(orbfe_context *ctx, int image, orbfe_keypoint *kps, uint8_t *desc,
+                                 float *u_right, float *depth, int cap, int *n)
+{
+    if (!ctx || image < 0 || image >= ctx->params.max_images || !n) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
+    int cnt = 0, status = 0;
+    HIP_TRY(ctx, hipMemcpy(&cnt, ctx->buf.kp_cnt + image, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(&status, ctx->buf.status + image, sizeof(int), hipMemcpyDeviceToHost));
+    if (status != 0) return fail(ctx, ORBFE_ERR_CAPACITY, "device-side capacity overflow (status %d) on image %d", status, image);
+    *n = cnt;
+    if (cnt > cap) return fail(ctx, ORBFE_ERR_CAPACITY, "caller buffers hold %d keypoints, image has %d", cap, cnt);
+    const size_t st = (size_t)ctx->cfg.sel_total;
+    if (cnt > 0) {
+        if (kps) HIP_TRY(ctx, hipMemcpy(kps, (const KeyPointPOD *)ctx->buf.kps + image * st, sizeof(KeyPointPOD) * cnt, hipMemcpyDeviceToHost));
+        if (desc) HIP_TRY(ctx, hipMemcpy(desc, ctx->buf.desc + image * st * 32, (size_t)32 * cnt, hipMemcpyDeviceToHost));
+        if (u_right) HIP_TRY(ctx, hipMemcpy(u_right, ctx->buf.u_right + image * st, sizeof(float) * cnt, hipMemcpyDeviceToHost));
+        if (depth) HIP_TRY(ctx, hipMemcpy(depth, ctx->buf.depth + image * st, sizeof(float) * cnt, hipMemcpyDeviceToHost));
+    }
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_device_buffers(orbfe_context *ctx, void **kps, void **desc, void **counts, void **u_right, void **depth)
+{
+    if (!ctx) return ORBFE_ERR_INVALID;
+    if (kps) *kps = ctx->buf.kps;
+    if (desc) *desc = ctx->buf.desc;
+    if (counts) *counts = ctx->buf.kp_cnt;
+    if (u_right) *u_right = ctx->buf.u_right;
+    if (depth) *depth = ctx->buf.depth;
+    return ORBFE_OK;
+}
+
+static int upload_image(orbfe_context *ctx, int slot, const uint8_t *img, int w, int h, size_t stride)
+{
+    if (w != ctx->params.width || h != ctx->params.height)
+        return fail(ctx, ORBFE_ERR_UNSUPPORTED, "image is %dx%d, context was built for %dx%d", w, h, ctx->params.width, ctx->params.height);
+    if (stride < (size_t)w) return fail(ctx, ORBFE_ERR_INVALID, "stride smaller than width");
+    HIP_TRY(ctx, hipMemcpy2DAsync(ctx->d_in + (size_t)slot * w * h, (size_t)w, img, stride, (size_t)w, (size_t)h,
+                                  hipMemcpyHostToDevice, ctx->stream));
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_extract(orbfe_context *ctx, const uint8_t *img, int w, int h, size_t stride,
+                             orbfe_keypoint *kps, uint8_t *desc, int cap, int *n)
+{
+    if (!ctx || !n) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    if (!img || w <= 0 || h <= 0) { *n = 0; return ORBFE_OK; } // _image.empty(): src/ORBextractor.cc:861-862
+    int rc = upload_image(ctx, 0, img, w, h, stride);
+    if (rc != ORBFE_OK) return rc;
+    rc = orbfe_enqueue_extract(ctx, ctx->d_in, 1, nullptr);
+    if (rc != ORBFE_OK) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return orbfe_fetch_image(ctx, 0, kps, desc, nullptr, nullptr, cap, n);
+}
+
+extern "C" int orbfe_stereo_frame(orbfe_context *ctx, const uint8_t *left, const uint8_t *right,
+                                  int w, int h, size_t stride,
+                                  orbfe_keypoint *kps_left, uint8_t *desc_left, int *n_left,
+                                  orbfe_keypoint *kps_right, uint8_t *desc_right, int *n_right,
+                                  float *u_right, float *depth, int cap)
+{
+    if (!ctx || !n_left || !n_right) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    if (!left || !right || w <= 0 || h <= 0) { *n_left = 0; *n_right = 0; return ORBFE_OK; }
+    if (ctx->params.max_images < 2) return fail(ctx, ORBFE_ERR_CAPACITY, "stereo needs max_images >= 2");
+    int rc = upload_image(ctx, 0, left, w, h, stride);
+    if (rc != ORBFE_OK) return rc;
+    rc = upload_image(ctx, 1, right, w, h, stride);
+    if (rc != ORBFE_OK) return rc;
+    rc = orbfe_enqueue_stereo(ctx, ctx->d_in, 1, nullptr);
+    if (rc != ORBFE_OK) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    rc = orbfe_fetch_image(ctx, 0, kps_left, desc_left, u_right, depth, cap, n_left);
+    if (rc != ORBFE_OK) return rc;
+    return orbfe_fetch_image(ctx, 1, kps_right, desc_right, nullptr, nullptr, cap, n_right);
+}
+
+extern "C" int orbfe_rgbd_frame(orbfe_context *ctx, const uint8_t *gray, const float *depth_img,
+                                int w, int h, size_t gray_stride, size_t depth_stride,
+                                orbfe_keypoint *kps, uint8_t *desc, int *n,
+                                float *u_right, float *depth, int cap)
+{
+    if (!ctx || !n) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    if (!gray || !depth_img || w <= 0 || h <= 0) { *n = 0; return ORBFE_OK; }
+    int rc = upload_image(ctx, 0, gray, w, h, gray_stride);
+    if (rc != ORBFE_OK) return rc;
+    if (!ctx->d_depth_in) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_depth_in, sizeof(float) * (size_t)w * h));
+    HIP_TRY(ctx, hipMemcpy2DAsync(ctx->d_depth_in, sizeof(float) * (size_t)w, depth_img, depth_stride, sizeof(float) * (size_t)w,
+                                  (size_t)h, hipMemcpyHostToDevice, ctx->stream));
+    rc = orbfe_enqueue_extract(ctx, ctx->d_in, 1, nullptr);
+    if (rc != ORBFE_OK) return rc;
+    orbfe_launch_rgbd(ctx->cfg, ctx->buf, ctx->d_depth_in, (size_t)w, 0, ctx->stream);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return orbfe_fetch_image(ctx, 0, kps, desc, u_right, depth, cap, n);
+}
+
+extern "C" int orbfe_fetch_pyramid(orbfe_context *ctx, int image, int level, int blurred, uint8_t *dst, size_t dst_stride)
+{
+    if (!ctx || !dst || image < 0 || image >= ctx->params.max_images || level < 0 || level >= ctx->cfg.nlevels)
+        return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
+    const LevelInfo &L = ctx->cfg.lv[level];
+    if (dst_stride < (size_t)L.w) return fail(ctx, ORBFE_ERR_INVALID, "dst_stride smaller than level width");
+    const uint8_t *src = (blurred ? ctx->buf.blur : ctx->buf.pyr) + (size_t)image * ctx->cfg.pyr_bytes + L.pyr_off;
+    HIP_TRY(ctx, hipMemcpy2D(dst, dst_stride, src, (size_t)L.pitch, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost));
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_fetch_candidates(orbfe_context *ctx, int image, int level, int32_t *xs, int32_t *ys,
+                                      int32_t *scores, int cap, int *n)
+{
+    if (!ctx || !n || image < 0 || image >= ctx->params.max_images || level < 0 || level >= ctx->cfg.nlevels)
+        return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
+    const DeviceConfig &c = ctx->cfg;
+    const LevelInfo &L = c.lv[level];
+    int nc = 0;
+    HIP_TRY(ctx, hipMemcpy(&nc, ctx->buf.lvl_ncand + (size_t)image * c.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    *n = nc;
+    if (nc > cap) return fail(ctx, ORBFE_ERR_CAPACITY, "caller buffers hold %d candidates, level has %d", cap, nc);
+    if (nc == 0) return ORBFE_OK;
+    std::vector<uint32_t> xy(nc);
+    std::vector<uint8_t> sc(nc);
+    HIP_TRY(ctx, hipMemcpy(xy.data(), ctx->buf.cand_xy + (size_t)image * c.cand_total + L.cand_off, sizeof(uint32_t) * nc, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(sc.data(), ctx->buf.cand_sc + (size_t)image * c.cand_total + L.cand_off, (size_t)nc, hipMemcpyDeviceToHost));
+    for (int i = 0; i < nc; i++) {
+        if (xs) xs[i] = (int32_t)(xy[i] & 0xffffu);
+        if (ys) ys[i] = (int32_t)(xy[i] >> 16);
+        if (scores) scores[i] = sc[i];
+    }
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_hamming_matrix(orbfe_context *ctx, const uint8_t *desc_a, int na, const uint8_t *desc_b, int nb, int32_t *dist)
+{
+    if (!ctx || !desc_a || !desc_b || !dist || na < 0 || nb < 0) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
+    if (na == 0 || nb == 0) return ORBFE_OK;
+    const size_t need = (size_t)32 * na + (size_t)32 * nb + sizeof(int) * (size_t)na * nb;
+    if (need > ctx->d_ham_bytes) {
+        if (ctx->d_ham) hipFree(ctx->d_ham);
+        ctx->d_ham = nullptr; ctx->d_ham_bytes = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_ham, need));
+        ctx->d_ham_bytes = need;
+    }
+    uint8_t *da = ctx->d_ham, *db = da + (size_t)32 * na;
+    int *dd = (int *)(db + (size_t)32 * nb);
+    HIP_TRY(ctx, hipMemcpyAsync(da, desc_a, (size_t)32 * na, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(db, desc_b, (size_t)32 * nb, hipMemcpyHostToDevice, ctx->stream));
+    orbfe_launch_hamming_matrix(da, na, db, nb, dd, ctx->stream);
+    HIP_TRY(ctx, hipMemcpyAsync(dist, dd, sizeof(int) * (size_t)na * nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ORBFE_OK;
+}

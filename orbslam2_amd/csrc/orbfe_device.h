@@ -1,0 +1,90 @@
+// orbfe_device.h -- device-side configuration shared by the kernels and the host API.
+// gfx950 only (wave64).  See DESIGN.md for the HBM layout.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ORBFE_MAX_LEVELS 16
+#define ORBFE_WAVE 64
+
+// Per-level geometry (reference: src/ORBextractor.cc:759-781,925-926,533-557).
+struct LevelInfo {
+    int w, h, pitch;       // level image size and row pitch (bytes)
+    int pyr_off;           // byte offset of the level inside one image's pyramid buffer
+    int n_cols, n_rows;    // FAST cell grid
+    int w_cell, h_cell;
+    int cell_off, n_cells; // cell index range inside one image's cell arrays
+    int quota;             // mnFeaturesPerLevel[level]
+    int n_ini;             // quadtree roots
+    float hx;              // root width (float, as the reference)
+    int cand_off, cand_cap;// candidate array range inside one image's candidate arrays
+    int sel_off, sel_cap;  // selected-keypoint slot range inside one image's slot arrays
+    int blur_tile_off;     // first blur tile of this level in the fused all-level grid
+    int blur_tiles_x, blur_tiles_y;
+    int scaled_patch;      // int(patchSize * scale)
+    float scale, inv_scale;
+    double rs_scale_x, rs_scale_y; // cv::resize scale from level-1 (1/(dw/sw))
+};
+
+struct DeviceConfig {
+    int nlevels;
+    int width, height;
+    int edge_threshold, min_border; // min_border = edge_threshold - 3
+    int ini_th, min_th;
+    int half_patch;
+    int cell_cap;          // slots per FAST cell
+    int cells_total;       // per image
+    int cand_total;        // per image
+    int sel_total;         // per image == keypoint capacity
+    int blur_tiles_total;
+    int max_nodes;         // quadtree node capacity (LDS)
+    int umax[64];
+    int taps[7];           // Gaussian 8.8 fixed-point taps
+    size_t pyr_bytes;      // per image
+    float bf, fx, mb;
+    LevelInfo lv[ORBFE_MAX_LEVELS];
+};
+
+// Per-batch device buffers (all [image][...] with the per-image strides of DeviceConfig).
+struct DeviceBuffers {
+    uint8_t *pyr;        // raw pyramid
+    uint8_t *blur;       // blurred pyramid
+    int *cell_cnt;       // [img][cells_total]
+    uint32_t *cell_xy;   // [img][cells_total*cell_cap]  x | y<<16 (region relative)
+    uint8_t *cell_sc;    // [img][cells_total*cell_cap]
+    int *cell_base;      // [img][cells_total] scratch (exclusive scan)
+    uint32_t *cand_xy;   // [img][cand_total]
+    uint8_t *cand_sc;    // [img][cand_total]
+    uint32_t *idx0, *idx1; // [img][cand_total] ping-pong permutation
+    int *lvl_ncand;      // [img][nlevels]
+    int *sel_cnt;        // [img][nlevels]
+    uint32_t *sel_xy;    // [img][sel_total]
+    uint8_t *sel_sc;     // [img][sel_total]
+    void *kps;           // [img][sel_total] orbfe_keypoint
+    uint8_t *desc;       // [img][sel_total][32]
+    int *kp_cnt;         // [img]
+    float *u_right;      // [img][sel_total]
+    float *depth;        // [img][sel_total]
+    int *sad;            // [img][sel_total] best SAD (or -1)
+    int *status;         // [img] non-zero = device-side capacity problem
+};
+
+struct KeyPointPOD {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+};
+static_assert(sizeof(KeyPointPOD) == 28, "keypoint must match cv::KeyPoint");
+
+// launchers (orbfe_kernels.hip)
+void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, const uint8_t *d_images,
+                         int n_images, hipStream_t s);
+void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
+void orbfe_launch_blur(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
+void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
+void orbfe_launch_octree(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
+void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
+void orbfe_launch_stereo(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s);
+void orbfe_launch_rgbd(const DeviceConfig &cfg, const DeviceBuffers &buf, const float *d_depth,
+                       size_t depth_pitch_floats, int image, hipStream_t s);
+void orbfe_launch_hamming_matrix(const uint8_t *da, int na, const uint8_t *db, int nb, int *dist, hipStream_t s);

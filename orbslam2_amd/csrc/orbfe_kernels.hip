@@ -1,0 +1,1061 @@
+// orbfe_kernels.hip -- hand-written gfx950 kernels of the ORB front-end.
+//
+// Integer / bitwise HBM-bound work: no MFMA.  Wave = 64 lanes everywhere.
+// Floating point follows contract Q4: compiled with -ffp-contract=off,
+// every float product/sum below is individually rounded (IEEE), divisions are
+// correctly rounded, cos/sin come from the shared deterministic routine.
+//
+// Reference routines replaced (paths under the reference tree):
+//   pyr_resize_kernel   <- ORBextractor::ComputePyramid        src/ORBextractor.cc:921-946 (cv::resize INTER_LINEAR)
+//   blur_kernel         <- cv::GaussianBlur 7x7 sigma 2        src/ORBextractor.cc:899-900
+//   fast_cell_kernel    <- cell-wise cv::FAST, 2 thresholds    src/ORBextractor.cc:783-823
+//   octree_kernel       <- ORBextractor::DistributeOctTree     src/ORBextractor.cc:533-757
+//   describe_kernel     <- IC_Angle + computeOrbDescriptor     src/ORBextractor.cc:72-142,831-846,909-915
+//   stereo_match_kernel <- Frame::ComputeStereoMatches         src/Frame.cc:464-626
+//   stereo_median_kernel<- outlier cut                         src/Frame.cc:628-641
+//   rgbd_kernel         <- Frame::ComputeStereoFromRGBD        src/Frame.cc:645-666
+//   hamming_matrix_kernel <- ORBmatcher::DescriptorDistance    src/ORBmatcher.cc:1643-1659
+#include "orbfe_device.h"
+
+#define OT_THREADS 512
+
+__device__ const int8_t g_pattern[1024] = {
+#include "orb_pattern_31.inc"
+};
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned t = (unsigned)__shfl_xor((int)v, o, 64);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) {
+        if (p < 0) p = -p;
+        else p = 2 * len - 2 - p;
+    }
+    return p;
+}
+
+// Exclusive scan of src[0..n) into dst[0..n) by the whole block (src may alias dst; LDS or
+// global).  s_tmp: blockDim.x ints of LDS.  Returns the total.  All threads must call.
+__device__ int block_excl_scan(const int *src, int *dst, int n, int *s_tmp)
+{
+    const int nt = blockDim.x, tid = threadIdx.x;
+    const int per = (n + nt - 1) / nt;
+    const int b = tid * per;
+    const int e = (b + per < n) ? b + per : n;
+    int sum = 0;
+    for (int i = b; i < e; i++) sum += src[i];
+    s_tmp[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < nt; off <<= 1) {
+        int v = tid >= off ? s_tmp[tid - off] : 0;
+        __syncthreads();
+        s_tmp[tid] += v;
+        __syncthreads();
+    }
+    const int total = s_tmp[nt - 1];
+    int run = s_tmp[tid] - sum;
+    for (int i = b; i < e; i++) {
+        int v = src[i];
+        dst[i] = run;
+        run += v;
+    }
+    __syncthreads();
+    return total;
+}
+
+// cv::fastAtan2 scalar path (see oracle/orb_oracle.c: orc_fast_atan2).
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float p1 = __uint_as_float(0x4265226fu);
+    const float p3 = __uint_as_float(0xc19556eeu);
+    const float p5 = __uint_as_float(0x410e9fbfu);
+    const float p7 = __uint_as_float(0xc0228ad9u);
+    const float eps = 2.220446049250313e-16f;
+    float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+// Contract Q4 sin/cos (same algorithm as oracle orc_sincos_det): double reduction by pi/2 +
+// fdlibm kernel polynomials, one rounding to float.
+__device__ __forceinline__ void sincos_det(float rad, float *s, float *c)
+{
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double PIO2_HI = 1.57079632673412561417e+00;
+    const double PIO2_LO = 6.07710050650619224932e-11;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double x = (double)rad;
+    double t = __dadd_rn(__dmul_rn(x, TWO_OVER_PI), 0.5);
+    int q = (int)t;
+    if (t < 0.0 && (double)q != t) q -= 1;
+    double qd = (double)q;
+    double r = __dsub_rn(__dsub_rn(x, __dmul_rn(qd, PIO2_HI)), __dmul_rn(qd, PIO2_LO));
+    double z = __dmul_rn(r, r);
+    double sp = __dadd_rn(S2, __dmul_rn(z, __dadd_rn(S3, __dmul_rn(z, __dadd_rn(S4, __dmul_rn(z, __dadd_rn(S5, __dmul_rn(z, S6))))))));
+    double sr = __dadd_rn(r, __dmul_rn(__dmul_rn(z, r), __dadd_rn(S1, __dmul_rn(z, sp))));
+    double cp = __dmul_rn(z, __dadd_rn(C1, __dmul_rn(z, __dadd_rn(C2, __dmul_rn(z, __dadd_rn(C3, __dmul_rn(z, __dadd_rn(C4, __dmul_rn(z, __dadd_rn(C5, __dmul_rn(z, C6)))))))))));
+    double cr = __dsub_rn(1.0, __dsub_rn(__dmul_rn(0.5, z), __dmul_rn(z, cp)));
+    double sv, cv;
+    switch (q & 3) {
+    case 0: sv = sr; cv = cr; break;
+    case 1: sv = cr; cv = -sr; break;
+    case 2: sv = -sr; cv = -cr; break;
+    default: sv = -cr; cv = sr; break;
+    }
+    *s = (float)sv;
+    *c = (float)cv;
+}
+
+__device__ __forceinline__ int hamming256(const uint32_t *a, const uint32_t *b)
+{
+    int d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d += __popc(a[i] ^ b[i]);
+    return d;
+}
+
+// ---------------------------------------------------------------------------
+// ingest: packed images -> level 0 of the pyramid buffer
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ingest_kernel(DeviceConfig cfg, DeviceBuffers buf, const uint8_t *__restrict__ src)
+{
+    const int img = blockIdx.z;
+    const int y = blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const LevelInfo &L = cfg.lv[0];
+    if (x >= L.w) return;
+    const uint8_t *s = src + (size_t)img * L.w * L.h + (size_t)y * L.w;
+    uint8_t *d = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (size_t)y * L.pitch;
+    d[x] = s[x];
+}
+
+// ---------------------------------------------------------------------------
+// pyramid: level l from level l-1 (cv::resize INTER_LINEAR, 8UC1 fixed point)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pyr_resize_kernel(DeviceConfig cfg, DeviceBuffers buf, int level)
+{
+    const int img = blockIdx.z;
+    const LevelInfo &D = cfg.lv[level];
+    const LevelInfo &S = cfg.lv[level - 1];
+    const int dx = blockIdx.x * 64 + threadIdx.x;
+    const int dy = blockIdx.y * 4 + threadIdx.y;
+    if (dx >= D.w || dy >= D.h) return;
+    const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + S.pyr_off;
+    uint8_t *dst = buf.pyr + (size_t)img * cfg.pyr_bytes + D.pyr_off;
+
+    float fx = (float)__dsub_rn(__dmul_rn(__dadd_rn((double)dx, 0.5), D.rs_scale_x), 0.5);
+    int sx = (int)floorf(fx);
+    fx = __fsub_rn(fx, (float)sx);
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= S.w - 1) { fx = 0.f; sx = S.w - 1; }
+    const int a0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fx), 2048.f));
+    const int a1 = (int)rintf(__fmul_rn(fx, 2048.f));
+    const int sx1 = sx + 1 < S.w ? sx + 1 : S.w - 1;
+
+    float fy = (float)__dsub_rn(__dmul_rn(__dadd_rn((double)dy, 0.5), D.rs_scale_y), 0.5);
+    int sy = (int)floorf(fy);
+    fy = __fsub_rn(fy, (float)sy);
+    const int b0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fy), 2048.f));
+    const int b1 = (int)rintf(__fmul_rn(fy, 2048.f));
+    const int sy0 = sy < 0 ? 0 : (sy > S.h - 1 ? S.h - 1 : sy);
+    const int sy1 = sy + 1 < 0 ? 0 : (sy + 1 > S.h - 1 ? S.h - 1 : sy + 1);
+
+    const uint8_t *r0 = src + (size_t)sy0 * S.pitch;
+    const uint8_t *r1 = src + (size_t)sy1 * S.pitch;
+    const int h0 = r0[sx] * a0 + r0[sx1] * a1;
+    const int h1 = r1[sx] * a0 + r1[sx1] * a1;
+    int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    dst[(size_t)dy * D.pitch + dx] = (uint8_t)v;
+}
+
+// ---------------------------------------------------------------------------
+// Gaussian 7x7 (8.8 fixed point, separable), all levels in one launch
+// ---------------------------------------------------------------------------
+#define BL_TW 64
+#define BL_TH 16
+__global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffers buf)
+{
+    __shared__ uint8_t s_in[(BL_TH + 6) * (BL_TW + 8)];
+    __shared__ uint16_t s_h[(BL_TH + 6) * BL_TW];
+    const int img = blockIdx.y;
+    int level = 0;
+    for (int l = 1; l < cfg.nlevels; l++)
+        if ((int)blockIdx.x >= cfg.lv[l].blur_tile_off) level = l;
+    const LevelInfo &L = cfg.lv[level];
+    const int t = blockIdx.x - L.blur_tile_off;
+    const int tx0 = (t % L.blur_tiles_x) * BL_TW;
+    const int ty0 = (t / L.blur_tiles_x) * BL_TH;
+    const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off;
+    uint8_t *dst = buf.blur + (size_t)img * cfg.pyr_bytes + L.pyr_off;
+    const int tid = threadIdx.x;
+    const int IP = BL_TW + 8;
+    for (int i = tid; i < (BL_TH + 6) * (BL_TW + 6); i += 256) {
+        const int r = i / (BL_TW + 6), c = i % (BL_TW + 6);
+        const int gy = reflect101(ty0 + r - 3, L.h);
+        const int gx = reflect101(tx0 + c - 3, L.w);
+        s_in[r * IP + c] = src[(size_t)gy * L.pitch + gx];
+    }
+    __syncthreads();
+    const int k0 = cfg.taps[0], k1 = cfg.taps[1], k2 = cfg.taps[2], k3 = cfg.taps[3],
+              k4 = cfg.taps[4], k5 = cfg.taps[5], k6 = cfg.taps[6];
+    for (int i = tid; i < (BL_TH + 6) * BL_TW; i += 256) {
+        const int r = i / BL_TW, c = i % BL_TW;
+        const uint8_t *p = &s_in[r * IP + c];
+        const unsigned acc = k0 * p[0] + k1 * p[1] + k2 * p[2] + k3 * p[3] + k4 * p[4] + k5 * p[5] + k6 * p[6];
+        s_h[r * BL_TW + c] = (uint16_t)acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < BL_TH * BL_TW; i += 256) {
+        const int r = i / BL_TW, c = i % BL_TW;
+        const int x = tx0 + c, y = ty0 + r;
+        if (x < L.w && y < L.h) {
+            const uint16_t *p = &s_h[r * BL_TW + c];
+            const unsigned acc = k0 * p[0] + k1 * p[BL_TW] + k2 * p[2 * BL_TW] + k3 * p[3 * BL_TW] +
+                                 k4 * p[4 * BL_TW] + k5 * p[5 * BL_TW] + k6 * p[6 * BL_TW];
+            unsigned v = (acc + 32768u) >> 16;
+            dst[(size_t)y * L.pitch + x] = (uint8_t)(v > 255u ? 255u : v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// FAST-9/16 per cell: score map + 3x3 NMS inside the cell + two-threshold select
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int fast_score16(const uint8_t *t, int pitch, int minth)
+{
+    const int v = t[0];
+    int d[16];
+    d[0] = v - t[3 * pitch];       d[1] = v - t[3 * pitch + 1];   d[2] = v - t[2 * pitch + 2];   d[3] = v - t[pitch + 3];
+    d[4] = v - t[3];               d[5] = v - t[-pitch + 3];      d[6] = v - t[-2 * pitch + 2];  d[7] = v - t[-3 * pitch + 1];
+    d[8] = v - t[-3 * pitch];      d[9] = v - t[-3 * pitch - 1];  d[10] = v - t[-2 * pitch - 2]; d[11] = v - t[-pitch - 3];
+    d[12] = v - t[-3];             d[13] = v - t[pitch - 3];      d[14] = v - t[2 * pitch - 2];  d[15] = v - t[3 * pitch - 1];
+    int mn2[16], mx2[16], mn4[16], mx4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+    int a = -512, b = 512;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+        const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+        a = max(a, mn9);
+        b = min(b, mx9);
+    }
+    return max(minth, max(a, -b)) - 1;
+}
+
+__global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, DeviceBuffers buf, int tile_pitch, int tile_bytes, int sc_bytes)
+{
+    extern __shared__ uint8_t s_mem[];
+    __shared__ int s_wcnt[4];
+    __shared__ int s_any_ini;
+    const int img = blockIdx.y;
+    const int cell = blockIdx.x;
+    int level = 0;
+    for (int l = 1; l < cfg.nlevels; l++)
+        if (cell >= cfg.lv[l].cell_off) level = l;
+    const LevelInfo &L = cfg.lv[level];
+    const int ci = cell - L.cell_off;
+    const int ci_i = ci / L.n_cols, ci_j = ci % L.n_cols;
+    const int tid = threadIdx.x;
+    int *cnt_out = buf.cell_cnt + (size_t)img * cfg.cells_total + cell;
+
+    const int min_b = cfg.min_border;
+    const int max_bx = L.w - cfg.edge_threshold + 3;
+    const int max_by = L.h - cfg.edge_threshold + 3;
+    const int ini_y = min_b + ci_i * L.h_cell;
+    const int ini_x = min_b + ci_j * L.w_cell;
+    int max_y = ini_y + L.h_cell + 6;
+    int max_x = ini_x + L.w_cell + 6;
+    if (ini_y >= max_by - 3 || ini_x >= max_bx - 6) { // src/ORBextractor.cc:788-798
+        if (tid == 0) *cnt_out = 0;
+        return;
+    }
+    if (max_y > max_by) max_y = max_by;
+    if (max_x > max_bx) max_x = max_bx;
+    const int tw = max_x - ini_x, th = max_y - ini_y;
+    const int iw = tw - 6, ih = th - 6;
+    if (iw <= 0 || ih <= 0) {
+        if (tid == 0) *cnt_out = 0;
+        return;
+    }
+    // LDS layout (sizes fixed by the host from the largest cell): tile | scores | flags
+    uint8_t *s_tile = s_mem;               // [th][tile_pitch]
+    uint8_t *s_sc = s_mem + tile_bytes;    // [(ih+2)][(iw+2)], zero border
+    uint8_t *s_fl = s_sc + sc_bytes;       // [ih*iw] 0 / 1 (local max, >= minTh) / 2 (>= iniTh)
+    const int scp = iw + 2;
+
+    const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (size_t)ini_y * L.pitch + ini_x;
+    for (int i = tid; i < th * tw; i += 256) {
+        const int r = i / tw, c = i % tw;
+        s_tile[r * tile_pitch + c] = src[(size_t)r * L.pitch + c];
+    }
+    for (int i = tid; i < (ih + 2) * scp; i += 256) s_sc[i] = 0;
+    if (tid == 0) s_any_ini = 0;
+    __syncthreads();
+    const int npx = iw * ih;
+    for (int i = tid; i < npx; i += 256) {
+        const int r = i / iw, c = i % iw;
+        const int s = fast_score16(&s_tile[(r + 3) * tile_pitch + c + 3], tile_pitch, cfg.min_th);
+        s_sc[(r + 1) * scp + c + 1] = (uint8_t)(s >= cfg.min_th ? s : 0);
+    }
+    __syncthreads();
+    int any = 0;
+    for (int i = tid; i < npx; i += 256) {
+        const int r = i / iw, c = i % iw;
+        const uint8_t *p = &s_sc[(r + 1) * scp + c + 1];
+        const int s = p[0];
+        int f = 0;
+        if (s > 0 && s > p[-1] && s > p[1] && s > p[-scp - 1] && s > p[-scp] && s > p[-scp + 1] &&
+            s > p[scp - 1] && s > p[scp] && s > p[scp + 1]) {
+            f = (s >= cfg.ini_th) ? 2 : 1;
+            if (f == 2) any = 1;
+        }
+        s_fl[i] = (uint8_t)f;
+    }
+    if (any) s_any_ini = 1; // benign race: all writers store 1
+    __syncthreads();
+    const int need = s_any_ini ? 2 : 1;
+    const int wave = tid >> 6, lane = tid & 63;
+    uint32_t *oxy = buf.cell_xy + ((size_t)img * cfg.cells_total + cell) * cfg.cell_cap;
+    uint8_t *osc = buf.cell_sc + ((size_t)img * cfg.cells_total + cell) * cfg.cell_cap;
+    int base = 0;
+    for (int i0 = 0; i0 < npx; i0 += 256) {
+        const int i = i0 + tid;
+        const bool pred = (i < npx) && (s_fl[i] >= need);
+        const unsigned long long m = __ballot(pred);
+        if (lane == 0) s_wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w2 = 0; w2 < wave; w2++) off += s_wcnt[w2];
+        const int tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        if (pred) {
+            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < cfg.cell_cap) {
+                const int r = i / iw, c = i % iw;
+                // cell-local FAST coords (c+3, r+3) + (j*wCell, i*hCell): src/ORBextractor.cc:816-817
+                const unsigned x = (unsigned)(c + 3 + ci_j * L.w_cell);
+                const unsigned y = (unsigned)(r + 3 + ci_i * L.h_cell);
+                oxy[pos] = x | (y << 16);
+                osc[pos] = s_sc[(r + 1) * scp + c + 1];
+            }
+        }
+        base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *cnt_out = base < cfg.cell_cap ? base : cfg.cell_cap;
+}
+
+// ---------------------------------------------------------------------------
+// DistributeOctTree: one workgroup per (image, level)
+// ---------------------------------------------------------------------------
+// Array formulation validated on the CPU by tests/octree_model.py:
+//  * nodes live in an array kept in std::list order (front -> back);
+//  * a pass splits a set of multi-point nodes; their non-empty children are written
+//    n4,n3,n2,n1 at the front, blocks of later-processed parents nearer the front;
+//  * every node owns a contiguous segment [beg, beg+cnt) of a candidate-index
+//    permutation (two ping-pong buffers); a split is a stable 4-way partition of the
+//    segment, so the per-node point order stays the FAST emission order;
+//  * the "expand the biggest node first" phase sorts on (count desc, position asc),
+//    which equals the reference's (size, pointer) ordering under contract Q3.
+struct OtNodes {
+    short *x0, *y0, *x1, *y1;
+    int *beg, *cnt;
+    uint8_t *bf;
+};
+
+__device__ __forceinline__ void ot_bind(OtNodes &n, uint8_t *&p, int cap)
+{
+    n.beg = (int *)p; p += sizeof(int) * cap;
+    n.cnt = (int *)p; p += sizeof(int) * cap;
+    n.x0 = (short *)p; p += sizeof(short) * cap;
+    n.y0 = (short *)p; p += sizeof(short) * cap;
+    n.x1 = (short *)p; p += sizeof(short) * cap;
+    n.y1 = (short *)p; p += sizeof(short) * cap;
+    n.bf = p; p += ((cap + 7) / 8) * 8;
+}
+
+__global__ __launch_bounds__(OT_THREADS) void octree_kernel(DeviceConfig cfg, DeviceBuffers buf, int sort_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
+    __shared__ int s_scan[OT_THREADS];
+    __shared__ int s_n, s_total_k, s_nproc, s_nexpand, s_mode, s_done;
+    const int level = blockIdx.x, img = blockIdx.y;
+    const LevelInfo &L = cfg.lv[level];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = OT_THREADS / 64;
+    const int MAXN = cfg.max_nodes;
+
+    uint8_t *p = s_raw;
+    unsigned long long *s_key = (unsigned long long *)p; p += sizeof(unsigned long long) * sort_cap;
+    OtNodes A, B;
+    ot_bind(A, p, MAXN);
+    ot_bind(B, p, MAXN);
+    int *s_ccnt = (int *)p; p += sizeof(int) * 4 * MAXN;   // child counts per old node
+    int *s_rank = (int *)p; p += sizeof(int) * MAXN;       // processing rank of old node (-1: not processed)
+    int *s_plist = (int *)p; p += sizeof(int) * MAXN;      // processing order -> old node
+    int *s_kk = (int *)p; p += sizeof(int) * MAXN;         // scan scratch
+    int *s_un = (int *)p; p += sizeof(int) * MAXN;         // scan scratch (unprocessed flags)
+
+    const size_t ib = (size_t)img;
+    int *cell_cnt = buf.cell_cnt + ib * cfg.cells_total + L.cell_off;
+    int *cell_base = buf.cell_base + ib * cfg.cells_total + L.cell_off;
+    const uint32_t *cell_xy = buf.cell_xy + (ib * cfg.cells_total + L.cell_off) * cfg.cell_cap;
+    const uint8_t *cell_sc = buf.cell_sc + (ib * cfg.cells_total + L.cell_off) * cfg.cell_cap;
+    uint32_t *cxy = buf.cand_xy + ib * cfg.cand_total + L.cand_off;
+    uint8_t *csc = buf.cand_sc + ib * cfg.cand_total + L.cand_off;
+    uint32_t *idx[2] = {buf.idx0 + ib * cfg.cand_total + L.cand_off, buf.idx1 + ib * cfg.cand_total + L.cand_off};
+    int *sel_cnt = buf.sel_cnt + ib * cfg.nlevels + level;
+    uint32_t *sel_xy = buf.sel_xy + ib * cfg.sel_total + L.sel_off;
+    uint8_t *sel_sc = buf.sel_sc + ib * cfg.sel_total + L.sel_off;
+
+    // ---- gather the per-cell candidates into emission order ----
+    int nc = block_excl_scan(cell_cnt, cell_base, L.n_cells, s_scan);
+    if (nc > L.cand_cap) { nc = L.cand_cap; if (tid == 0) buf.status[img] = 1; }
+    if (tid == 0) buf.lvl_ncand[ib * cfg.nlevels + level] = nc;
+    for (int i = tid; i < nc; i += OT_THREADS) {
+        int lo = 0, hi = L.n_cells - 1; // last cell with cell_base <= i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (cell_base[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        const int k = i - cell_base[lo];
+        cxy[i] = cell_xy[(size_t)lo * cfg.cell_cap + k];
+        csc[i] = cell_sc[(size_t)lo * cfg.cell_cap + k];
+    }
+    __syncthreads();
+    if (nc == 0) {
+        if (tid == 0) *sel_cnt = 0;
+        return;
+    }
+
+    // ---- roots: stable partition by int(x / hX) (src/ORBextractor.cc:537-564) ----
+    const int n_ini = L.n_ini;
+    const int region_h = (L.h - cfg.edge_threshold + 3) - cfg.min_border;
+    for (int i = tid; i < n_ini; i += OT_THREADS) s_kk[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < nc; i += OT_THREADS) {
+        int b = (int)__fdiv_rn((float)(cxy[i] & 0xffffu), L.hx);
+        b = b < 0 ? 0 : (b >= n_ini ? n_ini - 1 : b);
+        atomicAdd(&s_kk[b], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0, n = 0;
+        for (int b = 0; b < n_ini; b++) {
+            const int c = s_kk[b];
+            s_un[b] = run; // segment begin of bucket b
+            if (c > 0) {
+                A.x0[n] = (short)(int)__fmul_rn(L.hx, (float)b);
+                A.x1[n] = (short)(int)__fmul_rn(L.hx, (float)(b + 1));
+                A.y0[n] = 0;
+                A.y1[n] = (short)region_h;
+                A.beg[n] = run; A.cnt[n] = c; A.bf[n] = 0;
+                n++;
+            }
+            run += c;
+        }
+        s_n = n;
+        s_done = 0;
+    }
+    __syncthreads();
+    for (int b = wave; b < n_ini; b += nwaves) {
+        int run = s_un[b];
+        for (int i0 = 0; i0 < nc; i0 += 64) {
+            const int i = i0 + lane;
+            bool pred = false;
+            if (i < nc) {
+                int bb = (int)__fdiv_rn((float)(cxy[i] & 0xffffu), L.hx);
+                bb = bb < 0 ? 0 : (bb >= n_ini ? n_ini - 1 : bb);
+                pred = (bb == b);
+            }
+            const unsigned long long m = __ballot(pred);
+            if (pred) idx[0][run + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+            run += __popcll(m);
+        }
+    }
+    __syncthreads();
+
+    // ---- split passes ----
+    OtNodes cur = A, nxt = B;
+    int sorted_phase = 0;
+    for (int iter = 0; iter < 100000; iter++) { // n grows every pass, so this ends at n >= quota at the latest
+        const int n = s_n;
+        // (A) child counts of every multi-point node
+        for (int i = wave; i < n; i += nwaves) {
+            const int cnt = cur.cnt[i];
+            if (cnt > 1) {
+                const int mx = cur.x0[i] + ((cur.x1[i] - cur.x0[i] + 1) >> 1);
+                const int my = cur.y0[i] + ((cur.y1[i] - cur.y0[i] + 1) >> 1);
+                const uint32_t *src = idx[cur.bf[i]] + cur.beg[i];
+                int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+                for (int j = lane; j < cnt; j += 64) {
+                    const uint32_t xy = cxy[src[j]];
+                    const int cls = ((int)(xy & 0xffffu) < mx ? 0 : 1) + ((int)(xy >> 16) < my ? 0 : 2);
+                    c0 += cls == 0; c1 += cls == 1; c2 += cls == 2; c3 += cls == 3;
+                }
+                c0 = wave_sum_i32(c0); c1 = wave_sum_i32(c1); c2 = wave_sum_i32(c2); c3 = wave_sum_i32(c3);
+                if (lane == 0) { s_ccnt[4 * i] = c0; s_ccnt[4 * i + 1] = c1; s_ccnt[4 * i + 2] = c2; s_ccnt[4 * i + 3] = c3; }
+            }
+        }
+        for (int i = tid; i < n; i += OT_THREADS) { s_rank[i] = -1; s_kk[i] = cur.cnt[i] > 1 ? 1 : 0; }
+        __syncthreads();
+        // (B) processing order
+        int m;
+        if (!sorted_phase) {
+            m = block_excl_scan(s_kk, s_kk, n, s_scan); // s_kk[i] = rank among multi nodes
+            for (int i = tid; i < n; i += OT_THREADS)
+                if (cur.cnt[i] > 1) s_plist[s_kk[i]] = i;
+            __syncthreads();
+        } else {
+            m = block_excl_scan(s_kk, s_kk, n, s_scan);
+            int P = 1;
+            while (P < m) P <<= 1;
+            for (int i = tid; i < P; i += OT_THREADS) s_key[i] = ~0ull;
+            __syncthreads();
+            for (int i = tid; i < n; i += OT_THREADS)
+                if (cur.cnt[i] > 1)
+                    s_key[s_kk[i]] = ((unsigned long long)(0xffffffffu - (unsigned)cur.cnt[i]) << 32) | (unsigned)i;
+            __syncthreads();
+            for (int k = 2; k <= P; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < P; i += OT_THREADS) {
+                        const int ixj = i ^ j;
+                        if (ixj > i) {
+                            const unsigned long long a = s_key[i], b = s_key[ixj];
+                            const bool up = ((i & k) == 0);
+                            if ((a > b) == up) { s_key[i] = b; s_key[ixj] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (int i = tid; i < m; i += OT_THREADS) s_plist[i] = (int)(s_key[i] & 0xffffffffu);
+            __syncthreads();
+        }
+        // k (non-empty children) per processing rank; inclusive prefix decides the stop
+        for (int r = tid; r < m; r += OT_THREADS) {
+            const int i = s_plist[r];
+            s_kk[r] = (s_ccnt[4 * i] > 0) + (s_ccnt[4 * i + 1] > 0) + (s_ccnt[4 * i + 2] > 0) + (s_ccnt[4 * i + 3] > 0);
+        }
+        __syncthreads();
+        block_excl_scan(s_kk, s_un, m, s_scan); // s_un[r] = sum of k over ranks < r
+        if (tid == 0) {
+            int nproc = m;
+            if (sorted_phase) {
+                // first r with n + sum_{r'<=r}(k-1) >= quota (src/ORBextractor.cc:724-725)
+                nproc = m;
+                for (int r = 0; r < m; r++) {
+                    const int incl = s_un[r] + s_kk[r];
+                    if (n + incl - (r + 1) >= L.quota) { nproc = r + 1; break; }
+                }
+            }
+            s_nproc = nproc;
+            s_total_k = nproc > 0 ? s_un[nproc - 1] + s_kk[nproc - 1] : 0;
+        }
+        __syncthreads();
+        const int nproc = s_nproc, total_k = s_total_k;
+        for (int r = tid; r < nproc; r += OT_THREADS) s_rank[s_plist[r]] = r;
+        __syncthreads();
+        // unprocessed old nodes keep their relative order behind the new blocks
+        for (int i = tid; i < n; i += OT_THREADS) s_plist[i] = (s_rank[i] < 0) ? 1 : 0; // reuse as flag array
+        __syncthreads();
+        const int n_un = block_excl_scan(s_plist, s_plist, n, s_scan);
+        const int n_new = total_k + n_un;
+        if (n_new > MAXN) { // cannot happen for max_nodes >= max(quota+3, 4*n_ini); guard anyway
+            if (tid == 0) { buf.status[img] = 2; *sel_cnt = 0; }
+            return;
+        }
+        if (tid == 0) s_nexpand = 0;
+        __syncthreads();
+        // (D) emit new node array + scatter the points of processed nodes
+        for (int i = wave; i < n; i += nwaves) {
+            const int r = s_rank[i];
+            if (r < 0) {
+                if (lane == 0) {
+                    const int q = total_k + s_plist[i];
+                    nxt.x0[q] = cur.x0[i]; nxt.y0[q] = cur.y0[i]; nxt.x1[q] = cur.x1[i]; nxt.y1[q] = cur.y1[i];
+                    nxt.beg[q] = cur.beg[i]; nxt.cnt[q] = cur.cnt[i]; nxt.bf[q] = cur.bf[i];
+                }
+                continue;
+            }
+            const int x0 = cur.x0[i], y0 = cur.y0[i], x1 = cur.x1[i], y1 = cur.y1[i];
+            const int mx = x0 + ((x1 - x0 + 1) >> 1);
+            const int my = y0 + ((y1 - y0 + 1) >> 1);
+            const int cnt = cur.cnt[i], beg = cur.beg[i], sb = cur.bf[i];
+            const int c0 = s_ccnt[4 * i], c1 = s_ccnt[4 * i + 1], c2 = s_ccnt[4 * i + 2], c3 = s_ccnt[4 * i + 3];
+            const int k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+            // block of this parent starts after the blocks of all later-processed parents
+            int q = total_k - (s_un[r] + k);
+            if (lane == 0) {
+                int nexp = 0;
+                const int b0 = beg, b1 = beg + c0, b2 = b1 + c1, b3 = b2 + c2;
+                if (c3 > 0) { nxt.x0[q] = (short)mx; nxt.y0[q] = (short)my; nxt.x1[q] = (short)x1; nxt.y1[q] = (short)y1; nxt.beg[q] = b3; nxt.cnt[q] = c3; nxt.bf[q] = (uint8_t)(1 - sb); q++; nexp += c3 > 1; }
+                if (c2 > 0) { nxt.x0[q] = (short)x0; nxt.y0[q] = (short)my; nxt.x1[q] = (short)mx; nxt.y1[q] = (short)y1; nxt.beg[q] = b2; nxt.cnt[q] = c2; nxt.bf[q] = (uint8_t)(1 - sb); q++; nexp += c2 > 1; }
+                if (c1 > 0) { nxt.x0[q] = (short)mx; nxt.y0[q] = (short)y0; nxt.x1[q] = (short)x1; nxt.y1[q] = (short)my; nxt.beg[q] = b1; nxt.cnt[q] = c1; nxt.bf[q] = (uint8_t)(1 - sb); q++; nexp += c1 > 1; }
+                if (c0 > 0) { nxt.x0[q] = (short)x0; nxt.y0[q] = (short)y0; nxt.x1[q] = (short)mx; nxt.y1[q] = (short)my; nxt.beg[q] = b0; nxt.cnt[q] = c0; nxt.bf[q] = (uint8_t)(1 - sb); q++; nexp += c0 > 1; }
+                if (nexp) atomicAdd(&s_nexpand, nexp);
+            }
+            const uint32_t *src = idx[sb] + beg;
+            uint32_t *dst = idx[1 - sb];
+            int r0 = beg, r1 = beg + c0, r2 = r1 + c1, r3 = r2 + c2;
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            for (int j0 = 0; j0 < cnt; j0 += 64) {
+                const int j = j0 + lane;
+                int cls = -1;
+                uint32_t id = 0;
+                if (j < cnt) {
+                    id = src[j];
+                    const uint32_t xy = cxy[id];
+                    cls = ((int)(xy & 0xffffu) < mx ? 0 : 1) + ((int)(xy >> 16) < my ? 0 : 2);
+                }
+                const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1),
+                                         m2 = __ballot(cls == 2), m3 = __ballot(cls == 3);
+                if (cls == 0) dst[r0 + __popcll(m0 & lt)] = id;
+                else if (cls == 1) dst[r1 + __popcll(m1 & lt)] = id;
+                else if (cls == 2) dst[r2 + __popcll(m2 & lt)] = id;
+                else if (cls == 3) dst[r3 + __popcll(m3 & lt)] = id;
+                r0 += __popcll(m0); r1 += __popcll(m1); r2 += __popcll(m2); r3 += __popcll(m3);
+            }
+        }
+        __syncthreads();
+        // (E) stop logic (src/ORBextractor.cc:661-731)
+        if (tid == 0) {
+            const int prev = n;
+            s_n = n_new;
+            if (n_new >= L.quota || n_new == prev) s_done = 1;
+            else if (!sorted_phase && n_new + 3 * s_nexpand > L.quota) s_mode = 1;
+            else s_mode = sorted_phase;
+        }
+        __syncthreads();
+        { OtNodes t = cur; cur = nxt; nxt = t; }
+        if (s_done) break;
+        sorted_phase = s_mode;
+        __syncthreads();
+    }
+
+    // ---- keep the best response per node, first wins (src/ORBextractor.cc:735-754) ----
+    const int n = s_n;
+    int n_out = n < L.sel_cap ? n : L.sel_cap;
+    if (n > L.sel_cap && tid == 0) buf.status[img] = 3;
+    for (int i = wave; i < n_out; i += nwaves) {
+        const uint32_t *src = idx[cur.bf[i]] + cur.beg[i];
+        const int cnt = cur.cnt[i];
+        unsigned best = 0xffffffffu; // (255-score)<<24 | position in node  (cnt < 2^24)
+        for (int j = lane; j < cnt; j += 64) {
+            const unsigned key = ((unsigned)(255 - csc[src[j]]) << 24) | (unsigned)j;
+            best = key < best ? key : best;
+        }
+        best = wave_min_u32(best);
+        if (lane == 0) {
+            const uint32_t id = src[best & 0xffffffu];
+            sel_xy[i] = cxy[id];
+            sel_sc[i] = csc[id];
+        }
+    }
+    if (tid == 0) *sel_cnt = n_out;
+}
+
+// ---------------------------------------------------------------------------
+// orientation + descriptor + final keypoint record: one wave per keypoint slot
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void describe_kernel(DeviceConfig cfg, DeviceBuffers buf)
+{
+    const int img = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int *sel_cnt = buf.sel_cnt + (size_t)img * cfg.nlevels;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int tot = 0;
+        for (int l = 0; l < cfg.nlevels; l++) tot += sel_cnt[l];
+        buf.kp_cnt[img] = tot;
+    }
+    if (slot >= cfg.sel_total) return;
+    int level = 0;
+    for (int l = 1; l < cfg.nlevels; l++)
+        if (slot >= cfg.lv[l].sel_off) level = l;
+    const LevelInfo &L = cfg.lv[level];
+    const int k = slot - L.sel_off;
+    if (k >= sel_cnt[level]) return;
+    int out = k;
+    for (int l = 0; l < level; l++) out += sel_cnt[l];
+
+    const uint32_t xy = buf.sel_xy[(size_t)img * cfg.sel_total + slot];
+    const int score = buf.sel_sc[(size_t)img * cfg.sel_total + slot];
+    const int cx = (int)(xy & 0xffffu) + cfg.min_border;
+    const int cy = (int)(xy >> 16) + cfg.min_border;
+    const uint8_t *raw = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off;
+    const uint8_t *blr = buf.blur + (size_t)img * cfg.pyr_bytes + L.pyr_off;
+
+    // IC_Angle (src/ORBextractor.cc:72-99): integer moments over the circular patch
+    const int hp = cfg.half_patch;
+    int m10 = 0, m01 = 0;
+    for (int v = -hp; v <= hp; ++v) {
+        const int d = cfg.umax[v < 0 ? -v : v];
+        const uint8_t *row = raw + (size_t)(cy + v) * L.pitch + cx;
+        for (int u = -d + lane; u <= d; u += 64) {
+            const int I = row[u];
+            m10 += u * I;
+            m01 += v * I;
+        }
+    }
+    m10 = wave_sum_i32(m10);
+    m01 = wave_sum_i32(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // computeOrbDescriptor (src/ORBextractor.cc:103-142)
+    const float factor_pi = __uint_as_float(0x3c8efa35u); // (float)(CV_PI/180.f)
+    float a, b;
+    sincos_det(__fmul_rn(angle, factor_pi), &b, &a);
+    const uint8_t *center = blr + (size_t)cy * L.pitch + cx;
+    unsigned long long *dout = (unsigned long long *)(buf.desc + ((size_t)img * cfg.sel_total + out) * 32);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int pi = (r * 64 + lane) * 4;
+        const float x0 = (float)g_pattern[pi], y0 = (float)g_pattern[pi + 1];
+        const float x1 = (float)g_pattern[pi + 2], y1 = (float)g_pattern[pi + 3];
+        const int r0 = (int)rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+        const int c0 = (int)rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int r1 = (int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+        const int c1 = (int)rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        const int t0 = center[r0 * L.pitch + c0];
+        const int t1 = center[r1 * L.pitch + c1];
+        const unsigned long long bits = __ballot(t0 < t1);
+        if (lane == 0) dout[r] = bits;
+    }
+    if (lane == 0) {
+        KeyPointPOD kp;
+        float px = (float)cx, py = (float)cy;
+        if (level != 0) { px = __fmul_rn(px, L.scale); py = __fmul_rn(py, L.scale); }
+        kp.x = px; kp.y = py;
+        kp.size = (float)L.scaled_patch;
+        kp.angle = angle;
+        kp.response = (float)score;
+        kp.octave = level;
+        kp.class_id = -1;
+        ((KeyPointPOD *)buf.kps)[(size_t)img * cfg.sel_total + out] = kp;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// stereo: one wave per left keypoint (coarse Hamming band search + SAD + parabola)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, DeviceBuffers buf)
+{
+    const int pair = blockIdx.y;
+    const int imgL = 2 * pair, imgR = 2 * pair + 1;
+    const int lane = threadIdx.x & 63;
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nL = buf.kp_cnt[imgL], nR = buf.kp_cnt[imgR];
+    if (iL >= nL) return;
+    const KeyPointPOD *kL = (const KeyPointPOD *)buf.kps + (size_t)imgL * cfg.sel_total;
+    const KeyPointPOD *kR = (const KeyPointPOD *)buf.kps + (size_t)imgR * cfg.sel_total;
+    const uint8_t *dL = buf.desc + (size_t)imgL * cfg.sel_total * 32;
+    const uint8_t *dR = buf.desc + (size_t)imgR * cfg.sel_total * 32;
+    float *u_right = buf.u_right + (size_t)imgL * cfg.sel_total;
+    float *depth = buf.depth + (size_t)imgL * cfg.sel_total;
+    int *sad_out = buf.sad + (size_t)imgL * cfg.sel_total;
+
+    const KeyPointPOD kp = kL[iL];
+    const int level_l = kp.octave;
+    const float uL = kp.x, vL = kp.y;
+    const int row = (int)vL;
+    const float min_z = cfg.mb;
+    const float max_d = __fdiv_rn(cfg.bf, min_z);
+    const float min_u = __fsub_rn(uL, max_d);
+    const float max_u = uL; // uL - minD, minD = 0
+
+    uint32_t dl[8];
+    {
+        const uint32_t *p = (const uint32_t *)(dL + (size_t)iL * 32);
+#pragma unroll
+        for (int i = 0; i < 8; i++) dl[i] = p[i];
+    }
+    unsigned best = 100u << 16; // TH_HIGH
+    for (int i0 = 0; i0 < nR; i0 += 64) {
+        const int iR = i0 + lane;
+        if (iR < nR) {
+            const KeyPointPOD kr = kR[iR];
+            const float r = __fmul_rn(2.0f, cfg.lv[kr.octave].scale);
+            const int maxr = (int)ceilf(__fadd_rn(kr.y, r));
+            const int minr = (int)floorf(__fsub_rn(kr.y, r));
+            if (row >= minr && row <= maxr && kr.octave >= level_l - 1 && kr.octave <= level_l + 1 &&
+                kr.x >= min_u && kr.x <= max_u) {
+                const uint32_t *p = (const uint32_t *)(dR + (size_t)iR * 32);
+                uint32_t dr[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) dr[i] = p[i];
+                const unsigned key = ((unsigned)hamming256(dl, dr) << 16) | (unsigned)iR;
+                best = key < best ? key : best;
+            }
+        }
+    }
+    best = wave_min_u32(best);
+    const int best_dist = (int)(best >> 16);
+    const int best_r = (int)(best & 0xffffu);
+    float out_u = -1.0f, out_d = -1.0f;
+    int out_sad = -1;
+    if (best_dist < 75) { // (TH_HIGH + TH_LOW) / 2
+        const float uR0 = kR[best_r].x;
+        const float sf = cfg.lv[level_l].inv_scale;
+        const float s_uL = roundf(__fmul_rn(kp.x, sf));
+        const float s_vL = roundf(__fmul_rn(kp.y, sf));
+        const float s_uR0 = roundf(__fmul_rn(uR0, sf));
+        const LevelInfo &L = cfg.lv[level_l];
+        const int cu = (int)s_uL, cv = (int)s_vL, cr = (int)s_uR0;
+        const float iniu = s_uR0;                        // scaleduR0 + L - w
+        const float endu = __fadd_rn(s_uR0, 11.0f);      // scaleduR0 + L + w + 1
+        const bool in_ref = !(iniu < 0 || endu >= (float)L.w);
+        // the reference would throw on a window outside the level image; unreachable for
+        // keypoints >= 19 px from the border, kept as a memory-safety guard
+        const bool safe = cu - 5 >= 0 && cu + 5 < L.w && cv - 5 >= 0 && cv + 5 < L.h && cr - 10 >= 0 && cr + 10 < L.w;
+        if (in_ref && safe) {
+            const uint8_t *imL = buf.pyr + (size_t)imgL * cfg.pyr_bytes + L.pyr_off;
+            const uint8_t *imR = buf.pyr + (size_t)imgR * cfg.pyr_bytes + L.pyr_off;
+            const int lc = imL[(size_t)cv * L.pitch + cu];
+            // two window pixels per lane: p = lane, lane + 64 (< 121)
+            int a0 = 0, a1 = 0, dy0 = 0, dx0 = 0, dy1 = 0, dx1 = 0;
+            const bool has1 = lane + 64 < 121;
+            dy0 = lane / 11 - 5; dx0 = lane % 11 - 5;
+            a0 = (int)imL[(size_t)(cv + dy0) * L.pitch + cu + dx0] - lc;
+            if (has1) {
+                dy1 = (lane + 64) / 11 - 5; dx1 = (lane + 64) % 11 - 5;
+                a1 = (int)imL[(size_t)(cv + dy1) * L.pitch + cu + dx1] - lc;
+            }
+            int dists[11];
+            int sad_best = 0x7fffffff, best_inc = 0;
+#pragma unroll
+            for (int inc = -5; inc <= 5; inc++) {
+                const int rc = imR[(size_t)cv * L.pitch + cr + inc];
+                int s = abs(a0 - ((int)imR[(size_t)(cv + dy0) * L.pitch + cr + inc + dx0] - rc));
+                if (has1) s += abs(a1 - ((int)imR[(size_t)(cv + dy1) * L.pitch + cr + inc + dx1] - rc));
+                s = wave_sum_i32(s);
+                dists[inc + 5] = s;
+                if (s < sad_best) { sad_best = s; best_inc = inc; }
+            }
+            out_sad = -2 - sad_best; // coarse match without an accepted disparity (debug tap): negative
+            if (best_inc != -5 && best_inc != 5) {
+                float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+                for (int t = 1; t < 10; t++)
+                    if (t == best_inc + 5) { d1 = (float)dists[t - 1]; d2 = (float)dists[t]; d3 = (float)dists[t + 1]; }
+                const float delta = __fdiv_rn(__fsub_rn(d1, d3), __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
+                if (!(delta < -1.0f || delta > 1.0f)) {
+                    float best_ur = __fmul_rn(L.scale, __fadd_rn(__fadd_rn(s_uR0, (float)best_inc), delta));
+                    float disparity = __fsub_rn(uL, best_ur);
+                    if (disparity >= 0.0f && disparity < max_d) {
+                        if (disparity <= 0.0f) {
+                            disparity = 0.01f;
+                            best_ur = (float)__dsub_rn((double)uL, 0.01);
+                        }
+                        out_d = __fdiv_rn(cfg.bf, disparity);
+                        out_u = best_ur;
+                        out_sad = sad_best;
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        u_right[iL] = out_u;
+        depth[iL] = out_d;
+        sad_out[iL] = out_sad;
+    }
+}
+
+// median of the accepted SADs, then cut at 1.5*1.4*median (src/Frame.cc:628-641; Q2: skip when empty)
+__global__ __launch_bounds__(256) void stereo_median_kernel(DeviceConfig cfg, DeviceBuffers buf, int sort_cap)
+{
+    extern __shared__ int s_sad[];
+    __shared__ int s_cnt;
+    const int pair = blockIdx.x;
+    const int imgL = 2 * pair;
+    const int tid = threadIdx.x;
+    const int nL = buf.kp_cnt[imgL];
+    float *u_right = buf.u_right + (size_t)imgL * cfg.sel_total;
+    float *depth = buf.depth + (size_t)imgL * cfg.sel_total;
+    const int *sad = buf.sad + (size_t)imgL * cfg.sel_total;
+    if (tid == 0) s_cnt = 0;
+    for (int i = tid; i < sort_cap; i += 256) s_sad[i] = 0x7fffffff;
+    __syncthreads();
+    for (int i = tid; i < nL; i += 256)
+        if (sad[i] >= 0) s_sad[atomicAdd(&s_cnt, 1)] = sad[i];
+    __syncthreads();
+    const int m = s_cnt;
+    if (m == 0) return;
+    for (int k = 2; k <= sort_cap; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < sort_cap; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const int a = s_sad[i], b = s_sad[ixj];
+                    const bool up = ((i & k) == 0);
+                    if ((a > b) == up) { s_sad[i] = b; s_sad[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const float median = (float)s_sad[m / 2];
+    const float th_dist = __fmul_rn(__fmul_rn(1.5f, 1.4f), median);
+    for (int i = tid; i < nL; i += 256) {
+        const int s = sad[i];
+        if (s >= 0 && !((float)s < th_dist)) { u_right[i] = -1.0f; depth[i] = -1.0f; }
+    }
+}
+
+// Frame::ComputeStereoFromRGBD (src/Frame.cc:645-666), undistorted camera
+__global__ __launch_bounds__(256) void rgbd_kernel(DeviceConfig cfg, DeviceBuffers buf, const float *__restrict__ depth_img,
+                                                   size_t pitch_floats, int img)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = buf.kp_cnt[img];
+    if (i >= n) return;
+    const KeyPointPOD kp = ((const KeyPointPOD *)buf.kps)[(size_t)img * cfg.sel_total + i];
+    float u = -1.0f, dp = -1.0f;
+    const int v = (int)kp.y, uu = (int)kp.x;
+    if (uu >= 0 && v >= 0 && uu < cfg.width && v < cfg.height) {
+        const float d = depth_img[(size_t)v * pitch_floats + uu];
+        if (d > 0) { dp = d; u = __fsub_rn(kp.x, __fdiv_rn(cfg.bf, d)); }
+    }
+    buf.u_right[(size_t)img * cfg.sel_total + i] = u;
+    buf.depth[(size_t)img * cfg.sel_total + i] = dp;
+}
+
+// all-pairs Hamming distance: block (64 b-columns) x (4 a-rows per block.y step)
+__global__ __launch_bounds__(256) void hamming_matrix_kernel(const uint8_t *__restrict__ da, int na,
+                                                             const uint8_t *__restrict__ db, int nb, int *__restrict__ dist)
+{
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 16;
+    if (j >= nb) return;
+    uint32_t b[8];
+    const uint32_t *pb = (const uint32_t *)(db + (size_t)j * 32);
+#pragma unroll
+    for (int k = 0; k < 8; k++) b[k] = pb[k];
+    for (int i = i0; i < i0 + 16 && i < na; i++) {
+        const uint32_t *pa = (const uint32_t *)(da + (size_t)i * 32);
+        uint32_t a[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) a[k] = pa[k];
+        dist[(size_t)i * nb + j] = hamming256(a, b);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+static inline int max_cell_w(const DeviceConfig &cfg) { int m = 0; for (int l = 0; l < cfg.nlevels; l++) m = cfg.lv[l].w_cell > m ? cfg.lv[l].w_cell : m; return m; }
+static inline int max_cell_h(const DeviceConfig &cfg) { int m = 0; for (int l = 0; l < cfg.nlevels; l++) m = cfg.lv[l].h_cell > m ? cfg.lv[l].h_cell : m; return m; }
+
+void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, const uint8_t *d_images, int n_images, hipStream_t s)
+{
+    dim3 grid((cfg.lv[0].w + 255) / 256, cfg.lv[0].h, n_images);
+    hipLaunchKernelGGL(ingest_kernel, grid, dim3(256), 0, s, cfg, buf, d_images);
+}
+
+void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
+{
+    for (int l = 1; l < cfg.nlevels; l++) {
+        dim3 grid((cfg.lv[l].w + 63) / 64, (cfg.lv[l].h + 3) / 4, n_images);
+        hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(64, 4), 0, s, cfg, buf, l);
+    }
+}
+
+void orbfe_launch_blur(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
+{
+    dim3 grid(cfg.blur_tiles_total, n_images);
+    hipLaunchKernelGGL(blur_kernel, grid, dim3(256), 0, s, cfg, buf);
+}
+
+void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
+{
+    const int mw = max_cell_w(cfg), mh = max_cell_h(cfg);
+    const int tile_pitch = (mw + 6 + 3) & ~3;
+    const int tile_rows = mh + 6;
+    const int sc_bytes = ((mw + 2) * (mh + 2) + 15) & ~15;
+    const int fl_bytes = (mw * mh + 15) & ~15;
+    const int tile_bytes = (tile_pitch * tile_rows + 15) & ~15;
+    const size_t lds = (size_t)tile_bytes + sc_bytes + fl_bytes;
+    dim3 grid(cfg.cells_total, n_images);
+    hipLaunchKernelGGL(fast_cell_kernel, grid, dim3(256), lds, s, cfg, buf, tile_pitch, tile_bytes, sc_bytes);
+}
+
+static inline int ot_sort_cap(const DeviceConfig &cfg) { int p = 1; while (p < cfg.max_nodes) p <<= 1; return p; }
+
+size_t orbfe_octree_lds_bytes(const DeviceConfig &cfg)
+{
+    const int cap = cfg.max_nodes;
+    const size_t node = 2 * sizeof(int) * cap + 4 * sizeof(short) * cap + ((cap + 7) / 8) * 8;
+    return sizeof(unsigned long long) * ot_sort_cap(cfg) + 2 * node + sizeof(int) * 4 * cap + 4 * sizeof(int) * cap;
+}
+
+void orbfe_launch_octree(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
+{
+    dim3 grid(cfg.nlevels, n_images);
+    hipLaunchKernelGGL(octree_kernel, grid, dim3(OT_THREADS), orbfe_octree_lds_bytes(cfg), s, cfg, buf, ot_sort_cap(cfg));
+}
+
+void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
+{
+    dim3 grid((cfg.sel_total + 3) / 4, n_images);
+    hipLaunchKernelGGL(describe_kernel, grid, dim3(256), 0, s, cfg, buf);
+}
+
+void orbfe_launch_stereo(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s)
+{
+    dim3 grid((cfg.sel_total + 3) / 4, n_pairs);
+    hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(256), 0, s, cfg, buf);
+    int cap = 1;
+    while (cap < cfg.sel_total) cap <<= 1;
+    hipLaunchKernelGGL(stereo_median_kernel, dim3(n_pairs), dim3(256), sizeof(int) * cap, s, cfg, buf, cap);
+}
+
+void orbfe_launch_rgbd(const DeviceConfig &cfg, const DeviceBuffers &buf, const float *d_depth, size_t depth_pitch_floats,
+                       int image, hipStream_t s)
+{
+    hipLaunchKernelGGL(rgbd_kernel, dim3((cfg.sel_total + 255) / 256), dim3(256), 0, s, cfg, buf, d_depth, depth_pitch_floats, image);
+}
+
+void orbfe_launch_hamming_matrix(const uint8_t *da, int na, const uint8_t *db, int nb, int *dist, hipStream_t s)
+{
+    dim3 grid((nb + 63) / 64, (na + 63) / 64);
+    hipLaunchKernelGGL(hamming_matrix_kernel, grid, dim3(256), 0, s, da, na, db, nb, dist);
+}

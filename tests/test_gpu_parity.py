@@ -1,0 +1,127 @@
+"""GPU parity: HIP path (through the C ABI) == CPU oracle, bit for bit.
+
+Integer / byte / index work is compared exactly; the sub-pixel stereo outputs
+are floats and BASELINE.json's north_star allows 1e-4 -- the kernels follow the
+oracle's rounding contract (Q4) so they are compared exactly as well, with the
+1e-4 tolerance as the documented fallback bound.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from orbslam2_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+KITTI = dict(width=1241, height=376, nfeatures=2000, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, bf=386.1448)
+SMALL = dict(width=320, height=240, nfeatures=500, fx=300.0, fy=300.0, cx=160.0, cy=120.0, bf=120.0)
+TUM1 = dict(width=640, height=480, nfeatures=1000, fx=517.3, fy=516.5, cx=318.6, cy=255.3, bf=40.0)
+CONFIGS = {"small": SMALL, "kitti": KITTI, "tum1": TUM1}
+
+
+def _ctx(cfg, max_images=2):
+    from orbslam2_amd import api
+    return api.Context(max_images=max_images, **cfg)
+
+
+@pytest.fixture(scope="module", params=["small", "kitti", "tum1"])
+def case(request):
+    cfg = CONFIGS[request.param]
+    left, right = synth.stereo_pair(cfg["width"], cfg["height"], seed=1234)
+    ctx = _ctx(cfg)
+    exl = O.Extractor(nfeatures=cfg["nfeatures"])
+    exr = O.Extractor(nfeatures=cfg["nfeatures"])
+    kl, dl = exl.extract(left)
+    kr, dr = exr.extract(right)
+    out = ctx.stereo_frame(left, right)
+    yield dict(cfg=cfg, left=left, right=right, ctx=ctx, exl=exl, exr=exr, kl=kl, dl=dl, kr=kr, dr=dr, out=out)
+    ctx.close()
+
+
+def test_tables(case):
+    t = case["ctx"].tables()
+    ex = case["exl"]
+    assert np.array_equal(t["scale"], ex.scale_factors())
+    assert np.array_equal(t["inv_scale"], ex.inv_scale_factors())
+    assert np.array_equal(t["sigma2"], ex.sigma2())
+    assert np.array_equal(t["inv_sigma2"], ex.inv_sigma2())
+    assert np.array_equal(t["features_per_level"], ex.features_per_level())
+    assert np.array_equal(t["umax"], ex.umax())
+    cfg = case["cfg"]
+    for l in range(8):
+        assert case["ctx"].level_size(l) == ex.level_size(cfg["width"], cfg["height"], l)
+
+
+def test_pyramid_bit_exact(case):
+    for img, ex in ((0, case["exl"]), (1, case["exr"])):
+        for l in range(8):
+            got = case["ctx"].fetch_pyramid(img, l)
+            ref = ex.pyramid_level(l)
+            assert got.shape == ref.shape
+            bad = np.argwhere(got != ref)
+            assert bad.size == 0, "image %d level %d: %d pixels differ, first %s" % (img, l, len(bad), bad[:3].tolist())
+
+
+def test_blur_bit_exact(case):
+    ex = case["exl"]
+    for l in range(8):
+        got = case["ctx"].fetch_pyramid(0, l, blurred=True)
+        ref = O.gaussian7(ex.pyramid_level(l))
+        bad = np.argwhere(got != ref)
+        assert bad.size == 0, "level %d: %d pixels differ, first %s" % (l, len(bad), bad[:3].tolist())
+
+
+def test_fast_candidates_exact_order(case):
+    for img, ex in ((0, case["exl"]), (1, case["exr"])):
+        for l in range(8):
+            gx, gy, gs = case["ctx"].fetch_candidates(img, l)
+            rx, ry, rs = ex.level_candidates(l)
+            assert len(gx) == len(rx), "image %d level %d: %d vs %d candidates" % (img, l, len(gx), len(rx))
+            assert np.array_equal(gx, rx) and np.array_equal(gy, ry) and np.array_equal(gs, rs), "image %d level %d" % (img, l)
+
+
+def _assert_kps_equal(got, ref, what):
+    assert len(got) == len(ref), "%s: %d vs %d keypoints" % (what, len(got), len(ref))
+    for f in ("octave", "x", "y", "response", "size", "angle", "class_id"):
+        bad = np.nonzero(got[f] != ref[f])[0]
+        assert bad.size == 0, "%s: field %s differs at %s (got %s ref %s)" % (
+            what, f, bad[:5].tolist(), got[f][bad[:5]].tolist(), ref[f][bad[:5]].tolist())
+
+
+def test_keypoints_bit_exact(case):
+    _assert_kps_equal(case["out"]["kps_left"], case["kl"], "left")
+    _assert_kps_equal(case["out"]["kps_right"], case["kr"], "right")
+
+
+def test_descriptors_bit_exact(case):
+    for got, ref, what in ((case["out"]["desc_left"], case["dl"], "left"), (case["out"]["desc_right"], case["dr"], "right")):
+        assert got.shape == ref.shape
+        bad = np.nonzero((got != ref).any(axis=1))[0]
+        assert bad.size == 0, "%s: %d descriptors differ, first rows %s" % (what, len(bad), bad[:5].tolist())
+
+
+def test_stereo_matches(case):
+    cfg = case["cfg"]
+    ur, dp, m = O.stereo_matches(case["exl"], case["exr"], case["kl"], case["dl"], case["kr"], case["dr"], cfg["bf"], cfg["fx"])
+    got_u, got_d = case["out"]["u_right"], case["out"]["depth"]
+    assert len(got_u) == len(ur)
+    assert np.array_equal(got_u < 0, ur < 0), "matched sets differ at %s" % np.nonzero((got_u < 0) != (ur < 0))[0][:8].tolist()
+    assert m == int((ur >= 0).sum()) and m > len(ur) // 10
+    # north_star tolerance for the sub-pixel disparity: 1e-4; the kernels are expected to be exact
+    assert np.allclose(got_u, ur, rtol=0, atol=1e-4)
+    assert np.array_equal(got_u, ur), "u_right not bit-exact: max diff %g" % np.abs(got_u - ur).max()
+    assert np.array_equal(got_d, dp), "depth not bit-exact: max rel diff %g" % np.abs((got_d - dp) / np.maximum(dp, 1e-9)).max()
+
+
+def test_extract_entry_point_matches_stereo_slot(case):
+    k, d = case["ctx"].extract(case["left"])
+    _assert_kps_equal(k, case["kl"], "extract()")
+    assert np.array_equal(d, case["dl"])
+
+
+def test_hamming_matrix(case):
+    a, b = case["dl"][:100], case["dr"][:77]
+    got = case["ctx"].hamming_matrix(a, b)
+    ref = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(axis=2)
+    assert np.array_equal(got, ref)
+    assert got[3, 5] == O.hamming256(a[3], b[5])
