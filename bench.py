@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- ORB extract + stereo match throughput on KITTI geometry (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--pairs P]
+
+One process per GPU (the driver launches N>1 through torch.distributed.run).  A "step"
+is one pass of the hot path (extract left + extract right + ComputeStereoMatches) over
+one batch of P synthetic KITTI-geometry stereo pairs that are already resident in HBM.
+Frame pairs are independent, so ranks shard them with no data-path collective (weak
+scaling); the only RCCL traffic is a one-time broadcast of the extractor parameters and
+pattern checksum from rank 0 at start-up.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import json
+import os
+import struct
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+W, H, NFEAT, NLEVELS = 1241, 376, 2000, 8
+FX, FY, CX, CY, BF = 718.856, 718.856, 607.1928, 185.2157, 386.1448  # Config/Stereo-KITTI00-02.yaml
+LEVEL_PX = [1241 * 376, 1034 * 313, 862 * 261, 718 * 218, 598 * 181, 499 * 151, 416 * 126, 346 * 105]
+P_SUM = sum(LEVEL_PX)
+# algorithmic bytes per image / per stereo pair (N = 2000)
+B_PYR = sum(LEVEL_PX[:7]) + sum(LEVEL_PX[1:])
+B_FAST = P_SUM
+B_BLUR = 2 * P_SUM
+B_DESC = NFEAT * (749 + 512 + 32 + 28)
+B_IMG = B_PYR + B_FAST + B_BLUR + B_DESC
+B_STEREO = 2 * NFEAT * 32 + NFEAT * (121 + 231) + NFEAT * 8
+B_PAIR = 2 * B_IMG + B_STEREO
+assert B_PAIR == 19_567_078, B_PAIR
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def stage_alg_bytes_per_pair(n_cand_per_image: float):
+    """Algorithmic bytes per pair attributed to each stage."""
+    return {
+        "ingest": 2 * 2 * LEVEL_PX[0],
+        "pyramid": 2 * B_PYR,
+        "blur": 2 * B_BLUR,
+        "fast": 2 * B_FAST,
+        # not in SURVEY's formula (it prices pixels only): candidate records in, keypoint slots out
+        "octree": 2 * (n_cand_per_image * 5 + NFEAT * 5),
+        "describe": 2 * B_DESC,
+        "stereo_match": B_STEREO,
+        "stereo_median": NFEAT * 4 + NFEAT * 8,
+    }
+
+
+def cpu_baseline(n_pairs: int):
+    """Oracle (kind=port) timed with the reference's threading: 2 threads per pair (src/Frame.cc:78-81)."""
+    from oracle import oracle as O
+    from orbslam2_amd import synth
+    target = "liborb_oracle_fast.so"
+    pairs = [synth.stereo_pair(W, H, seed=5000 + i) for i in range(min(n_pairs, 4))]
+    exl = O.Extractor(nfeatures=NFEAT, target=target)
+    exr = O.Extractor(nfeatures=NFEAT, target=target)
+
+    def one(pair):
+        res = [None, None]
+        def run(i, ex, img):
+            res[i] = ex.extract(img)
+        tl = threading.Thread(target=run, args=(0, exl, pair[0]))
+        tr = threading.Thread(target=run, args=(1, exr, pair[1]))
+        tl.start(); tr.start(); tl.join(); tr.join()
+        (kl, dl), (kr, dr) = res
+        O.stereo_matches(exl, exr, kl, dl, kr, dr, BF, FX)
+
+    one(pairs[0])  # warm-up
+    t0 = time.perf_counter()
+    for i in range(n_pairs):
+        one(pairs[i % len(pairs)])
+    dt = time.perf_counter() - t0
+    return {"value": n_pairs / dt, "unit": "frames/s", "cores": 2, "kind": "port",
+            "sample": "%d KITTI-geometry synthetic stereo pairs, oracle -O3 -march=native, 2 threads/pair "
+                      "(reference threading), %.1f s" % (n_pairs, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=32, help="stereo pairs per step per GPU (in flight in HBM)")
+    ap.add_argument("--cpu-pairs", type=int, default=40, help="pairs in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-check", action="store_true", help="skip the post-run oracle spot check")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from orbslam2_amd import api, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    # one-time RCCL broadcast of the extractor parameters + rBRIEF pattern checksum
+    pat_path = os.path.join(ROOT, "orbslam2_amd", "csrc", "orb_pattern_31.inc")
+    blob = struct.pack("<ifiiiiii5f", NFEAT, 1.2, NLEVELS, 20, 7, 31, 15, 19, FX, FY, CX, CY, BF)
+    blob += hashlib.sha256(open(pat_path, "rb").read()).digest()
+    t_blob = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    if world > 1:
+        mine = t_blob.clone()
+        dist.broadcast(t_blob, src=0)
+        assert torch.equal(mine, t_blob), "rank %d: parameters/pattern differ from rank 0" % rank
+    nf, sf, nl, ini, mn, ps, hps, et, fx, fy, cx, cy, bf = struct.unpack("<ifiiiiii5f", bytes(t_blob.cpu().numpy().tobytes()[:52]))
+
+    P = args.pairs
+    ctx = api.Context(width=W, height=H, nfeatures=nf, scale_factor=sf, nlevels=nl, ini_th_fast=ini, min_th_fast=mn,
+                      patch_size=ps, half_patch_size=hps, edge_threshold=et, fx=fx, fy=fy, cx=cx, cy=cy, bf=bf,
+                      device=local_rank, max_images=2 * P)
+    n_distinct = min(P, 4)
+    host = np.empty((2 * P, H, W), np.uint8)
+    distinct = [synth.stereo_pair(W, H, seed=1234 + rank * 100 + i) for i in range(n_distinct)]
+    for i in range(P):
+        host[2 * i], host[2 * i + 1] = distinct[i % n_distinct]
+    d_images = torch.from_numpy(host).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.enqueue_stereo(d_images.data_ptr(), P, stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    stage_ms, calls = ctx.stage_times(reset=True)
+    ctx.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    counts = ctx.fetch_counts(2 * P)
+    n_cand = 0
+    if rank == 0:
+        n_cand = sum(len(ctx.fetch_candidates(0, l)[0]) for l in range(nl))
+        if not args.no_check:  # the timed path must be the correct path: spot-check pair 0 against the oracle
+            from oracle import oracle as O
+            exl, exr = O.Extractor(nfeatures=nf), O.Extractor(nfeatures=nf)
+            kl, dl = exl.extract(host[0]); kr, dr = exr.extract(host[1])
+            ur, dp, _ = O.stereo_matches(exl, exr, kl, dl, kr, dr, bf, fx)
+            got = ctx.fetch_image(0, stereo=True)
+            ok = (len(got["kps"]) == len(kl) and np.array_equal(got["desc"], dl) and np.array_equal(got["u_right"], ur)
+                  and np.array_equal(got["kps"]["x"], kl["x"]) and np.array_equal(got["kps"]["angle"], kl["angle"]))
+            if not ok:
+                raise SystemExit("bench: HIP output differs from the oracle -- result invalid")
+
+    if rank == 0:
+        total_pairs = P * args.steps * world
+        value = total_pairs / dt
+        alg = stage_alg_bytes_per_pair(n_cand)
+        per_launch_ms = {k: v / max(calls, 1) for k, v in stage_ms.items()}
+        dom = max(per_launch_ms, key=per_launch_ms.get)
+        # pyramid is 7 dependent launches; every other stage is one launch per step
+        launches = 7 if dom == "pyramid" else 1
+        dom_ms = per_launch_ms[dom] / launches
+        achieved = alg[dom] * P / launches / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        metric = "frames/sec ORB extract+match, KITTI 1241x376 stereo, 2000 feats"
+        try:
+            metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+        except Exception:
+            pass
+        out = {
+            "metric": metric, "value": value, "unit": "frames/s (1 frame = 1 stereo pair)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "Stereo-KITTI00-02 1241x376, 2000 features, 8 levels: extract L+R + ComputeStereoMatches",
+                       "pairs_per_step_per_gpu": P, "parallelism": "frame-pair sharding, no data-path collective",
+                       "keypoints_left_right_pair0": [int(counts[0]), int(counts[1])]},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launch_ms": dom_ms, "alg_bytes_per_launch": alg[dom] * P / launches,
+                         "whole_pipeline": {"alg_bytes_per_pair": B_PAIR, "achieved": B_PAIR * value / world / 1e9,
+                                            "frac": B_PAIR * value / world / 1e9 / HBM_PEAK_GBS},
+                         "stage_ms_per_step": per_launch_ms},
+        }
+        if world == 1 and args.cpu_pairs > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -130,6 +130,15 @@ int orbfe_fetch_counts(orbfe_context *ctx, int32_t *counts, int n_images);
 int orbfe_device_buffers(orbfe_context *ctx, void **kps, void **desc, void **counts,
                          void **u_right, void **depth);
 
+/* ---- stage timing (HIP events recorded on the stream each enqueue call uses) ----
+ * Stages: ingest, pyramid, blur, fast, octree, describe, stereo_match, stereo_median.
+ * orbfe_stage_times synchronises, adds up the per-stage elapsed ms of the enqueue calls
+ * recorded since the last reset (at most 128 are kept) and reports how many calls that was. */
+#define ORBFE_NUM_STAGES 8
+int orbfe_set_profiling(orbfe_context *ctx, int enabled);
+const char *orbfe_stage_name(int stage);
+int orbfe_stage_times(orbfe_context *ctx, float *ms, int *calls, int reset);
+
 /* ---- stage taps for parity tests (results of the latest call) ---- */
 /* FAST+NMS candidates of (image, level) in the reference's emission order
  * (src/ORBextractor.cc:783-823); coordinates relative to (minBorderX, minBorderY). */

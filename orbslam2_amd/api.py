@@ -26,7 +26,9 @@ EXPORTS = [
     "orbfe_stereo_frame", "orbfe_rgbd_frame", "orbfe_fetch_pyramid", "orbfe_enqueue_extract",
     "orbfe_enqueue_stereo", "orbfe_synchronize", "orbfe_fetch_image", "orbfe_fetch_counts",
     "orbfe_device_buffers", "orbfe_fetch_candidates", "orbfe_hamming_matrix",
+    "orbfe_set_profiling", "orbfe_stage_name", "orbfe_stage_times",
 ]
+NUM_STAGES = 8
 
 
 class Params(C.Structure):
@@ -85,6 +87,9 @@ def load():
     L.orbfe_fetch_candidates.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_int)]
     L.orbfe_hamming_matrix.restype = C.c_int
     L.orbfe_hamming_matrix.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
+    L.orbfe_set_profiling.restype = C.c_int; L.orbfe_set_profiling.argtypes = [vp, C.c_int]
+    L.orbfe_stage_name.restype = C.c_char_p; L.orbfe_stage_name.argtypes = [C.c_int]
+    L.orbfe_stage_times.restype = C.c_int; L.orbfe_stage_times.argtypes = [vp, vp, C.POINTER(C.c_int), C.c_int]
     _lib = L
     return L
 
@@ -217,6 +222,17 @@ class Context:
         if stereo:
             out.update(u_right=ur[:m].copy(), depth=dp[:m].copy())
         return out
+
+    def set_profiling(self, enabled: bool):
+        self._check(self.L.orbfe_set_profiling(self.h, int(enabled)))
+
+    def stage_times(self, reset=True):
+        """{stage: total ms} over the recorded enqueue calls, and the number of calls."""
+        ms = np.zeros(NUM_STAGES, np.float32)
+        calls = C.c_int()
+        self._check(self.L.orbfe_stage_times(self.h, _p(ms), C.byref(calls), int(reset)))
+        names = [self.L.orbfe_stage_name(i).decode() for i in range(NUM_STAGES)]
+        return dict(zip(names, ms.tolist())), calls.value
 
     def hamming_matrix(self, a: np.ndarray, b: np.ndarray):
         a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)

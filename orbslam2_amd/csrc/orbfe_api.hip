@@ -29,6 +29,13 @@ struct orbfe_context {
     uint8_t *d_ham = nullptr;     // scratch for orbfe_hamming_matrix
     size_t d_ham_bytes = 0;
     int last_images = 0;
+    // stage timing: ring of PROF_RING calls x (ORBFE_NUM_STAGES + 1) events
+    bool profiling = false;
+    bool in_stereo = false;
+    std::vector<hipEvent_t> events;
+    int prof_calls = 0;      // calls recorded since the last reset
+    int prof_stages[128];    // number of stages recorded by each call in the ring
+    hipStream_t prof_stream = nullptr;
     float scale[ORBFE_MAX_LEVELS], inv_scale[ORBFE_MAX_LEVELS], sigma2[ORBFE_MAX_LEVELS], inv_sigma2[ORBFE_MAX_LEVELS];
     int32_t feats[ORBFE_MAX_LEVELS];
     std::vector<void *> allocs;
@@ -288,6 +295,7 @@ extern "C" void orbfe_destroy(orbfe_context *ctx)
     if (!ctx) return;
     if (ctx->stream) { hipStreamSynchronize(ctx->stream); }
     for (void *q : ctx->allocs) hipFree(q);
+    for (hipEvent_t e : ctx->events) hipEventDestroy(e);
     if (ctx->d_depth_in) hipFree(ctx->d_depth_in);
     if (ctx->d_ham) hipFree(ctx->d_ham);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -321,6 +329,54 @@ extern "C" int orbfe_level_size(const orbfe_context *ctx, int level, int *w, int
 
 static hipStream_t pick_stream(orbfe_context *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
 
+#define PROF_RING 128
+static const char *k_stage_names[ORBFE_NUM_STAGES] = {"ingest", "pyramid", "blur", "fast", "octree", "describe",
+                                                      "stereo_match", "stereo_median"};
+extern "C" const char *orbfe_stage_name(int stage) { return stage >= 0 && stage < ORBFE_NUM_STAGES ? k_stage_names[stage] : ""; }
+
+extern "C" int orbfe_set_profiling(orbfe_context *ctx, int enabled)
+{
+    if (!ctx) return ORBFE_ERR_INVALID;
+    if (enabled && ctx->events.empty()) {
+        ctx->events.resize((size_t)PROF_RING * (ORBFE_NUM_STAGES + 1));
+        for (auto &e : ctx->events) HIP_TRY(ctx, hipEventCreate(&e));
+    }
+    ctx->profiling = enabled != 0;
+    ctx->prof_calls = 0;
+    return ORBFE_OK;
+}
+
+// record event #idx of the current call (idx 0 = before the first stage)
+static inline void prof_mark(orbfe_context *ctx, int idx, hipStream_t s)
+{
+    if (!ctx->profiling) return;
+    const int slot = ctx->prof_calls % PROF_RING;
+    hipEventRecord(ctx->events[(size_t)slot * (ORBFE_NUM_STAGES + 1) + idx], s);
+    ctx->prof_stages[slot] = idx;
+    ctx->prof_stream = s;
+}
+
+extern "C" int orbfe_stage_times(orbfe_context *ctx, float *ms, int *calls, int reset)
+{
+    if (!ctx || !ms) return ORBFE_ERR_INVALID;
+    for (int i = 0; i < ORBFE_NUM_STAGES; i++) ms[i] = 0.f;
+    int n = ctx->prof_calls < PROF_RING ? ctx->prof_calls : PROF_RING;
+    if (calls) *calls = n;
+    if (n > 0) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->prof_stream));
+        for (int c = 0; c < n; c++) {
+            const hipEvent_t *ev = &ctx->events[(size_t)c * (ORBFE_NUM_STAGES + 1)];
+            for (int st = 0; st < ctx->prof_stages[c]; st++) {
+                float t = 0.f;
+                HIP_TRY(ctx, hipEventElapsedTime(&t, ev[st], ev[st + 1]));
+                ms[st] += t;
+            }
+        }
+    }
+    if (reset) ctx->prof_calls = 0;
+    return ORBFE_OK;
+}
+
 extern "C" int orbfe_enqueue_extract(orbfe_context *ctx, const uint8_t *d_images, int n_images, void *stream)
 {
     if (!ctx || !d_images) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
@@ -329,14 +385,22 @@ extern "C" int orbfe_enqueue_extract(orbfe_context *ctx, const uint8_t *d_images
     hipStream_t s = pick_stream(ctx, stream);
     HIP_TRY(ctx, hipSetDevice(ctx->params.device));
     HIP_TRY(ctx, hipMemsetAsync(ctx->buf.status, 0, sizeof(int) * n_images, s));
+    prof_mark(ctx, 0, s);
     orbfe_launch_ingest(ctx->cfg, ctx->buf, d_images, n_images, s);
+    prof_mark(ctx, 1, s);
     orbfe_launch_pyramid(ctx->cfg, ctx->buf, n_images, s);
+    prof_mark(ctx, 2, s);
     orbfe_launch_blur(ctx->cfg, ctx->buf, n_images, s);
+    prof_mark(ctx, 3, s);
     orbfe_launch_fast(ctx->cfg, ctx->buf, n_images, s);
+    prof_mark(ctx, 4, s);
     orbfe_launch_octree(ctx->cfg, ctx->buf, n_images, s);
+    prof_mark(ctx, 5, s);
     orbfe_launch_describe(ctx->cfg, ctx->buf, n_images, s);
+    prof_mark(ctx, 6, s);
     HIP_TRY(ctx, hipGetLastError());
     ctx->last_images = n_images;
+    if (ctx->profiling && !ctx->in_stereo) ctx->prof_calls++;
     return ORBFE_OK;
 }
 
@@ -345,10 +409,17 @@ extern "C" int orbfe_enqueue_stereo(orbfe_context *ctx, const uint8_t *d_images,
     if (!ctx) return fail(ctx, ORBFE_ERR_INVALID, "null context");
     if (n_pairs < 1 || 2 * n_pairs > ctx->params.max_images)
         return fail(ctx, ORBFE_ERR_CAPACITY, "n_pairs %d needs max_images >= %d", n_pairs, 2 * n_pairs);
+    ctx->in_stereo = true;
     int rc = orbfe_enqueue_extract(ctx, d_images, 2 * n_pairs, stream);
+    ctx->in_stereo = false;
     if (rc != ORBFE_OK) return rc;
-    orbfe_launch_stereo(ctx->cfg, ctx->buf, n_pairs, pick_stream(ctx, stream));
+    hipStream_t s = pick_stream(ctx, stream);
+    orbfe_launch_stereo_match(ctx->cfg, ctx->buf, n_pairs, s);
+    prof_mark(ctx, 7, s);
+    orbfe_launch_stereo_median(ctx->cfg, ctx->buf, n_pairs, s);
+    prof_mark(ctx, 8, s);
     HIP_TRY(ctx, hipGetLastError());
+    if (ctx->profiling) ctx->prof_calls++;
     return ORBFE_OK;
 }
 

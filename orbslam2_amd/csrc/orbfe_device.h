@@ -84,7 +84,8 @@ void orbfe_launch_blur(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_
 void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
 void orbfe_launch_octree(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
 void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
-void orbfe_launch_stereo(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s);
+void orbfe_launch_stereo_match(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s);
+void orbfe_launch_stereo_median(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s);
 void orbfe_launch_rgbd(const DeviceConfig &cfg, const DeviceBuffers &buf, const float *d_depth,
                        size_t depth_pitch_floats, int image, hipStream_t s);
 void orbfe_launch_hamming_matrix(const uint8_t *da, int na, const uint8_t *db, int nb, int *dist, hipStream_t s);

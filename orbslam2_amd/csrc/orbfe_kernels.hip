@@ -1039,10 +1039,14 @@ void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, in
     hipLaunchKernelGGL(describe_kernel, grid, dim3(256), 0, s, cfg, buf);
 }
 
-void orbfe_launch_stereo(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s)
+void orbfe_launch_stereo_match(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s)
 {
     dim3 grid((cfg.sel_total + 3) / 4, n_pairs);
     hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(256), 0, s, cfg, buf);
+}
+
+void orbfe_launch_stereo_median(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s)
+{
     int cap = 1;
     while (cap < cfg.sel_total) cap <<= 1;
     hipLaunchKernelGGL(stereo_median_kernel, dim3(n_pairs), dim3(256), sizeof(int) * cap, s, cfg, buf, cap);

@@ -1,0 +1,214 @@
+// ORBextractor.h -- host-side mirror of ORB_SLAM2::ORBextractor over the C ABI.
+//
+// Same class name, constructor arguments, getters and call operator meaning as the
+// reference's include/ORBextractor.h:45-112, so Tracking (src/Tracking.cc:125-131) and
+// Frame::ExtractORB (src/Frame.cc:248-254) can keep calling it.  The arithmetic runs in
+// liborbfe.so (HIP, gfx950); this header only converts types.  OpenCV is optional: the
+// core overloads use plain views / orbfe_keypoint (layout-identical to cv::KeyPoint);
+// define ORBFE_WITH_OPENCV to get the cv::InputArray / cv::OutputArray overloads the
+// reference declares (include/ORBextractor.h:58-60).
+//
+// Differences a maintainer must know (also in INTEGRATION.md):
+//  * the image size is bound when the first frame arrives (one camera model per
+//    extractor, as the reference assumes through Frame's statics, src/Frame.cc:29-33);
+//  * mvImagePyramid is materialised on the host only if KeepHostPyramid(true) is set
+//    (the reference's own ComputeStereoMatches needs it; orbfe_stereo_frame does not).
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/orbfe.h"
+
+#ifdef ORBFE_WITH_OPENCV
+#include <opencv2/core/core.hpp>
+#endif
+
+namespace ORB_SLAM2
+{
+
+// Non-owning 8UC1 image view (what cv::Mat gives the reference: data, cols, rows, step).
+struct ImageView {
+    const uint8_t *data = nullptr;
+    int cols = 0, rows = 0;
+    size_t step = 0;
+    bool empty() const { return !data || cols <= 0 || rows <= 0; }
+};
+
+struct CameraParams {
+    float fx = 0.f, fy = 0.f, cx = 0.f, cy = 0.f, bf = 0.f;
+};
+
+class ORBextractor
+{
+public:
+    enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+    // include/ORBextractor.h:51 -- same eight arguments, same order.
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
+                 int patchSize, int halfPatchSize, int edgeThreshold)
+    {
+        std::memset(&mParams, 0, sizeof(mParams));
+        mParams.nfeatures = nfeatures;
+        mParams.scale_factor = scaleFactor;
+        mParams.nlevels = nlevels;
+        mParams.ini_th_fast = iniThFAST;
+        mParams.min_th_fast = minThFAST;
+        mParams.patch_size = patchSize;
+        mParams.half_patch_size = halfPatchSize;
+        mParams.edge_threshold = edgeThreshold;
+        mParams.max_images = 1;
+        // scale tables exactly as src/ORBextractor.cc:409-425 (scaleFactor member is double)
+        const double sf = (double)scaleFactor;
+        mvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels);
+        mvInvScaleFactor.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
+        mvScaleFactor[0] = 1.0f; mvLevelSigma2[0] = 1.0f;
+        for (int i = 1; i < nlevels; i++) {
+            mvScaleFactor[i] = (float)((double)mvScaleFactor[i - 1] * sf);
+            mvLevelSigma2[i] = mvScaleFactor[i] * mvScaleFactor[i];
+        }
+        for (int i = 0; i < nlevels; i++) {
+            mvInvScaleFactor[i] = 1.0f / mvScaleFactor[i];
+            mvInvLevelSigma2[i] = 1.0f / mvLevelSigma2[i];
+        }
+    }
+
+    ~ORBextractor() { if (mCtx) orbfe_destroy(mCtx); }
+    ORBextractor(const ORBextractor &) = delete;
+    ORBextractor &operator=(const ORBextractor &) = delete;
+
+    void SetCamera(const CameraParams &c) { mCam = c; }
+    void SetDevice(int device) { mParams.device = device; }
+    void KeepHostPyramid(bool keep) { mKeepPyramid = keep; }
+
+    // ORBextractor::operator() (src/ORBextractor.cc:858-919).  mask is ignored, as in the
+    // reference.  Empty image: silent return, outputs untouched (:861-862).
+    void operator()(const ImageView &image, std::vector<orbfe_keypoint> &keypoints, std::vector<uint8_t> &descriptors)
+    {
+        if (image.empty()) return;
+        EnsureContext(image.cols, image.rows, 1);
+        const int cap = orbfe_keypoint_capacity(mCtx);
+        keypoints.resize(cap);
+        descriptors.resize((size_t)cap * 32);
+        int n = 0;
+        Check(orbfe_extract(mCtx, image.data, image.cols, image.rows, image.step, keypoints.data(), descriptors.data(), cap, &n));
+        keypoints.resize(n);
+        descriptors.resize((size_t)n * 32);
+        if (mKeepPyramid) FetchPyramid();
+    }
+
+    int inline GetLevels() { return mParams.nlevels; }
+    float inline GetScaleFactor() { return (float)(double)mParams.scale_factor; }
+    std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
+    std::vector<float> inline GetInverseScaleFactors() { return mvInvScaleFactor; }
+    std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
+    std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+    // Host copy of the latest pyramid (only with KeepHostPyramid(true)): level l is
+    // mvPyramidData[l] with mvPyramidCols[l] x mvPyramidRows[l], step == cols.
+    std::vector<std::vector<uint8_t>> mvPyramidData;
+    std::vector<int> mvPyramidCols, mvPyramidRows;
+
+#ifdef ORBFE_WITH_OPENCV
+    // include/ORBextractor.h:58-60
+    void operator()(cv::InputArray _image, cv::InputArray /*mask*/, std::vector<cv::KeyPoint> &_keypoints, cv::OutputArray _descriptors)
+    {
+        if (_image.empty()) return;
+        cv::Mat image = _image.getMat();
+        if (image.type() != CV_8UC1) throw std::invalid_argument("ORBextractor: image must be CV_8UC1"); // assert at :865
+        static_assert(sizeof(cv::KeyPoint) == sizeof(orbfe_keypoint), "cv::KeyPoint layout");
+        std::vector<orbfe_keypoint> kps;
+        std::vector<uint8_t> desc;
+        (*this)(ImageView{image.data, image.cols, image.rows, image.step}, kps, desc);
+        _keypoints.resize(kps.size());
+        if (!kps.empty()) std::memcpy((void *)_keypoints.data(), kps.data(), kps.size() * sizeof(orbfe_keypoint));
+        if (kps.empty()) { _descriptors.release(); }
+        else {
+            _descriptors.create((int)kps.size(), 32, CV_8U);
+            std::memcpy(_descriptors.getMat().data, desc.data(), desc.size());
+        }
+        if (mKeepPyramid) {
+            mvImagePyramid.resize(mParams.nlevels);
+            for (int l = 0; l < mParams.nlevels; l++)
+                mvImagePyramid[l] = cv::Mat(mvPyramidRows[l], mvPyramidCols[l], CV_8UC1, mvPyramidData[l].data());
+        }
+    }
+    std::vector<cv::Mat> mvImagePyramid; // include/ORBextractor.h:84
+#endif
+
+    orbfe_context *Context() { return mCtx; }
+
+    // Creates (or re-creates) the device context for this image size / batch.
+    void EnsureContext(int width, int height, int maxImages)
+    {
+        if (mCtx && mParams.width == width && mParams.height == height && mParams.max_images >= maxImages) return;
+        if (mCtx) { orbfe_destroy(mCtx); mCtx = nullptr; }
+        mParams.width = width; mParams.height = height;
+        if (maxImages > mParams.max_images) mParams.max_images = maxImages;
+        mParams.fx = mCam.fx; mParams.fy = mCam.fy; mParams.cx = mCam.cx; mParams.cy = mCam.cy; mParams.bf = mCam.bf;
+        const int rc = orbfe_create(&mParams, &mCtx);
+        if (rc != ORBFE_OK) throw std::runtime_error(std::string("orbfe_create: ") + orbfe_last_error(nullptr));
+    }
+
+protected:
+    void Check(int rc)
+    {
+        if (rc != ORBFE_OK) throw std::runtime_error(std::string("orbfe: ") + orbfe_last_error(mCtx));
+    }
+    void FetchPyramid()
+    {
+        const int nl = mParams.nlevels;
+        mvPyramidData.resize(nl); mvPyramidCols.resize(nl); mvPyramidRows.resize(nl);
+        for (int l = 0; l < nl; l++) {
+            int w = 0, h = 0;
+            Check(orbfe_level_size(mCtx, l, &w, &h));
+            mvPyramidCols[l] = w; mvPyramidRows[l] = h;
+            mvPyramidData[l].resize((size_t)w * h);
+            Check(orbfe_fetch_pyramid(mCtx, 0, l, 0, mvPyramidData[l].data(), (size_t)w));
+        }
+    }
+
+    orbfe_params mParams;
+    CameraParams mCam;
+    orbfe_context *mCtx = nullptr;
+    bool mKeepPyramid = false;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+};
+
+// Frame::Frame(stereo) body (src/Frame.cc:61-117): both extractions + ComputeStereoMatches in one
+// device round trip.  Outputs are the Frame members the reference fills: mvKeys / mDescriptors,
+// mvKeysRight / mDescriptorsRight, mvuRight, mvDepth.
+struct StereoFrameOutput {
+    std::vector<orbfe_keypoint> mvKeys, mvKeysRight;
+    std::vector<uint8_t> mDescriptors, mDescriptorsRight; // N x 32
+    std::vector<float> mvuRight, mvDepth;
+    int N = 0;
+};
+
+inline void ComputeStereoFrame(ORBextractor &extractorLeft, const ImageView &imLeft, const ImageView &imRight, StereoFrameOutput &out)
+{
+    if (imLeft.empty() || imRight.empty()) { out = StereoFrameOutput(); return; }
+    if (imLeft.cols != imRight.cols || imLeft.rows != imRight.rows || imLeft.step != imRight.step)
+        throw std::invalid_argument("ComputeStereoFrame: left/right geometry differs");
+    extractorLeft.EnsureContext(imLeft.cols, imLeft.rows, 2);
+    orbfe_context *ctx = extractorLeft.Context();
+    const int cap = orbfe_keypoint_capacity(ctx);
+    out.mvKeys.resize(cap); out.mvKeysRight.resize(cap);
+    out.mDescriptors.resize((size_t)cap * 32); out.mDescriptorsRight.resize((size_t)cap * 32);
+    out.mvuRight.assign(cap, -1.0f); out.mvDepth.assign(cap, -1.0f);
+    int nl = 0, nr = 0;
+    const int rc = orbfe_stereo_frame(ctx, imLeft.data, imRight.data, imLeft.cols, imLeft.rows, imLeft.step,
+                                      out.mvKeys.data(), out.mDescriptors.data(), &nl,
+                                      out.mvKeysRight.data(), out.mDescriptorsRight.data(), &nr,
+                                      out.mvuRight.data(), out.mvDepth.data(), cap);
+    if (rc != ORBFE_OK) throw std::runtime_error(std::string("orbfe_stereo_frame: ") + orbfe_last_error(ctx));
+    out.N = nl;
+    out.mvKeys.resize(nl); out.mDescriptors.resize((size_t)nl * 32);
+    out.mvKeysRight.resize(nr); out.mDescriptorsRight.resize((size_t)nr * 32);
+    out.mvuRight.resize(nl); out.mvDepth.resize(nl);
+}
+
+} // namespace ORB_SLAM2

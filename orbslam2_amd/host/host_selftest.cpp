@@ -1,0 +1,62 @@
+// host_selftest.cpp -- exercises the C++ mirror (ORBextractor.h) the way Frame::Frame(stereo) would.
+// usage: host_selftest <raw_left_u8> <raw_right_u8> <width> <height> <nfeatures> <fx> <bf> <out_prefix>
+// Writes <out_prefix>.kl / .dl / .kr / .dr / .ur / .dp (raw binary) for the pytest comparison.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <vector>
+
+#include "ORBextractor.h"
+
+static std::vector<uint8_t> slurp(const char *path, size_t n)
+{
+    std::vector<uint8_t> v(n);
+    std::ifstream f(path, std::ios::binary);
+    if (!f.read((char *)v.data(), (std::streamsize)n)) { std::cerr << "cannot read " << path << "\n"; std::exit(2); }
+    return v;
+}
+template <typename T>
+static void dump(const std::string &path, const std::vector<T> &v)
+{
+    std::ofstream f(path, std::ios::binary);
+    f.write((const char *)v.data(), (std::streamsize)(v.size() * sizeof(T)));
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 9) { std::cerr << "usage: host_selftest left right w h nfeatures fx bf out_prefix\n"; return 2; }
+    const int w = std::atoi(argv[3]), h = std::atoi(argv[4]), nf = std::atoi(argv[5]);
+    const float fx = (float)std::atof(argv[6]), bf = (float)std::atof(argv[7]);
+    const std::string prefix = argv[8];
+    std::vector<uint8_t> left = slurp(argv[1], (size_t)w * h), right = slurp(argv[2], (size_t)w * h);
+    try {
+        // same construction as src/Tracking.cc:125-131 with the defaults of :118-123
+        ORB_SLAM2::ORBextractor extractorLeft(nf, 1.2f, 8, 20, 7, 31, 15, 19);
+        ORB_SLAM2::CameraParams cam; cam.fx = fx; cam.fy = fx; cam.cx = w * 0.5f; cam.cy = h * 0.5f; cam.bf = bf;
+        extractorLeft.SetCamera(cam);
+        ORB_SLAM2::StereoFrameOutput out;
+        ORB_SLAM2::ComputeStereoFrame(extractorLeft, ORB_SLAM2::ImageView{left.data(), w, h, (size_t)w},
+                                      ORB_SLAM2::ImageView{right.data(), w, h, (size_t)w}, out);
+        // mono call through operator(), pyramid kept on the host like mvImagePyramid
+        ORB_SLAM2::ORBextractor mono(nf, 1.2f, 8, 20, 7, 31, 15, 19);
+        mono.KeepHostPyramid(true);
+        std::vector<orbfe_keypoint> k; std::vector<uint8_t> d;
+        mono(ORB_SLAM2::ImageView{left.data(), w, h, (size_t)w}, k, d);
+        if (k.size() != out.mvKeys.size() || d != out.mDescriptors) { std::cerr << "mono/stereo mismatch\n"; return 3; }
+        if ((int)mono.mvPyramidData.size() != mono.GetLevels() || mono.mvPyramidCols[0] != w) { std::cerr << "pyramid missing\n"; return 4; }
+        // empty image: silent return, outputs untouched
+        std::vector<orbfe_keypoint> k2(3); std::vector<uint8_t> d2(96);
+        mono(ORB_SLAM2::ImageView{}, k2, d2);
+        if (k2.size() != 3 || d2.size() != 96) { std::cerr << "empty-image contract broken\n"; return 5; }
+        dump(prefix + ".kl", out.mvKeys); dump(prefix + ".dl", out.mDescriptors);
+        dump(prefix + ".kr", out.mvKeysRight); dump(prefix + ".dr", out.mDescriptorsRight);
+        dump(prefix + ".ur", out.mvuRight); dump(prefix + ".dp", out.mvDepth);
+        std::printf("N=%d NR=%zu levels=%d scale1=%.9g\n", out.N, out.mvKeysRight.size(), extractorLeft.GetLevels(),
+                    (double)extractorLeft.GetScaleFactors()[1]);
+    } catch (const std::exception &e) {
+        std::cerr << "error: " << e.what() << "\n";
+        return 1;
+    }
+    return 0;
+}
