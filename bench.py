@@ -13,10 +13,8 @@ pattern checksum from rank 0 at start-up.  Rank 0 prints ONE JSON line.
 from __future__ import annotations
 
 import argparse
-import hashlib
 import json
 import os
-import struct
 import sys
 import threading
 import time
@@ -101,30 +99,19 @@ def main():
     import torch.distributed as dist
     from orbslam2_amd import api, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    from orbslam2_amd import dist as D
+    rank, local_rank, world = D.world_info()
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+    D.init("nccl", dev)
 
     # one-time RCCL broadcast of the extractor parameters + rBRIEF pattern checksum
-    pat_path = os.path.join(ROOT, "orbslam2_amd", "csrc", "orb_pattern_31.inc")
-    blob = struct.pack("<ifiiiiii5f", NFEAT, 1.2, NLEVELS, 20, 7, 31, 15, 19, FX, FY, CX, CY, BF)
-    blob += hashlib.sha256(open(pat_path, "rb").read()).digest()
-    t_blob = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
-    if world > 1:
-        mine = t_blob.clone()
-        dist.broadcast(t_blob, src=0)
-        assert torch.equal(mine, t_blob), "rank %d: parameters/pattern differ from rank 0" % rank
-    nf, sf, nl, ini, mn, ps, hps, et, fx, fy, cx, cy, bf = struct.unpack("<ifiiiiii5f", bytes(t_blob.cpu().numpy().tobytes()[:52]))
+    blob = D.broadcast_params(D.pack_params(NFEAT, 1.2, NLEVELS, 20, 7, 31, 15, 19, FX, FY, CX, CY, BF), dev)
+    nf, sf, nl, ini, mn, ps, hps, et, fx, fy, cx, cy, bf = D.unpack_params(blob)
 
     P = args.pairs
     ctx = api.Context(width=W, height=H, nfeatures=nf, scale_factor=sf, nlevels=nl, ini_th_fast=ini, min_th_fast=mn,
@@ -142,8 +129,7 @@ def main():
         ctx.enqueue_stereo(d_images.data_ptr(), P, stream)
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        D.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -157,10 +143,7 @@ def main():
     dt = time.perf_counter() - t0
     stage_ms, calls = ctx.stage_times(reset=True)
     ctx.set_profiling(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = D.max_over_ranks(dt, dev)
 
     counts = ctx.fetch_counts(2 * P)
     n_cand = 0
@@ -214,7 +197,7 @@ def main():
         print(json.dumps(out))
     ctx.close()
     if world > 1:
-        dist.barrier()
+        D.barrier()
         dist.destroy_process_group()
 
 

@@ -1,0 +1,71 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" == RCCL over xGMI).
+
+Frame pairs are independent units: ranks shard them round-robin and never exchange
+pixels, keypoints or matches.  The only collective on the path is a ONE-TIME broadcast of the extractor
+parameters and the rBRIEF pattern checksum from rank 0 (every rank checks it runs the same front-end),
+plus a MAX all-reduce of the elapsed time for reporting.  CPU tests run the same code over gloo.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import struct
+
+import torch
+import torch.distributed as dist
+
+PARAM_FMT = "<ifiiiiii5f"  # nfeatures, scaleFactor, nlevels, iniTh, minTh, patch, halfPatch, edge, fx, fy, cx, cy, bf
+PATTERN_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "orb_pattern_31.inc")
+
+
+def world_info():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend: str, device=None):
+    rank, _, world = world_info()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
+def pack_params(nfeatures, scale_factor, nlevels, ini_th, min_th, patch, half_patch, edge, fx, fy, cx, cy, bf) -> bytes:
+    blob = struct.pack(PARAM_FMT, nfeatures, scale_factor, nlevels, ini_th, min_th, patch, half_patch, edge, fx, fy, cx, cy, bf)
+    return blob + hashlib.sha256(open(PATTERN_PATH, "rb").read()).digest()
+
+
+def unpack_params(blob: bytes):
+    return struct.unpack(PARAM_FMT, blob[: struct.calcsize(PARAM_FMT)])
+
+
+def broadcast_params(blob: bytes, device) -> bytes:
+    """Rank 0's parameter blob on every rank; raises if this rank's pattern table differs from rank 0's."""
+    t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        mine = t.clone()
+        dist.broadcast(t, src=0)
+        n = struct.calcsize(PARAM_FMT)
+        if not torch.equal(mine[n:], t[n:]):
+            raise RuntimeError("rank %d: rBRIEF pattern differs from rank 0" % dist.get_rank())
+    return bytes(t.cpu().numpy().tobytes())
+
+
+def shard_pairs(total_pairs: int, rank: int, world: int):
+    """Round-robin by frame index: pair i goes to rank i % world."""
+    return list(range(rank, total_pairs, world))
+
+
+def max_over_ranks(value: float, device) -> float:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([value], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    return value
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -1,0 +1,62 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/orbfe.h declares, validates its
+arguments, and fails loudly (ORBFE_ERR_NO_DEVICE) instead of falling back to a CPU path."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from orbslam2_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "orbfe.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(orbfe_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    lib = api.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "liborbfe.so does not export %s" % n
+    assert sorted(api.EXPORTS) == names, "api.EXPORTS out of sync with include/orbfe.h"
+    assert lib.orbfe_abi_version() == 1
+
+
+def test_struct_layouts():
+    assert C.sizeof(api.Params) == 17 * 4
+    assert api.KP_DTYPE.itemsize == 28
+
+
+def test_invalid_params_rejected():
+    lib = api.load()
+    h = C.c_void_p()
+    bad = api.Params(2000, 1.2, 0, 20, 7, 31, 15, 19, 1, 1, 0, 0, 1, 0, 640, 480, 2)  # nlevels = 0
+    assert lib.orbfe_create(C.byref(bad), C.byref(h)) == api.ERR_INVALID
+    assert b"invalid" in lib.orbfe_last_error(None)
+    assert lib.orbfe_create(None, C.byref(h)) == api.ERR_INVALID
+
+
+def test_no_gpu_means_loud_failure_not_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-marked tests")
+    with pytest.raises(api.OrbfeError) as e:
+        api.Context(width=640, height=480)
+    assert e.value.code == api.ERR_NO_DEVICE
+    assert "no CPU path" in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, "orbslam2_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".inc")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liborb_oracle" not in text and "from oracle" not in text and "import oracle" not in text \
+                    and "orb_oracle.h" not in text, os.path.join(dirpath, f)
