@@ -162,9 +162,10 @@ static int build_config(orbfe_context *ctx)
         L.w = cv_round_f((float)p.width * L.inv_scale);
         L.h = cv_round_f((float)p.height * L.inv_scale);
         if (L.w < 1 || L.h < 1) return fail(ctx, ORBFE_ERR_UNSUPPORTED, "level %d is empty (%dx%d)", l, L.w, L.h);
-        L.pitch = (L.w + 63) & ~63;
-        L.pyr_off = (int)pyr_off;
-        pyr_off += ((size_t)L.pitch * L.h + 255) & ~(size_t)255;
+        // reflect-101 margin: 4 px left, >= 12 px right, 3 rows above/below (see orbfe_kernels.hip)
+        L.pitch = (L.w + 16 + 63) & ~63;
+        L.pyr_off = (int)(pyr_off + (size_t)3 * L.pitch + 4);
+        pyr_off += ((size_t)L.pitch * (L.h + 6) + 255) & ~(size_t)255;
         if (l > 0) {
             L.rs_scale_x = 1.0 / ((double)L.w / (double)c.lv[l - 1].w);
             L.rs_scale_y = 1.0 / ((double)L.h / (double)c.lv[l - 1].h);
@@ -214,8 +215,8 @@ static int build_config(orbfe_context *ctx)
         sel_off += L.sel_cap;
         if (L.sel_cap + 1 > max_nodes) max_nodes = L.sel_cap + 1;
         L.blur_tile_off = tile_off;
-        L.blur_tiles_x = (L.w + 63) / 64;
-        L.blur_tiles_y = (L.h + 15) / 16;
+        L.blur_tiles_x = (L.w + 255) / 256;
+        L.blur_tiles_y = (L.h + 63) / 64;
         tile_off += L.blur_tiles_x * L.blur_tiles_y;
     }
     c.pyr_bytes = pyr_off;

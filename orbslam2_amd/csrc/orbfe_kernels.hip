@@ -18,6 +18,8 @@
 #include "orbfe_device.h"
 
 #define OT_THREADS 512
+#define PYR_MX 4
+#define PYR_MY 3
 
 __device__ const int8_t g_pattern[1024] = {
 #include "orb_pattern_31.inc"
@@ -151,43 +153,42 @@ __device__ __forceinline__ int hamming256(const uint32_t *a, const uint32_t *b)
 }
 
 // ---------------------------------------------------------------------------
-// ingest: packed images -> level 0 of the pyramid buffer
+// Pyramid storage.  Every level is stored with a reflect-101 margin (PYR_MX px on the left, at
+// least 8 px on the right, PYR_MY rows above and below) written by its producer (ingest / resize),
+// and pixel (0,0) sits on a 4-byte boundary.  Consumers can therefore use aligned 32-bit loads and
+// need no border logic: the margin IS cv::GaussianBlur's BORDER_REFLECT_101 (src/ORBextractor.cc:900).
 // ---------------------------------------------------------------------------
+
+// ingest: packed images -> level 0 (+ margin); one thread = 4 px of the extended domain
 __global__ __launch_bounds__(256) void ingest_kernel(DeviceConfig cfg, DeviceBuffers buf, const uint8_t *__restrict__ src)
 {
     const int img = blockIdx.z;
-    const int y = blockIdx.y;
-    const int x = blockIdx.x * 256 + threadIdx.x;
     const LevelInfo &L = cfg.lv[0];
-    if (x >= L.w) return;
-    const uint8_t *s = src + (size_t)img * L.w * L.h + (size_t)y * L.w;
-    uint8_t *d = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (size_t)y * L.pitch;
-    d[x] = s[x];
+    const int y = (int)blockIdx.y - PYR_MY;
+    const int x0 = (int)(blockIdx.x * 256 + threadIdx.x) * 4 - PYR_MX;
+    if (x0 >= L.w + 8) return;
+    const uint8_t *s = src + (size_t)img * L.w * L.h + (size_t)reflect101(y, L.h) * L.w;
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) v |= (uint32_t)s[reflect101(x0 + j, L.w)] << (8 * j);
+    uint8_t *d = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (ptrdiff_t)y * L.pitch + x0;
+    *(uint32_t *)d = v;
 }
 
-// ---------------------------------------------------------------------------
-// pyramid: level l from level l-1 (cv::resize INTER_LINEAR, 8UC1 fixed point)
-// ---------------------------------------------------------------------------
+// pyramid: level l from level l-1 (cv::resize INTER_LINEAR, 8UC1 fixed point); one thread = 4 px
+// of the extended (margin-included) domain of level l.
 __global__ __launch_bounds__(256) void pyr_resize_kernel(DeviceConfig cfg, DeviceBuffers buf, int level)
 {
     const int img = blockIdx.z;
     const LevelInfo &D = cfg.lv[level];
     const LevelInfo &S = cfg.lv[level - 1];
-    const int dx = blockIdx.x * 64 + threadIdx.x;
-    const int dy = blockIdx.y * 4 + threadIdx.y;
-    if (dx >= D.w || dy >= D.h) return;
+    const int x0 = (int)(blockIdx.x * 64 + threadIdx.x) * 4 - PYR_MX;
+    const int ye = (int)(blockIdx.y * 4 + threadIdx.y) - PYR_MY;
+    if (x0 >= D.w + 8 || ye >= D.h + PYR_MY) return;
     const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + S.pyr_off;
     uint8_t *dst = buf.pyr + (size_t)img * cfg.pyr_bytes + D.pyr_off;
 
-    float fx = (float)__dsub_rn(__dmul_rn(__dadd_rn((double)dx, 0.5), D.rs_scale_x), 0.5);
-    int sx = (int)floorf(fx);
-    fx = __fsub_rn(fx, (float)sx);
-    if (sx < 0) { fx = 0.f; sx = 0; }
-    if (sx >= S.w - 1) { fx = 0.f; sx = S.w - 1; }
-    const int a0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fx), 2048.f));
-    const int a1 = (int)rintf(__fmul_rn(fx, 2048.f));
-    const int sx1 = sx + 1 < S.w ? sx + 1 : S.w - 1;
-
+    const int dy = reflect101(ye, D.h);
     float fy = (float)__dsub_rn(__dmul_rn(__dadd_rn((double)dy, 0.5), D.rs_scale_y), 0.5);
     int sy = (int)floorf(fy);
     fy = __fsub_rn(fy, (float)sy);
@@ -195,62 +196,86 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(DeviceConfig cfg, Devic
     const int b1 = (int)rintf(__fmul_rn(fy, 2048.f));
     const int sy0 = sy < 0 ? 0 : (sy > S.h - 1 ? S.h - 1 : sy);
     const int sy1 = sy + 1 < 0 ? 0 : (sy + 1 > S.h - 1 ? S.h - 1 : sy + 1);
-
     const uint8_t *r0 = src + (size_t)sy0 * S.pitch;
     const uint8_t *r1 = src + (size_t)sy1 * S.pitch;
-    const int h0 = r0[sx] * a0 + r0[sx1] * a1;
-    const int h1 = r1[sx] * a0 + r1[sx1] * a1;
-    int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-    v = v < 0 ? 0 : (v > 255 ? 255 : v);
-    dst[(size_t)dy * D.pitch + dx] = (uint8_t)v;
+
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int dx = reflect101(x0 + j, D.w);
+        float fx = (float)__dsub_rn(__dmul_rn(__dadd_rn((double)dx, 0.5), D.rs_scale_x), 0.5);
+        int sx = (int)floorf(fx);
+        fx = __fsub_rn(fx, (float)sx);
+        if (sx < 0) { fx = 0.f; sx = 0; }
+        if (sx >= S.w - 1) { fx = 0.f; sx = S.w - 1; }
+        const int a0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fx), 2048.f));
+        const int a1 = (int)rintf(__fmul_rn(fx, 2048.f));
+        const int sx1 = sx + 1 < S.w ? sx + 1 : S.w - 1;
+        const int h0 = r0[sx] * a0 + r0[sx1] * a1;
+        const int h1 = r1[sx] * a0 + r1[sx1] * a1;
+        int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        out |= (uint32_t)v << (8 * j);
+    }
+    *(uint32_t *)(dst + (ptrdiff_t)ye * D.pitch + x0) = out;
 }
 
 // ---------------------------------------------------------------------------
-// Gaussian 7x7 (8.8 fixed point, separable), all levels in one launch
+// Gaussian 7x7 (8.8 fixed point, separable), all levels in one launch.
+// Register sliding window: a lane owns 4 adjacent columns and walks down BL_ROWS rows; per input
+// row it loads three aligned words (12 px), forms the four 7-tap row sums with v_dot4_u32_u8, keeps
+// the last seven row-sum vectors in registers and emits one 4-px output word.  No LDS, no barriers;
+// HBM traffic = one read of the level (+6/BL_ROWS row halo, L2-served) and one write.
 // ---------------------------------------------------------------------------
-#define BL_TW 64
-#define BL_TH 16
+#define BL_ROWS 16
+#define BL_COLS 256 // per wave: 64 lanes x 4 px
 __global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffers buf)
 {
-    __shared__ uint8_t s_in[(BL_TH + 6) * (BL_TW + 8)];
-    __shared__ uint16_t s_h[(BL_TH + 6) * BL_TW];
     const int img = blockIdx.y;
     int level = 0;
     for (int l = 1; l < cfg.nlevels; l++)
         if ((int)blockIdx.x >= cfg.lv[l].blur_tile_off) level = l;
     const LevelInfo &L = cfg.lv[level];
     const int t = blockIdx.x - L.blur_tile_off;
-    const int tx0 = (t % L.blur_tiles_x) * BL_TW;
-    const int ty0 = (t / L.blur_tiles_x) * BL_TH;
-    const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off;
-    uint8_t *dst = buf.blur + (size_t)img * cfg.pyr_bytes + L.pyr_off;
-    const int tid = threadIdx.x;
-    const int IP = BL_TW + 8;
-    for (int i = tid; i < (BL_TH + 6) * (BL_TW + 6); i += 256) {
-        const int r = i / (BL_TW + 6), c = i % (BL_TW + 6);
-        const int gy = reflect101(ty0 + r - 3, L.h);
-        const int gx = reflect101(tx0 + c - 3, L.w);
-        s_in[r * IP + c] = src[(size_t)gy * L.pitch + gx];
-    }
-    __syncthreads();
-    const int k0 = cfg.taps[0], k1 = cfg.taps[1], k2 = cfg.taps[2], k3 = cfg.taps[3],
-              k4 = cfg.taps[4], k5 = cfg.taps[5], k6 = cfg.taps[6];
-    for (int i = tid; i < (BL_TH + 6) * BL_TW; i += 256) {
-        const int r = i / BL_TW, c = i % BL_TW;
-        const uint8_t *p = &s_in[r * IP + c];
-        const unsigned acc = k0 * p[0] + k1 * p[1] + k2 * p[2] + k3 * p[3] + k4 * p[4] + k5 * p[5] + k6 * p[6];
-        s_h[r * BL_TW + c] = (uint16_t)acc;
-    }
-    __syncthreads();
-    for (int i = tid; i < BL_TH * BL_TW; i += 256) {
-        const int r = i / BL_TW, c = i % BL_TW;
-        const int x = tx0 + c, y = ty0 + r;
-        if (x < L.w && y < L.h) {
-            const uint16_t *p = &s_h[r * BL_TW + c];
-            const unsigned acc = k0 * p[0] + k1 * p[BL_TW] + k2 * p[2 * BL_TW] + k3 * p[3 * BL_TW] +
-                                 k4 * p[4 * BL_TW] + k5 * p[5 * BL_TW] + k6 * p[6 * BL_TW];
-            unsigned v = (acc + 32768u) >> 16;
-            dst[(size_t)y * L.pitch + x] = (uint8_t)(v > 255u ? 255u : v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x0 = (t % L.blur_tiles_x) * BL_COLS + lane * 4;
+    const int r0 = (t / L.blur_tiles_x) * (4 * BL_ROWS) + wave * BL_ROWS;
+    if (x0 >= L.w || r0 >= L.h) return;
+    const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + x0;
+    uint8_t *dst = buf.blur + (size_t)img * cfg.pyr_bytes + L.pyr_off + x0;
+    const unsigned k_lo = (unsigned)cfg.taps[0] | ((unsigned)cfg.taps[1] << 8) | ((unsigned)cfg.taps[2] << 16) | ((unsigned)cfg.taps[3] << 24);
+    const unsigned k_hi = (unsigned)cfg.taps[4] | ((unsigned)cfg.taps[5] << 8) | ((unsigned)cfg.taps[6] << 16);
+    const unsigned k0 = cfg.taps[0], k1 = cfg.taps[1], k2 = cfg.taps[2], k3 = cfg.taps[3];
+    const int y_max = L.h + PYR_MY - 1; // last materialised row
+    unsigned H[7][4];
+#pragma unroll
+    for (int i = 0; i < BL_ROWS + 6; i++) {
+        int y = r0 - 3 + i;
+        y = y > y_max ? y_max : y; // rows past the margin only feed outputs that are never stored
+        const uint32_t *row = (const uint32_t *)(src + (ptrdiff_t)y * L.pitch);
+        const unsigned w0 = row[-1], w1 = row[0], w2 = row[1];
+        unsigned hn[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned lo = j == 3 ? w1 : __builtin_amdgcn_alignbyte(w1, w0, j + 1);
+            const unsigned hi = j == 3 ? w2 : __builtin_amdgcn_alignbyte(w2, w1, j + 1);
+            hn[j] = __builtin_amdgcn_udot4(lo, k_lo, __builtin_amdgcn_udot4(hi, k_hi, 0u, false), false);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) H[i % 7][j] = hn[j];
+        if (i >= 6) {
+            const int yo = r0 + i - 6;
+            if (yo < L.h) {
+                // rows of the window in age order: oldest is slot (i+1)%7
+                unsigned o = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const unsigned acc = k0 * (H[(i + 1) % 7][j] + H[i % 7][j]) + k1 * (H[(i + 2) % 7][j] + H[(i + 6) % 7][j]) +
+                                         k2 * (H[(i + 3) % 7][j] + H[(i + 5) % 7][j]) + k3 * H[(i + 4) % 7][j];
+                    o |= ((acc + 32768u) >> 16) << (8 * j);
+                }
+                *(uint32_t *)(dst + (ptrdiff_t)yo * L.pitch) = o;
+            }
         }
     }
 }
@@ -987,14 +1012,16 @@ static inline int max_cell_h(const DeviceConfig &cfg) { int m = 0; for (int l = 
 
 void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, const uint8_t *d_images, int n_images, hipStream_t s)
 {
-    dim3 grid((cfg.lv[0].w + 255) / 256, cfg.lv[0].h, n_images);
+    const int words = (cfg.lv[0].w + 12 + 3) / 4;
+    dim3 grid((words + 255) / 256, cfg.lv[0].h + 2 * PYR_MY, n_images);
     hipLaunchKernelGGL(ingest_kernel, grid, dim3(256), 0, s, cfg, buf, d_images);
 }
 
 void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
 {
     for (int l = 1; l < cfg.nlevels; l++) {
-        dim3 grid((cfg.lv[l].w + 63) / 64, (cfg.lv[l].h + 3) / 4, n_images);
+        const int words = (cfg.lv[l].w + 12 + 3) / 4;
+        dim3 grid((words + 63) / 64, (cfg.lv[l].h + 2 * PYR_MY + 3) / 4, n_images);
         hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(64, 4), 0, s, cfg, buf, l);
     }
 }
