@@ -283,6 +283,30 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
     A(b.sad, B * c.sel_total);
     A(b.status, B);
     A(ctx->d_in, B * (size_t)p.width * p.height);
+    {   // stereo row table: a right keypoint spans at most 2*r+3 rows, r = 2*scale[top level]
+        const int span = (int)(2.0f * 2.0f * ctx->scale[p.nlevels - 1]) + 3;
+        ctx->cfg.row_idx_cap = c.sel_total * span;
+        const size_t pairs = (B + 1) / 2;
+        A(b.row_off, pairs * (size_t)(p.height + 1));
+        A(b.row_idx, pairs * (size_t)ctx->cfg.row_idx_cap);
+    }
+    {   // circular patch of IC_Angle (src/ORBextractor.cc:79-96): |v| <= hp, |u| <= umax[|v|]
+        std::vector<int16_t> uv;
+        const int hp = p.half_patch_size;
+        for (int v = -hp; v <= hp; v++) {
+            const int d = c.umax[v < 0 ? -v : v];
+            for (int u = -d; u <= d; u++) uv.push_back((int16_t)((u & 0xff) | ((v & 0xff) << 8)));
+        }
+        while (uv.size() % 64) uv.push_back(0);
+        int16_t *d_uv = nullptr;
+        A(d_uv, uv.size());
+        if (hipMemcpy(d_uv, uv.data(), uv.size() * sizeof(int16_t), hipMemcpyHostToDevice) != hipSuccess) {
+            orbfe_destroy(ctx);
+            return fail(nullptr, ORBFE_ERR_HIP, "patch table upload failed");
+        }
+        b.patch_uv = d_uv;
+        ctx->cfg.patch_n = (int)uv.size();
+    }
 #undef A
     hipMemset(b.kp_cnt, 0, sizeof(int) * B);
     hipMemset(b.sel_cnt, 0, sizeof(int) * B * c.nlevels);

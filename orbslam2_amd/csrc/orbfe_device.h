@@ -39,6 +39,8 @@ struct DeviceConfig {
     int sel_total;         // per image == keypoint capacity
     int blur_tiles_total;
     int max_nodes;         // quadtree node capacity (LDS)
+    int row_idx_cap;       // entries per pair in DeviceBuffers::row_idx
+    int patch_n;           // entries in DeviceBuffers::patch_uv (multiple of 64)
     int umax[64];
     int taps[7];           // Gaussian 8.8 fixed-point taps
     size_t pyr_bytes;      // per image
@@ -68,6 +70,9 @@ struct DeviceBuffers {
     float *depth;        // [img][sel_total]
     int *sad;            // [img][sel_total] best SAD (or -1)
     int *status;         // [img] non-zero = device-side capacity problem
+    int *row_off;        // [pair][height+1] stereo row table offsets
+    uint16_t *row_idx;   // [pair][row_idx_cap] right-keypoint indices per row
+    const int16_t *patch_uv; // IC_Angle patch offsets: (u & 0xff) | (v << 8), padded with (0,0)
 };
 
 struct KeyPointPOD {

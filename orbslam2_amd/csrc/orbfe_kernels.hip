@@ -307,11 +307,28 @@ __device__ __forceinline__ int fast_score16(const uint8_t *t, int pitch, int min
     return max(minth, max(a, -b)) - 1;
 }
 
-__global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, DeviceBuffers buf, int tile_pitch, int tile_bytes, int sc_bytes)
+// One wave (64-thread workgroup) per FAST cell (src/ORBextractor.cc:783-810): no inter-wave barriers,
+// and wave-ordered ballot compaction keeps every queue in row-major order, which is cv::FAST's
+// emission order.  Phases:
+//  0  aligned 32-bit loads of the (w+6)x(h+6) cell tile into LDS;
+//  A  cheap necessary test on the 4 cardinal ring pixels (a 9-arc always holds two adjacent
+//     cardinals)                                                        -> queue 1
+//  B  OpenCV's 8-opposite-pairs necessary test on the full ring         -> queue 2
+//  C  exact threshold-independent score (closed form of cornerScore<16>) for queue 2
+//  D  strict 3x3 NMS inside the cell interior; iniThFAST, or minThFAST if that leaves nothing
+//  E  ordered compaction of the survivors into the cell's slot.
+__device__ __forceinline__ void load_ring(const uint8_t *t, int pitch, int d[16])
 {
-    extern __shared__ uint8_t s_mem[];
-    __shared__ int s_wcnt[4];
-    __shared__ int s_any_ini;
+    const int v = t[0];
+    d[0] = v - t[3 * pitch];       d[1] = v - t[3 * pitch + 1];   d[2] = v - t[2 * pitch + 2];   d[3] = v - t[pitch + 3];
+    d[4] = v - t[3];               d[5] = v - t[-pitch + 3];      d[6] = v - t[-2 * pitch + 2];  d[7] = v - t[-3 * pitch + 1];
+    d[8] = v - t[-3 * pitch];      d[9] = v - t[-3 * pitch - 1];  d[10] = v - t[-2 * pitch - 2]; d[11] = v - t[-pitch - 3];
+    d[12] = v - t[-3];             d[13] = v - t[pitch - 3];      d[14] = v - t[2 * pitch - 2];  d[15] = v - t[3 * pitch - 1];
+}
+
+__global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceBuffers buf, int tile_pitch, int tile_bytes, int sc_bytes, int q_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
     const int img = blockIdx.y;
     const int cell = blockIdx.x;
     int level = 0;
@@ -319,8 +336,9 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
         if (cell >= cfg.lv[l].cell_off) level = l;
     const LevelInfo &L = cfg.lv[level];
     const int ci = cell - L.cell_off;
-    const int ci_i = ci / L.n_cols, ci_j = ci % L.n_cols;
-    const int tid = threadIdx.x;
+    const int ci_i = ci / L.n_cols, ci_j = ci - ci_i * L.n_cols;
+    const int lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     int *cnt_out = buf.cell_cnt + (size_t)img * cfg.cells_total + cell;
 
     const int min_b = cfg.min_border;
@@ -331,7 +349,7 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
     int max_y = ini_y + L.h_cell + 6;
     int max_x = ini_x + L.w_cell + 6;
     if (ini_y >= max_by - 3 || ini_x >= max_bx - 6) { // src/ORBextractor.cc:788-798
-        if (tid == 0) *cnt_out = 0;
+        if (lane == 0) *cnt_out = 0;
         return;
     }
     if (max_y > max_by) max_y = max_by;
@@ -339,63 +357,108 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
     const int tw = max_x - ini_x, th = max_y - ini_y;
     const int iw = tw - 6, ih = th - 6;
     if (iw <= 0 || ih <= 0) {
-        if (tid == 0) *cnt_out = 0;
+        if (lane == 0) *cnt_out = 0;
         return;
     }
-    // LDS layout (sizes fixed by the host from the largest cell): tile | scores | flags
-    uint8_t *s_tile = s_mem;               // [th][tile_pitch]
-    uint8_t *s_sc = s_mem + tile_bytes;    // [(ih+2)][(iw+2)], zero border
-    uint8_t *s_fl = s_sc + sc_bytes;       // [ih*iw] 0 / 1 (local max, >= minTh) / 2 (>= iniTh)
+    // LDS layout (sizes fixed by the host from the largest cell): tile | scores | queue1 | queue2 | flags
+    uint8_t *s_tile = s_mem;                           // [th][tile_pitch], column 0 = pixel xa (4-aligned)
+    uint8_t *s_sc = s_mem + tile_bytes;                // [(ih+2)][(iw+2)], zero border
+    uint16_t *s_q1 = (uint16_t *)(s_sc + sc_bytes);    // packed (r << 8 | c), row-major ascending
+    uint16_t *s_q2 = (uint16_t *)((uint8_t *)s_q1 + q_bytes);
+    uint8_t *s_qf = (uint8_t *)s_q2 + q_bytes;         // per queue-2 entry: 0 / 1 (local max, >= minTh) / 2 (>= iniTh)
     const int scp = iw + 2;
-
-    const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (size_t)ini_y * L.pitch + ini_x;
-    for (int i = tid; i < th * tw; i += 256) {
-        const int r = i / tw, c = i % tw;
-        s_tile[r * tile_pitch + c] = src[(size_t)r * L.pitch + c];
-    }
-    for (int i = tid; i < (ih + 2) * scp; i += 256) s_sc[i] = 0;
-    if (tid == 0) s_any_ini = 0;
-    __syncthreads();
     const int npx = iw * ih;
-    for (int i = tid; i < npx; i += 256) {
-        const int r = i / iw, c = i % iw;
-        const int s = fast_score16(&s_tile[(r + 3) * tile_pitch + c + 3], tile_pitch, cfg.min_th);
-        s_sc[(r + 1) * scp + c + 1] = (uint8_t)(s >= cfg.min_th ? s : 0);
+    const float rcp_iw = 1.0f / (float)iw;
+
+    const int xa = ini_x & ~3, ox = ini_x - xa;
+    const int wpr = (max_x - xa + 3) >> 2; // words per tile row
+    const float rcp_wpr = 1.0f / (float)wpr;
+    const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (size_t)ini_y * L.pitch + xa;
+    for (int i = lane; i < th * wpr; i += 64) {
+        const int r = (int)(((float)i + 0.5f) * rcp_wpr), c = i - r * wpr;
+        *(uint32_t *)(s_tile + r * tile_pitch + 4 * c) = *(const uint32_t *)(src + (size_t)r * L.pitch + 4 * c);
+    }
+    for (int i = lane; i < sc_bytes / 4; i += 64) ((uint32_t *)s_sc)[i] = 0;
+    __syncthreads();
+    const int t = cfg.min_th;
+    // ---- A: cardinal test ----
+    int n1 = 0;
+    for (int i0 = 0; i0 < npx; i0 += 64) {
+        const int i = i0 + lane;
+        bool pass = false;
+        int r = 0, c = 0;
+        if (i < npx) {
+            r = (int)(((float)i + 0.5f) * rcp_iw); c = i - r * iw;
+            const uint8_t *p = &s_tile[(r + 3) * tile_pitch + c + 3 + ox];
+            const int v = p[0];
+            const int d0 = v - p[3 * tile_pitch], d8 = v - p[-3 * tile_pitch], d4 = v - p[3], d12 = v - p[-3];
+            pass = ((d0 > t || d8 > t) && (d4 > t || d12 > t)) || ((d0 < -t || d8 < -t) && (d4 < -t || d12 < -t));
+        }
+        const unsigned long long m = __ballot(pass);
+        if (pass) s_q1[n1 + __popcll(m & lt)] = (uint16_t)((r << 8) | c);
+        n1 += __popcll(m);
     }
     __syncthreads();
-    int any = 0;
-    for (int i = tid; i < npx; i += 256) {
-        const int r = i / iw, c = i % iw;
-        const uint8_t *p = &s_sc[(r + 1) * scp + c + 1];
+    // ---- B: 8 opposite pairs: a dark (bright) 9-arc needs one darker (brighter) pixel in every pair ----
+    int n2 = 0;
+    for (int q0 = 0; q0 < n1; q0 += 64) {
+        const int q = q0 + lane;
+        bool pass = false;
+        unsigned rc = 0;
+        if (q < n1) {
+            rc = s_q1[q];
+            int d[16];
+            load_ring(&s_tile[((rc >> 8) + 3) * tile_pitch + (rc & 255) + 3 + ox], tile_pitch, d);
+            int lo = 512, hi = -512;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                lo = min(lo, max(d[k], d[k + 8])); // dark: every pair has a member with d > t
+                hi = max(hi, min(d[k], d[k + 8])); // bright: every pair has a member with d < -t
+            }
+            pass = lo > t || hi < -t;
+        }
+        const unsigned long long m = __ballot(pass);
+        if (pass) s_q2[n2 + __popcll(m & lt)] = (uint16_t)rc;
+        n2 += __popcll(m);
+    }
+    __syncthreads();
+    // ---- C: exact score ----
+    for (int q = lane; q < n2; q += 64) {
+        const unsigned rc = s_q2[q];
+        const int r = rc >> 8, c = rc & 255;
+        const int s = fast_score16(&s_tile[(r + 3) * tile_pitch + c + 3 + ox], tile_pitch, t);
+        s_sc[(r + 1) * scp + c + 1] = (uint8_t)(s >= t ? s : 0);
+    }
+    __syncthreads();
+    // ---- D: NMS + threshold choice ----
+    bool any = false;
+    for (int q = lane; q < n2; q += 64) {
+        const unsigned rc = s_q2[q];
+        const uint8_t *p = &s_sc[((rc >> 8) + 1) * scp + (rc & 255) + 1];
         const int s = p[0];
         int f = 0;
         if (s > 0 && s > p[-1] && s > p[1] && s > p[-scp - 1] && s > p[-scp] && s > p[-scp + 1] &&
             s > p[scp - 1] && s > p[scp] && s > p[scp + 1]) {
             f = (s >= cfg.ini_th) ? 2 : 1;
-            if (f == 2) any = 1;
+            any |= (f == 2);
         }
-        s_fl[i] = (uint8_t)f;
+        s_qf[q] = (uint8_t)f;
     }
-    if (any) s_any_ini = 1; // benign race: all writers store 1
+    const int need = __ballot(any) != 0ull ? 2 : 1;
     __syncthreads();
-    const int need = s_any_ini ? 2 : 1;
-    const int wave = tid >> 6, lane = tid & 63;
+    // ---- E: ordered emission ----
     uint32_t *oxy = buf.cell_xy + ((size_t)img * cfg.cells_total + cell) * cfg.cell_cap;
     uint8_t *osc = buf.cell_sc + ((size_t)img * cfg.cells_total + cell) * cfg.cell_cap;
-    int base = 0;
-    for (int i0 = 0; i0 < npx; i0 += 256) {
-        const int i = i0 + tid;
-        const bool pred = (i < npx) && (s_fl[i] >= need);
+    int run = 0;
+    for (int q0 = 0; q0 < n2; q0 += 64) {
+        const int q = q0 + lane;
+        const bool pred = q < n2 && s_qf[q] >= need;
         const unsigned long long m = __ballot(pred);
-        if (lane == 0) s_wcnt[wave] = __popcll(m);
-        __syncthreads();
-        int off = base;
-        for (int w2 = 0; w2 < wave; w2++) off += s_wcnt[w2];
-        const int tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
         if (pred) {
-            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            const int pos = run + __popcll(m & lt);
             if (pos < cfg.cell_cap) {
-                const int r = i / iw, c = i % iw;
+                const unsigned rc = s_q2[q];
+                const int r = rc >> 8, c = rc & 255;
                 // cell-local FAST coords (c+3, r+3) + (j*wCell, i*hCell): src/ORBextractor.cc:816-817
                 const unsigned x = (unsigned)(c + 3 + ci_j * L.w_cell);
                 const unsigned y = (unsigned)(r + 3 + ci_i * L.h_cell);
@@ -403,10 +466,9 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
                 osc[pos] = s_sc[(r + 1) * scp + c + 1];
             }
         }
-        base += tot;
-        __syncthreads();
+        run += __popcll(m);
     }
-    if (tid == 0) *cnt_out = base < cfg.cell_cap ? base : cfg.cell_cap;
+    if (lane == 0) *cnt_out = run < cfg.cell_cap ? run : cfg.cell_cap;
 }
 
 // ---------------------------------------------------------------------------
@@ -750,16 +812,18 @@ __global__ __launch_bounds__(256) void describe_kernel(DeviceConfig cfg, DeviceB
     const uint8_t *blr = buf.blur + (size_t)img * cfg.pyr_bytes + L.pyr_off;
 
     // IC_Angle (src/ORBextractor.cc:72-99): integer moments over the circular patch
-    const int hp = cfg.half_patch;
+    // The (u,v) offsets of the circular patch come from a host-built table (padded with (0,0), which
+    // contributes nothing), so a lane issues all of its ~12 pixel loads back to back instead of
+    // walking 31 dependent rows.
     int m10 = 0, m01 = 0;
-    for (int v = -hp; v <= hp; ++v) {
-        const int d = cfg.umax[v < 0 ? -v : v];
-        const uint8_t *row = raw + (size_t)(cy + v) * L.pitch + cx;
-        for (int u = -d + lane; u <= d; u += 64) {
-            const int I = row[u];
-            m10 += u * I;
-            m01 += v * I;
-        }
+    const uint8_t *pc = raw + (size_t)cy * L.pitch + cx;
+#pragma unroll 4
+    for (int k = lane; k < cfg.patch_n; k += 64) {
+        const int uv = buf.patch_uv[k];
+        const int u = (int)(int8_t)(uv & 0xff), v = (int)(int8_t)((uv >> 8) & 0xff);
+        const int I = pc[v * L.pitch + u];
+        m10 += u * I;
+        m01 += v * I;
     }
     m10 = wave_sum_i32(m10);
     m01 = wave_sum_i32(m01);
@@ -802,7 +866,43 @@ __global__ __launch_bounds__(256) void describe_kernel(DeviceConfig cfg, DeviceB
 // ---------------------------------------------------------------------------
 // stereo: one wave per left keypoint (coarse Hamming band search + SAD + parabola)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, DeviceBuffers buf)
+// Row table of Frame::ComputeStereoMatches (src/Frame.cc:474-491): right keypoint iR is listed in
+// rows floor(y - r) .. ceil(y + r), r = 2 * scale[octave].  One workgroup per pair; LDS row counters.
+__global__ __launch_bounds__(256) void stereo_rowtable_kernel(DeviceConfig cfg, DeviceBuffers buf)
+{
+    extern __shared__ int s_rows[]; // [height + 1]
+    __shared__ int s_scan[256];
+    const int pair = blockIdx.x, imgR = 2 * pair + 1, tid = threadIdx.x;
+    const int nR = buf.kp_cnt[imgR], h = cfg.height;
+    const KeyPointPOD *kR = (const KeyPointPOD *)buf.kps + (size_t)imgR * cfg.sel_total;
+    int *roff = buf.row_off + (size_t)pair * (h + 1);
+    uint16_t *ridx = buf.row_idx + (size_t)pair * cfg.row_idx_cap;
+    for (int i = tid; i <= h; i += 256) s_rows[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < nR; i += 256) {
+        const float y = kR[i].y;
+        const float r = __fmul_rn(2.0f, cfg.lv[kR[i].octave].scale);
+        int maxr = (int)ceilf(__fadd_rn(y, r)), minr = (int)floorf(__fsub_rn(y, r));
+        minr = minr < 0 ? 0 : minr; maxr = maxr > h - 1 ? h - 1 : maxr;
+        for (int yy = minr; yy <= maxr; yy++) atomicAdd(&s_rows[yy], 1);
+    }
+    __syncthreads();
+    block_excl_scan(s_rows, s_rows, h + 1, s_scan);
+    for (int i = tid; i <= h; i += 256) roff[i] = s_rows[i];
+    __syncthreads();
+    for (int i = tid; i < nR; i += 256) {
+        const float y = kR[i].y;
+        const float r = __fmul_rn(2.0f, cfg.lv[kR[i].octave].scale);
+        int maxr = (int)ceilf(__fadd_rn(y, r)), minr = (int)floorf(__fsub_rn(y, r));
+        minr = minr < 0 ? 0 : minr; maxr = maxr > h - 1 ? h - 1 : maxr;
+        for (int yy = minr; yy <= maxr; yy++) {
+            const int pos = atomicAdd(&s_rows[yy], 1);
+            if (pos < cfg.row_idx_cap) ridx[pos] = (uint16_t)i;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, DeviceBuffers buf, int use_table)
 {
     const int pair = blockIdx.y;
     const int imgL = 2 * pair, imgR = 2 * pair + 1;
@@ -834,21 +934,46 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, Dev
         for (int i = 0; i < 8; i++) dl[i] = p[i];
     }
     unsigned best = 100u << 16; // TH_HIGH
-    for (int i0 = 0; i0 < nR; i0 += 64) {
-        const int iR = i0 + lane;
-        if (iR < nR) {
-            const KeyPointPOD kr = kR[iR];
-            const float r = __fmul_rn(2.0f, cfg.lv[kr.octave].scale);
-            const int maxr = (int)ceilf(__fadd_rn(kr.y, r));
-            const int minr = (int)floorf(__fsub_rn(kr.y, r));
-            if (row >= minr && row <= maxr && kr.octave >= level_l - 1 && kr.octave <= level_l + 1 &&
-                kr.x >= min_u && kr.x <= max_u) {
-                const uint32_t *p = (const uint32_t *)(dR + (size_t)iR * 32);
-                uint32_t dr[8];
+    if (use_table) {
+        // candidates = right keypoints whose row band covers int(vL) (vRowIndices[vL], src/Frame.cc:513);
+        // the arg-min key (dist << 16 | iR) makes the result independent of the order inside a row list
+        const int *roff = buf.row_off + (size_t)pair * (cfg.height + 1);
+        const uint16_t *ridx = buf.row_idx + (size_t)pair * cfg.row_idx_cap;
+        int beg = 0, end = 0;
+        if (row >= 0 && row < cfg.height) { beg = roff[row]; end = roff[row + 1]; }
+        for (int j0 = beg; j0 < end; j0 += 64) {
+            const int j = j0 + lane;
+            if (j < end) {
+                const int iR = ridx[j];
+                const int oct = kR[iR].octave;
+                const float xr = kR[iR].x;
+                if (oct >= level_l - 1 && oct <= level_l + 1 && xr >= min_u && xr <= max_u) {
+                    const uint32_t *p = (const uint32_t *)(dR + (size_t)iR * 32);
+                    uint32_t dr[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) dr[i] = p[i];
-                const unsigned key = ((unsigned)hamming256(dl, dr) << 16) | (unsigned)iR;
-                best = key < best ? key : best;
+                    for (int i = 0; i < 8; i++) dr[i] = p[i];
+                    const unsigned key = ((unsigned)hamming256(dl, dr) << 16) | (unsigned)iR;
+                    best = key < best ? key : best;
+                }
+            }
+        }
+    } else {
+        for (int i0 = 0; i0 < nR; i0 += 64) {
+            const int iR = i0 + lane;
+            if (iR < nR) {
+                const KeyPointPOD kr = kR[iR];
+                const float r = __fmul_rn(2.0f, cfg.lv[kr.octave].scale);
+                const int maxr = (int)ceilf(__fadd_rn(kr.y, r));
+                const int minr = (int)floorf(__fsub_rn(kr.y, r));
+                if (row >= minr && row <= maxr && kr.octave >= level_l - 1 && kr.octave <= level_l + 1 &&
+                    kr.x >= min_u && kr.x <= max_u) {
+                    const uint32_t *p = (const uint32_t *)(dR + (size_t)iR * 32);
+                    uint32_t dr[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) dr[i] = p[i];
+                    const unsigned key = ((unsigned)hamming256(dl, dr) << 16) | (unsigned)iR;
+                    best = key < best ? key : best;
+                }
             }
         }
     }
@@ -1035,14 +1160,15 @@ void orbfe_launch_blur(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_
 void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
 {
     const int mw = max_cell_w(cfg), mh = max_cell_h(cfg);
-    const int tile_pitch = (mw + 6 + 3) & ~3;
+    const int tile_pitch = (mw + 6 + 3 + 3 + 3) & ~3; // + alignment slack on both sides
     const int tile_rows = mh + 6;
-    const int sc_bytes = ((mw + 2) * (mh + 2) + 15) & ~15;
-    const int fl_bytes = (mw * mh + 15) & ~15;
     const int tile_bytes = (tile_pitch * tile_rows + 15) & ~15;
-    const size_t lds = (size_t)tile_bytes + sc_bytes + fl_bytes;
+    const int sc_bytes = ((mw + 2) * (mh + 2) + 15) & ~15;
+    const int q_bytes = (2 * mw * mh + 15) & ~15;
+    const int qf_bytes = (mw * mh + 15) & ~15;
+    const size_t lds = (size_t)tile_bytes + sc_bytes + 2 * q_bytes + qf_bytes;
     dim3 grid(cfg.cells_total, n_images);
-    hipLaunchKernelGGL(fast_cell_kernel, grid, dim3(256), lds, s, cfg, buf, tile_pitch, tile_bytes, sc_bytes);
+    hipLaunchKernelGGL(fast_cell_kernel, grid, dim3(64), lds, s, cfg, buf, tile_pitch, tile_bytes, sc_bytes, q_bytes);
 }
 
 static inline int ot_sort_cap(const DeviceConfig &cfg) { int p = 1; while (p < cfg.max_nodes) p <<= 1; return p; }
@@ -1068,8 +1194,12 @@ void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, in
 
 void orbfe_launch_stereo_match(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s)
 {
+    // the LDS row table needs (height + 1) counters; taller images use the brute-force band scan
+    const int use_table = (size_t)(cfg.height + 1) * sizeof(int) <= 48 * 1024 ? 1 : 0;
+    if (use_table)
+        hipLaunchKernelGGL(stereo_rowtable_kernel, dim3(n_pairs), dim3(256), (cfg.height + 1) * sizeof(int), s, cfg, buf);
     dim3 grid((cfg.sel_total + 3) / 4, n_pairs);
-    hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(256), 0, s, cfg, buf);
+    hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(256), 0, s, cfg, buf, use_table);
 }
 
 void orbfe_launch_stereo_median(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s)

@@ -1,0 +1,11 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --pmc csv run: mean counter value per kernel name."""
+import csv, glob, sys, collections
+d = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = row.get("Kernel_Name", "")[:40]
+        acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for k in sorted(acc):
+    print(k, {c: round(sum(v) / len(v), 1) for c, v in sorted(acc[k].items())}, "n=%d" % len(next(iter(acc[k].values()))))
