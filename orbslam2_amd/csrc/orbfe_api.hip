@@ -29,6 +29,10 @@ struct orbfe_context {
     uint8_t *d_ham = nullptr;     // scratch for orbfe_hamming_matrix
     size_t d_ham_bytes = 0;
     int last_images = 0;
+    bool use_octree2 = false; // point-parallel quadtree (all levels have <= 4 roots and the LDS budget fits)
+    int ot2_sort_cap = 0;
+    int ot2_lds_pts = 0;      // candidates per level the quadtree keeps in LDS
+    size_t ot2_lds = 0;
     // stage timing: ring of PROF_RING calls x (ORBFE_NUM_STAGES + 1) events
     bool profiling = false;
     bool in_stereo = false;
@@ -228,7 +232,24 @@ static int build_config(orbfe_context *ctx)
     c.max_nodes = max_nodes;
     if (p.width > 32767 || p.height > 32767) return fail(ctx, ORBFE_ERR_UNSUPPORTED, "image larger than 32767 px");
     if (c.sel_total > 65535) return fail(ctx, ORBFE_ERR_UNSUPPORTED, "nfeatures too large (keypoint capacity %d > 65535)", c.sel_total);
-    if (orbfe_octree_lds_bytes(c) > 64 * 1024) return fail(ctx, ORBFE_ERR_UNSUPPORTED, "nfeatures too large for the quadtree LDS budget");
+    {
+        int sc = 1;
+        while (sc < c.max_nodes) sc <<= 1;
+        bool roots_ok = true;
+        for (int l = 0; l < p.nlevels; l++) roots_ok = roots_ok && c.lv[l].n_ini <= 4;
+        int max_cand = 0;
+        for (int l = 0; l < p.nlevels; l++) { roots_ok = roots_ok && c.lv[l].cand_cap <= (1 << 20); max_cand = c.lv[l].cand_cap > max_cand ? c.lv[l].cand_cap : max_cand; }
+        ctx->ot2_sort_cap = sc;
+        // LDS-resident point arrays for levels of up to 8192 candidates (9 B each) if the budget allows
+        int pts = max_cand < 8192 ? ((max_cand + 63) & ~63) : 8192;
+        while (pts > 0 && orbfe_octree2_lds_bytes(c.max_nodes, sc, pts) > 150 * 1024) pts -= 1024;
+        if (pts < 0) pts = 0;
+        ctx->ot2_lds_pts = pts;
+        ctx->ot2_lds = orbfe_octree2_lds_bytes(c.max_nodes, sc, pts);
+        ctx->use_octree2 = roots_ok && c.max_nodes <= 4096 && ctx->ot2_lds <= 150 * 1024;
+        if (!ctx->use_octree2 && orbfe_octree_lds_bytes(c) > 64 * 1024)
+            return fail(ctx, ORBFE_ERR_UNSUPPORTED, "nfeatures too large for the quadtree LDS budget");
+    }
     return ORBFE_OK;
 }
 
@@ -255,6 +276,7 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
     // edge threshold must cover the descriptor reach (pattern radius 18.4 + rounding) and the patch
     if (hipSetDevice(p.device) != hipSuccess) { delete ctx; return fail(nullptr, ORBFE_ERR_NO_DEVICE, "hipSetDevice failed"); }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return fail(nullptr, ORBFE_ERR_NO_DEVICE, "hipStreamCreate failed"); }
+    if (ctx->use_octree2 && orbfe_octree2_prepare(ctx->ot2_lds) != 0) ctx->use_octree2 = false;
     const DeviceConfig &c = ctx->cfg;
     const size_t B = (size_t)p.max_images;
     DeviceBuffers &b = ctx->buf;
@@ -268,6 +290,9 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
     A(b.cell_base, B * c.cells_total);
     A(b.cand_xy, B * c.cand_total);
     A(b.cand_sc, B * c.cand_total);
+    A(b.cand_sc2, B * c.cand_total);
+    A(b.ot_xy2, B * c.cand_total);
+    A(b.ot_sc3, B * c.cand_total);
     A(b.idx0, B * c.cand_total);
     A(b.idx1, B * c.cand_total);
     A(b.lvl_ncand, B * c.nlevels);
@@ -419,7 +444,8 @@ extern "C" int orbfe_enqueue_extract(orbfe_context *ctx, const uint8_t *d_images
     prof_mark(ctx, 3, s);
     orbfe_launch_fast(ctx->cfg, ctx->buf, n_images, s);
     prof_mark(ctx, 4, s);
-    orbfe_launch_octree(ctx->cfg, ctx->buf, n_images, s);
+    if (ctx->use_octree2) orbfe_launch_octree2(ctx->cfg, ctx->buf, n_images, ctx->ot2_sort_cap, ctx->ot2_lds_pts, ctx->ot2_lds, s);
+    else orbfe_launch_octree_generic(ctx->cfg, ctx->buf, n_images, s);
     prof_mark(ctx, 5, s);
     orbfe_launch_describe(ctx->cfg, ctx->buf, n_images, s);
     prof_mark(ctx, 6, s);

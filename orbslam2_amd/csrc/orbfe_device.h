@@ -58,6 +58,9 @@ struct DeviceBuffers {
     int *cell_base;      // [img][cells_total] scratch (exclusive scan)
     uint32_t *cand_xy;   // [img][cand_total]
     uint8_t *cand_sc;    // [img][cand_total]
+    uint8_t *cand_sc2;   // [img][cand_total] quadtree ping-pong (with idx0)
+    uint32_t *ot_xy2;    // [img][cand_total] quadtree ping-pong partner
+    uint8_t *ot_sc3;     // [img][cand_total]
     uint32_t *idx0, *idx1; // [img][cand_total] ping-pong permutation
     int *lvl_ncand;      // [img][nlevels]
     int *sel_cnt;        // [img][nlevels]
@@ -87,7 +90,10 @@ void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, cons
 void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
 void orbfe_launch_blur(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
 void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
-void orbfe_launch_octree(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
+void orbfe_launch_octree_generic(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
+void orbfe_launch_octree2(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, int lds_pts, size_t lds, hipStream_t s);
+size_t orbfe_octree2_lds_bytes(int max_nodes, int sort_cap, int lds_pts);
+int orbfe_octree2_prepare(size_t lds);
 void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
 void orbfe_launch_stereo_match(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s);
 void orbfe_launch_stereo_median(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s);

@@ -472,7 +472,7 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
 }
 
 // ---------------------------------------------------------------------------
-// DistributeOctTree: one workgroup per (image, level)
+// DistributeOctTree, generic node-parallel kernel (any n_ini; fallback of orbfe_octree.hip): one workgroup per (image, level)
 // ---------------------------------------------------------------------------
 // Array formulation validated on the CPU by tests/octree_model.py:
 //  * nodes live in an array kept in std::list order (front -> back);
@@ -500,7 +500,7 @@ __device__ __forceinline__ void ot_bind(OtNodes &n, uint8_t *&p, int cap)
     n.bf = p; p += ((cap + 7) / 8) * 8;
 }
 
-__global__ __launch_bounds__(OT_THREADS) void octree_kernel(DeviceConfig cfg, DeviceBuffers buf, int sort_cap)
+__global__ __launch_bounds__(OT_THREADS) void octree_generic_kernel(DeviceConfig cfg, DeviceBuffers buf, int sort_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     __shared__ int s_scan[OT_THREADS];
@@ -1180,10 +1180,10 @@ size_t orbfe_octree_lds_bytes(const DeviceConfig &cfg)
     return sizeof(unsigned long long) * ot_sort_cap(cfg) + 2 * node + sizeof(int) * 4 * cap + 4 * sizeof(int) * cap;
 }
 
-void orbfe_launch_octree(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
+void orbfe_launch_octree_generic(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
 {
     dim3 grid(cfg.nlevels, n_images);
-    hipLaunchKernelGGL(octree_kernel, grid, dim3(OT_THREADS), orbfe_octree_lds_bytes(cfg), s, cfg, buf, ot_sort_cap(cfg));
+    hipLaunchKernelGGL(octree_generic_kernel, grid, dim3(OT_THREADS), orbfe_octree_lds_bytes(cfg), s, cfg, buf, ot_sort_cap(cfg));
 }
 
 void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
