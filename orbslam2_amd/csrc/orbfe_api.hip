@@ -315,6 +315,52 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
         A(b.row_off, pairs * (size_t)(p.height + 1));
         A(b.row_idx, pairs * (size_t)ctx->cfg.row_idx_cap);
     }
+    {   // cv::resize tables (resize.cpp: xofs/ialpha, yofs/ibeta) over the margin-extended domain of each level
+        std::vector<uint32_t> tab;
+        auto reflect = [](int q, int len) { if (len == 1) return 0; while (q < 0 || q >= len) q = q < 0 ? -q : 2 * len - 2 - q; return q; };
+        for (int l = 1; l < p.nlevels; l++) {
+            LevelInfo &D = ctx->cfg.lv[l];
+            const LevelInfo &S = ctx->cfg.lv[l - 1];
+            const int nx = (D.w + 12 + 3) & ~3, ny = D.h + 6;
+            while (tab.size() % 4) tab.push_back(0);
+            D.rs_xtab_off = (int)tab.size(); D.rs_xtab_n = nx;
+            tab.resize(tab.size() + 2 * (size_t)nx, 0);
+            for (int i = 0; i < nx; i++) {
+                const int dx = reflect(i - 4, D.w);
+                float fx = (float)(((double)dx + 0.5) * D.rs_scale_x - 0.5);
+                int sx = (int)floorf(fx);
+                fx -= (float)sx;
+                if (sx < 0) { fx = 0.f; sx = 0; }
+                if (sx >= S.w - 1) { fx = 0.f; sx = S.w - 1; }
+                const int a0 = (int)lrintf((1.f - fx) * 2048.f), a1 = (int)lrintf(fx * 2048.f);
+                const int sx1 = sx + 1 < S.w ? sx + 1 : S.w - 1;
+                tab[D.rs_xtab_off + i] = (uint32_t)sx | ((uint32_t)sx1 << 16);
+                tab[D.rs_xtab_off + nx + i] = (uint32_t)a0 | ((uint32_t)a1 << 16);
+            }
+            D.rs_ytab_off = (int)tab.size(); D.rs_ytab_n = ny;
+            tab.resize(tab.size() + 2 * (size_t)ny, 0);
+            for (int i = 0; i < ny; i++) {
+                const int dy = reflect(i - 3, D.h);
+                float fy = (float)(((double)dy + 0.5) * D.rs_scale_y - 0.5);
+                int sy = (int)floorf(fy);
+                fy -= (float)sy;
+                const int b0 = (int)lrintf((1.f - fy) * 2048.f), b1 = (int)lrintf(fy * 2048.f);
+                const int sy0 = sy < 0 ? 0 : (sy > S.h - 1 ? S.h - 1 : sy);
+                const int sy1 = sy + 1 < 0 ? 0 : (sy + 1 > S.h - 1 ? S.h - 1 : sy + 1);
+                tab[D.rs_ytab_off + i] = (uint32_t)sy0 | ((uint32_t)sy1 << 16);
+                tab[D.rs_ytab_off + ny + i] = (uint32_t)b0 | ((uint32_t)b1 << 16);
+            }
+        }
+        while (tab.size() % 4) tab.push_back(0);
+        if (tab.empty()) tab.resize(4, 0);
+        uint32_t *d_tab = nullptr;
+        A(d_tab, tab.size());
+        if (hipMemcpy(d_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            orbfe_destroy(ctx);
+            return fail(nullptr, ORBFE_ERR_HIP, "resize table upload failed");
+        }
+        b.rs_tab = d_tab;
+    }
     {   // circular patch of IC_Angle (src/ORBextractor.cc:79-96): |v| <= hp, |u| <= umax[|v|]
         std::vector<int16_t> uv;
         const int hp = p.half_patch_size;

@@ -25,6 +25,8 @@ struct LevelInfo {
     int scaled_patch;      // int(patchSize * scale)
     float scale, inv_scale;
     double rs_scale_x, rs_scale_y; // cv::resize scale from level-1 (1/(dw/sw))
+    int rs_xtab_off, rs_xtab_n;    // resize column table (two planes of rs_xtab_n words) in DeviceBuffers::rs_tab
+    int rs_ytab_off, rs_ytab_n;    // resize row table
 };
 
 struct DeviceConfig {
@@ -75,6 +77,7 @@ struct DeviceBuffers {
     int *status;         // [img] non-zero = device-side capacity problem
     int *row_off;        // [pair][height+1] stereo row table offsets
     uint16_t *row_idx;   // [pair][row_idx_cap] right-keypoint indices per row
+    const uint32_t *rs_tab; // cv::resize offset/weight tables of every level (see pyr_resize_kernel)
     const int16_t *patch_uv; // IC_Angle patch offsets: (u & 0xff) | (v << 8), padded with (0,0)
 };
 

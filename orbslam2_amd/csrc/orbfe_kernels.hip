@@ -176,48 +176,41 @@ __global__ __launch_bounds__(256) void ingest_kernel(DeviceConfig cfg, DeviceBuf
 }
 
 // pyramid: level l from level l-1 (cv::resize INTER_LINEAR, 8UC1 fixed point); one thread = 4 px
-// of the extended (margin-included) domain of level l.
+// of the extended (margin-included) domain of level l.  The per-column / per-row source offsets and
+// 11-bit weights (cv::resize's xofs/ialpha, yofs/ibeta tables) are built once per context on the
+// host with exactly the arithmetic of resize.cpp and read here as packed words:
+//   X0 = sx | sx1 << 16, X1 = a0 | a1 << 16 (per extended column), Y0 = sy0 | sy1 << 16, Y1 = b0 | b1 << 16.
 __global__ __launch_bounds__(256) void pyr_resize_kernel(DeviceConfig cfg, DeviceBuffers buf, int level)
 {
     const int img = blockIdx.z;
     const LevelInfo &D = cfg.lv[level];
     const LevelInfo &S = cfg.lv[level - 1];
-    const int x0 = (int)(blockIdx.x * 64 + threadIdx.x) * 4 - PYR_MX;
-    const int ye = (int)(blockIdx.y * 4 + threadIdx.y) - PYR_MY;
-    if (x0 >= D.w + 8 || ye >= D.h + PYR_MY) return;
+    const int xi = (int)(blockIdx.x * 64 + threadIdx.x) * 4; // index into the extended column table
+    const int yi = (int)(blockIdx.y * 4 + threadIdx.y);
+    if (xi >= D.w + 12 || yi >= D.h + 2 * PYR_MY) return;
     const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + S.pyr_off;
     uint8_t *dst = buf.pyr + (size_t)img * cfg.pyr_bytes + D.pyr_off;
-
-    const int dy = reflect101(ye, D.h);
-    float fy = (float)__dsub_rn(__dmul_rn(__dadd_rn((double)dy, 0.5), D.rs_scale_y), 0.5);
-    int sy = (int)floorf(fy);
-    fy = __fsub_rn(fy, (float)sy);
-    const int b0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fy), 2048.f));
-    const int b1 = (int)rintf(__fmul_rn(fy, 2048.f));
-    const int sy0 = sy < 0 ? 0 : (sy > S.h - 1 ? S.h - 1 : sy);
-    const int sy1 = sy + 1 < 0 ? 0 : (sy + 1 > S.h - 1 ? S.h - 1 : sy + 1);
-    const uint8_t *r0 = src + (size_t)sy0 * S.pitch;
-    const uint8_t *r1 = src + (size_t)sy1 * S.pitch;
-
+    const uint32_t *xt = buf.rs_tab + D.rs_xtab_off;
+    const uint32_t *yt = buf.rs_tab + D.rs_ytab_off;
+    const uint4 X0 = *(const uint4 *)(xt + xi);
+    const uint4 X1 = *(const uint4 *)(xt + D.rs_xtab_n + xi);
+    const uint32_t Y0 = yt[yi], Y1 = yt[D.rs_ytab_n + yi];
+    const int b0 = (int)(Y1 & 0xffffu), b1 = (int)(Y1 >> 16);
+    const uint8_t *r0 = src + (size_t)(Y0 & 0xffffu) * S.pitch;
+    const uint8_t *r1 = src + (size_t)(Y0 >> 16) * S.pitch;
+    const uint32_t x0v[4] = {X0.x, X0.y, X0.z, X0.w}, x1v[4] = {X1.x, X1.y, X1.z, X1.w};
     uint32_t out = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int dx = reflect101(x0 + j, D.w);
-        float fx = (float)__dsub_rn(__dmul_rn(__dadd_rn((double)dx, 0.5), D.rs_scale_x), 0.5);
-        int sx = (int)floorf(fx);
-        fx = __fsub_rn(fx, (float)sx);
-        if (sx < 0) { fx = 0.f; sx = 0; }
-        if (sx >= S.w - 1) { fx = 0.f; sx = S.w - 1; }
-        const int a0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fx), 2048.f));
-        const int a1 = (int)rintf(__fmul_rn(fx, 2048.f));
-        const int sx1 = sx + 1 < S.w ? sx + 1 : S.w - 1;
+        const int sx = (int)(x0v[j] & 0xffffu), sx1 = (int)(x0v[j] >> 16);
+        const int a0 = (int)(x1v[j] & 0xffffu), a1 = (int)(x1v[j] >> 16);
         const int h0 = r0[sx] * a0 + r0[sx1] * a1;
         const int h1 = r1[sx] * a0 + r1[sx1] * a1;
         int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
         v = v < 0 ? 0 : (v > 255 ? 255 : v);
         out |= (uint32_t)v << (8 * j);
     }
-    *(uint32_t *)(dst + (ptrdiff_t)ye * D.pitch + x0) = out;
+    *(uint32_t *)(dst + (ptrdiff_t)(yi - PYR_MY) * D.pitch + (xi - PYR_MX)) = out;
 }
 
 // ---------------------------------------------------------------------------
@@ -360,12 +353,14 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
         if (lane == 0) *cnt_out = 0;
         return;
     }
-    // LDS layout (sizes fixed by the host from the largest cell): tile | scores | queue1 | queue2 | flags
+    // LDS layout (sizes fixed by the host from the largest cell): tile | scores | queue.  Queue 2 is
+    // compacted in place over queue 1 (writes never pass the read cursor); the per-entry flags of
+    // phase D reuse the tile, which is dead after phase C.  4.7 KB per wave keeps 32 waves per CU.
     uint8_t *s_tile = s_mem;                           // [th][tile_pitch], column 0 = pixel xa (4-aligned)
     uint8_t *s_sc = s_mem + tile_bytes;                // [(ih+2)][(iw+2)], zero border
     uint16_t *s_q1 = (uint16_t *)(s_sc + sc_bytes);    // packed (r << 8 | c), row-major ascending
-    uint16_t *s_q2 = (uint16_t *)((uint8_t *)s_q1 + q_bytes);
-    uint8_t *s_qf = (uint8_t *)s_q2 + q_bytes;         // per queue-2 entry: 0 / 1 (local max, >= minTh) / 2 (>= iniTh)
+    uint16_t *s_q2 = s_q1;
+    uint8_t *s_qf = s_tile;                            // per queue-2 entry: 0 / 1 (local max, >= minTh) / 2 (>= iniTh)
     const int scp = iw + 2;
     const int npx = iw * ih;
     const float rcp_iw = 1.0f / (float)iw;
@@ -383,20 +378,22 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
     const int t = cfg.min_th;
     // ---- A: cardinal test ----
     int n1 = 0;
-    for (int i0 = 0; i0 < npx; i0 += 64) {
-        const int i = i0 + lane;
-        bool pass = false;
-        int r = 0, c = 0;
-        if (i < npx) {
-            r = (int)(((float)i + 0.5f) * rcp_iw); c = i - r * iw;
-            const uint8_t *p = &s_tile[(r + 3) * tile_pitch + c + 3 + ox];
+    {
+        int r = (int)(((float)lane + 0.5f) * rcp_iw), c = lane - r * iw; // (r, c) of pixel i = lane, advanced by 64 per step
+        const int dr = 64 / iw, dc = 64 - dr * iw;
+        for (int i0 = 0; i0 < npx; i0 += 64) {
+            const bool in = i0 + lane < npx;
+            const uint8_t *p = &s_tile[__mul24(in ? r + 3 : 3, tile_pitch) + (in ? c : 0) + 3 + ox];
             const int v = p[0];
             const int d0 = v - p[3 * tile_pitch], d8 = v - p[-3 * tile_pitch], d4 = v - p[3], d12 = v - p[-3];
-            pass = ((d0 > t || d8 > t) && (d4 > t || d12 > t)) || ((d0 < -t || d8 < -t) && (d4 < -t || d12 < -t));
+            const int passi = (int)in & ((((int)(max(d0, d8) > t)) & ((int)(max(d4, d12) > t))) | (((int)(min(d0, d8) < -t)) & ((int)(min(d4, d12) < -t))));
+            const bool pass = passi != 0;
+            const unsigned long long m = __ballot(pass);
+            if (pass) s_q1[n1 + __popcll(m & lt)] = (uint16_t)((r << 8) | c);
+            n1 += __popcll(m);
+            c += dc; r += dr;
+            if (c >= iw) { c -= iw; r++; }
         }
-        const unsigned long long m = __ballot(pass);
-        if (pass) s_q1[n1 + __popcll(m & lt)] = (uint16_t)((r << 8) | c);
-        n1 += __popcll(m);
     }
     __syncthreads();
     // ---- B: 8 opposite pairs: a dark (bright) 9-arc needs one darker (brighter) pixel in every pair ----
@@ -415,7 +412,7 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
                 lo = min(lo, max(d[k], d[k + 8])); // dark: every pair has a member with d > t
                 hi = max(hi, min(d[k], d[k + 8])); // bright: every pair has a member with d < -t
             }
-            pass = lo > t || hi < -t;
+            pass = ((int)(lo > t) | (int)(hi < -t)) != 0;
         }
         const unsigned long long m = __ballot(pass);
         if (pass) s_q2[n2 + __popcll(m & lt)] = (uint16_t)rc;
@@ -446,6 +443,7 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
     }
     const int need = __ballot(any) != 0ull ? 2 : 1;
     __syncthreads();
+    (void)q_bytes;
     // ---- E: ordered emission ----
     uint32_t *oxy = buf.cell_xy + ((size_t)img * cfg.cells_total + cell) * cfg.cell_cap;
     uint8_t *osc = buf.cell_sc + ((size_t)img * cfg.cells_total + cell) * cfg.cell_cap;
@@ -1050,11 +1048,13 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, Dev
     }
 }
 
-// median of the accepted SADs, then cut at 1.5*1.4*median (src/Frame.cc:628-641; Q2: skip when empty)
-__global__ __launch_bounds__(256) void stereo_median_kernel(DeviceConfig cfg, DeviceBuffers buf, int sort_cap)
+// Median of the accepted SADs, then cut at 1.5*1.4*median (src/Frame.cc:628-641; Q2: skip when empty).
+// The reference sorts (SAD, iL) pairs and reads element size/2; only its SAD matters, so the median is
+// found by a 3-level radix select (8 bits per level, LDS histograms) instead of a sort.
+__global__ __launch_bounds__(256) void stereo_median_kernel(DeviceConfig cfg, DeviceBuffers buf)
 {
-    extern __shared__ int s_sad[];
-    __shared__ int s_cnt;
+    __shared__ int s_hist[256];
+    __shared__ int s_sel[3]; // selected digit, rank inside the digit's bucket, count of valid entries
     const int pair = blockIdx.x;
     const int imgL = 2 * pair;
     const int tid = threadIdx.x;
@@ -1062,32 +1062,44 @@ __global__ __launch_bounds__(256) void stereo_median_kernel(DeviceConfig cfg, De
     float *u_right = buf.u_right + (size_t)imgL * cfg.sel_total;
     float *depth = buf.depth + (size_t)imgL * cfg.sel_total;
     const int *sad = buf.sad + (size_t)imgL * cfg.sel_total;
-    if (tid == 0) s_cnt = 0;
-    for (int i = tid; i < sort_cap; i += 256) s_sad[i] = 0x7fffffff;
-    __syncthreads();
-    for (int i = tid; i < nL; i += 256)
-        if (sad[i] >= 0) s_sad[atomicAdd(&s_cnt, 1)] = sad[i];
-    __syncthreads();
-    const int m = s_cnt;
-    if (m == 0) return;
-    for (int k = 2; k <= sort_cap; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < sort_cap; i += 256) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const int a = s_sad[i], b = s_sad[ixj];
-                    const bool up = ((i & k) == 0);
-                    if ((a > b) == up) { s_sad[i] = b; s_sad[ixj] = a; }
-                }
-            }
-            __syncthreads();
+    unsigned prefix = 0, mask = 0;
+    int rank = 0;
+    for (int shift = 16; shift >= 0; shift -= 8) { // SAD < 2^24 (121 px * 510)
+        s_hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < nL; i += 256) {
+            const int v = sad[i];
+            if (v >= 0 && ((unsigned)v & mask) == prefix) atomicAdd(&s_hist[((unsigned)v >> shift) & 255u], 1);
         }
+        __syncthreads();
+        if (tid == 0) {
+            if (shift == 16) {
+                int m = 0;
+                for (int d = 0; d < 256; d++) m += s_hist[d];
+                s_sel[2] = m;
+                rank = m / 2; // vDistIdx[size/2] in ascending order
+            } else {
+                rank = s_sel[1];
+            }
+            int d = 0;
+            for (; d < 255; d++) {
+                if (rank < s_hist[d]) break;
+                rank -= s_hist[d];
+            }
+            s_sel[0] = d;
+            s_sel[1] = rank;
+        }
+        __syncthreads();
+        if (s_sel[2] == 0) return;
+        prefix |= (unsigned)s_sel[0] << shift;
+        mask |= 255u << shift;
+        __syncthreads();
     }
-    const float median = (float)s_sad[m / 2];
+    const float median = (float)(int)prefix;
     const float th_dist = __fmul_rn(__fmul_rn(1.5f, 1.4f), median);
     for (int i = tid; i < nL; i += 256) {
-        const int s = sad[i];
-        if (s >= 0 && !((float)s < th_dist)) { u_right[i] = -1.0f; depth[i] = -1.0f; }
+        const int v = sad[i];
+        if (v >= 0 && !((float)v < th_dist)) { u_right[i] = -1.0f; depth[i] = -1.0f; }
     }
 }
 
@@ -1165,8 +1177,8 @@ void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_
     const int tile_bytes = (tile_pitch * tile_rows + 15) & ~15;
     const int sc_bytes = ((mw + 2) * (mh + 2) + 15) & ~15;
     const int q_bytes = (2 * mw * mh + 15) & ~15;
-    const int qf_bytes = (mw * mh + 15) & ~15;
-    const size_t lds = (size_t)tile_bytes + sc_bytes + 2 * q_bytes + qf_bytes;
+    // flags alias the tile: it must hold one byte per interior pixel
+    const size_t lds = (size_t)(tile_bytes > mw * mh ? tile_bytes : ((mw * mh + 15) & ~15)) + sc_bytes + q_bytes;
     dim3 grid(cfg.cells_total, n_images);
     hipLaunchKernelGGL(fast_cell_kernel, grid, dim3(64), lds, s, cfg, buf, tile_pitch, tile_bytes, sc_bytes, q_bytes);
 }
@@ -1204,9 +1216,7 @@ void orbfe_launch_stereo_match(const DeviceConfig &cfg, const DeviceBuffers &buf
 
 void orbfe_launch_stereo_median(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s)
 {
-    int cap = 1;
-    while (cap < cfg.sel_total) cap <<= 1;
-    hipLaunchKernelGGL(stereo_median_kernel, dim3(n_pairs), dim3(256), sizeof(int) * cap, s, cfg, buf, cap);
+    hipLaunchKernelGGL(stereo_median_kernel, dim3(n_pairs), dim3(256), 0, s, cfg, buf);
 }
 
 void orbfe_launch_rgbd(const DeviceConfig &cfg, const DeviceBuffers &buf, const float *d_depth, size_t depth_pitch_floats,

@@ -504,17 +504,27 @@ __global__ __launch_bounds__(OT2_THREADS) void octree2_kernel(DeviceConfig cfg, 
     if (nc > (1 << OT2_ID_BITS)) { nc = 1 << OT2_ID_BITS; if (tid == 0) buf.status[img] = 4; } // host routes such levels to the generic kernel
     if (tid == 0) buf.lvl_ncand[ib * cfg.nlevels + level] = nc;
     const bool ldsp = nc <= lds_pts && nc <= 16 * OT2_THREADS;
-    for (int c = tid; c < L.n_cells; c += OT2_THREADS) {
-        const int base = cell_base[c];
-        int cnt = cell_cnt[c];
-        if (base + cnt > nc) cnt = nc - base > 0 ? nc - base : 0;
-        const uint32_t *sx = cell_xy + (size_t)c * cfg.cell_cap;
-        const uint8_t *ss = cell_sc + (size_t)c * cfg.cell_cap;
-        for (int k = 0; k < cnt; k++) {
-            const uint32_t xy = sx[k];
-            const uint8_t sc = ss[k];
-            xy_a[base + k] = xy; sc_a[base + k] = sc; // emission-order copy (orbfe_fetch_candidates, generic path)
-            if (ldsp) { s_xy[base + k] = xy; s_sc[base + k] = sc; }
+    // position-parallel copy: the cell of position i is found by a binary search over the scanned cell
+    // offsets (staged in LDS when they fit), so the reads of one cell's slot are contiguous
+    {
+        int *s_cb = K.s_ct; // 4*OT2_THREADS ints, free until the first pass
+        const bool cb_lds = L.n_cells <= 4 * OT2_THREADS;
+        if (cb_lds)
+            for (int c = tid; c < L.n_cells; c += OT2_THREADS) s_cb[c] = cell_base[c];
+        __syncthreads();
+        const int *cb = cb_lds ? s_cb : cell_base;
+#pragma unroll 2
+        for (int i = tid; i < nc; i += OT2_THREADS) {
+            int lo = 0, hi = L.n_cells - 1; // last cell with cell_base <= i
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (cb[mid] <= i) lo = mid; else hi = mid - 1;
+            }
+            const int k = i - cb[lo];
+            const uint32_t xy = cell_xy[(size_t)lo * cfg.cell_cap + k];
+            const uint8_t sc = cell_sc[(size_t)lo * cfg.cell_cap + k];
+            xy_a[i] = xy; sc_a[i] = sc; // emission-order copy (orbfe_fetch_candidates, HBM path)
+            if (ldsp) { s_xy[i] = xy; s_sc[i] = sc; }
         }
     }
     __syncthreads();
