@@ -361,6 +361,18 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
         }
         b.rs_tab = d_tab;
     }
+    {   // keypoint slot -> level
+        std::vector<uint8_t> sl(c.sel_total);
+        for (int l = 0; l < p.nlevels; l++)
+            for (int k = 0; k < c.lv[l].sel_cap; k++) sl[c.lv[l].sel_off + k] = (uint8_t)l;
+        uint8_t *d_sl = nullptr;
+        A(d_sl, sl.size());
+        if (hipMemcpy(d_sl, sl.data(), sl.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            orbfe_destroy(ctx);
+            return fail(nullptr, ORBFE_ERR_HIP, "slot table upload failed");
+        }
+        b.slot_level = d_sl;
+    }
     {   // circular patch of IC_Angle (src/ORBextractor.cc:79-96): |v| <= hp, |u| <= umax[|v|]
         std::vector<int16_t> uv;
         const int hp = p.half_patch_size;

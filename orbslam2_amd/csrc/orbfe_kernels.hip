@@ -16,12 +16,14 @@
 //   rgbd_kernel         <- Frame::ComputeStereoFromRGBD        src/Frame.cc:645-666
 //   hamming_matrix_kernel <- ORBmatcher::DescriptorDistance    src/ORBmatcher.cc:1643-1659
 #include "orbfe_device.h"
+#include <cstdlib>
 
 #define OT_THREADS 512
+typedef short pk16 __attribute__((ext_vector_type(2))); // two int16 lanes in one VGPR (v_pk_* ops)
 #define PYR_MX 4
 #define PYR_MY 3
 
-__device__ const int8_t g_pattern[1024] = {
+__device__ __attribute__((aligned(16))) const int8_t g_pattern[1024] = {
 #include "orb_pattern_31.inc"
 };
 
@@ -180,37 +182,57 @@ __global__ __launch_bounds__(256) void ingest_kernel(DeviceConfig cfg, DeviceBuf
 // 11-bit weights (cv::resize's xofs/ialpha, yofs/ibeta tables) are built once per context on the
 // host with exactly the arithmetic of resize.cpp and read here as packed words:
 //   X0 = sx | sx1 << 16, X1 = a0 | a1 << 16 (per extended column), Y0 = sy0 | sy1 << 16, Y1 = b0 | b1 << 16.
-__global__ __launch_bounds__(256) void pyr_resize_kernel(DeviceConfig cfg, DeviceBuffers buf, int level)
+// A 256-thread workgroup produces RS_ROWS extended rows of level l at full (margin-included) width.
+// The two source rows each output row needs are staged in LDS with coalesced 32-bit loads (the rows
+// of a block overlap, so most of those loads hit L2), which turns the 16 scattered byte gathers per
+// 4 output pixels into LDS reads; margin columns / rows simply index reflected source positions.
+#define RS_ROWS 4
+__global__ __launch_bounds__(256) void pyr_resize_kernel(DeviceConfig cfg, DeviceBuffers buf, int level, int src_words)
 {
-    const int img = blockIdx.z;
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_src[]; // [RS_ROWS][2][src_words * 4]
+    const int img = blockIdx.y;
     const LevelInfo &D = cfg.lv[level];
     const LevelInfo &S = cfg.lv[level - 1];
-    const int xi = (int)(blockIdx.x * 64 + threadIdx.x) * 4; // index into the extended column table
-    const int yi = (int)(blockIdx.y * 4 + threadIdx.y);
-    if (xi >= D.w + 12 || yi >= D.h + 2 * PYR_MY) return;
+    const int tid = threadIdx.x;
+    const int y0 = blockIdx.x * RS_ROWS; // first extended row of this block
     const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + S.pyr_off;
     uint8_t *dst = buf.pyr + (size_t)img * cfg.pyr_bytes + D.pyr_off;
     const uint32_t *xt = buf.rs_tab + D.rs_xtab_off;
     const uint32_t *yt = buf.rs_tab + D.rs_ytab_off;
-    const uint4 X0 = *(const uint4 *)(xt + xi);
-    const uint4 X1 = *(const uint4 *)(xt + D.rs_xtab_n + xi);
-    const uint32_t Y0 = yt[yi], Y1 = yt[D.rs_ytab_n + yi];
-    const int b0 = (int)(Y1 & 0xffffu), b1 = (int)(Y1 >> 16);
-    const uint8_t *r0 = src + (size_t)(Y0 & 0xffffu) * S.pitch;
-    const uint8_t *r1 = src + (size_t)(Y0 >> 16) * S.pitch;
-    const uint32_t x0v[4] = {X0.x, X0.y, X0.z, X0.w}, x1v[4] = {X1.x, X1.y, X1.z, X1.w};
-    uint32_t out = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int sx = (int)(x0v[j] & 0xffffu), sx1 = (int)(x0v[j] >> 16);
-        const int a0 = (int)(x1v[j] & 0xffffu), a1 = (int)(x1v[j] >> 16);
-        const int h0 = r0[sx] * a0 + r0[sx1] * a1;
-        const int h1 = r1[sx] * a0 + r1[sx1] * a1;
-        int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-        v = v < 0 ? 0 : (v > 255 ? 255 : v);
-        out |= (uint32_t)v << (8 * j);
+    const int nrows = (D.h + 2 * PYR_MY - y0) < RS_ROWS ? (D.h + 2 * PYR_MY - y0) : RS_ROWS;
+    const int row_bytes = src_words * 4;
+    // stage source rows: slot (k, 0) = sy0 of output row k, slot (k, 1) = sy1
+    for (int i = tid; i < nrows * 2 * src_words; i += 256) {
+        const int slot = i / src_words, c = i - slot * src_words;
+        const uint32_t Y0 = yt[y0 + (slot >> 1)];
+        const int sy = (slot & 1) ? (int)(Y0 >> 16) : (int)(Y0 & 0xffffu);
+        ((uint32_t *)s_src)[slot * src_words + c] = *(const uint32_t *)(src + (size_t)sy * S.pitch + 4 * c);
     }
-    *(uint32_t *)(dst + (ptrdiff_t)(yi - PYR_MY) * D.pitch + (xi - PYR_MX)) = out;
+    __syncthreads();
+    const int nwords = (D.w + 12 + 3) >> 2; // extended row in 4-px words
+    for (int i = tid; i < nrows * nwords; i += 256) {
+        const int k = i / nwords, xw = i - k * nwords;
+        const int xi = xw * 4;
+        const uint4 X0 = *(const uint4 *)(xt + xi);
+        const uint4 X1 = *(const uint4 *)(xt + D.rs_xtab_n + xi);
+        const uint32_t Y1 = yt[D.rs_ytab_n + y0 + k];
+        const int b0 = (int)(Y1 & 0xffffu), b1 = (int)(Y1 >> 16);
+        const uint8_t *r0 = s_src + (2 * k) * row_bytes;
+        const uint8_t *r1 = r0 + row_bytes;
+        const uint32_t x0v[4] = {X0.x, X0.y, X0.z, X0.w}, x1v[4] = {X1.x, X1.y, X1.z, X1.w};
+        uint32_t out = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int sx = (int)(x0v[j] & 0xffffu), sx1 = (int)(x0v[j] >> 16);
+            const int a0 = (int)(x1v[j] & 0xffffu), a1 = (int)(x1v[j] >> 16);
+            const int h0 = r0[sx] * a0 + r0[sx1] * a1;
+            const int h1 = r1[sx] * a0 + r1[sx1] * a1;
+            int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            out |= (uint32_t)v << (8 * j);
+        }
+        *(uint32_t *)(dst + (ptrdiff_t)(y0 + k - PYR_MY) * D.pitch + (xi - PYR_MX)) = out;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -319,7 +341,7 @@ __device__ __forceinline__ void load_ring(const uint8_t *t, int pitch, int d[16]
     d[12] = v - t[-3];             d[13] = v - t[pitch - 3];      d[14] = v - t[2 * pitch - 2];  d[15] = v - t[3 * pitch - 1];
 }
 
-__global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceBuffers buf, int tile_pitch, int tile_bytes, int sc_bytes, int q_bytes)
+__global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceBuffers buf, int tile_pitch, int tile_bytes, int sc_bytes, int q_bytes, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
     const int img = blockIdx.y;
@@ -376,6 +398,7 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
     for (int i = lane; i < sc_bytes / 4; i += 64) ((uint32_t *)s_sc)[i] = 0;
     __syncthreads();
     const int t = cfg.min_th;
+    if (dbg == 1) { if (lane == 0) *cnt_out = 0; return; }
     // ---- A: cardinal test ----
     int n1 = 0;
     {
@@ -396,41 +419,79 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
         }
     }
     __syncthreads();
-    // ---- B: 8 opposite pairs: a dark (bright) 9-arc needs one darker (brighter) pixel in every pair ----
+    if (dbg == 2) { if (lane == 0) *cnt_out = 0; return; }
+    // Phases B and C work on TWO queue entries per lane, one in each 16-bit half of a register, with
+    // packed v_pk_{sub,min,max}_i16: ring differences are in [-255, 255].
+    int roff[16]; // ring offsets inside the LDS tile (uniform)
+    roff[0] = 3 * tile_pitch;      roff[1] = 3 * tile_pitch + 1;   roff[2] = 2 * tile_pitch + 2;   roff[3] = tile_pitch + 3;
+    roff[4] = 3;                   roff[5] = -tile_pitch + 3;      roff[6] = -2 * tile_pitch + 2;  roff[7] = -3 * tile_pitch + 1;
+    roff[8] = -3 * tile_pitch;     roff[9] = -3 * tile_pitch - 1;  roff[10] = -2 * tile_pitch - 2; roff[11] = -tile_pitch - 3;
+    roff[12] = -3;                 roff[13] = tile_pitch - 3;      roff[14] = 2 * tile_pitch - 2;  roff[15] = 3 * tile_pitch - 1;
+    const pk16 tt = {(short)t, (short)t};
+    // ---- B: 8 opposite pairs (cv::FAST's quick test): a dark (bright) 9-arc needs one darker (brighter)
+    //      pixel in every pair.  Passing BOTH polarities means every pair straddles the centre, which
+    //      excludes any 9-arc, so such pixels are dropped; survivors carry their polarity in bit 15. ----
     int n2 = 0;
-    for (int q0 = 0; q0 < n1; q0 += 64) {
-        const int q = q0 + lane;
-        bool pass = false;
-        unsigned rc = 0;
-        if (q < n1) {
-            rc = s_q1[q];
-            int d[16];
-            load_ring(&s_tile[((rc >> 8) + 3) * tile_pitch + (rc & 255) + 3 + ox], tile_pitch, d);
-            int lo = 512, hi = -512;
+    for (int q0 = 0; q0 < n1; q0 += 128) {
+        const int qa = q0 + lane, qb = q0 + 64 + lane;
+        const bool va = qa < n1, vb = qb < n1;
+        const unsigned rca = s_q1[va ? qa : 0], rcb = s_q1[vb ? qb : 0];
+        const uint8_t *pa = &s_tile[((rca >> 8) + 3) * tile_pitch + (rca & 255) + 3 + ox];
+        const uint8_t *pb = &s_tile[((rcb >> 8) + 3) * tile_pitch + (rcb & 255) + 3 + ox];
+        const pk16 vv = {(short)pa[0], (short)pb[0]};
+        pk16 lo = {512, 512}, hi = {-512, -512};
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                lo = min(lo, max(d[k], d[k + 8])); // dark: every pair has a member with d > t
-                hi = max(hi, min(d[k], d[k + 8])); // bright: every pair has a member with d < -t
-            }
-            pass = ((int)(lo > t) | (int)(hi < -t)) != 0;
+        for (int k = 0; k < 8; k++) {
+            const pk16 d0 = vv - (pk16){(short)pa[roff[k]], (short)pb[roff[k]]};
+            const pk16 d1 = vv - (pk16){(short)pa[roff[k + 8]], (short)pb[roff[k + 8]]};
+            lo = __builtin_elementwise_min(lo, __builtin_elementwise_max(d0, d1));
+            hi = __builtin_elementwise_max(hi, __builtin_elementwise_min(d0, d1));
         }
-        const unsigned long long m = __ballot(pass);
-        if (pass) s_q2[n2 + __popcll(m & lt)] = (uint16_t)rc;
-        n2 += __popcll(m);
+        const bool da = lo.x > t, ba = hi.x < -t, db = lo.y > t, bb = hi.y < -t;
+        const bool passa = va & (da != ba), passb = vb & (db != bb);
+        const unsigned long long ma = __ballot(passa), mb = __ballot(passb);
+        // every lane has read its queue-1 entries; in-place writes stay below the read cursor
+        if (passa) s_q2[n2 + __popcll(ma & lt)] = (uint16_t)(rca | (ba ? 0x8000u : 0u));
+        n2 += __popcll(ma);
+        if (passb) s_q2[n2 + __popcll(mb & lt)] = (uint16_t)(rcb | (bb ? 0x8000u : 0u));
+        n2 += __popcll(mb);
     }
     __syncthreads();
-    // ---- C: exact score ----
-    for (int q = lane; q < n2; q += 64) {
-        const unsigned rc = s_q2[q];
-        const int r = rc >> 8, c = rc & 255;
-        const int s = fast_score16(&s_tile[(r + 3) * tile_pitch + c + 3 + ox], tile_pitch, t);
-        s_sc[(r + 1) * scp + c + 1] = (uint8_t)(s >= t ? s : 0);
+    if (dbg == 3) { if (lane == 0) *cnt_out = 0; return; }
+    // ---- C: exact score for the entry's polarity: max over the 16 arcs of the min of 9 (sign-normalised)
+    //      differences; windows of 2, 4, 8 (+1) by doubling. ----
+    for (int q0 = 0; q0 < n2; q0 += 128) {
+        const int qa = q0 + lane, qb = q0 + 64 + lane;
+        const bool va = qa < n2, vb = qb < n2;
+        const unsigned ea = s_q2[va ? qa : 0], eb = s_q2[vb ? qb : 0];
+        const int ra = (ea >> 8) & 127, ca = ea & 255, rb = (eb >> 8) & 127, cb = eb & 255;
+        const uint8_t *pa = &s_tile[(ra + 3) * tile_pitch + ca + 3 + ox];
+        const uint8_t *pb = &s_tile[(rb + 3) * tile_pitch + cb + 3 + ox];
+        const pk16 vv = {(short)pa[0], (short)pb[0]};
+        const pk16 sg = {(short)((ea & 0x8000u) ? -1 : 1), (short)((eb & 0x8000u) ? -1 : 1)};
+        pk16 e[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) e[k] = (vv - (pk16){(short)pa[roff[k]], (short)pb[roff[k]]}) * sg;
+        pk16 m2[16], m4[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_min(e[k], e[(k + 1) & 15]);
+#pragma unroll
+        for (int k = 0; k < 16; k++) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
+        pk16 best = {-512, -512};
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            best = __builtin_elementwise_max(best, __builtin_elementwise_min(__builtin_elementwise_min(m4[k], m4[(k + 4) & 15]), e[(k + 8) & 15]));
+        best = __builtin_elementwise_max(best, tt);
+        const int sa = (int)best.x - 1, sb = (int)best.y - 1;
+        if (va && sa >= t) s_sc[(ra + 1) * scp + ca + 1] = (uint8_t)sa;
+        if (vb && sb >= t) s_sc[(rb + 1) * scp + cb + 1] = (uint8_t)sb;
     }
     __syncthreads();
+    if (dbg == 4) { if (lane == 0) *cnt_out = 0; return; }
     // ---- D: NMS + threshold choice ----
     bool any = false;
     for (int q = lane; q < n2; q += 64) {
-        const unsigned rc = s_q2[q];
+        const unsigned rc = s_q2[q] & 0x7fffu;
         const uint8_t *p = &s_sc[((rc >> 8) + 1) * scp + (rc & 255) + 1];
         const int s = p[0];
         int f = 0;
@@ -455,7 +516,7 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
         if (pred) {
             const int pos = run + __popcll(m & lt);
             if (pos < cfg.cell_cap) {
-                const unsigned rc = s_q2[q];
+                const unsigned rc = s_q2[q] & 0x7fffu;
                 const int r = rc >> 8, c = rc & 255;
                 // cell-local FAST coords (c+3, r+3) + (j*wCell, i*hCell): src/ORBextractor.cc:816-817
                 const unsigned x = (unsigned)(c + 3 + ci_j * L.w_cell);
@@ -781,72 +842,114 @@ __global__ __launch_bounds__(OT_THREADS) void octree_generic_kernel(DeviceConfig
 // ---------------------------------------------------------------------------
 // orientation + descriptor + final keypoint record: one wave per keypoint slot
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void describe_kernel(DeviceConfig cfg, DeviceBuffers buf)
+// The kernel is bound by vector-memory INSTRUCTION issue (a wave64 byte gather costs the texture
+// addresser ~16 cycles whatever it fetches), so everything is fetched as aligned dwords into LDS:
+// the block stages the two tables once, each wave stages its 31-row raw patch (5 loads) and 37-row
+// blurred patch (6 loads), and all per-pixel / per-sample accesses become LDS byte reads.
+#define DS_PATCH_W 40 // bytes per staged patch row (10 words: covers 31+3 / 37+3 px at any alignment)
+__global__ __launch_bounds__(256) void describe_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int dbg)
 {
-    const int img = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dm[];
+    // XCD-aware block -> (image, block) map: workgroups are dealt round-robin over the 8 XCDs, so block
+    // b runs on XCD b % 8 (placement is a speed assumption only).  All blocks of one image are given to
+    // one XCD, whose 4 MiB L2 then holds that image's raw + blurred pyramid (3.3 MB) while its ~2000
+    // overlapping 31x31 / 37x37 patches are read, instead of every patch row coming from the MALL.
+    const int bpi = (cfg.sel_total + 3) / 4; // blocks per image
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int img = (jb / bpi) * 8 + xcd;
+    if (img >= n_images) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = (jb % bpi) * 4 + wave;
+    const int hp = cfg.half_patch;
+    const int raw_rows = 2 * hp + 1;
     const int *sel_cnt = buf.sel_cnt + (size_t)img * cfg.nlevels;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (jb % bpi == 0 && tid == 0) {
         int tot = 0;
         for (int l = 0; l < cfg.nlevels; l++) tot += sel_cnt[l];
         buf.kp_cnt[img] = tot;
     }
-    if (slot >= cfg.sel_total) return;
-    int level = 0;
-    for (int l = 1; l < cfg.nlevels; l++)
-        if (slot >= cfg.lv[l].sel_off) level = l;
+    // block-shared tables: patch offsets (patch_n shorts) | pattern (256 words)
+    int16_t *s_uv = (int16_t *)s_dm;
+    int *s_pat = (int *)(s_dm + ((cfg.patch_n * 2 + 15) & ~15));
+    uint8_t *s_raw = (uint8_t *)(s_pat + 256) + wave * ((raw_rows + 37) * DS_PATCH_W);
+    uint8_t *s_blr = s_raw + raw_rows * DS_PATCH_W;
+    for (int i = tid; i < cfg.patch_n / 2; i += 256) ((int *)s_uv)[i] = ((const int *)buf.patch_uv)[i];
+    s_pat[tid] = ((const int *)g_pattern)[tid];
+    // per-wave independent loads, issued before the barrier
+    const bool in_range = slot < cfg.sel_total;
+    const int level = in_range ? buf.slot_level[slot] : 0;
+    const int c_l = lane < cfg.nlevels ? sel_cnt[lane] : 0;
+    const uint32_t xy = in_range ? buf.sel_xy[(size_t)img * cfg.sel_total + slot] : 0u;
+    const int score = in_range ? buf.sel_sc[(size_t)img * cfg.sel_total + slot] : 0;
+    __syncthreads();
+    if (!in_range) return;
     const LevelInfo &L = cfg.lv[level];
     const int k = slot - L.sel_off;
-    if (k >= sel_cnt[level]) return;
-    int out = k;
-    for (int l = 0; l < level; l++) out += sel_cnt[l];
+    int inc = c_l;
+#pragma unroll
+    for (int o = 1; o < ORBFE_MAX_LEVELS; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (k >= __shfl(c_l, level, 64)) return;
+    const int out = k + __shfl(inc - c_l, level, 64);
+    if (dbg == 1) return;
 
-    const uint32_t xy = buf.sel_xy[(size_t)img * cfg.sel_total + slot];
-    const int score = buf.sel_sc[(size_t)img * cfg.sel_total + slot];
     const int cx = (int)(xy & 0xffffu) + cfg.min_border;
     const int cy = (int)(xy >> 16) + cfg.min_border;
     const uint8_t *raw = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off;
     const uint8_t *blr = buf.blur + (size_t)img * cfg.pyr_bytes + L.pyr_off;
+    // stage both patches (aligned dwords; the right overshoot stays inside the level's margin)
+    const int xr = (cx - hp) & ~3, xb = (cx - 18) & ~3;
+    for (int i = lane; i < raw_rows * (DS_PATCH_W / 4); i += 64) {
+        const int r = i / (DS_PATCH_W / 4), c = i - r * (DS_PATCH_W / 4);
+        ((uint32_t *)s_raw)[i] = *(const uint32_t *)(raw + (ptrdiff_t)(cy - hp + r) * L.pitch + xr + 4 * c);
+    }
+    for (int i = lane; i < 37 * (DS_PATCH_W / 4); i += 64) {
+        const int r = i / (DS_PATCH_W / 4), c = i - r * (DS_PATCH_W / 4);
+        ((uint32_t *)s_blr)[i] = *(const uint32_t *)(blr + (ptrdiff_t)(cy - 18 + r) * L.pitch + xb + 4 * c);
+    }
+    __builtin_amdgcn_s_waitcnt(0); // LDS writes of this wave are visible to its own later reads in order
+    __builtin_amdgcn_wave_barrier();
+    if (dbg == 2) return;
 
-    // IC_Angle (src/ORBextractor.cc:72-99): integer moments over the circular patch
-    // The (u,v) offsets of the circular patch come from a host-built table (padded with (0,0), which
-    // contributes nothing), so a lane issues all of its ~12 pixel loads back to back instead of
-    // walking 31 dependent rows.
+    // IC_Angle (src/ORBextractor.cc:72-99): integer moments over the circular patch (host-built offset
+    // table, padded with (0,0) entries that contribute nothing)
     int m10 = 0, m01 = 0;
-    const uint8_t *pc = raw + (size_t)cy * L.pitch + cx;
-#pragma unroll 4
-    for (int k = lane; k < cfg.patch_n; k += 64) {
-        const int uv = buf.patch_uv[k];
+    const uint8_t *pc = s_raw + hp * DS_PATCH_W + (cx - xr);
+    for (int kk = lane; kk < cfg.patch_n; kk += 64) {
+        const int uv = s_uv[kk];
         const int u = (int)(int8_t)(uv & 0xff), v = (int)(int8_t)((uv >> 8) & 0xff);
-        const int I = pc[v * L.pitch + u];
+        const int I = pc[v * DS_PATCH_W + u];
         m10 += u * I;
         m01 += v * I;
     }
     m10 = wave_sum_i32(m10);
     m01 = wave_sum_i32(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
+    if (dbg == 3) { if (lane == 0) buf.depth[(size_t)img * cfg.sel_total + out] = angle; return; }
 
     // computeOrbDescriptor (src/ORBextractor.cc:103-142)
     const float factor_pi = __uint_as_float(0x3c8efa35u); // (float)(CV_PI/180.f)
     float a, b;
     sincos_det(__fmul_rn(angle, factor_pi), &b, &a);
-    const uint8_t *center = blr + (size_t)cy * L.pitch + cx;
+    const uint8_t *center = s_blr + 18 * DS_PATCH_W + (cx - xb);
     unsigned long long *dout = (unsigned long long *)(buf.desc + ((size_t)img * cfg.sel_total + out) * 32);
+    unsigned long long bits[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int pi = (r * 64 + lane) * 4;
-        const float x0 = (float)g_pattern[pi], y0 = (float)g_pattern[pi + 1];
-        const float x1 = (float)g_pattern[pi + 2], y1 = (float)g_pattern[pi + 3];
+        const int pw = s_pat[r * 64 + lane]; // (x0, y0, x1, y1) as 4 signed bytes
+        const float x0 = (float)(int)(int8_t)(pw & 0xff), y0 = (float)(int)(int8_t)((pw >> 8) & 0xff);
+        const float x1 = (float)(int)(int8_t)((pw >> 16) & 0xff), y1 = (float)(pw >> 24);
         const int r0 = (int)rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
         const int c0 = (int)rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int r1 = (int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int c1 = (int)rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = center[r0 * L.pitch + c0];
-        const int t1 = center[r1 * L.pitch + c1];
-        const unsigned long long bits = __ballot(t0 < t1);
-        if (lane == 0) dout[r] = bits;
+        const int t0 = center[r0 * DS_PATCH_W + c0];
+        const int t1 = center[r1 * DS_PATCH_W + c1];
+        bits[r] = __ballot(t0 < t1);
     }
+    if (lane < 4) dout[lane] = lane == 0 ? bits[0] : (lane == 1 ? bits[1] : (lane == 2 ? bits[2] : bits[3]));
     if (lane == 0) {
         KeyPointPOD kp;
         float px = (float)cx, py = (float)cy;
@@ -1157,9 +1260,9 @@ void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, cons
 void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
 {
     for (int l = 1; l < cfg.nlevels; l++) {
-        const int words = (cfg.lv[l].w + 12 + 3) / 4;
-        dim3 grid((words + 63) / 64, (cfg.lv[l].h + 2 * PYR_MY + 3) / 4, n_images);
-        hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(64, 4), 0, s, cfg, buf, l);
+        const int src_words = (cfg.lv[l - 1].w + 3) / 4; // interior pixels of the source row (4-aligned start)
+        dim3 grid((cfg.lv[l].h + 2 * PYR_MY + RS_ROWS - 1) / RS_ROWS, n_images);
+        hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), (size_t)RS_ROWS * 2 * src_words * 4, s, cfg, buf, l, src_words);
     }
 }
 
@@ -1180,7 +1283,8 @@ void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_
     // flags alias the tile: it must hold one byte per interior pixel
     const size_t lds = (size_t)(tile_bytes > mw * mh ? tile_bytes : ((mw * mh + 15) & ~15)) + sc_bytes + q_bytes;
     dim3 grid(cfg.cells_total, n_images);
-    hipLaunchKernelGGL(fast_cell_kernel, grid, dim3(64), lds, s, cfg, buf, tile_pitch, tile_bytes, sc_bytes, q_bytes);
+    static const int dbg = getenv("ORBFE_FAST_DBG") ? atoi(getenv("ORBFE_FAST_DBG")) : 0; // profiling aid only
+    hipLaunchKernelGGL(fast_cell_kernel, grid, dim3(64), lds, s, cfg, buf, tile_pitch, tile_bytes, sc_bytes, q_bytes, dbg);
 }
 
 static inline int ot_sort_cap(const DeviceConfig &cfg) { int p = 1; while (p < cfg.max_nodes) p <<= 1; return p; }
@@ -1200,8 +1304,10 @@ void orbfe_launch_octree_generic(const DeviceConfig &cfg, const DeviceBuffers &b
 
 void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
 {
-    dim3 grid((cfg.sel_total + 3) / 4, n_images);
-    hipLaunchKernelGGL(describe_kernel, grid, dim3(256), 0, s, cfg, buf);
+    dim3 grid(((cfg.sel_total + 3) / 4) * ((n_images + 7) / 8) * 8);
+    const size_t lds = ((cfg.patch_n * 2 + 15) & ~15) + 256 * 4 + (size_t)4 * (2 * cfg.half_patch + 1 + 37) * DS_PATCH_W;
+    static const int dbg = getenv("ORBFE_DESC_DBG") ? atoi(getenv("ORBFE_DESC_DBG")) : 0; // profiling aid only
+    hipLaunchKernelGGL(describe_kernel, grid, dim3(256), lds, s, cfg, buf, n_images, dbg);
 }
 
 void orbfe_launch_stereo_match(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s)
