@@ -399,62 +399,50 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
     __syncthreads();
     const int t = cfg.min_th;
     if (dbg == 1) { if (lane == 0) *cnt_out = 0; return; }
-    // ---- A: cardinal test ----
-    int n1 = 0;
-    {
-        int r = (int)(((float)lane + 0.5f) * rcp_iw), c = lane - r * iw; // (r, c) of pixel i = lane, advanced by 64 per step
-        const int dr = 64 / iw, dc = 64 - dr * iw;
-        for (int i0 = 0; i0 < npx; i0 += 64) {
-            const bool in = i0 + lane < npx;
-            const uint8_t *p = &s_tile[__mul24(in ? r + 3 : 3, tile_pitch) + (in ? c : 0) + 3 + ox];
-            const int v = p[0];
-            const int d0 = v - p[3 * tile_pitch], d8 = v - p[-3 * tile_pitch], d4 = v - p[3], d12 = v - p[-3];
-            const int passi = (int)in & ((((int)(max(d0, d8) > t)) & ((int)(max(d4, d12) > t))) | (((int)(min(d0, d8) < -t)) & ((int)(min(d4, d12) < -t))));
-            const bool pass = passi != 0;
-            const unsigned long long m = __ballot(pass);
-            if (pass) s_q1[n1 + __popcll(m & lt)] = (uint16_t)((r << 8) | c);
-            n1 += __popcll(m);
-            c += dc; r += dr;
-            if (c >= iw) { c -= iw; r++; }
-        }
-    }
-    __syncthreads();
-    if (dbg == 2) { if (lane == 0) *cnt_out = 0; return; }
-    // Phases B and C work on TWO queue entries per lane, one in each 16-bit half of a register, with
-    // packed v_pk_{sub,min,max}_i16: ring differences are in [-255, 255].
+    // Phases A and C work on TWO pixels per lane, one in each 16-bit half of a register, with packed
+    // v_pk_{sub,min,max}_i16 (ring differences are in [-255, 255]): integer VALU issue is what bounds
+    // this kernel (measured ~1 wave64 instruction / cycle / CU), so instructions are what is saved.
     int roff[16]; // ring offsets inside the LDS tile (uniform)
     roff[0] = 3 * tile_pitch;      roff[1] = 3 * tile_pitch + 1;   roff[2] = 2 * tile_pitch + 2;   roff[3] = tile_pitch + 3;
     roff[4] = 3;                   roff[5] = -tile_pitch + 3;      roff[6] = -2 * tile_pitch + 2;  roff[7] = -3 * tile_pitch + 1;
     roff[8] = -3 * tile_pitch;     roff[9] = -3 * tile_pitch - 1;  roff[10] = -2 * tile_pitch - 2; roff[11] = -tile_pitch - 3;
     roff[12] = -3;                 roff[13] = tile_pitch - 3;      roff[14] = 2 * tile_pitch - 2;  roff[15] = 3 * tile_pitch - 1;
     const pk16 tt = {(short)t, (short)t};
-    // ---- B: 8 opposite pairs (cv::FAST's quick test): a dark (bright) 9-arc needs one darker (brighter)
-    //      pixel in every pair.  Passing BOTH polarities means every pair straddles the centre, which
-    //      excludes any 9-arc, so such pixels are dropped; survivors carry their polarity in bit 15. ----
+    // ---- A: cv::FAST's quick test on the 8 opposite ring pairs, for every interior pixel: a dark
+    //      (bright) 9-arc needs one darker (brighter) pixel in every pair.  Passing BOTH polarities means
+    //      every pair straddles the centre, which excludes any 9-arc, so such pixels are dropped;
+    //      survivors are queued in row-major order with their polarity in bit 15. ----
     int n2 = 0;
-    for (int q0 = 0; q0 < n1; q0 += 128) {
-        const int qa = q0 + lane, qb = q0 + 64 + lane;
-        const bool va = qa < n1, vb = qb < n1;
-        const unsigned rca = s_q1[va ? qa : 0], rcb = s_q1[vb ? qb : 0];
-        const uint8_t *pa = &s_tile[((rca >> 8) + 3) * tile_pitch + (rca & 255) + 3 + ox];
-        const uint8_t *pb = &s_tile[((rcb >> 8) + 3) * tile_pitch + (rcb & 255) + 3 + ox];
-        const pk16 vv = {(short)pa[0], (short)pb[0]};
-        pk16 lo = {512, 512}, hi = {-512, -512};
+    {
+        // (r, c) of pixels i = lane and i = lane + 64, both advanced by 128 per step
+        int ra = (int)(((float)lane + 0.5f) * rcp_iw), ca = lane - ra * iw;
+        int rb = (int)(((float)(lane + 64) + 0.5f) * rcp_iw), cb = lane + 64 - rb * iw;
+        const int dr = 128 / iw, dc = 128 - dr * iw;
+        for (int i0 = 0; i0 < npx; i0 += 128) {
+            const bool va = i0 + lane < npx, vb = i0 + 64 + lane < npx;
+            const uint8_t *pa = &s_tile[__mul24(va ? ra + 3 : 3, tile_pitch) + (va ? ca : 0) + 3 + ox];
+            const uint8_t *pb = &s_tile[__mul24(vb ? rb + 3 : 3, tile_pitch) + (vb ? cb : 0) + 3 + ox];
+            const pk16 vv = {(short)pa[0], (short)pb[0]};
+            pk16 lo = {512, 512}, hi = {-512, -512};
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const pk16 d0 = vv - (pk16){(short)pa[roff[k]], (short)pb[roff[k]]};
-            const pk16 d1 = vv - (pk16){(short)pa[roff[k + 8]], (short)pb[roff[k + 8]]};
-            lo = __builtin_elementwise_min(lo, __builtin_elementwise_max(d0, d1));
-            hi = __builtin_elementwise_max(hi, __builtin_elementwise_min(d0, d1));
+            for (int k = 0; k < 8; k++) {
+                const pk16 d0 = vv - (pk16){(short)pa[roff[k]], (short)pb[roff[k]]};
+                const pk16 d1 = vv - (pk16){(short)pa[roff[k + 8]], (short)pb[roff[k + 8]]};
+                lo = __builtin_elementwise_min(lo, __builtin_elementwise_max(d0, d1));
+                hi = __builtin_elementwise_max(hi, __builtin_elementwise_min(d0, d1));
+            }
+            const bool da = lo.x > t, ba = hi.x < -t, db = lo.y > t, bb = hi.y < -t;
+            const bool passa = va & (da != ba), passb = vb & (db != bb);
+            const unsigned long long ma = __ballot(passa), mb = __ballot(passb);
+            if (passa) s_q2[n2 + __popcll(ma & lt)] = (uint16_t)((ra << 8) | ca | (ba ? 0x8000 : 0));
+            n2 += __popcll(ma);
+            if (passb) s_q2[n2 + __popcll(mb & lt)] = (uint16_t)((rb << 8) | cb | (bb ? 0x8000 : 0));
+            n2 += __popcll(mb);
+            ca += dc; ra += dr;
+            if (ca >= iw) { ca -= iw; ra++; }
+            cb += dc; rb += dr;
+            if (cb >= iw) { cb -= iw; rb++; }
         }
-        const bool da = lo.x > t, ba = hi.x < -t, db = lo.y > t, bb = hi.y < -t;
-        const bool passa = va & (da != ba), passb = vb & (db != bb);
-        const unsigned long long ma = __ballot(passa), mb = __ballot(passb);
-        // every lane has read its queue-1 entries; in-place writes stay below the read cursor
-        if (passa) s_q2[n2 + __popcll(ma & lt)] = (uint16_t)(rca | (ba ? 0x8000u : 0u));
-        n2 += __popcll(ma);
-        if (passb) s_q2[n2 + __popcll(mb & lt)] = (uint16_t)(rcb | (bb ? 0x8000u : 0u));
-        n2 += __popcll(mb);
     }
     __syncthreads();
     if (dbg == 3) { if (lane == 0) *cnt_out = 0; return; }
