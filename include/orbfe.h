@@ -119,6 +119,9 @@ int orbfe_fetch_pyramid(orbfe_context *ctx, int image, int level, int blurred,
 int orbfe_enqueue_extract(orbfe_context *ctx, const uint8_t *d_images, int n_images, void *stream);
 int orbfe_enqueue_stereo(orbfe_context *ctx, const uint8_t *d_images, int n_pairs, void *stream);
 int orbfe_synchronize(orbfe_context *ctx, void *stream);
+/* Cut every batched call into `groups` (1..8) contiguous sub-batches whose stage chains run on internal
+ * streams forked from / joined to the caller's stream (overlaps barrier-bound and ALU-bound stages). */
+int orbfe_set_streams(orbfe_context *ctx, int groups);
 /* Copy the results of image slot `image` to host.  u_right/depth may be NULL. */
 int orbfe_fetch_image(orbfe_context *ctx, int image, orbfe_keypoint *kps, uint8_t *desc,
                       float *u_right, float *depth, int cap, int *n);
@@ -133,7 +136,8 @@ int orbfe_device_buffers(orbfe_context *ctx, void **kps, void **desc, void **cou
 /* ---- stage timing (HIP events recorded on the stream each enqueue call uses) ----
  * Stages: ingest, pyramid, blur, fast, octree, describe, stereo_match, stereo_median.
  * orbfe_stage_times synchronises, adds up the per-stage elapsed ms of the enqueue calls
- * recorded since the last reset (at most 128 are kept) and reports how many calls that was. */
+ * recorded since the last reset (at most 64 are kept; summed over the stream groups of each call) and
+ * reports how many calls that was. */
 #define ORBFE_NUM_STAGES 8
 int orbfe_set_profiling(orbfe_context *ctx, int enabled);
 const char *orbfe_stage_name(int stage);

@@ -26,7 +26,7 @@ EXPORTS = [
     "orbfe_stereo_frame", "orbfe_rgbd_frame", "orbfe_fetch_pyramid", "orbfe_enqueue_extract",
     "orbfe_enqueue_stereo", "orbfe_synchronize", "orbfe_fetch_image", "orbfe_fetch_counts",
     "orbfe_device_buffers", "orbfe_fetch_candidates", "orbfe_hamming_matrix",
-    "orbfe_set_profiling", "orbfe_stage_name", "orbfe_stage_times",
+    "orbfe_set_profiling", "orbfe_stage_name", "orbfe_stage_times", "orbfe_set_streams",
 ]
 NUM_STAGES = 8
 
@@ -90,6 +90,7 @@ def load():
     L.orbfe_set_profiling.restype = C.c_int; L.orbfe_set_profiling.argtypes = [vp, C.c_int]
     L.orbfe_stage_name.restype = C.c_char_p; L.orbfe_stage_name.argtypes = [C.c_int]
     L.orbfe_stage_times.restype = C.c_int; L.orbfe_stage_times.argtypes = [vp, vp, C.POINTER(C.c_int), C.c_int]
+    L.orbfe_set_streams.restype = C.c_int; L.orbfe_set_streams.argtypes = [vp, C.c_int]
     _lib = L
     return L
 
@@ -222,6 +223,9 @@ class Context:
         if stereo:
             out.update(u_right=ur[:m].copy(), depth=dp[:m].copy())
         return out
+
+    def set_streams(self, groups: int):
+        self._check(self.L.orbfe_set_streams(self.h, groups))
 
     def set_profiling(self, enabled: bool):
         self._check(self.L.orbfe_set_profiling(self.h, int(enabled)))

@@ -18,6 +18,7 @@
 #include <vector>
 
 size_t orbfe_octree_lds_bytes(const DeviceConfig &cfg);
+#define ORBFE_MAX_GROUPS 8
 
 struct orbfe_context {
     orbfe_params params;
@@ -35,11 +36,15 @@ struct orbfe_context {
     size_t ot2_lds = 0;
     // stage timing: ring of PROF_RING calls x (ORBFE_NUM_STAGES + 1) events
     bool profiling = false;
-    bool in_stereo = false;
     std::vector<hipEvent_t> events;
     int prof_calls = 0;      // calls recorded since the last reset
-    int prof_stages[128];    // number of stages recorded by each call in the ring
+    int prof_stages[64];     // number of stages recorded by each call in the ring
+    int prof_groups = 1;
     hipStream_t prof_stream = nullptr;
+    // stream groups (orbfe_set_streams)
+    int groups = 1;
+    hipStream_t gstreams[ORBFE_MAX_GROUPS] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[ORBFE_MAX_GROUPS] = {};
     float scale[ORBFE_MAX_LEVELS], inv_scale[ORBFE_MAX_LEVELS], sigma2[ORBFE_MAX_LEVELS], inv_sigma2[ORBFE_MAX_LEVELS];
     int32_t feats[ORBFE_MAX_LEVELS];
     std::vector<void *> allocs;
@@ -404,6 +409,11 @@ extern "C" void orbfe_destroy(orbfe_context *ctx)
     if (ctx->stream) { hipStreamSynchronize(ctx->stream); }
     for (void *q : ctx->allocs) hipFree(q);
     for (hipEvent_t e : ctx->events) hipEventDestroy(e);
+    for (int g = 0; g < ORBFE_MAX_GROUPS; g++) {
+        if (ctx->gstreams[g]) { hipStreamSynchronize(ctx->gstreams[g]); hipStreamDestroy(ctx->gstreams[g]); }
+        if (ctx->ev_join[g]) hipEventDestroy(ctx->ev_join[g]);
+    }
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->d_depth_in) hipFree(ctx->d_depth_in);
     if (ctx->d_ham) hipFree(ctx->d_ham);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -437,7 +447,7 @@ extern "C" int orbfe_level_size(const orbfe_context *ctx, int level, int *w, int
 
 static hipStream_t pick_stream(orbfe_context *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
 
-#define PROF_RING 128
+#define PROF_RING 64
 static const char *k_stage_names[ORBFE_NUM_STAGES] = {"ingest", "pyramid", "blur", "fast", "octree", "describe",
                                                       "stereo_match", "stereo_median"};
 extern "C" const char *orbfe_stage_name(int stage) { return stage >= 0 && stage < ORBFE_NUM_STAGES ? k_stage_names[stage] : ""; }
@@ -446,7 +456,7 @@ extern "C" int orbfe_set_profiling(orbfe_context *ctx, int enabled)
 {
     if (!ctx) return ORBFE_ERR_INVALID;
     if (enabled && ctx->events.empty()) {
-        ctx->events.resize((size_t)PROF_RING * (ORBFE_NUM_STAGES + 1));
+        ctx->events.resize((size_t)PROF_RING * ORBFE_MAX_GROUPS * (ORBFE_NUM_STAGES + 1));
         for (auto &e : ctx->events) HIP_TRY(ctx, hipEventCreate(&e));
     }
     ctx->profiling = enabled != 0;
@@ -454,16 +464,17 @@ extern "C" int orbfe_set_profiling(orbfe_context *ctx, int enabled)
     return ORBFE_OK;
 }
 
-// record event #idx of the current call (idx 0 = before the first stage)
-static inline void prof_mark(orbfe_context *ctx, int idx, hipStream_t s)
+// record event #idx of the current call for stream group `group` (idx 0 = before the first stage)
+static inline void prof_mark(orbfe_context *ctx, int group, int idx, hipStream_t s)
 {
     if (!ctx->profiling) return;
     const int slot = ctx->prof_calls % PROF_RING;
-    hipEventRecord(ctx->events[(size_t)slot * (ORBFE_NUM_STAGES + 1) + idx], s);
+    hipEventRecord(ctx->events[((size_t)slot * ORBFE_MAX_GROUPS + group) * (ORBFE_NUM_STAGES + 1) + idx], s);
     ctx->prof_stages[slot] = idx;
-    ctx->prof_stream = s;
 }
 
+// Per-stage elapsed ms summed over the recorded calls AND over the stream groups of each call
+// (with G groups a stage runs as G launches per call, or 7*G for the pyramid).
 extern "C" int orbfe_stage_times(orbfe_context *ctx, float *ms, int *calls, int reset)
 {
     if (!ctx || !ms) return ORBFE_ERR_INVALID;
@@ -472,16 +483,112 @@ extern "C" int orbfe_stage_times(orbfe_context *ctx, float *ms, int *calls, int 
     if (calls) *calls = n;
     if (n > 0) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->prof_stream));
-        for (int c = 0; c < n; c++) {
-            const hipEvent_t *ev = &ctx->events[(size_t)c * (ORBFE_NUM_STAGES + 1)];
-            for (int st = 0; st < ctx->prof_stages[c]; st++) {
-                float t = 0.f;
-                HIP_TRY(ctx, hipEventElapsedTime(&t, ev[st], ev[st + 1]));
-                ms[st] += t;
+        for (int c = 0; c < n; c++)
+            for (int g = 0; g < ctx->prof_groups; g++) {
+                const hipEvent_t *ev = &ctx->events[((size_t)c * ORBFE_MAX_GROUPS + g) * (ORBFE_NUM_STAGES + 1)];
+                for (int st = 0; st < ctx->prof_stages[c]; st++) {
+                    float t = 0.f;
+                    HIP_TRY(ctx, hipEventElapsedTime(&t, ev[st], ev[st + 1]));
+                    ms[st] += t;
+                }
             }
-        }
     }
     if (reset) ctx->prof_calls = 0;
+    return ORBFE_OK;
+}
+
+// View of the per-image buffers starting at image img0 (kernels index images from 0).
+static DeviceBuffers shift_buffers(const DeviceBuffers &b, const DeviceConfig &c, int img0)
+{
+    DeviceBuffers o = b;
+    const size_t i = (size_t)img0;
+    o.pyr += i * c.pyr_bytes; o.blur += i * c.pyr_bytes;
+    o.cell_cnt += i * c.cells_total; o.cell_base += i * c.cells_total;
+    o.cell_xy += i * c.cells_total * c.cell_cap; o.cell_sc += i * c.cells_total * c.cell_cap;
+    o.cand_xy += i * c.cand_total; o.cand_sc += i * c.cand_total; o.cand_sc2 += i * c.cand_total;
+    o.idx0 += i * c.cand_total; o.idx1 += i * c.cand_total; o.ot_xy2 += i * c.cand_total; o.ot_sc3 += i * c.cand_total;
+    o.lvl_ncand += i * c.nlevels; o.sel_cnt += i * c.nlevels;
+    o.sel_xy += i * c.sel_total; o.sel_sc += i * c.sel_total;
+    o.kps = (KeyPointPOD *)o.kps + i * c.sel_total; o.desc += i * c.sel_total * 32;
+    o.kp_cnt += i; o.status += i;
+    o.u_right += i * c.sel_total; o.depth += i * c.sel_total; o.sad += i * c.sel_total;
+    o.row_off += (i / 2) * (size_t)(c.height + 1); o.row_idx += (i / 2) * (size_t)c.row_idx_cap;
+    return o;
+}
+
+// One chain of stages over images [img0, img0 + n_images) on stream s; stereo stages if n_pairs > 0.
+static void run_chain(orbfe_context *ctx, const uint8_t *d_images, int img0, int n_images, int n_pairs, hipStream_t s, int group)
+{
+    const DeviceConfig &cfg = ctx->cfg;
+    const DeviceBuffers buf = shift_buffers(ctx->buf, cfg, img0);
+    const uint8_t *src = d_images + (size_t)img0 * cfg.width * cfg.height;
+    prof_mark(ctx, group, 0, s);
+    orbfe_launch_ingest(cfg, buf, src, n_images, s);
+    prof_mark(ctx, group, 1, s);
+    orbfe_launch_pyramid(cfg, buf, n_images, s);
+    prof_mark(ctx, group, 2, s);
+    orbfe_launch_blur(cfg, buf, n_images, s);
+    prof_mark(ctx, group, 3, s);
+    orbfe_launch_fast(cfg, buf, n_images, s);
+    prof_mark(ctx, group, 4, s);
+    if (ctx->use_octree2) orbfe_launch_octree2(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot2_lds_pts, ctx->ot2_lds, s);
+    else orbfe_launch_octree_generic(cfg, buf, n_images, s);
+    prof_mark(ctx, group, 5, s);
+    orbfe_launch_describe(cfg, buf, n_images, s);
+    prof_mark(ctx, group, 6, s);
+    if (n_pairs > 0) {
+        orbfe_launch_stereo_match(cfg, buf, n_pairs, s);
+        prof_mark(ctx, group, 7, s);
+        orbfe_launch_stereo_median(cfg, buf, n_pairs, s);
+        prof_mark(ctx, group, 8, s);
+    }
+}
+
+// Images (or pairs) are independent, so a batch is cut into `groups` contiguous sub-batches whose stage
+// chains run on separate streams: the latency / barrier-bound stages of one sub-batch (quadtree,
+// describe) overlap the VALU-bound stages of another (FAST).  The caller's stream is the fork/join point.
+static int enqueue_batch(orbfe_context *ctx, const uint8_t *d_images, int n_units, int imgs_per_unit, void *stream)
+{
+    hipStream_t s = pick_stream(ctx, stream);
+    HIP_TRY(ctx, hipSetDevice(ctx->params.device));
+    const int n_images = n_units * imgs_per_unit;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->buf.status, 0, sizeof(int) * n_images, s));
+    int G = ctx->groups < n_units ? ctx->groups : n_units;
+    if (G < 1) G = 1;
+    if (G == 1) {
+        run_chain(ctx, d_images, 0, n_images, imgs_per_unit == 2 ? n_units : 0, s, 0);
+    } else {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
+        int u0 = 0;
+        for (int g = 0; g < G; g++) {
+            const int nu = n_units / G + (g < n_units % G ? 1 : 0);
+            hipStream_t sg = ctx->gstreams[g];
+            HIP_TRY(ctx, hipStreamWaitEvent(sg, ctx->ev_fork, 0));
+            run_chain(ctx, d_images, u0 * imgs_per_unit, nu * imgs_per_unit, imgs_per_unit == 2 ? nu : 0, sg, g);
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_join[g], sg));
+            HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join[g], 0));
+            u0 += nu;
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->last_images = n_images;
+    ctx->prof_groups = G;
+    ctx->prof_stream = s;
+    if (ctx->profiling) ctx->prof_calls++;
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_set_streams(orbfe_context *ctx, int groups)
+{
+    if (!ctx || groups < 1 || groups > ORBFE_MAX_GROUPS) return fail(ctx, ORBFE_ERR_INVALID, "groups must be in [1, %d]", ORBFE_MAX_GROUPS);
+    if (ctx->profiling) return fail(ctx, ORBFE_ERR_INVALID, "change the stream count before enabling profiling");
+    HIP_TRY(ctx, hipSetDevice(ctx->params.device));
+    if (!ctx->ev_fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    for (int g = 0; g < groups; g++) {
+        if (!ctx->gstreams[g]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->gstreams[g], hipStreamNonBlocking));
+        if (!ctx->ev_join[g]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join[g], hipEventDisableTiming));
+    }
+    ctx->groups = groups;
     return ORBFE_OK;
 }
 
@@ -490,46 +597,15 @@ extern "C" int orbfe_enqueue_extract(orbfe_context *ctx, const uint8_t *d_images
     if (!ctx || !d_images) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
     if (n_images < 1 || n_images > ctx->params.max_images)
         return fail(ctx, ORBFE_ERR_CAPACITY, "n_images %d outside [1, %d]", n_images, ctx->params.max_images);
-    hipStream_t s = pick_stream(ctx, stream);
-    HIP_TRY(ctx, hipSetDevice(ctx->params.device));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->buf.status, 0, sizeof(int) * n_images, s));
-    prof_mark(ctx, 0, s);
-    orbfe_launch_ingest(ctx->cfg, ctx->buf, d_images, n_images, s);
-    prof_mark(ctx, 1, s);
-    orbfe_launch_pyramid(ctx->cfg, ctx->buf, n_images, s);
-    prof_mark(ctx, 2, s);
-    orbfe_launch_blur(ctx->cfg, ctx->buf, n_images, s);
-    prof_mark(ctx, 3, s);
-    orbfe_launch_fast(ctx->cfg, ctx->buf, n_images, s);
-    prof_mark(ctx, 4, s);
-    if (ctx->use_octree2) orbfe_launch_octree2(ctx->cfg, ctx->buf, n_images, ctx->ot2_sort_cap, ctx->ot2_lds_pts, ctx->ot2_lds, s);
-    else orbfe_launch_octree_generic(ctx->cfg, ctx->buf, n_images, s);
-    prof_mark(ctx, 5, s);
-    orbfe_launch_describe(ctx->cfg, ctx->buf, n_images, s);
-    prof_mark(ctx, 6, s);
-    HIP_TRY(ctx, hipGetLastError());
-    ctx->last_images = n_images;
-    if (ctx->profiling && !ctx->in_stereo) ctx->prof_calls++;
-    return ORBFE_OK;
+    return enqueue_batch(ctx, d_images, n_images, 1, stream);
 }
 
 extern "C" int orbfe_enqueue_stereo(orbfe_context *ctx, const uint8_t *d_images, int n_pairs, void *stream)
 {
-    if (!ctx) return fail(ctx, ORBFE_ERR_INVALID, "null context");
+    if (!ctx || !d_images) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
     if (n_pairs < 1 || 2 * n_pairs > ctx->params.max_images)
         return fail(ctx, ORBFE_ERR_CAPACITY, "n_pairs %d needs max_images >= %d", n_pairs, 2 * n_pairs);
-    ctx->in_stereo = true;
-    int rc = orbfe_enqueue_extract(ctx, d_images, 2 * n_pairs, stream);
-    ctx->in_stereo = false;
-    if (rc != ORBFE_OK) return rc;
-    hipStream_t s = pick_stream(ctx, stream);
-    orbfe_launch_stereo_match(ctx->cfg, ctx->buf, n_pairs, s);
-    prof_mark(ctx, 7, s);
-    orbfe_launch_stereo_median(ctx->cfg, ctx->buf, n_pairs, s);
-    prof_mark(ctx, 8, s);
-    HIP_TRY(ctx, hipGetLastError());
-    if (ctx->profiling) ctx->prof_calls++;
-    return ORBFE_OK;
+    return enqueue_batch(ctx, d_images, n_pairs, 2, stream);
 }
 
 extern "C" int orbfe_synchronize(orbfe_context *ctx, void *stream)
