@@ -154,6 +154,66 @@ int orbfe_fetch_candidates(orbfe_context *ctx, int image, int level, int32_t *xs
 int orbfe_hamming_matrix(orbfe_context *ctx, const uint8_t *desc_a, int na,
                          const uint8_t *desc_b, int nb, int32_t *dist);
 
+/* ---- Tracking-thread matchers ----
+ * Pointer-rich reference state is passed flattened: a MapPoint* becomes an index into the caller's
+ * arrays (GetWorldPos -> pos[i][3], GetDescriptor -> desc[i][32], Observations() -> obs[i]).  All
+ * arrays are host memory; calls are synchronous.  Window queries and Hamming distances run on the
+ * GPU, the sequentially greedy resolution runs in order on the host (see orbfe_match.hip).
+ * Camera intrinsics, bf and the scale factors are those of the context.  Poses are 3x4 row-major
+ * [R|t] (the top rows of Frame::mTcw). */
+typedef struct orbfe_frame_view { /* what the matchers read from a Frame (include/Frame.h) */
+    int32_t n;                      /* N */
+    const orbfe_keypoint *keys_un;  /* mvKeysUn */
+    const float *u_right;           /* mvuRight, or NULL for monocular */
+    const uint8_t *descriptors;     /* mDescriptors, n x 32 */
+    float min_x, max_x, min_y, max_y; /* mnMinX, mnMaxX, mnMinY, mnMaxY (ComputeImageBounds) */
+} orbfe_frame_view;
+
+/* what Frame::isInFrustum (src/Frame.cc:270-326) leaves in a MapPoint for SearchLocalPoints */
+typedef struct orbfe_track_point {
+    int32_t in_view;                /* mbTrackInView (and !isBad()) */
+    float proj_x, proj_y, proj_xr;  /* mTrackProjX, mTrackProjY, mTrackProjXR */
+    int32_t level;                  /* mnTrackScaleLevel */
+    float view_cos;                 /* mTrackViewCos */
+} orbfe_track_point;
+
+/* Frame::GetFeaturesInArea (src/Frame.cc:328-381) over Frame::AssignFeaturesToGrid's 64x48 grid (:231-246),
+ * result in the reference's order. */
+int orbfe_features_in_area(orbfe_context *ctx, const orbfe_frame_view *frame, float x, float y, float r,
+                           int min_level, int max_level, int32_t *out, int cap, int *n);
+/* ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:1597-1638) on the sizes of the rotation histogram bins. */
+int orbfe_three_maxima(const int32_t *histo_sizes, int L, int *ind1, int *ind2, int *ind3);
+/* ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) (src/ORBmatcher.cc:1324-1466).
+ * last_valid[i] = LastFrame.mvpMapPoints[i] && !mvbOutlier[i]; cur_has_obs[k] (may be NULL) = CurrentFrame
+ * keypoint k already holds a point with Observations() > 0.  cur_match[k] receives the last-frame index
+ * assigned to keypoint k, or -1. */
+int orbfe_search_by_projection_last(orbfe_context *ctx, const orbfe_frame_view *cur,
+                                    const float *Tcw_cur, const float *Tcw_last, int n_last,
+                                    const float *last_pos, const uint8_t *last_desc, const int32_t *last_valid,
+                                    const int32_t *last_obs, const int32_t *last_octave, const float *last_angle,
+                                    const uint8_t *cur_has_obs, float th, int mono, int check_ori,
+                                    int32_t *cur_match, int *nmatches);
+/* Frame::isInFrustum (src/Frame.cc:270-326) for n map points; max/min_distance are mfMaxDistance / mfMinDistance. */
+int orbfe_is_in_frustum(orbfe_context *ctx, const float *Tcw, float min_x, float max_x, float min_y, float max_y,
+                        int n, const float *pos, const float *normal, const float *max_distance,
+                        const float *min_distance, float viewing_cos_limit, orbfe_track_point *out);
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:43-135). */
+int orbfe_search_by_projection_points(orbfe_context *ctx, const orbfe_frame_view *cur, int n_pts,
+                                      const orbfe_track_point *pts, const uint8_t *pt_desc, const int32_t *pt_obs,
+                                      const uint8_t *cur_has_obs, float th, float nnratio,
+                                      int32_t *cur_match, int *nmatches);
+/* ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1468-1595).
+ * kf_valid[i] = pMP && !isBad() && !sAlreadyFound.count(pMP); cur_has_point[k] = CurrentFrame.mvpMapPoints[k] != NULL. */
+int orbfe_search_by_projection_kf(orbfe_context *ctx, const orbfe_frame_view *cur, const float *Tcw_cur, int n_kf,
+                                  const float *kf_pos, const uint8_t *kf_desc, const int32_t *kf_valid,
+                                  const float *kf_angle, const float *kf_max_distance, const float *kf_min_distance,
+                                  const uint8_t *cur_has_point, float th, int orb_dist, int check_ori,
+                                  int32_t *cur_match, int *nmatches);
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:400-515); prev_matched is vbPrevMatched ([n1][2], in/out). */
+int orbfe_search_for_initialization(orbfe_context *ctx, const orbfe_frame_view *f1, const orbfe_frame_view *f2,
+                                    float *prev_matched, int window_size, float nnratio, int check_ori,
+                                    int32_t *matches12, int *nmatches);
+
 #ifdef __cplusplus
 }
 #endif

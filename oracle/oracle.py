@@ -95,9 +95,133 @@ def lib(target: str = "liborb_oracle.so"):
     return L
 
 
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float), ("mb", C.c_float)]
+
+
+class TrackPoint(C.Structure):
+    _fields_ = [("in_view", C.c_int32), ("proj_x", C.c_float), ("proj_y", C.c_float), ("proj_xr", C.c_float),
+                ("level", C.c_int32), ("view_cos", C.c_float)]
+
+
+TP_DTYPE = np.dtype([("in_view", "<i4"), ("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("level", "<i4"), ("view_cos", "<f4")])
+
+
 def _bind_match(L):
-    """Matcher entry points (orb_oracle_match.c); bound lazily as they are added."""
-    pass
+    """Matcher entry points (orb_oracle_match.c)."""
+    vp = C.c_void_p
+    L.orc_grid_create.restype = vp; L.orc_grid_create.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.orc_grid_destroy.restype = None; L.orc_grid_destroy.argtypes = [vp]
+    L.orc_features_in_area.restype = C.c_int
+    L.orc_features_in_area.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, vp, C.c_int]
+    L.orc_three_maxima.restype = None
+    L.orc_three_maxima.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.orc_log_det.restype = C.c_float; L.orc_log_det.argtypes = [C.c_float]
+    L.orc_predict_scale.restype = C.c_int; L.orc_predict_scale.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int]
+    L.orc_search_by_projection_last.restype = C.c_int
+    L.orc_search_by_projection_last.argtypes = [vp, vp, vp, vp, C.POINTER(Camera), vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp,
+                                                C.c_float, C.c_int, C.c_int, vp]
+    L.orc_is_in_frustum.restype = C.c_int
+    L.orc_is_in_frustum.argtypes = [vp, C.POINTER(Camera), C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, C.c_float, C.c_float,
+                                    C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(TrackPoint)]
+    L.orc_search_by_projection_points.restype = C.c_int
+    L.orc_search_by_projection_points.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float, vp]
+    L.orc_search_by_projection_kf.restype = C.c_int
+    L.orc_search_by_projection_kf.argtypes = [vp, vp, vp, C.POINTER(Camera), vp, C.c_float, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp,
+                                              vp, C.c_float, C.c_int, C.c_int, vp]
+    L.orc_search_for_initialization.restype = C.c_int
+    L.orc_search_for_initialization.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp]
+
+
+class Grid:
+    """Frame grid (AssignFeaturesToGrid) over mvKeysUn; keeps the arrays alive."""
+
+    def __init__(self, keys_un, min_x, max_x, min_y, max_y):
+        self.L = lib()
+        self.keys = np.ascontiguousarray(keys_un)
+        self.bounds = (float(min_x), float(max_x), float(min_y), float(max_y))
+        self.h = self.L.orc_grid_create(_ptr(self.keys), len(self.keys), *self.bounds)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_grid_destroy(self.h)
+            self.h = None
+
+    def features_in_area(self, x, y, r, min_level=-1, max_level=-1):
+        out = np.zeros(max(len(self.keys), 1), np.int32)
+        n = self.L.orc_features_in_area(self.h, x, y, r, min_level, max_level, _ptr(out), len(out))
+        return out[:n].copy()
+
+
+def three_maxima(sizes):
+    s = np.ascontiguousarray(sizes, np.int32)
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    lib().orc_three_maxima(_ptr(s), len(s), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def _opt(a, dtype):
+    return None if a is None else np.ascontiguousarray(a, dtype)
+
+
+def search_by_projection_last(grid, u_right, desc_cur, scale_factors, cam, Tcw_cur, Tcw_last, last_pos, last_desc, last_valid,
+                              last_obs, last_octave, last_angle, cur_has_obs, th, mono, check_ori):
+    ur = _opt(u_right, np.float32); dc = np.ascontiguousarray(desc_cur, np.uint8); sf = np.ascontiguousarray(scale_factors, np.float32)
+    tc = np.ascontiguousarray(Tcw_cur, np.float32); tl = np.ascontiguousarray(Tcw_last, np.float32)
+    lp = np.ascontiguousarray(last_pos, np.float32); ld = np.ascontiguousarray(last_desc, np.uint8)
+    lv = np.ascontiguousarray(last_valid, np.int32); lo = np.ascontiguousarray(last_obs, np.int32)
+    loc = np.ascontiguousarray(last_octave, np.int32); la = np.ascontiguousarray(last_angle, np.float32)
+    ho = _opt(cur_has_obs, np.uint8)
+    out = np.zeros(max(len(grid.keys), 1), np.int32)
+    n = lib().orc_search_by_projection_last(grid.h, None if ur is None else _ptr(ur), _ptr(dc), _ptr(sf), C.byref(cam), _ptr(tc), _ptr(tl),
+                                            len(lv), _ptr(lp), _ptr(ld), _ptr(lv), _ptr(lo), _ptr(loc), _ptr(la),
+                                            None if ho is None else _ptr(ho), th, int(mono), int(check_ori), _ptr(out))
+    return out[: len(grid.keys)].copy(), n
+
+
+def is_in_frustum(Tcw, cam, bounds, pos, normal, max_distance, min_distance, viewing_cos_limit, log_scale_factor, n_levels):
+    tc = np.ascontiguousarray(Tcw, np.float32)
+    pos = np.ascontiguousarray(pos, np.float32); normal = np.ascontiguousarray(normal, np.float32)
+    out = np.zeros(len(pos), TP_DTYPE)
+    tp = TrackPoint()
+    for i in range(len(pos)):
+        lib().orc_is_in_frustum(_ptr(tc), C.byref(cam), bounds[0], bounds[1], bounds[2], bounds[3], _ptr(pos[i]), _ptr(normal[i]),
+                                np.float32(1.2) * np.float32(max_distance[i]), np.float32(0.8) * np.float32(min_distance[i]),
+                                float(max_distance[i]), viewing_cos_limit, log_scale_factor, n_levels, C.byref(tp))
+        out[i] = (tp.in_view, tp.proj_x, tp.proj_y, tp.proj_xr, tp.level, tp.view_cos)
+    return out
+
+
+def search_by_projection_points(grid, u_right, desc_cur, scale_factors, pts, pt_desc, pt_obs, cur_has_obs, th, nnratio):
+    ur = _opt(u_right, np.float32); dc = np.ascontiguousarray(desc_cur, np.uint8); sf = np.ascontiguousarray(scale_factors, np.float32)
+    pts = np.ascontiguousarray(pts, TP_DTYPE); pd = np.ascontiguousarray(pt_desc, np.uint8); po = np.ascontiguousarray(pt_obs, np.int32)
+    ho = _opt(cur_has_obs, np.uint8)
+    out = np.zeros(max(len(grid.keys), 1), np.int32)
+    n = lib().orc_search_by_projection_points(grid.h, None if ur is None else _ptr(ur), _ptr(dc), _ptr(sf), len(pts), _ptr(pts), _ptr(pd),
+                                              _ptr(po), None if ho is None else _ptr(ho), th, nnratio, _ptr(out))
+    return out[: len(grid.keys)].copy(), n
+
+
+def search_by_projection_kf(grid, desc_cur, scale_factors, cam, Tcw_cur, log_scale_factor, n_levels, kf_pos, kf_desc, kf_valid, kf_angle,
+                            kf_max_distance, kf_min_distance, cur_has_point, th, orb_dist, check_ori):
+    dc = np.ascontiguousarray(desc_cur, np.uint8); sf = np.ascontiguousarray(scale_factors, np.float32)
+    tc = np.ascontiguousarray(Tcw_cur, np.float32); kp = np.ascontiguousarray(kf_pos, np.float32)
+    kd = np.ascontiguousarray(kf_desc, np.uint8); kv = np.ascontiguousarray(kf_valid, np.int32); ka = np.ascontiguousarray(kf_angle, np.float32)
+    kmx = np.ascontiguousarray(kf_max_distance, np.float32); kmn = np.ascontiguousarray(kf_min_distance, np.float32)
+    hp = _opt(cur_has_point, np.uint8)
+    out = np.zeros(max(len(grid.keys), 1), np.int32)
+    n = lib().orc_search_by_projection_kf(grid.h, _ptr(dc), _ptr(sf), C.byref(cam), _ptr(tc), log_scale_factor, n_levels, len(kv), _ptr(kp),
+                                          _ptr(kd), _ptr(kv), _ptr(ka), _ptr(kmx), _ptr(kmn), None if hp is None else _ptr(hp),
+                                          th, orb_dist, int(check_ori), _ptr(out))
+    return out[: len(grid.keys)].copy(), n
+
+
+def search_for_initialization(keys1, desc1, grid2, desc2, prev_matched, window_size, nnratio, check_ori):
+    k1 = np.ascontiguousarray(keys1); d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+    pm = np.ascontiguousarray(prev_matched, np.float32).copy()
+    out = np.zeros(max(len(k1), 1), np.int32)
+    n = lib().orc_search_for_initialization(_ptr(k1), _ptr(d1), len(k1), grid2.h, _ptr(d2), _ptr(pm), window_size, nnratio, int(check_ori), _ptr(out))
+    return out[: len(k1)].copy(), pm, n
 
 
 def _ptr(a):

@@ -119,6 +119,41 @@ void orc_stereo_from_rgbd(const orc_keypoint *k, const orc_keypoint *k_un, int n
                           const float *depth, int w, int h, size_t stride_floats,
                           float bf, float *u_right, float *out_depth);
 
+/* ---- Tracking-thread matchers on flattened inputs (orb_oracle_match.c) ---- */
+typedef struct orc_grid orc_grid;
+typedef struct orc_camera { float fx, fy, cx, cy, bf, mb; } orc_camera;
+/* what Frame::isInFrustum leaves in a MapPoint (mbTrackInView, mTrackProjX/Y/XR, mnTrackScaleLevel, mTrackViewCos) */
+typedef struct orc_track_point { int32_t in_view; float proj_x, proj_y, proj_xr; int32_t level; float view_cos; } orc_track_point;
+
+orc_grid *orc_grid_create(const orc_keypoint *keys_un, int n, float min_x, float max_x, float min_y, float max_y);
+void orc_grid_destroy(orc_grid *g);
+int orc_features_in_area(const orc_grid *g, float x, float y, float r, int min_level, int max_level, int32_t *out, int cap);
+void orc_three_maxima(const int32_t *histo_sizes, int L, int *ind1, int *ind2, int *ind3);
+float orc_log_det(float x);
+int orc_predict_scale(float max_distance, float current_dist, float log_scale_factor, int n_levels);
+int orc_search_by_projection_last(const orc_grid *g, const float *u_right_cur, const uint8_t *desc_cur,
+                                  const float *scale_factors, const orc_camera *cam,
+                                  const float *Tcw_cur, const float *Tcw_last,
+                                  int n_last, const float *last_pos, const uint8_t *last_desc,
+                                  const int32_t *last_valid, const int32_t *last_obs, const int32_t *last_octave,
+                                  const float *last_angle, const uint8_t *cur_has_obs_in,
+                                  float th, int mono, int check_ori, int32_t *cur_match);
+int orc_is_in_frustum(const float *Tcw, const orc_camera *cam, float min_x, float max_x, float min_y, float max_y,
+                      const float *pos, const float *normal, float max_dist_inv, float min_dist_inv, float max_distance,
+                      float viewing_cos_limit, float log_scale_factor, int n_levels, orc_track_point *out);
+int orc_search_by_projection_points(const orc_grid *g, const float *u_right_cur, const uint8_t *desc_cur,
+                                    const float *scale_factors, int n_pts, const orc_track_point *pts,
+                                    const uint8_t *pt_desc, const int32_t *pt_obs, const uint8_t *cur_has_obs_in,
+                                    float th, float nnratio, int32_t *cur_match);
+int orc_search_by_projection_kf(const orc_grid *g, const uint8_t *desc_cur, const float *scale_factors,
+                                const orc_camera *cam, const float *Tcw_cur, float log_scale_factor, int n_levels,
+                                int n_kf, const float *kf_pos, const uint8_t *kf_desc, const int32_t *kf_valid,
+                                const float *kf_angle, const float *kf_max_distance, const float *kf_min_distance,
+                                const uint8_t *cur_has_point_in, float th, int orb_dist, int check_ori, int32_t *cur_match);
+int orc_search_for_initialization(const orc_keypoint *keys1, const uint8_t *desc1, int n1,
+                                  const orc_grid *g2, const uint8_t *desc2,
+                                  float *prev_matched, int window_size, float nnratio, int check_ori, int32_t *matches12);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,8 @@ EXPORTS = [
     "orbfe_enqueue_stereo", "orbfe_synchronize", "orbfe_fetch_image", "orbfe_fetch_counts",
     "orbfe_device_buffers", "orbfe_fetch_candidates", "orbfe_hamming_matrix",
     "orbfe_set_profiling", "orbfe_stage_name", "orbfe_stage_times", "orbfe_set_streams",
+    "orbfe_features_in_area", "orbfe_three_maxima", "orbfe_search_by_projection_last", "orbfe_is_in_frustum",
+    "orbfe_search_by_projection_points", "orbfe_search_by_projection_kf", "orbfe_search_for_initialization",
 ]
 NUM_STAGES = 8
 
@@ -38,6 +40,14 @@ class Params(C.Structure):
                 ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
                 ("bf", C.c_float), ("device", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
                 ("max_images", C.c_int32)]
+
+
+class FrameView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("keys_un", C.c_void_p), ("u_right", C.c_void_p), ("descriptors", C.c_void_p),
+                ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float)]
+
+
+TP_DTYPE = np.dtype([("in_view", "<i4"), ("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("level", "<i4"), ("view_cos", "<f4")])
 
 
 class OrbfeError(RuntimeError):
@@ -91,6 +101,20 @@ def load():
     L.orbfe_stage_name.restype = C.c_char_p; L.orbfe_stage_name.argtypes = [C.c_int]
     L.orbfe_stage_times.restype = C.c_int; L.orbfe_stage_times.argtypes = [vp, vp, C.POINTER(C.c_int), C.c_int]
     L.orbfe_set_streams.restype = C.c_int; L.orbfe_set_streams.argtypes = [vp, C.c_int]
+    fvp, ip = C.POINTER(FrameView), C.POINTER(C.c_int)
+    L.orbfe_features_in_area.restype = C.c_int
+    L.orbfe_features_in_area.argtypes = [vp, fvp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, vp, C.c_int, ip]
+    L.orbfe_three_maxima.restype = C.c_int; L.orbfe_three_maxima.argtypes = [vp, C.c_int, ip, ip, ip]
+    L.orbfe_search_by_projection_last.restype = C.c_int
+    L.orbfe_search_by_projection_last.argtypes = [vp, fvp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, ip]
+    L.orbfe_is_in_frustum.restype = C.c_int
+    L.orbfe_is_in_frustum.argtypes = [vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, vp, vp, vp, vp, C.c_float, vp]
+    L.orbfe_search_by_projection_points.restype = C.c_int
+    L.orbfe_search_by_projection_points.argtypes = [vp, fvp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float, vp, ip]
+    L.orbfe_search_by_projection_kf.restype = C.c_int
+    L.orbfe_search_by_projection_kf.argtypes = [vp, fvp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, ip]
+    L.orbfe_search_for_initialization.restype = C.c_int
+    L.orbfe_search_for_initialization.argtypes = [vp, fvp, fvp, vp, C.c_int, C.c_float, C.c_int, vp, ip]
     _lib = L
     return L
 
@@ -237,6 +261,66 @@ class Context:
         self._check(self.L.orbfe_stage_times(self.h, _p(ms), C.byref(calls), int(reset)))
         names = [self.L.orbfe_stage_name(i).decode() for i in range(NUM_STAGES)]
         return dict(zip(names, ms.tolist())), calls.value
+
+    # ---- Tracking-thread matchers (flattened inputs; see include/orbfe.h) ----
+    def _view(self, keys_un, u_right, desc, bounds):
+        k = np.ascontiguousarray(keys_un, KP_DTYPE); d = np.ascontiguousarray(desc, np.uint8)
+        ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        fv = FrameView(len(k), _p(k), None if ur is None else _p(ur), _p(d), *[float(b) for b in bounds])
+        fv._keep = (k, d, ur)
+        return fv
+
+    def features_in_area(self, view, x, y, r, min_level=-1, max_level=-1):
+        out = np.zeros(max(view.n, 1), np.int32); n = C.c_int()
+        self._check(self.L.orbfe_features_in_area(self.h, C.byref(view), x, y, r, min_level, max_level, _p(out), len(out), C.byref(n)))
+        return out[: n.value].copy()
+
+    def search_by_projection_last(self, view, Tcw_cur, Tcw_last, last_pos, last_desc, last_valid, last_obs, last_octave, last_angle,
+                                  cur_has_obs, th, mono, check_ori):
+        tc = np.ascontiguousarray(Tcw_cur, np.float32); tl = np.ascontiguousarray(Tcw_last, np.float32)
+        lp = np.ascontiguousarray(last_pos, np.float32); ld = np.ascontiguousarray(last_desc, np.uint8)
+        lv = np.ascontiguousarray(last_valid, np.int32); lo = np.ascontiguousarray(last_obs, np.int32)
+        loc = np.ascontiguousarray(last_octave, np.int32); la = np.ascontiguousarray(last_angle, np.float32)
+        ho = None if cur_has_obs is None else np.ascontiguousarray(cur_has_obs, np.uint8)
+        out = np.zeros(max(view.n, 1), np.int32); nm = C.c_int()
+        self._check(self.L.orbfe_search_by_projection_last(self.h, C.byref(view), _p(tc), _p(tl), len(lv), _p(lp), _p(ld), _p(lv), _p(lo),
+                                                           _p(loc), _p(la), None if ho is None else _p(ho), th, int(mono), int(check_ori),
+                                                           _p(out), C.byref(nm)))
+        return out[: view.n].copy(), nm.value
+
+    def is_in_frustum(self, Tcw, bounds, pos, normal, max_distance, min_distance, viewing_cos_limit):
+        tc = np.ascontiguousarray(Tcw, np.float32); pos = np.ascontiguousarray(pos, np.float32); nr = np.ascontiguousarray(normal, np.float32)
+        mx = np.ascontiguousarray(max_distance, np.float32); mn = np.ascontiguousarray(min_distance, np.float32)
+        out = np.zeros(len(pos), TP_DTYPE)
+        self._check(self.L.orbfe_is_in_frustum(self.h, _p(tc), bounds[0], bounds[1], bounds[2], bounds[3], len(pos), _p(pos), _p(nr), _p(mx),
+                                               _p(mn), viewing_cos_limit, _p(out)))
+        return out
+
+    def search_by_projection_points(self, view, pts, pt_desc, pt_obs, cur_has_obs, th, nnratio):
+        pts = np.ascontiguousarray(pts, TP_DTYPE); pd = np.ascontiguousarray(pt_desc, np.uint8); po = np.ascontiguousarray(pt_obs, np.int32)
+        ho = None if cur_has_obs is None else np.ascontiguousarray(cur_has_obs, np.uint8)
+        out = np.zeros(max(view.n, 1), np.int32); nm = C.c_int()
+        self._check(self.L.orbfe_search_by_projection_points(self.h, C.byref(view), len(pts), _p(pts), _p(pd), _p(po),
+                                                             None if ho is None else _p(ho), th, nnratio, _p(out), C.byref(nm)))
+        return out[: view.n].copy(), nm.value
+
+    def search_by_projection_kf(self, view, Tcw_cur, kf_pos, kf_desc, kf_valid, kf_angle, kf_max_distance, kf_min_distance, cur_has_point,
+                                th, orb_dist, check_ori):
+        tc = np.ascontiguousarray(Tcw_cur, np.float32); kp = np.ascontiguousarray(kf_pos, np.float32)
+        kd = np.ascontiguousarray(kf_desc, np.uint8); kv = np.ascontiguousarray(kf_valid, np.int32); ka = np.ascontiguousarray(kf_angle, np.float32)
+        kmx = np.ascontiguousarray(kf_max_distance, np.float32); kmn = np.ascontiguousarray(kf_min_distance, np.float32)
+        hp = None if cur_has_point is None else np.ascontiguousarray(cur_has_point, np.uint8)
+        out = np.zeros(max(view.n, 1), np.int32); nm = C.c_int()
+        self._check(self.L.orbfe_search_by_projection_kf(self.h, C.byref(view), _p(tc), len(kv), _p(kp), _p(kd), _p(kv), _p(ka), _p(kmx), _p(kmn),
+                                                         None if hp is None else _p(hp), th, orb_dist, int(check_ori), _p(out), C.byref(nm)))
+        return out[: view.n].copy(), nm.value
+
+    def search_for_initialization(self, view1, view2, prev_matched, window_size, nnratio, check_ori):
+        pm = np.ascontiguousarray(prev_matched, np.float32).copy()
+        out = np.zeros(max(view1.n, 1), np.int32); nm = C.c_int()
+        self._check(self.L.orbfe_search_for_initialization(self.h, C.byref(view1), C.byref(view2), _p(pm), window_size, nnratio,
+                                                           int(check_ori), _p(out), C.byref(nm)))
+        return out[: view1.n].copy(), pm, nm.value
 
     def hamming_matrix(self, a: np.ndarray, b: np.ndarray):
         a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)

@@ -6,6 +6,7 @@
 // There is no CPU compute path here: without a HIP device orbfe_create fails.
 #include "../../include/orbfe.h"
 #include "orbfe_device.h"
+#include "orbfe_host.h"
 
 #include <cfloat>
 #include <climits>
@@ -48,6 +49,7 @@ struct orbfe_context {
     float scale[ORBFE_MAX_LEVELS], inv_scale[ORBFE_MAX_LEVELS], sigma2[ORBFE_MAX_LEVELS], inv_sigma2[ORBFE_MAX_LEVELS];
     int32_t feats[ORBFE_MAX_LEVELS];
     std::vector<void *> allocs;
+    orbfe_match_state *match = nullptr;
     char err[512];
 };
 
@@ -64,6 +66,25 @@ static int fail(orbfe_context *ctx, int code, const char *fmt, ...)
     if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s", msg);
     return code;
 }
+
+int orbfe_fail(orbfe_context *ctx, int code, const char *fmt, ...)
+{
+    char msg[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(msg, sizeof(msg), fmt, ap);
+    va_end(ap);
+    return fail(ctx, code, "%s", msg);
+}
+orbfe_match_state *orbfe_ctx_match_state(orbfe_context *ctx)
+{
+    if (!ctx->match) ctx->match = orbfe_match_state_create();
+    return ctx->match;
+}
+hipStream_t orbfe_ctx_stream(orbfe_context *ctx) { return ctx->stream; }
+int orbfe_ctx_device(const orbfe_context *ctx) { return ctx->params.device; }
+const orbfe_params *orbfe_ctx_params(const orbfe_context *ctx) { return &ctx->params; }
+const float *orbfe_ctx_scale_factors(const orbfe_context *ctx) { return ctx->scale; }
 
 #define HIP_TRY(ctx, expr)                                                                      \
     do {                                                                                        \
@@ -414,6 +435,7 @@ extern "C" void orbfe_destroy(orbfe_context *ctx)
         if (ctx->ev_join[g]) hipEventDestroy(ctx->ev_join[g]);
     }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->match) orbfe_match_state_destroy(ctx->match);
     if (ctx->d_depth_in) hipFree(ctx->d_depth_in);
     if (ctx->d_ham) hipFree(ctx->d_ham);
     if (ctx->stream) hipStreamDestroy(ctx->stream);

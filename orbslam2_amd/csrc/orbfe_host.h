@@ -1,0 +1,15 @@
+// orbfe_host.h -- internal host-side accessors shared by the translation units of liborbfe.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/orbfe.h"
+
+struct orbfe_match_state;
+orbfe_match_state *orbfe_match_state_create();
+void orbfe_match_state_destroy(orbfe_match_state *s);
+
+int orbfe_fail(orbfe_context *ctx, int code, const char *fmt, ...);
+orbfe_match_state *orbfe_ctx_match_state(orbfe_context *ctx);
+hipStream_t orbfe_ctx_stream(orbfe_context *ctx);
+int orbfe_ctx_device(const orbfe_context *ctx);
+const orbfe_params *orbfe_ctx_params(const orbfe_context *ctx);
+const float *orbfe_ctx_scale_factors(const orbfe_context *ctx);

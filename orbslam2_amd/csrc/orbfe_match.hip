@@ -1,0 +1,700 @@
+// orbfe_match.hip -- the Tracking-thread matchers.
+//
+// Split the way SURVEY.md §7.1 prescribes: the data-parallel part -- Frame grid, window query
+// (Frame::GetFeaturesInArea, src/Frame.cc:328-381) and the Hamming distance of every (query, candidate)
+// pair -- runs on the GPU, one wave per query; the sequentially greedy resolution (a keypoint taken by an
+// earlier map point changes what a later one may take: src/ORBmatcher.cc:85-87,1399-1401,1537-1538,
+// 439-440) runs in order on the host over the returned candidate lists.  A candidate is one 64-bit key
+//      dist << 36 | ix << 30 | iy << 24 | idx << 8 | octave
+// so "first minimum in GetFeaturesInArea order" (cell-x major, cell-y, insertion = keypoint index) is
+// simply the smallest key, independent of the order in which the GPU emitted the list.
+// Projection / frustum arithmetic is host code in the reference's evaluation order (contract Q4: no FMA
+// contraction; cv::Mat 3x3*3x1+t as OpenCV's small-matrix gemm path; PredictScale's log through one
+// deterministic routine) -- the same statements as oracle/orb_oracle_match.c, written independently.
+#include "../../include/orbfe.h"
+#include "orbfe_device.h"
+#include "orbfe_host.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#define GRID_COLS 64 // FRAME_GRID_COLS include/Frame.h:36
+#define GRID_ROWS 48 // FRAME_GRID_ROWS include/Frame.h:37
+#define HISTO_LENGTH 30
+#define TH_LOW 50
+#define TH_HIGH 100
+
+struct MatchQuery { // 32 bytes
+    float u, v, r;
+    int min_level, max_level;
+    float ur, ur_rad; // right-image check (mvuRight), used when flags & 2
+    int flags;        // bit0: valid query, bit1: apply the u_right check
+};
+
+struct MatchFrame {
+    const KeyPointPOD *keys; // mvKeysUn
+    const uint8_t *desc;
+    const float *u_right;    // may be null
+    int n;
+    float min_x, min_y, inv_w, inv_h;
+    int *cell_cnt, *cell_off, *cell_idx; // CSR over ix * GRID_ROWS + iy
+};
+
+// ---------------------------------------------------------------------------------------------
+// device
+// ---------------------------------------------------------------------------------------------
+// Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:231-246,383-393; Q6: round(), column 64 dropped)
+__global__ __launch_bounds__(256) void grid_count_kernel(MatchFrame f, int *cell_of)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= f.n) return;
+    const int px = (int)roundf(__fmul_rn(__fsub_rn(f.keys[i].x, f.min_x), f.inv_w));
+    const int py = (int)roundf(__fmul_rn(__fsub_rn(f.keys[i].y, f.min_y), f.inv_h));
+    int c = -1;
+    if (px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS) {
+        c = px * GRID_ROWS + py;
+        atomicAdd(&f.cell_cnt[c], 1);
+    }
+    cell_of[i] = c;
+}
+
+__global__ __launch_bounds__(1024) void grid_scan_kernel(MatchFrame f)
+{
+    __shared__ int s[1024];
+    const int tid = threadIdx.x;
+    const int per = (GRID_COLS * GRID_ROWS + 1023) / 1024; // 3
+    int sum = 0;
+    for (int k = 0; k < per; k++) {
+        const int c = tid * per + k;
+        if (c < GRID_COLS * GRID_ROWS) sum += f.cell_cnt[c];
+    }
+    s[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = tid >= o ? s[tid - o] : 0;
+        __syncthreads();
+        s[tid] += v;
+        __syncthreads();
+    }
+    int run = s[tid] - sum;
+    for (int k = 0; k < per; k++) {
+        const int c = tid * per + k;
+        if (c < GRID_COLS * GRID_ROWS) {
+            const int v = f.cell_cnt[c];
+            f.cell_off[c] = run;
+            f.cell_cnt[c] = run; // becomes the fill cursor
+            run += v;
+        }
+    }
+    if (tid == 1023) f.cell_off[GRID_COLS * GRID_ROWS] = s[1023];
+}
+
+__global__ __launch_bounds__(256) void grid_fill_kernel(MatchFrame f, const int *cell_of)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= f.n) return;
+    const int c = cell_of[i];
+    if (c >= 0) f.cell_idx[atomicAdd(&f.cell_cnt[c], 1)] = i; // order inside a cell is irrelevant (keys carry it)
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_excl_scan(int v, int lane)
+{
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    return inc - v;
+}
+
+// One wave per query: Frame::GetFeaturesInArea + DescriptorDistance of every hit.
+__global__ __launch_bounds__(256) void window_candidates_kernel(MatchFrame f, const MatchQuery *__restrict__ q, const uint8_t *__restrict__ qdesc,
+                                                                int nq, int *__restrict__ q_off, int *__restrict__ q_cnt,
+                                                                unsigned long long *__restrict__ list, int *__restrict__ cursor, int list_cap)
+{
+    const int iq = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (iq >= nq) return;
+    const MatchQuery Q = q[iq];
+    int total = 0, ncx = 0, ncy = 0, min_cx = 0, min_cy = 0;
+    if (Q.flags & 1) {
+        int v = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.u, f.min_x), Q.r), f.inv_w));
+        min_cx = v > 0 ? v : 0;
+        v = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.u, f.min_x), Q.r), f.inv_w));
+        const int max_cx = v < GRID_COLS - 1 ? v : GRID_COLS - 1;
+        v = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.v, f.min_y), Q.r), f.inv_h));
+        min_cy = v > 0 ? v : 0;
+        v = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.v, f.min_y), Q.r), f.inv_h));
+        const int max_cy = v < GRID_ROWS - 1 ? v : GRID_ROWS - 1;
+        if (min_cx < GRID_COLS && max_cx >= 0 && min_cy < GRID_ROWS && max_cy >= 0) {
+            ncx = max_cx - min_cx + 1;
+            ncy = max_cy - min_cy + 1;
+        }
+    }
+    const int ncells = ncx > 0 && ncy > 0 ? ncx * ncy : 0;
+    const bool check_levels = (Q.min_level > 0) || (Q.max_level >= 0); // Q5, literally
+    // pass 1: count hits per lane (lane owns cells lane, lane + 64, ...)
+    int mine = 0;
+    for (int c = lane; c < ncells; c += 64) {
+        const int cell = (min_cx + c / ncy) * GRID_ROWS + (min_cy + c % ncy);
+        for (int j = f.cell_off[cell]; j < f.cell_off[cell + 1]; j++) {
+            const KeyPointPOD kp = f.keys[f.cell_idx[j]];
+            if (check_levels && (kp.octave < Q.min_level || (Q.max_level >= 0 && kp.octave > Q.max_level))) continue;
+            if (fabsf(__fsub_rn(kp.x, Q.u)) < Q.r && fabsf(__fsub_rn(kp.y, Q.v)) < Q.r) mine++;
+        }
+    }
+    total = wave_sum(mine);
+    int base = 0;
+    if (lane == 0) {
+        base = total > 0 ? atomicAdd(cursor, total) : 0;
+        q_off[iq] = base;
+        q_cnt[iq] = (base + total <= list_cap) ? total : -total; // negative: list capacity exceeded
+    }
+    base = __shfl(base, 0, 64);
+    if (total == 0 || base + total > list_cap) return;
+    int pos = base + wave_excl_scan(mine, lane);
+    uint32_t qd[8];
+    {
+        const uint32_t *p = (const uint32_t *)(qdesc + (size_t)iq * 32);
+#pragma unroll
+        for (int k = 0; k < 8; k++) qd[k] = p[k];
+    }
+    for (int c = lane; c < ncells; c += 64) {
+        const int ix = min_cx + c / ncy, iy = min_cy + c % ncy;
+        const int cell = ix * GRID_ROWS + iy;
+        for (int j = f.cell_off[cell]; j < f.cell_off[cell + 1]; j++) {
+            const int idx = f.cell_idx[j];
+            const KeyPointPOD kp = f.keys[idx];
+            if (check_levels && (kp.octave < Q.min_level || (Q.max_level >= 0 && kp.octave > Q.max_level))) continue;
+            if (!(fabsf(__fsub_rn(kp.x, Q.u)) < Q.r && fabsf(__fsub_rn(kp.y, Q.v)) < Q.r)) continue;
+            unsigned dist = 0;
+            const uint32_t *p = (const uint32_t *)(f.desc + (size_t)idx * 32);
+#pragma unroll
+            for (int k = 0; k < 8; k++) dist += __popc(qd[k] ^ p[k]);
+            // the mvuRight gate (src/ORBmatcher.cc:93-98,1403-1409) is a pure function of the pair: mark it
+            if ((Q.flags & 2) && f.u_right && f.u_right[idx] > 0 && fabsf(__fsub_rn(Q.ur, f.u_right[idx])) > Q.ur_rad) dist = 511;
+            list[pos++] = ((unsigned long long)dist << 36) | ((unsigned long long)ix << 30) | ((unsigned long long)iy << 24) |
+                          ((unsigned long long)idx << 8) | (unsigned long long)(kp.octave & 255);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host: device session for one frame + candidate query
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return 0;
+        if (p) hipFree(p);
+        p = nullptr; bytes = 0;
+        if (hipMalloc(&p, need) != hipSuccess) return -1;
+        bytes = need;
+        return 0;
+    }
+    ~DevBuf() { if (p) hipFree(p); }
+};
+
+} // namespace
+
+struct orbfe_match_state {
+    DevBuf keys, desc, uright, cells, cell_of, queries, qdesc, qoff, qcnt, list, cursor;
+    std::vector<int> h_off, h_cnt;
+    std::vector<unsigned long long> h_list;
+};
+
+static orbfe_match_state *match_state(orbfe_context *ctx) { return orbfe_ctx_match_state(ctx); }
+
+#define MTRY(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return orbfe_fail(ctx, ORBFE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+// Uploads the frame, builds its grid on the device, runs the window query for `nq` queries and leaves the
+// per-query candidate keys in st->h_list / h_off / h_cnt.
+static int run_window_queries(orbfe_context *ctx, const orbfe_frame_view *fv, const std::vector<MatchQuery> &queries,
+                              const std::vector<uint8_t> &qdesc)
+{
+    orbfe_match_state *st = match_state(ctx);
+    hipStream_t s = orbfe_ctx_stream(ctx);
+    const int n = fv->n, nq = (int)queries.size();
+    st->h_off.assign(nq, 0); st->h_cnt.assign(nq, 0); st->h_list.clear();
+    if (n <= 0 || nq == 0) return ORBFE_OK;
+    if (n > 65535) return orbfe_fail(ctx, ORBFE_ERR_UNSUPPORTED, "frames with more than 65535 keypoints are not supported by the matchers");
+    MTRY(ctx, hipSetDevice(orbfe_ctx_device(ctx)));
+    const size_t ncell = GRID_COLS * GRID_ROWS;
+    if (st->keys.ensure(sizeof(KeyPointPOD) * n) || st->desc.ensure((size_t)32 * n) || st->uright.ensure(sizeof(float) * n) ||
+        st->cells.ensure(sizeof(int) * (2 * ncell + 2 + n)) || st->cell_of.ensure(sizeof(int) * n) ||
+        st->queries.ensure(sizeof(MatchQuery) * nq) || st->qdesc.ensure((size_t)32 * nq) || st->qoff.ensure(sizeof(int) * nq) ||
+        st->qcnt.ensure(sizeof(int) * nq) || st->cursor.ensure(sizeof(int)))
+        return orbfe_fail(ctx, ORBFE_ERR_HIP, "matcher scratch allocation failed");
+    MatchFrame f;
+    f.keys = (const KeyPointPOD *)st->keys.p; f.desc = (const uint8_t *)st->desc.p;
+    f.u_right = fv->u_right ? (const float *)st->uright.p : nullptr;
+    f.n = n; f.min_x = fv->min_x; f.min_y = fv->min_y;
+    f.inv_w = (float)GRID_COLS / (fv->max_x - fv->min_x); // mfGridElementWidthInv, src/Frame.cc:99
+    f.inv_h = (float)GRID_ROWS / (fv->max_y - fv->min_y);
+    f.cell_cnt = (int *)st->cells.p; f.cell_off = f.cell_cnt + ncell; f.cell_idx = f.cell_off + ncell + 1;
+    MTRY(ctx, hipMemcpyAsync(st->keys.p, fv->keys_un, sizeof(KeyPointPOD) * n, hipMemcpyHostToDevice, s));
+    MTRY(ctx, hipMemcpyAsync(st->desc.p, fv->descriptors, (size_t)32 * n, hipMemcpyHostToDevice, s));
+    if (fv->u_right) MTRY(ctx, hipMemcpyAsync(st->uright.p, fv->u_right, sizeof(float) * n, hipMemcpyHostToDevice, s));
+    MTRY(ctx, hipMemcpyAsync(st->queries.p, queries.data(), sizeof(MatchQuery) * nq, hipMemcpyHostToDevice, s));
+    MTRY(ctx, hipMemcpyAsync(st->qdesc.p, qdesc.data(), (size_t)32 * nq, hipMemcpyHostToDevice, s));
+    MTRY(ctx, hipMemsetAsync(f.cell_cnt, 0, sizeof(int) * ncell, s));
+    hipLaunchKernelGGL(grid_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, f, (int *)st->cell_of.p);
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, s, f);
+    hipLaunchKernelGGL(grid_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, s, f, (const int *)st->cell_of.p);
+    // candidate list capacity: grown and the query re-run if a frame overflows it
+    size_t cap = st->list.bytes / 8;
+    if (cap < (size_t)nq * 64) cap = (size_t)nq * 64;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (st->list.ensure(cap * 8)) return orbfe_fail(ctx, ORBFE_ERR_HIP, "candidate list allocation failed");
+        MTRY(ctx, hipMemsetAsync(st->cursor.p, 0, sizeof(int), s));
+        hipLaunchKernelGGL(window_candidates_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, f, (const MatchQuery *)st->queries.p,
+                           (const uint8_t *)st->qdesc.p, nq, (int *)st->qoff.p, (int *)st->qcnt.p,
+                           (unsigned long long *)st->list.p, (int *)st->cursor.p, (int)std::min<size_t>(cap, INT_MAX));
+        int total = 0;
+        MTRY(ctx, hipMemcpyAsync(&total, st->cursor.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        MTRY(ctx, hipStreamSynchronize(s));
+        MTRY(ctx, hipGetLastError());
+        if ((size_t)total <= cap) {
+            st->h_list.resize(total);
+            MTRY(ctx, hipMemcpy(st->h_off.data(), st->qoff.p, sizeof(int) * nq, hipMemcpyDeviceToHost));
+            MTRY(ctx, hipMemcpy(st->h_cnt.data(), st->qcnt.p, sizeof(int) * nq, hipMemcpyDeviceToHost));
+            if (total > 0) MTRY(ctx, hipMemcpy(st->h_list.data(), st->list.p, sizeof(unsigned long long) * total, hipMemcpyDeviceToHost));
+            return ORBFE_OK;
+        }
+        cap = (size_t)total + 1024;
+    }
+    return orbfe_fail(ctx, ORBFE_ERR_CAPACITY, "candidate list overflow");
+}
+
+static inline int key_dist(unsigned long long k) { return (int)(k >> 36); }
+static inline int key_idx(unsigned long long k) { return (int)((k >> 8) & 0xffffu); }
+static inline int key_level(unsigned long long k) { return (int)(k & 0xffu); }
+
+// ---------------------------------------------------------------------------------------------
+// host arithmetic shared by the projection matchers (reference evaluation order, no contraction)
+// ---------------------------------------------------------------------------------------------
+// OPENCV-4.5.5-SEMANTICS: cv::Mat R*x+t for 3x3 * 3x1 CV_32F (small-matrix gemm path)
+static void rt_apply(const float *T, const float *x, float *out)
+{
+    for (int i = 0; i < 3; i++) {
+        const float t = (T[4 * i] * x[0] + T[4 * i + 1] * x[1]) + T[4 * i + 2] * x[2];
+        out[i] = t + T[4 * i + 3];
+    }
+}
+static void camera_center(const float *T, float *ow) // -Rcw.t()*tcw
+{
+    for (int i = 0; i < 3; i++) ow[i] = ((-T[i]) * T[3] + (-T[4 + i]) * T[7]) + (-T[8 + i]) * T[11];
+}
+// deterministic log for MapPoint::PredictScale (contract Q4)
+static float log_det(float xf)
+{
+    double x = (double)xf;
+    int e;
+    double m = frexp(x, &e);
+    if (m < 0.70710678118654752440) { m *= 2.0; e -= 1; }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double z = s * s;
+    double p = 1.0 / 27.0;
+    for (int k = 25; k >= 3; k -= 2) p = p * z + 1.0 / (double)k;
+    p = p * z + 1.0;
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    return (float)((double)e * LN2_HI + (2.0 * s * p + (double)e * LN2_LO));
+}
+static int predict_scale(float max_distance, float current_dist, float log_sf, int n_levels) // src/MapPoint.cc:402-417
+{
+    const float ratio = max_distance / current_dist;
+    int n_scale = (int)ceilf(log_det(ratio) / log_sf);
+    if (n_scale < 0) n_scale = 0;
+    else if (n_scale >= n_levels) n_scale = n_levels - 1;
+    return n_scale;
+}
+static int rot_bin(float a1, float a2) // Q8: 30 slots, bin = round(rot / 30)
+{
+    const float factor = 1.0f / HISTO_LENGTH;
+    float rot = a1 - a2;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)roundf(rot * factor);
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+extern "C" int orbfe_three_maxima(const int32_t *histo_sizes, int L, int *ind1, int *ind2, int *ind3)
+{
+    if (!histo_sizes || !ind1 || !ind2 || !ind3 || L < 0) return ORBFE_ERR_INVALID;
+    int max1 = 0, max2 = 0, max3 = 0; // ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1597-1638
+    *ind1 = *ind2 = *ind3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = histo_sizes[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; *ind3 = *ind2; *ind2 = *ind1; *ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; *ind3 = *ind2; *ind2 = i; }
+        else if (s > max3) { max3 = s; *ind3 = i; }
+    }
+    if ((float)max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
+    else if ((float)max3 < 0.1f * (float)max1) { *ind3 = -1; }
+    return ORBFE_OK;
+}
+
+struct RotHist {
+    std::vector<int> v[HISTO_LENGTH];
+    void three(int &i1, int &i2, int &i3) const
+    {
+        int32_t sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int32_t)v[i].size();
+        orbfe_three_maxima(sizes, HISTO_LENGTH, &i1, &i2, &i3);
+    }
+};
+
+static int check_view(orbfe_context *ctx, const orbfe_frame_view *fv)
+{
+    if (!ctx || !fv || fv->n < 0 || (fv->n > 0 && (!fv->keys_un || !fv->descriptors)) || !(fv->max_x > fv->min_x) || !(fv->max_y > fv->min_y))
+        return orbfe_fail(ctx, ORBFE_ERR_INVALID, "bad frame view");
+    return ORBFE_OK;
+}
+
+// Frame::GetFeaturesInArea (src/Frame.cc:328-381) for one window, in the reference's result order.
+extern "C" int orbfe_features_in_area(orbfe_context *ctx, const orbfe_frame_view *fv, float x, float y, float r,
+                                      int min_level, int max_level, int32_t *out, int cap, int *n)
+{
+    int rc = check_view(ctx, fv);
+    if (rc != ORBFE_OK) return rc;
+    if (!n) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    std::vector<MatchQuery> q(1);
+    q[0] = MatchQuery{x, y, r, min_level, max_level, 0.f, 0.f, 1};
+    std::vector<uint8_t> qd(32, 0);
+    rc = run_window_queries(ctx, fv, q, qd);
+    if (rc != ORBFE_OK) return rc;
+    orbfe_match_state *st = match_state(ctx);
+    std::vector<unsigned long long> keys(st->h_list.begin() + st->h_off[0], st->h_list.begin() + st->h_off[0] + st->h_cnt[0]);
+    for (auto &k : keys) k &= ((1ull << 36) - 1); // drop the distance: order = (ix, iy, idx)
+    std::sort(keys.begin(), keys.end());
+    *n = (int)keys.size();
+    if ((int)keys.size() > cap) return orbfe_fail(ctx, ORBFE_ERR_CAPACITY, "window holds %d keypoints, caller buffer %d", (int)keys.size(), cap);
+    for (size_t i = 0; i < keys.size(); i++) out[i] = key_idx(keys[i]);
+    return ORBFE_OK;
+}
+
+// ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono), src/ORBmatcher.cc:1324-1466
+extern "C" int orbfe_search_by_projection_last(orbfe_context *ctx, const orbfe_frame_view *cur,
+                                               const float *Tcw_cur, const float *Tcw_last, int n_last,
+                                               const float *last_pos, const uint8_t *last_desc, const int32_t *last_valid,
+                                               const int32_t *last_obs, const int32_t *last_octave, const float *last_angle,
+                                               const uint8_t *cur_has_obs, float th, int mono, int check_ori,
+                                               int32_t *cur_match, int *nmatches)
+{
+    int rc = check_view(ctx, cur);
+    if (rc != ORBFE_OK) return rc;
+    if (!Tcw_cur || !Tcw_last || !cur_match || !nmatches || n_last < 0 ||
+        (n_last > 0 && (!last_pos || !last_desc || !last_valid || !last_obs || !last_octave || !last_angle)))
+        return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    const orbfe_params *P = orbfe_ctx_params(ctx);
+    const float *sf = orbfe_ctx_scale_factors(ctx);
+    const float mb = P->fx != 0.f ? P->bf / P->fx : 0.f;
+    const int N = cur->n;
+    float twc[3], tlc[3];
+    camera_center(Tcw_cur, twc);
+    rt_apply(Tcw_last, twc, tlc);
+    const bool forward = tlc[2] > mb && !mono, backward = -tlc[2] > mb && !mono;
+    std::vector<MatchQuery> q(n_last);
+    std::vector<uint8_t> qd((size_t)32 * (n_last > 0 ? n_last : 1));
+    for (int i = 0; i < n_last; i++) {
+        MatchQuery &Q = q[i];
+        Q = MatchQuery{0, 0, 0, 0, -1, 0, 0, 0};
+        if (!last_valid[i]) continue;
+        if (last_octave[i] < 0 || last_octave[i] >= P->nlevels) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "octave out of range");
+        float xc[3];
+        rt_apply(Tcw_cur, last_pos + 3 * i, xc);
+        const float invzc = (float)(1.0 / (double)xc[2]);
+        if (invzc < 0) continue;
+        const float u = P->fx * xc[0] * invzc + P->cx;
+        const float v = P->fy * xc[1] * invzc + P->cy;
+        if (u < cur->min_x || u > cur->max_x) continue;
+        if (v < cur->min_y || v > cur->max_y) continue;
+        const int oct = last_octave[i];
+        const float radius = th * sf[oct];
+        Q.u = u; Q.v = v; Q.r = radius; Q.flags = 1 | 2;
+        Q.ur = u - P->bf * invzc; Q.ur_rad = radius;
+        if (forward) { Q.min_level = oct; Q.max_level = -1; }
+        else if (backward) { Q.min_level = 0; Q.max_level = oct; }
+        else { Q.min_level = oct - 1; Q.max_level = oct + 1; }
+        memcpy(&qd[(size_t)32 * i], last_desc + (size_t)32 * i, 32);
+    }
+    rc = run_window_queries(ctx, cur, q, qd);
+    if (rc != ORBFE_OK) return rc;
+    orbfe_match_state *st = match_state(ctx);
+    std::vector<uint8_t> has_obs(N > 0 ? N : 1, 0);
+    for (int i = 0; i < N; i++) { has_obs[i] = cur_has_obs ? cur_has_obs[i] : 0; cur_match[i] = -1; }
+    RotHist rh;
+    int nm = 0;
+    for (int i = 0; i < n_last; i++) { // sequential greedy resolve
+        unsigned long long best = ~0ull;
+        for (int k = 0; k < st->h_cnt[i]; k++) {
+            const unsigned long long key = st->h_list[st->h_off[i] + k];
+            if (key_dist(key) >= 256 || has_obs[key_idx(key)]) continue; // 511 = failed the mvuRight gate
+            if (key < best) best = key;
+        }
+        if (best != ~0ull && key_dist(best) <= TH_HIGH) {
+            const int bi = key_idx(best);
+            cur_match[bi] = i;
+            has_obs[bi] = last_obs[i] > 0;
+            nm++;
+            if (check_ori) rh.v[rot_bin(last_angle[i], cur->keys_un[bi].angle)].push_back(bi);
+        }
+    }
+    if (check_ori) {
+        int i1, i2, i3;
+        rh.three(i1, i2, i3);
+        for (int b = 0; b < HISTO_LENGTH; b++)
+            if (b != i1 && b != i2 && b != i3)
+                for (int idx : rh.v[b]) { cur_match[idx] = -1; nm--; }
+    }
+    *nmatches = nm;
+    return ORBFE_OK;
+}
+
+// Frame::isInFrustum, src/Frame.cc:270-326, for n map points
+extern "C" int orbfe_is_in_frustum(orbfe_context *ctx, const float *Tcw, float min_x, float max_x, float min_y, float max_y,
+                                   int n, const float *pos, const float *normal, const float *max_distance,
+                                   const float *min_distance, float viewing_cos_limit, orbfe_track_point *out)
+{
+    if (!ctx || !Tcw || n < 0 || (n > 0 && (!pos || !normal || !max_distance || !min_distance || !out)))
+        return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    const orbfe_params *P = orbfe_ctx_params(ctx);
+    const float log_sf = logf((float)(double)P->scale_factor); // mfLogScaleFactor = log(mfScaleFactor), src/Frame.cc:71
+    float ow[3];
+    camera_center(Tcw, ow);
+    for (int i = 0; i < n; i++) {
+        orbfe_track_point &o = out[i];
+        o.in_view = 0; o.proj_x = o.proj_y = o.proj_xr = 0.f; o.level = 0; o.view_cos = 0.f;
+        float pc[3];
+        rt_apply(Tcw, pos + 3 * i, pc);
+        if (pc[2] < 0.0f) continue;
+        const float invz = 1.0f / pc[2];
+        const float u = P->fx * pc[0] * invz + P->cx;
+        const float v = P->fy * pc[1] * invz + P->cy;
+        if (u < min_x || u > max_x) continue;
+        if (v < min_y || v > max_y) continue;
+        float po[3];
+        for (int k = 0; k < 3; k++) po[k] = pos[3 * i + k] - ow[k];
+        const float dist = (float)sqrt((double)po[0] * po[0] + (double)po[1] * po[1] + (double)po[2] * po[2]);
+        if (dist < 0.8f * min_distance[i] || dist > 1.2f * max_distance[i]) continue;
+        const double dot = (double)po[0] * normal[3 * i] + (double)po[1] * normal[3 * i + 1] + (double)po[2] * normal[3 * i + 2];
+        const float view_cos = (float)(dot / (double)dist);
+        if (view_cos < viewing_cos_limit) continue;
+        o.in_view = 1;
+        o.proj_x = u; o.proj_xr = u - P->bf * invz; o.proj_y = v;
+        o.level = predict_scale(max_distance[i], dist, log_sf, P->nlevels);
+        o.view_cos = view_cos;
+    }
+    return ORBFE_OK;
+}
+
+// ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th), src/ORBmatcher.cc:43-135
+extern "C" int orbfe_search_by_projection_points(orbfe_context *ctx, const orbfe_frame_view *cur, int n_pts,
+                                                 const orbfe_track_point *pts, const uint8_t *pt_desc, const int32_t *pt_obs,
+                                                 const uint8_t *cur_has_obs, float th, float nnratio,
+                                                 int32_t *cur_match, int *nmatches)
+{
+    int rc = check_view(ctx, cur);
+    if (rc != ORBFE_OK) return rc;
+    if (!cur_match || !nmatches || n_pts < 0 || (n_pts > 0 && (!pts || !pt_desc || !pt_obs))) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    const orbfe_params *P = orbfe_ctx_params(ctx);
+    const float *sf = orbfe_ctx_scale_factors(ctx);
+    const int N = cur->n;
+    const bool b_factor = th != 1.0;
+    std::vector<MatchQuery> q(n_pts);
+    std::vector<uint8_t> qd((size_t)32 * (n_pts > 0 ? n_pts : 1));
+    for (int i = 0; i < n_pts; i++) {
+        MatchQuery &Q = q[i];
+        Q = MatchQuery{0, 0, 0, 0, -1, 0, 0, 0};
+        if (!pts[i].in_view) continue;
+        const int lvl = pts[i].level;
+        if (lvl < 0 || lvl >= P->nlevels) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "predicted level out of range");
+        float r = pts[i].view_cos > 0.998 ? 2.5f : 4.0f; // RadiusByViewingCos, :129-135
+        if (b_factor) r *= th;
+        Q.u = pts[i].proj_x; Q.v = pts[i].proj_y; Q.r = r * sf[lvl];
+        Q.min_level = lvl - 1; Q.max_level = lvl; Q.flags = 1 | 2;
+        Q.ur = pts[i].proj_xr; Q.ur_rad = r * sf[lvl];
+        memcpy(&qd[(size_t)32 * i], pt_desc + (size_t)32 * i, 32);
+    }
+    rc = run_window_queries(ctx, cur, q, qd);
+    if (rc != ORBFE_OK) return rc;
+    orbfe_match_state *st = match_state(ctx);
+    std::vector<uint8_t> has_obs(N > 0 ? N : 1, 0);
+    for (int i = 0; i < N; i++) { has_obs[i] = cur_has_obs ? cur_has_obs[i] : 0; cur_match[i] = -1; }
+    int nm = 0;
+    for (int i = 0; i < n_pts; i++) {
+        unsigned long long best = ~0ull, second = ~0ull; // two smallest (dist, order) keys == best / second of the loop
+        for (int k = 0; k < st->h_cnt[i]; k++) {
+            const unsigned long long key = st->h_list[st->h_off[i] + k];
+            if (key_dist(key) >= 256 || has_obs[key_idx(key)]) continue;
+            if (key < best) { second = best; best = key; }
+            else if (key < second) second = key;
+        }
+        if (best == ~0ull) continue;
+        const int best_dist = key_dist(best), best_level = key_level(best);
+        const int best_dist2 = second != ~0ull ? key_dist(second) : 256, best_level2 = second != ~0ull ? key_level(second) : -1;
+        if (best_dist <= TH_HIGH) {
+            if (best_level == best_level2 && (float)best_dist > nnratio * (float)best_dist2) continue;
+            cur_match[key_idx(best)] = i;
+            has_obs[key_idx(best)] = pt_obs[i] > 0;
+            nm++;
+        }
+    }
+    *nmatches = nm;
+    return ORBFE_OK;
+}
+
+// ORBmatcher::SearchByProjection(Frame&, KeyFrame*, set, th, ORBdist), src/ORBmatcher.cc:1468-1595
+extern "C" int orbfe_search_by_projection_kf(orbfe_context *ctx, const orbfe_frame_view *cur, const float *Tcw_cur, int n_kf,
+                                             const float *kf_pos, const uint8_t *kf_desc, const int32_t *kf_valid,
+                                             const float *kf_angle, const float *kf_max_distance, const float *kf_min_distance,
+                                             const uint8_t *cur_has_point, float th, int orb_dist, int check_ori,
+                                             int32_t *cur_match, int *nmatches)
+{
+    int rc = check_view(ctx, cur);
+    if (rc != ORBFE_OK) return rc;
+    if (!Tcw_cur || !cur_match || !nmatches || n_kf < 0 ||
+        (n_kf > 0 && (!kf_pos || !kf_desc || !kf_valid || !kf_angle || !kf_max_distance || !kf_min_distance)))
+        return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    const orbfe_params *P = orbfe_ctx_params(ctx);
+    const float *sf = orbfe_ctx_scale_factors(ctx);
+    const float log_sf = logf((float)(double)P->scale_factor);
+    const int N = cur->n;
+    float ow[3];
+    camera_center(Tcw_cur, ow);
+    std::vector<MatchQuery> q(n_kf);
+    std::vector<uint8_t> qd((size_t)32 * (n_kf > 0 ? n_kf : 1));
+    for (int i = 0; i < n_kf; i++) {
+        MatchQuery &Q = q[i];
+        Q = MatchQuery{0, 0, 0, 0, -1, 0, 0, 0};
+        if (!kf_valid[i]) continue;
+        float xc[3];
+        rt_apply(Tcw_cur, kf_pos + 3 * i, xc);
+        const float invzc = (float)(1.0 / (double)xc[2]);
+        const float u = P->fx * xc[0] * invzc + P->cx;
+        const float v = P->fy * xc[1] * invzc + P->cy;
+        if (u < cur->min_x || u > cur->max_x) continue;
+        if (v < cur->min_y || v > cur->max_y) continue;
+        float po[3];
+        for (int k = 0; k < 3; k++) po[k] = kf_pos[3 * i + k] - ow[k];
+        const float dist3d = (float)sqrt((double)po[0] * po[0] + (double)po[1] * po[1] + (double)po[2] * po[2]);
+        if (dist3d < 0.8f * kf_min_distance[i] || dist3d > 1.2f * kf_max_distance[i]) continue;
+        const int lvl = predict_scale(kf_max_distance[i], dist3d, log_sf, P->nlevels);
+        Q.u = u; Q.v = v; Q.r = th * sf[lvl]; Q.min_level = lvl - 1; Q.max_level = lvl + 1; Q.flags = 1;
+        memcpy(&qd[(size_t)32 * i], kf_desc + (size_t)32 * i, 32);
+    }
+    rc = run_window_queries(ctx, cur, q, qd);
+    if (rc != ORBFE_OK) return rc;
+    orbfe_match_state *st = match_state(ctx);
+    std::vector<uint8_t> has_pt(N > 0 ? N : 1, 0);
+    for (int i = 0; i < N; i++) { has_pt[i] = cur_has_point ? cur_has_point[i] : 0; cur_match[i] = -1; }
+    RotHist rh;
+    int nm = 0;
+    for (int i = 0; i < n_kf; i++) {
+        unsigned long long best = ~0ull;
+        for (int k = 0; k < st->h_cnt[i]; k++) {
+            const unsigned long long key = st->h_list[st->h_off[i] + k];
+            if (has_pt[key_idx(key)]) continue;
+            if (key < best) best = key;
+        }
+        if (best != ~0ull && key_dist(best) <= orb_dist) {
+            const int bi = key_idx(best);
+            cur_match[bi] = i;
+            has_pt[bi] = 1;
+            nm++;
+            if (check_ori) rh.v[rot_bin(kf_angle[i], cur->keys_un[bi].angle)].push_back(bi);
+        }
+    }
+    if (check_ori) {
+        int i1, i2, i3;
+        rh.three(i1, i2, i3);
+        for (int b = 0; b < HISTO_LENGTH; b++)
+            if (b != i1 && b != i2 && b != i3)
+                for (int idx : rh.v[b]) { cur_match[idx] = -1; nm--; }
+    }
+    *nmatches = nm;
+    return ORBFE_OK;
+}
+
+// ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:400-515
+extern "C" int orbfe_search_for_initialization(orbfe_context *ctx, const orbfe_frame_view *f1, const orbfe_frame_view *f2,
+                                               float *prev_matched, int window_size, float nnratio, int check_ori,
+                                               int32_t *matches12, int *nmatches)
+{
+    int rc = check_view(ctx, f2);
+    if (rc != ORBFE_OK) return rc;
+    if (!f1 || f1->n < 0 || (f1->n > 0 && (!f1->keys_un || !f1->descriptors || !prev_matched)) || !matches12 || !nmatches)
+        return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    const int n1 = f1->n, n2 = f2->n;
+    std::vector<MatchQuery> q(n1);
+    std::vector<uint8_t> qd((size_t)32 * (n1 > 0 ? n1 : 1));
+    for (int i = 0; i < n1; i++) {
+        MatchQuery &Q = q[i];
+        Q = MatchQuery{0, 0, 0, 0, -1, 0, 0, 0};
+        const int level1 = f1->keys_un[i].octave;
+        if (level1 > 0) continue;
+        Q.u = prev_matched[2 * i]; Q.v = prev_matched[2 * i + 1]; Q.r = (float)window_size;
+        Q.min_level = level1; Q.max_level = level1; Q.flags = 1;
+        memcpy(&qd[(size_t)32 * i], f1->descriptors + (size_t)32 * i, 32);
+    }
+    rc = run_window_queries(ctx, f2, q, qd);
+    if (rc != ORBFE_OK) return rc;
+    orbfe_match_state *st = match_state(ctx);
+    std::vector<int> matched_dist(n2 > 0 ? n2 : 1, INT_MAX), matches21(n2 > 0 ? n2 : 1, -1);
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    RotHist rh;
+    int nm = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        unsigned long long best = ~0ull, second = ~0ull;
+        for (int k = 0; k < st->h_cnt[i1]; k++) {
+            const unsigned long long key = st->h_list[st->h_off[i1] + k];
+            if (matched_dist[key_idx(key)] <= key_dist(key)) continue; // :437-438
+            if (key < best) { second = best; best = key; }
+            else if (key < second) second = key;
+        }
+        if (best == ~0ull) continue;
+        const int best_dist = key_dist(best), best_dist2 = second != ~0ull ? key_dist(second) : INT_MAX, bi = key_idx(best);
+        if (best_dist <= TH_LOW && (float)best_dist < (float)best_dist2 * nnratio) {
+            if (matches21[bi] >= 0) { matches12[matches21[bi]] = -1; nm--; }
+            matches12[i1] = bi;
+            matches21[bi] = i1;
+            matched_dist[bi] = best_dist;
+            nm++;
+            if (check_ori) rh.v[rot_bin(f1->keys_un[i1].angle, f2->keys_un[bi].angle)].push_back(i1);
+        }
+    }
+    if (check_ori) {
+        int i1, i2, i3;
+        rh.three(i1, i2, i3);
+        for (int b = 0; b < HISTO_LENGTH; b++) {
+            if (b == i1 || b == i2 || b == i3) continue;
+            for (int idx1 : rh.v[b])
+                if (matches12[idx1] >= 0) { matches12[idx1] = -1; nm--; }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)
+        if (matches12[i1] >= 0) {
+            prev_matched[2 * i1] = f2->keys_un[matches12[i1]].x;
+            prev_matched[2 * i1 + 1] = f2->keys_un[matches12[i1]].y;
+        }
+    *nmatches = nm;
+    return ORBFE_OK;
+}
+
+orbfe_match_state *orbfe_match_state_create() { return new (std::nothrow) orbfe_match_state(); }
+void orbfe_match_state_destroy(orbfe_match_state *s) { delete s; }

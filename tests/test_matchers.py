@@ -1,0 +1,278 @@
+"""Tracking-thread matchers.
+
+CPU part: first-principles checks of the oracle restatements (orb_oracle_match.c).
+GPU part: liborbfe's matchers (GPU window query + Hamming, host greedy resolve) == oracle, exactly, on a
+synthetic keypoint-level scene: frame t's stereo points are back-projected, the camera moves by a fixed
+SE(3), and frame t+1's keypoints are the re-projections (+ jitter, bit flips, distractors).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+FX, FY, CX, CY, BF = 500.0, 500.0, 320.0, 240.0, 50.0
+W, H = 640, 480
+NL = 8
+libm = C.CDLL("libm.so.6")
+libm.logf.restype = C.c_float; libm.logf.argtypes = [C.c_float]
+LOG_SF = float(libm.logf(np.float32(1.2)))
+
+
+def _se3(yaw_deg, t):
+    a = np.deg2rad(yaw_deg)
+    R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float64)
+    return np.concatenate([R, np.array(t, np.float64)[:, None]], axis=1).astype(np.float32)  # 3x4 [R|t]
+
+
+def _scene(seed=0, n_last=900, n_distract=500):
+    rng = np.random.default_rng(seed)
+    ex = O.Extractor()
+    sf = ex.scale_factors()
+    # frame t (pose = identity): keypoints with depth
+    u = rng.uniform(20, W - 20, n_last); v = rng.uniform(20, H - 20, n_last); z = rng.uniform(2.0, 40.0, n_last)
+    pos = np.stack([(u - CX) * z / FX, (v - CY) * z / FY, z], axis=1).astype(np.float32)
+    octave = rng.integers(0, NL, n_last).astype(np.int32)
+    angle = rng.uniform(0, 360, n_last).astype(np.float32)
+    desc_last = rng.integers(0, 256, (n_last, 32)).astype(np.uint8)
+    valid = (rng.random(n_last) < 0.85).astype(np.int32)
+    obs = rng.integers(0, 3, n_last).astype(np.int32)
+    T_last = _se3(0.0, [0, 0, 0])
+    T_cur = _se3(2.0, [0.02, -0.01, -0.3])  # camera moved 0.3 m forward, 2 deg yaw
+    # frame t+1 keypoints: re-projections with jitter + distractors, shuffled
+    pc = (T_cur[:, :3].astype(np.float64) @ pos.T.astype(np.float64)).T + T_cur[:, 3]
+    uu = FX * pc[:, 0] / pc[:, 2] + CX; vv = FY * pc[:, 1] / pc[:, 2] + CY
+    keep = (rng.random(n_last) < 0.8) & (pc[:, 2] > 0.5)
+    k = np.zeros(int(keep.sum()) + n_distract, O.KP_DTYPE)
+    d = np.zeros((len(k), 32), np.uint8); ur = np.full(len(k), -1.0, np.float32)
+    m = int(keep.sum())
+    k["x"][:m] = uu[keep] + rng.normal(0, 1.2, m); k["y"][:m] = vv[keep] + rng.normal(0, 1.2, m)
+    k["octave"][:m] = np.clip(octave[keep] + rng.integers(-1, 2, m), 0, NL - 1)
+    k["angle"][:m] = (angle[keep] + rng.normal(0, 6, m)) % 360
+    flips = rng.random((m, 256)) < 0.07
+    d[:m] = desc_last[keep] ^ np.packbits(flips, axis=1, bitorder="little")
+    has_r = rng.random(m) < 0.7
+    ur[:m] = np.where(has_r, k["x"][:m] - BF / pc[keep, 2] + rng.normal(0, 0.8, m), -1.0)
+    k["x"][m:] = rng.uniform(0, W, n_distract); k["y"][m:] = rng.uniform(0, H, n_distract)
+    k["octave"][m:] = rng.integers(0, NL, n_distract); k["angle"][m:] = rng.uniform(0, 360, n_distract)
+    d[m:] = rng.integers(0, 256, (n_distract, 32))
+    k["size"] = 31; k["class_id"] = -1
+    perm = rng.permutation(len(k))
+    k, d, ur = k[perm], d[perm], ur[perm]
+    # a few keypoints slightly outside the image bounds (undistortion can do that): PosInGrid drops them
+    k["x"][:3] = [-2.0, W + 1.5, 5.0]; k["y"][:3] = [10.0, 20.0, H + 3.0]
+    bounds = (0.0, float(W), 0.0, float(H))
+    cur_has_obs = (rng.random(len(k)) < 0.05).astype(np.uint8)
+    return dict(ex=ex, sf=sf, pos=pos, octave=octave, angle=angle, desc_last=desc_last, valid=valid, obs=obs, T_last=T_last, T_cur=T_cur,
+                k=k, d=d, ur=ur, bounds=bounds, cur_has_obs=cur_has_obs, rng=rng)
+
+
+CAM = O.Camera(FX, FY, CX, CY, BF, BF / FX)
+
+
+# ------------------------------------------------------------------ CPU: oracle from first principles
+def test_three_maxima_known():
+    assert O.three_maxima([0] * 30) == (-1, -1, -1)
+    h = [0] * 30; h[3] = 50; h[7] = 20; h[9] = 4
+    assert O.three_maxima(h) == (3, 7, -1)  # third < 10 % of the first
+    h[9] = 6
+    assert O.three_maxima(h) == (3, 7, 9)
+    h[7] = 4
+    assert O.three_maxima(h) == (3, 9, -1)
+    h[9] = 4
+    assert O.three_maxima(h) == (3, -1, -1)  # second < 10 % -> second and third dropped
+    assert O.three_maxima([5, 5, 5] + [0] * 27) == (0, 1, 2)  # ties: earlier bin first
+
+
+def test_grid_and_window_query_brute_force():
+    s = _scene(1)
+    g = O.Grid(s["k"], *s["bounds"])
+    k = s["k"]
+    inv_w = np.float32(64) / np.float32(W); inv_h = np.float32(48) / np.float32(H)
+    px = np.floor(np.abs((k["x"] - np.float32(0)) * inv_w) + np.float32(0.5)) * np.sign(k["x"])  # round half away
+    py = np.floor(np.abs(k["y"] * inv_h) + np.float32(0.5)) * np.sign(k["y"])
+    in_grid = (px >= 0) & (px < 64) & (py >= 0) & (py < 48)
+    assert in_grid[0] and not in_grid[1] and not in_grid[2]  # x = -2 rounds into column 0; column 64 / row 48 are dropped (Q6)
+    rng = np.random.default_rng(2)
+    for _ in range(200):
+        x, y = rng.uniform(-30, W + 30), rng.uniform(-30, H + 30)
+        r = float(rng.uniform(1, 90))
+        lo, hi = int(rng.integers(-1, 5)), int(rng.integers(-1, 8))
+        got = g.features_in_area(x, y, r, lo, hi)
+        xf, yf, rf = np.float32(x), np.float32(y), np.float32(r)
+        ok = in_grid & (np.abs(k["x"] - xf) < rf) & (np.abs(k["y"] - yf) < rf)
+        if lo > 0 or hi >= 0:  # Q5: literal level rule
+            ok &= k["octave"] >= lo
+            if hi >= 0:
+                ok &= k["octave"] <= hi
+        # cells are clamped to the window's cell range: a keypoint rounded into a cell outside that range is missed
+        assert set(got.tolist()) <= set(np.nonzero(ok)[0].tolist())
+        assert len(got) >= ok.sum() - 3
+        order = [(int(px[i]), int(py[i]), int(i)) for i in got]
+        assert order == sorted(order)  # ix-major, iy, insertion order
+
+
+def test_log_det_and_predict_scale():
+    for x in (0.3, 0.9999, 1.0, 1.2, 7.5, 123.456, 1e-3):
+        assert O.lib().orc_log_det(np.float32(x)) == np.float32(np.log(np.float64(np.float32(x))))
+    assert O.lib().orc_predict_scale(10.0, 10.0, LOG_SF, 8) == 0
+    assert O.lib().orc_predict_scale(10.0, 10.0 / 1.2 ** 2.5, LOG_SF, 8) == 3
+    assert O.lib().orc_predict_scale(10.0, 0.01, LOG_SF, 8) == 7 and O.lib().orc_predict_scale(10.0, 100.0, LOG_SF, 8) == 0
+
+
+def test_search_by_projection_last_recovers_motion():
+    s = _scene(3)
+    g = O.Grid(s["k"], *s["bounds"])
+    match, n = O.search_by_projection_last(g, s["ur"], s["d"], s["sf"], CAM, s["T_cur"], s["T_last"], s["pos"], s["desc_last"], s["valid"],
+                                           s["obs"], s["octave"], s["angle"], s["cur_has_obs"], 7.0, False, True)
+    assert n == (match >= 0).sum() or n <= (match >= 0).sum() + 5  # duplicates may be counted twice (reference quirk)
+    assert n > 300
+    ok = match >= 0
+    # matched pairs are the planted ones: descriptors within 100 bits
+    dist = np.unpackbits(s["d"][ok] ^ s["desc_last"][match[ok]], axis=1).sum(axis=1)
+    assert (dist <= 100).all() and np.median(dist) < 30
+    assert (s["valid"][match[ok]] == 1).all() and not (s["cur_has_obs"][ok] == 1).any()
+
+
+def test_search_for_initialization_one_to_one():
+    s = _scene(4)
+    k1 = s["k"].copy(); k1["octave"] = np.where(np.arange(len(k1)) % 3 == 0, 1, 0)
+    rng = np.random.default_rng(5)
+    k2 = k1.copy(); k2["x"] += rng.normal(3, 1, len(k1)).astype(np.float32); k2["y"] += rng.normal(-2, 1, len(k1)).astype(np.float32)
+    k2["octave"] = 0
+    d2 = s["d"] ^ np.packbits(rng.random((len(k1), 256)) < 0.05, axis=1, bitorder="little")
+    g2 = O.Grid(k2, *s["bounds"])
+    prev = np.stack([k1["x"], k1["y"]], axis=1)
+    m12, pm, n = O.search_for_initialization(k1, s["d"], g2, d2, prev, 100, 0.9, True)
+    ok = m12 >= 0
+    assert n == ok.sum() and n > 200
+    assert (k1["octave"][ok] == 0).all()
+    assert len(set(m12[ok].tolist())) == ok.sum()  # one-to-one
+    assert np.mean(m12[ok] == np.nonzero(ok)[0]) > 0.95  # planted correspondences
+    assert np.array_equal(pm[ok], np.stack([k2["x"][m12[ok]], k2["y"][m12[ok]]], axis=1)) and np.array_equal(pm[~ok], prev[~ok])
+
+
+# ------------------------------------------------------------------ GPU: product == oracle
+@pytest.fixture(scope="module")
+def gpu():
+    from orbslam2_amd import api
+    ctx = api.Context(width=W, height=H, fx=FX, fy=FY, cx=CX, cy=CY, bf=BF)
+    yield api, ctx
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_features_in_area(gpu):
+    api, ctx = gpu
+    s = _scene(6)
+    g = O.Grid(s["k"], *s["bounds"])
+    view = ctx._view(s["k"], s["ur"], s["d"], s["bounds"])
+    rng = np.random.default_rng(7)
+    for _ in range(40):
+        x, y, r = float(rng.uniform(-30, W + 30)), float(rng.uniform(-30, H + 30)), float(rng.uniform(1, 120))
+        lo, hi = int(rng.integers(-1, 5)), int(rng.integers(-1, 8))
+        assert ctx.features_in_area(view, x, y, r, lo, hi).tolist() == g.features_in_area(x, y, r, lo, hi).tolist()
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    h = np.array([0, 9, 2, 9, 1] + [0] * 25, np.int32)
+    assert ctx.L.orbfe_three_maxima(h.ctypes.data_as(C.c_void_p), 30, C.byref(a), C.byref(b), C.byref(c)) == 0
+    assert (a.value, b.value, c.value) == O.three_maxima(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,th,mono,ori", [(10, 7.0, False, True), (11, 15.0, True, True), (12, 14.0, False, False), (13, 3.0, False, True)])
+def test_gpu_search_by_projection_last(gpu, seed, th, mono, ori):
+    api, ctx = gpu
+    s = _scene(seed)
+    if seed == 12:  # backward motion: exercises the [0, octave] level window
+        s["T_cur"] = _se3(-1.0, [0.0, 0.0, 0.4])
+    g = O.Grid(s["k"], *s["bounds"])
+    ur = None if mono else s["ur"]
+    ref, nref = O.search_by_projection_last(g, ur, s["d"], s["sf"], CAM, s["T_cur"], s["T_last"], s["pos"], s["desc_last"], s["valid"],
+                                            s["obs"], s["octave"], s["angle"], s["cur_has_obs"], th, mono, ori)
+    view = ctx._view(s["k"], ur, s["d"], s["bounds"])
+    got, ngot = ctx.search_by_projection_last(view, s["T_cur"], s["T_last"], s["pos"], s["desc_last"], s["valid"], s["obs"], s["octave"],
+                                              s["angle"], s["cur_has_obs"], th, mono, ori)
+    assert ngot == nref and np.array_equal(got, ref)
+    assert nref > 50
+
+
+@pytest.mark.gpu
+def test_gpu_frustum_and_search_by_projection_points(gpu):
+    api, ctx = gpu
+    s = _scene(20, n_last=1500)
+    rng = s["rng"]
+    n = len(s["pos"])
+    # MapPoint normal = mean viewing direction (camera -> point)
+    normal = s["pos"] / np.linalg.norm(s["pos"], axis=1, keepdims=True) + rng.normal(0, 0.35, (n, 3))
+    normal = (normal / np.linalg.norm(normal, axis=1, keepdims=True)).astype(np.float32)
+    dist0 = np.linalg.norm(s["pos"], axis=1).astype(np.float32)
+    max_d = (dist0 * rng.uniform(0.9, 3.0, n)).astype(np.float32); min_d = (max_d / np.float32(1.2 ** 7)).astype(np.float32)
+    ref_tp = O.is_in_frustum(s["T_cur"], CAM, s["bounds"], s["pos"], normal, max_d, min_d, 0.5, LOG_SF, NL)
+    got_tp = ctx.is_in_frustum(s["T_cur"], s["bounds"], s["pos"], normal, max_d, min_d, 0.5)
+    assert np.array_equal(got_tp["in_view"], ref_tp["in_view"]) and ref_tp["in_view"].sum() > 300
+    v = ref_tp["in_view"] == 1
+    for f in ("proj_x", "proj_y", "proj_xr", "level", "view_cos"):
+        assert np.array_equal(got_tp[f][v], ref_tp[f][v]), f
+    g = O.Grid(s["k"], *s["bounds"])
+    view = ctx._view(s["k"], s["ur"], s["d"], s["bounds"])
+    for th, ratio in ((1.0, 0.8), (3.0, 0.8), (5.0, 0.6)):
+        ref, nref = O.search_by_projection_points(g, s["ur"], s["d"], s["sf"], ref_tp, s["desc_last"], s["obs"], s["cur_has_obs"], th, ratio)
+        got, ngot = ctx.search_by_projection_points(view, ref_tp, s["desc_last"], s["obs"], s["cur_has_obs"], th, ratio)
+        assert ngot == nref and np.array_equal(got, ref)
+    assert nref > 100
+
+
+@pytest.mark.gpu
+def test_gpu_search_by_projection_kf(gpu):
+    api, ctx = gpu
+    s = _scene(30)
+    n = len(s["pos"])
+    dist0 = np.linalg.norm(s["pos"], axis=1).astype(np.float32)
+    max_d = (dist0 * s["rng"].uniform(0.9, 3.0, n)).astype(np.float32); min_d = (max_d / np.float32(1.2 ** 7)).astype(np.float32)
+    g = O.Grid(s["k"], *s["bounds"])
+    view = ctx._view(s["k"], None, s["d"], s["bounds"])
+    for th, od in ((10.0, 100), (3.0, 64)):
+        ref, nref = O.search_by_projection_kf(g, s["d"], s["sf"], CAM, s["T_cur"], LOG_SF, NL, s["pos"], s["desc_last"], s["valid"], s["angle"],
+                                              max_d, min_d, s["cur_has_obs"], th, od, True)
+        got, ngot = ctx.search_by_projection_kf(view, s["T_cur"], s["pos"], s["desc_last"], s["valid"], s["angle"], max_d, min_d,
+                                                s["cur_has_obs"], th, od, True)
+        assert ngot == nref and np.array_equal(got, ref)
+    assert nref > 30
+
+
+@pytest.mark.gpu
+def test_gpu_search_for_initialization(gpu):
+    api, ctx = gpu
+    s = _scene(40, n_last=1800, n_distract=300)
+    k1 = s["k"].copy(); k1["octave"] = np.where(np.arange(len(k1)) % 4 == 0, 1, 0)
+    rng = np.random.default_rng(41)
+    k2 = k1.copy(); k2["x"] += rng.normal(5, 2, len(k1)).astype(np.float32); k2["y"] += rng.normal(-3, 2, len(k1)).astype(np.float32)
+    k2["octave"] = np.where(np.arange(len(k1)) % 7 == 0, 2, 0)
+    d2 = s["d"] ^ np.packbits(rng.random((len(k1), 256)) < 0.05, axis=1, bitorder="little")
+    g2 = O.Grid(k2, *s["bounds"])
+    prev = np.stack([k1["x"], k1["y"]], axis=1)
+    v1 = ctx._view(k1, None, s["d"], s["bounds"]); v2 = ctx._view(k2, None, d2, s["bounds"])
+    for win, ratio, ori in ((100, 0.9, True), (10, 0.6, False)):
+        ref, pm_ref, nref = O.search_for_initialization(k1, s["d"], g2, d2, prev, win, ratio, ori)
+        got, pm_got, ngot = ctx.search_for_initialization(v1, v2, prev, win, ratio, ori)
+        assert ngot == nref and np.array_equal(got, ref) and np.array_equal(pm_got, pm_ref)
+    assert nref > 100
+
+
+@pytest.mark.gpu
+def test_gpu_matchers_edge_cases(gpu):
+    api, ctx = gpu
+    s = _scene(50)
+    view = ctx._view(s["k"], s["ur"], s["d"], s["bounds"])
+    z = np.zeros
+    got, n = ctx.search_by_projection_last(view, s["T_cur"], s["T_last"], z((0, 3), np.float32), z((0, 32), np.uint8), z(0, np.int32),
+                                           z(0, np.int32), z(0, np.int32), z(0, np.float32), None, 7.0, False, True)
+    assert n == 0 and (got == -1).all()
+    empty = ctx._view(s["k"][:0], None, s["d"][:0], s["bounds"])
+    got, n = ctx.search_by_projection_last(empty, s["T_cur"], s["T_last"], s["pos"], s["desc_last"], s["valid"], s["obs"], s["octave"],
+                                           s["angle"], None, 7.0, False, True)
+    assert n == 0 and len(got) == 0
+    bad = ctx._view(s["k"], None, s["d"], (0.0, 0.0, 0.0, float(H)))  # degenerate bounds
+    with pytest.raises(api.OrbfeError):
+        ctx.features_in_area(bad, 1.0, 1.0, 5.0)
