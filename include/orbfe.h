@@ -214,6 +214,31 @@ int orbfe_search_for_initialization(orbfe_context *ctx, const orbfe_frame_view *
                                     float *prev_matched, int window_size, float nnratio, int check_ori,
                                     int32_t *matches12, int *nmatches);
 
+/* ---- bag of words ----
+ * orbfe_vocab_load: fbow::Vocabulary::readFromFile / fromStream (Thirdparty/fbow/src/fbow.cpp:172-191) from a
+ * memory blob in the fbow file format (u64 55824124, 120-byte params, block data); the tree stays in HBM. */
+int orbfe_vocab_load(orbfe_context *ctx, const uint8_t *blob, size_t size);
+/* Frame::ComputeFboW (src/Frame.cc:395-400) = Vocabulary::transform(desc, level, fBow, fBow2)
+ * (Thirdparty/fbow/src/fbow.h:400-444): per descriptor the leaf word id, its weight and the id of the
+ * node reached at `level` (4 in ORB-SLAM2).  n == 0 is an error, as in fbow (fbow.cpp:52). */
+int orbfe_bow_transform(orbfe_context *ctx, const uint8_t *desc, int n, int level,
+                        uint32_t *word_id, float *weight, uint32_t *node_id);
+/* The two std::map results as sorted arrays: fBow = (words[i], word_w[i]) with weights summed in feature
+ * order; fBow2 = nodes[k] -> node_feat[node_off[k] .. node_off[k+1]) (ascending feature indices).
+ * All output arrays need n entries (node_off n+1). */
+int orbfe_bow_maps(const uint32_t *word_id, const float *weight, const uint32_t *node_id, int n,
+                   uint32_t *words, float *word_w, int *n_words,
+                   uint32_t *nodes, int32_t *node_off, int32_t *node_feat, int *n_nodes);
+/* ORBmatcher::SearchByFboW(KeyFrame*, Frame&, vpMapPointMatches) (src/ORBmatcher.cc:157-283) on the feature
+ * vectors of orbfe_bow_maps.  kf_valid[i] = KF keypoint i has a map point that is not bad.  f_match[j] receives
+ * the KF keypoint whose map point frame keypoint j got, or -1. */
+int orbfe_search_by_bow(orbfe_context *ctx,
+                        const uint32_t *kf_nodes, const int32_t *kf_off, const int32_t *kf_feat, int kf_nnodes,
+                        const int32_t *kf_valid, const uint8_t *kf_desc, const float *kf_angle, int n_kf,
+                        const uint32_t *f_nodes, const int32_t *f_off, const int32_t *f_feat, int f_nnodes,
+                        const uint8_t *f_desc, const float *f_angle, int n_f,
+                        float nnratio, int check_ori, int32_t *f_match, int *nmatches);
+
 #ifdef __cplusplus
 }
 #endif

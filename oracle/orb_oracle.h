@@ -154,6 +154,22 @@ int orc_search_for_initialization(const orc_keypoint *keys1, const uint8_t *desc
                                   const orc_grid *g2, const uint8_t *desc2,
                                   float *prev_matched, int window_size, float nnratio, int check_ori, int32_t *matches12);
 
+/* ---- fbow vocabulary transform + SearchByFboW (orb_oracle_bow.c) ---- */
+typedef struct orc_vocab orc_vocab;
+orc_vocab *orc_vocab_from_blob(const uint8_t *blob, size_t size);
+void orc_vocab_destroy(orc_vocab *v);
+int orc_vocab_k(const orc_vocab *v);
+int orc_vocab_nblocks(const orc_vocab *v);
+void orc_bow_descend(const orc_vocab *v, const uint8_t *desc, int n, int store_level,
+                     uint32_t *word_id, float *weight, uint32_t *node_id);
+int orc_bow_maps(const uint32_t *word_id, const float *weight, const uint32_t *node_id, int n,
+                 uint32_t *words, float *word_w, uint32_t *nodes, int32_t *node_off, int32_t *node_feat, int *n_nodes);
+int orc_search_by_bow(const uint32_t *kf_nodes, const int32_t *kf_off, const int32_t *kf_feat, int kf_nnodes,
+                      const int32_t *kf_valid, const uint8_t *kf_desc, const float *kf_angle,
+                      const uint32_t *f_nodes, const int32_t *f_off, const int32_t *f_feat, int f_nnodes,
+                      const uint8_t *f_desc, const float *f_angle, int n_f,
+                      float nnratio, int check_ori, int32_t *f_match);
+
 #ifdef __cplusplus
 }
 #endif

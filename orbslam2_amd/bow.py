@@ -1,0 +1,123 @@
+"""ctypes plumbing for the bag-of-words entry points of include/orbfe.h (tests only) and a writer for the
+fbow vocabulary file format (Thirdparty/fbow/src/fbow.cpp:10-49,172-191) used to synthesise test vocabularies."""
+from __future__ import annotations
+
+import ctypes as C
+import struct
+
+import numpy as np
+
+from . import api
+
+_bound = False
+
+
+def _bind():
+    global _bound
+    L = api.load()
+    if _bound:
+        return L
+    vp, ip = C.c_void_p, C.POINTER(C.c_int)
+    L.orbfe_vocab_load.restype = C.c_int; L.orbfe_vocab_load.argtypes = [vp, vp, C.c_size_t]
+    L.orbfe_bow_transform.restype = C.c_int; L.orbfe_bow_transform.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    L.orbfe_bow_maps.restype = C.c_int; L.orbfe_bow_maps.argtypes = [vp, vp, vp, C.c_int, vp, vp, ip, vp, vp, vp, ip]
+    L.orbfe_search_by_bow.restype = C.c_int
+    L.orbfe_search_by_bow.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int,
+                                      C.c_float, C.c_int, vp, ip]
+    _bound = True
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def vocab_load(ctx, blob: bytes):
+    L = _bind()
+    buf = np.frombuffer(blob, np.uint8)
+    ctx._check(L.orbfe_vocab_load(ctx.h, _p(buf), len(buf)))
+
+
+def transform(ctx, desc, level=4):
+    L = _bind()
+    d = np.ascontiguousarray(desc, np.uint8); n = len(d)
+    w = np.zeros(max(n, 1), np.uint32); wt = np.zeros(max(n, 1), np.float32); nd = np.zeros(max(n, 1), np.uint32)
+    ctx._check(L.orbfe_bow_transform(ctx.h, _p(d), n, level, _p(w), _p(wt), _p(nd)))
+    return w[:n], wt[:n], nd[:n]
+
+
+def maps(word_id, weight, node_id):
+    L = _bind()
+    n = len(word_id)
+    wi = np.ascontiguousarray(word_id, np.uint32); we = np.ascontiguousarray(weight, np.float32); ni = np.ascontiguousarray(node_id, np.uint32)
+    words = np.zeros(max(n, 1), np.uint32); ww = np.zeros(max(n, 1), np.float32); nodes = np.zeros(max(n, 1), np.uint32)
+    off = np.zeros(n + 1, np.int32); feat = np.zeros(max(n, 1), np.int32); nw, nn = C.c_int(), C.c_int()
+    rc = L.orbfe_bow_maps(_p(wi), _p(we), _p(ni), n, _p(words), _p(ww), C.byref(nw), _p(nodes), _p(off), _p(feat), C.byref(nn))
+    assert rc == 0
+    return words[: nw.value], ww[: nw.value], nodes[: nn.value], off[: nn.value + 1], feat[:n]
+
+
+def search_by_bow(ctx, kf_fv, kf_valid, kf_desc, kf_angle, f_fv, f_desc, f_angle, nnratio, check_ori):
+    L = _bind()
+    kn, ko, kf = (np.ascontiguousarray(a) for a in kf_fv); fn, fo, ff = (np.ascontiguousarray(a) for a in f_fv)
+    kv = np.ascontiguousarray(kf_valid, np.int32); kd = np.ascontiguousarray(kf_desc, np.uint8); ka = np.ascontiguousarray(kf_angle, np.float32)
+    fd = np.ascontiguousarray(f_desc, np.uint8); fa = np.ascontiguousarray(f_angle, np.float32)
+    out = np.zeros(max(len(fd), 1), np.int32); nm = C.c_int()
+    ctx._check(L.orbfe_search_by_bow(ctx.h, _p(kn), _p(ko), _p(kf), len(kn), _p(kv), _p(kd), _p(ka), len(kd),
+                                     _p(fn), _p(fo), _p(ff), len(fn), _p(fd), _p(fa), len(fd), nnratio, int(check_ori), _p(out), C.byref(nm)))
+    return out[: len(fd)].copy(), nm.value
+
+
+def build_vocabulary(desc: np.ndarray, k: int = 10, levels: int = 3, seed: int = 7) -> bytes:
+    """Hierarchical k-majority clustering of binary descriptors, serialised in the fbow file format
+    (alignment 8; block = u16 N, u16 isLeaf, u32 parent, k x 32 B descriptors, k x {u32 id|leafbit, f32 weight})."""
+    rng = np.random.default_rng(seed)
+    bits = np.unpackbits(desc, axis=1, bitorder="little")
+    blocks = []  # dict(parent, feats[list of 32B], infos[list of (id_or_child, weight)], leaf)
+    n_words = [0]
+    total = len(desc)
+
+    def split(idx, parent, depth):
+        bid = len(blocks)
+        blk = dict(parent=parent, feats=[], infos=[], leaf=depth == levels - 1)
+        blocks.append(blk)
+        kk = min(k, len(idx))
+        centers = bits[rng.choice(idx, kk, replace=False)].copy()
+        assign = None
+        for _ in range(4):
+            dist = (bits[idx][:, None, :] != centers[None, :, :]).sum(axis=2)
+            assign = dist.argmin(axis=1)
+            for c in range(kk):
+                m = assign == c
+                if m.any():
+                    centers[c] = (bits[idx][m].mean(axis=0) >= 0.5)
+        dist = (bits[idx][:, None, :] != centers[None, :, :]).sum(axis=2)
+        assign = dist.argmin(axis=1)
+        for c in range(kk):
+            sub = idx[assign == c]
+            blk["feats"].append(np.packbits(centers[c], bitorder="little").tobytes())
+            if depth == levels - 1 or len(sub) < 2:
+                w = float(np.log(total / max(len(sub), 1)))
+                blk["infos"].append((0x80000000 | n_words[0], np.float32(w)))
+                n_words[0] += 1
+            else:
+                blk["infos"].append(None)  # patched below
+                child = split(sub, bid, depth + 1)
+                blk["infos"][c] = (child, np.float32(0.0))
+        return bid
+
+    split(np.arange(total), 0, 0)
+    desc_wp, feat_off = 32, 8
+    child_off = feat_off + k * desc_wp
+    block_size = feat_off + k * (desc_wp + 8)
+    data = bytearray(block_size * len(blocks))
+    for b, blk in enumerate(blocks):
+        o = b * block_size
+        all_leaf = all(i[0] & 0x80000000 for i in blk["infos"])
+        struct.pack_into("<HHI", data, o, len(blk["feats"]), 1 if all_leaf else 0, blk["parent"])
+        for c, f in enumerate(blk["feats"]):
+            data[o + feat_off + c * desc_wp: o + feat_off + c * desc_wp + 32] = f
+            struct.pack_into("<If", data, o + child_off + c * 8, blk["infos"][c][0], float(blk["infos"][c][1]))
+    params = struct.pack("<50s2xII4x5QiiI4x", b"orb", 8, len(blocks), desc_wp, block_size, feat_off, child_off, len(data), 0, 32, k)
+    assert len(params) == 120
+    return struct.pack("<Q", 55824124) + params + bytes(data)

@@ -50,6 +50,7 @@ struct orbfe_context {
     int32_t feats[ORBFE_MAX_LEVELS];
     std::vector<void *> allocs;
     orbfe_match_state *match = nullptr;
+    orbfe_bow_state *bow = nullptr;
     char err[512];
 };
 
@@ -85,6 +86,11 @@ hipStream_t orbfe_ctx_stream(orbfe_context *ctx) { return ctx->stream; }
 int orbfe_ctx_device(const orbfe_context *ctx) { return ctx->params.device; }
 const orbfe_params *orbfe_ctx_params(const orbfe_context *ctx) { return &ctx->params; }
 const float *orbfe_ctx_scale_factors(const orbfe_context *ctx) { return ctx->scale; }
+orbfe_bow_state *orbfe_ctx_bow_state(orbfe_context *ctx)
+{
+    if (!ctx->bow) ctx->bow = orbfe_bow_state_create();
+    return ctx->bow;
+}
 
 #define HIP_TRY(ctx, expr)                                                                      \
     do {                                                                                        \
@@ -436,6 +442,7 @@ extern "C" void orbfe_destroy(orbfe_context *ctx)
     }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->match) orbfe_match_state_destroy(ctx->match);
+    if (ctx->bow) orbfe_bow_state_destroy(ctx->bow);
     if (ctx->d_depth_in) hipFree(ctx->d_depth_in);
     if (ctx->d_ham) hipFree(ctx->d_ham);
     if (ctx->stream) hipStreamDestroy(ctx->stream);

@@ -1,0 +1,314 @@
+// orbfe_bow.hip -- fbow vocabulary transform (Frame::ComputeFboW, src/Frame.cc:395-400 ->
+// fbow::Vocabulary::_transform2<L1_32bytes>, Thirdparty/fbow/src/fbow.h:400-444) and
+// ORBmatcher::SearchByFboW(KeyFrame*, Frame&) (src/ORBmatcher.cc:157-283), SURVEY.md §8a row 17.
+//
+// The vocabulary blob (fbow file format, fbow.cpp:172-191) is uploaded once and stays resident in HBM
+// (k=10, L=6: ~44 MB; L2 / Infinity-Cache resident).  bow_descend_kernel: one thread per descriptor walks
+// the k-ary tree by minimum Hamming distance (first minimum wins) and returns (word id, weight, node id
+// at the store level); the two std::map results are rebuilt on the host, weights summed in feature order
+// so the float sums equal the reference's.  SearchByFboW: the Hamming distances of all (KF feature, frame
+// feature) pairs that share a vocabulary node are computed on the GPU (one thread per pair); the greedy
+// per-node resolution runs in order on the host, like the other matchers (orbfe_match.hip).
+#include "../../include/orbfe.h"
+#include "orbfe_device.h"
+#include "orbfe_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <new>
+#include <vector>
+
+#define HISTO_LENGTH 30
+#define TH_LOW 50
+
+struct FbowParams { // fbow::Vocabulary::params, Thirdparty/fbow/src/fbow.h:118-129
+    char desc_name[50];
+    uint32_t aligment, nblocks;
+    uint64_t desc_size_bytes_wp, block_size_bytes_wp, feature_off_start, child_off_start, total_size;
+    int32_t desc_type, desc_size;
+    uint32_t m_k;
+};
+static_assert(sizeof(FbowParams) == 120, "fbow params layout");
+
+struct orbfe_bow_state {
+    FbowParams p;
+    uint8_t *d_data = nullptr;
+    bool loaded = false;
+    void *d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    ~orbfe_bow_state()
+    {
+        if (d_data) hipFree(d_data);
+        if (d_scratch) hipFree(d_scratch);
+    }
+};
+
+orbfe_bow_state *orbfe_bow_state_create() { return new (std::nothrow) orbfe_bow_state(); }
+void orbfe_bow_state_destroy(orbfe_bow_state *s) { delete s; }
+
+#define BTRY(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return orbfe_fail(ctx, ORBFE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+static int ensure_scratch(orbfe_context *ctx, orbfe_bow_state *st, size_t need)
+{
+    if (need <= st->scratch_bytes) return ORBFE_OK;
+    if (st->d_scratch) hipFree(st->d_scratch);
+    st->d_scratch = nullptr; st->scratch_bytes = 0;
+    BTRY(ctx, hipMalloc(&st->d_scratch, need));
+    st->scratch_bytes = need;
+    return ORBFE_OK;
+}
+
+// one thread per descriptor: descend by minimum Hamming distance
+__global__ __launch_bounds__(256) void bow_descend_kernel(const uint8_t *__restrict__ data, unsigned block_size, unsigned feat_off,
+                                                          unsigned child_off, unsigned desc_wp, int nbits, int store_level,
+                                                          const uint8_t *__restrict__ desc, int n,
+                                                          uint32_t *__restrict__ word_id, float *__restrict__ weight, uint32_t *__restrict__ node_id)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= n) return;
+    unsigned long long feat[4];
+    {
+        const unsigned long long *p = (const unsigned long long *)(desc + (size_t)32 * f);
+#pragma unroll
+        for (int i = 0; i < 4; i++) feat[i] = p[i];
+    }
+    const uint8_t *blk = data;
+    uint32_t level = 0, cur_node = 0, nid = 0, wid = 0;
+    float w = 0.f;
+    for (;;) {
+        const int N = *(const uint16_t *)blk;
+        unsigned best_d = 0xffffffffu, best_i = 0;
+        for (int c = 0; c < N; c++) {
+            const unsigned long long *nf = (const unsigned long long *)(blk + feat_off + (size_t)c * desc_wp);
+            const unsigned d = __popcll(nf[0] ^ feat[0]) + __popcll(nf[1] ^ feat[1]) + __popcll(nf[2] ^ feat[2]) + __popcll(nf[3] ^ feat[3]);
+            if (d < best_d) { best_d = d; best_i = (unsigned)c; }
+        }
+        if (level == (uint32_t)store_level) nid = cur_node;
+        const uint32_t id_or_child = *(const uint32_t *)(blk + child_off + (size_t)best_i * 8);
+        if (id_or_child & 0x80000000u) {
+            wid = id_or_child & 0x7fffffffu;
+            w = *(const float *)(blk + child_off + (size_t)best_i * 8 + 4);
+            if (level < (uint32_t)store_level) nid = cur_node;
+            break;
+        }
+        const uint32_t child = id_or_child & 0x7fffffffu;
+        blk = data + (size_t)child * block_size;
+        cur_node = (cur_node << nbits) | best_i;
+        level++;
+        if (child == 0) break;
+    }
+    word_id[f] = wid; weight[f] = w; node_id[f] = nid;
+}
+
+__global__ __launch_bounds__(256) void pair_hamming_kernel(const uint8_t *__restrict__ da, const uint8_t *__restrict__ db,
+                                                           const uint32_t *__restrict__ pa, const uint32_t *__restrict__ pb, int npairs,
+                                                           uint16_t *__restrict__ dist)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= npairs) return;
+    const uint32_t *a = (const uint32_t *)(da + (size_t)32 * pa[i]);
+    const uint32_t *b = (const uint32_t *)(db + (size_t)32 * pb[i]);
+    int d = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d += __popc(a[k] ^ b[k]);
+    dist[i] = (uint16_t)d;
+}
+
+// fbow::Vocabulary::fromStream (fbow.cpp:181-191) from a memory blob; the tree goes to HBM.
+extern "C" int orbfe_vocab_load(orbfe_context *ctx, const uint8_t *blob, size_t size)
+{
+    if (!ctx || !blob) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
+    if (!st) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "out of host memory");
+    if (size < 8 + sizeof(FbowParams)) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "vocabulary blob too small");
+    uint64_t sig;
+    memcpy(&sig, blob, 8);
+    if (sig != 55824124ull) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "Vocabulary::fromStream invalid signature");
+    FbowParams p;
+    memcpy(&p, blob + 8, sizeof(p));
+    if (p.desc_size != 32) return orbfe_fail(ctx, ORBFE_ERR_UNSUPPORTED, "only 32-byte (ORB) vocabularies are supported");
+    if (p.m_k == 0 || p.nblocks == 0 || p.total_size != p.block_size_bytes_wp * (uint64_t)p.nblocks || size < 8 + sizeof(p) + p.total_size ||
+        p.child_off_start + (uint64_t)p.m_k * 8 > p.block_size_bytes_wp || p.feature_off_start + (uint64_t)p.m_k * p.desc_size_bytes_wp > p.child_off_start ||
+        (p.desc_size_bytes_wp % 8) || (p.feature_off_start % 8) || (p.block_size_bytes_wp % 8))
+        return orbfe_fail(ctx, ORBFE_ERR_INVALID, "inconsistent vocabulary header");
+    // validate child links once so the kernel cannot leave the blob
+    const uint8_t *data = blob + 8 + sizeof(p);
+    for (uint32_t b = 0; b < p.nblocks; b++) {
+        const uint8_t *blk = data + (size_t)b * p.block_size_bytes_wp;
+        const unsigned N = *(const uint16_t *)blk;
+        if (N > p.m_k) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "block %u holds %u > k nodes", b, N);
+        for (unsigned c = 0; c < N; c++) {
+            uint32_t ic;
+            memcpy(&ic, blk + p.child_off_start + (size_t)c * 8, 4);
+            if (!(ic & 0x80000000u) && ic >= p.nblocks) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "block %u links to block %u", b, ic);
+        }
+    }
+    BTRY(ctx, hipSetDevice(orbfe_ctx_device(ctx)));
+    if (st->d_data) { hipFree(st->d_data); st->d_data = nullptr; }
+    st->loaded = false;
+    BTRY(ctx, hipMalloc((void **)&st->d_data, p.total_size));
+    BTRY(ctx, hipMemcpy(st->d_data, data, p.total_size, hipMemcpyHostToDevice));
+    st->p = p;
+    st->loaded = true;
+    return ORBFE_OK;
+}
+
+// Vocabulary::transform(features, level, fBow, fBow2): per-feature results (word, weight, node at `level`).
+extern "C" int orbfe_bow_transform(orbfe_context *ctx, const uint8_t *desc, int n, int level,
+                                   uint32_t *word_id, float *weight, uint32_t *node_id)
+{
+    if (!ctx || n < 0 || level < 0 || (n > 0 && (!desc || !word_id || !weight || !node_id))) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "bad argument");
+    orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
+    if (!st || !st->loaded) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "no vocabulary loaded (orbfe_vocab_load)");
+    if (n == 0) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "Vocabulary::transform No input data"); // fbow.cpp:52
+    hipStream_t s = orbfe_ctx_stream(ctx);
+    BTRY(ctx, hipSetDevice(orbfe_ctx_device(ctx)));
+    int rc = ensure_scratch(ctx, st, (size_t)n * (32 + 12));
+    if (rc != ORBFE_OK) return rc;
+    uint8_t *d_desc = (uint8_t *)st->d_scratch;
+    uint32_t *d_word = (uint32_t *)(d_desc + (size_t)32 * n);
+    float *d_w = (float *)(d_word + n);
+    uint32_t *d_node = (uint32_t *)(d_w + n);
+    BTRY(ctx, hipMemcpyAsync(d_desc, desc, (size_t)32 * n, hipMemcpyHostToDevice, s));
+    const int nbits = (int)ceil(log2((double)st->p.m_k));
+    hipLaunchKernelGGL(bow_descend_kernel, dim3((n + 255) / 256), dim3(256), 0, s, st->d_data, (unsigned)st->p.block_size_bytes_wp,
+                       (unsigned)st->p.feature_off_start, (unsigned)st->p.child_off_start, (unsigned)st->p.desc_size_bytes_wp, nbits, level,
+                       d_desc, n, d_word, d_w, d_node);
+    BTRY(ctx, hipMemcpyAsync(word_id, d_word, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, s));
+    BTRY(ctx, hipMemcpyAsync(weight, d_w, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+    BTRY(ctx, hipMemcpyAsync(node_id, d_node, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, s));
+    BTRY(ctx, hipStreamSynchronize(s));
+    BTRY(ctx, hipGetLastError());
+    return ORBFE_OK;
+}
+
+// fBow / fBow2 as sorted arrays from the per-feature results (host; weights summed in feature order).
+extern "C" int orbfe_bow_maps(const uint32_t *word_id, const float *weight, const uint32_t *node_id, int n,
+                              uint32_t *words, float *word_w, int *n_words,
+                              uint32_t *nodes, int32_t *node_off, int32_t *node_feat, int *n_nodes)
+{
+    if (n < 0 || !n_words || !n_nodes || (n > 0 && (!word_id || !weight || !node_id || !words || !word_w || !nodes || !node_off || !node_feat)))
+        return ORBFE_ERR_INVALID;
+    std::map<uint32_t, float> r1;
+    std::map<uint32_t, std::vector<int32_t>> r2;
+    for (int f = 0; f < n; f++) {
+        r1[word_id[f]] += weight[f]; // fbow.h:431, _float default 0
+        r2[node_id[f]].push_back(f);
+    }
+    int i = 0;
+    for (auto &kv : r1) { words[i] = kv.first; word_w[i] = kv.second; i++; }
+    *n_words = i;
+    int k = 0, o = 0;
+    for (auto &kv : r2) {
+        nodes[k] = kv.first; node_off[k] = o;
+        for (int32_t f : kv.second) node_feat[o++] = f;
+        k++;
+    }
+    if (n > 0) node_off[k] = o;
+    *n_nodes = k;
+    return ORBFE_OK;
+}
+
+static int rot_bin(float a1, float a2)
+{
+    const float factor = 1.0f / HISTO_LENGTH;
+    float rot = a1 - a2;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)roundf(rot * factor);
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+// ORBmatcher::SearchByFboW(KeyFrame*, Frame&, vpMapPointMatches), src/ORBmatcher.cc:157-283
+extern "C" int orbfe_search_by_bow(orbfe_context *ctx,
+                                   const uint32_t *kf_nodes, const int32_t *kf_off, const int32_t *kf_feat, int kf_nnodes,
+                                   const int32_t *kf_valid, const uint8_t *kf_desc, const float *kf_angle, int n_kf,
+                                   const uint32_t *f_nodes, const int32_t *f_off, const int32_t *f_feat, int f_nnodes,
+                                   const uint8_t *f_desc, const float *f_angle, int n_f,
+                                   float nnratio, int check_ori, int32_t *f_match, int *nmatches)
+{
+    if (!ctx || !nmatches || n_kf < 0 || n_f < 0 || kf_nnodes < 0 || f_nnodes < 0 || (n_f > 0 && !f_match) ||
+        (kf_nnodes > 0 && (!kf_nodes || !kf_off || !kf_feat || !kf_valid || !kf_desc || !kf_angle)) ||
+        (f_nnodes > 0 && (!f_nodes || !f_off || !f_feat || !f_desc || !f_angle)))
+        return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
+    if (!st) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "out of host memory");
+    for (int j = 0; j < n_f; j++) f_match[j] = -1;
+    *nmatches = 0;
+    // merge-join of the two feature vectors: enumerate every (KF feature, frame feature) pair of a shared node
+    struct Seg { int a, b, pair0; };
+    std::vector<Seg> segs;
+    std::vector<uint32_t> pa, pb;
+    for (int a = 0, b = 0; a < kf_nnodes && b < f_nnodes;) {
+        if (kf_nodes[a] == f_nodes[b]) {
+            segs.push_back(Seg{a, b, (int)pa.size()});
+            for (int ik = kf_off[a]; ik < kf_off[a + 1]; ik++) {
+                if (kf_feat[ik] < 0 || kf_feat[ik] >= n_kf) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "KF feature index out of range");
+                for (int jf = f_off[b]; jf < f_off[b + 1]; jf++) {
+                    if (f_feat[jf] < 0 || f_feat[jf] >= n_f) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "frame feature index out of range");
+                    pa.push_back((uint32_t)kf_feat[ik]); pb.push_back((uint32_t)f_feat[jf]);
+                }
+            }
+            a++; b++;
+        } else if (kf_nodes[a] < f_nodes[b]) a++;
+        else b++;
+    }
+    const int np = (int)pa.size();
+    std::vector<uint16_t> dist(np > 0 ? np : 1);
+    if (np > 0) {
+        hipStream_t s = orbfe_ctx_stream(ctx);
+        BTRY(ctx, hipSetDevice(orbfe_ctx_device(ctx)));
+        const size_t need = (size_t)32 * n_kf + (size_t)32 * n_f + (size_t)np * (4 + 4 + 2) + 64;
+        int rc = ensure_scratch(ctx, st, need);
+        if (rc != ORBFE_OK) return rc;
+        uint8_t *d_a = (uint8_t *)st->d_scratch, *d_b = d_a + (size_t)32 * n_kf;
+        uint32_t *d_pa = (uint32_t *)(d_b + (size_t)32 * n_f), *d_pb = d_pa + np;
+        uint16_t *d_dist = (uint16_t *)(d_pb + np);
+        BTRY(ctx, hipMemcpyAsync(d_a, kf_desc, (size_t)32 * n_kf, hipMemcpyHostToDevice, s));
+        BTRY(ctx, hipMemcpyAsync(d_b, f_desc, (size_t)32 * n_f, hipMemcpyHostToDevice, s));
+        BTRY(ctx, hipMemcpyAsync(d_pa, pa.data(), sizeof(uint32_t) * np, hipMemcpyHostToDevice, s));
+        BTRY(ctx, hipMemcpyAsync(d_pb, pb.data(), sizeof(uint32_t) * np, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(pair_hamming_kernel, dim3((np + 255) / 256), dim3(256), 0, s, d_a, d_b, d_pa, d_pb, np, d_dist);
+        BTRY(ctx, hipMemcpyAsync(dist.data(), d_dist, sizeof(uint16_t) * np, hipMemcpyDeviceToHost, s));
+        BTRY(ctx, hipStreamSynchronize(s));
+        BTRY(ctx, hipGetLastError());
+    }
+    // greedy resolve in the reference's order
+    std::vector<int> hist[HISTO_LENGTH];
+    int nm = 0;
+    for (const Seg &sg : segs) {
+        const int nf = f_off[sg.b + 1] - f_off[sg.b];
+        int pi = sg.pair0;
+        for (int ik = kf_off[sg.a]; ik < kf_off[sg.a + 1]; ik++, pi += nf) {
+            const int real_kf = kf_feat[ik];
+            if (!kf_valid[real_kf]) continue;
+            int best1 = 256, best_f = -1, best2 = 256;
+            for (int j = 0; j < nf; j++) {
+                const int real_f = f_feat[f_off[sg.b] + j];
+                if (f_match[real_f] >= 0) continue;
+                const int d = dist[pi + j];
+                if (d < best1) { best2 = best1; best1 = d; best_f = real_f; }
+                else if (d < best2) best2 = d;
+            }
+            if (best1 <= TH_LOW && (float)best1 < nnratio * (float)best2) {
+                f_match[best_f] = real_kf;
+                if (check_ori) hist[rot_bin(kf_angle[real_kf], f_angle[best_f])].push_back(best_f);
+                nm++;
+            }
+        }
+    }
+    if (check_ori) {
+        int32_t sizes[HISTO_LENGTH];
+        for (int b = 0; b < HISTO_LENGTH; b++) sizes[b] = (int32_t)hist[b].size();
+        int i1, i2, i3;
+        orbfe_three_maxima(sizes, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int b = 0; b < HISTO_LENGTH; b++) {
+            if (b == i1 || b == i2 || b == i3) continue;
+            for (int idx : hist[b]) { f_match[idx] = -1; nm--; }
+        }
+    }
+    *nmatches = nm;
+    return ORBFE_OK;
+}

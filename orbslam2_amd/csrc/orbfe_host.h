@@ -13,3 +13,8 @@ hipStream_t orbfe_ctx_stream(orbfe_context *ctx);
 int orbfe_ctx_device(const orbfe_context *ctx);
 const orbfe_params *orbfe_ctx_params(const orbfe_context *ctx);
 const float *orbfe_ctx_scale_factors(const orbfe_context *ctx);
+
+struct orbfe_bow_state;
+orbfe_bow_state *orbfe_bow_state_create();
+void orbfe_bow_state_destroy(orbfe_bow_state *s);
+orbfe_bow_state *orbfe_ctx_bow_state(orbfe_context *ctx);

@@ -1,0 +1,126 @@
+"""Bag of words: fbow transform + SearchByFboW.  The vocabulary file is missing from the
+reference tree (.MISSING_LARGE_BLOBS), so a small one is synthesised (k-majority tree) in the fbow format."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from orbslam2_amd import bow as B
+
+
+def _descs(seed, n, base=None, flip=0.0):
+    rng = np.random.default_rng(seed)
+    if base is None:
+        protos = rng.integers(0, 256, (40, 32)).astype(np.uint8)
+        d = protos[rng.integers(0, 40, n)]
+        d = d ^ np.packbits(rng.random((n, 256)) < 0.12, axis=1, bitorder="little")
+        return d
+    return base ^ np.packbits(rng.random((len(base), 256)) < flip, axis=1, bitorder="little")
+
+
+@pytest.fixture(scope="module")
+def vocab():
+    train = _descs(1, 6000)
+    return B.build_vocabulary(train, k=10, levels=5, seed=7)
+
+
+def _oracle_voc(blob):
+    L = O.lib()
+    L.orc_vocab_from_blob.restype = C.c_void_p; L.orc_vocab_from_blob.argtypes = [C.c_void_p, C.c_size_t]
+    L.orc_vocab_destroy.argtypes = [C.c_void_p]; L.orc_vocab_destroy.restype = None
+    L.orc_vocab_k.argtypes = [C.c_void_p]; L.orc_vocab_k.restype = C.c_int
+    L.orc_bow_descend.restype = None
+    L.orc_bow_descend.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_bow_maps.restype = C.c_int
+    L.orc_bow_maps.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5 + [C.POINTER(C.c_int)]
+    L.orc_search_by_bow.restype = C.c_int
+    L.orc_search_by_bow.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 2 + \
+        [C.c_int, C.c_float, C.c_int, C.c_void_p]
+    buf = np.frombuffer(blob, np.uint8)
+    v = L.orc_vocab_from_blob(buf.ctypes.data_as(C.c_void_p), len(buf))
+    assert v
+    return L, v
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _oracle_transform(L, v, d, level=4):
+    n = len(d)
+    d = np.ascontiguousarray(d)
+    w = np.zeros(n, np.uint32); wt = np.zeros(n, np.float32); nd = np.zeros(n, np.uint32)
+    L.orc_bow_descend(v, _p(d), n, level, _p(w), _p(wt), _p(nd))
+    words = np.zeros(n, np.uint32); ww = np.zeros(n, np.float32); nodes = np.zeros(n, np.uint32)
+    off = np.zeros(n + 1, np.int32); feat = np.zeros(n, np.int32); nn = C.c_int()
+    nw = L.orc_bow_maps(_p(w), _p(wt), _p(nd), n, _p(words), _p(ww), _p(nodes), _p(off), _p(feat), C.byref(nn))
+    return (w, wt, nd), (words[:nw], ww[:nw]), (nodes[: nn.value], off[: nn.value + 1], feat)
+
+
+def test_vocabulary_format_and_oracle_descend(vocab):
+    sig, = struct.unpack_from("<Q", vocab, 0)
+    assert sig == 55824124 and len(vocab) > 128
+    L, v = _oracle_voc(vocab)
+    assert L.orc_vocab_k(v) == 10
+    d = _descs(2, 800)
+    (w, wt, nd), (words, ww), (nodes, off, feat) = _oracle_transform(L, v, d)
+    assert (wt > 0).all() and len(words) > 50
+    # weights of a word: n additions of the same leaf weight in float
+    for i in (0, len(words) // 2, len(words) - 1):
+        m = w == words[i]
+        acc = np.float32(0)
+        for x in wt[m]:
+            acc = np.float32(acc + x)
+        assert ww[i] == acc and len(set(wt[m].tolist())) == 1
+    assert off[-1] == len(d) and sorted(feat.tolist()) == list(range(len(d)))
+    for kk in range(len(nodes)):
+        seg = feat[off[kk]:off[kk + 1]]
+        assert (np.diff(seg) > 0).all() and (nd[seg] == nodes[kk]).all()
+    # identical descriptors land in the same word / node; node ids are 4 bits per level
+    d2 = np.concatenate([d[:5], d[:5]])
+    (w2, _, nd2), _, _ = _oracle_transform(L, v, d2)
+    assert np.array_equal(w2[:5], w2[5:]) and np.array_equal(nd2[:5], nd2[5:]) and (nd2 < 16 ** 4).all()
+    L.orc_vocab_destroy(v)
+
+
+@pytest.mark.gpu
+def test_gpu_bow_transform_and_search(vocab):
+    from orbslam2_amd import api
+    ctx = api.Context(width=640, height=480)
+    with pytest.raises(api.OrbfeError):
+        B.transform(ctx, _descs(3, 10))  # no vocabulary yet
+    with pytest.raises(api.OrbfeError):
+        B.vocab_load(ctx, b"\x00" * 200)  # bad signature
+    B.vocab_load(ctx, vocab)
+    L, v = _oracle_voc(vocab)
+    kf_d = _descs(4, 1500)
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(1500)[:1200]
+    f_d = np.concatenate([_descs(6, 0, base=kf_d[perm], flip=0.04), _descs(7, 400)])
+    for level in (4, 2, 9):
+        (w, wt, nd), (words, ww), fv = _oracle_transform(L, v, kf_d, level)
+        gw, gwt, gnd = B.transform(ctx, kf_d, level)
+        assert np.array_equal(gw, w) and np.array_equal(gwt, wt) and np.array_equal(gnd, nd)
+        mw, mww, mn, mo, mf = B.maps(gw, gwt, gnd)
+        assert np.array_equal(mw, words) and np.array_equal(mww, ww)
+        assert np.array_equal(mn, fv[0]) and np.array_equal(mo, fv[1]) and np.array_equal(mf, fv[2])
+    with pytest.raises(api.OrbfeError):
+        B.transform(ctx, kf_d[:0])  # fbow: "No input data"
+    _, _, kf_fv = _oracle_transform(L, v, kf_d)
+    _, _, f_fv = _oracle_transform(L, v, f_d)
+    kf_valid = (rng.random(len(kf_d)) < 0.8).astype(np.int32)
+    kf_ang = rng.uniform(0, 360, len(kf_d)).astype(np.float32)
+    f_ang = np.concatenate([(kf_ang[perm] + rng.normal(0, 5, 1200)) % 360, rng.uniform(0, 360, 400)]).astype(np.float32)
+    for ratio, ori in ((0.7, True), (0.75, False), (0.95, True)):
+        ref = np.zeros(len(f_d), np.int32)
+        nref = L.orc_search_by_bow(_p(kf_fv[0]), _p(kf_fv[1]), _p(kf_fv[2]), len(kf_fv[0]), _p(kf_valid), _p(kf_d), _p(kf_ang),
+                                   _p(f_fv[0]), _p(f_fv[1]), _p(f_fv[2]), len(f_fv[0]), _p(f_d), _p(f_ang), len(f_d), ratio, int(ori), _p(ref))
+        got, ngot = B.search_by_bow(ctx, kf_fv, kf_valid, kf_d, kf_ang, f_fv, f_d, f_ang, ratio, ori)
+        assert ngot == nref and np.array_equal(got, ref)
+    assert nref > 300
+    ok = ref >= 0
+    assert np.mean(perm[np.nonzero(ok)[0][np.nonzero(ok)[0] < 1200]] == ref[ok][np.nonzero(ok)[0] < 1200]) > 0.9
+    L.orc_vocab_destroy(v)
+    ctx.close()
