@@ -1,15 +1,61 @@
-// ORBmatcher.h -- host-side mirror of ORB_SLAM2::ORBmatcher (include/ORBmatcher.h:38-102).  See below.
+// ORBmatcher.h -- host-side mirror of ORB_SLAM2::ORBmatcher (reference include/ORBmatcher.h:38-102) over
+// the C ABI (include/orbfe.h).  Same class name, constructor (nnratio, checkOri), constants and method
+// names for the Tracking-thread overloads; the pointer-rich arguments (Frame&, KeyFrame*, MapPoint*) are
+// replaced by the flattened views a maintainer fills from those objects (INTEGRATION.md shows how):
+//   FrameView   <- Frame::N, mvKeysUn, mvuRight, mDescriptors, mnMin/MaxX/Y          (include/Frame.h)
+//   PointArrays <- per map point: GetWorldPos(), GetDescriptor(), Observations(), ... (include/MapPoint.h)
+// Results come back as index arrays: "keypoint k of the frame received point i" instead of MapPoint*.
 #pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
 #include "../../include/orbfe.h"
+
 namespace ORB_SLAM2
 {
+
+struct FrameView {
+    std::vector<orbfe_keypoint> mvKeysUn;
+    std::vector<float> mvuRight;          // empty for monocular
+    std::vector<uint8_t> mDescriptors;    // N x 32
+    float mnMinX = 0.f, mnMaxX = 0.f, mnMinY = 0.f, mnMaxY = 0.f;
+    orbfe_frame_view c_view() const
+    {
+        orbfe_frame_view v;
+        v.n = (int32_t)mvKeysUn.size();
+        v.keys_un = mvKeysUn.data();
+        v.u_right = mvuRight.empty() ? nullptr : mvuRight.data();
+        v.descriptors = mDescriptors.data();
+        v.min_x = mnMinX; v.max_x = mnMaxX; v.min_y = mnMinY; v.max_y = mnMaxY;
+        return v;
+    }
+};
+
+// Map points seen from a frame / keyframe, one entry per keypoint slot of that frame.
+struct PointArrays {
+    std::vector<float> pos;        // GetWorldPos(), n x 3
+    std::vector<uint8_t> desc;     // GetDescriptor(), n x 32
+    std::vector<int32_t> valid;    // pMP != NULL && usable (see each method)
+    std::vector<int32_t> obs;      // Observations()
+    std::vector<int32_t> octave;   // mvKeys[i].octave of the owning frame
+    std::vector<float> angle;      // mvKeysUn[i].angle of the owning frame
+    std::vector<float> maxDistance, minDistance; // mfMaxDistance, mfMinDistance
+    int size() const { return (int)valid.size(); }
+};
+
 class ORBmatcher
 {
 public:
-    ORBmatcher(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+    // include/ORBmatcher.h:42
+    ORBmatcher(orbfe_context *ctx, float nnratio = 0.6, bool checkOri = true) : mCtx(ctx), mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
     static const int TH_LOW = 50;   // src/ORBmatcher.cc:35-37
     static const int TH_HIGH = 100;
     static const int HISTO_LENGTH = 30;
+
     // ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1643-1659) on two 32-byte rows.
     static int DescriptorDistance(const uint8_t *a, const uint8_t *b)
     {
@@ -17,8 +63,80 @@ public:
         for (int i = 0; i < 32; i++) dist += __builtin_popcount((unsigned)(a[i] ^ b[i]));
         return dist;
     }
+
+    // SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono), src/ORBmatcher.cc:1324.
+    // Tcw are the top 3x4 rows of Frame::mTcw.  curMatch[k] = index into `last`, or -1.
+    int SearchByProjection(const FrameView &CurrentFrame, const float *TcwCur, const float *TcwLast, const PointArrays &last,
+                           const std::vector<uint8_t> &curHasObs, float th, bool bMono, std::vector<int32_t> &curMatch)
+    {
+        const orbfe_frame_view v = CurrentFrame.c_view();
+        curMatch.assign(v.n > 0 ? v.n : 1, -1);
+        int n = 0;
+        Check(orbfe_search_by_projection_last(mCtx, &v, TcwCur, TcwLast, last.size(), last.pos.data(), last.desc.data(), last.valid.data(),
+                                              last.obs.data(), last.octave.data(), last.angle.data(),
+                                              curHasObs.empty() ? nullptr : curHasObs.data(), th, bMono ? 1 : 0, mbCheckOrientation ? 1 : 0,
+                                              curMatch.data(), &n));
+        curMatch.resize(v.n);
+        return n;
+    }
+
+    // SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th), src/ORBmatcher.cc:43; the
+    // track points are the outputs of Frame::isInFrustum (orbfe_is_in_frustum).
+    int SearchByProjection(const FrameView &F, const std::vector<orbfe_track_point> &pts, const std::vector<uint8_t> &desc,
+                           const std::vector<int32_t> &obs, const std::vector<uint8_t> &hasObs, float th, std::vector<int32_t> &match)
+    {
+        const orbfe_frame_view v = F.c_view();
+        match.assign(v.n > 0 ? v.n : 1, -1);
+        int n = 0;
+        Check(orbfe_search_by_projection_points(mCtx, &v, (int)pts.size(), pts.data(), desc.data(), obs.data(),
+                                                hasObs.empty() ? nullptr : hasObs.data(), th, mfNNratio, match.data(), &n));
+        match.resize(v.n);
+        return n;
+    }
+
+    // SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist), src/ORBmatcher.cc:1468
+    int SearchByProjection(const FrameView &CurrentFrame, const float *TcwCur, const PointArrays &kf, const std::vector<uint8_t> &curHasPoint,
+                           float th, int ORBdist, std::vector<int32_t> &curMatch)
+    {
+        const orbfe_frame_view v = CurrentFrame.c_view();
+        curMatch.assign(v.n > 0 ? v.n : 1, -1);
+        int n = 0;
+        Check(orbfe_search_by_projection_kf(mCtx, &v, TcwCur, kf.size(), kf.pos.data(), kf.desc.data(), kf.valid.data(), kf.angle.data(),
+                                            kf.maxDistance.data(), kf.minDistance.data(), curHasPoint.empty() ? nullptr : curHasPoint.data(),
+                                            th, ORBdist, mbCheckOrientation ? 1 : 0, curMatch.data(), &n));
+        curMatch.resize(v.n);
+        return n;
+    }
+
+    // SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize), src/ORBmatcher.cc:400
+    int SearchForInitialization(const FrameView &F1, const FrameView &F2, std::vector<float> &vbPrevMatched /* n1 x 2 */,
+                                std::vector<int32_t> &vnMatches12, int windowSize = 10)
+    {
+        const orbfe_frame_view v1 = F1.c_view(), v2 = F2.c_view();
+        vnMatches12.assign(v1.n > 0 ? v1.n : 1, -1);
+        int n = 0;
+        Check(orbfe_search_for_initialization(mCtx, &v1, &v2, vbPrevMatched.data(), windowSize, mfNNratio, mbCheckOrientation ? 1 : 0,
+                                              vnMatches12.data(), &n));
+        vnMatches12.resize(v1.n);
+        return n;
+    }
+
+    // ComputeThreeMaxima(histo, L, ind1, ind2, ind3), src/ORBmatcher.cc:1597
+    void ComputeThreeMaxima(const std::vector<int> *histo, const int L, int &ind1, int &ind2, int &ind3)
+    {
+        std::vector<int32_t> sizes(L);
+        for (int i = 0; i < L; i++) sizes[i] = (int32_t)histo[i].size();
+        orbfe_three_maxima(sizes.data(), L, &ind1, &ind2, &ind3);
+    }
+
 protected:
+    void Check(int rc)
+    {
+        if (rc != ORBFE_OK) throw std::runtime_error(std::string("orbfe: ") + orbfe_last_error(mCtx));
+    }
+    orbfe_context *mCtx;
     float mfNNratio;
     bool mbCheckOrientation;
 };
+
 } // namespace ORB_SLAM2

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "ORBextractor.h"
+#include "ORBmatcher.h"
 
 static std::vector<uint8_t> slurp(const char *path, size_t n)
 {
@@ -49,6 +50,19 @@ int main(int argc, char **argv)
         std::vector<orbfe_keypoint> k2(3); std::vector<uint8_t> d2(96);
         mono(ORB_SLAM2::ImageView{}, k2, d2);
         if (k2.size() != 3 || d2.size() != 96) { std::cerr << "empty-image contract broken\n"; return 5; }
+        // ORBmatcher mirror: mono initialisation matching of the left frame against the right frame
+        ORB_SLAM2::FrameView F1, F2;
+        F1.mvKeysUn = out.mvKeys; F1.mDescriptors = out.mDescriptors;
+        F2.mvKeysUn = out.mvKeysRight; F2.mDescriptors = out.mDescriptorsRight;
+        F1.mnMinX = F2.mnMinX = 0.f; F1.mnMaxX = F2.mnMaxX = (float)w; F1.mnMinY = F2.mnMinY = 0.f; F1.mnMaxY = F2.mnMaxY = (float)h;
+        std::vector<float> prev(2 * out.mvKeys.size());
+        for (size_t i = 0; i < out.mvKeys.size(); i++) { prev[2 * i] = out.mvKeys[i].x; prev[2 * i + 1] = out.mvKeys[i].y; }
+        ORB_SLAM2::ORBmatcher matcher(extractorLeft.Context(), 0.9f, true); // src/Tracking.cc:698
+        std::vector<int32_t> m12;
+        const int nInit = matcher.SearchForInitialization(F1, F2, prev, m12, 100);
+        if (ORB_SLAM2::ORBmatcher::DescriptorDistance(out.mDescriptors.data(), out.mDescriptors.data()) != 0) { std::cerr << "distance\n"; return 6; }
+        dump(prefix + ".m12", m12); dump(prefix + ".pm", prev);
+        std::printf("init matches=%d\n", nInit);
         dump(prefix + ".kl", out.mvKeys); dump(prefix + ".dl", out.mDescriptors);
         dump(prefix + ".kr", out.mvKeysRight); dump(prefix + ".dr", out.mDescriptorsRight);
         dump(prefix + ".ur", out.mvuRight); dump(prefix + ".dp", out.mvDepth);

@@ -16,7 +16,9 @@ pytestmark = pytest.mark.gpu
 KITTI = dict(width=1241, height=376, nfeatures=2000, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, bf=386.1448)
 SMALL = dict(width=320, height=240, nfeatures=500, fx=300.0, fy=300.0, cx=160.0, cy=120.0, bf=120.0)
 TUM1 = dict(width=640, height=480, nfeatures=1000, fx=517.3, fy=516.5, cx=318.6, cy=255.3, bf=40.0)
-CONFIGS = {"small": SMALL, "kitti": KITTI, "tum1": TUM1}
+EUROC = dict(width=752, height=480, nfeatures=1200, fx=458.654, fy=457.296, cx=367.215, cy=248.375, bf=47.9)
+D435I = dict(width=1280, height=720, nfeatures=2500, fx=911.0, fy=911.0, cx=640.0, cy=360.0, bf=45.5)
+CONFIGS = {"small": SMALL, "kitti": KITTI, "tum1": TUM1, "euroc": EUROC, "d435i": D435I}
 
 
 def _ctx(cfg, max_images=2):
@@ -24,7 +26,7 @@ def _ctx(cfg, max_images=2):
     return api.Context(max_images=max_images, **cfg)
 
 
-@pytest.fixture(scope="module", params=["small", "kitti", "tum1"])
+@pytest.fixture(scope="module", params=["small", "kitti", "tum1", "euroc", "d435i"])
 def case(request):
     cfg = CONFIGS[request.param]
     left, right = synth.stereo_pair(cfg["width"], cfg["height"], seed=1234)
@@ -125,3 +127,31 @@ def test_hamming_matrix(case):
     ref = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(axis=2)
     assert np.array_equal(got, ref)
     assert got[3, 5] == O.hamming256(a[3], b[5])
+
+
+def test_rgbd_frame_matches_oracle():
+    """Frame::Frame(rgbd) body: extract + ComputeStereoFromRGBD (src/Frame.cc:645-666), BASELINE config 5 geometry."""
+    cfg = D435I
+    left, _, depth = synth.stereo_pair(cfg["width"], cfg["height"], seed=77, with_depth=True, bf=cfg["bf"])
+    ctx = _ctx(cfg, max_images=1)
+    out = ctx.rgbd_frame(left, depth)
+    ex = O.Extractor(nfeatures=cfg["nfeatures"])
+    k, d = ex.extract(left)
+    ur, dp = O.stereo_from_rgbd(k, k, depth, cfg["bf"])
+    _assert_kps_equal(out["kps"], k, "rgbd")
+    assert np.array_equal(out["desc"], d)
+    assert np.array_equal(out["u_right"], ur) and np.array_equal(out["depth"], dp)
+    assert (dp > 0).mean() > 0.8 and (dp == -1).sum() > 0  # 5 % holes in the synthetic depth map
+    ctx.close()
+
+
+def test_empty_and_flat_images():
+    from orbslam2_amd import api
+    ctx = _ctx(SMALL)
+    k, d = ctx.extract(np.zeros((SMALL["height"], SMALL["width"]), np.uint8))  # no corners at all
+    assert len(k) == 0 and d.shape == (0, 32)
+    out = ctx.stereo_frame(np.full((SMALL["height"], SMALL["width"]), 200, np.uint8), np.zeros((SMALL["height"], SMALL["width"]), np.uint8))
+    assert len(out["kps_left"]) == 0 and len(out["u_right"]) == 0
+    with pytest.raises(api.OrbfeError):
+        ctx.extract(np.zeros((100, 100), np.uint8))  # size other than the context's
+    ctx.close()

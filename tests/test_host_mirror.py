@@ -1,0 +1,47 @@
+"""The C++ host mirror (orbslam2_amd/host: ORBextractor / ORBmatcher classes with the reference's names and
+call patterns) drives the same C ABI and reproduces the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from orbslam2_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "orbslam2_amd", "host", "host_selftest")
+
+
+def test_mirror_headers_keep_the_reference_names():
+    ex = open(os.path.join(ROOT, "orbslam2_amd", "host", "ORBextractor.h")).read()
+    for name in ("class ORBextractor", "GetLevels", "GetScaleFactor", "GetScaleFactors", "GetInverseScaleFactors", "GetScaleSigmaSquares",
+                 "GetInverseScaleSigmaSquares", "mvImagePyramid", "int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST"):
+        assert name in ex, name
+    m = open(os.path.join(ROOT, "orbslam2_amd", "host", "ORBmatcher.h")).read()
+    for name in ("class ORBmatcher", "TH_LOW = 50", "TH_HIGH = 100", "HISTO_LENGTH = 30", "DescriptorDistance", "SearchByProjection",
+                 "SearchForInitialization", "ComputeThreeMaxima"):
+        assert name in m, name
+
+
+@pytest.mark.gpu
+def test_cpp_selftest_matches_oracle(tmp_path):
+    assert os.path.exists(EXE), "host_selftest not built (make -C orbslam2_amd/host)"
+    w, h, nf, fx, bf = 480, 300, 500, 420.0, 150.0
+    left, right = synth.stereo_pair(w, h, seed=55)
+    lp, rp, pre = tmp_path / "l.raw", tmp_path / "r.raw", str(tmp_path / "out")
+    left.tofile(lp); right.tofile(rp)
+    r = subprocess.run([EXE, str(lp), str(rp), str(w), str(h), str(nf), str(fx), str(bf), pre], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    exl, exr = O.Extractor(nfeatures=nf), O.Extractor(nfeatures=nf)
+    kl, dl = exl.extract(left); kr, dr = exr.extract(right)
+    ur, dp, _ = O.stereo_matches(exl, exr, kl, dl, kr, dr, bf, fx)
+    assert np.array_equal(np.fromfile(pre + ".kl", O.KP_DTYPE), kl) and np.array_equal(np.fromfile(pre + ".kr", O.KP_DTYPE), kr)
+    assert np.array_equal(np.fromfile(pre + ".dl", np.uint8).reshape(-1, 32), dl)
+    assert np.array_equal(np.fromfile(pre + ".dr", np.uint8).reshape(-1, 32), dr)
+    assert np.array_equal(np.fromfile(pre + ".ur", np.float32), ur) and np.array_equal(np.fromfile(pre + ".dp", np.float32), dp)
+    g2 = O.Grid(kr, 0.0, float(w), 0.0, float(h))
+    prev = np.stack([kl["x"], kl["y"]], axis=1)
+    m12, pm, n = O.search_for_initialization(kl, dl, g2, dr, prev, 100, 0.9, True)
+    assert np.array_equal(np.fromfile(pre + ".m12", np.int32), m12) and np.array_equal(np.fromfile(pre + ".pm", np.float32).reshape(-1, 2), pm)
+    assert ("init matches=%d" % n) in r.stdout and n > 20
