@@ -68,6 +68,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise OSError("liborbfe.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "or `make -C orbslam2_amd/csrc`")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; two HIP runtimes in one process make the second one
+    # see no GPU.  Importing torch first makes its copy the process-wide runtime that liborbfe.so binds to.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.orbfe_abi_version.restype = C.c_int

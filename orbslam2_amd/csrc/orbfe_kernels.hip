@@ -889,13 +889,25 @@ __global__ __launch_bounds__(256) void describe_kernel(DeviceConfig cfg, DeviceB
     const uint8_t *blr = buf.blur + (size_t)img * cfg.pyr_bytes + L.pyr_off;
     // stage both patches (aligned dwords; the right overshoot stays inside the level's margin)
     const int xr = (cx - hp) & ~3, xb = (cx - 18) & ~3;
-    for (int i = lane; i < raw_rows * (DS_PATCH_W / 4); i += 64) {
-        const int r = i / (DS_PATCH_W / 4), c = i - r * (DS_PATCH_W / 4);
-        ((uint32_t *)s_raw)[i] = *(const uint32_t *)(raw + (ptrdiff_t)(cy - hp + r) * L.pitch + xr + 4 * c);
-    }
-    for (int i = lane; i < 37 * (DS_PATCH_W / 4); i += 64) {
-        const int r = i / (DS_PATCH_W / 4), c = i - r * (DS_PATCH_W / 4);
-        ((uint32_t *)s_blr)[i] = *(const uint32_t *)(blr + (ptrdiff_t)(cy - 18 + r) * L.pitch + xb + 4 * c);
+    // word i = lane + 64*k of a staged patch is (row i / 10, word i % 10); rows advance by 6 and words by 4
+    // per step, so the (quarter-rate) integer multiplies and the division stay out of the loops
+    {
+        const int r0 = lane / (DS_PATCH_W / 4), c0 = lane - r0 * (DS_PATCH_W / 4);
+        const uint8_t *gp = raw + (ptrdiff_t)__mul24(cy - hp + r0, L.pitch) + xr + 4 * c0;
+        const int step = 6 * L.pitch + 16, wrap = L.pitch - DS_PATCH_W;
+        int c = c0;
+        for (int i = lane; i < raw_rows * (DS_PATCH_W / 4); i += 64) {
+            ((uint32_t *)s_raw)[i] = *(const uint32_t *)gp;
+            gp += step; c += 4;
+            if (c >= DS_PATCH_W / 4) { c -= DS_PATCH_W / 4; gp += wrap; }
+        }
+        gp = blr + (ptrdiff_t)__mul24(cy - 18 + r0, L.pitch) + xb + 4 * c0;
+        c = c0;
+        for (int i = lane; i < 37 * (DS_PATCH_W / 4); i += 64) {
+            ((uint32_t *)s_blr)[i] = *(const uint32_t *)gp;
+            gp += step; c += 4;
+            if (c >= DS_PATCH_W / 4) { c -= DS_PATCH_W / 4; gp += wrap; }
+        }
     }
     __builtin_amdgcn_s_waitcnt(0); // LDS writes of this wave are visible to its own later reads in order
     __builtin_amdgcn_wave_barrier();
@@ -908,7 +920,7 @@ __global__ __launch_bounds__(256) void describe_kernel(DeviceConfig cfg, DeviceB
     for (int kk = lane; kk < cfg.patch_n; kk += 64) {
         const int uv = s_uv[kk];
         const int u = (int)(int8_t)(uv & 0xff), v = (int)(int8_t)((uv >> 8) & 0xff);
-        const int I = pc[v * DS_PATCH_W + u];
+        const int I = pc[__mul24(v, DS_PATCH_W) + u];
         m10 += u * I;
         m01 += v * I;
     }
@@ -933,8 +945,8 @@ __global__ __launch_bounds__(256) void describe_kernel(DeviceConfig cfg, DeviceB
         const int c0 = (int)rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int r1 = (int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int c1 = (int)rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = center[r0 * DS_PATCH_W + c0];
-        const int t1 = center[r1 * DS_PATCH_W + c1];
+        const int t0 = center[__mul24(r0, DS_PATCH_W) + c0];
+        const int t1 = center[__mul24(r1, DS_PATCH_W) + c1];
         bits[r] = __ballot(t0 < t1);
     }
     if (lane < 4) dout[lane] = lane == 0 ? bits[0] : (lane == 1 ? bits[1] : (lane == 2 ? bits[2] : bits[3]));

@@ -429,12 +429,9 @@ __device__ void ot2_body(const Ot2Ctx &K, const LevelInfo &L, int region_h, int 
     if (tid == 0) *sel_cnt = n_out;
 }
 
-__global__ __launch_bounds__(OT2_THREADS) void octree2_kernel(DeviceConfig cfg, DeviceBuffers buf, int sort_cap, int lds_pts, int dbg_stop)
+__device__ void ot2_run_level(const DeviceConfig &cfg, const DeviceBuffers &buf, int level, int img, int sort_cap, int lds_pts, int dbg_stop,
+                              uint8_t *s_raw, int *s_w, int *s_scal)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
-    __shared__ int s_w[4 * OT2_WAVES];
-    __shared__ int s_scal[8];
-    const int level = blockIdx.x, img = blockIdx.y;
     const LevelInfo &L = cfg.lv[level];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int MAXN = cfg.max_nodes;
@@ -540,9 +537,25 @@ __global__ __launch_bounds__(OT2_THREADS) void octree2_kernel(DeviceConfig cfg, 
                         buf.status + img);
 }
 
+// A workgroup handles levels p and nlevels-1-p of one image back to back: candidates shrink ~1.44x per
+// level, so the pairs (0,7), (1,6), ... are balanced, and a batch of 32 stereo pairs is exactly one
+// workgroup per CU (the LDS footprint allows only one) instead of two unbalanced rounds.
+__global__ __launch_bounds__(OT2_THREADS) void octree2_kernel(DeviceConfig cfg, DeviceBuffers buf, int sort_cap, int lds_pts, int dbg_stop)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
+    __shared__ int s_w[4 * OT2_WAVES];
+    __shared__ int s_scal[8];
+    const int la = blockIdx.x, lb = cfg.nlevels - 1 - (int)blockIdx.x, img = blockIdx.y;
+    ot2_run_level(cfg, buf, la, img, sort_cap, lds_pts, dbg_stop, s_raw, s_w, s_scal);
+    if (lb != la) {
+        __syncthreads();
+        ot2_run_level(cfg, buf, lb, img, sort_cap, lds_pts, dbg_stop, s_raw, s_w, s_scal);
+    }
+}
+
 void orbfe_launch_octree2(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, int lds_pts, size_t lds, hipStream_t s)
 {
-    dim3 grid(cfg.nlevels, n_images);
+    dim3 grid((cfg.nlevels + 1) / 2, n_images);
     static const int dbg_stop = getenv("ORBFE_OT2_STOP") ? atoi(getenv("ORBFE_OT2_STOP")) : 0; // profiling aid only
     hipLaunchKernelGGL(octree2_kernel, grid, dim3(OT2_THREADS), lds, s, cfg, buf, sort_cap, lds_pts, dbg_stop);
 }
