@@ -340,6 +340,8 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
     A(b.sad, B * c.sel_total);
     A(b.status, B);
     A(ctx->d_in, B * (size_t)p.width * p.height);
+    A(b.dbg_ts, 4096);
+    hipMemset(b.dbg_ts, 0, 4096 * sizeof(long long));
     {   // stereo row table: a right keypoint spans at most 2*r+3 rows, r = 2*scale[top level]
         const int span = (int)(2.0f * 2.0f * ctx->scale[p.nlevels - 1]) + 3;
         ctx->cfg.row_idx_cap = c.sel_total * span;
@@ -668,6 +670,13 @@ extern "C" int orbfe_fetch_image(orbfe_context *ctx, int image, orbfe_keypoint *
         if (u_right) HIP_TRY(ctx, hipMemcpy(u_right, ctx->buf.u_right + image * st, sizeof(float) * cnt, hipMemcpyDeviceToHost));
         if (depth) HIP_TRY(ctx, hipMemcpy(depth, ctx->buf.depth + image * st, sizeof(float) * cnt, hipMemcpyDeviceToHost));
     }
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_debug_timestamps(orbfe_context *ctx, long long *dst, int n)
+{
+    if (!ctx || !dst || n < 0 || n > 4096) return ORBFE_ERR_INVALID;
+    HIP_TRY(ctx, hipMemcpy(dst, ctx->buf.dbg_ts, sizeof(long long) * n, hipMemcpyDeviceToHost));
     return ORBFE_OK;
 }
 

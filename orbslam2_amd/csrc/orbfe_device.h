@@ -78,6 +78,7 @@ struct DeviceBuffers {
     int *row_off;        // [pair][height+1] stereo row table offsets
     uint16_t *row_idx;   // [pair][row_idx_cap] right-keypoint indices per row
     const uint32_t *rs_tab; // cv::resize offset/weight tables of every level (see pyr_resize_kernel)
+    long long *dbg_ts;   // 4096 timestamps for kernel bring-up (ORBFE_OT2_STOP=99); never read by product code
     const uint8_t *slot_level; // [sel_total] level of every keypoint slot
     const int16_t *patch_uv; // IC_Angle patch offsets: (u & 0xff) | (v << 8), padded with (0,0)
 };

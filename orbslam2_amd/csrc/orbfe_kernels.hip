@@ -341,11 +341,16 @@ __device__ __forceinline__ void load_ring(const uint8_t *t, int pitch, int d[16]
     d[12] = v - t[-3];             d[13] = v - t[pitch - 3];      d[14] = v - t[2 * pitch - 2];  d[15] = v - t[3 * pitch - 1];
 }
 
-__global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceBuffers buf, int tile_pitch, int tile_bytes, int sc_bytes, int q_bytes, int dbg)
+__global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int tile_pitch, int tile_bytes, int sc_bytes, int q_bytes, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
-    const int img = blockIdx.y;
-    const int cell = blockIdx.x;
+    // XCD-aware block -> (image, cell) map (same scheme as describe_kernel): consecutive cells of one image run
+    // on one XCD, so the 128-B lines that horizontally / vertically adjacent cell tiles share (a 37-row tile
+    // uses ~44 B of each line) are served by that XCD's L2 instead of being re-fetched from HBM by 8 XCDs.
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int img = (jb / cfg.cells_total) * 8 + xcd;
+    if (img >= n_images) return;
+    const int cell = jb % cfg.cells_total;
     int level = 0;
     for (int l = 1; l < cfg.nlevels; l++)
         if (cell >= cfg.lv[l].cell_off) level = l;
@@ -1282,9 +1287,9 @@ void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_
     const int q_bytes = (2 * mw * mh + 15) & ~15;
     // flags alias the tile: it must hold one byte per interior pixel
     const size_t lds = (size_t)(tile_bytes > mw * mh ? tile_bytes : ((mw * mh + 15) & ~15)) + sc_bytes + q_bytes;
-    dim3 grid(cfg.cells_total, n_images);
+    dim3 grid(cfg.cells_total * ((n_images + 7) / 8) * 8);
     static const int dbg = getenv("ORBFE_FAST_DBG") ? atoi(getenv("ORBFE_FAST_DBG")) : 0; // profiling aid only
-    hipLaunchKernelGGL(fast_cell_kernel, grid, dim3(64), lds, s, cfg, buf, tile_pitch, tile_bytes, sc_bytes, q_bytes, dbg);
+    hipLaunchKernelGGL(fast_cell_kernel, grid, dim3(64), lds, s, cfg, buf, n_images, tile_pitch, tile_bytes, sc_bytes, q_bytes, dbg);
 }
 
 static inline int ot_sort_cap(const DeviceConfig &cfg) { int p = 1; while (p < cfg.max_nodes) p <<= 1; return p; }

@@ -24,6 +24,8 @@
 #define OT2_WAVES (OT2_THREADS / 64)
 #define OT2_ID_BITS 20 // position word = candidate id (20 bits) | owning node (12 bits)
 #define OT2_ID_MASK 0xfffffu
+// bring-up aid: thread 0 of (image 0, the level in g_ts_level) stamps the shader clock
+#define OT2_TS(slot) do { if (ts && threadIdx.x == 0) ts[(slot)] = clock64(); } while (0)
 
 __device__ __forceinline__ int ot2_wave_incl_scan(int v, int lane)
 {
@@ -123,7 +125,7 @@ struct Ot2Ctx {
 
 // LDSP: point array + xy/score tables in LDS (nc <= 16 * OT2_THREADS); else ping-pong in HBM.
 template <bool LDSP>
-__device__ void ot2_body(const Ot2Ctx &K, const LevelInfo &L, int region_h, int nc, int quota,
+__device__ __forceinline__ void ot2_body(long long *ts, const Ot2Ctx &K, const LevelInfo &L, int region_h, int nc, int quota,
                          const uint32_t *xy_tab, const uint8_t *sc_tab, // indexed by candidate id
                          uint32_t *ip_c, uint32_t *ip_n,                // (id | node << 16) by position
                          uint32_t *sel_xy, uint8_t *sel_sc, int *sel_cnt, int *status)
@@ -176,11 +178,13 @@ __device__ void ot2_body(const Ot2Ctx &K, const LevelInfo &L, int region_h, int 
         __syncthreads();
     }
 
+    OT2_TS(3);
     // ---- split passes ----
     Ot2Nodes cur = K.A, nxt = K.B;
     int sorted_phase = 0;
     for (int iter = 0; iter < 100000; iter++) { // n grows every pass, so this ends at n >= quota at the latest
         const int n = *K.s_n;
+        if (iter < 20) OT2_TS(8 + 8 * iter);
         for (int i = tid; i < 4 * n; i += OT2_THREADS) s_ccnt[i] = 0;
         for (int i = tid; i < n; i += OT2_THREADS) { s_rank[i] = -1; s_kk[i] = cur.cnt[i] > 1 ? 1 : 0; }
         __syncthreads();
@@ -204,6 +208,27 @@ __device__ void ot2_body(const Ot2Ctx &K, const LevelInfo &L, int region_h, int 
                     if (r1) atomicAdd(&s_ccnt[4 * run_nd + 1], r1);
                     if (r2) atomicAdd(&s_ccnt[4 * run_nd + 2], r2);
                     if (r3) atomicAdd(&s_ccnt[4 * run_nd + 3], r3);
+                }
+            };
+            // final flush: while nodes are few and large a whole wave sits inside one node and 64 lanes would
+            // serialise on the same four LDS counters; reduce across the wave first in that case
+            auto flush_final = [&]() {
+                const int first = __builtin_amdgcn_readfirstlane(run_nd);
+                if (__all(run_nd == first)) {
+                    int a0 = multi ? r0 : 0, a1 = multi ? r1 : 0, a2 = multi ? r2 : 0, a3 = multi ? r3 : 0;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64);
+                        a2 += __shfl_xor(a2, o, 64); a3 += __shfl_xor(a3, o, 64);
+                    }
+                    if ((threadIdx.x & 63) == 0 && first >= 0) {
+                        if (a0) atomicAdd(&s_ccnt[4 * first], a0);
+                        if (a1) atomicAdd(&s_ccnt[4 * first + 1], a1);
+                        if (a2) atomicAdd(&s_ccnt[4 * first + 2], a2);
+                        if (a3) atomicAdd(&s_ccnt[4 * first + 3], a3);
+                    }
+                } else {
+                    flush();
                 }
             };
             auto step1 = [&](int j, uint32_t ip, uint32_t xy_staged) {
@@ -234,102 +259,154 @@ __device__ void ot2_body(const Ot2Ctx &K, const LevelInfo &L, int region_h, int 
 #pragma unroll 4
                 for (int j = jb; j < je; j++) step1(j, ip_c[j], 0u);
             }
-            flush();
+            flush_final();
         }
+        if (iter < 20) OT2_TS(9 + 8 * iter);
         int tot4[4];
         ot2_block_scan4(lc, tot4, s_w); // lc = E(chunk start)[c]
         s_ct[4 * tid] = lc[0]; s_ct[4 * tid + 1] = lc[1]; s_ct[4 * tid + 2] = lc[2]; s_ct[4 * tid + 3] = lc[3];
-        // (2) processing order of the multi-point nodes
-        const int m = ot2_scan_array(s_kk, n, s_w); // s_kk[i] = rank among multi nodes (list order)
-        if (!sorted_phase) {
-            for (int i = tid; i < n; i += OT2_THREADS)
-                if (cur.cnt[i] > 1) s_plist[s_kk[i]] = i;
-            __syncthreads();
+        int n_new, nexpand_fast = -1;
+        if (!sorted_phase && n <= OT2_THREADS) {
+            // Streamlined full pass (every multi-point node is split, list order = processing order): thread i
+            // owns node i and one 4-value block scan yields its rank, the children ahead of it, the unsplit nodes
+            // ahead of it and the pass totals -- 7 barriers per pass instead of 18.
+            int v4[4] = {0, 0, 0, 0}, c0 = 0, c1 = 0, c2 = 0, c3 = 0, k = 0, multi = 0;
+            if (tid < n) {
+                multi = cur.cnt[tid] > 1;
+                if (multi) {
+                    c0 = s_ccnt[4 * tid]; c1 = s_ccnt[4 * tid + 1]; c2 = s_ccnt[4 * tid + 2]; c3 = s_ccnt[4 * tid + 3];
+                    k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+                    v4[0] = 1; v4[1] = k; v4[3] = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
+                } else {
+                    v4[2] = 1;
+                }
+            }
+            int tot[4];
+            ot2_block_scan4(v4, tot, s_w); // exclusive prefixes in list order
+            const int total_k = tot[1];
+            n_new = total_k + tot[2];
+            nexpand_fast = tot[3];
+            if (n_new > MAXN) {
+                if (tid == 0) { *status = 2; *sel_cnt = 0; }
+                return;
+            }
+            if (tid < n) {
+                const int i = tid;
+                if (!multi) {
+                    const int q = total_k + v4[2];
+                    nxt.x0[q] = cur.x0[i]; nxt.y0[q] = cur.y0[i]; nxt.x1[q] = cur.x1[i]; nxt.y1[q] = cur.y1[i];
+                    nxt.beg[q] = cur.beg[i]; nxt.cnt[q] = cur.cnt[i];
+                    s_newun[i] = q;
+                    s_rank[i] = -1;
+                } else {
+                    s_rank[i] = v4[0];
+                    const int x0 = cur.x0[i], y0 = cur.y0[i], x1 = cur.x1[i], y1 = cur.y1[i];
+                    const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+                    const int beg = cur.beg[i];
+                    int q = total_k - (v4[1] + k);
+                    const int b0 = beg, b1 = beg + c0, b2 = b1 + c1, b3 = b2 + c2;
+                    if (c3 > 0) { nxt.x0[q] = (short)mx; nxt.y0[q] = (short)my; nxt.x1[q] = (short)x1; nxt.y1[q] = (short)y1; nxt.beg[q] = b3; nxt.cnt[q] = c3; s_newidx[4 * i + 3] = q; q++; }
+                    if (c2 > 0) { nxt.x0[q] = (short)x0; nxt.y0[q] = (short)my; nxt.x1[q] = (short)mx; nxt.y1[q] = (short)y1; nxt.beg[q] = b2; nxt.cnt[q] = c2; s_newidx[4 * i + 2] = q; q++; }
+                    if (c1 > 0) { nxt.x0[q] = (short)mx; nxt.y0[q] = (short)y0; nxt.x1[q] = (short)x1; nxt.y1[q] = (short)my; nxt.beg[q] = b1; nxt.cnt[q] = c1; s_newidx[4 * i + 1] = q; q++; }
+                    if (c0 > 0) { nxt.x0[q] = (short)x0; nxt.y0[q] = (short)y0; nxt.x1[q] = (short)mx; nxt.y1[q] = (short)my; nxt.beg[q] = b0; nxt.cnt[q] = c0; s_newidx[4 * i] = q; q++; }
+                }
+            }
         } else {
-            int P = 1;
-            while (P < m) P <<= 1;
-            for (int i = tid; i < P; i += OT2_THREADS) s_key[i] = ~0ull;
-            __syncthreads();
-            for (int i = tid; i < n; i += OT2_THREADS)
-                if (cur.cnt[i] > 1)
-                    s_key[s_kk[i]] = ((unsigned long long)(0xffffffffu - (unsigned)cur.cnt[i]) << 32) | (unsigned)i;
-            __syncthreads();
-            for (int k = 2; k <= P; k <<= 1) {
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int i = tid; i < P; i += OT2_THREADS) {
-                        const int ixj = i ^ j;
-                        if (ixj > i) {
-                            const unsigned long long a = s_key[i], b = s_key[ixj];
-                            const bool up = ((i & k) == 0);
-                            if ((a > b) == up) { s_key[i] = b; s_key[ixj] = a; }
+            // (2) processing order of the multi-point nodes
+            const int m = ot2_scan_array(s_kk, n, s_w); // s_kk[i] = rank among multi nodes (list order)
+            if (!sorted_phase) {
+                for (int i = tid; i < n; i += OT2_THREADS)
+                    if (cur.cnt[i] > 1) s_plist[s_kk[i]] = i;
+                __syncthreads();
+            } else {
+                int P = 1;
+                while (P < m) P <<= 1;
+                for (int i = tid; i < P; i += OT2_THREADS) s_key[i] = ~0ull;
+                __syncthreads();
+                for (int i = tid; i < n; i += OT2_THREADS)
+                    if (cur.cnt[i] > 1)
+                        s_key[s_kk[i]] = ((unsigned long long)(0xffffffffu - (unsigned)cur.cnt[i]) << 32) | (unsigned)i;
+                __syncthreads();
+                for (int k = 2; k <= P; k <<= 1) {
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        for (int i = tid; i < P; i += OT2_THREADS) {
+                            const int ixj = i ^ j;
+                            if (ixj > i) {
+                                const unsigned long long a = s_key[i], b = s_key[ixj];
+                                const bool up = ((i & k) == 0);
+                                if ((a > b) == up) { s_key[i] = b; s_key[ixj] = a; }
+                            }
                         }
+                        __syncthreads();
                     }
-                    __syncthreads();
                 }
+                for (int i = tid; i < m; i += OT2_THREADS) s_plist[i] = (int)(s_key[i] & 0xffffffffu);
+                __syncthreads();
             }
-            for (int i = tid; i < m; i += OT2_THREADS) s_plist[i] = (int)(s_key[i] & 0xffffffffu);
+            if (iter < 20) OT2_TS(10 + 8 * iter);
+            // k = non-empty children per processing rank; exclusive prefix in s_un
+            for (int r = tid; r < m; r += OT2_THREADS) {
+                const int i = s_plist[r];
+                const int k = (s_ccnt[4 * i] > 0) + (s_ccnt[4 * i + 1] > 0) + (s_ccnt[4 * i + 2] > 0) + (s_ccnt[4 * i + 3] > 0);
+                s_kk[r] = k;
+                s_un[r] = k;
+            }
             __syncthreads();
-        }
-        // k = non-empty children per processing rank; exclusive prefix in s_un
-        for (int r = tid; r < m; r += OT2_THREADS) {
-            const int i = s_plist[r];
-            const int k = (s_ccnt[4 * i] > 0) + (s_ccnt[4 * i + 1] > 0) + (s_ccnt[4 * i + 2] > 0) + (s_ccnt[4 * i + 3] > 0);
-            s_kk[r] = k;
-            s_un[r] = k;
-        }
-        __syncthreads();
-        ot2_scan_array(s_un, m, s_w);
-        if (tid == 0) {
-            int nproc = m;
-            if (sorted_phase) { // first r with n + sum_{r'<=r}(k-1) >= quota (src/ORBextractor.cc:724-725)
-                for (int r = 0; r < m; r++) {
-                    const int incl = s_un[r] + s_kk[r];
-                    if (n + incl - (r + 1) >= quota) { nproc = r + 1; break; }
+            ot2_scan_array(s_un, m, s_w);
+            if (tid == 0) {
+                int nproc = m;
+                if (sorted_phase) { // first r with n + sum_{r'<=r}(k-1) >= quota (src/ORBextractor.cc:724-725)
+                    for (int r = 0; r < m; r++) {
+                        const int incl = s_un[r] + s_kk[r];
+                        if (n + incl - (r + 1) >= quota) { nproc = r + 1; break; }
+                    }
                 }
+                *K.s_nproc = nproc;
+                *K.s_total_k = nproc > 0 ? s_un[nproc - 1] + s_kk[nproc - 1] : 0;
+                *K.s_nexpand = 0;
             }
-            *K.s_nproc = nproc;
-            *K.s_total_k = nproc > 0 ? s_un[nproc - 1] + s_kk[nproc - 1] : 0;
-            *K.s_nexpand = 0;
-        }
-        __syncthreads();
-        const int nproc = *K.s_nproc, total_k = *K.s_total_k;
-        for (int r = tid; r < nproc; r += OT2_THREADS) s_rank[s_plist[r]] = r;
-        __syncthreads();
-        for (int i = tid; i < n; i += OT2_THREADS) s_plist[i] = (s_rank[i] < 0) ? 1 : 0; // reuse: unprocessed flags
-        __syncthreads();
-        const int n_un = ot2_scan_array(s_plist, n, s_w);
-        const int n_new = total_k + n_un;
-        if (n_new > MAXN) { // cannot happen for max_nodes >= max(quota+3, 4*n_ini); guard anyway
-            if (tid == 0) { *status = 2; *sel_cnt = 0; }
-            return;
-        }
-        // (3) new node array in list order: blocks of later-processed parents nearer the front, children n4..n1
-        for (int i = tid; i < n; i += OT2_THREADS) {
-            const int r = s_rank[i];
-            if (r < 0) {
-                const int q = total_k + s_plist[i];
-                nxt.x0[q] = cur.x0[i]; nxt.y0[q] = cur.y0[i]; nxt.x1[q] = cur.x1[i]; nxt.y1[q] = cur.y1[i];
-                nxt.beg[q] = cur.beg[i]; nxt.cnt[q] = cur.cnt[i];
-                s_newun[i] = q;
-                continue;
+            __syncthreads();
+            const int nproc = *K.s_nproc, total_k = *K.s_total_k;
+            for (int r = tid; r < nproc; r += OT2_THREADS) s_rank[s_plist[r]] = r;
+            __syncthreads();
+            for (int i = tid; i < n; i += OT2_THREADS) s_plist[i] = (s_rank[i] < 0) ? 1 : 0; // reuse: unprocessed flags
+            __syncthreads();
+            const int n_un = ot2_scan_array(s_plist, n, s_w);
+            n_new = total_k + n_un;
+            if (n_new > MAXN) { // cannot happen for max_nodes >= max(quota+3, 4*n_ini); guard anyway
+                if (tid == 0) { *status = 2; *sel_cnt = 0; }
+                return;
             }
-            const int x0 = cur.x0[i], y0 = cur.y0[i], x1 = cur.x1[i], y1 = cur.y1[i];
-            const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
-            const int beg = cur.beg[i];
-            const int c0 = s_ccnt[4 * i], c1 = s_ccnt[4 * i + 1], c2 = s_ccnt[4 * i + 2], c3 = s_ccnt[4 * i + 3];
-            const int k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
-            int q = total_k - (s_un[r] + k);
-            int nexp = 0;
-            const int b0 = beg, b1 = beg + c0, b2 = b1 + c1, b3 = b2 + c2;
-            if (c3 > 0) { nxt.x0[q] = (short)mx; nxt.y0[q] = (short)my; nxt.x1[q] = (short)x1; nxt.y1[q] = (short)y1; nxt.beg[q] = b3; nxt.cnt[q] = c3; s_newidx[4 * i + 3] = q; q++; nexp += c3 > 1; }
-            if (c2 > 0) { nxt.x0[q] = (short)x0; nxt.y0[q] = (short)my; nxt.x1[q] = (short)mx; nxt.y1[q] = (short)y1; nxt.beg[q] = b2; nxt.cnt[q] = c2; s_newidx[4 * i + 2] = q; q++; nexp += c2 > 1; }
-            if (c1 > 0) { nxt.x0[q] = (short)mx; nxt.y0[q] = (short)y0; nxt.x1[q] = (short)x1; nxt.y1[q] = (short)my; nxt.beg[q] = b1; nxt.cnt[q] = c1; s_newidx[4 * i + 1] = q; q++; nexp += c1 > 1; }
-            if (c0 > 0) { nxt.x0[q] = (short)x0; nxt.y0[q] = (short)y0; nxt.x1[q] = (short)mx; nxt.y1[q] = (short)my; nxt.beg[q] = b0; nxt.cnt[q] = c0; s_newidx[4 * i] = q; q++; nexp += c0 > 1; }
-            if (nexp) atomicAdd(K.s_nexpand, nexp);
+            if (iter < 20) OT2_TS(11 + 8 * iter);
+            // (3) new node array in list order: blocks of later-processed parents nearer the front, children n4..n1
+            for (int i = tid; i < n; i += OT2_THREADS) {
+                const int r = s_rank[i];
+                if (r < 0) {
+                    const int q = total_k + s_plist[i];
+                    nxt.x0[q] = cur.x0[i]; nxt.y0[q] = cur.y0[i]; nxt.x1[q] = cur.x1[i]; nxt.y1[q] = cur.y1[i];
+                    nxt.beg[q] = cur.beg[i]; nxt.cnt[q] = cur.cnt[i];
+                    s_newun[i] = q;
+                    continue;
+                }
+                const int x0 = cur.x0[i], y0 = cur.y0[i], x1 = cur.x1[i], y1 = cur.y1[i];
+                const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+                const int beg = cur.beg[i];
+                const int c0 = s_ccnt[4 * i], c1 = s_ccnt[4 * i + 1], c2 = s_ccnt[4 * i + 2], c3 = s_ccnt[4 * i + 3];
+                const int k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+                int q = total_k - (s_un[r] + k);
+                int nexp = 0;
+                const int b0 = beg, b1 = beg + c0, b2 = b1 + c1, b3 = b2 + c2;
+                if (c3 > 0) { nxt.x0[q] = (short)mx; nxt.y0[q] = (short)my; nxt.x1[q] = (short)x1; nxt.y1[q] = (short)y1; nxt.beg[q] = b3; nxt.cnt[q] = c3; s_newidx[4 * i + 3] = q; q++; nexp += c3 > 1; }
+                if (c2 > 0) { nxt.x0[q] = (short)x0; nxt.y0[q] = (short)my; nxt.x1[q] = (short)mx; nxt.y1[q] = (short)y1; nxt.beg[q] = b2; nxt.cnt[q] = c2; s_newidx[4 * i + 2] = q; q++; nexp += c2 > 1; }
+                if (c1 > 0) { nxt.x0[q] = (short)mx; nxt.y0[q] = (short)y0; nxt.x1[q] = (short)x1; nxt.y1[q] = (short)my; nxt.beg[q] = b1; nxt.cnt[q] = c1; s_newidx[4 * i + 1] = q; q++; nexp += c1 > 1; }
+                if (c0 > 0) { nxt.x0[q] = (short)x0; nxt.y0[q] = (short)y0; nxt.x1[q] = (short)mx; nxt.y1[q] = (short)my; nxt.beg[q] = b0; nxt.cnt[q] = c0; s_newidx[4 * i] = q; q++; nexp += c0 > 1; }
+                if (nexp) atomicAdd(K.s_nexpand, nexp);
+            }
         }
         // (4) walk 2: scatter every point (children ranges subdivide the parent's range; others stay put)
         // (LDS mode: single buffer; every thread staged its chunk at the top of the pass, before any write)
         __syncthreads();
+        if (iter < 20) OT2_TS(12 + 8 * iter);
         {
             int e0 = s_ct[4 * tid], e1 = s_ct[4 * tid + 1], e2 = s_ct[4 * tid + 2], e3 = s_ct[4 * tid + 3]; // E(j)[c], running
             int run_nd = -1, mx = 0, my = 0, multi = 0, rk = -1, cb0 = 0, cb1 = 0, cb2 = 0, cb3 = 0, nun = 0;
@@ -375,12 +452,13 @@ __device__ void ot2_body(const Ot2Ctx &K, const LevelInfo &L, int region_h, int 
                 for (int j = jb; j < je; j++) step(j, ip_c[j], 0u);
             }
         }
+        if (iter < 20) OT2_TS(13 + 8 * iter);
         // (5) stop logic (src/ORBextractor.cc:661-731)
         if (tid == 0) {
             const int prev = n;
             *K.s_n = n_new;
             if (n_new >= quota || n_new == prev) *K.s_done = 1;
-            else if (!sorted_phase && n_new + 3 * *K.s_nexpand > quota) *K.s_mode = 1;
+            else if (!sorted_phase && n_new + 3 * (nexpand_fast >= 0 ? nexpand_fast : *K.s_nexpand) > quota) *K.s_mode = 1;
             else *K.s_mode = sorted_phase;
         }
         __syncthreads();
@@ -391,6 +469,7 @@ __device__ void ot2_body(const Ot2Ctx &K, const LevelInfo &L, int region_h, int 
         __syncthreads();
     }
 
+    OT2_TS(4);
     // ---- keep the best response per node, first wins (src/ORBextractor.cc:735-754) ----
     const int n = *K.s_n;
     const int n_out = n < L.sel_cap ? n : L.sel_cap;
@@ -427,14 +506,17 @@ __device__ void ot2_body(const Ot2Ctx &K, const LevelInfo &L, int region_h, int 
         }
     }
     if (tid == 0) *sel_cnt = n_out;
+    OT2_TS(5);
 }
 
-__device__ void ot2_run_level(const DeviceConfig &cfg, const DeviceBuffers &buf, int level, int img, int sort_cap, int lds_pts, int dbg_stop,
+__device__ __forceinline__ void ot2_run_level(const DeviceConfig &cfg, const DeviceBuffers &buf, int level, int img, int sort_cap, int lds_pts, int dbg_stop,
                               uint8_t *s_raw, int *s_w, int *s_scal)
 {
     const LevelInfo &L = cfg.lv[level];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int MAXN = cfg.max_nodes;
+    long long *ts = (dbg_stop >= 100 && img == 0 && level == dbg_stop - 100) ? buf.dbg_ts : nullptr;
+    OT2_TS(0);
 
     Ot2Ctx K;
     uint8_t *p = s_raw;
@@ -497,6 +579,7 @@ __device__ void ot2_run_level(const DeviceConfig &cfg, const DeviceBuffers &buf,
         nc = total;
         __syncthreads();
     }
+    OT2_TS(1);
     if (nc > L.cand_cap) { nc = L.cand_cap; if (tid == 0) buf.status[img] = 1; }
     if (nc > (1 << OT2_ID_BITS)) { nc = 1 << OT2_ID_BITS; if (tid == 0) buf.status[img] = 4; } // host routes such levels to the generic kernel
     if (tid == 0) buf.lvl_ncand[ib * cfg.nlevels + level] = nc;
@@ -525,15 +608,16 @@ __device__ void ot2_run_level(const DeviceConfig &cfg, const DeviceBuffers &buf,
         }
     }
     __syncthreads();
+    OT2_TS(2);
     if (nc == 0 || dbg_stop == 1) {
         if (tid == 0) *sel_cnt = 0;
         return;
     }
     const int region_h = (L.h - cfg.edge_threshold + 3) - cfg.min_border;
     if (ldsp)
-        ot2_body<true>(K, L, region_h, nc, dbg_stop >= 2 ? dbg_stop - 1 : L.quota, s_xy, s_sc, s_ip, s_ip, sel_xy, sel_sc, sel_cnt, buf.status + img);
+        ot2_body<true>(ts, K, L, region_h, nc, (dbg_stop >= 2 && dbg_stop < 100) ? dbg_stop - 1 : L.quota, s_xy, s_sc, s_ip, s_ip, sel_xy, sel_sc, sel_cnt, buf.status + img);
     else
-        ot2_body<false>(K, L, region_h, nc, L.quota, xy_a, sc_a, buf.idx0 + coff, buf.ot_xy2 + coff, sel_xy, sel_sc, sel_cnt,
+        ot2_body<false>(ts, K, L, region_h, nc, L.quota, xy_a, sc_a, buf.idx0 + coff, buf.ot_xy2 + coff, sel_xy, sel_sc, sel_cnt,
                         buf.status + img);
 }
 
