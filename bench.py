@@ -56,6 +56,18 @@ def stage_alg_bytes_per_pair(n_cand_per_image: float):
     }
 
 
+def traffic_bytes(stage: str, pairs: int, launches: int):
+    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (profiles/r01_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate passes of this same command, gfx950 correction 2 x FETCH_SIZE as
+    MI355X_MICROARCH.md prescribes), scaled from the profiled batch to this run's batch; None if not profiled."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"][stage]
+        per_pair = (2.0 * t["fetch_kb_per_pair"] + t["write_kb_per_pair"]) * 1024.0
+        return per_pair * pairs / launches
+    except Exception:
+        return None
+
+
 def cpu_baseline(n_pairs: int):
     """Oracle (kind=port) timed with the reference's threading: 2 threads per pair (src/Frame.cc:78-81)."""
     from oracle import oracle as O
@@ -91,7 +103,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=32, help="stereo pairs per step per GPU (in flight in HBM)")
-    ap.add_argument("--streams", type=int, default=2, help="stream groups the batch is cut into inside the library")
+    ap.add_argument("--streams", type=int, default=1, help="stream groups the batch is cut into inside the library (1 keeps per-kernel times clean; 2 overlaps stages, ~+5%)")
     ap.add_argument("--cpu-pairs", type=int, default=40, help="pairs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run oracle spot check")
     args = ap.parse_args()
@@ -188,7 +200,7 @@ def main():
                        "pairs_per_step_per_gpu": P, "stream_groups": G, "parallelism": "frame-pair sharding, no data-path collective",
                        "keypoints_left_right_pair0": [int(counts[0]), int(counts[1])]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bytes(dom, P, launches),
                          "launch_ms": dom_ms, "alg_bytes_per_launch": alg[dom] * P / launches,
                          "whole_pipeline": {"alg_bytes_per_pair": B_PAIR, "achieved": B_PAIR * value / world / 1e9,
                                             "frac": B_PAIR * value / world / 1e9 / HBM_PEAK_GBS},

@@ -1008,12 +1008,17 @@ __global__ __launch_bounds__(256) void stereo_rowtable_kernel(DeviceConfig cfg, 
     }
 }
 
-__global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, DeviceBuffers buf, int use_table)
+__global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_pairs, int use_table)
 {
-    const int pair = blockIdx.y;
+    // XCD-aware block -> (pair, block) map: all blocks of a pair on one XCD (its L2 then holds the pair's
+    // descriptors, keypoints and the pyramid rows the SAD windows touch)
+    const int bpp = (cfg.sel_total + 3) / 4;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int pair = (jb / bpp) * 8 + xcd;
+    if (pair >= n_pairs) return;
     const int imgL = 2 * pair, imgR = 2 * pair + 1;
     const int lane = threadIdx.x & 63;
-    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int iL = (jb % bpp) * 4 + (threadIdx.x >> 6);
     const int nL = buf.kp_cnt[imgL], nR = buf.kp_cnt[imgR];
     if (iL >= nL) return;
     const KeyPointPOD *kL = (const KeyPointPOD *)buf.kps + (size_t)imgL * cfg.sel_total;
@@ -1321,8 +1326,8 @@ void orbfe_launch_stereo_match(const DeviceConfig &cfg, const DeviceBuffers &buf
     const int use_table = (size_t)(cfg.height + 1) * sizeof(int) <= 48 * 1024 ? 1 : 0;
     if (use_table)
         hipLaunchKernelGGL(stereo_rowtable_kernel, dim3(n_pairs), dim3(256), (cfg.height + 1) * sizeof(int), s, cfg, buf);
-    dim3 grid((cfg.sel_total + 3) / 4, n_pairs);
-    hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(256), 0, s, cfg, buf, use_table);
+    dim3 grid(((cfg.sel_total + 3) / 4) * ((n_pairs + 7) / 8) * 8);
+    hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(256), 0, s, cfg, buf, n_pairs, use_table);
 }
 
 void orbfe_launch_stereo_median(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s)
