@@ -1,0 +1,63 @@
+"""Wider GPU parity sweep: odd geometries, feature budgets that stress every quadtree path (few / many nodes, the
+"largest first" phase, levels without cells), several scenes.  Everything is compared bit-exactly with the oracle."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from orbslam2_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (width, height, nfeatures, seed)
+    (777, 333, 1500, 1), (1241, 376, 500, 2), (1241, 376, 4000, 3), (640, 480, 3000, 4), (200, 160, 300, 5),
+    (131, 97, 200, 6), (1920, 1080, 2000, 7), (1241, 376, 37, 8), (410, 1000, 800, 9), (1241, 376, 2000, 10),
+    (1241, 376, 2000, 11), (96, 64, 100, 12), (64, 62, 50, 13),
+]
+
+
+@pytest.mark.parametrize("w,h,nf,seed", CASES)
+def test_stereo_frame_bit_exact(w, h, nf, seed):
+    from orbslam2_amd import api
+    left, right = synth.stereo_pair(w, h, seed=seed)
+    fx, bf = 0.6 * w, 0.25 * w
+    ctx = api.Context(width=w, height=h, nfeatures=nf, fx=fx, fy=fx, cx=w / 2, cy=h / 2, bf=bf)
+    out = ctx.stereo_frame(left, right)
+    exl, exr = O.Extractor(nfeatures=nf), O.Extractor(nfeatures=nf)
+    kl, dl = exl.extract(left); kr, dr = exr.extract(right)
+    ur, dp, _ = O.stereo_matches(exl, exr, kl, dl, kr, dr, bf, fx)
+    for l in range(8):
+        for a, b in zip(ctx.fetch_candidates(0, l), exl.level_candidates(l)):
+            assert np.array_equal(a, b), "candidates level %d" % l
+    assert np.array_equal(out["kps_left"], kl.astype(api.KP_DTYPE)), "left keypoints"
+    assert np.array_equal(out["kps_right"], kr.astype(api.KP_DTYPE)), "right keypoints"
+    assert np.array_equal(out["desc_left"], dl) and np.array_equal(out["desc_right"], dr)
+    assert np.array_equal(out["u_right"], ur) and np.array_equal(out["depth"], dp)
+    ctx.close()
+
+
+def test_noise_image_many_candidates():
+    """Pure noise: ~20 % of the pixels are FAST corners; exercises big candidate sets (HBM quadtree path for level 0)."""
+    from orbslam2_amd import api
+    rng = np.random.default_rng(99)
+    img = rng.integers(0, 256, (376, 1241)).astype(np.uint8)
+    ctx = api.Context(width=1241, height=376, nfeatures=2000)
+    k, d = ctx.extract(img)
+    ex = O.Extractor(nfeatures=2000)
+    kr, dr = ex.extract(img)
+    ncand = [len(ex.level_candidates(l)[0]) for l in range(8)]
+    assert ncand[0] > 8192  # above the LDS-resident limit
+    assert np.array_equal(k, kr.astype(api.KP_DTYPE)) and np.array_equal(d, dr)
+    ctx.close()
+
+
+def test_reuse_context_many_frames():
+    from orbslam2_amd import api
+    ctx = api.Context(width=480, height=320, nfeatures=700, fx=400.0, fy=400.0, cx=240.0, cy=160.0, bf=100.0)
+    ex = O.Extractor(nfeatures=700)
+    for seed in range(20, 26):
+        left = synth.mono_image(480, 320, seed=seed)
+        k, d = ctx.extract(left)
+        kr, dr = ex.extract(left)
+        assert np.array_equal(k, kr.astype(api.KP_DTYPE)) and np.array_equal(d, dr), seed
+    ctx.close()
