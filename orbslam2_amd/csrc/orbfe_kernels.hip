@@ -341,6 +341,16 @@ __device__ __forceinline__ void load_ring(const uint8_t *t, int pitch, int d[16]
     d[12] = v - t[-3];             d[13] = v - t[pitch - 3];      d[14] = v - t[2 * pitch - 2];  d[15] = v - t[3 * pitch - 1];
 }
 
+// Two adjacent bytes P, P+1 of a 12-byte row window (w[0] | w[1] | w[2]), zero-extended into the two
+// 16-bit halves of a register: one v_perm_b32 with a constant selector (0x0c selects 0x00).
+template <int P> __device__ __forceinline__ pk16 row_pair(const unsigned (&w)[3])
+{
+    if constexpr (P + 1 <= 7)
+        return __builtin_bit_cast(pk16, __builtin_amdgcn_perm(w[1], w[0], (unsigned)P | 0x0c00u | ((unsigned)(P + 1) << 16) | 0x0c000000u));
+    else
+        return __builtin_bit_cast(pk16, __builtin_amdgcn_perm(w[2], w[1], (unsigned)(P - 4) | 0x0c00u | ((unsigned)(P - 3) << 16) | 0x0c000000u));
+}
+
 __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int tile_pitch, int tile_bytes, int sc_bytes, int q_bytes, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
@@ -389,8 +399,6 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
     uint16_t *s_q2 = s_q1;
     uint8_t *s_qf = s_tile;                            // per queue-2 entry: 0 / 1 (local max, >= minTh) / 2 (>= iniTh)
     const int scp = iw + 2;
-    const int npx = iw * ih;
-    const float rcp_iw = 1.0f / (float)iw;
 
     const int xa = ini_x & ~3, ox = ini_x - xa;
     const int wpr = (max_x - xa + 3) >> 2; // words per tile row
@@ -416,37 +424,73 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
     // ---- A: cv::FAST's quick test on the 8 opposite ring pairs, for every interior pixel: a dark
     //      (bright) 9-arc needs one darker (brighter) pixel in every pair.  Passing BOTH polarities means
     //      every pair straddles the centre, which excludes any 9-arc, so such pixels are dropped;
-    //      survivors are queued in row-major order with their polarity in bit 15. ----
+    //      survivors are queued in row-major order with their polarity in bit 15.
+    //      A lane owns FOUR horizontally adjacent pixels whose tile bytes are 3..6 of a 12-byte window
+    //      (3 aligned LDS words per ring row, 21 per group): every ring column x-3..x+3 of the four pixels
+    //      lies inside the window, so each ring position is two v_perm_b32 with constant selectors, and the
+    //      test runs on raw ring values (with d = v - r: min_k max(d_k, d_k+8) = v - max_k min(r_k, r_k+8)). ----
     int n2 = 0;
     {
-        // (r, c) of pixels i = lane and i = lane + 64, both advanced by 128 per step
-        int ra = (int)(((float)lane + 0.5f) * rcp_iw), ca = lane - ra * iw;
-        int rb = (int)(((float)(lane + 64) + 0.5f) * rcp_iw), cb = lane + 64 - rb * iw;
-        const int dr = 128 / iw, dc = 128 - dr * iw;
-        for (int i0 = 0; i0 < npx; i0 += 128) {
-            const bool va = i0 + lane < npx, vb = i0 + 64 + lane < npx;
-            const uint8_t *pa = &s_tile[__mul24(va ? ra + 3 : 3, tile_pitch) + (va ? ca : 0) + 3 + ox];
-            const uint8_t *pb = &s_tile[__mul24(vb ? rb + 3 : 3, tile_pitch) + (vb ? cb : 0) + 3 + ox];
-            const pk16 vv = {(short)pa[0], (short)pb[0]};
-            pk16 lo = {512, 512}, hi = {-512, -512};
+        const int ng = (iw + ox + 3) >> 2;       // groups per interior row; group j covers c = 4j - ox .. 4j - ox + 3
+        const int G = ng * ih;
+        const float rcp_ng = 1.0f / (float)ng;
+        int rg = (int)(((float)lane + 0.5f) * rcp_ng), jg = lane - rg * ng;
+        const int dr = 64 / ng, dj = 64 - dr * ng;
+        const int pw = tile_pitch >> 2;
+        for (int g0 = 0; g0 < G; g0 += 64) {
+            const bool vg = g0 + lane < G;
+            const uint32_t *tw4 = (const uint32_t *)s_tile + (vg ? __mul24(rg, pw) + jg : 0);
+            unsigned w[7][3];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const pk16 d0 = vv - (pk16){(short)pa[roff[k]], (short)pb[roff[k]]};
-                const pk16 d1 = vv - (pk16){(short)pa[roff[k + 8]], (short)pb[roff[k + 8]]};
-                lo = __builtin_elementwise_min(lo, __builtin_elementwise_max(d0, d1));
-                hi = __builtin_elementwise_max(hi, __builtin_elementwise_min(d0, d1));
+            for (int y = 0; y < 7; y++) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) w[y][i] = tw4[y * pw + i];
             }
-            const bool da = lo.x > t, ba = hi.x < -t, db = lo.y > t, bb = hi.y < -t;
-            const bool passa = va & (da != ba), passb = vb & (db != bb);
-            const unsigned long long ma = __ballot(passa), mb = __ballot(passb);
-            if (passa) s_q2[n2 + __popcll(ma & lt)] = (uint16_t)((ra << 8) | ca | (ba ? 0x8000 : 0));
-            n2 += __popcll(ma);
-            if (passb) s_q2[n2 + __popcll(mb & lt)] = (uint16_t)((rb << 8) | cb | (bb ? 0x8000 : 0));
-            n2 += __popcll(mb);
-            ca += dc; ra += dr;
-            if (ca >= iw) { ca -= iw; ra++; }
-            cb += dc; rb += dr;
-            if (cb >= iw) { cb -= iw; rb++; }
+            pk16 A01, A23, B01, B23;
+#define FAST_PAIR(first, ya, sa, yb, sb)                                                                          \
+    {                                                                                                             \
+        const pk16 a01 = row_pair<sa>(w[ya]), a23 = row_pair<sa + 2>(w[ya]);                                     \
+        const pk16 b01 = row_pair<sb>(w[yb]), b23 = row_pair<sb + 2>(w[yb]);                                     \
+        const pk16 n01 = __builtin_elementwise_min(a01, b01), x01 = __builtin_elementwise_max(a01, b01);          \
+        const pk16 n23 = __builtin_elementwise_min(a23, b23), x23 = __builtin_elementwise_max(a23, b23);          \
+        if (first) { A01 = n01; B01 = x01; A23 = n23; B23 = x23; }                                                \
+        else {                                                                                                    \
+            A01 = __builtin_elementwise_max(A01, n01); B01 = __builtin_elementwise_min(B01, x01);                 \
+            A23 = __builtin_elementwise_max(A23, n23); B23 = __builtin_elementwise_min(B23, x23);                 \
+        }                                                                                                         \
+    }
+            // ring pairs (k, k+8): (dx, dy) -> window start byte 3 + dx, tile row 3 + dy
+            FAST_PAIR(true, 6, 3, 0, 3)   // ( 0, 3) / ( 0,-3)
+            FAST_PAIR(false, 6, 4, 0, 2)  // ( 1, 3) / (-1,-3)
+            FAST_PAIR(false, 5, 5, 1, 1)  // ( 2, 2) / (-2,-2)
+            FAST_PAIR(false, 4, 6, 2, 0)  // ( 3, 1) / (-3,-1)
+            FAST_PAIR(false, 3, 6, 3, 0)  // ( 3, 0) / (-3, 0)
+            FAST_PAIR(false, 2, 6, 4, 0)  // ( 3,-1) / (-3, 1)
+            FAST_PAIR(false, 1, 5, 5, 1)  // ( 2,-2) / (-2, 2)
+            FAST_PAIR(false, 0, 4, 6, 2)  // ( 1,-3) / (-1, 3)
+#undef FAST_PAIR
+            const pk16 v01 = row_pair<3>(w[3]), v23 = row_pair<5>(w[3]);
+            const pk16 lo01 = v01 - A01, hi01 = v01 - B01, lo23 = v23 - A23, hi23 = v23 - B23;
+            const int c0 = 4 * jg - ox;
+            const bool d0 = lo01.x > t, b0 = hi01.x < -t, d1 = lo01.y > t, b1 = hi01.y < -t;
+            const bool d2 = lo23.x > t, b2 = hi23.x < -t, d3 = lo23.y > t, b3 = hi23.y < -t;
+            const bool p0 = vg & (c0 >= 0) & (d0 != b0);
+            const bool p1 = vg & (c0 + 1 >= 0) & (c0 + 1 < iw) & (d1 != b1);
+            const bool p2 = vg & (c0 + 2 >= 0) & (c0 + 2 < iw) & (d2 != b2);
+            const bool p3 = vg & (c0 + 3 < iw) & (d3 != b3);
+            const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1), m2 = __ballot(p2), m3 = __ballot(p3);
+            int pos = n2 + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt);
+            const int e = (rg << 8) + c0; // c0 < 0 only for pixels that are never stored
+            if (p0) s_q2[pos] = (uint16_t)(e | (b0 ? 0x8000 : 0));
+            pos += p0;
+            if (p1) s_q2[pos] = (uint16_t)((e + 1) | (b1 ? 0x8000 : 0));
+            pos += p1;
+            if (p2) s_q2[pos] = (uint16_t)((e + 2) | (b2 ? 0x8000 : 0));
+            pos += p2;
+            if (p3) s_q2[pos] = (uint16_t)((e + 3) | (b3 ? 0x8000 : 0));
+            n2 += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+            jg += dj; rg += dr;
+            if (jg >= ng) { jg -= ng; rg++; }
         }
     }
     __syncthreads();
@@ -460,20 +504,23 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
         const int ra = (ea >> 8) & 127, ca = ea & 255, rb = (eb >> 8) & 127, cb = eb & 255;
         const uint8_t *pa = &s_tile[(ra + 3) * tile_pitch + ca + 3 + ox];
         const uint8_t *pb = &s_tile[(rb + 3) * tile_pitch + cb + 3 + ox];
-        const pk16 vv = {(short)pa[0], (short)pb[0]};
-        const pk16 sg = {(short)((ea & 0x8000u) ? -1 : 1), (short)((eb & 0x8000u) ? -1 : 1)};
+        // sign-normalise by complementing bright entries (x -> -x-1 in both centre and ring keeps differences):
+        // score = max_arcs min_arc (v' - r'_k) = v' - min_arcs max_arc r'_k, so the arcs run on raw ring values
+        const pk16 sg = {(short)((ea & 0x8000u) ? -1 : 0), (short)((eb & 0x8000u) ? -1 : 0)};
+        const pk16 vv = (pk16){(short)pa[0], (short)pb[0]} ^ sg;
         pk16 e[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) e[k] = (vv - (pk16){(short)pa[roff[k]], (short)pb[roff[k]]}) * sg;
+        for (int k = 0; k < 16; k++) e[k] = (pk16){(short)pa[roff[k]], (short)pb[roff[k]]} ^ sg;
         pk16 m2[16], m4[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_min(e[k], e[(k + 1) & 15]);
+        for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_max(e[k], e[(k + 1) & 15]);
 #pragma unroll
-        for (int k = 0; k < 16; k++) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
-        pk16 best = {-512, -512};
+        for (int k = 0; k < 16; k++) m4[k] = __builtin_elementwise_max(m2[k], m2[(k + 2) & 15]);
+        pk16 worst = {512, 512};
 #pragma unroll
         for (int k = 0; k < 16; k++)
-            best = __builtin_elementwise_max(best, __builtin_elementwise_min(__builtin_elementwise_min(m4[k], m4[(k + 4) & 15]), e[(k + 8) & 15]));
+            worst = __builtin_elementwise_min(worst, __builtin_elementwise_max(__builtin_elementwise_max(m4[k], m4[(k + 4) & 15]), e[(k + 8) & 15]));
+        pk16 best = vv - worst;
         best = __builtin_elementwise_max(best, tt);
         const int sa = (int)best.x - 1, sb = (int)best.y - 1;
         if (va && sa >= t) s_sc[(ra + 1) * scp + ca + 1] = (uint8_t)sa;
