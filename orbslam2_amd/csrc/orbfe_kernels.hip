@@ -341,6 +341,12 @@ __device__ __forceinline__ void load_ring(const uint8_t *t, int pitch, int d[16]
     d[12] = v - t[-3];             d[13] = v - t[pitch - 3];      d[14] = v - t[2 * pitch - 2];  d[15] = v - t[3 * pitch - 1];
 }
 
+// number of set bits of m below this lane, plus acc (v_mbcnt_lo/hi accumulate form)
+__device__ __forceinline__ unsigned mbcnt64(unsigned long long m, unsigned acc)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, acc));
+}
+
 // Two adjacent bytes P, P+1 of a 12-byte row window (w[0] | w[1] | w[2]), zero-extended into the two
 // 16-bit halves of a register: one v_perm_b32 with a constant selector (0x0c selects 0x00).
 template <int P> __device__ __forceinline__ pk16 row_pair(const unsigned (&w)[3])
@@ -351,8 +357,12 @@ template <int P> __device__ __forceinline__ pk16 row_pair(const unsigned (&w)[3]
         return __builtin_bit_cast(pk16, __builtin_amdgcn_perm(w[2], w[1], (unsigned)(P - 4) | 0x0c00u | ((unsigned)(P - 3) << 16) | 0x0c000000u));
 }
 
-__global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int tile_pitch, int tile_bytes, int sc_bytes, int q_bytes, int dbg)
+// TP = tile pitch in bytes as a compile-time constant (0: run-time value): with it every ring / row offset folds
+// into the immediate offset field of the LDS instructions instead of costing address VALU.
+template <int TP>
+__global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int tile_pitch_rt, int tile_bytes, int sc_bytes, int q_bytes, int dbg)
 {
+    const int tile_pitch = TP ? TP : tile_pitch_rt;
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
     // XCD-aware block -> (image, cell) map (same scheme as describe_kernel): consecutive cells of one image run
     // on one XCD, so the 128-B lines that horizontally / vertically adjacent cell tiles share (a 37-row tile
@@ -402,11 +412,27 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
 
     const int xa = ini_x & ~3, ox = ini_x - xa;
     const int wpr = (max_x - xa + 3) >> 2; // words per tile row
-    const float rcp_wpr = 1.0f / (float)wpr;
     const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (size_t)ini_y * L.pitch + xa;
-    for (int i = lane; i < th * wpr; i += 64) {
-        const int r = (int)(((float)i + 0.5f) * rcp_wpr), c = i - r * wpr;
-        *(uint32_t *)(s_tile + r * tile_pitch + 4 * c) = *(const uint32_t *)(src + (size_t)r * L.pitch + 4 * c);
+    {
+        // (row, word) of element i = lane, advanced by 64 per step; 32-bit offsets only (64-bit multiplies and a
+        // per-element division cost more VALU issue than the copy itself)
+        int r = (int)(((float)lane + 0.5f) * (1.0f / (float)wpr)), c = lane - r * wpr;
+        const int dr = 64 / wpr, dc = 64 - dr * wpr;
+        const int nw = th * wpr;
+        for (int i0 = lane; i0 < nw; i0 += 256) { // 4 loads in flight per lane
+            uint32_t v[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                dst[u] = __mul24(r, tile_pitch) + 4 * c;
+                if (i0 + 64 * u < nw) v[u] = *(const uint32_t *)(src + (unsigned)(__mul24(r, L.pitch) + 4 * c));
+                c += dc; r += dr;
+                if (c >= wpr) { c -= wpr; r++; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (i0 + 64 * u < nw) *(uint32_t *)(s_tile + dst[u]) = v[u];
+        }
     }
     for (int i = lane; i < sc_bytes / 4; i += 64) ((uint32_t *)s_sc)[i] = 0;
     __syncthreads();
@@ -479,7 +505,7 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
             const bool p2 = vg & (c0 + 2 >= 0) & (c0 + 2 < iw) & (d2 != b2);
             const bool p3 = vg & (c0 + 3 < iw) & (d3 != b3);
             const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1), m2 = __ballot(p2), m3 = __ballot(p3);
-            int pos = n2 + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt);
+            int pos = n2 + (int)mbcnt64(m3, mbcnt64(m2, mbcnt64(m1, mbcnt64(m0, 0u))));
             const int e = (rg << 8) + c0; // c0 < 0 only for pixels that are never stored
             if (p0) s_q2[pos] = (uint16_t)(e | (b0 ? 0x8000 : 0));
             pos += p0;
@@ -534,12 +560,11 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
         const unsigned rc = s_q2[q] & 0x7fffu;
         const uint8_t *p = &s_sc[((rc >> 8) + 1) * scp + (rc & 255) + 1];
         const int s = p[0];
-        int f = 0;
-        if (s > 0 && s > p[-1] && s > p[1] && s > p[-scp - 1] && s > p[-scp] && s > p[-scp + 1] &&
-            s > p[scp - 1] && s > p[scp] && s > p[scp + 1]) {
-            f = (s >= cfg.ini_th) ? 2 : 1;
-            any |= (f == 2);
-        }
+        // all nine reads issued together (a short-circuit chain would be nine dependent LDS round trips)
+        const int n0 = p[-scp - 1], n1 = p[-scp], n2_ = p[-scp + 1], n3 = p[-1], n4 = p[1], n5 = p[scp - 1], n6 = p[scp], n7 = p[scp + 1];
+        const int mx = max(max(max(n0, n1), max(n2_, n3)), max(max(n4, n5), max(n6, n7)));
+        const int f = ((s > 0) & (s > mx)) ? ((s >= cfg.ini_th) ? 2 : 1) : 0;
+        any |= (f == 2);
         s_qf[q] = (uint8_t)f;
     }
     const int need = __ballot(any) != 0ull ? 2 : 1;
@@ -1341,7 +1366,17 @@ void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_
     const size_t lds = (size_t)(tile_bytes > mw * mh ? tile_bytes : ((mw * mh + 15) & ~15)) + sc_bytes + q_bytes;
     dim3 grid(cfg.cells_total * ((n_images + 7) / 8) * 8);
     static const int dbg = getenv("ORBFE_FAST_DBG") ? atoi(getenv("ORBFE_FAST_DBG")) : 0; // profiling aid only
-    hipLaunchKernelGGL(fast_cell_kernel, grid, dim3(64), lds, s, cfg, buf, n_images, tile_pitch, tile_bytes, sc_bytes, q_bytes, dbg);
+#define FAST_LAUNCH(TP) hipLaunchKernelGGL(fast_cell_kernel<TP>, grid, dim3(64), lds, s, cfg, buf, n_images, tile_pitch, tile_bytes, sc_bytes, q_bytes, dbg)
+    switch (tile_pitch) {
+    case 44: FAST_LAUNCH(44); break;
+    case 48: FAST_LAUNCH(48); break;
+    case 52: FAST_LAUNCH(52); break;
+    case 56: FAST_LAUNCH(56); break;
+    case 60: FAST_LAUNCH(60); break;
+    case 64: FAST_LAUNCH(64); break;
+    default: FAST_LAUNCH(0); break;
+    }
+#undef FAST_LAUNCH
 }
 
 static inline int ot_sort_cap(const DeviceConfig &cfg) { int p = 1; while (p < cfg.max_nodes) p <<= 1; return p; }
