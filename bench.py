@@ -197,7 +197,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "Stereo-KITTI00-02 1241x376, 2000 features, 8 levels: extract L+R + ComputeStereoMatches",
-                       "pairs_per_step_per_gpu": P, "stream_groups": G, "parallelism": "frame-pair sharding, no data-path collective",
+                       "pairs_per_step_per_gpu": P, "stream_groups": G, "quadtree_kernel": ctx.quadtree_kernel(), "parallelism": "frame-pair sharding, no data-path collective",
                        "keypoints_left_right_pair0": [int(counts[0]), int(counts[1])]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bytes(dom, P, launches),

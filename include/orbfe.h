@@ -122,6 +122,9 @@ int orbfe_synchronize(orbfe_context *ctx, void *stream);
 /* Cut every batched call into `groups` (1..8) contiguous sub-batches whose stage chains run on internal
  * streams forked from / joined to the caller's stream (overlaps barrier-bound and ALU-bound stages). */
 int orbfe_set_streams(orbfe_context *ctx, int groups);
+/* Which DistributeOctTree kernel this context uses (src/ORBextractor.cc:533-757): 3 = bucket pyramid,
+ * 2 = point-parallel, 1 = generic node-parallel (chosen at create time from the geometry / LDS limits). */
+int orbfe_quadtree_kernel(const orbfe_context *ctx);
 /* Copy the results of image slot `image` to host.  u_right/depth may be NULL. */
 int orbfe_fetch_image(orbfe_context *ctx, int image, orbfe_keypoint *kps, uint8_t *desc,
                       float *u_right, float *depth, int cap, int *n);

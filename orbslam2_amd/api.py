@@ -26,7 +26,7 @@ EXPORTS = [
     "orbfe_stereo_frame", "orbfe_rgbd_frame", "orbfe_fetch_pyramid", "orbfe_enqueue_extract",
     "orbfe_enqueue_stereo", "orbfe_synchronize", "orbfe_fetch_image", "orbfe_fetch_counts",
     "orbfe_device_buffers", "orbfe_fetch_candidates", "orbfe_hamming_matrix",
-    "orbfe_set_profiling", "orbfe_stage_name", "orbfe_stage_times", "orbfe_set_streams",
+    "orbfe_set_profiling", "orbfe_stage_name", "orbfe_stage_times", "orbfe_set_streams", "orbfe_quadtree_kernel",
     "orbfe_features_in_area", "orbfe_three_maxima", "orbfe_search_by_projection_last", "orbfe_is_in_frustum",
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_kf", "orbfe_search_for_initialization",
     "orbfe_vocab_load", "orbfe_bow_transform", "orbfe_bow_maps", "orbfe_search_by_bow",  # bound in orbslam2_amd/bow.py
@@ -108,6 +108,7 @@ def load():
     L.orbfe_stage_name.restype = C.c_char_p; L.orbfe_stage_name.argtypes = [C.c_int]
     L.orbfe_stage_times.restype = C.c_int; L.orbfe_stage_times.argtypes = [vp, vp, C.POINTER(C.c_int), C.c_int]
     L.orbfe_set_streams.restype = C.c_int; L.orbfe_set_streams.argtypes = [vp, C.c_int]
+    L.orbfe_quadtree_kernel.restype = C.c_int; L.orbfe_quadtree_kernel.argtypes = [vp]
     fvp, ip = C.POINTER(FrameView), C.POINTER(C.c_int)
     L.orbfe_features_in_area.restype = C.c_int
     L.orbfe_features_in_area.argtypes = [vp, fvp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, vp, C.c_int, ip]
@@ -254,6 +255,9 @@ class Context:
         if stereo:
             out.update(u_right=ur[:m].copy(), depth=dp[:m].copy())
         return out
+
+    def quadtree_kernel(self) -> int:
+        return int(self.L.orbfe_quadtree_kernel(self.h))
 
     def set_streams(self, groups: int):
         self._check(self.L.orbfe_set_streams(self.h, groups))

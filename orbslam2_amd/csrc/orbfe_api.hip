@@ -32,6 +32,8 @@ struct orbfe_context {
     size_t d_ham_bytes = 0;
     int last_images = 0;
     bool use_octree2 = false; // point-parallel quadtree (all levels have <= 4 roots and the LDS budget fits)
+    bool use_octree3 = false; // bucket-pyramid quadtree (orbfe_octree3.hip); preferred when its limits hold
+    size_t ot3_lds = 0;
     int ot2_sort_cap = 0;
     int ot2_lds_pts = 0;      // candidates per level the quadtree keeps in LDS
     size_t ot2_lds = 0;
@@ -279,7 +281,15 @@ static int build_config(orbfe_context *ctx)
         ctx->ot2_lds_pts = pts;
         ctx->ot2_lds = orbfe_octree2_lds_bytes(c.max_nodes, sc, pts);
         ctx->use_octree2 = roots_ok && c.max_nodes <= 4096 && ctx->ot2_lds <= 150 * 1024;
-        if (!ctx->use_octree2 && orbfe_octree_lds_bytes(c) > 64 * 1024)
+        {
+            bool ok3 = roots_ok && c.cell_cap <= 4096; // key fields: 12-bit cell, 12-bit slot
+            for (int l = 0; l < p.nlevels; l++) ok3 = ok3 && c.lv[l].n_cells <= 4096;
+            ctx->ot3_lds = orbfe_octree3_lds_bytes(c.max_nodes, sc);
+            const char *force = getenv("ORBFE_OCTREE"); // test knob: 2 = point-parallel kernel, 1 = generic kernel
+            ctx->use_octree3 = ok3 && ctx->ot3_lds <= 150 * 1024 && !(force && (atoi(force) == 2 || atoi(force) == 1));
+            if (force && atoi(force) == 1) ctx->use_octree2 = false;
+        }
+        if (!ctx->use_octree3 && !ctx->use_octree2 && orbfe_octree_lds_bytes(c) > 64 * 1024)
             return fail(ctx, ORBFE_ERR_UNSUPPORTED, "nfeatures too large for the quadtree LDS budget");
     }
     return ORBFE_OK;
@@ -309,6 +319,7 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
     if (hipSetDevice(p.device) != hipSuccess) { delete ctx; return fail(nullptr, ORBFE_ERR_NO_DEVICE, "hipSetDevice failed"); }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return fail(nullptr, ORBFE_ERR_NO_DEVICE, "hipStreamCreate failed"); }
     if (ctx->use_octree2 && orbfe_octree2_prepare(ctx->ot2_lds) != 0) ctx->use_octree2 = false;
+    if (ctx->use_octree3 && orbfe_octree3_prepare(ctx->ot3_lds) != 0) ctx->use_octree3 = false;
     const DeviceConfig &c = ctx->cfg;
     const size_t B = (size_t)p.max_images;
     DeviceBuffers &b = ctx->buf;
@@ -327,6 +338,10 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
     A(b.ot_sc3, B * c.cand_total);
     A(b.idx0, B * c.cand_total);
     A(b.idx1, B * c.cand_total);
+    A(b.bk_cnt, B * c.nlevels * 4096);
+    A(b.bk_best, B * c.nlevels * 4096);
+    hipMemset(b.bk_cnt, 0, B * c.nlevels * 4096 * sizeof(uint32_t));
+    hipMemset(b.bk_best, 0, B * c.nlevels * 4096 * sizeof(uint32_t));
     A(b.lvl_ncand, B * c.nlevels);
     A(b.sel_cnt, B * c.nlevels);
     A(b.sel_xy, B * c.sel_total);
@@ -539,6 +554,7 @@ static DeviceBuffers shift_buffers(const DeviceBuffers &b, const DeviceConfig &c
     o.cand_xy += i * c.cand_total; o.cand_sc += i * c.cand_total; o.cand_sc2 += i * c.cand_total;
     o.idx0 += i * c.cand_total; o.idx1 += i * c.cand_total; o.ot_xy2 += i * c.cand_total; o.ot_sc3 += i * c.cand_total;
     o.lvl_ncand += i * c.nlevels; o.sel_cnt += i * c.nlevels;
+    o.bk_cnt += i * c.nlevels * 4096; o.bk_best += i * c.nlevels * 4096;
     o.sel_xy += i * c.sel_total; o.sel_sc += i * c.sel_total;
     o.kps = (KeyPointPOD *)o.kps + i * c.sel_total; o.desc += i * c.sel_total * 32;
     o.kp_cnt += i; o.status += i;
@@ -562,7 +578,8 @@ static void run_chain(orbfe_context *ctx, const uint8_t *d_images, int img0, int
     prof_mark(ctx, group, 3, s);
     orbfe_launch_fast(cfg, buf, n_images, s);
     prof_mark(ctx, group, 4, s);
-    if (ctx->use_octree2) orbfe_launch_octree2(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot2_lds_pts, ctx->ot2_lds, s);
+    if (ctx->use_octree3) orbfe_launch_octree3(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot3_lds, s);
+    else if (ctx->use_octree2) orbfe_launch_octree2(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot2_lds_pts, ctx->ot2_lds, s);
     else orbfe_launch_octree_generic(cfg, buf, n_images, s);
     prof_mark(ctx, group, 5, s);
     orbfe_launch_describe(cfg, buf, n_images, s);
@@ -607,6 +624,12 @@ static int enqueue_batch(orbfe_context *ctx, const uint8_t *d_images, int n_unit
     ctx->prof_stream = s;
     if (ctx->profiling) ctx->prof_calls++;
     return ORBFE_OK;
+}
+
+extern "C" int orbfe_quadtree_kernel(const orbfe_context *ctx)
+{
+    if (!ctx) return 0;
+    return ctx->use_octree3 ? 3 : (ctx->use_octree2 ? 2 : 1);
 }
 
 extern "C" int orbfe_set_streams(orbfe_context *ctx, int groups)
@@ -772,6 +795,10 @@ extern "C" int orbfe_fetch_candidates(orbfe_context *ctx, int image, int level, 
         return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     const DeviceConfig &c = ctx->cfg;
     const LevelInfo &L = c.lv[level];
+    if (ctx->use_octree3) { // this path never materialises the emission-order arrays; build them for the tap
+        orbfe_launch_candidates_gather(c, ctx->buf, ctx->params.max_images, ctx->stream);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     int nc = 0;
     HIP_TRY(ctx, hipMemcpy(&nc, ctx->buf.lvl_ncand + (size_t)image * c.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
     *n = nc;

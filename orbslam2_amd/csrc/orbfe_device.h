@@ -64,6 +64,8 @@ struct DeviceBuffers {
     uint32_t *ot_xy2;    // [img][cand_total] quadtree ping-pong partner
     uint8_t *ot_sc3;     // [img][cand_total]
     uint32_t *idx0, *idx1; // [img][cand_total] ping-pong permutation
+    uint32_t *bk_cnt;    // [img][nlevels][4096] quadtree bucket counts (orbfe_octree3.hip); zero between frames
+    uint32_t *bk_best;   // [img][nlevels][4096] quadtree bucket best keys; zero between frames
     int *lvl_ncand;      // [img][nlevels]
     int *sel_cnt;        // [img][nlevels]
     uint32_t *sel_xy;    // [img][sel_total]
@@ -99,6 +101,11 @@ void orbfe_launch_octree_generic(const DeviceConfig &cfg, const DeviceBuffers &b
 void orbfe_launch_octree2(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, int lds_pts, size_t lds, hipStream_t s);
 size_t orbfe_octree2_lds_bytes(int max_nodes, int sort_cap, int lds_pts);
 int orbfe_octree2_prepare(size_t lds);
+// orbfe_octree3.hip
+void orbfe_launch_octree3(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, size_t lds, hipStream_t s);
+void orbfe_launch_candidates_gather(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
+size_t orbfe_octree3_lds_bytes(int max_nodes, int sort_cap);
+int orbfe_octree3_prepare(size_t lds);
 void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
 void orbfe_launch_stereo_match(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s);
 void orbfe_launch_stereo_median(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s);

@@ -1,0 +1,620 @@
+// orbfe_octree3.hip -- DistributeOctTree (reference src/ORBextractor.cc:533-757) on bucket pyramids.
+//
+// The split geometry of the reference is data independent: a node's box is halved at
+// x0 + ceil((x1-x0)/2), y0 + ceil((y1-y0)/2) whatever its points are, so the path of a point through the
+// tree (root index, then one quadrant per depth) depends on its coordinates only.  What IS data
+// dependent -- which nodes are split, in which order, and when the process stops -- needs nothing but
+// the number of points in a node and in its four children.  Hence:
+//   1. one sweep over the level's FAST cells computes every candidate's root and its quadrant path
+//      down to depth 5 ("bucket"), and with two LDS atomics per point builds per-bucket counts and the
+//      per-bucket best key  score << 24 | ~(cell << 12 | slot)  (max score, first in cv::FAST emission
+//      order = the reference's "first maximum wins");
+//   2. counts and best keys are summed / maximised up the quadrant pyramid (depths 4..0);
+//   3. the split passes work on the node list alone (<= max_nodes entries in LDS): a node is
+//      (box, depth, path), its child counts are pyramid look-ups, and the list-order bookkeeping, the
+//      "largest node first" phase and the stop rules are those of the point-parallel kernel
+//      (orbfe_octree.hip), which tests/octree_model.py validates against the literal std::list
+//      restatement.  No pass touches the points again;
+//   4. the surviving point of a node is a best-key look-up.
+// Nodes deeper than the bucket depth (clustered candidates with a generous quota) take a slow path:
+// the candidates are counting-sorted by bucket once (HBM scratch), and a deep node classifies the few
+// points of its bucket by replaying their paths.
+// Candidates are never gathered into emission order on this path; orbfe_fetch_candidates runs
+// candidates_gather_kernel on demand (parity tap).
+#include "orbfe_device.h"
+#include <cstdlib>
+
+#define OT3_THREADS 512
+#define OT3_WAVES (OT3_THREADS / 64)
+#define OT3_DB 5                       // bucket depth
+#define OT3_ROOTS 4                    // root slots per level (n_ini <= 4)
+#define OT3_PYR (OT3_ROOTS * 1365)     // sum_{d=0..5} 4^d = 1365 entries per root
+#define OT3_BUCKETS (OT3_ROOTS * 1024)
+// best key: score (8 bits) << 24 | ~(cell (12 bits) << 12 | slot (12 bits)); the host checks the field widths
+#define OT3_REF_MASK 0xffffffu
+#define OT3_KEY(sc, cell, slot) (((sc) << 24) | (OT3_REF_MASK - (unsigned)(((cell) << 12) | (slot))))
+
+// entries of depths < d; entry (d, root, path) = ot3_off(d) + (root << 2d) + path, its children are
+// ot3_off(d+1) + 4 * ((root << 2d) + path) + quadrant
+__device__ __forceinline__ int ot3_off(int d) { return OT3_ROOTS * (((1 << (2 * d)) - 1) / 3); }
+
+__device__ __forceinline__ int ot3_wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// exclusive block scan of 4 values per thread; totals in tot[4].  s_w: 4*OT3_WAVES ints.
+__device__ __forceinline__ void ot3_block_scan4(int v[4], int tot[4], int *s_w)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) inc[c] = ot3_wave_incl_scan(v[c], lane);
+    if (lane == 63) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) s_w[4 * wave + c] = inc[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        int base = 0, t = 0;
+        for (int w = 0; w < OT3_WAVES; w++) {
+            const int x = s_w[4 * w + c];
+            if (w < wave) base += x;
+            t += x;
+        }
+        tot[c] = t;
+        v[c] = base + inc[c] - v[c];
+    }
+    __syncthreads();
+}
+
+// in-place exclusive scan of an LDS int array a[0..n); returns the total.
+__device__ __forceinline__ int ot3_scan_array(int *a, int n, int *s_w)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (n + OT3_THREADS - 1) / OT3_THREADS;
+    const int b = tid * per < n ? tid * per : n, e = (b + per < n) ? b + per : n;
+    int sum = 0;
+    for (int i = b; i < e; i++) sum += a[i];
+    const int inc = ot3_wave_incl_scan(sum, lane);
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int w = 0; w < OT3_WAVES; w++) {
+        const int x = s_w[w];
+        if (w < wave) base += x;
+        total += x;
+    }
+    int run = base + inc - sum;
+    for (int i = b; i < e; i++) {
+        const int v = a[i];
+        a[i] = run;
+        run += v;
+    }
+    __syncthreads();
+    return total;
+}
+
+struct Ot3Nodes {
+    int *cnt;
+    unsigned *path;          // quadrant path, 2 bits per depth (depth <= 15)
+    int *dr;                 // depth | root << 4
+    short *x0, *y0, *x1, *y1;
+};
+
+__device__ __forceinline__ void ot3_bind(Ot3Nodes &n, uint8_t *&p, int cap)
+{
+    n.cnt = (int *)p; p += sizeof(int) * cap;
+    n.path = (unsigned *)p; p += sizeof(unsigned) * cap;
+    n.dr = (int *)p; p += sizeof(int) * cap;
+    n.x0 = (short *)p; p += sizeof(short) * cap;
+    n.y0 = (short *)p; p += sizeof(short) * cap;
+    n.x1 = (short *)p; p += sizeof(short) * cap;
+    n.y1 = (short *)p; p += sizeof(short) * cap;
+    p = (uint8_t *)(((uintptr_t)p + 7) & ~(uintptr_t)7);
+}
+
+size_t orbfe_octree3_lds_bytes(int max_nodes, int sort_cap)
+{
+    const size_t cap = (size_t)max_nodes;
+    const size_t node = 3 * sizeof(int) * cap + 4 * sizeof(short) * cap + 8;
+    return 2 * sizeof(int) * OT3_PYR + sizeof(int) * (OT3_BUCKETS + 1) + sizeof(unsigned long long) * sort_cap + 2 * node +
+           sizeof(int) * cap * (4 + 1 + 1 + 1 + 1) + 64;
+}
+
+// root and quadrant path of a point down to `depth` (src/ORBextractor.cc:537-564 for the root, :145-209 for a split)
+__device__ __forceinline__ unsigned ot3_path(int x, int y, int depth, float hx, int n_ini, int region_h, int &root)
+{
+    int b = (int)__fdiv_rn((float)x, hx);
+    b = b < 0 ? 0 : (b >= n_ini ? n_ini - 1 : b);
+    root = b;
+    int x0 = (int)__fmul_rn(hx, (float)b), x1 = (int)__fmul_rn(hx, (float)(b + 1)), y0 = 0, y1 = region_h;
+    unsigned path = 0;
+    for (int d = 0; d < depth; d++) {
+        const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+        const int cx = x < mx ? 0 : 1, cy = y < my ? 0 : 1;
+        path = (path << 2) | (unsigned)(cx + 2 * cy);
+        x0 = cx ? mx : x0; x1 = cx ? x1 : mx;
+        y0 = cy ? my : y0; y1 = cy ? y1 : my;
+    }
+    return path;
+}
+
+// Walk over the level's cell slots: wave w takes cells w, w+8, ...; lanes take slots.  The first two
+// 64-slot chunks of a cell are loaded without waiting for the cell's count (slots beyond it are
+// allocated but unused), so a wave keeps six independent loads in flight.  f(xy, score, cell, slot).
+template <typename F>
+__device__ __forceinline__ void ot3_for_each_point(const int *cell_cnt, const uint32_t *cell_xy, const uint8_t *cell_sc, int n_cells, int cell_cap, F f)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = wave; c < n_cells; c += OT3_WAVES) {
+        const size_t base = (size_t)c * cell_cap;
+        const int k1 = lane + 64;
+        const int cnt = cell_cnt[c];
+        const uint32_t xa = lane < cell_cap ? cell_xy[base + lane] : 0u;
+        const uint8_t sa = lane < cell_cap ? cell_sc[base + lane] : (uint8_t)0;
+        const uint32_t xb = k1 < cell_cap ? cell_xy[base + k1] : 0u;
+        const uint8_t sb = k1 < cell_cap ? cell_sc[base + k1] : (uint8_t)0;
+        if (lane < cnt) f(xa, (unsigned)sa, c, lane);
+        if (k1 < cnt) f(xb, (unsigned)sb, c, k1);
+        for (int k = lane + 128; k < cnt; k += 64) f(cell_xy[base + k], (unsigned)cell_sc[base + k], c, k);
+    }
+}
+
+// Bucket counts and best keys of every (image, level): one wave per FAST cell over the whole chip, two
+// fire-and-forget global atomics per candidate.  Blocks are dealt to the XCDs like fast_cell_kernel's
+// (all cells of an image on one XCD), so an image's 32 KB of bucket words stay in one L2.
+__global__ __launch_bounds__(256) void bucket_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images)
+{
+    const int bpi = (cfg.cells_total + 3) / 4;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int img = (jb / bpi) * 8 + xcd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cell = (jb % bpi) * 4 + wave;
+    if (img >= n_images || cell >= cfg.cells_total) return;
+    int level = 0;
+    for (int l = 1; l < cfg.nlevels; l++)
+        if (cell >= cfg.lv[l].cell_off) level = l;
+    const LevelInfo &L = cfg.lv[level];
+    const size_t ib = (size_t)img;
+    const int cnt = buf.cell_cnt[ib * cfg.cells_total + cell];
+    if (cnt == 0) return;
+    const uint32_t *cxy = buf.cell_xy + (ib * cfg.cells_total + cell) * cfg.cell_cap;
+    const uint8_t *csc = buf.cell_sc + (ib * cfg.cells_total + cell) * cfg.cell_cap;
+    uint32_t *g_cnt = buf.bk_cnt + (ib * cfg.nlevels + level) * OT3_BUCKETS;
+    uint32_t *g_best = buf.bk_best + (ib * cfg.nlevels + level) * OT3_BUCKETS;
+    const int region_h = (L.h - cfg.edge_threshold + 3) - cfg.min_border;
+    const int lcell = cell - L.cell_off;
+    for (int k = lane; k < cnt; k += 64) {
+        const uint32_t xy = cxy[k];
+        const unsigned sc = csc[k];
+        int root;
+        const unsigned path = ot3_path((int)(xy & 0xffffu), (int)(xy >> 16), OT3_DB, L.hx, L.n_ini, region_h, root);
+        const int b = (root << (2 * OT3_DB)) + (int)path;
+        atomicAdd(&g_cnt[b], 1u);
+        atomicMax(&g_best[b], OT3_KEY(sc, lcell, k));
+    }
+}
+
+__global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, DeviceBuffers buf, int sort_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
+    __shared__ int s_w[4 * OT3_WAVES];
+    __shared__ int s_scal[8];
+    const int level = blockIdx.x, img = blockIdx.y;
+    const LevelInfo &L = cfg.lv[level];
+    const int tid = threadIdx.x;
+    const int MAXN = cfg.max_nodes;
+
+    uint8_t *p = s_raw;
+    int *s_cnt = (int *)p; p += sizeof(int) * OT3_PYR;            // point counts, all depths 0..5
+    unsigned *s_best = (unsigned *)p; p += sizeof(int) * OT3_PYR; // best key, all depths
+    int *s_bend = (int *)p; p += sizeof(int) * (OT3_BUCKETS + 1); // deep path: s_bend[1 + b] = end of bucket b in the sorted arrays
+    unsigned long long *s_key = (unsigned long long *)p; p += sizeof(unsigned long long) * sort_cap;
+    Ot3Nodes A, B;
+    ot3_bind(A, p, MAXN);
+    ot3_bind(B, p, MAXN);
+    int *s_ccnt = (int *)p; p += sizeof(int) * 4 * MAXN; // child counts per node
+    int *s_rank = (int *)p; p += sizeof(int) * MAXN;     // processing rank (-1: not processed this pass)
+    int *s_plist = (int *)p; p += sizeof(int) * MAXN;    // processing order -> node
+    int *s_kk = (int *)p; p += sizeof(int) * MAXN;
+    int *s_un = (int *)p; p += sizeof(int) * MAXN;
+    int *s_n = &s_scal[0], *s_total_k = &s_scal[1], *s_nproc = &s_scal[2], *s_nexpand = &s_scal[3], *s_mode = &s_scal[4], *s_done = &s_scal[5],
+        *s_deep = &s_scal[6];
+
+    const size_t ib = (size_t)img;
+    const int *cell_cnt = buf.cell_cnt + ib * cfg.cells_total + L.cell_off;
+    const uint32_t *cell_xy = buf.cell_xy + (ib * cfg.cells_total + L.cell_off) * cfg.cell_cap;
+    const uint8_t *cell_sc = buf.cell_sc + (ib * cfg.cells_total + L.cell_off) * cfg.cell_cap;
+    const size_t coff = ib * cfg.cand_total + L.cand_off;
+    uint32_t *deep_xy = buf.ot_xy2 + coff;  // deep path: candidates counting-sorted by bucket
+    uint32_t *deep_key = buf.idx0 + coff;
+    int *sel_cnt = buf.sel_cnt + ib * cfg.nlevels + level;
+    uint32_t *sel_xy = buf.sel_xy + ib * cfg.sel_total + L.sel_off;
+    uint8_t *sel_sc = buf.sel_sc + ib * cfg.sel_total + L.sel_off;
+    int *status = buf.status + img;
+    const int region_h = (L.h - cfg.edge_threshold + 3) - cfg.min_border;
+    const int n_ini = L.n_ini, quota = L.quota;
+    const float hx = L.hx;
+
+    // ---- 1. buckets: filled by bucket_kernel (chip-wide, one wave per cell); taken over and cleared for the next frame ----
+    {
+        uint32_t *g_cnt = buf.bk_cnt + (ib * cfg.nlevels + level) * OT3_BUCKETS;
+        uint32_t *g_best = buf.bk_best + (ib * cfg.nlevels + level) * OT3_BUCKETS;
+        int *cnt5 = s_cnt + ot3_off(OT3_DB);
+        unsigned *best5 = s_best + ot3_off(OT3_DB);
+        const uint4 zero = {0u, 0u, 0u, 0u};
+        for (int i = tid; i < OT3_BUCKETS / 4; i += OT3_THREADS) {
+            const uint4 c = ((const uint4 *)g_cnt)[i], b = ((const uint4 *)g_best)[i];
+            ((uint4 *)g_cnt)[i] = zero; ((uint4 *)g_best)[i] = zero;
+            cnt5[4 * i] = (int)c.x; cnt5[4 * i + 1] = (int)c.y; cnt5[4 * i + 2] = (int)c.z; cnt5[4 * i + 3] = (int)c.w;
+            best5[4 * i] = b.x; best5[4 * i + 1] = b.y; best5[4 * i + 2] = b.z; best5[4 * i + 3] = b.w;
+        }
+    }
+    __syncthreads();
+    // ---- 2. pyramid ----
+    for (int d = OT3_DB - 1; d >= 0; d--) {
+        const int n_e = OT3_ROOTS << (2 * d);
+        const int o = ot3_off(d), oc = ot3_off(d + 1);
+        for (int e = tid; e < n_e; e += OT3_THREADS) {
+            const int c = oc + 4 * e;
+            s_cnt[o + e] = s_cnt[c] + s_cnt[c + 1] + s_cnt[c + 2] + s_cnt[c + 3];
+            const unsigned b0 = s_best[c], b1 = s_best[c + 1], b2 = s_best[c + 2], b3 = s_best[c + 3];
+            const unsigned m01 = b0 > b1 ? b0 : b1, m23 = b2 > b3 ? b2 : b3;
+            s_best[o + e] = m01 > m23 ? m01 : m23;
+        }
+        __syncthreads();
+    }
+    // ---- roots (src/ORBextractor.cc:537-581) ----
+    if (tid == 0) {
+        int n = 0, nc = 0;
+        for (int b = 0; b < n_ini; b++) {
+            const int c = s_cnt[b];
+            nc += c;
+            if (c > 0) {
+                A.x0[n] = (short)(int)__fmul_rn(hx, (float)b);
+                A.x1[n] = (short)(int)__fmul_rn(hx, (float)(b + 1));
+                A.y0[n] = 0;
+                A.y1[n] = (short)region_h;
+                A.cnt[n] = c; A.path[n] = 0u; A.dr[n] = b << 4;
+                n++;
+            }
+        }
+        *s_n = n;
+        *s_done = 0;
+        *s_deep = 0;
+        buf.lvl_ncand[ib * cfg.nlevels + level] = nc;
+        s_scal[7] = nc;
+    }
+    __syncthreads();
+    const int nc = s_scal[7];
+    if (nc == 0) {
+        if (tid == 0) *sel_cnt = 0;
+        return;
+    }
+    const bool deep_ok = nc <= L.cand_cap; // the sorted arrays hold cand_cap entries
+    if (!deep_ok && tid == 0) *status = 1;
+    bool deep_ready = false;
+
+    // child counts of a node deeper than the buckets: replay the paths of its bucket's points
+    auto deep_children = [&](int dr, unsigned path, int c[4]) {
+        const int d = dr & 15, root = dr >> 4;
+        const int b = (root << (2 * OT3_DB)) + (int)(path >> (2 * (d - OT3_DB)));
+        c[0] = c[1] = c[2] = c[3] = 0;
+        for (int j = s_bend[b]; j < s_bend[b + 1]; j++) {
+            const uint32_t xy = deep_xy[j];
+            int r;
+            const unsigned pp = ot3_path((int)(xy & 0xffffu), (int)(xy >> 16), d + 1, hx, n_ini, region_h, r);
+            if ((pp >> 2) == path) c[pp & 3u]++;
+        }
+    };
+
+    // ---- 3. split passes ----
+    Ot3Nodes cur = A, nxt = B;
+    int sorted_phase = 0;
+    for (int iter = 0; iter < 100000; iter++) { // n grows every pass, so this ends at n >= quota at the latest
+        const int n = *s_n;
+        // child counts
+        for (int i = tid; i < n; i += OT3_THREADS) {
+            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            const int multi = cur.cnt[i] > 1;
+            if (multi) {
+                const int dr = cur.dr[i], d = dr & 15, root = dr >> 4;
+                if (d < OT3_DB) {
+                    const int c = ot3_off(d + 1) + 4 * ((root << (2 * d)) + (int)cur.path[i]);
+                    c0 = s_cnt[c]; c1 = s_cnt[c + 1]; c2 = s_cnt[c + 2]; c3 = s_cnt[c + 3];
+                } else {
+                    *s_deep = 1;
+                }
+            }
+            s_ccnt[4 * i] = c0; s_ccnt[4 * i + 1] = c1; s_ccnt[4 * i + 2] = c2; s_ccnt[4 * i + 3] = c3;
+            s_rank[i] = -1;
+            s_kk[i] = multi;
+        }
+        __syncthreads();
+        if (*s_deep) {
+            if (!deep_ready && deep_ok) {
+                // counting sort of the candidates by bucket: s_bend[1 + b] runs from the bucket's start to its end
+                const int *cnt5 = s_cnt + ot3_off(OT3_DB);
+                for (int b = tid; b < OT3_BUCKETS; b += OT3_THREADS) s_bend[1 + b] = cnt5[b];
+                if (tid == 0) s_bend[0] = 0;
+                __syncthreads();
+                ot3_scan_array(s_bend + 1, OT3_BUCKETS, s_w);
+                ot3_for_each_point(cell_cnt, cell_xy, cell_sc, L.n_cells, cfg.cell_cap, [&](uint32_t xy, unsigned sc, int cell, int slot) {
+                    int root;
+                    const unsigned path = ot3_path((int)(xy & 0xffffu), (int)(xy >> 16), OT3_DB, hx, n_ini, region_h, root);
+                    const int b = (root << (2 * OT3_DB)) + (int)path;
+                    const int pos = atomicAdd(&s_bend[1 + b], 1);
+                    deep_xy[pos] = xy;
+                    deep_key[pos] = OT3_KEY(sc, cell, slot);
+                });
+                __syncthreads();
+                deep_ready = true;
+            }
+            for (int i = tid; i < n; i += OT3_THREADS) {
+                const int dr = cur.dr[i];
+                if (cur.cnt[i] > 1 && (dr & 15) >= OT3_DB) {
+                    int c[4] = {0, 0, 0, 0};
+                    if (deep_ready && (dr & 15) < 15) deep_children(dr, cur.path[i], c);
+                    else { c[0] = cur.cnt[i]; } // cannot be refined (capacity guards only): keep the node whole
+                    s_ccnt[4 * i] = c[0]; s_ccnt[4 * i + 1] = c[1]; s_ccnt[4 * i + 2] = c[2]; s_ccnt[4 * i + 3] = c[3];
+                }
+            }
+            __syncthreads();
+        }
+
+        // child k of node i as new node q
+        auto emit = [&](int q, int i, int k, int cnt, int x0, int y0, int x1, int y1, int mx, int my) {
+            nxt.x0[q] = (short)((k & 1) ? mx : x0); nxt.x1[q] = (short)((k & 1) ? x1 : mx);
+            nxt.y0[q] = (short)((k & 2) ? my : y0); nxt.y1[q] = (short)((k & 2) ? y1 : my);
+            nxt.cnt[q] = cnt;
+            nxt.path[q] = (cur.path[i] << 2) | (unsigned)k;
+            nxt.dr[q] = (cur.dr[i] & 15) < 15 ? cur.dr[i] + 1 : cur.dr[i]; // depth 15 = 1-px boxes: never multi-point
+        };
+        auto copy_node = [&](int q, int i) {
+            nxt.x0[q] = cur.x0[i]; nxt.y0[q] = cur.y0[i]; nxt.x1[q] = cur.x1[i]; nxt.y1[q] = cur.y1[i];
+            nxt.cnt[q] = cur.cnt[i]; nxt.path[q] = cur.path[i]; nxt.dr[q] = cur.dr[i];
+        };
+
+        int n_new, nexpand_fast = -1;
+        if (!sorted_phase && n <= OT3_THREADS) {
+            // full pass (every multi-point node is split, list order = processing order): thread i owns node i and
+            // one 4-value block scan yields its rank, the children ahead of it, the unsplit nodes ahead of it and
+            // the pass totals
+            int v4[4] = {0, 0, 0, 0}, c0 = 0, c1 = 0, c2 = 0, c3 = 0, k = 0, multi = 0;
+            if (tid < n) {
+                multi = cur.cnt[tid] > 1;
+                if (multi) {
+                    c0 = s_ccnt[4 * tid]; c1 = s_ccnt[4 * tid + 1]; c2 = s_ccnt[4 * tid + 2]; c3 = s_ccnt[4 * tid + 3];
+                    k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+                    v4[0] = 1; v4[1] = k; v4[3] = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
+                } else {
+                    v4[2] = 1;
+                }
+            }
+            int tot[4];
+            ot3_block_scan4(v4, tot, s_w); // exclusive prefixes in list order
+            const int total_k = tot[1];
+            n_new = total_k + tot[2];
+            nexpand_fast = tot[3];
+            if (n_new > MAXN) {
+                if (tid == 0) { *status = 2; *sel_cnt = 0; }
+                return;
+            }
+            if (tid < n) {
+                const int i = tid;
+                if (!multi) {
+                    copy_node(total_k + v4[2], i);
+                } else {
+                    const int x0 = cur.x0[i], y0 = cur.y0[i], x1 = cur.x1[i], y1 = cur.y1[i];
+                    const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+                    int q = total_k - (v4[1] + k); // blocks of later-processed parents sit nearer the front; children n4..n1
+                    if (c3 > 0) emit(q++, i, 3, c3, x0, y0, x1, y1, mx, my);
+                    if (c2 > 0) emit(q++, i, 2, c2, x0, y0, x1, y1, mx, my);
+                    if (c1 > 0) emit(q++, i, 1, c1, x0, y0, x1, y1, mx, my);
+                    if (c0 > 0) emit(q++, i, 0, c0, x0, y0, x1, y1, mx, my);
+                }
+            }
+        } else {
+            // processing order of the multi-point nodes
+            const int m = ot3_scan_array(s_kk, n, s_w); // s_kk[i] = rank among multi nodes (list order)
+            if (!sorted_phase) {
+                for (int i = tid; i < n; i += OT3_THREADS)
+                    if (cur.cnt[i] > 1) s_plist[s_kk[i]] = i;
+                __syncthreads();
+            } else {
+                // (size, pointer) order of the reference under contract Q3: count descending, list position ascending
+                int P = 1;
+                while (P < m) P <<= 1;
+                for (int i = tid; i < P; i += OT3_THREADS) s_key[i] = ~0ull;
+                __syncthreads();
+                for (int i = tid; i < n; i += OT3_THREADS)
+                    if (cur.cnt[i] > 1)
+                        s_key[s_kk[i]] = ((unsigned long long)(0xffffffffu - (unsigned)cur.cnt[i]) << 32) | (unsigned)i;
+                __syncthreads();
+                for (int k = 2; k <= P; k <<= 1) {
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        for (int i = tid; i < P; i += OT3_THREADS) {
+                            const int ixj = i ^ j;
+                            if (ixj > i) {
+                                const unsigned long long a = s_key[i], b = s_key[ixj];
+                                const bool up = ((i & k) == 0);
+                                if ((a > b) == up) { s_key[i] = b; s_key[ixj] = a; }
+                            }
+                        }
+                        __syncthreads();
+                    }
+                }
+                for (int i = tid; i < m; i += OT3_THREADS) s_plist[i] = (int)(s_key[i] & 0xffffffffu);
+                __syncthreads();
+            }
+            // k = non-empty children per processing rank; exclusive prefix in s_un
+            for (int r = tid; r < m; r += OT3_THREADS) {
+                const int i = s_plist[r];
+                const int k = (s_ccnt[4 * i] > 0) + (s_ccnt[4 * i + 1] > 0) + (s_ccnt[4 * i + 2] > 0) + (s_ccnt[4 * i + 3] > 0);
+                s_kk[r] = k;
+                s_un[r] = k;
+            }
+            __syncthreads();
+            ot3_scan_array(s_un, m, s_w);
+            if (tid == 0) {
+                int nproc = m;
+                if (sorted_phase) { // first r with n + sum_{r'<=r}(k-1) >= quota (src/ORBextractor.cc:724-725)
+                    for (int r = 0; r < m; r++) {
+                        const int incl = s_un[r] + s_kk[r];
+                        if (n + incl - (r + 1) >= quota) { nproc = r + 1; break; }
+                    }
+                }
+                *s_nproc = nproc;
+                *s_total_k = nproc > 0 ? s_un[nproc - 1] + s_kk[nproc - 1] : 0;
+                *s_nexpand = 0;
+            }
+            __syncthreads();
+            const int nproc = *s_nproc, total_k = *s_total_k;
+            for (int r = tid; r < nproc; r += OT3_THREADS) s_rank[s_plist[r]] = r;
+            __syncthreads();
+            for (int i = tid; i < n; i += OT3_THREADS) s_plist[i] = (s_rank[i] < 0) ? 1 : 0; // reuse: unprocessed flags
+            __syncthreads();
+            const int n_un = ot3_scan_array(s_plist, n, s_w);
+            n_new = total_k + n_un;
+            if (n_new > MAXN) { // cannot happen for max_nodes >= max(quota+3, 4*n_ini); guard anyway
+                if (tid == 0) { *status = 2; *sel_cnt = 0; }
+                return;
+            }
+            // new node array in list order: blocks of later-processed parents nearer the front, children n4..n1
+            for (int i = tid; i < n; i += OT3_THREADS) {
+                const int r = s_rank[i];
+                if (r < 0) {
+                    copy_node(total_k + s_plist[i], i);
+                    continue;
+                }
+                const int x0 = cur.x0[i], y0 = cur.y0[i], x1 = cur.x1[i], y1 = cur.y1[i];
+                const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+                const int c0 = s_ccnt[4 * i], c1 = s_ccnt[4 * i + 1], c2 = s_ccnt[4 * i + 2], c3 = s_ccnt[4 * i + 3];
+                const int k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+                int q = total_k - (s_un[r] + k);
+                if (c3 > 0) emit(q++, i, 3, c3, x0, y0, x1, y1, mx, my);
+                if (c2 > 0) emit(q++, i, 2, c2, x0, y0, x1, y1, mx, my);
+                if (c1 > 0) emit(q++, i, 1, c1, x0, y0, x1, y1, mx, my);
+                if (c0 > 0) emit(q++, i, 0, c0, x0, y0, x1, y1, mx, my);
+                const int nexp = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
+                if (nexp) atomicAdd(s_nexpand, nexp);
+            }
+        }
+        __syncthreads();
+        // stop logic (src/ORBextractor.cc:661-731)
+        if (tid == 0) {
+            const int prev = n;
+            *s_n = n_new;
+            *s_deep = 0;
+            if (n_new >= quota || n_new == prev) *s_done = 1;
+            else if (!sorted_phase && n_new + 3 * (nexpand_fast >= 0 ? nexpand_fast : *s_nexpand) > quota) *s_mode = 1;
+            else *s_mode = sorted_phase;
+        }
+        __syncthreads();
+        { Ot3Nodes t = cur; cur = nxt; nxt = t; }
+        if (*s_done) break;
+        sorted_phase = *s_mode;
+        __syncthreads();
+    }
+
+    // ---- 4. keep the best response per node, first wins (src/ORBextractor.cc:735-754) ----
+    const int n = *s_n;
+    const int n_out = n < L.sel_cap ? n : L.sel_cap;
+    if (n > L.sel_cap && tid == 0) *status = 3;
+    for (int i = tid; i < n_out; i += OT3_THREADS) {
+        const int dr = cur.dr[i], d = dr & 15, root = dr >> 4;
+        const unsigned path = cur.path[i];
+        unsigned key = 0u;
+        if (d <= OT3_DB) {
+            key = s_best[ot3_off(d) + (root << (2 * d)) + (int)path];
+        } else { // only reachable through deep_children, i.e. with the sorted arrays built
+            const int b = (root << (2 * OT3_DB)) + (int)(path >> (2 * (d - OT3_DB)));
+            for (int j = s_bend[b]; j < s_bend[b + 1]; j++) {
+                const uint32_t xy = deep_xy[j];
+                int r;
+                const unsigned pp = ot3_path((int)(xy & 0xffffu), (int)(xy >> 16), d, hx, n_ini, region_h, r);
+                const unsigned kj = deep_key[j];
+                if (pp == path && kj > key) key = kj;
+            }
+        }
+        const unsigned ref = OT3_REF_MASK - (key & OT3_REF_MASK);
+        sel_xy[i] = cell_xy[(size_t)(ref >> 12) * cfg.cell_cap + (ref & 4095u)];
+        sel_sc[i] = (uint8_t)(key >> 24);
+    }
+    if (tid == 0) *sel_cnt = n_out;
+}
+
+// Parity tap (orbfe_fetch_candidates): the candidates of every level in cv::FAST emission order
+// (cell-row-major, in-cell order).  One workgroup per (image, level); not part of the frame path.
+__global__ __launch_bounds__(OT3_THREADS) void candidates_gather_kernel(DeviceConfig cfg, DeviceBuffers buf)
+{
+    __shared__ int s_w[OT3_WAVES];
+    const int level = blockIdx.x, img = blockIdx.y;
+    const LevelInfo &L = cfg.lv[level];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t ib = (size_t)img;
+    const int *cell_cnt = buf.cell_cnt + ib * cfg.cells_total + L.cell_off;
+    int *cell_base = buf.cell_base + ib * cfg.cells_total + L.cell_off;
+    const uint32_t *cell_xy = buf.cell_xy + (ib * cfg.cells_total + L.cell_off) * cfg.cell_cap;
+    const uint8_t *cell_sc = buf.cell_sc + (ib * cfg.cells_total + L.cell_off) * cfg.cell_cap;
+    const size_t coff = ib * cfg.cand_total + L.cand_off;
+    const int n = L.n_cells;
+    const int per = (n + OT3_THREADS - 1) / OT3_THREADS;
+    const int b = tid * per < n ? tid * per : n, e = (b + per < n) ? b + per : n;
+    int sum = 0;
+    for (int i = b; i < e; i++) sum += cell_cnt[i];
+    const int inc = ot3_wave_incl_scan(sum, lane);
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int w = 0; w < OT3_WAVES; w++) {
+        const int x = s_w[w];
+        if (w < wave) base += x;
+        total += x;
+    }
+    int run = base + inc - sum;
+    for (int i = b; i < e; i++) {
+        const int v = cell_cnt[i];
+        cell_base[i] = run;
+        run += v;
+    }
+    __syncthreads();
+    int nc = total;
+    if (nc > L.cand_cap) nc = L.cand_cap;
+    if (tid == 0) buf.lvl_ncand[ib * cfg.nlevels + level] = nc;
+    for (int c = wave; c < n; c += OT3_WAVES) {
+        const int cb = cell_base[c], cnt = cell_cnt[c];
+        for (int k = lane; k < cnt; k += 64)
+            if (cb + k < nc) {
+                buf.cand_xy[coff + cb + k] = cell_xy[(size_t)c * cfg.cell_cap + k];
+                buf.cand_sc[coff + cb + k] = cell_sc[(size_t)c * cfg.cell_cap + k];
+            }
+    }
+}
+
+void orbfe_launch_octree3(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, size_t lds, hipStream_t s)
+{
+    const int bpi = (cfg.cells_total + 3) / 4;
+    hipLaunchKernelGGL(bucket_kernel, dim3(bpi * ((n_images + 7) / 8) * 8), dim3(256), 0, s, cfg, buf, n_images);
+    dim3 grid(cfg.nlevels, n_images);
+    hipLaunchKernelGGL(octree3_kernel, grid, dim3(OT3_THREADS), lds, s, cfg, buf, sort_cap);
+}
+
+void orbfe_launch_candidates_gather(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
+{
+    dim3 grid(cfg.nlevels, n_images);
+    hipLaunchKernelGGL(candidates_gather_kernel, grid, dim3(OT3_THREADS), 0, s, cfg, buf);
+}
+
+int orbfe_octree3_prepare(size_t lds)
+{
+    if (lds <= 64 * 1024) return 0;
+    return hipFuncSetAttribute((const void *)octree3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1;
+}

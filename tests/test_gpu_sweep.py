@@ -61,3 +61,44 @@ def test_reuse_context_many_frames():
         kr, dr = ex.extract(left)
         assert np.array_equal(k, kr.astype(api.KP_DTYPE)) and np.array_equal(d, dr), seed
     ctx.close()
+
+
+@pytest.mark.parametrize("patch,nf", [(40, 2000), (24, 1000), (90, 3000), (160, 4000)])
+def test_clustered_candidates_deep_quadtree(patch, nf):
+    """All corners inside one small textured square and a generous quota: the quadtree must split far below the
+    bucket depth of the pyramid kernel (its slow path: counting sort by bucket + path replay)."""
+    from orbslam2_amd import api
+    rng = np.random.default_rng(patch)
+    img = np.full((376, 1241), 128, np.uint8)
+    img[150:150 + patch, 600:600 + patch] = rng.integers(0, 256, (patch, patch)).astype(np.uint8)
+    img[40:40 + patch // 2, 100:100 + patch // 2] = rng.integers(0, 256, (patch // 2, patch // 2)).astype(np.uint8)
+    ctx = api.Context(width=1241, height=376, nfeatures=nf)
+    k, d = ctx.extract(img)
+    ex = O.Extractor(nfeatures=nf)
+    kr, dr = ex.extract(img)
+    assert len(kr) > 20
+    assert np.array_equal(k, kr.astype(api.KP_DTYPE)) and np.array_equal(d, dr)
+    ctx.close()
+
+
+def test_point_parallel_quadtree_kernel_still_matches(monkeypatch):
+    """ORBFE_OCTREE=2 routes the quadtree to the point-parallel kernel (the fallback beyond the pyramid kernel's limits)."""
+    from orbslam2_amd import api
+    left = synth.mono_image(640, 480, seed=5)
+    ctx = api.Context(width=640, height=480, nfeatures=1200)
+    assert ctx.quadtree_kernel() == 3  # the default
+    ctx.close()
+    monkeypatch.setenv("ORBFE_OCTREE", "2")
+    ctx = api.Context(width=640, height=480, nfeatures=1200)
+    assert ctx.quadtree_kernel() == 2
+    k, d = ctx.extract(left)
+    ctx.close()
+    monkeypatch.setenv("ORBFE_OCTREE", "1")
+    ctx = api.Context(width=640, height=480, nfeatures=1200)
+    assert ctx.quadtree_kernel() == 1
+    k1, d1 = ctx.extract(left)
+    ctx.close()
+    ex = O.Extractor(nfeatures=1200)
+    kr, dr = ex.extract(left)
+    assert np.array_equal(k, kr.astype(api.KP_DTYPE)) and np.array_equal(d, dr)
+    assert np.array_equal(k1, kr.astype(api.KP_DTYPE)) and np.array_equal(d1, dr)
