@@ -342,6 +342,7 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
     A(b.bk_best, B * c.nlevels * 4096);
     hipMemset(b.bk_cnt, 0, B * c.nlevels * 4096 * sizeof(uint32_t));
     hipMemset(b.bk_best, 0, B * c.nlevels * 4096 * sizeof(uint32_t));
+    A(b.bk_end, B * c.nlevels * 4097);
     A(b.lvl_ncand, B * c.nlevels);
     A(b.sel_cnt, B * c.nlevels);
     A(b.sel_xy, B * c.sel_total);
@@ -554,7 +555,7 @@ static DeviceBuffers shift_buffers(const DeviceBuffers &b, const DeviceConfig &c
     o.cand_xy += i * c.cand_total; o.cand_sc += i * c.cand_total; o.cand_sc2 += i * c.cand_total;
     o.idx0 += i * c.cand_total; o.idx1 += i * c.cand_total; o.ot_xy2 += i * c.cand_total; o.ot_sc3 += i * c.cand_total;
     o.lvl_ncand += i * c.nlevels; o.sel_cnt += i * c.nlevels;
-    o.bk_cnt += i * c.nlevels * 4096; o.bk_best += i * c.nlevels * 4096;
+    o.bk_cnt += i * c.nlevels * 4096; o.bk_best += i * c.nlevels * 4096; o.bk_end += i * c.nlevels * 4097;
     o.sel_xy += i * c.sel_total; o.sel_sc += i * c.sel_total;
     o.kps = (KeyPointPOD *)o.kps + i * c.sel_total; o.desc += i * c.sel_total * 32;
     o.kp_cnt += i; o.status += i;

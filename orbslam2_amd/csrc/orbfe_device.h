@@ -66,6 +66,7 @@ struct DeviceBuffers {
     uint32_t *idx0, *idx1; // [img][cand_total] ping-pong permutation
     uint32_t *bk_cnt;    // [img][nlevels][4096] quadtree bucket counts (orbfe_octree3.hip); zero between frames
     uint32_t *bk_best;   // [img][nlevels][4096] quadtree bucket best keys; zero between frames
+    int *bk_end;         // [img][nlevels][4097] quadtree deep path: bucket ends of the counting sort
     int *lvl_ncand;      // [img][nlevels]
     int *sel_cnt;        // [img][nlevels]
     uint32_t *sel_xy;    // [img][sel_total]

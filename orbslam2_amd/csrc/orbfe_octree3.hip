@@ -124,7 +124,7 @@ size_t orbfe_octree3_lds_bytes(int max_nodes, int sort_cap)
 {
     const size_t cap = (size_t)max_nodes;
     const size_t node = 3 * sizeof(int) * cap + 4 * sizeof(short) * cap + 8;
-    return 2 * sizeof(int) * OT3_PYR + sizeof(int) * (OT3_BUCKETS + 1) + sizeof(unsigned long long) * sort_cap + 2 * node +
+    return 2 * sizeof(int) * OT3_PYR + sizeof(unsigned long long) * sort_cap + 2 * node +
            sizeof(int) * cap * (4 + 1 + 1 + 1 + 1) + 64;
 }
 
@@ -215,7 +215,9 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
     uint8_t *p = s_raw;
     int *s_cnt = (int *)p; p += sizeof(int) * OT3_PYR;            // point counts, all depths 0..5
     unsigned *s_best = (unsigned *)p; p += sizeof(int) * OT3_PYR; // best key, all depths
-    int *s_bend = (int *)p; p += sizeof(int) * (OT3_BUCKETS + 1); // deep path: s_bend[1 + b] = end of bucket b in the sorted arrays
+    // deep path only: s_bend[1 + b] = end of bucket b in the sorted arrays.  Kept in HBM scratch so that the LDS
+    // footprint lets two workgroups share a CU.
+    int *s_bend = buf.bk_end + ((size_t)img * cfg.nlevels + level) * (OT3_BUCKETS + 1);
     unsigned long long *s_key = (unsigned long long *)p; p += sizeof(unsigned long long) * sort_cap;
     Ot3Nodes A, B;
     ot3_bind(A, p, MAXN);
@@ -438,6 +440,24 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
                     if (cur.cnt[i] > 1)
                         s_key[s_kk[i]] = ((unsigned long long)(0xffffffffu - (unsigned)cur.cnt[i]) << 32) | (unsigned)i;
                 __syncthreads();
+                if (m <= 2 * OT3_THREADS) {
+                    // few keys (all distinct): rank by counting -- m broadcast LDS reads per thread and one barrier
+                    // instead of the log^2 barrier steps of the sorting network below
+                    unsigned long long mine[2];
+                    int rk[2] = {0, 0};
+#pragma unroll
+                    for (int u = 0; u < 2; u++) mine[u] = tid + u * OT3_THREADS < m ? s_key[tid + u * OT3_THREADS] : ~0ull;
+                    for (int j = 0; j < m; j++) {
+                        const unsigned long long kj = s_key[j];
+                        rk[0] += kj < mine[0]; rk[1] += kj < mine[1];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+                        if (tid + u * OT3_THREADS < m) s_key[rk[u]] = mine[u];
+                    __syncthreads();
+                    P = 0; // skip the network
+                }
                 for (int k = 2; k <= P; k <<= 1) {
                     for (int j = k >> 1; j > 0; j >>= 1) {
                         for (int i = tid; i < P; i += OT3_THREADS) {
@@ -463,17 +483,16 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
             }
             __syncthreads();
             ot3_scan_array(s_un, m, s_w);
+            if (tid == 0) { *s_nproc = m; *s_nexpand = 0; }
+            __syncthreads();
+            if (sorted_phase) { // first r with n + sum_{r'<=r}(k-1) >= quota (src/ORBextractor.cc:724-725); monotone in r
+                for (int r = tid; r < m; r += OT3_THREADS)
+                    if (n + s_un[r] + s_kk[r] - (r + 1) >= quota) atomicMin(s_nproc, r + 1);
+                __syncthreads();
+            }
             if (tid == 0) {
-                int nproc = m;
-                if (sorted_phase) { // first r with n + sum_{r'<=r}(k-1) >= quota (src/ORBextractor.cc:724-725)
-                    for (int r = 0; r < m; r++) {
-                        const int incl = s_un[r] + s_kk[r];
-                        if (n + incl - (r + 1) >= quota) { nproc = r + 1; break; }
-                    }
-                }
-                *s_nproc = nproc;
+                const int nproc = *s_nproc;
                 *s_total_k = nproc > 0 ? s_un[nproc - 1] + s_kk[nproc - 1] : 0;
-                *s_nexpand = 0;
             }
             __syncthreads();
             const int nproc = *s_nproc, total_k = *s_total_k;
