@@ -283,7 +283,7 @@ static int build_config(orbfe_context *ctx)
         ctx->use_octree2 = roots_ok && c.max_nodes <= 4096 && ctx->ot2_lds <= 150 * 1024;
         {
             bool ok3 = roots_ok && c.cell_cap <= 4096; // key fields: 12-bit cell, 12-bit slot
-            for (int l = 0; l < p.nlevels; l++) ok3 = ok3 && c.lv[l].n_cells <= 4096;
+            for (int l = 0; l < p.nlevels; l++) ok3 = ok3 && c.lv[l].n_cells <= 4096 && c.lv[l].w_cell <= 64 && c.lv[l].h_cell <= 64; // one lane per cell column / row
             ctx->ot3_lds = orbfe_octree3_lds_bytes(c.max_nodes, sc);
             const char *force = getenv("ORBFE_OCTREE"); // test knob: 2 = point-parallel kernel, 1 = generic kernel
             ctx->use_octree3 = ok3 && ctx->ot3_lds <= 150 * 1024 && !(force && (atoi(force) == 2 || atoi(force) == 1));
@@ -410,6 +410,49 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
             return fail(nullptr, ORBFE_ERR_HIP, "resize table upload failed");
         }
         b.rs_tab = d_tab;
+    }
+    {   // quadtree bucket tables (orbfe_octree3.hip): root and depth-5 path bits of every x / y of each level's
+        // candidate region, with the reference's arithmetic (src/ORBextractor.cc:537-564 roots, :145-209 splits)
+        std::vector<uint32_t> tab;
+        auto spread5 = [](unsigned v) { unsigned r = 0; for (int i = 0; i < 5; i++) r |= ((v >> i) & 1u) << (2 * i); return r; };
+        for (int l = 0; l < p.nlevels; l++) {
+            LevelInfo &L = ctx->cfg.lv[l];
+            const int region_w = (L.w - p.edge_threshold + 3) - c.min_border, region_h = (L.h - p.edge_threshold + 3) - c.min_border;
+            L.bk_xoff = (int)tab.size();
+            for (int x = 0; x < region_w; x++) {
+                int b = (int)((float)x / L.hx);
+                b = b < 0 ? 0 : (b >= L.n_ini ? L.n_ini - 1 : b);
+                int x0 = (int)(L.hx * (float)b), x1 = (int)(L.hx * (float)(b + 1));
+                unsigned col = 0;
+                for (int d = 0; d < ORBFE_BK_DEPTH; d++) {
+                    const int mx = x0 + ((x1 - x0 + 1) >> 1);
+                    const int cx = x < mx ? 0 : 1;
+                    col = (col << 1) | (unsigned)cx;
+                    if (cx) x0 = mx; else x1 = mx;
+                }
+                tab.push_back(((unsigned)b << 10) | spread5(col) | (((unsigned)b * 32u + col) << 16));
+            }
+            L.bk_yoff = (int)tab.size();
+            for (int y = 0; y < region_h; y++) {
+                int y0 = 0, y1 = region_h;
+                unsigned row = 0;
+                for (int d = 0; d < ORBFE_BK_DEPTH; d++) {
+                    const int my = y0 + ((y1 - y0 + 1) >> 1);
+                    const int cy = y < my ? 0 : 1;
+                    row = (row << 1) | (unsigned)cy;
+                    if (cy) y0 = my; else y1 = my;
+                }
+                tab.push_back((spread5(row) << 1) | (row << 16));
+            }
+        }
+        if (tab.empty()) tab.resize(4, 0);
+        uint32_t *d_tab = nullptr;
+        A(d_tab, tab.size());
+        if (hipMemcpy(d_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            orbfe_destroy(ctx);
+            return fail(nullptr, ORBFE_ERR_HIP, "bucket table upload failed");
+        }
+        b.bk_tab = d_tab;
     }
     {   // keypoint slot -> level
         std::vector<uint8_t> sl(c.sel_total);
@@ -577,7 +620,7 @@ static void run_chain(orbfe_context *ctx, const uint8_t *d_images, int img0, int
     prof_mark(ctx, group, 2, s);
     orbfe_launch_blur(cfg, buf, n_images, s);
     prof_mark(ctx, group, 3, s);
-    orbfe_launch_fast(cfg, buf, n_images, s);
+    orbfe_launch_fast(cfg, buf, n_images, ctx->use_octree3, s);
     prof_mark(ctx, group, 4, s);
     if (ctx->use_octree3) orbfe_launch_octree3(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot3_lds, s);
     else if (ctx->use_octree2) orbfe_launch_octree2(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot2_lds_pts, ctx->ot2_lds, s);

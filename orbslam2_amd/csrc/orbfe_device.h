@@ -27,6 +27,7 @@ struct LevelInfo {
     double rs_scale_x, rs_scale_y; // cv::resize scale from level-1 (1/(dw/sw))
     int rs_xtab_off, rs_xtab_n;    // resize column table (two planes of rs_xtab_n words) in DeviceBuffers::rs_tab
     int rs_ytab_off, rs_ytab_n;    // resize row table
+    int bk_xoff, bk_yoff;          // quadtree bucket tables of this level in DeviceBuffers::bk_tab (orbfe_octree3.hip)
 };
 
 struct DeviceConfig {
@@ -80,11 +81,23 @@ struct DeviceBuffers {
     int *status;         // [img] non-zero = device-side capacity problem
     int *row_off;        // [pair][height+1] stereo row table offsets
     uint16_t *row_idx;   // [pair][row_idx_cap] right-keypoint indices per row
+    const uint32_t *bk_tab; // quadtree bucket tables: per level X[region_w] then Y[region_h] (see ORBFE_BK_*)
     const uint32_t *rs_tab; // cv::resize offset/weight tables of every level (see pyr_resize_kernel)
     long long *dbg_ts;   // 4096 timestamps for kernel bring-up (ORBFE_OT2_STOP=99); never read by product code
     const uint8_t *slot_level; // [sel_total] level of every keypoint slot
     const int16_t *patch_uv; // IC_Angle patch offsets: (u & 0xff) | (v << 8), padded with (0,0)
 };
+
+// Quadtree buckets (orbfe_octree3.hip).  A candidate's bucket = its root and quadrant path down to depth 5; the
+// path is separable (x decides the x bits, y the y bits), so it is X[x] | Y[y] from two host-built tables:
+//   X[x] = root << 10 | x bits spread to the even positions | (root * 32 + column) << 16
+//   Y[y] = y bits spread to the odd positions | row << 16
+// Best key of a bucket: score (8 bits) << 24 | ~(level-local cell (12 bits) << 12 | slot (12 bits)) -- maximum
+// = best score, first in cv::FAST emission order.
+#define ORBFE_BK_DEPTH 5
+#define ORBFE_BK_BUCKETS 4096
+#define ORBFE_BK_REF_MASK 0xffffffu
+#define ORBFE_BK_KEY(sc, cell, slot) (((sc) << 24) | (ORBFE_BK_REF_MASK - (unsigned)(((cell) << 12) | (slot))))
 
 struct KeyPointPOD {
     float x, y, size, angle, response;
@@ -97,7 +110,7 @@ void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, cons
                          int n_images, hipStream_t s);
 void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
 void orbfe_launch_blur(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
-void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
+void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool buckets, hipStream_t s);
 void orbfe_launch_octree_generic(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
 void orbfe_launch_octree2(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, int lds_pts, size_t lds, hipStream_t s);
 size_t orbfe_octree2_lds_bytes(int max_nodes, int sort_cap, int lds_pts);

@@ -359,7 +359,9 @@ template <int P> __device__ __forceinline__ pk16 row_pair(const unsigned (&w)[3]
 
 // TP = tile pitch in bytes as a compile-time constant (0: run-time value): with it every ring / row offset folds
 // into the immediate offset field of the LDS instructions instead of costing address VALU.
-template <int TP>
+// BK: also accumulate the quadtree bucket counts / best keys of the survivors (orbfe_octree3.hip) -- aggregated per
+// cell in LDS, then a few global atomics per cell.
+template <int TP, bool BK>
 __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int tile_pitch_rt, int tile_bytes, int sc_bytes, int q_bytes, int dbg)
 {
     const int tile_pitch = TP ? TP : tile_pitch_rt;
@@ -399,6 +401,14 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
     if (iw <= 0 || ih <= 0) {
         if (lane == 0) *cnt_out = 0;
         return;
+    }
+    // bucket tables of this cell's columns / rows (BK): issued now, consumed in phase E
+    unsigned tabx = 0u, taby = 0u;
+    if (BK) {
+        const uint32_t *bx_tab = buf.bk_tab + L.bk_xoff + 3 + ci_j * L.w_cell; // survivor x = c + 3 + j * wCell
+        const uint32_t *by_tab = buf.bk_tab + L.bk_yoff + 3 + ci_i * L.h_cell;
+        tabx = bx_tab[lane < iw ? lane : iw - 1];
+        taby = by_tab[lane < ih ? lane : ih - 1];
     }
     // LDS layout (sizes fixed by the host from the largest cell): tile | scores | queue.  Queue 2 is
     // compacted in place over queue 1 (writes never pass the read cursor); the per-entry flags of
@@ -573,26 +583,68 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
     // ---- E: ordered emission ----
     uint32_t *oxy = buf.cell_xy + ((size_t)img * cfg.cells_total + cell) * cfg.cell_cap;
     uint8_t *osc = buf.cell_sc + ((size_t)img * cfg.cells_total + cell) * cfg.cell_cap;
+    // BK: the cell's survivors fall into the bucket columns gx0..gx1 and rows by0..by1 (tables are monotone); when
+    // that rectangle has at most 64 buckets they are accumulated in LDS first
+    unsigned *s_ac = (unsigned *)(s_mem + tile_bytes + sc_bytes + q_bytes), *s_ab = s_ac + 64;
+    int gx0 = 0, by0 = 0, ncols = 1, nb = 0;
+    uint32_t *g_cnt = nullptr, *g_best = nullptr;
+    if (BK) {
+        gx0 = (int)(__builtin_amdgcn_readfirstlane(tabx) >> 16);
+        by0 = (int)(__builtin_amdgcn_readfirstlane(taby) >> 16);
+        ncols = (int)(__builtin_amdgcn_readlane(tabx, 63) >> 16) - gx0 + 1; // lanes >= iw hold the last column / row
+        nb = ncols * ((int)(__builtin_amdgcn_readlane(taby, 63) >> 16) - by0 + 1);
+        if (nb <= 64) { s_ac[lane] = 0u; s_ab[lane] = 0u; }
+        g_cnt = buf.bk_cnt + ((size_t)img * cfg.nlevels + level) * ORBFE_BK_BUCKETS;
+        g_best = buf.bk_best + ((size_t)img * cfg.nlevels + level) * ORBFE_BK_BUCKETS;
+        __syncthreads();
+    }
     int run = 0;
     for (int q0 = 0; q0 < n2; q0 += 64) {
         const int q = q0 + lane;
         const bool pred = q < n2 && s_qf[q] >= need;
         const unsigned long long m = __ballot(pred);
+        const unsigned rc = q < n2 ? (s_q2[q] & 0x7fffu) : 0u;
+        const int r = rc >> 8, c = rc & 255;
+        unsigned tx = 0u, ty = 0u;
+        if (BK) { tx = (unsigned)__shfl((int)tabx, c, 64); ty = (unsigned)__shfl((int)taby, r, 64); }
         if (pred) {
             const int pos = run + __popcll(m & lt);
             if (pos < cfg.cell_cap) {
-                const unsigned rc = s_q2[q] & 0x7fffu;
-                const int r = rc >> 8, c = rc & 255;
                 // cell-local FAST coords (c+3, r+3) + (j*wCell, i*hCell): src/ORBextractor.cc:816-817
                 const unsigned x = (unsigned)(c + 3 + ci_j * L.w_cell);
                 const unsigned y = (unsigned)(r + 3 + ci_i * L.h_cell);
+                const unsigned sc = s_sc[(r + 1) * scp + c + 1];
                 oxy[pos] = x | (y << 16);
-                osc[pos] = s_sc[(r + 1) * scp + c + 1];
+                osc[pos] = (uint8_t)sc;
+                if (BK) {
+                    const unsigned key = ORBFE_BK_KEY(sc, (unsigned)ci, (unsigned)pos);
+                    if (nb <= 64) {
+                        const int li = ((int)(ty >> 16) - by0) * ncols + ((int)(tx >> 16) - gx0);
+                        atomicAdd(&s_ac[li], 1u);
+                        atomicMax(&s_ab[li], key);
+                    } else {
+                        const unsigned b = (tx | ty) & 0xfffu;
+                        atomicAdd(&g_cnt[b], 1u);
+                        atomicMax(&g_best[b], key);
+                    }
+                }
             }
         }
         run += __popcll(m);
     }
     if (lane == 0) *cnt_out = run < cfg.cell_cap ? run : cfg.cell_cap;
+    if (BK && nb <= 64) {
+        __syncthreads();
+        const unsigned cnt = lane < nb ? s_ac[lane] : 0u;
+        if (cnt) {
+            const int ly = (int)(((float)lane + 0.5f) / (float)ncols), lx = lane - ly * ncols;
+            const unsigned gx = (unsigned)(gx0 + lx), by = (unsigned)(by0 + ly);
+            auto spread5 = [](unsigned v) { return (v & 1u) | ((v & 2u) << 1) | ((v & 4u) << 2) | ((v & 8u) << 3) | ((v & 16u) << 4); };
+            const unsigned b = ((gx >> 5) << 10) | spread5(gx & 31u) | (spread5(by) << 1);
+            atomicAdd(&g_cnt[b], cnt);
+            atomicMax(&g_best[b], s_ab[lane]);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1354,7 +1406,7 @@ void orbfe_launch_blur(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_
     hipLaunchKernelGGL(blur_kernel, grid, dim3(256), 0, s, cfg, buf);
 }
 
-void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
+void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool buckets, hipStream_t s)
 {
     const int mw = max_cell_w(cfg), mh = max_cell_h(cfg);
     const int tile_pitch = (mw + 6 + 3 + 3 + 3) & ~3; // + alignment slack on both sides
@@ -1363,10 +1415,16 @@ void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_
     const int sc_bytes = ((mw + 2) * (mh + 2) + 15) & ~15;
     const int q_bytes = (2 * mw * mh + 15) & ~15;
     // flags alias the tile: it must hold one byte per interior pixel
-    const size_t lds = (size_t)(tile_bytes > mw * mh ? tile_bytes : ((mw * mh + 15) & ~15)) + sc_bytes + q_bytes;
+    // flags alias the tile region: tile_bytes passed to the kernel covers both; + 2 x 64 words of bucket accumulators
+    const int tile_region = tile_bytes > mw * mh ? tile_bytes : ((mw * mh + 15) & ~15);
+    const size_t lds = (size_t)tile_region + sc_bytes + q_bytes + 512;
     dim3 grid(cfg.cells_total * ((n_images + 7) / 8) * 8);
     static const int dbg = getenv("ORBFE_FAST_DBG") ? atoi(getenv("ORBFE_FAST_DBG")) : 0; // profiling aid only
-#define FAST_LAUNCH(TP) hipLaunchKernelGGL(fast_cell_kernel<TP>, grid, dim3(64), lds, s, cfg, buf, n_images, tile_pitch, tile_bytes, sc_bytes, q_bytes, dbg)
+#define FAST_LAUNCH(TP)                                                                                                                   \
+    do {                                                                                                                              \
+        if (buckets) hipLaunchKernelGGL((fast_cell_kernel<TP, true>), grid, dim3(64), lds, s, cfg, buf, n_images, tile_pitch, tile_region, sc_bytes, q_bytes, dbg); \
+        else hipLaunchKernelGGL((fast_cell_kernel<TP, false>), grid, dim3(64), lds, s, cfg, buf, n_images, tile_pitch, tile_region, sc_bytes, q_bytes, dbg); \
+    } while (0)
     switch (tile_pitch) {
     case 44: FAST_LAUNCH(44); break;
     case 48: FAST_LAUNCH(48); break;

@@ -5,10 +5,11 @@
 // tree (root index, then one quadrant per depth) depends on its coordinates only.  What IS data
 // dependent -- which nodes are split, in which order, and when the process stops -- needs nothing but
 // the number of points in a node and in its four children.  Hence:
-//   1. one sweep over the level's FAST cells computes every candidate's root and its quadrant path
-//      down to depth 5 ("bucket"), and with two LDS atomics per point builds per-bucket counts and the
-//      per-bucket best key  score << 24 | ~(cell << 12 | slot)  (max score, first in cv::FAST emission
-//      order = the reference's "first maximum wins");
+//   1. fast_cell_kernel (phase E) looks up every survivor's root and quadrant path down to depth 5
+//      ("bucket") in two host-built tables (the path is separable in x and y) and accumulates per-bucket
+//      counts and the per-bucket best key  score << 24 | ~(cell << 12 | slot)  (max score, first in
+//      cv::FAST emission order = the reference's "first maximum wins") -- per cell in LDS, then a few
+//      global atomics per cell; this kernel takes the 4096 + 4096 words over and clears them;
 //   2. counts and best keys are summed / maximised up the quadrant pyramid (depths 4..0);
 //   3. the split passes work on the node list alone (<= max_nodes entries in LDS): a node is
 //      (box, depth, path), its child counts are pyramid look-ups, and the list-order bookkeeping, the
@@ -31,8 +32,9 @@
 #define OT3_PYR (OT3_ROOTS * 1365)     // sum_{d=0..5} 4^d = 1365 entries per root
 #define OT3_BUCKETS (OT3_ROOTS * 1024)
 // best key: score (8 bits) << 24 | ~(cell (12 bits) << 12 | slot (12 bits)); the host checks the field widths
-#define OT3_REF_MASK 0xffffffu
-#define OT3_KEY(sc, cell, slot) (((sc) << 24) | (OT3_REF_MASK - (unsigned)(((cell) << 12) | (slot))))
+#define OT3_REF_MASK ORBFE_BK_REF_MASK
+#define OT3_KEY(sc, cell, slot) ORBFE_BK_KEY(sc, cell, slot)
+static_assert(OT3_DB == ORBFE_BK_DEPTH && OT3_BUCKETS == ORBFE_BK_BUCKETS, "bucket geometry is shared with fast_cell_kernel");
 
 // entries of depths < d; entry (d, root, path) = ot3_off(d) + (root << 2d) + path, its children are
 // ot3_off(d+1) + 4 * ((root << 2d) + path) + quadrant
@@ -167,41 +169,6 @@ __device__ __forceinline__ void ot3_for_each_point(const int *cell_cnt, const ui
     }
 }
 
-// Bucket counts and best keys of every (image, level): one wave per FAST cell over the whole chip, two
-// fire-and-forget global atomics per candidate.  Blocks are dealt to the XCDs like fast_cell_kernel's
-// (all cells of an image on one XCD), so an image's 32 KB of bucket words stay in one L2.
-__global__ __launch_bounds__(256) void bucket_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images)
-{
-    const int bpi = (cfg.cells_total + 3) / 4;
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int img = (jb / bpi) * 8 + xcd;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cell = (jb % bpi) * 4 + wave;
-    if (img >= n_images || cell >= cfg.cells_total) return;
-    int level = 0;
-    for (int l = 1; l < cfg.nlevels; l++)
-        if (cell >= cfg.lv[l].cell_off) level = l;
-    const LevelInfo &L = cfg.lv[level];
-    const size_t ib = (size_t)img;
-    const int cnt = buf.cell_cnt[ib * cfg.cells_total + cell];
-    if (cnt == 0) return;
-    const uint32_t *cxy = buf.cell_xy + (ib * cfg.cells_total + cell) * cfg.cell_cap;
-    const uint8_t *csc = buf.cell_sc + (ib * cfg.cells_total + cell) * cfg.cell_cap;
-    uint32_t *g_cnt = buf.bk_cnt + (ib * cfg.nlevels + level) * OT3_BUCKETS;
-    uint32_t *g_best = buf.bk_best + (ib * cfg.nlevels + level) * OT3_BUCKETS;
-    const int region_h = (L.h - cfg.edge_threshold + 3) - cfg.min_border;
-    const int lcell = cell - L.cell_off;
-    for (int k = lane; k < cnt; k += 64) {
-        const uint32_t xy = cxy[k];
-        const unsigned sc = csc[k];
-        int root;
-        const unsigned path = ot3_path((int)(xy & 0xffffu), (int)(xy >> 16), OT3_DB, L.hx, L.n_ini, region_h, root);
-        const int b = (root << (2 * OT3_DB)) + (int)path;
-        atomicAdd(&g_cnt[b], 1u);
-        atomicMax(&g_best[b], OT3_KEY(sc, lcell, k));
-    }
-}
-
 __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, DeviceBuffers buf, int sort_cap)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
@@ -245,7 +212,7 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
     const int n_ini = L.n_ini, quota = L.quota;
     const float hx = L.hx;
 
-    // ---- 1. buckets: filled by bucket_kernel (chip-wide, one wave per cell); taken over and cleared for the next frame ----
+    // ---- 1. buckets: filled by fast_cell_kernel<.., true> (phase E); taken over and cleared for the next frame ----
     {
         uint32_t *g_cnt = buf.bk_cnt + (ib * cfg.nlevels + level) * OT3_BUCKETS;
         uint32_t *g_best = buf.bk_best + (ib * cfg.nlevels + level) * OT3_BUCKETS;
@@ -620,8 +587,6 @@ __global__ __launch_bounds__(OT3_THREADS) void candidates_gather_kernel(DeviceCo
 
 void orbfe_launch_octree3(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, size_t lds, hipStream_t s)
 {
-    const int bpi = (cfg.cells_total + 3) / 4;
-    hipLaunchKernelGGL(bucket_kernel, dim3(bpi * ((n_images + 7) / 8) * 8), dim3(256), 0, s, cfg, buf, n_images);
     dim3 grid(cfg.nlevels, n_images);
     hipLaunchKernelGGL(octree3_kernel, grid, dim3(OT3_THREADS), lds, s, cfg, buf, sort_cap);
 }
