@@ -598,42 +598,49 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
         g_best = buf.bk_best + ((size_t)img * cfg.nlevels + level) * ORBFE_BK_BUCKETS;
         __syncthreads();
     }
+    // survivors are first compacted in place over the queue (a write never passes this iteration's reads), then
+    // emitted densely: one pass of 64 lanes per 64 survivors instead of one per 64 queue entries
     int run = 0;
     for (int q0 = 0; q0 < n2; q0 += 64) {
         const int q = q0 + lane;
         const bool pred = q < n2 && s_qf[q] >= need;
         const unsigned long long m = __ballot(pred);
-        const unsigned rc = q < n2 ? (s_q2[q] & 0x7fffu) : 0u;
+        const uint16_t rc = q < n2 ? s_q2[q] : (uint16_t)0;
+        if (pred) s_q2[run + __popcll(m & lt)] = rc;
+        run += __popcll(m);
+    }
+    __syncthreads();
+    const int n_out = run < cfg.cell_cap ? run : cfg.cell_cap;
+    for (int p0 = 0; p0 < n_out; p0 += 64) {
+        const int pos = p0 + lane;
+        const bool v = pos < n_out;
+        const unsigned rc = v ? (s_q2[pos] & 0x7fffu) : 0u;
         const int r = rc >> 8, c = rc & 255;
         unsigned tx = 0u, ty = 0u;
         if (BK) { tx = (unsigned)__shfl((int)tabx, c, 64); ty = (unsigned)__shfl((int)taby, r, 64); }
-        if (pred) {
-            const int pos = run + __popcll(m & lt);
-            if (pos < cfg.cell_cap) {
-                // cell-local FAST coords (c+3, r+3) + (j*wCell, i*hCell): src/ORBextractor.cc:816-817
-                const unsigned x = (unsigned)(c + 3 + ci_j * L.w_cell);
-                const unsigned y = (unsigned)(r + 3 + ci_i * L.h_cell);
-                const unsigned sc = s_sc[(r + 1) * scp + c + 1];
-                oxy[pos] = x | (y << 16);
-                osc[pos] = (uint8_t)sc;
-                if (BK) {
-                    const unsigned key = ORBFE_BK_KEY(sc, (unsigned)ci, (unsigned)pos);
-                    if (nb <= 64) {
-                        const int li = ((int)(ty >> 16) - by0) * ncols + ((int)(tx >> 16) - gx0);
-                        atomicAdd(&s_ac[li], 1u);
-                        atomicMax(&s_ab[li], key);
-                    } else {
-                        const unsigned b = (tx | ty) & 0xfffu;
-                        atomicAdd(&g_cnt[b], 1u);
-                        atomicMax(&g_best[b], key);
-                    }
+        if (v) {
+            // cell-local FAST coords (c+3, r+3) + (j*wCell, i*hCell): src/ORBextractor.cc:816-817
+            const unsigned x = (unsigned)(c + 3 + ci_j * L.w_cell);
+            const unsigned y = (unsigned)(r + 3 + ci_i * L.h_cell);
+            const unsigned sc = s_sc[(r + 1) * scp + c + 1];
+            oxy[pos] = x | (y << 16);
+            osc[pos] = (uint8_t)sc;
+            if (BK) {
+                const unsigned key = ORBFE_BK_KEY(sc, (unsigned)ci, (unsigned)pos);
+                if (nb <= 64) {
+                    const int li = ((int)(ty >> 16) - by0) * ncols + ((int)(tx >> 16) - gx0);
+                    atomicAdd(&s_ac[li], 1u);
+                    atomicMax(&s_ab[li], key);
+                } else {
+                    const unsigned b = (tx | ty) & 0xfffu;
+                    atomicAdd(&g_cnt[b], 1u);
+                    atomicMax(&g_best[b], key);
                 }
             }
         }
-        run += __popcll(m);
     }
     if (lane == 0) *cnt_out = run < cfg.cell_cap ? run : cfg.cell_cap;
-    if (BK && nb <= 64) {
+    if (BK && nb <= 64 && dbg != 5) {
         __syncthreads();
         const unsigned cnt = lane < nb ? s_ac[lane] : 0u;
         if (cnt) {
