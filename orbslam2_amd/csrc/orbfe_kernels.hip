@@ -968,9 +968,17 @@ __global__ __launch_bounds__(OT_THREADS) void octree_generic_kernel(DeviceConfig
 // ---------------------------------------------------------------------------
 // The kernel is bound by vector-memory INSTRUCTION issue (a wave64 byte gather costs the texture
 // addresser ~16 cycles whatever it fetches), so everything is fetched as aligned dwords into LDS:
-// the block stages the two tables once, each wave stages its 31-row raw patch (5 loads) and 37-row
-// blurred patch (6 loads), and all per-pixel / per-sample accesses become LDS byte reads.
+// the block stages the two tables once, each wave stages a keypoint's 31-row raw patch (5 loads) and
+// 37-row blurred patch (6 loads), and all per-pixel / per-sample accesses become LDS byte reads.
+// A wave handles DS_KPW consecutive keypoint slots: the table staging and the slot bookkeeping are paid
+// once per 4 * DS_KPW keypoints, and the patch words of keypoint i+1 are fetched into registers while
+// keypoint i is computed from LDS, so the global-load latency is off the critical path.
 #define DS_PATCH_W 40 // bytes per staged patch row (10 words: covers 31+3 / 37+3 px at any alignment)
+#define DS_KPW 4      // keypoint slots per wave
+#define DS_RAW_REGS 8 // prefetch registers for the raw patch (raw_rows * 10 words <= 512, i.e. half_patch <= 25)
+#define DS_BLR_REGS 6 // 37 rows * 10 words = 370 words
+
+
 __global__ __launch_bounds__(256) void describe_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dm[];
@@ -978,14 +986,15 @@ __global__ __launch_bounds__(256) void describe_kernel(DeviceConfig cfg, DeviceB
     // b runs on XCD b % 8 (placement is a speed assumption only).  All blocks of one image are given to
     // one XCD, whose 4 MiB L2 then holds that image's raw + blurred pyramid (3.3 MB) while its ~2000
     // overlapping 31x31 / 37x37 patches are read, instead of every patch row coming from the MALL.
-    const int bpi = (cfg.sel_total + 3) / 4; // blocks per image
+    const int bpi = (cfg.sel_total + 4 * DS_KPW - 1) / (4 * DS_KPW); // blocks per image
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int img = (jb / bpi) * 8 + xcd;
     if (img >= n_images) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slot = (jb % bpi) * 4 + wave;
+    const int slot0 = (jb % bpi) * (4 * DS_KPW) + wave * DS_KPW;
     const int hp = cfg.half_patch;
     const int raw_rows = 2 * hp + 1;
+    const int raw_words = raw_rows * (DS_PATCH_W / 4);
     const int *sel_cnt = buf.sel_cnt + (size_t)img * cfg.nlevels;
     if (jb % bpi == 0 && tid == 0) {
         int tot = 0;
@@ -999,104 +1008,147 @@ __global__ __launch_bounds__(256) void describe_kernel(DeviceConfig cfg, DeviceB
     uint8_t *s_blr = s_raw + raw_rows * DS_PATCH_W;
     for (int i = tid; i < cfg.patch_n / 2; i += 256) ((int *)s_uv)[i] = ((const int *)buf.patch_uv)[i];
     s_pat[tid] = ((const int *)g_pattern)[tid];
-    // per-wave independent loads, issued before the barrier
-    const bool in_range = slot < cfg.sel_total;
-    const int level = in_range ? buf.slot_level[slot] : 0;
+    // per-wave slot data, one slot per lane (lanes < DS_KPW), issued before the barrier
+    const int my_slot = slot0 + (lane < DS_KPW ? lane : 0);
+    const bool my_in = lane < DS_KPW && my_slot < cfg.sel_total;
+    const int level_l = my_in ? buf.slot_level[my_slot] : 0;
+    const uint32_t xy_l = my_in ? buf.sel_xy[(size_t)img * cfg.sel_total + my_slot] : 0u;
+    const int score_l = my_in ? buf.sel_sc[(size_t)img * cfg.sel_total + my_slot] : 0;
     const int c_l = lane < cfg.nlevels ? sel_cnt[lane] : 0;
-    const uint32_t xy = in_range ? buf.sel_xy[(size_t)img * cfg.sel_total + slot] : 0u;
-    const int score = in_range ? buf.sel_sc[(size_t)img * cfg.sel_total + slot] : 0;
     __syncthreads();
-    if (!in_range) return;
-    const LevelInfo &L = cfg.lv[level];
-    const int k = slot - L.sel_off;
     int inc = c_l;
 #pragma unroll
     for (int o = 1; o < ORBFE_MAX_LEVELS; o <<= 1) {
         const int t = __shfl_up(inc, o, 64);
         if (lane >= o) inc += t;
     }
-    if (k >= __shfl(c_l, level, 64)) return;
-    const int out = k + __shfl(inc - c_l, level, 64);
+    const int excl = inc - c_l; // keypoints of the lower levels
     if (dbg == 1) return;
 
-    const int cx = (int)(xy & 0xffffu) + cfg.min_border;
-    const int cy = (int)(xy >> 16) + cfg.min_border;
-    const uint8_t *raw = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off;
-    const uint8_t *blr = buf.blur + (size_t)img * cfg.pyr_bytes + L.pyr_off;
-    // stage both patches (aligned dwords; the right overshoot stays inside the level's margin)
-    const int xr = (cx - hp) & ~3, xb = (cx - 18) & ~3;
+    const int r0 = lane / (DS_PATCH_W / 4), c0 = lane - r0 * (DS_PATCH_W / 4);
+    const bool raw_in_regs = raw_words <= 64 * DS_RAW_REGS;
+    uint32_t pr[DS_RAW_REGS], pb[DS_BLR_REGS];
     // word i = lane + 64*k of a staged patch is (row i / 10, word i % 10); rows advance by 6 and words by 4
     // per step, so the (quarter-rate) integer multiplies and the division stay out of the loops
-    {
-        const int r0 = lane / (DS_PATCH_W / 4), c0 = lane - r0 * (DS_PATCH_W / 4);
-        const uint8_t *gp = raw + (ptrdiff_t)__mul24(cy - hp + r0, L.pitch) + xr + 4 * c0;
+    auto fetch = [&](const uint8_t *img_base, const LevelInfo &L, int x_al, int y_top, uint32_t *dst, int nregs, int nwords) {
+        const uint8_t *gp = img_base + (ptrdiff_t)__mul24(y_top + r0, L.pitch) + x_al + 4 * c0;
         const int step = 6 * L.pitch + 16, wrap = L.pitch - DS_PATCH_W;
         int c = c0;
-        for (int i = lane; i < raw_rows * (DS_PATCH_W / 4); i += 64) {
-            ((uint32_t *)s_raw)[i] = *(const uint32_t *)gp;
-            gp += step; c += 4;
-            if (c >= DS_PATCH_W / 4) { c -= DS_PATCH_W / 4; gp += wrap; }
-        }
-        gp = blr + (ptrdiff_t)__mul24(cy - 18 + r0, L.pitch) + xb + 4 * c0;
-        c = c0;
-        for (int i = lane; i < 37 * (DS_PATCH_W / 4); i += 64) {
-            ((uint32_t *)s_blr)[i] = *(const uint32_t *)gp;
-            gp += step; c += 4;
-            if (c >= DS_PATCH_W / 4) { c -= DS_PATCH_W / 4; gp += wrap; }
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0); // LDS writes of this wave are visible to its own later reads in order
-    __builtin_amdgcn_wave_barrier();
-    if (dbg == 2) return;
-
-    // IC_Angle (src/ORBextractor.cc:72-99): integer moments over the circular patch (host-built offset
-    // table, padded with (0,0) entries that contribute nothing)
-    int m10 = 0, m01 = 0;
-    const uint8_t *pc = s_raw + hp * DS_PATCH_W + (cx - xr);
-    for (int kk = lane; kk < cfg.patch_n; kk += 64) {
-        const int uv = s_uv[kk];
-        const int u = (int)(int8_t)(uv & 0xff), v = (int)(int8_t)((uv >> 8) & 0xff);
-        const int I = pc[__mul24(v, DS_PATCH_W) + u];
-        m10 += u * I;
-        m01 += v * I;
-    }
-    m10 = wave_sum_i32(m10);
-    m01 = wave_sum_i32(m01);
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
-    if (dbg == 3) { if (lane == 0) buf.depth[(size_t)img * cfg.sel_total + out] = angle; return; }
-
-    // computeOrbDescriptor (src/ORBextractor.cc:103-142)
-    const float factor_pi = __uint_as_float(0x3c8efa35u); // (float)(CV_PI/180.f)
-    float a, b;
-    sincos_det(__fmul_rn(angle, factor_pi), &b, &a);
-    const uint8_t *center = s_blr + 18 * DS_PATCH_W + (cx - xb);
-    unsigned long long *dout = (unsigned long long *)(buf.desc + ((size_t)img * cfg.sel_total + out) * 32);
-    unsigned long long bits[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int pw = s_pat[r * 64 + lane]; // (x0, y0, x1, y1) as 4 signed bytes
-        const float x0 = (float)(int)(int8_t)(pw & 0xff), y0 = (float)(int)(int8_t)((pw >> 8) & 0xff);
-        const float x1 = (float)(int)(int8_t)((pw >> 16) & 0xff), y1 = (float)(pw >> 24);
-        const int r0 = (int)rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-        const int c0 = (int)rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int r1 = (int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        const int c1 = (int)rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = center[__mul24(r0, DS_PATCH_W) + c0];
-        const int t1 = center[__mul24(r1, DS_PATCH_W) + c1];
-        bits[r] = __ballot(t0 < t1);
-    }
-    if (lane < 4) dout[lane] = lane == 0 ? bits[0] : (lane == 1 ? bits[1] : (lane == 2 ? bits[2] : bits[3]));
-    if (lane == 0) {
-        KeyPointPOD kp;
-        float px = (float)cx, py = (float)cy;
-        if (level != 0) { px = __fmul_rn(px, L.scale); py = __fmul_rn(py, L.scale); }
-        kp.x = px; kp.y = py;
-        kp.size = (float)L.scaled_patch;
-        kp.angle = angle;
-        kp.response = (float)score;
-        kp.octave = level;
-        kp.class_id = -1;
-        ((KeyPointPOD *)buf.kps)[(size_t)img * cfg.sel_total + out] = kp;
+        for (int k = 0; k < DS_RAW_REGS; k++) {
+            if (k < nregs) {
+                if (lane + 64 * k < nwords) dst[k] = *(const uint32_t *)gp;
+                gp += step; c += 4;
+                if (c >= DS_PATCH_W / 4) { c -= DS_PATCH_W / 4; gp += wrap; }
+            }
+        }
+    };
+    // slot i of this wave: uniform keypoint data; returns false if the slot holds no keypoint
+    int level = 0, cx = 0, cy = 0, score = 0, out = 0;
+    auto slot_data = [&](int i) -> bool {
+        if (slot0 + i >= cfg.sel_total) return false;
+        level = __builtin_amdgcn_readlane(level_l, i);
+        const uint32_t xy = (uint32_t)__builtin_amdgcn_readlane((int)xy_l, i);
+        score = __builtin_amdgcn_readlane(score_l, i);
+        const int k = slot0 + i - cfg.lv[level].sel_off;
+        if (k >= __shfl(c_l, level, 64)) return false;
+        out = k + __shfl(excl, level, 64);
+        cx = (int)(xy & 0xffffu) + cfg.min_border;
+        cy = (int)(xy >> 16) + cfg.min_border;
+        return true;
+    };
+    auto prefetch = [&](int i) -> bool {
+        if (i >= DS_KPW || !slot_data(i)) return false;
+        const LevelInfo &L = cfg.lv[level];
+        const uint8_t *raw = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off;
+        const uint8_t *blr = buf.blur + (size_t)img * cfg.pyr_bytes + L.pyr_off;
+        if (raw_in_regs) fetch(raw, L, (cx - hp) & ~3, cy - hp, pr, DS_RAW_REGS, raw_words);
+        fetch(blr, L, (cx - 18) & ~3, cy - 18, pb, DS_BLR_REGS, 37 * (DS_PATCH_W / 4));
+        return true;
+    };
+
+    bool have = prefetch(0);
+    for (int i = 0; i < DS_KPW; i++) {
+        const bool cur = have;
+        // keypoint i: uniform data again (cheap), then its patches from the prefetch registers into LDS
+        int lv = 0, kx = 0, ky = 0, ksc = 0, kout = 0;
+        if (cur) {
+            slot_data(i);
+            lv = level; kx = cx; ky = cy; ksc = score; kout = out;
+#pragma unroll
+            for (int k = 0; k < DS_RAW_REGS; k++)
+                if (raw_in_regs && lane + 64 * k < raw_words) ((uint32_t *)s_raw)[lane + 64 * k] = pr[k];
+#pragma unroll
+            for (int k = 0; k < DS_BLR_REGS; k++)
+                if (lane + 64 * k < 37 * (DS_PATCH_W / 4)) ((uint32_t *)s_blr)[lane + 64 * k] = pb[k];
+            if (!raw_in_regs) { // big patches: straight through (no prefetch)
+                const LevelInfo &Lr = cfg.lv[lv];
+                const uint8_t *gp = buf.pyr + (size_t)img * cfg.pyr_bytes + Lr.pyr_off + (ptrdiff_t)__mul24(ky - hp + r0, Lr.pitch) + ((kx - hp) & ~3) + 4 * c0;
+                const int step = 6 * Lr.pitch + 16, wrap = Lr.pitch - DS_PATCH_W;
+                int c = c0;
+                for (int w = lane; w < raw_words; w += 64) {
+                    ((uint32_t *)s_raw)[w] = *(const uint32_t *)gp;
+                    gp += step; c += 4;
+                    if (c >= DS_PATCH_W / 4) { c -= DS_PATCH_W / 4; gp += wrap; }
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0); // LDS writes of this wave are visible to its own later reads in order
+        __builtin_amdgcn_wave_barrier();
+        have = prefetch(i + 1); // in flight while keypoint i is computed
+        if (!cur || dbg == 2) continue;
+        const LevelInfo &L = cfg.lv[lv];
+        const int xr = (kx - hp) & ~3, xb = (kx - 18) & ~3;
+
+        // IC_Angle (src/ORBextractor.cc:72-99): integer moments over the circular patch (host-built offset
+        // table, padded with (0,0) entries that contribute nothing)
+        int m10 = 0, m01 = 0;
+        const uint8_t *pc = s_raw + hp * DS_PATCH_W + (kx - xr);
+        for (int kk = lane; kk < cfg.patch_n; kk += 64) {
+            const int uv = s_uv[kk];
+            const int u = (int)(int8_t)(uv & 0xff), v = (int)(int8_t)((uv >> 8) & 0xff);
+            const int I = pc[__mul24(v, DS_PATCH_W) + u];
+            m10 += u * I;
+            m01 += v * I;
+        }
+        m10 = wave_sum_i32(m10);
+        m01 = wave_sum_i32(m01);
+        const float angle = fast_atan2_deg((float)m01, (float)m10);
+        if (dbg == 3) { if (lane == 0) buf.depth[(size_t)img * cfg.sel_total + kout] = angle; continue; }
+
+        // computeOrbDescriptor (src/ORBextractor.cc:103-142)
+        const float factor_pi = __uint_as_float(0x3c8efa35u); // (float)(CV_PI/180.f)
+        float a, b;
+        sincos_det(__fmul_rn(angle, factor_pi), &b, &a);
+        const uint8_t *center = s_blr + 18 * DS_PATCH_W + (kx - xb);
+        unsigned long long *dout = (unsigned long long *)(buf.desc + ((size_t)img * cfg.sel_total + kout) * 32);
+        unsigned long long bits[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int pw = s_pat[r * 64 + lane]; // (x0, y0, x1, y1) as 4 signed bytes
+            const float x0 = (float)(int)(int8_t)(pw & 0xff), y0 = (float)(int)(int8_t)((pw >> 8) & 0xff);
+            const float x1 = (float)(int)(int8_t)((pw >> 16) & 0xff), y1 = (float)(pw >> 24);
+            const int rr0 = (int)rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+            const int cc0 = (int)rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+            const int rr1 = (int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+            const int cc1 = (int)rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+            const int t0 = center[__mul24(rr0, DS_PATCH_W) + cc0];
+            const int t1 = center[__mul24(rr1, DS_PATCH_W) + cc1];
+            bits[r] = __ballot(t0 < t1);
+        }
+        if (lane < 4) dout[lane] = lane == 0 ? bits[0] : (lane == 1 ? bits[1] : (lane == 2 ? bits[2] : bits[3]));
+        if (lane == 0) {
+            KeyPointPOD kp;
+            float px = (float)kx, py = (float)ky;
+            if (lv != 0) { px = __fmul_rn(px, L.scale); py = __fmul_rn(py, L.scale); }
+            kp.x = px; kp.y = py;
+            kp.size = (float)L.scaled_patch;
+            kp.angle = angle;
+            kp.response = (float)ksc;
+            kp.octave = lv;
+            kp.class_id = -1;
+            ((KeyPointPOD *)buf.kps)[(size_t)img * cfg.sel_total + kout] = kp;
+        }
     }
 }
 
@@ -1461,7 +1513,7 @@ void orbfe_launch_octree_generic(const DeviceConfig &cfg, const DeviceBuffers &b
 
 void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
 {
-    dim3 grid(((cfg.sel_total + 3) / 4) * ((n_images + 7) / 8) * 8);
+    dim3 grid(((cfg.sel_total + 4 * DS_KPW - 1) / (4 * DS_KPW)) * ((n_images + 7) / 8) * 8);
     const size_t lds = ((cfg.patch_n * 2 + 15) & ~15) + 256 * 4 + (size_t)4 * (2 * cfg.half_patch + 1 + 37) * DS_PATCH_W;
     static const int dbg = getenv("ORBFE_DESC_DBG") ? atoi(getenv("ORBFE_DESC_DBG")) : 0; // profiling aid only
     hipLaunchKernelGGL(describe_kernel, grid, dim3(256), lds, s, cfg, buf, n_images, dbg);
