@@ -150,14 +150,23 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ctx.set_profiling(True)
+    # Timed region: HIP events only around the dominant kernel (cell-wise FAST, stage 3) -- an event at every stage
+    # boundary costs ~6 us of idle GPU each, i.e. ~6 % of a step.  The full per-stage table comes from a separate,
+    # untimed pass after the timed region.
+    DOM = "fast"
+    ctx.set_profiling(2 + api.STAGE_NAMES.index(DOM))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    dom_ms_sum, dom_calls = ctx.stage_times(reset=True)
+    ctx.set_profiling(1)
+    for _ in range(min(args.steps, 10)):
+        step()
+    barrier()
     stage_ms, calls = ctx.stage_times(reset=True)
-    ctx.set_profiling(False)
+    ctx.set_profiling(0)
     dt = D.max_over_ranks(dt, dev)
 
     counts = ctx.fetch_counts(2 * P)
@@ -181,10 +190,12 @@ def main():
         alg = stage_alg_bytes_per_pair(n_cand)
         # stage time per step, summed over the G stream groups (they overlap in wall time)
         per_launch_ms = {k: v / max(calls, 1) for k, v in stage_ms.items()}
-        dom = max(per_launch_ms, key=per_launch_ms.get)
-        # per step a stage is G launches (one per stream group); the pyramid is 7 dependent launches per group
-        launches = G * (7 if dom == "pyramid" else 1)
-        dom_ms = per_launch_ms[dom] / launches
+        dom = DOM
+        if max(per_launch_ms, key=per_launch_ms.get) != DOM:
+            print("bench: note: stage %s is now longer than %s" % (max(per_launch_ms, key=per_launch_ms.get), DOM), file=sys.stderr)
+        # per step a stage is G launches (one per stream group)
+        launches = G
+        dom_ms = dom_ms_sum[dom] / max(dom_calls, 1) / launches  # from the events of the timed region
         achieved = alg[dom] * P / launches / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         metric = "frames/sec ORB extract+match, KITTI 1241x376 stereo, 2000 feats"
         try:
@@ -204,7 +215,8 @@ def main():
                          "launch_ms": dom_ms, "alg_bytes_per_launch": alg[dom] * P / launches,
                          "whole_pipeline": {"alg_bytes_per_pair": B_PAIR, "achieved": B_PAIR * value / world / 1e9,
                                             "frac": B_PAIR * value / world / 1e9 / HBM_PEAK_GBS},
-                         "stage_ms_per_step_summed_over_groups": per_launch_ms},
+                         "stage_ms_per_step_summed_over_groups": per_launch_ms,
+                         "stage_ms_note": "per-stage table from a separate untimed pass with events at every stage boundary; launch_ms from the timed region"},
         }
         if world == 1 and args.cpu_pairs > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)

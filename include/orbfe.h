@@ -140,7 +140,9 @@ int orbfe_device_buffers(orbfe_context *ctx, void **kps, void **desc, void **cou
  * Stages: ingest, pyramid, blur, fast, octree, describe, stereo_match, stereo_median.
  * orbfe_stage_times synchronises, adds up the per-stage elapsed ms of the enqueue calls
  * recorded since the last reset (at most 64 are kept; summed over the stream groups of each call) and
- * reports how many calls that was. */
+ * reports how many calls that was.
+ * orbfe_set_profiling: 0 = off, 1 = events at every stage boundary (each costs a few us of idle GPU),
+ * 2 + k = only the two events around stage k (the other stages report 0). */
 #define ORBFE_NUM_STAGES 8
 int orbfe_set_profiling(orbfe_context *ctx, int enabled);
 const char *orbfe_stage_name(int stage);

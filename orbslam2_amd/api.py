@@ -32,6 +32,7 @@ EXPORTS = [
     "orbfe_vocab_load", "orbfe_bow_transform", "orbfe_bow_maps", "orbfe_search_by_bow",  # bound in orbslam2_amd/bow.py
 ]
 NUM_STAGES = 8
+STAGE_NAMES = ["ingest", "pyramid", "blur", "fast", "octree", "describe", "stereo_match", "stereo_median"]  # orbfe_stage_name()
 
 
 class Params(C.Structure):
@@ -262,8 +263,9 @@ class Context:
     def set_streams(self, groups: int):
         self._check(self.L.orbfe_set_streams(self.h, groups))
 
-    def set_profiling(self, enabled: bool):
-        self._check(self.L.orbfe_set_profiling(self.h, int(enabled)))
+    def set_profiling(self, mode):
+        """0/False = off, 1/True = events at every stage boundary, 2 + k = only around stage k."""
+        self._check(self.L.orbfe_set_profiling(self.h, int(mode)))
 
     def stage_times(self, reset=True):
         """{stage: total ms} over the recorded enqueue calls, and the number of calls."""

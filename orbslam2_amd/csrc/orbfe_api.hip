@@ -39,6 +39,7 @@ struct orbfe_context {
     size_t ot2_lds = 0;
     // stage timing: ring of PROF_RING calls x (ORBFE_NUM_STAGES + 1) events
     bool profiling = false;
+    int prof_only = -1; // >= 0: record only the two events around that stage
     std::vector<hipEvent_t> events;
     int prof_calls = 0;      // calls recorded since the last reset
     int prof_stages[64];     // number of stages recorded by each call in the ring
@@ -549,7 +550,9 @@ extern "C" int orbfe_set_profiling(orbfe_context *ctx, int enabled)
         ctx->events.resize((size_t)PROF_RING * ORBFE_MAX_GROUPS * (ORBFE_NUM_STAGES + 1));
         for (auto &e : ctx->events) HIP_TRY(ctx, hipEventCreate(&e));
     }
+    if (enabled >= 2 + ORBFE_NUM_STAGES || enabled < 0) return fail(ctx, ORBFE_ERR_INVALID, "profiling mode must be 0, 1 or 2 + stage");
     ctx->profiling = enabled != 0;
+    ctx->prof_only = enabled >= 2 ? enabled - 2 : -1;
     ctx->prof_calls = 0;
     return ORBFE_OK;
 }
@@ -558,6 +561,10 @@ extern "C" int orbfe_set_profiling(orbfe_context *ctx, int enabled)
 static inline void prof_mark(orbfe_context *ctx, int group, int idx, hipStream_t s)
 {
     if (!ctx->profiling) return;
+    if (ctx->prof_only >= 0 && idx != ctx->prof_only && idx != ctx->prof_only + 1) {
+        ctx->prof_stages[ctx->prof_calls % PROF_RING] = idx;
+        return;
+    }
     const int slot = ctx->prof_calls % PROF_RING;
     hipEventRecord(ctx->events[((size_t)slot * ORBFE_MAX_GROUPS + group) * (ORBFE_NUM_STAGES + 1) + idx], s);
     ctx->prof_stages[slot] = idx;
@@ -577,6 +584,7 @@ extern "C" int orbfe_stage_times(orbfe_context *ctx, float *ms, int *calls, int 
             for (int g = 0; g < ctx->prof_groups; g++) {
                 const hipEvent_t *ev = &ctx->events[((size_t)c * ORBFE_MAX_GROUPS + g) * (ORBFE_NUM_STAGES + 1)];
                 for (int st = 0; st < ctx->prof_stages[c]; st++) {
+                    if (ctx->prof_only >= 0 && st != ctx->prof_only) continue;
                     float t = 0.f;
                     HIP_TRY(ctx, hipEventElapsedTime(&t, ev[st], ev[st + 1]));
                     ms[st] += t;
@@ -644,7 +652,6 @@ static int enqueue_batch(orbfe_context *ctx, const uint8_t *d_images, int n_unit
     hipStream_t s = pick_stream(ctx, stream);
     HIP_TRY(ctx, hipSetDevice(ctx->params.device));
     const int n_images = n_units * imgs_per_unit;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->buf.status, 0, sizeof(int) * n_images, s));
     int G = ctx->groups < n_units ? ctx->groups : n_units;
     if (G < 1) G = 1;
     if (G == 1) {

@@ -161,18 +161,25 @@ __device__ __forceinline__ int hamming256(const uint32_t *a, const uint32_t *b)
 // need no border logic: the margin IS cv::GaussianBlur's BORDER_REFLECT_101 (src/ORBextractor.cc:900).
 // ---------------------------------------------------------------------------
 
-// ingest: packed images -> level 0 (+ margin); one thread = 4 px of the extended domain
+// ingest: packed images -> level 0 (+ margin); one thread = 4 px of the extended domain, block = 64 words x 4 rows.
+// Interior words are one (unaligned) 32-bit load of the packed source; only the margin words gather reflected bytes.
+// Also clears the image's status word (first kernel of every chain).
 __global__ __launch_bounds__(256) void ingest_kernel(DeviceConfig cfg, DeviceBuffers buf, const uint8_t *__restrict__ src)
 {
     const int img = blockIdx.z;
     const LevelInfo &L = cfg.lv[0];
-    const int y = (int)blockIdx.y - PYR_MY;
-    const int x0 = (int)(blockIdx.x * 256 + threadIdx.x) * 4 - PYR_MX;
-    if (x0 >= L.w + 8) return;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) buf.status[img] = 0;
+    const int y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6)) - PYR_MY;
+    const int x0 = (int)(blockIdx.x * 64 + (threadIdx.x & 63)) * 4 - PYR_MX;
+    if (x0 >= L.w + 8 || y >= L.h + PYR_MY) return;
     const uint8_t *s = src + (size_t)img * L.w * L.h + (size_t)reflect101(y, L.h) * L.w;
     uint32_t v = 0;
+    if (x0 >= 0 && x0 + 3 < L.w) {
+        __builtin_memcpy(&v, s + x0, 4);
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; j++) v |= (uint32_t)s[reflect101(x0 + j, L.w)] << (8 * j);
+        for (int j = 0; j < 4; j++) v |= (uint32_t)s[reflect101(x0 + j, L.w)] << (8 * j);
+    }
     uint8_t *d = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (ptrdiff_t)y * L.pitch + x0;
     *(uint32_t *)d = v;
 }
@@ -1446,7 +1453,7 @@ static inline int max_cell_h(const DeviceConfig &cfg) { int m = 0; for (int l = 
 void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, const uint8_t *d_images, int n_images, hipStream_t s)
 {
     const int words = (cfg.lv[0].w + 12 + 3) / 4;
-    dim3 grid((words + 255) / 256, cfg.lv[0].h + 2 * PYR_MY, n_images);
+    dim3 grid((words + 63) / 64, (cfg.lv[0].h + 2 * PYR_MY + 3) / 4, n_images);
     hipLaunchKernelGGL(ingest_kernel, grid, dim3(256), 0, s, cfg, buf, d_images);
 }
 
