@@ -8,6 +8,7 @@
 #include "orbfe_device.h"
 #include "orbfe_host.h"
 
+#include <algorithm>
 #include <cfloat>
 #include <climits>
 #include <cmath>
@@ -400,6 +401,20 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
                 const int sy1 = sy + 1 < 0 ? 0 : (sy + 1 > S.h - 1 ? S.h - 1 : sy + 1);
                 tab[D.rs_ytab_off + i] = (uint32_t)sy0 | ((uint32_t)sy1 << 16);
                 tab[D.rs_ytab_off + ny + i] = (uint32_t)b0 | ((uint32_t)b1 << 16);
+            }
+            for (int v = 0; v < 3; v++) { // source-row span of the worst block of 16 / 8 / 4 output rows
+                const int rows = 16 >> v;
+                int worst = 1;
+                for (int y0 = 0; y0 < ny; y0 += rows) {
+                    int lo = INT_MAX, hi = -1;
+                    for (int i = y0; i < y0 + rows && i < ny; i++) {
+                        const uint32_t e = tab[D.rs_ytab_off + i];
+                        const int a = (int)(e & 0xffffu), b = (int)(e >> 16);
+                        lo = std::min(lo, std::min(a, b)); hi = std::max(hi, std::max(a, b));
+                    }
+                    worst = std::max(worst, hi - lo + 1);
+                }
+                D.rs_src_rows[v] = worst;
             }
         }
         while (tab.size() % 4) tab.push_back(0);

@@ -27,6 +27,7 @@ struct LevelInfo {
     double rs_scale_x, rs_scale_y; // cv::resize scale from level-1 (1/(dw/sw))
     int rs_xtab_off, rs_xtab_n;    // resize column table (two planes of rs_xtab_n words) in DeviceBuffers::rs_tab
     int rs_ytab_off, rs_ytab_n;    // resize row table
+    int rs_src_rows[3];            // source rows spanned by the worst block of 16 / 8 / 4 output rows (pyr_resize_kernel)
     int bk_xoff, bk_yoff;          // quadtree bucket tables of this level in DeviceBuffers::bk_tab (orbfe_octree3.hip)
 };
 

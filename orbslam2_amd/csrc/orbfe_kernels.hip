@@ -184,61 +184,127 @@ __global__ __launch_bounds__(256) void ingest_kernel(DeviceConfig cfg, DeviceBuf
     *(uint32_t *)d = v;
 }
 
-// pyramid: level l from level l-1 (cv::resize INTER_LINEAR, 8UC1 fixed point); one thread = 4 px
-// of the extended (margin-included) domain of level l.  The per-column / per-row source offsets and
-// 11-bit weights (cv::resize's xofs/ialpha, yofs/ibeta tables) are built once per context on the
-// host with exactly the arithmetic of resize.cpp and read here as packed words:
+// pyramid: level l from level l-1 (cv::resize INTER_LINEAR, 8UC1 fixed point) over the extended (margin-
+// included) domain of level l.  The per-column / per-row source offsets and 11-bit weights (cv::resize's
+// xofs/ialpha, yofs/ibeta tables) are built once per context on the host with exactly the arithmetic of
+// resize.cpp and read here as packed words:
 //   X0 = sx | sx1 << 16, X1 = a0 | a1 << 16 (per extended column), Y0 = sy0 | sy1 << 16, Y1 = b0 | b1 << 16.
-// A 256-thread workgroup produces RS_ROWS extended rows of level l at full (margin-included) width.
-// The two source rows each output row needs are staged in LDS with coalesced 32-bit loads (the rows
-// of a block overlap, so most of those loads hit L2), which turns the 16 scattered byte gathers per
-// 4 output pixels into LDS reads; margin columns / rows simply index reflected source positions.
-#define RS_ROWS 4
-__global__ __launch_bounds__(256) void pyr_resize_kernel(DeviceConfig cfg, DeviceBuffers buf, int level, int src_words)
+// A 256-thread workgroup produces 4 * RW extended rows: the source rows they touch (a contiguous range,
+// margins index reflected rows) are staged in LDS with coalesced 32-bit loads; wave w then owns RW
+// consecutive output rows and a lane owns 4 output columns, whose column table entries stay in registers.
+// resize.cpp's horizontal pass of a source row, h = S[sx] * a0 + S[sx1] * a1, is kept in registers for the
+// two most recent source rows, so a source row shared by consecutive output rows is filtered once (the
+// 1.2 : 1 row ratio makes that 0.83 instead of 2 horizontal passes per output row).  The vertical pass
+// ((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) is two 24-bit high multiplies: (b << 12) * (h & ~15)
+// = b * (h >> 4) * 2^16, and the sum is <= 1020 so resize.cpp's saturating cast never clips.
+template <int RW>
+__global__ __launch_bounds__(256) void pyr_resize_kernel(DeviceConfig cfg, DeviceBuffers buf, int level, int src_words, int max_src_rows)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_src[]; // [RS_ROWS][2][src_words * 4]
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_src[]; // [max_src_rows][src_words * 4]
     const int img = blockIdx.y;
     const LevelInfo &D = cfg.lv[level];
     const LevelInfo &S = cfg.lv[level - 1];
-    const int tid = threadIdx.x;
-    const int y0 = blockIdx.x * RS_ROWS; // first extended row of this block
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int y0 = blockIdx.x * (4 * RW); // first extended row of this block
     const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + S.pyr_off;
     uint8_t *dst = buf.pyr + (size_t)img * cfg.pyr_bytes + D.pyr_off;
     const uint32_t *xt = buf.rs_tab + D.rs_xtab_off;
     const uint32_t *yt = buf.rs_tab + D.rs_ytab_off;
-    const int nrows = (D.h + 2 * PYR_MY - y0) < RS_ROWS ? (D.h + 2 * PYR_MY - y0) : RS_ROWS;
+    const int total_rows = D.h + 2 * PYR_MY;
+    const int nrows = (total_rows - y0) < 4 * RW ? (total_rows - y0) : 4 * RW;
     const int row_bytes = src_words * 4;
-    // stage source rows: slot (k, 0) = sy0 of output row k, slot (k, 1) = sy1
-    for (int i = tid; i < nrows * 2 * src_words; i += 256) {
-        const int slot = i / src_words, c = i - slot * src_words;
-        const uint32_t Y0 = yt[y0 + (slot >> 1)];
-        const int sy = (slot & 1) ? (int)(Y0 >> 16) : (int)(Y0 & 0xffffu);
-        ((uint32_t *)s_src)[slot * src_words + c] = *(const uint32_t *)(src + (size_t)sy * S.pitch + 4 * c);
+    // source row range of the block (every wave computes it: lanes < nrows hold one output row each)
+    const uint32_t Yl = yt[y0 + (lane < nrows ? lane : 0)];
+    int smin = (int)(Yl & 0xffffu), smax = (int)(Yl >> 16);
+    { const int t = smin < smax ? smin : smax; smax = smin < smax ? smax : smin; smin = t; }
+#pragma unroll
+    for (int o = 1; o < 4 * RW; o <<= 1) {
+        const int a = __shfl_xor(smin, o, 64), b = __shfl_xor(smax, o, 64);
+        smin = a < smin ? a : smin; smax = b > smax ? b : smax;
+    }
+    smin = __builtin_amdgcn_readfirstlane(smin); smax = __builtin_amdgcn_readfirstlane(smax);
+    int n_src = smax - smin + 1;
+    if (n_src > max_src_rows) n_src = max_src_rows; // cannot happen: the host sized max_src_rows from the same table
+    {
+        int r = (int)(((float)tid + 0.5f) * (1.0f / (float)src_words)), c = tid - r * src_words;
+        const int dr = 256 / src_words, dc = 256 - dr * src_words;
+        const uint8_t *sp = src + (size_t)smin * S.pitch;
+        const int nw = n_src * src_words;
+        for (int i0 = tid; i0 < nw; i0 += 1024) { // 4 loads in flight per thread
+            uint32_t v[4];
+            int di[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                di[u] = __mul24(r, src_words) + c;
+                if (i0 + 256 * u < nw) v[u] = *(const uint32_t *)(sp + (unsigned)(__mul24(r, S.pitch) + 4 * c));
+                c += dc; r += dr;
+                if (c >= src_words) { c -= src_words; r++; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (i0 + 256 * u < nw) ((uint32_t *)s_src)[di[u]] = v[u];
+        }
     }
     __syncthreads();
     const int nwords = (D.w + 12 + 3) >> 2; // extended row in 4-px words
-    for (int i = tid; i < nrows * nwords; i += 256) {
-        const int k = i / nwords, xw = i - k * nwords;
+    const int k0 = wave * RW;
+    if (k0 >= nrows) return;
+    // per-row vertical table entries of this wave's rows (uniform)
+    uint32_t Y0r[RW], Y1r[RW];
+#pragma unroll
+    for (int k = 0; k < RW; k++) {
+        const int yy = y0 + (k0 + k < nrows ? k0 + k : nrows - 1);
+        Y0r[k] = yt[yy]; Y1r[k] = yt[D.rs_ytab_n + yy];
+    }
+    for (int xw = lane; xw < nwords; xw += 64) {
         const int xi = xw * 4;
         const uint4 X0 = *(const uint4 *)(xt + xi);
         const uint4 X1 = *(const uint4 *)(xt + D.rs_xtab_n + xi);
-        const uint32_t Y1 = yt[D.rs_ytab_n + y0 + k];
-        const int b0 = (int)(Y1 & 0xffffu), b1 = (int)(Y1 >> 16);
-        const uint8_t *r0 = s_src + (2 * k) * row_bytes;
-        const uint8_t *r1 = r0 + row_bytes;
         const uint32_t x0v[4] = {X0.x, X0.y, X0.z, X0.w}, x1v[4] = {X1.x, X1.y, X1.z, X1.w};
-        uint32_t out = 0;
+        int tagA = -1, tagB = -1;          // source rows held in hA / hB
+        unsigned hA[4], hB[4];             // (S[sx] * a0 + S[sx1] * a1) & ~15
+        auto hpass = [&](int sy, unsigned h[4]) {
+            const uint8_t *r = s_src + __mul24(sy - smin, row_bytes);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int sx = (int)(x0v[j] & 0xffffu), sx1 = (int)(x0v[j] >> 16);
-            const int a0 = (int)(x1v[j] & 0xffffu), a1 = (int)(x1v[j] >> 16);
-            const int h0 = r0[sx] * a0 + r0[sx1] * a1;
-            const int h1 = r1[sx] * a0 + r1[sx1] * a1;
-            int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-            v = v < 0 ? 0 : (v > 255 ? 255 : v);
-            out |= (uint32_t)v << (8 * j);
+            for (int j = 0; j < 4; j++) {
+                const unsigned p0 = r[x0v[j] & 0xffffu], p1 = r[x0v[j] >> 16];
+                h[j] = (__umul24(p0, x1v[j] & 0xffffu) + __umul24(p1, x1v[j] >> 16)) & ~15u;
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < RW; k++) {
+            if (k0 + k < nrows) {
+                const int sy0 = (int)(Y0r[k] & 0xffffu), sy1 = (int)(Y0r[k] >> 16);
+                // make hA = row sy0, hB = row sy1 (uniform branches: all lanes walk the same rows)
+                if (tagA != sy0) {
+                    if (tagB == sy0) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) { const unsigned t = hA[j]; hA[j] = hB[j]; hB[j] = t; }
+                        tagB = tagA; tagA = sy0;
+                    } else {
+                        hpass(sy0, hA); tagA = sy0;
+                    }
+                }
+                if (tagB != sy1) {
+                    if (sy1 == sy0) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) hB[j] = hA[j];
+                    } else {
+                        hpass(sy1, hB);
+                    }
+                    tagB = sy1;
+                }
+                const unsigned b0 = (Y1r[k] & 0xffffu) << 12, b1 = (Y1r[k] >> 16) << 12; // <= 2^23
+                uint32_t out = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const unsigned v0 = (unsigned)(((unsigned long long)(b0 & 0xffffffu) * (unsigned long long)(hA[j] & 0xffffffu)) >> 32);
+                    const unsigned v1 = (unsigned)(((unsigned long long)(b1 & 0xffffffu) * (unsigned long long)(hB[j] & 0xffffffu)) >> 32);
+                    out |= ((v0 + v1 + 2u) >> 2) << (8 * j);
+                }
+                *(uint32_t *)(dst + (ptrdiff_t)(y0 + k0 + k - PYR_MY) * D.pitch + (xi - PYR_MX)) = out;
+            }
         }
-        *(uint32_t *)(dst + (ptrdiff_t)(y0 + k - PYR_MY) * D.pitch + (xi - PYR_MX)) = out;
     }
 }
 
@@ -1461,8 +1527,20 @@ void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int
 {
     for (int l = 1; l < cfg.nlevels; l++) {
         const int src_words = (cfg.lv[l - 1].w + 3) / 4; // interior pixels of the source row (4-aligned start)
-        dim3 grid((cfg.lv[l].h + 2 * PYR_MY + RS_ROWS - 1) / RS_ROWS, n_images);
-        hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), (size_t)RS_ROWS * 2 * src_words * 4, s, cfg, buf, l, src_words);
+        const int total_rows = cfg.lv[l].h + 2 * PYR_MY;
+        // rows per wave: the largest of 4, 2, 1 whose staged source rows fit 60 KB of LDS (rs_src_rows[i] = source
+        // row span of the worst block of 16 / 8 / 4 output rows, from the host's row table)
+        const int *span = cfg.lv[l].rs_src_rows;
+        if ((size_t)span[0] * src_words * 4 <= 60 * 1024) {
+            dim3 grid((total_rows + 15) / 16, n_images);
+            hipLaunchKernelGGL(pyr_resize_kernel<4>, grid, dim3(256), (size_t)span[0] * src_words * 4, s, cfg, buf, l, src_words, span[0]);
+        } else if ((size_t)span[1] * src_words * 4 <= 60 * 1024) {
+            dim3 grid((total_rows + 7) / 8, n_images);
+            hipLaunchKernelGGL(pyr_resize_kernel<2>, grid, dim3(256), (size_t)span[1] * src_words * 4, s, cfg, buf, l, src_words, span[1]);
+        } else {
+            dim3 grid((total_rows + 3) / 4, n_images);
+            hipLaunchKernelGGL(pyr_resize_kernel<1>, grid, dim3(256), (size_t)span[2] * src_words * 4, s, cfg, buf, l, src_words, span[2]);
+        }
     }
 }
 
