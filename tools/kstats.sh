@@ -9,7 +9,7 @@ import csv, glob, collections, json
 for r in csv.DictReader(open("gpurun_out/kstats.csv")):
     print(r["Name"][:34].ljust(34), r["Calls"], round(float(r["AverageNs"]) / 1e3, 1))
 f = glob.glob("gpurun_out/kst/*/*kernel_trace.csv")[0]
-rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith("pyr_resize")]
+rows = [r for r in csv.DictReader(open(f)) if "pyr_resize" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 acc = collections.defaultdict(list)
 for i, r in enumerate(rows):

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""pmc_FETCH_SIZE.txt + pmc_WRITE_SIZE.txt (tools/pmc_summary.py output) -> traffic json read by bench.py.
+
+usage: make_traffic.py <dir with pmc_FETCH_SIZE.txt, pmc_WRITE_SIZE.txt> <pairs per launch> <out.json>
+Counter values are KB per launch (mean over launches); the pyramid's 7 launches per step are summed.
+"""
+import ast, json, sys
+
+STAGE_OF = {"ingest_kernel": "ingest", "pyr_resize_kernel": "pyramid", "blur_kernel": "blur", "fast_cell_kernel": "fast",
+            "octree": "octree", "describe_kernel": "describe", "stereo_match_kernel": "stereo_match",
+            "stereo_rowtable_kernel": "stereo_match", "stereo_median_kernel": "stereo_median"}
+LAUNCHES = {"pyr_resize_kernel": 7}
+
+
+def read(path, counter):
+    out = {}
+    for line in open(path):
+        if "{" not in line:
+            continue
+        name = line[:line.index("{")].strip()
+        vals = ast.literal_eval(line[line.index("{"):line.rindex("}") + 1])
+        for k, st in STAGE_OF.items():
+            if k in name and "gather" not in name:
+                out[st] = out.get(st, 0.0) + vals[counter] * LAUNCHES.get(k, 1)
+    return out
+
+
+d, pairs, dst = sys.argv[1], float(sys.argv[2]), sys.argv[3]
+f, w = read(d + "/pmc_FETCH_SIZE.txt", "FETCH_SIZE"), read(d + "/pmc_WRITE_SIZE.txt", "WRITE_SIZE")
+json.dump({
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --cpu-pairs 0 "
+              "--no-check; KB per launch averaged over launches, %g pairs per launch" % pairs,
+    "correction": "gfx950: hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, HBM section); narrow access widths are uncalibrated",
+    "kernels": {s: {"fetch_kb_per_pair": f[s] / pairs, "write_kb_per_pair": w.get(s, 0.0) / pairs} for s in sorted(f)},
+}, open(dst, "w"), indent=1)
+print(open(dst).read())
