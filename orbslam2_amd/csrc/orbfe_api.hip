@@ -365,7 +365,7 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
         ctx->cfg.row_idx_cap = c.sel_total * span;
         const size_t pairs = (B + 1) / 2;
         A(b.row_off, pairs * (size_t)(p.height + 1));
-        A(b.row_idx, pairs * (size_t)ctx->cfg.row_idx_cap);
+        A(b.row_ent, pairs * (size_t)ctx->cfg.row_idx_cap);
     }
     {   // cv::resize tables (resize.cpp: xofs/ialpha, yofs/ibeta) over the margin-extended domain of each level
         std::vector<uint32_t> tab;
@@ -626,7 +626,7 @@ static DeviceBuffers shift_buffers(const DeviceBuffers &b, const DeviceConfig &c
     o.kps = (KeyPointPOD *)o.kps + i * c.sel_total; o.desc += i * c.sel_total * 32;
     o.kp_cnt += i; o.status += i;
     o.u_right += i * c.sel_total; o.depth += i * c.sel_total; o.sad += i * c.sel_total;
-    o.row_off += (i / 2) * (size_t)(c.height + 1); o.row_idx += (i / 2) * (size_t)c.row_idx_cap;
+    o.row_off += (i / 2) * (size_t)(c.height + 1); o.row_ent += (i / 2) * (size_t)c.row_idx_cap;
     return o;
 }
 

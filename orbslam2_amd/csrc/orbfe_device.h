@@ -43,7 +43,7 @@ struct DeviceConfig {
     int sel_total;         // per image == keypoint capacity
     int blur_tiles_total;
     int max_nodes;         // quadtree node capacity (LDS)
-    int row_idx_cap;       // entries per pair in DeviceBuffers::row_idx
+    int row_idx_cap;       // entries per pair in DeviceBuffers::row_ent
     int patch_n;           // entries in DeviceBuffers::patch_uv (multiple of 64)
     int umax[64];
     int taps[7];           // Gaussian 8.8 fixed-point taps
@@ -81,7 +81,7 @@ struct DeviceBuffers {
     int *sad;            // [img][sel_total] best SAD (or -1)
     int *status;         // [img] non-zero = device-side capacity problem
     int *row_off;        // [pair][height+1] stereo row table offsets
-    uint16_t *row_idx;   // [pair][row_idx_cap] right-keypoint indices per row
+    uint2 *row_ent;      // [pair][row_idx_cap] stereo row table entries: (iR | octave << 16, x bits)
     const uint32_t *bk_tab; // quadtree bucket tables: per level X[region_w] then Y[region_h] (see ORBFE_BK_*)
     const uint32_t *rs_tab; // cv::resize offset/weight tables of every level (see pyr_resize_kernel)
     long long *dbg_ts;   // 4096 timestamps for kernel bring-up (ORBFE_OT2_STOP=99); never read by product code

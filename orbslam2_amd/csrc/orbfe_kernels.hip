@@ -1230,18 +1230,20 @@ __global__ __launch_bounds__(256) void describe_kernel(DeviceConfig cfg, DeviceB
 // ---------------------------------------------------------------------------
 // Row table of Frame::ComputeStereoMatches (src/Frame.cc:474-491): right keypoint iR is listed in
 // rows floor(y - r) .. ceil(y + r), r = 2 * scale[octave].  One workgroup per pair; LDS row counters.
-__global__ __launch_bounds__(256) void stereo_rowtable_kernel(DeviceConfig cfg, DeviceBuffers buf)
+// An entry carries what the coarse search filters on -- (iR | octave << 16, x) -- so a candidate costs
+// one 8-byte load before its descriptor instead of two dependent hops through the keypoint array.
+__global__ __launch_bounds__(1024) void stereo_rowtable_kernel(DeviceConfig cfg, DeviceBuffers buf)
 {
     extern __shared__ int s_rows[]; // [height + 1]
-    __shared__ int s_scan[256];
+    __shared__ int s_scan[1024];
     const int pair = blockIdx.x, imgR = 2 * pair + 1, tid = threadIdx.x;
     const int nR = buf.kp_cnt[imgR], h = cfg.height;
     const KeyPointPOD *kR = (const KeyPointPOD *)buf.kps + (size_t)imgR * cfg.sel_total;
     int *roff = buf.row_off + (size_t)pair * (h + 1);
-    uint16_t *ridx = buf.row_idx + (size_t)pair * cfg.row_idx_cap;
-    for (int i = tid; i <= h; i += 256) s_rows[i] = 0;
+    uint2 *rent = buf.row_ent + (size_t)pair * cfg.row_idx_cap;
+    for (int i = tid; i <= h; i += 1024) s_rows[i] = 0;
     __syncthreads();
-    for (int i = tid; i < nR; i += 256) {
+    for (int i = tid; i < nR; i += 1024) {
         const float y = kR[i].y;
         const float r = __fmul_rn(2.0f, cfg.lv[kR[i].octave].scale);
         int maxr = (int)ceilf(__fadd_rn(y, r)), minr = (int)floorf(__fsub_rn(y, r));
@@ -1250,33 +1252,58 @@ __global__ __launch_bounds__(256) void stereo_rowtable_kernel(DeviceConfig cfg, 
     }
     __syncthreads();
     block_excl_scan(s_rows, s_rows, h + 1, s_scan);
-    for (int i = tid; i <= h; i += 256) roff[i] = s_rows[i];
+    for (int i = tid; i <= h; i += 1024) roff[i] = s_rows[i];
     __syncthreads();
-    for (int i = tid; i < nR; i += 256) {
-        const float y = kR[i].y;
-        const float r = __fmul_rn(2.0f, cfg.lv[kR[i].octave].scale);
-        int maxr = (int)ceilf(__fadd_rn(y, r)), minr = (int)floorf(__fsub_rn(y, r));
+    for (int i = tid; i < nR; i += 1024) {
+        const KeyPointPOD k = kR[i];
+        const float r = __fmul_rn(2.0f, cfg.lv[k.octave].scale);
+        int maxr = (int)ceilf(__fadd_rn(k.y, r)), minr = (int)floorf(__fsub_rn(k.y, r));
         minr = minr < 0 ? 0 : minr; maxr = maxr > h - 1 ? h - 1 : maxr;
+        const uint2 e = {(uint32_t)i | ((uint32_t)k.octave << 16), __float_as_uint(k.x)};
         for (int yy = minr; yy <= maxr; yy++) {
             const int pos = atomicAdd(&s_rows[yy], 1);
-            if (pos < cfg.row_idx_cap) ridx[pos] = (uint16_t)i;
+            if (pos < cfg.row_idx_cap) rent[pos] = e;
         }
     }
+}
+
+// One 16-lane group per left keypoint (four keypoints per wave, sixteen per workgroup): a row list holds a few
+// dozen candidates of which ~10 pass the octave / disparity filter, so a whole wave per keypoint idles most lanes
+// and, with ~7 dependent global round trips per keypoint, needs 4x the waves to hide the same latency.
+//   coarse search: lanes stride the row list; arg-min key dist << 16 | iR (= the reference's first minimum);
+//   SAD: lane handles window pixels p = gl, gl + 16, .. < 121; the 11 shifted right-image bytes of a pixel are
+//        12 contiguous bytes = three unaligned dword loads; sums reduced over the group by xor shuffles.
+#define SM_G 16
+__device__ __forceinline__ unsigned group_min_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = SM_G / 2; o > 0; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)v, o, 64);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int group_sum_i32(int v)
+{
+#pragma unroll
+    for (int o = SM_G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
 
 __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_pairs, int use_table)
 {
     // XCD-aware block -> (pair, block) map: all blocks of a pair on one XCD (its L2 then holds the pair's
     // descriptors, keypoints and the pyramid rows the SAD windows touch)
-    const int bpp = (cfg.sel_total + 3) / 4;
+    const int kpb = 256 / SM_G;
+    const int bpp = (cfg.sel_total + kpb - 1) / kpb;
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int pair = (jb / bpp) * 8 + xcd;
     if (pair >= n_pairs) return;
     const int imgL = 2 * pair, imgR = 2 * pair + 1;
-    const int lane = threadIdx.x & 63;
-    const int iL = (jb % bpp) * 4 + (threadIdx.x >> 6);
+    const int gl = threadIdx.x & (SM_G - 1);
+    const int iL = (jb % bpp) * kpb + (threadIdx.x / SM_G);
     const int nL = buf.kp_cnt[imgL], nR = buf.kp_cnt[imgR];
-    if (iL >= nL) return;
+    if (iL >= nL) return; // whole group; the groups of a wave only meet in xor shuffles below the group size
     const KeyPointPOD *kL = (const KeyPointPOD *)buf.kps + (size_t)imgL * cfg.sel_total;
     const KeyPointPOD *kR = (const KeyPointPOD *)buf.kps + (size_t)imgR * cfg.sel_total;
     const uint8_t *dL = buf.desc + (size_t)imgL * cfg.sel_total * 32;
@@ -1296,61 +1323,54 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, Dev
 
     uint32_t dl[8];
     {
-        const uint32_t *p = (const uint32_t *)(dL + (size_t)iL * 32);
-#pragma unroll
-        for (int i = 0; i < 8; i++) dl[i] = p[i];
+        const uint4 *p = (const uint4 *)(dL + (size_t)iL * 32);
+        const uint4 lo = p[0], hi = p[1];
+        dl[0] = lo.x; dl[1] = lo.y; dl[2] = lo.z; dl[3] = lo.w; dl[4] = hi.x; dl[5] = hi.y; dl[6] = hi.z; dl[7] = hi.w;
     }
-    unsigned best = 100u << 16; // TH_HIGH
+    unsigned best = (100u << 16) | 0xffffu; // TH_HIGH; the index field only matters below it
+    float best_x = 0.f;
+    auto consider = [&](int iR, int oct, float xr) {
+        if (oct >= level_l - 1 && oct <= level_l + 1 && xr >= min_u && xr <= max_u) {
+            const uint4 *p = (const uint4 *)(dR + (size_t)iR * 32);
+            const uint4 lo = p[0], hi = p[1];
+            const uint32_t dr[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const unsigned key = ((unsigned)hamming256(dl, dr) << 16) | (unsigned)iR;
+            if (key < best) { best = key; best_x = xr; }
+        }
+    };
     if (use_table) {
         // candidates = right keypoints whose row band covers int(vL) (vRowIndices[vL], src/Frame.cc:513);
         // the arg-min key (dist << 16 | iR) makes the result independent of the order inside a row list
         const int *roff = buf.row_off + (size_t)pair * (cfg.height + 1);
-        const uint16_t *ridx = buf.row_idx + (size_t)pair * cfg.row_idx_cap;
+        const uint2 *rent = buf.row_ent + (size_t)pair * cfg.row_idx_cap;
         int beg = 0, end = 0;
         if (row >= 0 && row < cfg.height) { beg = roff[row]; end = roff[row + 1]; }
-        for (int j0 = beg; j0 < end; j0 += 64) {
-            const int j = j0 + lane;
-            if (j < end) {
-                const int iR = ridx[j];
-                const int oct = kR[iR].octave;
-                const float xr = kR[iR].x;
-                if (oct >= level_l - 1 && oct <= level_l + 1 && xr >= min_u && xr <= max_u) {
-                    const uint32_t *p = (const uint32_t *)(dR + (size_t)iR * 32);
-                    uint32_t dr[8];
-#pragma unroll
-                    for (int i = 0; i < 8; i++) dr[i] = p[i];
-                    const unsigned key = ((unsigned)hamming256(dl, dr) << 16) | (unsigned)iR;
-                    best = key < best ? key : best;
-                }
-            }
+        for (int j = beg + gl; j < end; j += SM_G) {
+            const uint2 e = rent[j];
+            consider((int)(e.x & 0xffffu), (int)(e.x >> 16), __uint_as_float(e.y));
         }
     } else {
-        for (int i0 = 0; i0 < nR; i0 += 64) {
-            const int iR = i0 + lane;
-            if (iR < nR) {
-                const KeyPointPOD kr = kR[iR];
-                const float r = __fmul_rn(2.0f, cfg.lv[kr.octave].scale);
-                const int maxr = (int)ceilf(__fadd_rn(kr.y, r));
-                const int minr = (int)floorf(__fsub_rn(kr.y, r));
-                if (row >= minr && row <= maxr && kr.octave >= level_l - 1 && kr.octave <= level_l + 1 &&
-                    kr.x >= min_u && kr.x <= max_u) {
-                    const uint32_t *p = (const uint32_t *)(dR + (size_t)iR * 32);
-                    uint32_t dr[8];
-#pragma unroll
-                    for (int i = 0; i < 8; i++) dr[i] = p[i];
-                    const unsigned key = ((unsigned)hamming256(dl, dr) << 16) | (unsigned)iR;
-                    best = key < best ? key : best;
-                }
-            }
+        for (int iR = gl; iR < nR; iR += SM_G) {
+            const KeyPointPOD kr = kR[iR];
+            const float r = __fmul_rn(2.0f, cfg.lv[kr.octave].scale);
+            const int maxr = (int)ceilf(__fadd_rn(kr.y, r));
+            const int minr = (int)floorf(__fsub_rn(kr.y, r));
+            if (row >= minr && row <= maxr) consider(iR, kr.octave, kr.x);
         }
     }
-    best = wave_min_u32(best);
-    const int best_dist = (int)(best >> 16);
-    const int best_r = (int)(best & 0xffffu);
+    const unsigned gbest = group_min_u32(best);
+    const int best_dist = (int)(gbest >> 16);
+    // x of the winning candidate: held by the lane whose key won (keys are unique per iR)
+    float uR0 = best == gbest ? best_x : 0.f;
+    {
+        int bits = __float_as_int(uR0);
+#pragma unroll
+        for (int o = SM_G / 2; o > 0; o >>= 1) bits |= __shfl_xor(bits, o, 64); // one lane holds it, the others 0
+        uR0 = __int_as_float(bits);
+    }
     float out_u = -1.0f, out_d = -1.0f;
     int out_sad = -1;
     if (best_dist < 75) { // (TH_HIGH + TH_LOW) / 2
-        const float uR0 = kR[best_r].x;
         const float sf = cfg.lv[level_l].inv_scale;
         const float s_uL = roundf(__fmul_rn(kp.x, sf));
         const float s_vL = roundf(__fmul_rn(kp.y, sf));
@@ -1366,26 +1386,34 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, Dev
         if (in_ref && safe) {
             const uint8_t *imL = buf.pyr + (size_t)imgL * cfg.pyr_bytes + L.pyr_off;
             const uint8_t *imR = buf.pyr + (size_t)imgR * cfg.pyr_bytes + L.pyr_off;
-            const int lc = imL[(size_t)cv * L.pitch + cu];
-            // two window pixels per lane: p = lane, lane + 64 (< 121)
-            int a0 = 0, a1 = 0, dy0 = 0, dx0 = 0, dy1 = 0, dx1 = 0;
-            const bool has1 = lane + 64 < 121;
-            dy0 = lane / 11 - 5; dx0 = lane % 11 - 5;
-            a0 = (int)imL[(size_t)(cv + dy0) * L.pitch + cu + dx0] - lc;
-            if (has1) {
-                dy1 = (lane + 64) / 11 - 5; dx1 = (lane + 64) % 11 - 5;
-                a1 = (int)imL[(size_t)(cv + dy1) * L.pitch + cu + dx1] - lc;
-            }
+            const int lc = imL[__mul24(cv, L.pitch) + cu];
+            // centre row of the right image: bytes cr-5 .. cr+5 (+1 spare) = rc of the 11 shifts
+            uint32_t rcw[3];
+            __builtin_memcpy(rcw, imR + __mul24(cv, L.pitch) + cr - 5, 12);
             int dists[11];
+#pragma unroll
+            for (int t = 0; t < 11; t++) dists[t] = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int p = gl + SM_G * t;
+                if (p < 121) {
+                    const int py = (p * 745) >> 13, dy = py - 5, dx = p - py * 11 - 5; // p / 11 for p < 128
+                    const int a = (int)imL[__mul24(cv + dy, L.pitch) + cu + dx] - lc;
+                    uint32_t w[3];
+                    __builtin_memcpy(w, imR + __mul24(cv + dy, L.pitch) + cr + dx - 5, 12);
+#pragma unroll
+                    for (int i = 0; i < 11; i++) {
+                        const int rb = (int)((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+                        const int rc = (int)((rcw[i >> 2] >> (8 * (i & 3))) & 0xffu);
+                        dists[i] += abs(a - (rb - rc));
+                    }
+                }
+            }
             int sad_best = 0x7fffffff, best_inc = 0;
 #pragma unroll
-            for (int inc = -5; inc <= 5; inc++) {
-                const int rc = imR[(size_t)cv * L.pitch + cr + inc];
-                int s = abs(a0 - ((int)imR[(size_t)(cv + dy0) * L.pitch + cr + inc + dx0] - rc));
-                if (has1) s += abs(a1 - ((int)imR[(size_t)(cv + dy1) * L.pitch + cr + inc + dx1] - rc));
-                s = wave_sum_i32(s);
-                dists[inc + 5] = s;
-                if (s < sad_best) { sad_best = s; best_inc = inc; }
+            for (int i = 0; i < 11; i++) {
+                dists[i] = group_sum_i32(dists[i]);
+                if (dists[i] < sad_best) { sad_best = dists[i]; best_inc = i - 5; }
             }
             out_sad = -2 - sad_best; // coarse match without an accepted disparity (debug tap): negative
             if (best_inc != -5 && best_inc != 5) {
@@ -1410,7 +1438,7 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, Dev
             }
         }
     }
-    if (lane == 0) {
+    if (gl == 0) {
         u_right[iL] = out_u;
         depth[iL] = out_d;
         sad_out[iL] = out_sad;
@@ -1609,8 +1637,9 @@ void orbfe_launch_stereo_match(const DeviceConfig &cfg, const DeviceBuffers &buf
     // the LDS row table needs (height + 1) counters; taller images use the brute-force band scan
     const int use_table = (size_t)(cfg.height + 1) * sizeof(int) <= 48 * 1024 ? 1 : 0;
     if (use_table)
-        hipLaunchKernelGGL(stereo_rowtable_kernel, dim3(n_pairs), dim3(256), (cfg.height + 1) * sizeof(int), s, cfg, buf);
-    dim3 grid(((cfg.sel_total + 3) / 4) * ((n_pairs + 7) / 8) * 8);
+        hipLaunchKernelGGL(stereo_rowtable_kernel, dim3(n_pairs), dim3(1024), (cfg.height + 1) * sizeof(int), s, cfg, buf);
+    const int kpb = 256 / SM_G;
+    dim3 grid(((cfg.sel_total + kpb - 1) / kpb) * ((n_pairs + 7) / 8) * 8);
     hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(256), 0, s, cfg, buf, n_pairs, use_table);
 }
 
