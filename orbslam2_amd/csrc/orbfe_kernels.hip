@@ -1450,41 +1450,46 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, Dev
 // found by a 3-level radix select (8 bits per level, LDS histograms) instead of a sort.
 __global__ __launch_bounds__(256) void stereo_median_kernel(DeviceConfig cfg, DeviceBuffers buf)
 {
+    extern __shared__ int s_vals[]; // [sel_total] the pair's SADs, read from HBM once
     __shared__ int s_hist[256];
     __shared__ int s_sel[3]; // selected digit, rank inside the digit's bucket, count of valid entries
     const int pair = blockIdx.x;
     const int imgL = 2 * pair;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int nL = buf.kp_cnt[imgL];
     float *u_right = buf.u_right + (size_t)imgL * cfg.sel_total;
     float *depth = buf.depth + (size_t)imgL * cfg.sel_total;
     const int *sad = buf.sad + (size_t)imgL * cfg.sel_total;
+    for (int i = tid; i < nL; i += 256) s_vals[i] = sad[i];
     unsigned prefix = 0, mask = 0;
-    int rank = 0;
     for (int shift = 16; shift >= 0; shift -= 8) { // SAD < 2^24 (121 px * 510)
         s_hist[tid] = 0;
         __syncthreads();
         for (int i = tid; i < nL; i += 256) {
-            const int v = sad[i];
+            const int v = s_vals[i];
             if (v >= 0 && ((unsigned)v & mask) == prefix) atomicAdd(&s_hist[((unsigned)v >> shift) & 255u], 1);
         }
         __syncthreads();
-        if (tid == 0) {
-            if (shift == 16) {
-                int m = 0;
-                for (int d = 0; d < 256; d++) m += s_hist[d];
-                s_sel[2] = m;
-                rank = m / 2; // vDistIdx[size/2] in ascending order
-            } else {
-                rank = s_sel[1];
+        if (tid < 64) { // digit that holds the wanted rank: lane = 4 bins, wave scan, owner lane resolves its bins
+            const int h0 = s_hist[4 * lane], h1 = s_hist[4 * lane + 1], h2 = s_hist[4 * lane + 2], h3 = s_hist[4 * lane + 3];
+            const int sum = h0 + h1 + h2 + h3;
+            int inc = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += t;
             }
-            int d = 0;
-            for (; d < 255; d++) {
-                if (rank < s_hist[d]) break;
-                rank -= s_hist[d];
+            const int total = __shfl(inc, 63, 64);
+            if (shift == 16 && lane == 0) s_sel[2] = total;
+            // vDistIdx[size/2] in ascending order; later digits continue with the rank left inside the chosen bucket
+            const int rank = shift == 16 ? total / 2 : s_sel[1];
+            const int before = inc - sum;
+            if (total > 0 && rank >= before && rank < inc) {
+                int r = rank - before, d = 4 * lane;
+                if (r >= h0) { r -= h0; d++; if (r >= h1) { r -= h1; d++; if (r >= h2) { r -= h2; d++; } } }
+                s_sel[0] = d;
+                s_sel[1] = r;
             }
-            s_sel[0] = d;
-            s_sel[1] = rank;
         }
         __syncthreads();
         if (s_sel[2] == 0) return;
@@ -1495,7 +1500,7 @@ __global__ __launch_bounds__(256) void stereo_median_kernel(DeviceConfig cfg, De
     const float median = (float)(int)prefix;
     const float th_dist = __fmul_rn(__fmul_rn(1.5f, 1.4f), median);
     for (int i = tid; i < nL; i += 256) {
-        const int v = sad[i];
+        const int v = s_vals[i];
         if (v >= 0 && !((float)v < th_dist)) { u_right[i] = -1.0f; depth[i] = -1.0f; }
     }
 }
@@ -1645,7 +1650,7 @@ void orbfe_launch_stereo_match(const DeviceConfig &cfg, const DeviceBuffers &buf
 
 void orbfe_launch_stereo_median(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s)
 {
-    hipLaunchKernelGGL(stereo_median_kernel, dim3(n_pairs), dim3(256), 0, s, cfg, buf);
+    hipLaunchKernelGGL(stereo_median_kernel, dim3(n_pairs), dim3(256), (size_t)cfg.sel_total * sizeof(int), s, cfg, buf);
 }
 
 void orbfe_launch_rgbd(const DeviceConfig &cfg, const DeviceBuffers &buf, const float *d_depth, size_t depth_pitch_floats,
