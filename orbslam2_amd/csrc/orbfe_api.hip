@@ -360,12 +360,16 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
     A(ctx->d_in, B * (size_t)p.width * p.height);
     A(b.dbg_ts, 4096);
     hipMemset(b.dbg_ts, 0, 4096 * sizeof(long long));
-    {   // stereo row table: a right keypoint spans at most 2*r+3 rows, r = 2*scale[top level]
-        const int span = (int)(2.0f * 2.0f * ctx->scale[p.nlevels - 1]) + 3;
-        ctx->cfg.row_idx_cap = c.sel_total * span;
+    {   // stereo row lists (vRowIndices, src/Frame.cc:474-491): fixed capacity per row, ~4x the mean occupancy
+        // (a right keypoint is listed in ~2 * 2 * scale + 1 rows); a fuller row makes stereo_match_kernel scan all keypoints
+        int cap = (int)(4.0 * c.sel_total * 10.0 / p.height);
+        cap = cap < 64 ? 64 : cap;
+        cap = cap > c.sel_total ? c.sel_total : cap;
+        ctx->cfg.row_cap = cap;
         const size_t pairs = (B + 1) / 2;
-        A(b.row_off, pairs * (size_t)(p.height + 1));
-        A(b.row_ent, pairs * (size_t)ctx->cfg.row_idx_cap);
+        A(b.row_cnt, pairs * (size_t)p.height);
+        A(b.row_ent, pairs * (size_t)p.height * cap);
+        hipMemset(b.row_cnt, 0, pairs * (size_t)p.height * sizeof(int));
     }
     {   // cv::resize tables (resize.cpp: xofs/ialpha, yofs/ibeta) over the margin-extended domain of each level
         std::vector<uint32_t> tab;
@@ -626,7 +630,7 @@ static DeviceBuffers shift_buffers(const DeviceBuffers &b, const DeviceConfig &c
     o.kps = (KeyPointPOD *)o.kps + i * c.sel_total; o.desc += i * c.sel_total * 32;
     o.kp_cnt += i; o.status += i;
     o.u_right += i * c.sel_total; o.depth += i * c.sel_total; o.sad += i * c.sel_total;
-    o.row_off += (i / 2) * (size_t)(c.height + 1); o.row_ent += (i / 2) * (size_t)c.row_idx_cap;
+    o.row_cnt += (i / 2) * (size_t)c.height; o.row_ent += (i / 2) * (size_t)c.height * c.row_cap;
     return o;
 }
 
@@ -649,7 +653,7 @@ static void run_chain(orbfe_context *ctx, const uint8_t *d_images, int img0, int
     else if (ctx->use_octree2) orbfe_launch_octree2(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot2_lds_pts, ctx->ot2_lds, s);
     else orbfe_launch_octree_generic(cfg, buf, n_images, s);
     prof_mark(ctx, group, 5, s);
-    orbfe_launch_describe(cfg, buf, n_images, s);
+    orbfe_launch_describe(cfg, buf, n_images, n_pairs > 0, s);
     prof_mark(ctx, group, 6, s);
     if (n_pairs > 0) {
         orbfe_launch_stereo_match(cfg, buf, n_pairs, s);

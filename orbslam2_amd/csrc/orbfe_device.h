@@ -43,7 +43,7 @@ struct DeviceConfig {
     int sel_total;         // per image == keypoint capacity
     int blur_tiles_total;
     int max_nodes;         // quadtree node capacity (LDS)
-    int row_idx_cap;       // entries per pair in DeviceBuffers::row_ent
+    int row_cap;           // entries per image row in DeviceBuffers::row_ent
     int patch_n;           // entries in DeviceBuffers::patch_uv (multiple of 64)
     int umax[64];
     int taps[7];           // Gaussian 8.8 fixed-point taps
@@ -80,8 +80,8 @@ struct DeviceBuffers {
     float *depth;        // [img][sel_total]
     int *sad;            // [img][sel_total] best SAD (or -1)
     int *status;         // [img] non-zero = device-side capacity problem
-    int *row_off;        // [pair][height+1] stereo row table offsets
-    uint2 *row_ent;      // [pair][row_idx_cap] stereo row table entries: (iR | octave << 16, x bits)
+    int *row_cnt;        // [pair][height] stereo row lists: right keypoints whose band covers the row (cleared by ingest)
+    uint2 *row_ent;      // [pair][height][row_cap] entries: (iR | octave << 16, x bits), appended by describe_kernel
     const uint32_t *bk_tab; // quadtree bucket tables: per level X[region_w] then Y[region_h] (see ORBFE_BK_*)
     const uint32_t *rs_tab; // cv::resize offset/weight tables of every level (see pyr_resize_kernel)
     long long *dbg_ts;   // 4096 timestamps for kernel bring-up (ORBFE_OT2_STOP=99); never read by product code
@@ -121,7 +121,7 @@ void orbfe_launch_octree3(const DeviceConfig &cfg, const DeviceBuffers &buf, int
 void orbfe_launch_candidates_gather(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
 size_t orbfe_octree3_lds_bytes(int max_nodes, int sort_cap);
 int orbfe_octree3_prepare(size_t lds);
-void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
+void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool stereo, hipStream_t s);
 void orbfe_launch_stereo_match(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s);
 void orbfe_launch_stereo_median(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s);
 void orbfe_launch_rgbd(const DeviceConfig &cfg, const DeviceBuffers &buf, const float *d_depth,

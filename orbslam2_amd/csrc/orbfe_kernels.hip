@@ -168,7 +168,11 @@ __global__ __launch_bounds__(256) void ingest_kernel(DeviceConfig cfg, DeviceBuf
 {
     const int img = blockIdx.z;
     const LevelInfo &L = cfg.lv[0];
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) buf.status[img] = 0;
+    if (blockIdx.x == 0 && blockIdx.y == 0) { // first kernel of every chain: clear the image's status word and, for a right image, its pair's stereo row counters
+        if (threadIdx.x == 0) buf.status[img] = 0;
+        if (img & 1)
+            for (int i = threadIdx.x; i < cfg.height; i += 256) buf.row_cnt[(size_t)(img >> 1) * cfg.height + i] = 0;
+    }
     const int y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6)) - PYR_MY;
     const int x0 = (int)(blockIdx.x * 64 + (threadIdx.x & 63)) * 4 - PYR_MX;
     if (x0 >= L.w + 8 || y >= L.h + PYR_MY) return;
@@ -1052,7 +1056,7 @@ __global__ __launch_bounds__(OT_THREADS) void octree_generic_kernel(DeviceConfig
 #define DS_BLR_REGS 6 // 37 rows * 10 words = 370 words
 
 
-__global__ __launch_bounds__(256) void describe_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int dbg)
+__global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int stereo, int dbg)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dm[];
     // XCD-aware block -> (image, block) map: workgroups are dealt round-robin over the 8 XCDs, so block
@@ -1140,6 +1144,8 @@ __global__ __launch_bounds__(256) void describe_kernel(DeviceConfig cfg, DeviceB
         return true;
     };
 
+    int rl_lv = -1;          // lane i < DS_KPW: level | index << 8 of the wave's i-th keypoint (-1: none), its x and y
+    float rl_x = 0.f, rl_y = 0.f;
     bool have = prefetch(0);
     for (int i = 0; i < DS_KPW; i++) {
         const bool cur = have;
@@ -1210,10 +1216,11 @@ __global__ __launch_bounds__(256) void describe_kernel(DeviceConfig cfg, DeviceB
             bits[r] = __ballot(t0 < t1);
         }
         if (lane < 4) dout[lane] = lane == 0 ? bits[0] : (lane == 1 ? bits[1] : (lane == 2 ? bits[2] : bits[3]));
+        float px = (float)kx, py = (float)ky;
+        if (lv != 0) { px = __fmul_rn(px, L.scale); py = __fmul_rn(py, L.scale); }
+        if (lane == i) { rl_lv = lv | (kout << 8); rl_x = px; rl_y = py; } // for the stereo row lists below
         if (lane == 0) {
             KeyPointPOD kp;
-            float px = (float)kx, py = (float)ky;
-            if (lv != 0) { px = __fmul_rn(px, L.scale); py = __fmul_rn(py, L.scale); }
             kp.x = px; kp.y = py;
             kp.size = (float)L.scaled_patch;
             kp.angle = angle;
@@ -1223,50 +1230,42 @@ __global__ __launch_bounds__(256) void describe_kernel(DeviceConfig cfg, DeviceB
             ((KeyPointPOD *)buf.kps)[(size_t)img * cfg.sel_total + kout] = kp;
         }
     }
+    if (stereo && (img & 1)) {
+        // right image of a pair: list each keypoint in the rows its band covers (vRowIndices, src/Frame.cc:474-491: rows
+        // floor(y - r) .. ceil(y + r), r = 2 * scale[octave]); the order inside a row list is irrelevant to
+        // stereo_match_kernel's arg-min.  All of the wave's atomics are issued before the first dependent store.
+        int *rcnt = buf.row_cnt + (size_t)(img >> 1) * cfg.height;
+        uint2 *rent = buf.row_ent + (size_t)(img >> 1) * cfg.height * cfg.row_cap;
+        int pos[DS_KPW], yy[DS_KPW];
+        uint2 e[DS_KPW];
+#pragma unroll
+        for (int i = 0; i < DS_KPW; i++) {
+            const int lvk = __builtin_amdgcn_readlane(rl_lv, i);
+            const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rl_x), i));
+            const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rl_y), i));
+            pos[i] = -1; yy[i] = 0;
+            e[i].x = (uint32_t)(lvk >> 8) | ((uint32_t)(lvk & 255) << 16); e[i].y = __float_as_uint(x);
+            if (lvk >= 0) {
+                const float r = __fmul_rn(2.0f, cfg.lv[lvk & 255].scale);
+                int maxr = (int)ceilf(__fadd_rn(y, r)), minr = (int)floorf(__fsub_rn(y, r));
+                minr = minr < 0 ? 0 : minr; maxr = maxr > cfg.height - 1 ? cfg.height - 1 : maxr;
+                yy[i] = minr + lane;
+                if (yy[i] <= maxr) pos[i] = atomicAdd(&rcnt[yy[i]], 1);
+                for (int y2 = yy[i] + 64; y2 <= maxr; y2 += 64) { // bands taller than a wave (large scale factors only)
+                    const int p2 = atomicAdd(&rcnt[y2], 1);
+                    if (p2 < cfg.row_cap) rent[(size_t)y2 * cfg.row_cap + p2] = e[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < DS_KPW; i++)
+            if (pos[i] >= 0 && pos[i] < cfg.row_cap) rent[(size_t)yy[i] * cfg.row_cap + pos[i]] = e[i];
+    }
 }
 
 // ---------------------------------------------------------------------------
 // stereo: one wave per left keypoint (coarse Hamming band search + SAD + parabola)
 // ---------------------------------------------------------------------------
-// Row table of Frame::ComputeStereoMatches (src/Frame.cc:474-491): right keypoint iR is listed in
-// rows floor(y - r) .. ceil(y + r), r = 2 * scale[octave].  One workgroup per pair; LDS row counters.
-// An entry carries what the coarse search filters on -- (iR | octave << 16, x) -- so a candidate costs
-// one 8-byte load before its descriptor instead of two dependent hops through the keypoint array.
-__global__ __launch_bounds__(1024) void stereo_rowtable_kernel(DeviceConfig cfg, DeviceBuffers buf)
-{
-    extern __shared__ int s_rows[]; // [height + 1]
-    __shared__ int s_scan[1024];
-    const int pair = blockIdx.x, imgR = 2 * pair + 1, tid = threadIdx.x;
-    const int nR = buf.kp_cnt[imgR], h = cfg.height;
-    const KeyPointPOD *kR = (const KeyPointPOD *)buf.kps + (size_t)imgR * cfg.sel_total;
-    int *roff = buf.row_off + (size_t)pair * (h + 1);
-    uint2 *rent = buf.row_ent + (size_t)pair * cfg.row_idx_cap;
-    for (int i = tid; i <= h; i += 1024) s_rows[i] = 0;
-    __syncthreads();
-    for (int i = tid; i < nR; i += 1024) {
-        const float y = kR[i].y;
-        const float r = __fmul_rn(2.0f, cfg.lv[kR[i].octave].scale);
-        int maxr = (int)ceilf(__fadd_rn(y, r)), minr = (int)floorf(__fsub_rn(y, r));
-        minr = minr < 0 ? 0 : minr; maxr = maxr > h - 1 ? h - 1 : maxr;
-        for (int yy = minr; yy <= maxr; yy++) atomicAdd(&s_rows[yy], 1);
-    }
-    __syncthreads();
-    block_excl_scan(s_rows, s_rows, h + 1, s_scan);
-    for (int i = tid; i <= h; i += 1024) roff[i] = s_rows[i];
-    __syncthreads();
-    for (int i = tid; i < nR; i += 1024) {
-        const KeyPointPOD k = kR[i];
-        const float r = __fmul_rn(2.0f, cfg.lv[k.octave].scale);
-        int maxr = (int)ceilf(__fadd_rn(k.y, r)), minr = (int)floorf(__fsub_rn(k.y, r));
-        minr = minr < 0 ? 0 : minr; maxr = maxr > h - 1 ? h - 1 : maxr;
-        const uint2 e = {(uint32_t)i | ((uint32_t)k.octave << 16), __float_as_uint(k.x)};
-        for (int yy = minr; yy <= maxr; yy++) {
-            const int pos = atomicAdd(&s_rows[yy], 1);
-            if (pos < cfg.row_idx_cap) rent[pos] = e;
-        }
-    }
-}
-
 // One 16-lane group per left keypoint (four keypoints per wave, sixteen per workgroup): a row list holds a few
 // dozen candidates of which ~10 pass the octave / disparity filter, so a whole wave per keypoint idles most lanes
 // and, with ~7 dependent global round trips per keypoint, needs 4x the waves to hide the same latency.
@@ -1290,7 +1289,7 @@ __device__ __forceinline__ int group_sum_i32(int v)
     return v;
 }
 
-__global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_pairs, int use_table)
+__global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_pairs)
 {
     // XCD-aware block -> (pair, block) map: all blocks of a pair on one XCD (its L2 then holds the pair's
     // descriptors, keypoints and the pyramid rows the SAD windows touch)
@@ -1338,18 +1337,17 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, Dev
             if (key < best) { best = key; best_x = xr; }
         }
     };
-    if (use_table) {
-        // candidates = right keypoints whose row band covers int(vL) (vRowIndices[vL], src/Frame.cc:513);
-        // the arg-min key (dist << 16 | iR) makes the result independent of the order inside a row list
-        const int *roff = buf.row_off + (size_t)pair * (cfg.height + 1);
-        const uint2 *rent = buf.row_ent + (size_t)pair * cfg.row_idx_cap;
-        int beg = 0, end = 0;
-        if (row >= 0 && row < cfg.height) { beg = roff[row]; end = roff[row + 1]; }
-        for (int j = beg + gl; j < end; j += SM_G) {
+    // candidates = right keypoints whose row band covers int(vL) (vRowIndices[vL], src/Frame.cc:513), listed per row by
+    // describe_kernel; the arg-min key (dist << 16 | iR) makes the result independent of the order inside a row list
+    int cnt = 0;
+    if (row >= 0 && row < cfg.height) cnt = buf.row_cnt[(size_t)pair * cfg.height + row];
+    if (cnt <= cfg.row_cap) {
+        const uint2 *rent = buf.row_ent + ((size_t)pair * cfg.height + row) * cfg.row_cap;
+        for (int j = gl; j < cnt; j += SM_G) {
             const uint2 e = rent[j];
             consider((int)(e.x & 0xffffu), (int)(e.x >> 16), __uint_as_float(e.y));
         }
-    } else {
+    } else { // the row's list overflowed its capacity: test every right keypoint's band
         for (int iR = gl; iR < nR; iR += SM_G) {
             const KeyPointPOD kr = kR[iR];
             const float r = __fmul_rn(2.0f, cfg.lv[kr.octave].scale);
@@ -1629,25 +1627,20 @@ void orbfe_launch_octree_generic(const DeviceConfig &cfg, const DeviceBuffers &b
     hipLaunchKernelGGL(octree_generic_kernel, grid, dim3(OT_THREADS), orbfe_octree_lds_bytes(cfg), s, cfg, buf, ot_sort_cap(cfg));
 }
 
-void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
+void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool stereo, hipStream_t s)
 {
     dim3 grid(((cfg.sel_total + 4 * DS_KPW - 1) / (4 * DS_KPW)) * ((n_images + 7) / 8) * 8);
     const size_t lds = ((cfg.patch_n * 2 + 15) & ~15) + 256 * 4 + (size_t)4 * (2 * cfg.half_patch + 1 + 37) * DS_PATCH_W;
     static const int dbg = getenv("ORBFE_DESC_DBG") ? atoi(getenv("ORBFE_DESC_DBG")) : 0; // profiling aid only
-    hipLaunchKernelGGL(describe_kernel, grid, dim3(256), lds, s, cfg, buf, n_images, dbg);
+    hipLaunchKernelGGL(describe_kernel, grid, dim3(256), lds, s, cfg, buf, n_images, stereo ? 1 : 0, dbg);
 }
 
 void orbfe_launch_stereo_match(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s)
 {
-    // the LDS row table needs (height + 1) counters; taller images use the brute-force band scan
-    const int use_table = (size_t)(cfg.height + 1) * sizeof(int) <= 48 * 1024 ? 1 : 0;
-    if (use_table)
-        hipLaunchKernelGGL(stereo_rowtable_kernel, dim3(n_pairs), dim3(1024), (cfg.height + 1) * sizeof(int), s, cfg, buf);
     const int kpb = 256 / SM_G;
     dim3 grid(((cfg.sel_total + kpb - 1) / kpb) * ((n_pairs + 7) / 8) * 8);
-    hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(256), 0, s, cfg, buf, n_pairs, use_table);
+    hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(256), 0, s, cfg, buf, n_pairs);
 }
-
 void orbfe_launch_stereo_median(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s)
 {
     hipLaunchKernelGGL(stereo_median_kernel, dim3(n_pairs), dim3(256), (size_t)cfg.sel_total * sizeof(int), s, cfg, buf);

@@ -102,3 +102,30 @@ def test_point_parallel_quadtree_kernel_still_matches(monkeypatch):
     kr, dr = ex.extract(left)
     assert np.array_equal(k, kr.astype(api.KP_DTYPE)) and np.array_equal(d, dr)
     assert np.array_equal(k1, kr.astype(api.KP_DTYPE)) and np.array_equal(d1, dr)
+
+
+def test_stereo_row_list_overflow():
+    """All keypoints inside a thin horizontal band: the per-row candidate lists exceed their fixed capacity and the
+    stereo search must fall back to scanning every right keypoint -- same matches as the oracle."""
+    from orbslam2_amd import api
+    w, h, nf = 1241, 376, 2000
+    rng = np.random.default_rng(7)
+    tex = rng.integers(0, 256, (44, w + 40)).astype(np.uint8)
+    left = np.full((h, w), 120, np.uint8); right = left.copy()
+    left[160:204, :] = tex[:, 40:40 + w]
+    right[160:204, :] = tex[:, 28:28 + w]  # 12 px disparity
+    fx, bf = 718.856, 386.1448
+    ctx = api.Context(width=w, height=h, nfeatures=nf, fx=fx, fy=fx, cx=607.0, cy=185.0, bf=bf)
+    out = ctx.stereo_frame(left, right)
+    exl, exr = O.Extractor(nfeatures=nf), O.Extractor(nfeatures=nf)
+    kl, dl = exl.extract(left); kr, dr = exr.extract(right)
+    ur, dp, m = O.stereo_matches(exl, exr, kl, dl, kr, dr, bf, fx)
+    rows = np.zeros(h, int)
+    for k in kr:
+        r = 2.0 * 1.2 ** int(k["octave"])
+        rows[max(0, int(np.floor(k["y"] - r))):min(h - 1, int(np.ceil(k["y"] + r))) + 1] += 1
+    assert rows.max() > 4 * len(kr) * 10 // h  # the capacity formula of orbfe_create
+    assert m > 100
+    assert np.array_equal(out["kps_right"], kr.astype(api.KP_DTYPE))
+    assert np.array_equal(out["u_right"], ur) and np.array_equal(out["depth"], dp)
+    ctx.close()
