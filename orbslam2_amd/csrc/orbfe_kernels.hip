@@ -217,6 +217,19 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(DeviceConfig cfg, Devic
     const int total_rows = D.h + 2 * PYR_MY;
     const int nrows = (total_rows - y0) < 4 * RW ? (total_rows - y0) : 4 * RW;
     const int row_bytes = src_words * 4;
+    // table entries this wave needs after the barrier, requested now so that their latency overlaps the staging:
+    // the vertical entries of its rows (uniform) and the column entries of its first pass
+    const int nwords = (D.w + 12 + 3) >> 2; // extended row in 4-px words
+    const int k0 = wave * RW;
+    uint32_t Y0r[RW], Y1r[RW];
+#pragma unroll
+    for (int k = 0; k < RW; k++) {
+        const int yy = y0 + (k0 + k < nrows ? k0 + k : nrows - 1);
+        Y0r[k] = yt[yy]; Y1r[k] = yt[D.rs_ytab_n + yy];
+    }
+    const int xi_first = (lane < nwords ? lane : 0) * 4;
+    uint4 X0 = *(const uint4 *)(xt + xi_first);
+    uint4 X1 = *(const uint4 *)(xt + D.rs_xtab_n + xi_first);
     // source row range of the block (every wave computes it: lanes < nrows hold one output row each)
     const uint32_t Yl = yt[y0 + (lane < nrows ? lane : 0)];
     int smin = (int)(Yl & 0xffffu), smax = (int)(Yl >> 16);
@@ -250,20 +263,13 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(DeviceConfig cfg, Devic
         }
     }
     __syncthreads();
-    const int nwords = (D.w + 12 + 3) >> 2; // extended row in 4-px words
-    const int k0 = wave * RW;
     if (k0 >= nrows) return;
-    // per-row vertical table entries of this wave's rows (uniform)
-    uint32_t Y0r[RW], Y1r[RW];
-#pragma unroll
-    for (int k = 0; k < RW; k++) {
-        const int yy = y0 + (k0 + k < nrows ? k0 + k : nrows - 1);
-        Y0r[k] = yt[yy]; Y1r[k] = yt[D.rs_ytab_n + yy];
-    }
     for (int xw = lane; xw < nwords; xw += 64) {
         const int xi = xw * 4;
-        const uint4 X0 = *(const uint4 *)(xt + xi);
-        const uint4 X1 = *(const uint4 *)(xt + D.rs_xtab_n + xi);
+        if (xw != lane) {
+            X0 = *(const uint4 *)(xt + xi);
+            X1 = *(const uint4 *)(xt + D.rs_xtab_n + xi);
+        }
         const uint32_t x0v[4] = {X0.x, X0.y, X0.z, X0.w}, x1v[4] = {X1.x, X1.y, X1.z, X1.w};
         int tagA = -1, tagB = -1;          // source rows held in hA / hB
         unsigned hA[4], hB[4];             // (S[sx] * a0 + S[sx1] * a1) & ~15
