@@ -444,25 +444,33 @@ template <int P> __device__ __forceinline__ pk16 row_pair(const unsigned (&w)[3]
 // into the immediate offset field of the LDS instructions instead of costing address VALU.
 // BK: also accumulate the quadtree bucket counts / best keys of the survivors (orbfe_octree3.hip) -- aggregated per
 // cell in LDS, then a few global atomics per cell.
+// the waves of a workgroup are independent; a wave's own LDS traffic only needs its outstanding LDS operations retired
+#define FAST_WAVE_SYNC() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); } while (0)
 template <int TP, bool BK>
-__global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int tile_pitch_rt, int tile_bytes, int sc_bytes, int q_bytes, int dbg)
+__global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int tile_pitch_rt, int tile_bytes, int sc_bytes, int q_bytes, int lds_per_wave, int dbg)
 {
     const int tile_pitch = TP ? TP : tile_pitch_rt;
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_mem_all[];
     // XCD-aware block -> (image, cell) map (same scheme as describe_kernel): consecutive cells of one image run
     // on one XCD, so the 128-B lines that horizontally / vertically adjacent cell tiles share (a 37-row tile
     // uses ~44 B of each line) are served by that XCD's L2 instead of being re-fetched from HBM by 8 XCDs.
+    // A workgroup is four independent waves = four consecutive cells (no workgroup barriers: FAST_WAVE_SYNC): horizontally
+    // adjacent cells share the 128-B lines of their tile rows, and on one CU those lines are fetched from L2 once.
+    const int bpi = (cfg.cells_total + 3) >> 2;
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int img = (jb / cfg.cells_total) * 8 + xcd;
+    const int img = (jb / bpi) * 8 + xcd;
     if (img >= n_images) return;
-    const int cell = jb % cfg.cells_total;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int cell = (jb % bpi) * 4 + wave;
+    if (cell >= cfg.cells_total) return;
+    uint8_t *s_mem = s_mem_all + wave * lds_per_wave;
     int level = 0;
     for (int l = 1; l < cfg.nlevels; l++)
         if (cell >= cfg.lv[l].cell_off) level = l;
     const LevelInfo &L = cfg.lv[level];
     const int ci = cell - L.cell_off;
     const int ci_i = ci / L.n_cols, ci_j = ci - ci_i * L.n_cols;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int *cnt_out = buf.cell_cnt + (size_t)img * cfg.cells_total + cell;
 
@@ -512,23 +520,23 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
         int r = (int)(((float)lane + 0.5f) * (1.0f / (float)wpr)), c = lane - r * wpr;
         const int dr = 64 / wpr, dc = 64 - dr * wpr;
         const int nw = th * wpr;
-        for (int i0 = lane; i0 < nw; i0 += 256) { // 4 loads in flight per lane
-            uint32_t v[4];
-            int dst[4];
+        for (int i0 = lane; i0 < nw; i0 += 512) { // 8 loads in flight per lane: a typical 37-row tile is one round trip
+            uint32_t v[8];
+            int dst[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 8; u++) {
                 dst[u] = __mul24(r, tile_pitch) + 4 * c;
                 if (i0 + 64 * u < nw) v[u] = *(const uint32_t *)(src + (unsigned)(__mul24(r, L.pitch) + 4 * c));
                 c += dc; r += dr;
                 if (c >= wpr) { c -= wpr; r++; }
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++)
+            for (int u = 0; u < 8; u++)
                 if (i0 + 64 * u < nw) *(uint32_t *)(s_tile + dst[u]) = v[u];
         }
     }
     for (int i = lane; i < sc_bytes / 4; i += 64) ((uint32_t *)s_sc)[i] = 0;
-    __syncthreads();
+    FAST_WAVE_SYNC();
     const int t = cfg.min_th;
     if (dbg == 1) { if (lane == 0) *cnt_out = 0; return; }
     // Phases A and C work on TWO pixels per lane, one in each 16-bit half of a register, with packed
@@ -612,7 +620,7 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
             if (jg >= ng) { jg -= ng; rg++; }
         }
     }
-    __syncthreads();
+    FAST_WAVE_SYNC();
     if (dbg == 3) { if (lane == 0) *cnt_out = 0; return; }
     // ---- C: exact score for the entry's polarity: max over the 16 arcs of the min of 9 (sign-normalised)
     //      differences; windows of 2, 4, 8 (+1) by doubling. ----
@@ -645,7 +653,7 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
         if (va && sa >= t) s_sc[(ra + 1) * scp + ca + 1] = (uint8_t)sa;
         if (vb && sb >= t) s_sc[(rb + 1) * scp + cb + 1] = (uint8_t)sb;
     }
-    __syncthreads();
+    FAST_WAVE_SYNC();
     if (dbg == 4) { if (lane == 0) *cnt_out = 0; return; }
     // ---- D: NMS + threshold choice ----
     bool any = false;
@@ -661,7 +669,7 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
         s_qf[q] = (uint8_t)f;
     }
     const int need = __ballot(any) != 0ull ? 2 : 1;
-    __syncthreads();
+    FAST_WAVE_SYNC();
     (void)q_bytes;
     // ---- E: ordered emission ----
     uint32_t *oxy = buf.cell_xy + ((size_t)img * cfg.cells_total + cell) * cfg.cell_cap;
@@ -679,7 +687,7 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
         if (nb <= 64) { s_ac[lane] = 0u; s_ab[lane] = 0u; }
         g_cnt = buf.bk_cnt + ((size_t)img * cfg.nlevels + level) * ORBFE_BK_BUCKETS;
         g_best = buf.bk_best + ((size_t)img * cfg.nlevels + level) * ORBFE_BK_BUCKETS;
-        __syncthreads();
+        FAST_WAVE_SYNC();
     }
     // survivors are first compacted in place over the queue (a write never passes this iteration's reads), then
     // emitted densely: one pass of 64 lanes per 64 survivors instead of one per 64 queue entries
@@ -692,7 +700,7 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
         if (pred) s_q2[run + __popcll(m & lt)] = rc;
         run += __popcll(m);
     }
-    __syncthreads();
+    FAST_WAVE_SYNC();
     const int n_out = run < cfg.cell_cap ? run : cfg.cell_cap;
     for (int p0 = 0; p0 < n_out; p0 += 64) {
         const int pos = p0 + lane;
@@ -724,7 +732,7 @@ __global__ __launch_bounds__(64) void fast_cell_kernel(DeviceConfig cfg, DeviceB
     }
     if (lane == 0) *cnt_out = run < cfg.cell_cap ? run : cfg.cell_cap;
     if (BK && nb <= 64 && dbg != 5) {
-        __syncthreads();
+        FAST_WAVE_SYNC();
         const unsigned cnt = lane < nb ? s_ac[lane] : 0u;
         if (cnt) {
             const int ly = (int)(((float)lane + 0.5f) / (float)ncols), lx = lane - ly * ncols;
@@ -1598,13 +1606,14 @@ void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_
     // flags alias the tile: it must hold one byte per interior pixel
     // flags alias the tile region: tile_bytes passed to the kernel covers both; + 2 x 64 words of bucket accumulators
     const int tile_region = tile_bytes > mw * mh ? tile_bytes : ((mw * mh + 15) & ~15);
-    const size_t lds = (size_t)tile_region + sc_bytes + q_bytes + 512;
-    dim3 grid(cfg.cells_total * ((n_images + 7) / 8) * 8);
+    const int lds_per_wave = tile_region + sc_bytes + q_bytes + 512;
+    const size_t lds = (size_t)4 * lds_per_wave;
+    dim3 grid(((cfg.cells_total + 3) / 4) * ((n_images + 7) / 8) * 8);
     static const int dbg = getenv("ORBFE_FAST_DBG") ? atoi(getenv("ORBFE_FAST_DBG")) : 0; // profiling aid only
 #define FAST_LAUNCH(TP)                                                                                                                   \
     do {                                                                                                                              \
-        if (buckets) hipLaunchKernelGGL((fast_cell_kernel<TP, true>), grid, dim3(64), lds, s, cfg, buf, n_images, tile_pitch, tile_region, sc_bytes, q_bytes, dbg); \
-        else hipLaunchKernelGGL((fast_cell_kernel<TP, false>), grid, dim3(64), lds, s, cfg, buf, n_images, tile_pitch, tile_region, sc_bytes, q_bytes, dbg); \
+        if (buckets) hipLaunchKernelGGL((fast_cell_kernel<TP, true>), grid, dim3(256), lds, s, cfg, buf, n_images, tile_pitch, tile_region, sc_bytes, q_bytes, lds_per_wave, dbg); \
+        else hipLaunchKernelGGL((fast_cell_kernel<TP, false>), grid, dim3(256), lds, s, cfg, buf, n_images, tile_pitch, tile_region, sc_bytes, q_bytes, lds_per_wave, dbg); \
     } while (0)
     switch (tile_pitch) {
     case 44: FAST_LAUNCH(44); break;
