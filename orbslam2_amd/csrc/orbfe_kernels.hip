@@ -514,24 +514,43 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
     const int xa = ini_x & ~3, ox = ini_x - xa;
     const int wpr = (max_x - xa + 3) >> 2; // words per tile row
     const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (size_t)ini_y * L.pitch + xa;
-    {
+    if (wpr <= 16) {
+        // tile rows of at most 16 words (cells up to ~55 px): a wave-load covers 4 rows x 16 words; lanes beyond the row /
+        // the last row repeat the last valid element (same value to the same LDS word), so nothing is predicated
+        const int c4 = 4 * ((lane & 15) < wpr ? (lane & 15) : wpr - 1);
+        const int rr = lane >> 4;
+        const int nu = (th + 3) >> 2;
+        for (int u0 = 0; u0 < nu; u0 += 4) { // 4 loads in flight per lane
+            uint32_t v[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                int r = rr + 4 * (u0 + u);
+                r = r < th ? r : th - 1;
+                dst[u] = __mul24(r, tile_pitch) + c4;
+                v[u] = *(const uint32_t *)(src + (unsigned)(__mul24(r, L.pitch) + c4));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) *(uint32_t *)(s_tile + dst[u]) = v[u];
+        }
+    } else {
         // (row, word) of element i = lane, advanced by 64 per step; 32-bit offsets only (64-bit multiplies and a
         // per-element division cost more VALU issue than the copy itself)
         int r = (int)(((float)lane + 0.5f) * (1.0f / (float)wpr)), c = lane - r * wpr;
         const int dr = 64 / wpr, dc = 64 - dr * wpr;
         const int nw = th * wpr;
-        for (int i0 = lane; i0 < nw; i0 += 512) { // 8 loads in flight per lane: a typical 37-row tile is one round trip
-            uint32_t v[8];
-            int dst[8];
+        for (int i0 = lane; i0 < nw; i0 += 256) {
+            uint32_t v[4];
+            int dst[4];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 4; u++) {
                 dst[u] = __mul24(r, tile_pitch) + 4 * c;
                 if (i0 + 64 * u < nw) v[u] = *(const uint32_t *)(src + (unsigned)(__mul24(r, L.pitch) + 4 * c));
                 c += dc; r += dr;
                 if (c >= wpr) { c -= wpr; r++; }
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++)
+            for (int u = 0; u < 4; u++)
                 if (i0 + 64 * u < nw) *(uint32_t *)(s_tile + dst[u]) = v[u];
         }
     }
