@@ -13,6 +13,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $out/pmc_sq -- python3 bench.py --steps 3 --warmup 1 --cpu-pairs 0 --no-check > /dev/null 2>&1 || exit 1
 python3 tools/pmc_summary.py $out/pmc_sq > $out/pmc_sq.txt
-python3 tools/make_traffic.py $out 32 $out/traffic.json > /dev/null
+python3 tools/make_traffic.py $out 64 $out/traffic.json > /dev/null
 rm -rf $out/stats $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_sq
 cat $out/bench.json; cut -c1-120 $out/kernel_stats.csv; cat $out/pmc_FETCH_SIZE.txt $out/pmc_WRITE_SIZE.txt | grep -v rocclr
