@@ -1167,32 +1167,34 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, Devi
         cy = (int)(xy >> 16) + cfg.min_border;
         return true;
     };
-    auto prefetch = [&](int i) -> bool {
+    auto prefetch_raw = [&](int i) -> bool {
         if (i >= DS_KPW || !slot_data(i)) return false;
         const LevelInfo &L = cfg.lv[level];
-        const uint8_t *raw = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off;
-        const uint8_t *blr = buf.blur + (size_t)img * cfg.pyr_bytes + L.pyr_off;
-        if (raw_in_regs) fetch(raw, L, (cx - hp) & ~3, cy - hp, pr, DS_RAW_REGS, raw_words);
-        fetch(blr, L, (cx - 18) & ~3, cy - 18, pb, DS_BLR_REGS, 37 * (DS_PATCH_W / 4));
+        if (raw_in_regs) fetch(buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off, L, (cx - hp) & ~3, cy - hp, pr, DS_RAW_REGS, raw_words);
+        return true;
+    };
+    auto prefetch_blur = [&](int i) -> bool {
+        if (i >= DS_KPW || !slot_data(i)) return false;
+        const LevelInfo &L = cfg.lv[level];
+        fetch(buf.blur + (size_t)img * cfg.pyr_bytes + L.pyr_off, L, (cx - 18) & ~3, cy - 18, pb, DS_BLR_REGS, 37 * (DS_PATCH_W / 4));
         return true;
     };
 
-    int rl_lv = -1;          // lane i < DS_KPW: level | index << 8 of the wave's i-th keypoint (-1: none), its x and y
-    float rl_x = 0.f, rl_y = 0.f;
-    bool have = prefetch(0);
+    // Pass 1: raw patches -> IC_Angle moments of the wave's keypoints (lane i keeps keypoint i's);
+    // then fastAtan2 and the sin / cos ONCE for all of them (lane i computes keypoint i's: those ~150 scalar-like
+    // instructions, part of them double precision, would otherwise be repeated per keypoint by all 64 lanes);
+    // pass 2: blurred patches -> descriptors and keypoint records.
+    int m10_l = 0, m01_l = 0;
+    bool have = prefetch_raw(0);
     for (int i = 0; i < DS_KPW; i++) {
         const bool cur = have;
-        // keypoint i: uniform data again (cheap), then its patches from the prefetch registers into LDS
-        int lv = 0, kx = 0, ky = 0, ksc = 0, kout = 0;
+        int kx = 0, ky = 0, lv = 0;
         if (cur) {
             slot_data(i);
-            lv = level; kx = cx; ky = cy; ksc = score; kout = out;
+            kx = cx; ky = cy; lv = level;
 #pragma unroll
             for (int k = 0; k < DS_RAW_REGS; k++)
                 if (raw_in_regs && lane + 64 * k < raw_words) ((uint32_t *)s_raw)[lane + 64 * k] = pr[k];
-#pragma unroll
-            for (int k = 0; k < DS_BLR_REGS; k++)
-                if (lane + 64 * k < 37 * (DS_PATCH_W / 4)) ((uint32_t *)s_blr)[lane + 64 * k] = pb[k];
             if (!raw_in_regs) { // big patches: straight through (no prefetch)
                 const LevelInfo &Lr = cfg.lv[lv];
                 const uint8_t *gp = buf.pyr + (size_t)img * cfg.pyr_bytes + Lr.pyr_off + (ptrdiff_t)__mul24(ky - hp + r0, Lr.pitch) + ((kx - hp) & ~3) + 4 * c0;
@@ -1207,13 +1209,11 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, Devi
         }
         __builtin_amdgcn_s_waitcnt(0); // LDS writes of this wave are visible to its own later reads in order
         __builtin_amdgcn_wave_barrier();
-        have = prefetch(i + 1); // in flight while keypoint i is computed
+        have = prefetch_raw(i + 1); // in flight while keypoint i is computed
         if (!cur || dbg == 2) continue;
-        const LevelInfo &L = cfg.lv[lv];
-        const int xr = (kx - hp) & ~3, xb = (kx - 18) & ~3;
-
         // IC_Angle (src/ORBextractor.cc:72-99): integer moments over the circular patch (host-built offset
         // table, padded with (0,0) entries that contribute nothing)
+        const int xr = (kx - hp) & ~3;
         int m10 = 0, m01 = 0;
         const uint8_t *pc = s_raw + hp * DS_PATCH_W + (kx - xr);
         for (int kk = lane; kk < cfg.patch_n; kk += 64) {
@@ -1225,13 +1225,38 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, Devi
         }
         m10 = wave_sum_i32(m10);
         m01 = wave_sum_i32(m01);
-        const float angle = fast_atan2_deg((float)m01, (float)m10);
+        if (lane == i) { m10_l = m10; m01_l = m01; }
+    }
+    have = prefetch_blur(0); // in flight during the angle arithmetic
+    const float angle_l = fast_atan2_deg((float)m01_l, (float)m10_l);
+    const float factor_pi = __uint_as_float(0x3c8efa35u); // (float)(CV_PI/180.f)
+    float a_l, b_l;
+    sincos_det(__fmul_rn(angle_l, factor_pi), &b_l, &a_l);
+
+    int rl_lv = -1;          // lane i < DS_KPW: level | index << 8 of the wave's i-th keypoint (-1: none), its x and y
+    float rl_x = 0.f, rl_y = 0.f;
+    for (int i = 0; i < DS_KPW; i++) {
+        const bool cur = have;
+        int lv = 0, kx = 0, ky = 0, ksc = 0, kout = 0;
+        if (cur) {
+            slot_data(i);
+            lv = level; kx = cx; ky = cy; ksc = score; kout = out;
+#pragma unroll
+            for (int k = 0; k < DS_BLR_REGS; k++)
+                if (lane + 64 * k < 37 * (DS_PATCH_W / 4)) ((uint32_t *)s_blr)[lane + 64 * k] = pb[k];
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        have = prefetch_blur(i + 1);
+        if (!cur || dbg == 2) continue;
+        const LevelInfo &L = cfg.lv[lv];
+        const int xb = (kx - 18) & ~3;
+        const float angle = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(angle_l), i));
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_l), i));
+        const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_l), i));
         if (dbg == 3) { if (lane == 0) buf.depth[(size_t)img * cfg.sel_total + kout] = angle; continue; }
 
         // computeOrbDescriptor (src/ORBextractor.cc:103-142)
-        const float factor_pi = __uint_as_float(0x3c8efa35u); // (float)(CV_PI/180.f)
-        float a, b;
-        sincos_det(__fmul_rn(angle, factor_pi), &b, &a);
         const uint8_t *center = s_blr + 18 * DS_PATCH_W + (kx - xb);
         unsigned long long *dout = (unsigned long long *)(buf.desc + ((size_t)img * cfg.sel_total + kout) * 32);
         unsigned long long bits[4];
