@@ -325,19 +325,22 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(DeviceConfig cfg, Devic
 // the last seven row-sum vectors in registers and emits one 4-px output word.  No LDS, no barriers;
 // HBM traffic = one read of the level (+6/BL_ROWS row halo, L2-served) and one write.
 // ---------------------------------------------------------------------------
-#define BL_ROWS 16
+#define BL_ROWS 32  // rows per wave: 6 / BL_ROWS of the rows are loaded (and row-filtered) twice
 #define BL_COLS 256 // per wave: 64 lanes x 4 px
 __global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffers buf)
 {
+    // the waves of a workgroup are independent: wave u of the flattened (level, row band, 256-column strip) list
     const int img = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int u = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (u >= cfg.blur_tiles_total) return;
     int level = 0;
     for (int l = 1; l < cfg.nlevels; l++)
-        if ((int)blockIdx.x >= cfg.lv[l].blur_tile_off) level = l;
+        if (u >= cfg.lv[l].blur_tile_off) level = l;
     const LevelInfo &L = cfg.lv[level];
-    const int t = blockIdx.x - L.blur_tile_off;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = u - L.blur_tile_off;
     const int x0 = (t % L.blur_tiles_x) * BL_COLS + lane * 4;
-    const int r0 = (t / L.blur_tiles_x) * (4 * BL_ROWS) + wave * BL_ROWS;
+    const int r0 = (t / L.blur_tiles_x) * BL_ROWS;
     if (x0 >= L.w || r0 >= L.h) return;
     const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + x0;
     uint8_t *dst = buf.blur + (size_t)img * cfg.pyr_bytes + L.pyr_off + x0;
@@ -471,7 +474,6 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
     const int ci = cell - L.cell_off;
     const int ci_i = ci / L.n_cols, ci_j = ci - ci_i * L.n_cols;
     const int lane = threadIdx.x & 63;
-    const unsigned long long lt = (1ull << lane) - 1ull;
     int *cnt_out = buf.cell_cnt + (size_t)img * cfg.cells_total + cell;
 
     const int min_b = cfg.min_border;
@@ -674,16 +676,31 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
     }
     FAST_WAVE_SYNC();
     if (dbg == 4) { if (lane == 0) *cnt_out = 0; return; }
-    // ---- D: NMS + threshold choice ----
+    // ---- D: NMS + threshold choice.  The first 256 queue entries (all of them for ordinary cells) keep their flag and
+    //      coordinates in registers for the compaction of phase E; later ones go through the LDS flag array. ----
     bool any = false;
-    for (int q = lane; q < n2; q += 64) {
-        const unsigned rc = s_q2[q] & 0x7fffu;
+    auto nms_flag = [&](unsigned rc) {
         const uint8_t *p = &s_sc[((rc >> 8) + 1) * scp + (rc & 255) + 1];
         const int s = p[0];
         // all nine reads issued together (a short-circuit chain would be nine dependent LDS round trips)
         const int n0 = p[-scp - 1], n1 = p[-scp], n2_ = p[-scp + 1], n3 = p[-1], n4 = p[1], n5 = p[scp - 1], n6 = p[scp], n7 = p[scp + 1];
         const int mx = max(max(max(n0, n1), max(n2_, n3)), max(max(n4, n5), max(n6, n7)));
-        const int f = ((s > 0) & (s > mx)) ? ((s >= cfg.ini_th) ? 2 : 1) : 0;
+        return ((s > 0) & (s > mx)) ? ((s >= cfg.ini_th) ? 2 : 1) : 0;
+    };
+    unsigned rcq[4];
+    int fq[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int q = lane + 64 * k;
+        rcq[k] = 0u; fq[k] = 0;
+        if (q < n2) {
+            rcq[k] = s_q2[q] & 0x7fffu;
+            fq[k] = nms_flag(rcq[k]);
+            any |= (fq[k] == 2);
+        }
+    }
+    for (int q = lane + 256; q < n2; q += 64) {
+        const int f = nms_flag(s_q2[q] & 0x7fffu);
         any |= (f == 2);
         s_qf[q] = (uint8_t)f;
     }
@@ -711,12 +728,21 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
     // survivors are first compacted in place over the queue (a write never passes this iteration's reads), then
     // emitted densely: one pass of 64 lanes per 64 survivors instead of one per 64 queue entries
     int run = 0;
-    for (int q0 = 0; q0 < n2; q0 += 64) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (64 * k < n2) {
+            const bool pred = fq[k] >= need; // fq = 0 beyond the queue
+            const unsigned long long m = __ballot(pred);
+            if (pred) s_q2[run + (int)mbcnt64(m, 0u)] = (uint16_t)rcq[k];
+            run += __popcll(m);
+        }
+    }
+    for (int q0 = 256; q0 < n2; q0 += 64) {
         const int q = q0 + lane;
         const bool pred = q < n2 && s_qf[q] >= need;
         const unsigned long long m = __ballot(pred);
         const uint16_t rc = q < n2 ? s_q2[q] : (uint16_t)0;
-        if (pred) s_q2[run + __popcll(m & lt)] = rc;
+        if (pred) s_q2[run + (int)mbcnt64(m, 0u)] = rc;
         run += __popcll(m);
     }
     FAST_WAVE_SYNC();
@@ -1635,7 +1661,7 @@ void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int
 
 void orbfe_launch_blur(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
 {
-    dim3 grid(cfg.blur_tiles_total, n_images);
+    dim3 grid((cfg.blur_tiles_total + 3) / 4, n_images);
     hipLaunchKernelGGL(blur_kernel, grid, dim3(256), 0, s, cfg, buf);
 }
 
