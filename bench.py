@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU (in flight in HBM; BASELINE.json config 4 batches 64 pairs)")
     ap.add_argument("--streams", type=int, default=1, help="stream groups the batch is cut into inside the library (1 keeps per-kernel times clean; 2 overlaps stages, ~+5%)")
     ap.add_argument("--cpu-pairs", type=int, default=40, help="pairs in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run oracle spot check")
     args = ap.parse_args()
 
@@ -118,18 +119,23 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    D.init("nccl", dev)
+    # --backend gloo with ORBFE_BENCH_ONE_GPU=1 rehearses the multi-rank path on a one-GPU box (all ranks on device 0,
+    # collectives on CPU tensors); the real run is one rank per GPU over RCCL.
+    one_gpu = args.backend == "gloo" and os.environ.get("ORBFE_BENCH_ONE_GPU") == "1"
+    gpu_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
+    D.init(args.backend, dev)
 
     # one-time RCCL broadcast of the extractor parameters + rBRIEF pattern checksum
-    blob = D.broadcast_params(D.pack_params(NFEAT, 1.2, NLEVELS, 20, 7, 31, 15, 19, FX, FY, CX, CY, BF), dev)
+    blob = D.broadcast_params(D.pack_params(NFEAT, 1.2, NLEVELS, 20, 7, 31, 15, 19, FX, FY, CX, CY, BF), cdev)
     nf, sf, nl, ini, mn, ps, hps, et, fx, fy, cx, cy, bf = D.unpack_params(blob)
 
     P = args.pairs
     ctx = api.Context(width=W, height=H, nfeatures=nf, scale_factor=sf, nlevels=nl, ini_th_fast=ini, min_th_fast=mn,
                       patch_size=ps, half_patch_size=hps, edge_threshold=et, fx=fx, fy=fy, cx=cx, cy=cy, bf=bf,
-                      device=local_rank, max_images=2 * P)
+                      device=gpu_index, max_images=2 * P)
     G = max(1, min(args.streams, P, 8))
     ctx.set_streams(G)
     n_distinct = min(P, 4)
@@ -167,7 +173,7 @@ def main():
     barrier()
     stage_ms, calls = ctx.stage_times(reset=True)
     ctx.set_profiling(0)
-    dt = D.max_over_ranks(dt, dev)
+    dt = D.max_over_ranks(dt, cdev)
 
     counts = ctx.fetch_counts(2 * P)
     n_cand = 0
