@@ -327,6 +327,7 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
     DeviceBuffers &b = ctx->buf;
     KeyPointPOD *kps = nullptr;
 #define A(ptr, count) do { rc = dev_alloc(ctx, &(ptr), (count)); if (rc != ORBFE_OK) { orbfe_destroy(ctx); return rc; } } while (0)
+#define Z(ptr, bytes) do { if (hipMemset((ptr), 0, (bytes)) != hipSuccess) { orbfe_destroy(ctx); return fail(nullptr, ORBFE_ERR_HIP, "hipMemset failed"); } } while (0)
     A(b.pyr, B * c.pyr_bytes);
     A(b.blur, B * c.pyr_bytes);
     A(b.cell_cnt, B * c.cells_total);
@@ -342,8 +343,8 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
     A(b.idx1, B * c.cand_total);
     A(b.bk_cnt, B * c.nlevels * 4096);
     A(b.bk_best, B * c.nlevels * 4096);
-    hipMemset(b.bk_cnt, 0, B * c.nlevels * 4096 * sizeof(uint32_t));
-    hipMemset(b.bk_best, 0, B * c.nlevels * 4096 * sizeof(uint32_t));
+    Z(b.bk_cnt, B * c.nlevels * 4096 * sizeof(uint32_t));
+    Z(b.bk_best, B * c.nlevels * 4096 * sizeof(uint32_t));
     A(b.bk_end, B * c.nlevels * 4097);
     A(b.lvl_ncand, B * c.nlevels);
     A(b.sel_cnt, B * c.nlevels);
@@ -359,7 +360,7 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
     A(b.status, B);
     A(ctx->d_in, B * (size_t)p.width * p.height);
     A(b.dbg_ts, 4096);
-    hipMemset(b.dbg_ts, 0, 4096 * sizeof(long long));
+    Z(b.dbg_ts, 4096 * sizeof(long long));
     {   // stereo row lists (vRowIndices, src/Frame.cc:474-491): fixed capacity per row, ~4x the mean occupancy
         // (a right keypoint is listed in ~2 * 2 * scale + 1 rows); a fuller row makes stereo_match_kernel scan all keypoints
         int cap = (int)(4.0 * c.sel_total * 10.0 / p.height);
@@ -369,7 +370,7 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
         const size_t pairs = (B + 1) / 2;
         A(b.row_cnt, pairs * (size_t)p.height);
         A(b.row_ent, pairs * (size_t)p.height * cap);
-        hipMemset(b.row_cnt, 0, pairs * (size_t)p.height * sizeof(int));
+        Z(b.row_cnt, pairs * (size_t)p.height * sizeof(int));
     }
     {   // cv::resize tables (resize.cpp: xofs/ialpha, yofs/ibeta) over the margin-extended domain of each level
         std::vector<uint32_t> tab;
@@ -503,10 +504,11 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
         b.patch_uv = d_uv;
         ctx->cfg.patch_n = (int)uv.size();
     }
+    Z(b.kp_cnt, sizeof(int) * B);
+    Z(b.sel_cnt, sizeof(int) * B * c.nlevels);
+    Z(b.status, sizeof(int) * B);
 #undef A
-    hipMemset(b.kp_cnt, 0, sizeof(int) * B);
-    hipMemset(b.sel_cnt, 0, sizeof(int) * B * c.nlevels);
-    hipMemset(b.status, 0, sizeof(int) * B);
+#undef Z
     *out = ctx;
     return ORBFE_OK;
 }
