@@ -243,6 +243,15 @@ int orbfe_search_by_bow(orbfe_context *ctx,
                         const uint32_t *f_nodes, const int32_t *f_off, const int32_t *f_feat, int f_nnodes,
                         const uint8_t *f_desc, const float *f_angle, int n_f,
                         float nnratio, int check_ori, int32_t *f_match, int *nmatches);
+/* ORBmatcher::SearchByFboW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12) (src/ORBmatcher.cc:517-650; LoopClosing and
+ * relocalisation).  valid1 / valid2 = the keypoint has a map point that is not bad.  match12[i1] receives the KF2
+ * keypoint whose map point KF1 keypoint i1 got, or -1 (n1 entries). */
+int orbfe_search_by_bow_kf(orbfe_context *ctx,
+                           const uint32_t *nodes1, const int32_t *off1, const int32_t *feat1, int nnodes1,
+                           const int32_t *valid1, const uint8_t *desc1, const float *angle1, int n1,
+                           const uint32_t *nodes2, const int32_t *off2, const int32_t *feat2, int nnodes2,
+                           const int32_t *valid2, const uint8_t *desc2, const float *angle2, int n2,
+                           float nnratio, int check_ori, int32_t *match12, int *nmatches);
 
 #ifdef __cplusplus
 }

@@ -169,6 +169,11 @@ int orc_search_by_bow(const uint32_t *kf_nodes, const int32_t *kf_off, const int
                       const uint32_t *f_nodes, const int32_t *f_off, const int32_t *f_feat, int f_nnodes,
                       const uint8_t *f_desc, const float *f_angle, int n_f,
                       float nnratio, int check_ori, int32_t *f_match);
+int orc_search_by_bow_kf(const uint32_t *n1, const int32_t *off1, const int32_t *feat1, int nn1,
+                         const int32_t *valid1, const uint8_t *desc1, const float *angle1, int nk1,
+                         const uint32_t *n2, const int32_t *off2, const int32_t *feat2, int nn2,
+                         const int32_t *valid2, const uint8_t *desc2, const float *angle2, int nk2,
+                         float nnratio, int check_ori, int32_t *match12);
 
 #ifdef __cplusplus
 }

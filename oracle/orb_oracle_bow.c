@@ -209,3 +209,64 @@ int orc_search_by_bow(const uint32_t *kf_nodes, const int32_t *kf_off, const int
     for (int k = 0; k < HISTO_LENGTH; k++) free(hist[k]);
     return nmatches;
 }
+
+/* ORBmatcher::SearchByFboW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12) (src/ORBmatcher.cc:517-650): like the
+ * (KeyFrame, Frame) overload, but both sides need a good map point (valid1 / valid2), a KF2 feature is taken at most
+ * once (vbMatched2), the distance bound is strict (bestDist1 < TH_LOW, :590) and the result is indexed by the KF1
+ * feature: match12[idx1] = idx2 or -1. */
+int orc_search_by_bow_kf(const uint32_t *n1, const int32_t *off1, const int32_t *feat1, int nn1,
+                         const int32_t *valid1, const uint8_t *desc1, const float *angle1, int nk1,
+                         const uint32_t *n2, const int32_t *off2, const int32_t *feat2, int nn2,
+                         const int32_t *valid2, const uint8_t *desc2, const float *angle2, int nk2,
+                         float nnratio, int check_ori, int32_t *match12)
+{
+    int nmatches = 0;
+    for (int i = 0; i < nk1; i++) match12[i] = -1;
+    uint8_t *matched2 = (uint8_t *)calloc((size_t)(nk2 > 0 ? nk2 : 1), 1);
+    int *hist[HISTO_LENGTH], hn[HISTO_LENGTH], hc[HISTO_LENGTH];
+    for (int b = 0; b < HISTO_LENGTH; b++) { hist[b] = NULL; hn[b] = 0; hc[b] = 0; }
+    int a = 0, b = 0;
+    while (a < nn1 && b < nn2) {
+        if (n1[a] == n2[b]) {
+            for (int i1 = off1[a]; i1 < off1[a + 1]; i1++) {
+                const int idx1 = feat1[i1];
+                if (!valid1[idx1]) continue;
+                int best1 = 256, best_idx2 = -1, best2 = 256;
+                for (int i2 = off2[b]; i2 < off2[b + 1]; i2++) {
+                    const int idx2 = feat2[i2];
+                    if (matched2[idx2] || !valid2[idx2]) continue;
+                    const int dist = orc_hamming256(desc1 + (size_t)32 * idx1, desc2 + (size_t)32 * idx2);
+                    if (dist < best1) { best2 = best1; best1 = dist; best_idx2 = idx2; }
+                    else if (dist < best2) best2 = dist;
+                }
+                if (best1 < TH_LOW && (float)best1 < nnratio * (float)best2) {
+                    match12[idx1] = best_idx2;
+                    matched2[best_idx2] = 1;
+                    if (check_ori) {
+                        const int bin = rot_bin(angle1[idx1], angle2[best_idx2]);
+                        if (hn[bin] == hc[bin]) { hc[bin] = hc[bin] ? 2 * hc[bin] : 64; hist[bin] = (int *)realloc(hist[bin], sizeof(int) * (size_t)hc[bin]); }
+                        hist[bin][hn[bin]++] = idx1;
+                    }
+                    nmatches++;
+                }
+            }
+            a++; b++;
+        } else if (n1[a] < n2[b]) {
+            while (a < nn1 && n1[a] < n2[b]) a++; /* lower_bound */
+        } else {
+            while (b < nn2 && n2[b] < n1[a]) b++;
+        }
+    }
+    if (check_ori) {
+        int i1, i2, i3;
+        orc_three_maxima(hn, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int k = 0; k < HISTO_LENGTH; k++) {
+            if (k == i1 || k == i2 || k == i3) continue;
+            for (int j = 0; j < hn[k]; j++) { match12[hist[k][j]] = -1; nmatches--; }
+        }
+    }
+    for (int k = 0; k < HISTO_LENGTH; k++) free(hist[k]);
+    free(matched2);
+    (void)nk2;
+    return nmatches;
+}

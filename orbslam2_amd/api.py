@@ -29,7 +29,7 @@ EXPORTS = [
     "orbfe_set_profiling", "orbfe_stage_name", "orbfe_stage_times", "orbfe_set_streams", "orbfe_quadtree_kernel",
     "orbfe_features_in_area", "orbfe_three_maxima", "orbfe_search_by_projection_last", "orbfe_is_in_frustum",
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_kf", "orbfe_search_for_initialization",
-    "orbfe_vocab_load", "orbfe_bow_transform", "orbfe_bow_maps", "orbfe_search_by_bow",  # bound in orbslam2_amd/bow.py
+    "orbfe_vocab_load", "orbfe_bow_transform", "orbfe_bow_maps", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",  # bound in orbslam2_amd/bow.py
 ]
 NUM_STAGES = 8
 STAGE_NAMES = ["ingest", "pyramid", "blur", "fast", "octree", "describe", "stereo_match", "stereo_median"]  # orbfe_stage_name()

@@ -24,6 +24,9 @@ def _bind():
     L.orbfe_search_by_bow.restype = C.c_int
     L.orbfe_search_by_bow.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int,
                                       C.c_float, C.c_int, vp, ip]
+    L.orbfe_search_by_bow_kf.restype = C.c_int
+    L.orbfe_search_by_bow_kf.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
+                                         C.c_float, C.c_int, vp, ip]
     _bound = True
     return L
 
@@ -66,6 +69,19 @@ def search_by_bow(ctx, kf_fv, kf_valid, kf_desc, kf_angle, f_fv, f_desc, f_angle
     ctx._check(L.orbfe_search_by_bow(ctx.h, _p(kn), _p(ko), _p(kf), len(kn), _p(kv), _p(kd), _p(ka), len(kd),
                                      _p(fn), _p(fo), _p(ff), len(fn), _p(fd), _p(fa), len(fd), nnratio, int(check_ori), _p(out), C.byref(nm)))
     return out[: len(fd)].copy(), nm.value
+
+
+def search_by_bow_kf(ctx, fv1, valid1, desc1, angle1, fv2, valid2, desc2, angle2, nnratio, check_ori):
+    """ORBmatcher::SearchByFboW(KeyFrame*, KeyFrame*, vpMatches12): match12[i1] = KF2 keypoint or -1, and the count."""
+    L = _bind()
+    a_n, a_o, a_f = (np.ascontiguousarray(a) for a in fv1); b_n, b_o, b_f = (np.ascontiguousarray(a) for a in fv2)
+    v1 = np.ascontiguousarray(valid1, np.int32); d1 = np.ascontiguousarray(desc1, np.uint8); g1 = np.ascontiguousarray(angle1, np.float32)
+    v2 = np.ascontiguousarray(valid2, np.int32); d2 = np.ascontiguousarray(desc2, np.uint8); g2 = np.ascontiguousarray(angle2, np.float32)
+    out = np.zeros(max(len(d1), 1), np.int32); nm = C.c_int()
+    ctx._check(L.orbfe_search_by_bow_kf(ctx.h, _p(a_n), _p(a_o), _p(a_f), len(a_n), _p(v1), _p(d1), _p(g1), len(d1),
+                                        _p(b_n), _p(b_o), _p(b_f), len(b_n), _p(v2), _p(d2), _p(g2), len(d2),
+                                        nnratio, int(check_ori), _p(out), C.byref(nm)))
+    return out[: len(d1)].copy(), nm.value
 
 
 def build_vocabulary(desc: np.ndarray, k: int = 10, levels: int = 3, seed: int = 7) -> bytes:

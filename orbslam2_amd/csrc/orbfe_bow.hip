@@ -222,20 +222,25 @@ static int rot_bin(float a1, float a2)
 }
 
 // ORBmatcher::SearchByFboW(KeyFrame*, Frame&, vpMapPointMatches), src/ORBmatcher.cc:157-283
-extern "C" int orbfe_search_by_bow(orbfe_context *ctx,
-                                   const uint32_t *kf_nodes, const int32_t *kf_off, const int32_t *kf_feat, int kf_nnodes,
-                                   const int32_t *kf_valid, const uint8_t *kf_desc, const float *kf_angle, int n_kf,
-                                   const uint32_t *f_nodes, const int32_t *f_off, const int32_t *f_feat, int f_nnodes,
-                                   const uint8_t *f_desc, const float *f_angle, int n_f,
-                                   float nnratio, int check_ori, int32_t *f_match, int *nmatches)
+// Shared body of the two SearchByFboW overloads.  kf_kf = false: (KeyFrame, Frame), src/ORBmatcher.cc:157-283, result
+// indexed by the frame keypoint; kf_kf = true: (KeyFrame, KeyFrame), :517-650, the second side needs f_valid, takes each of
+// its keypoints at most once, the distance bound is strict and the result is indexed by the first keyframe's keypoint.
+static int search_by_bow_impl(orbfe_context *ctx, bool kf_kf,
+                              const uint32_t *kf_nodes, const int32_t *kf_off, const int32_t *kf_feat, int kf_nnodes,
+                              const int32_t *kf_valid, const uint8_t *kf_desc, const float *kf_angle, int n_kf,
+                              const uint32_t *f_nodes, const int32_t *f_off, const int32_t *f_feat, int f_nnodes,
+                              const int32_t *f_valid, const uint8_t *f_desc, const float *f_angle, int n_f,
+                              float nnratio, int check_ori, int32_t *match, int *nmatches)
 {
-    if (!ctx || !nmatches || n_kf < 0 || n_f < 0 || kf_nnodes < 0 || f_nnodes < 0 || (n_f > 0 && !f_match) ||
+    const int n_out = kf_kf ? n_kf : n_f;
+    if (!ctx || !nmatches || n_kf < 0 || n_f < 0 || kf_nnodes < 0 || f_nnodes < 0 || (n_out > 0 && !match) || (kf_kf && n_f > 0 && !f_valid) ||
         (kf_nnodes > 0 && (!kf_nodes || !kf_off || !kf_feat || !kf_valid || !kf_desc || !kf_angle)) ||
         (f_nnodes > 0 && (!f_nodes || !f_off || !f_feat || !f_desc || !f_angle)))
         return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
     orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
     if (!st) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "out of host memory");
-    for (int j = 0; j < n_f; j++) f_match[j] = -1;
+    for (int j = 0; j < n_out; j++) match[j] = -1;
+    std::vector<uint8_t> taken(kf_kf ? (size_t)(n_f > 0 ? n_f : 1) : 1, 0); // vbMatched2
     *nmatches = 0;
     // merge-join of the two feature vectors: enumerate every (KF feature, frame feature) pair of a shared node
     struct Seg { int a, b, pair0; };
@@ -287,14 +292,15 @@ extern "C" int orbfe_search_by_bow(orbfe_context *ctx,
             int best1 = 256, best_f = -1, best2 = 256;
             for (int j = 0; j < nf; j++) {
                 const int real_f = f_feat[f_off[sg.b] + j];
-                if (f_match[real_f] >= 0) continue;
+                if (kf_kf ? (taken[real_f] || !f_valid[real_f]) : (match[real_f] >= 0)) continue;
                 const int d = dist[pi + j];
                 if (d < best1) { best2 = best1; best1 = d; best_f = real_f; }
                 else if (d < best2) best2 = d;
             }
-            if (best1 <= TH_LOW && (float)best1 < nnratio * (float)best2) {
-                f_match[best_f] = real_kf;
-                if (check_ori) hist[rot_bin(kf_angle[real_kf], f_angle[best_f])].push_back(best_f);
+            if ((kf_kf ? best1 < TH_LOW : best1 <= TH_LOW) && (float)best1 < nnratio * (float)best2) {
+                if (kf_kf) { match[real_kf] = best_f; taken[best_f] = 1; }
+                else match[best_f] = real_kf;
+                if (check_ori) hist[rot_bin(kf_angle[real_kf], f_angle[best_f])].push_back(kf_kf ? real_kf : best_f);
                 nm++;
             }
         }
@@ -306,9 +312,31 @@ extern "C" int orbfe_search_by_bow(orbfe_context *ctx,
         orbfe_three_maxima(sizes, HISTO_LENGTH, &i1, &i2, &i3);
         for (int b = 0; b < HISTO_LENGTH; b++) {
             if (b == i1 || b == i2 || b == i3) continue;
-            for (int idx : hist[b]) { f_match[idx] = -1; nm--; }
+            for (int idx : hist[b]) { match[idx] = -1; nm--; }
         }
     }
     *nmatches = nm;
     return ORBFE_OK;
+}
+
+extern "C" int orbfe_search_by_bow(orbfe_context *ctx,
+                                   const uint32_t *kf_nodes, const int32_t *kf_off, const int32_t *kf_feat, int kf_nnodes,
+                                   const int32_t *kf_valid, const uint8_t *kf_desc, const float *kf_angle, int n_kf,
+                                   const uint32_t *f_nodes, const int32_t *f_off, const int32_t *f_feat, int f_nnodes,
+                                   const uint8_t *f_desc, const float *f_angle, int n_f,
+                                   float nnratio, int check_ori, int32_t *f_match, int *nmatches)
+{
+    return search_by_bow_impl(ctx, false, kf_nodes, kf_off, kf_feat, kf_nnodes, kf_valid, kf_desc, kf_angle, n_kf,
+                              f_nodes, f_off, f_feat, f_nnodes, nullptr, f_desc, f_angle, n_f, nnratio, check_ori, f_match, nmatches);
+}
+
+extern "C" int orbfe_search_by_bow_kf(orbfe_context *ctx,
+                                      const uint32_t *nodes1, const int32_t *off1, const int32_t *feat1, int nnodes1,
+                                      const int32_t *valid1, const uint8_t *desc1, const float *angle1, int n1,
+                                      const uint32_t *nodes2, const int32_t *off2, const int32_t *feat2, int nnodes2,
+                                      const int32_t *valid2, const uint8_t *desc2, const float *angle2, int n2,
+                                      float nnratio, int check_ori, int32_t *match12, int *nmatches)
+{
+    return search_by_bow_impl(ctx, true, nodes1, off1, feat1, nnodes1, valid1, desc1, angle1, n1,
+                              nodes2, off2, feat2, nnodes2, valid2, desc2, angle2, n2, nnratio, check_ori, match12, nmatches);
 }

@@ -121,6 +121,43 @@ public:
         return n;
     }
 
+    // SearchByFboW(KeyFrame *pKF, Frame &F, vpMapPointMatches), src/ORBmatcher.cc:157.  FeatVec = the fBow2 map of
+    // Frame::ComputeFboW / KeyFrame::mFbowFeatVec flattened by orbfe_bow_maps; fMatch[j] = KF keypoint or -1.
+    struct FeatVec {
+        std::vector<uint32_t> nodes;
+        std::vector<int32_t> off, feat; // node k -> feat[off[k] .. off[k+1])
+    };
+    int SearchByFboW(const FeatVec &kfFeat, const std::vector<int32_t> &kfValid, const std::vector<uint8_t> &kfDesc,
+                     const std::vector<float> &kfAngle, const FeatVec &fFeat, const std::vector<uint8_t> &fDesc,
+                     const std::vector<float> &fAngle, std::vector<int32_t> &fMatch)
+    {
+        const int nk = (int)kfValid.size(), nf = (int)fAngle.size();
+        fMatch.assign(nf > 0 ? nf : 1, -1);
+        int n = 0;
+        Check(orbfe_search_by_bow(mCtx, kfFeat.nodes.data(), kfFeat.off.data(), kfFeat.feat.data(), (int)kfFeat.nodes.size(),
+                                  kfValid.data(), kfDesc.data(), kfAngle.data(), nk, fFeat.nodes.data(), fFeat.off.data(),
+                                  fFeat.feat.data(), (int)fFeat.nodes.size(), fDesc.data(), fAngle.data(), nf, mfNNratio,
+                                  mbCheckOrientation ? 1 : 0, fMatch.data(), &n));
+        fMatch.resize(nf);
+        return n;
+    }
+
+    // SearchByFboW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12), src/ORBmatcher.cc:517; vnMatches12[i1] = KF2 keypoint or -1.
+    int SearchByFboW(const FeatVec &feat1, const std::vector<int32_t> &valid1, const std::vector<uint8_t> &desc1,
+                     const std::vector<float> &angle1, const FeatVec &feat2, const std::vector<int32_t> &valid2,
+                     const std::vector<uint8_t> &desc2, const std::vector<float> &angle2, std::vector<int32_t> &vnMatches12)
+    {
+        const int n1 = (int)valid1.size(), n2 = (int)valid2.size();
+        vnMatches12.assign(n1 > 0 ? n1 : 1, -1);
+        int n = 0;
+        Check(orbfe_search_by_bow_kf(mCtx, feat1.nodes.data(), feat1.off.data(), feat1.feat.data(), (int)feat1.nodes.size(),
+                                     valid1.data(), desc1.data(), angle1.data(), n1, feat2.nodes.data(), feat2.off.data(),
+                                     feat2.feat.data(), (int)feat2.nodes.size(), valid2.data(), desc2.data(), angle2.data(), n2,
+                                     mfNNratio, mbCheckOrientation ? 1 : 0, vnMatches12.data(), &n));
+        vnMatches12.resize(n1);
+        return n;
+    }
+
     // ComputeThreeMaxima(histo, L, ind1, ind2, ind3), src/ORBmatcher.cc:1597
     void ComputeThreeMaxima(const std::vector<int> *histo, const int L, int &ind1, int &ind2, int &ind3)
     {

@@ -35,6 +35,8 @@ def _oracle_voc(blob):
     L.orc_bow_descend.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_bow_maps.restype = C.c_int
     L.orc_bow_maps.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5 + [C.POINTER(C.c_int)]
+    L.orc_search_by_bow_kf.restype = C.c_int
+    L.orc_search_by_bow_kf.argtypes = ([C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int]) * 2 + [C.c_float, C.c_int, C.c_void_p]
     L.orc_search_by_bow.restype = C.c_int
     L.orc_search_by_bow.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 2 + \
         [C.c_int, C.c_float, C.c_int, C.c_void_p]
@@ -120,6 +122,18 @@ def test_gpu_bow_transform_and_search(vocab):
         got, ngot = B.search_by_bow(ctx, kf_fv, kf_valid, kf_d, kf_ang, f_fv, f_d, f_ang, ratio, ori)
         assert ngot == nref and np.array_equal(got, ref)
     assert nref > 300
+    # SearchByFboW(KeyFrame*, KeyFrame*, ...) (src/ORBmatcher.cc:517-650): both sides need a good map point, result by KF1 keypoint
+    f_valid = (rng.random(len(f_d)) < 0.85).astype(np.int32)
+    for ratio, ori in ((0.75, True), (0.8, False), (0.95, True)):
+        ref12 = np.zeros(len(kf_d), np.int32)
+        n12 = L.orc_search_by_bow_kf(_p(kf_fv[0]), _p(kf_fv[1]), _p(kf_fv[2]), len(kf_fv[0]), _p(kf_valid), _p(kf_d), _p(kf_ang), len(kf_d),
+                                     _p(f_fv[0]), _p(f_fv[1]), _p(f_fv[2]), len(f_fv[0]), _p(f_valid), _p(f_d), _p(f_ang), len(f_d),
+                                     ratio, int(ori), _p(ref12))
+        got12, ng12 = B.search_by_bow_kf(ctx, kf_fv, kf_valid, kf_d, kf_ang, f_fv, f_valid, f_d, f_ang, ratio, ori)
+        assert ng12 == n12 and np.array_equal(got12, ref12)
+        assert n12 == int((ref12 >= 0).sum()) and n12 > 200
+        m = ref12[ref12 >= 0]
+        assert len(np.unique(m)) == len(m) and f_valid[m].all() and kf_valid[ref12 >= 0].all()  # one-to-one, valid on both sides
     ok = ref >= 0
     assert np.mean(perm[np.nonzero(ok)[0][np.nonzero(ok)[0] < 1200]] == ref[ok][np.nonzero(ok)[0] < 1200]) > 0.9
     L.orc_vocab_destroy(v)
