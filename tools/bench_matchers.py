@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Measurement for SURVEY.md §8 rows 13-19 (Tracking-thread matchers and BoW): wall time per call of the library entry
+points (host arrays in, host arrays out -- the H2D / D2H copies and the host-side greedy resolve are inside the time)
+beside the CPU oracle on the same inputs (1 thread).  Prints one JSON object; run on the GPU box:
+    python3 tools/bench_matchers.py > gpurun_out/matchers.json
+The scenario is the keypoint-level scene of tests/test_matchers.py scaled to 2000 last-frame points, and the
+BoW case of tests/test_bow.py (k=10, L=3 vocabulary, 1500 / 1600 descriptors).
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+from tests import test_matchers as TM  # noqa: E402
+
+
+def timeit(fn, reps):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def main():
+    from orbslam2_amd import api
+    ctx = api.Context(width=TM.W, height=TM.H, fx=TM.FX, fy=TM.FY, cx=TM.CX, cy=TM.CY, bf=TM.BF)
+    s = TM._scene(3, n_last=2000, n_distract=700)
+    g = O.Grid(s["k"], *s["bounds"])
+    view = ctx._view(s["k"], s["ur"], s["d"], s["bounds"])
+    out = {"unit": "ms per call", "scene": "2000 last-frame points, %d current keypoints" % len(s["k"]), "rows": {}}
+
+    def row(name, gpu_fn, cpu_fn, reps=20):
+        g_ms, c_ms = timeit(gpu_fn, reps), timeit(cpu_fn, max(3, reps // 4))
+        out["rows"][name] = {"gpu_ms": round(g_ms, 4), "oracle_1thread_ms": round(c_ms, 4)}
+
+    row("SearchByProjection(Frame, LastFrame) [row 14]",
+        lambda: ctx.search_by_projection_last(view, s["T_cur"], s["T_last"], s["pos"], s["desc_last"], s["valid"], s["obs"], s["octave"],
+                                              s["angle"], s["cur_has_obs"], 7.0, False, True),
+        lambda: O.search_by_projection_last(g, s["ur"], s["d"], s["sf"], TM.CAM, s["T_cur"], s["T_last"], s["pos"], s["desc_last"],
+                                            s["valid"], s["obs"], s["octave"], s["angle"], s["cur_has_obs"], 7.0, False, True))
+    rng = np.random.default_rng(5)
+    qs = [(float(rng.uniform(0, TM.W)), float(rng.uniform(0, TM.H)), float(rng.uniform(5, 60))) for _ in range(64)]
+    row("GetFeaturesInArea x64 [rows 13]",
+        lambda: [ctx.features_in_area(view, x, y, r, -1, -1) for x, y, r in qs],
+        lambda: [g.features_in_area(x, y, r, -1, -1) for x, y, r in qs], reps=5)
+    # mono initialisation: frame 1 = level-0 keypoints, frame 2 = the scene's current frame
+    k1 = s["k"].copy(); k1["octave"] = 0
+    prev = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32)
+    view1 = ctx._view(k1, None, s["d"], s["bounds"])
+    row("SearchForInitialization [row 18]",
+        lambda: ctx.search_for_initialization(view1, view, prev.copy(), 100, 0.9, True),
+        lambda: O.search_for_initialization(k1, s["d"], g, s["d"], prev.copy(), 100, 0.9, True), reps=10)
+
+    # BoW (row 17): vocabulary k=10, L=5 (tests/test_bow.py), transform + SearchByFboW of a 1500-keypoint keyframe against
+    # a 1600-keypoint frame
+    from orbslam2_amd import bow as B
+    from tests import test_bow as TB
+    blob = B.build_vocabulary(TB._descs(1, 6000), k=10, levels=5, seed=7)
+    B.vocab_load(ctx, blob)
+    L, v = TB._oracle_voc(blob)
+    rng = np.random.default_rng(3)
+    kf_d = TB._descs(5, 1500)
+    perm = rng.permutation(1500)[:1200]
+    f_d = np.concatenate([TB._descs(6, 0, base=kf_d[perm], flip=0.04), TB._descs(7, 400)])
+    row("fbow transform, 1500 descriptors [row 17]", lambda: B.transform(ctx, kf_d, 4), lambda: TB._oracle_transform(L, v, kf_d, 4))
+    _, _, kf_fv = TB._oracle_transform(L, v, kf_d)
+    _, _, f_fv = TB._oracle_transform(L, v, f_d)
+    kf_valid = (rng.random(len(kf_d)) < 0.8).astype(np.int32)
+    kf_ang = rng.uniform(0, 360, len(kf_d)).astype(np.float32)
+    f_ang = rng.uniform(0, 360, len(f_d)).astype(np.float32)
+    ref = np.zeros(len(f_d), np.int32)
+    P = TB._p
+    row("SearchByFboW(KeyFrame, Frame) [row 17]",
+        lambda: B.search_by_bow(ctx, kf_fv, kf_valid, kf_d, kf_ang, f_fv, f_d, f_ang, 0.75, True),
+        lambda: L.orc_search_by_bow(P(kf_fv[0]), P(kf_fv[1]), P(kf_fv[2]), len(kf_fv[0]), P(kf_valid), P(kf_d), P(kf_ang),
+                                    P(f_fv[0]), P(f_fv[1]), P(f_fv[2]), len(f_fv[0]), P(f_d), P(f_ang), len(f_d), 0.75, 1, P(ref)))
+    print(json.dumps(out, indent=1))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
