@@ -243,6 +243,24 @@ int orbfe_search_by_bow(orbfe_context *ctx,
                         const uint32_t *f_nodes, const int32_t *f_off, const int32_t *f_feat, int f_nnodes,
                         const uint8_t *f_desc, const float *f_angle, int n_f,
                         float nnratio, int check_ori, int32_t *f_match, int *nmatches);
+/* ---- keyframe database (KeyFrameDatabase, src/KeyFrameDatabase.cc): the keyframes' BoW vectors stay in HBM ----
+ * orbfe_kfdb_add = KeyFrameDatabase::add (:38-44) for one keyframe: its fBow as ascending word ids + weights
+ * (orbfe_bow_maps); returns the keyframe's index (insertion order = inverted-file order).  orbfe_kfdb_erase (:46-62)
+ * removes it from every query; indices are not reused.  orbfe_kfdb_clear (:64-70). */
+int orbfe_kfdb_clear(orbfe_context *ctx);
+int orbfe_kfdb_add(orbfe_context *ctx, const uint32_t *words, const float *weights, int n, int *kf_index);
+int orbfe_kfdb_erase(orbfe_context *ctx, int kf_index);
+int orbfe_kfdb_size(orbfe_context *ctx);
+/* Per keyframe: number of words shared with the query and fbow::fBow::score(query, keyframe)
+ * (Thirdparty/fbow/src/fbow.cpp:206-256: float products summed in double in word order).  Either output may be NULL. */
+int orbfe_kfdb_score(orbfe_context *ctx, const uint32_t *q_words, const float *q_w, int nq, int32_t *common, float *score);
+/* KeyFrameDatabase::DetectRelocalizationCandidates(Frame*) (:196-307).  covis_off / covis_idx = every keyframe's
+ * GetBestCovisibilityKeyFrames(10) list in its order (CSR over the database indices).  reloc_score = the keyframes'
+ * persistent mRelocScore, in/out: the reference never initialises it and updates it only for keyframes that pass the
+ * common-word filter, so it is caller-owned state (start from zeros).  Candidates in the reference's order. */
+int orbfe_detect_reloc_candidates(orbfe_context *ctx, const uint32_t *q_words, const float *q_w, int nq,
+                                  const int32_t *covis_off, const int32_t *covis_idx, float *reloc_score,
+                                  int32_t *cand, int cap, int *n_cand);
 /* ORBmatcher::SearchByFboW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12) (src/ORBmatcher.cc:517-650; LoopClosing and
  * relocalisation).  valid1 / valid2 = the keypoint has a map point that is not bad.  match12[i1] receives the KF2
  * keypoint whose map point KF1 keypoint i1 got, or -1 (n1 entries). */

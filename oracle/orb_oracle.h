@@ -174,6 +174,10 @@ int orc_search_by_bow_kf(const uint32_t *n1, const int32_t *off1, const int32_t 
                          const uint32_t *n2, const int32_t *off2, const int32_t *feat2, int nn2,
                          const int32_t *valid2, const uint8_t *desc2, const float *angle2, int nk2,
                          float nnratio, int check_ori, int32_t *match12);
+double orc_bow_score(const uint32_t *w1, const float *v1, int n1, const uint32_t *w2, const float *v2, int n2);
+int orc_detect_reloc_candidates(const uint32_t *q_words, const float *q_w, int nq,
+                                int n_kf, const int32_t *kf_off, const uint32_t *db_words, const float *db_w,
+                                const int32_t *covis_off, const int32_t *covis_idx, float *reloc_score, int32_t *cand, int cap);
 
 #ifdef __cplusplus
 }

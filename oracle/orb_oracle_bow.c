@@ -270,3 +270,104 @@ int orc_search_by_bow_kf(const uint32_t *n1, const int32_t *off1, const int32_t 
     (void)nk2;
     return nmatches;
 }
+
+/* fbow::fBow::score (Thirdparty/fbow/src/fbow.cpp:206-256): both vectors sorted by word id; the products are floats
+ * (the map's value type converts to float), accumulated in double in ascending word order. */
+double orc_bow_score(const uint32_t *w1, const float *v1, int n1, const uint32_t *w2, const float *v2, int n2)
+{
+    double score = 0;
+    int a = 0, b = 0;
+    while (a < n1 && b < n2) {
+        if (w1[a] == w2[b]) { const float p = v1[a] * v2[b]; score += p; a++; b++; }
+        else if (w1[a] < w2[b]) { while (a < n1 && w1[a] < w2[b]) a++; }
+        else { while (b < n2 && w2[b] < w1[a]) b++; }
+    }
+    if (score >= 1) score = 1.0;
+    else score = 1.0 - sqrt(1.0 - score);
+    return score;
+}
+
+/* KeyFrameDatabase::DetectRelocalizationCandidates (src/KeyFrameDatabase.cc:196-307).  The database is n_kf BoW
+ * vectors in CSR form (kf_off, db_words ascending per keyframe, db_w); the inverted file lists keyframes in index order
+ * (KeyFrameDatabase::add appends, :38-44).  covis = each keyframe's GetBestCovisibilityKeyFrames(10) list in its order.
+ * reloc_score[] is the keyframes' persistent mRelocScore (in/out): the reference never initialises it and only updates it
+ * for keyframes that pass the common-word filter, so a neighbour that merely shares a word contributes its OLD value
+ * (contract Q10: the caller owns that state; start from zeros).  Returns the number of candidates written to cand[]. */
+int orc_detect_reloc_candidates(const uint32_t *q_words, const float *q_w, int nq,
+                                int n_kf, const int32_t *kf_off, const uint32_t *db_words, const float *db_w,
+                                const int32_t *covis_off, const int32_t *covis_idx, float *reloc_score, int32_t *cand, int cap)
+{
+    /* inverted file: word -> keyframes (index order) */
+    uint32_t max_word = 0;
+    for (int i = 0; i < kf_off[n_kf]; i++) if (db_words[i] > max_word) max_word = db_words[i];
+    for (int i = 0; i < nq; i++) if (q_words[i] > max_word) max_word = q_words[i];
+    const size_t nw = (size_t)max_word + 2;
+    int *inv_off = (int *)calloc(nw + 1, sizeof(int));
+    for (int i = 0; i < kf_off[n_kf]; i++) inv_off[db_words[i] + 1]++;
+    for (size_t w = 0; w < nw; w++) inv_off[w + 1] += inv_off[w];
+    int *inv = (int *)malloc(sizeof(int) * (size_t)(kf_off[n_kf] > 0 ? kf_off[n_kf] : 1));
+    int *cur = (int *)malloc(sizeof(int) * (nw + 1));
+    memcpy(cur, inv_off, sizeof(int) * (nw + 1));
+    for (int k = 0; k < n_kf; k++)
+        for (int i = kf_off[k]; i < kf_off[k + 1]; i++) inv[cur[db_words[i]]++] = k;
+    /* keyframes sharing a word, in first-encounter order (:205-221) */
+    int *words = (int *)calloc((size_t)(n_kf > 0 ? n_kf : 1), sizeof(int));
+    uint8_t *seen = (uint8_t *)calloc((size_t)(n_kf > 0 ? n_kf : 1), 1);
+    int *sharing = (int *)malloc(sizeof(int) * (size_t)(n_kf > 0 ? n_kf : 1));
+    int n_sh = 0;
+    for (int i = 0; i < nq; i++)
+        for (int j = inv_off[q_words[i]]; j < inv_off[q_words[i] + 1]; j++) {
+            const int k = inv[j];
+            if (!seen[k]) { seen[k] = 1; words[k] = 0; sharing[n_sh++] = k; }
+            words[k]++;
+        }
+    int n_out = 0;
+    if (n_sh > 0) {
+        int max_common = 0;
+        for (int i = 0; i < n_sh; i++) if (words[sharing[i]] > max_common) max_common = words[sharing[i]];
+        const int min_common = (int)((float)max_common * 0.8f);
+        int *sm_kf = (int *)malloc(sizeof(int) * (size_t)n_sh);
+        float *sm_s = (float *)malloc(sizeof(float) * (size_t)n_sh);
+        int n_sm = 0;
+        for (int i = 0; i < n_sh; i++) {
+            const int k = sharing[i];
+            if (words[k] > min_common) {
+                const float si = (float)orc_bow_score(q_words, q_w, nq, db_words + kf_off[k], db_w + kf_off[k], kf_off[k + 1] - kf_off[k]);
+                reloc_score[k] = si;
+                sm_kf[n_sm] = k; sm_s[n_sm] = si; n_sm++;
+            }
+        }
+        if (n_sm > 0) {
+            float *acc = (float *)malloc(sizeof(float) * (size_t)n_sm);
+            int *best_kf = (int *)malloc(sizeof(int) * (size_t)n_sm);
+            float best_acc = 0;
+            for (int i = 0; i < n_sm; i++) { /* accumulate score by covisibility (:254-277) */
+                const int k = sm_kf[i];
+                float best = sm_s[i], a = best;
+                int bk = k;
+                int nn = covis_off[k + 1] - covis_off[k];
+                if (nn > 10) nn = 10;
+                for (int j = 0; j < nn; j++) {
+                    const int k2 = covis_idx[covis_off[k] + j];
+                    if (!seen[k2]) continue;
+                    a += reloc_score[k2];
+                    if (reloc_score[k2] > best) { bk = k2; best = reloc_score[k2]; }
+                }
+                acc[i] = a; best_kf[i] = bk;
+                if (a > best_acc) best_acc = a;
+            }
+            const float min_retain = 0.75f * best_acc;
+            uint8_t *added = (uint8_t *)calloc((size_t)n_kf, 1);
+            for (int i = 0; i < n_sm; i++)
+                if (acc[i] > min_retain && !added[best_kf[i]]) {
+                    added[best_kf[i]] = 1;
+                    if (n_out < cap) cand[n_out] = best_kf[i];
+                    n_out++;
+                }
+            free(added); free(acc); free(best_kf);
+        }
+        free(sm_kf); free(sm_s);
+    }
+    free(inv_off); free(inv); free(cur); free(words); free(seen); free(sharing);
+    return n_out;
+}

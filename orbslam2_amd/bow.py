@@ -27,6 +27,13 @@ def _bind():
     L.orbfe_search_by_bow_kf.restype = C.c_int
     L.orbfe_search_by_bow_kf.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
                                          C.c_float, C.c_int, vp, ip]
+    L.orbfe_kfdb_clear.restype = C.c_int; L.orbfe_kfdb_clear.argtypes = [vp]
+    L.orbfe_kfdb_add.restype = C.c_int; L.orbfe_kfdb_add.argtypes = [vp, vp, vp, C.c_int, ip]
+    L.orbfe_kfdb_erase.restype = C.c_int; L.orbfe_kfdb_erase.argtypes = [vp, C.c_int]
+    L.orbfe_kfdb_size.restype = C.c_int; L.orbfe_kfdb_size.argtypes = [vp]
+    L.orbfe_kfdb_score.restype = C.c_int; L.orbfe_kfdb_score.argtypes = [vp, vp, vp, C.c_int, vp, vp]
+    L.orbfe_detect_reloc_candidates.restype = C.c_int
+    L.orbfe_detect_reloc_candidates.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, ip]
     _bound = True
     return L
 
@@ -82,6 +89,42 @@ def search_by_bow_kf(ctx, fv1, valid1, desc1, angle1, fv2, valid2, desc2, angle2
                                         _p(b_n), _p(b_o), _p(b_f), len(b_n), _p(v2), _p(d2), _p(g2), len(d2),
                                         nnratio, int(check_ori), _p(out), C.byref(nm)))
     return out[: len(d1)].copy(), nm.value
+
+
+class KeyFrameDB:
+    """KeyFrameDatabase mirror: BoW vectors resident in HBM (orbfe_kfdb_*)."""
+
+    def __init__(self, ctx):
+        self.ctx, self.L = ctx, _bind()
+        ctx._check(self.L.orbfe_kfdb_clear(ctx.h))
+
+    def add(self, words, weights) -> int:
+        w = np.ascontiguousarray(words, np.uint32); v = np.ascontiguousarray(weights, np.float32)
+        idx = C.c_int()
+        self.ctx._check(self.L.orbfe_kfdb_add(self.ctx.h, _p(w), _p(v), len(w), C.byref(idx)))
+        return idx.value
+
+    def erase(self, kf: int):
+        self.ctx._check(self.L.orbfe_kfdb_erase(self.ctx.h, kf))
+
+    def __len__(self):
+        return self.L.orbfe_kfdb_size(self.ctx.h)
+
+    def score(self, q_words, q_w):
+        w = np.ascontiguousarray(q_words, np.uint32); v = np.ascontiguousarray(q_w, np.float32)
+        n = max(len(self), 1)
+        common = np.zeros(n, np.int32); score = np.zeros(n, np.float32)
+        self.ctx._check(self.L.orbfe_kfdb_score(self.ctx.h, _p(w), _p(v), len(w), _p(common), _p(score)))
+        return common[: len(self)], score[: len(self)]
+
+    def detect_reloc_candidates(self, q_words, q_w, covis_off, covis_idx, reloc_score):
+        w = np.ascontiguousarray(q_words, np.uint32); v = np.ascontiguousarray(q_w, np.float32)
+        co = np.ascontiguousarray(covis_off, np.int32); ci = np.ascontiguousarray(covis_idx, np.int32)
+        assert reloc_score.dtype == np.float32 and reloc_score.flags.c_contiguous and len(reloc_score) >= len(self)
+        cand = np.zeros(max(len(self), 1), np.int32); n = C.c_int()
+        self.ctx._check(self.L.orbfe_detect_reloc_candidates(self.ctx.h, _p(w), _p(v), len(w), _p(co), _p(ci), _p(reloc_score),
+                                                             _p(cand), len(cand), C.byref(n)))
+        return cand[: n.value].copy()
 
 
 def build_vocabulary(desc: np.ndarray, k: int = 10, levels: int = 3, seed: int = 7) -> bytes:

@@ -38,10 +38,18 @@ struct orbfe_bow_state {
     bool loaded = false;
     void *d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    // keyframe database (KeyFrameDatabase): BoW vectors of the keyframes, resident in HBM, CSR by keyframe
+    uint32_t *d_db_words = nullptr;
+    float *d_db_w = nullptr;
+    size_t db_cap = 0;                 // entries allocated
+    std::vector<int> db_off, db_len;   // per keyframe: first entry, number of words (0 after erase)
+    size_t db_used = 0;
     ~orbfe_bow_state()
     {
         if (d_data) hipFree(d_data);
         if (d_scratch) hipFree(d_scratch);
+        if (d_db_words) hipFree(d_db_words);
+        if (d_db_w) hipFree(d_db_w);
     }
 };
 
@@ -339,4 +347,232 @@ extern "C" int orbfe_search_by_bow_kf(orbfe_context *ctx,
 {
     return search_by_bow_impl(ctx, true, nodes1, off1, feat1, nnodes1, valid1, desc1, angle1, n1,
                               nodes2, off2, feat2, nnodes2, valid2, desc2, angle2, n2, nnratio, check_ori, match12, nmatches);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Keyframe database: KeyFrameDatabase::add / erase / clear / DetectRelocalizationCandidates
+// (src/KeyFrameDatabase.cc:38-70,196-307) with fbow::fBow::score (Thirdparty/fbow/src/fbow.cpp:206-256)
+// ---------------------------------------------------------------------------------------------
+#define KFDB_Q_LDS 3072 // query words staged in LDS (longer queries are searched in HBM)
+
+// One wave per keyframe: its words are looked up in the query by binary search, 64 at a time; the matching products are
+// compacted in word order and added by lane 0 SEQUENTIALLY in double -- the association order of fBow::score, which its
+// float result depends on.  Outputs per keyframe: shared-word count, smallest shared word (the inverted file's
+// first-encounter order = ascending (first shared word, keyframe index)), score.
+__global__ __launch_bounds__(256) void kfdb_score_kernel(const uint32_t *__restrict__ q_words, const float *__restrict__ q_w, int nq,
+                                                         const int *__restrict__ kf_off, const int *__restrict__ kf_len,
+                                                         const uint32_t *__restrict__ db_words, const float *__restrict__ db_w, int n_kf,
+                                                         int *__restrict__ common, uint32_t *__restrict__ first_word, float *__restrict__ score)
+{
+    __shared__ uint32_t s_qw[KFDB_Q_LDS];
+    __shared__ float s_qv[KFDB_Q_LDS];
+    __shared__ float s_prod[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool in_lds = nq <= KFDB_Q_LDS;
+    if (in_lds)
+        for (int i = threadIdx.x; i < nq; i += 256) { s_qw[i] = q_words[i]; s_qv[i] = q_w[i]; }
+    __syncthreads();
+    const int kf = blockIdx.x * 4 + wave;
+    if (kf >= n_kf) return;
+    const uint32_t *qw = in_lds ? s_qw : q_words;
+    const float *qv = in_lds ? s_qv : q_w;
+    const int o = kf_off[kf], len = kf_len[kf];
+    double sum = 0.0;
+    int ncommon = 0;
+    uint32_t first = 0xffffffffu;
+    for (int i0 = 0; i0 < len; i0 += 64) {
+        const int i = i0 + lane;
+        bool hit = false;
+        float prod = 0.f;
+        uint32_t w = 0;
+        if (i < len) {
+            w = db_words[o + i];
+            int lo = 0, hi = nq; // first query word >= w
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (qw[mid] < w) lo = mid + 1; else hi = mid;
+            }
+            if (lo < nq && qw[lo] == w) { hit = true; prod = __fmul_rn(qv[lo], db_w[o + i]); }
+        }
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+            if (hit) s_prod[wave][__popcll(m & ((1ull << lane) - 1ull))] = prod;
+            if (first == 0xffffffffu) first = (uint32_t)__shfl((int)w, __ffsll((long long)m) - 1, 64);
+            const int c = __popcll(m);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0)
+                for (int j = 0; j < c; j++) sum = __dadd_rn(sum, (double)s_prod[wave][j]);
+            __builtin_amdgcn_wave_barrier();
+            ncommon += c;
+        }
+    }
+    if (lane == 0) {
+        common[kf] = ncommon;
+        first_word[kf] = first;
+        const double sc = sum >= 1.0 ? 1.0 : 1.0 - sqrt(1.0 - sum);
+        score[kf] = (float)sc;
+    }
+}
+
+extern "C" int orbfe_kfdb_clear(orbfe_context *ctx)
+{
+    if (!ctx) return ORBFE_ERR_INVALID;
+    orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
+    if (!st) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "out of host memory");
+    st->db_off.clear(); st->db_len.clear(); st->db_used = 0;
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_kfdb_add(orbfe_context *ctx, const uint32_t *words, const float *weights, int n, int *kf_index)
+{
+    if (!ctx || n < 0 || (n > 0 && (!words || !weights))) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
+    if (!st) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "out of host memory");
+    for (int i = 1; i < n; i++)
+        if (words[i] <= words[i - 1]) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "BoW words must be strictly ascending (std::map order)");
+    BTRY(ctx, hipSetDevice(orbfe_ctx_device(ctx)));
+    hipStream_t s = orbfe_ctx_stream(ctx);
+    if (st->db_used + (size_t)n > st->db_cap) { // grow: twice the need, contents moved device to device
+        const size_t cap = 2 * (st->db_used + (size_t)n) + 1024;
+        uint32_t *nw = nullptr; float *nv = nullptr;
+        BTRY(ctx, hipMalloc((void **)&nw, cap * sizeof(uint32_t)));
+        if (hipMalloc((void **)&nv, cap * sizeof(float)) != hipSuccess) { hipFree(nw); return orbfe_fail(ctx, ORBFE_ERR_HIP, "hipMalloc failed"); }
+        if (st->db_used) {
+            hipMemcpyAsync(nw, st->d_db_words, st->db_used * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+            hipMemcpyAsync(nv, st->d_db_w, st->db_used * sizeof(float), hipMemcpyDeviceToDevice, s);
+        }
+        BTRY(ctx, hipStreamSynchronize(s));
+        if (st->d_db_words) hipFree(st->d_db_words);
+        if (st->d_db_w) hipFree(st->d_db_w);
+        st->d_db_words = nw; st->d_db_w = nv; st->db_cap = cap;
+    }
+    if (n > 0) {
+        BTRY(ctx, hipMemcpyAsync(st->d_db_words + st->db_used, words, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+        BTRY(ctx, hipMemcpyAsync(st->d_db_w + st->db_used, weights, sizeof(float) * n, hipMemcpyHostToDevice, s));
+        BTRY(ctx, hipStreamSynchronize(s));
+    }
+    if (kf_index) *kf_index = (int)st->db_off.size();
+    st->db_off.push_back((int)st->db_used); st->db_len.push_back(n);
+    st->db_used += (size_t)n;
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_kfdb_erase(orbfe_context *ctx, int kf_index)
+{
+    if (!ctx) return ORBFE_ERR_INVALID;
+    orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
+    if (!st || kf_index < 0 || kf_index >= (int)st->db_len.size()) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "keyframe index out of range");
+    st->db_len[kf_index] = 0; // KeyFrameDatabase::erase: the keyframe leaves every inverted-file list
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_kfdb_size(orbfe_context *ctx)
+{
+    if (!ctx) return 0;
+    orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
+    return st ? (int)st->db_off.size() : 0;
+}
+
+// scores of every keyframe against the query; host vectors out
+static int kfdb_scores(orbfe_context *ctx, orbfe_bow_state *st, const uint32_t *q_words, const float *q_w, int nq,
+                       std::vector<int> &common, std::vector<uint32_t> &first, std::vector<float> &score)
+{
+    const int n_kf = (int)st->db_off.size();
+    common.assign(n_kf > 0 ? n_kf : 1, 0); first.assign(n_kf > 0 ? n_kf : 1, 0xffffffffu); score.assign(n_kf > 0 ? n_kf : 1, 0.f);
+    if (n_kf == 0 || nq == 0) return ORBFE_OK;
+    BTRY(ctx, hipSetDevice(orbfe_ctx_device(ctx)));
+    hipStream_t s = orbfe_ctx_stream(ctx);
+    const size_t need = (size_t)nq * 8 + (size_t)n_kf * 20 + 64;
+    int rc = ensure_scratch(ctx, st, need);
+    if (rc != ORBFE_OK) return rc;
+    uint32_t *d_qw = (uint32_t *)st->d_scratch;
+    float *d_qv = (float *)(d_qw + nq);
+    int *d_off = (int *)(d_qv + nq), *d_len = d_off + n_kf, *d_common = d_len + n_kf;
+    uint32_t *d_first = (uint32_t *)(d_common + n_kf);
+    float *d_score = (float *)(d_first + n_kf);
+    BTRY(ctx, hipMemcpyAsync(d_qw, q_words, sizeof(uint32_t) * nq, hipMemcpyHostToDevice, s));
+    BTRY(ctx, hipMemcpyAsync(d_qv, q_w, sizeof(float) * nq, hipMemcpyHostToDevice, s));
+    BTRY(ctx, hipMemcpyAsync(d_off, st->db_off.data(), sizeof(int) * n_kf, hipMemcpyHostToDevice, s));
+    BTRY(ctx, hipMemcpyAsync(d_len, st->db_len.data(), sizeof(int) * n_kf, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(kfdb_score_kernel, dim3((n_kf + 3) / 4), dim3(256), 0, s, d_qw, d_qv, nq, d_off, d_len, st->d_db_words, st->d_db_w, n_kf,
+                       d_common, d_first, d_score);
+    BTRY(ctx, hipMemcpyAsync(common.data(), d_common, sizeof(int) * n_kf, hipMemcpyDeviceToHost, s));
+    BTRY(ctx, hipMemcpyAsync(first.data(), d_first, sizeof(uint32_t) * n_kf, hipMemcpyDeviceToHost, s));
+    BTRY(ctx, hipMemcpyAsync(score.data(), d_score, sizeof(float) * n_kf, hipMemcpyDeviceToHost, s));
+    BTRY(ctx, hipStreamSynchronize(s));
+    BTRY(ctx, hipGetLastError());
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_kfdb_score(orbfe_context *ctx, const uint32_t *q_words, const float *q_w, int nq, int32_t *common, float *score)
+{
+    if (!ctx || nq < 0 || (nq > 0 && (!q_words || !q_w))) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
+    if (!st) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "out of host memory");
+    std::vector<int> c; std::vector<uint32_t> f; std::vector<float> sc;
+    int rc = kfdb_scores(ctx, st, q_words, q_w, nq, c, f, sc);
+    if (rc != ORBFE_OK) return rc;
+    const int n_kf = (int)st->db_off.size();
+    for (int k = 0; k < n_kf; k++) { if (common) common[k] = c[k]; if (score) score[k] = sc[k]; }
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_detect_reloc_candidates(orbfe_context *ctx, const uint32_t *q_words, const float *q_w, int nq,
+                                             const int32_t *covis_off, const int32_t *covis_idx, float *reloc_score,
+                                             int32_t *cand, int cap, int *n_cand)
+{
+    if (!ctx || !n_cand || nq < 0 || (nq > 0 && (!q_words || !q_w)) || !covis_off || !reloc_score || cap < 0 || (cap > 0 && !cand))
+        return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
+    if (!st) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "out of host memory");
+    *n_cand = 0;
+    const int n_kf = (int)st->db_off.size();
+    std::vector<int> common; std::vector<uint32_t> first; std::vector<float> score;
+    int rc = kfdb_scores(ctx, st, q_words, q_w, nq, common, first, score);
+    if (rc != ORBFE_OK) return rc;
+    // keyframes sharing a word, in the inverted file's first-encounter order (src/KeyFrameDatabase.cc:205-221)
+    std::vector<int> sharing;
+    for (int k = 0; k < n_kf; k++)
+        if (common[k] > 0) sharing.push_back(k);
+    if (sharing.empty()) return ORBFE_OK;
+    std::stable_sort(sharing.begin(), sharing.end(), [&](int a, int b) { return first[a] < first[b]; });
+    int max_common = 0;
+    for (int k : sharing) max_common = common[k] > max_common ? common[k] : max_common;
+    const int min_common = (int)((float)max_common * 0.8f);
+    std::vector<int> sm_kf;
+    for (int k : sharing)
+        if (common[k] > min_common) { reloc_score[k] = score[k]; sm_kf.push_back(k); }
+    if (sm_kf.empty()) return ORBFE_OK;
+    std::vector<float> acc(sm_kf.size());
+    std::vector<int> best_kf(sm_kf.size());
+    float best_acc = 0.f;
+    for (size_t i = 0; i < sm_kf.size(); i++) { // accumulate score by covisibility (:254-277)
+        const int k = sm_kf[i];
+        float best = score[k], a = best;
+        int bk = k;
+        int nn = covis_off[k + 1] - covis_off[k];
+        if (nn > 10) nn = 10;
+        for (int j = 0; j < nn; j++) {
+            const int k2 = covis_idx[covis_off[k] + j];
+            if (k2 < 0 || k2 >= n_kf) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "covisibility index out of range");
+            if (common[k2] <= 0) continue;
+            a += reloc_score[k2];
+            if (reloc_score[k2] > best) { bk = k2; best = reloc_score[k2]; }
+        }
+        acc[i] = a; best_kf[i] = bk;
+        if (a > best_acc) best_acc = a;
+    }
+    const float min_retain = 0.75f * best_acc;
+    std::vector<uint8_t> added(n_kf, 0);
+    int n = 0;
+    for (size_t i = 0; i < sm_kf.size(); i++)
+        if (acc[i] > min_retain && !added[best_kf[i]]) {
+            added[best_kf[i]] = 1;
+            if (n < cap) cand[n] = best_kf[i];
+            n++;
+        }
+    *n_cand = n;
+    if (n > cap) return orbfe_fail(ctx, ORBFE_ERR_CAPACITY, "caller buffer holds %d candidates, %d found", cap, n);
+    return ORBFE_OK;
 }

@@ -138,3 +138,60 @@ def test_gpu_bow_transform_and_search(vocab):
     assert np.mean(perm[np.nonzero(ok)[0][np.nonzero(ok)[0] < 1200]] == ref[ok][np.nonzero(ok)[0] < 1200]) > 0.9
     L.orc_vocab_destroy(v)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_keyframe_database_relocalisation(vocab):
+    """BASELINE config 3's database side: 500 keyframes' BoW vectors in HBM, fBow::score + DetectRelocalizationCandidates
+    (src/KeyFrameDatabase.cc:196-307) == oracle; also erase() and the persistent mRelocScore state (contract Q10)."""
+    from orbslam2_amd import api
+    L, v = _oracle_voc(vocab)
+    L.orc_bow_score.restype = C.c_double
+    L.orc_bow_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_detect_reloc_candidates.restype = C.c_int
+    L.orc_detect_reloc_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int]
+    ctx = api.Context(width=752, height=480, nfeatures=1200)
+    B.vocab_load(ctx, vocab)
+    rng = np.random.default_rng(11)
+    n_kf = 500
+    places = [_descs(100 + p, 1200) for p in range(25)]  # 25 places, 20 keyframes each share most descriptors
+    db = B.KeyFrameDB(ctx)
+    kf_words, kf_w = [], []
+    for k in range(n_kf):
+        base = places[k % 25]
+        d = np.concatenate([base[rng.permutation(1200)[:900]], _descs(2000 + k, 300)])  # a revisit re-detects the same corners
+        _, (words, ww), _ = _oracle_transform(L, v, d)
+        kf_words.append(words.copy()); kf_w.append(ww.copy())
+        assert db.add(words, ww) == k
+    assert len(db) == n_kf
+    kf_off = np.zeros(n_kf + 1, np.int32); kf_off[1:] = np.cumsum([len(w) for w in kf_words])
+    db_words = np.concatenate(kf_words); db_w = np.concatenate(kf_w)
+    covis = [[(k + 25 * j) % n_kf for j in (1, -1, 2, -2, 3)] + [int(x) for x in rng.integers(0, n_kf, 8)] for k in range(n_kf)]  # 13 > 10 listed
+    covis_off = np.zeros(n_kf + 1, np.int32); covis_off[1:] = np.cumsum([len(c) for c in covis])
+    covis_idx = np.concatenate(covis).astype(np.int32)
+    state_ref = np.zeros(n_kf, np.float32); state_gpu = np.zeros(n_kf, np.float32)
+    for q in range(6):
+        place = int(rng.integers(0, 25))
+        qd = np.concatenate([places[place][rng.permutation(1200)[:850]], _descs(4000 + q, 350)])
+        _, (qw, qv), _ = _oracle_transform(L, v, qd)
+        common, score = db.score(qw, qv)
+        for k in rng.integers(0, n_kf, 25):  # fBow::score, bit for bit (float of a double sum in word order)
+            if len(kf_words[k]) == 0:
+                continue
+            ref = np.float32(L.orc_bow_score(_p(qw), _p(qv), len(qw), _p(kf_words[k]), _p(kf_w[k]), len(kf_words[k])))
+            assert score[k] == ref, (q, k, score[k], ref)
+            assert common[k] == len(np.intersect1d(qw, kf_words[k]))
+        cand_ref = np.zeros(n_kf, np.int32)
+        n_ref = L.orc_detect_reloc_candidates(_p(qw), _p(qv), len(qw), n_kf, _p(kf_off), _p(db_words), _p(db_w), _p(covis_off), _p(covis_idx),
+                                              _p(state_ref), _p(cand_ref), n_kf)
+        got = db.detect_reloc_candidates(qw, qv, covis_off, covis_idx, state_gpu)
+        assert got.tolist() == cand_ref[:n_ref].tolist(), q
+        assert np.array_equal(state_gpu, state_ref)
+        assert n_ref >= 1 and (cand_ref[:n_ref] % 25 == place).mean() > 0.8  # the query's place wins
+        if q == 2:  # KeyFrameDatabase::erase: the best candidate leaves the database (both sides)
+            gone = int(cand_ref[0])
+            db.erase(gone)
+            kf_words[gone] = kf_words[gone][:0]; kf_w[gone] = kf_w[gone][:0]
+            kf_off[1:] = np.cumsum([len(w) for w in kf_words]); db_words = np.concatenate(kf_words); db_w = np.concatenate(kf_w)
+    L.orc_vocab_destroy(v)
+    ctx.close()
