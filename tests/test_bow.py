@@ -195,3 +195,38 @@ def test_gpu_keyframe_database_relocalisation(vocab):
             kf_off[1:] = np.cumsum([len(w) for w in kf_words]); db_words = np.concatenate(kf_words); db_w = np.concatenate(kf_w)
     L.orc_vocab_destroy(v)
     ctx.close()
+
+
+def test_oracle_bow_score_and_reloc_known_answers():
+    """fbow::fBow::score and DetectRelocalizationCandidates restatements from first principles (CPU only)."""
+    L = O.lib()
+    L.orc_bow_score.restype = C.c_double
+    L.orc_bow_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_detect_reloc_candidates.restype = C.c_int
+    L.orc_detect_reloc_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int]
+    w = np.array([3, 7, 9, 20], np.uint32); v = np.array([0.5, 0.5, 0.5, 0.5], np.float32)  # unit L2 norm
+    assert L.orc_bow_score(_p(w), _p(v), 4, _p(w), _p(v), 4) == 1.0
+    w2 = np.array([1, 8, 10], np.uint32); v2 = np.array([0.6, 0.0, 0.8], np.float32)
+    assert L.orc_bow_score(_p(w), _p(v), 4, _p(w2), _p(v2), 3) == 0.0  # no shared word
+    w3 = np.array([7, 20, 30], np.uint32); v3 = np.array([0.6, 0.64, 0.48], np.float32)
+    dot = float(np.float32(0.5) * np.float32(0.6)) + float(np.float32(0.5) * np.float32(0.64))
+    assert L.orc_bow_score(_p(w), _p(v), 4, _p(w3), _p(v3), 3) == 1.0 - np.sqrt(1.0 - dot)
+    # database of 4 keyframes; query shares 3 words with kf0, 3 with kf2, 1 with kf1 (filtered: 1 <= int(3 * 0.8) = 2), 0 with kf3
+    kfs = [([3, 7, 9], [0.6, 0.6, 0.5]), ([20, 21], [0.9, 0.4]), ([3, 7, 20], [0.5, 0.5, 0.7]), ([50], [1.0])]
+    kf_off = np.zeros(5, np.int32); kf_off[1:] = np.cumsum([len(a) for a, _ in kfs])
+    dbw = np.concatenate([np.array(a, np.uint32) for a, _ in kfs]); dbv = np.concatenate([np.array(b, np.float32) for _, b in kfs])
+    covis_off = np.array([0, 1, 1, 2, 2], np.int32); covis_idx = np.array([1, 0], np.int32)  # kf0 -> [kf1], kf2 -> [kf0]
+    state = np.array([0.0, 0.25, 0.0, 0.0], np.float32)  # kf1's stale mRelocScore counts for kf0 (Q10)
+    cand = np.zeros(4, np.int32)
+    n = L.orc_detect_reloc_candidates(_p(w), _p(v), 4, 4, _p(kf_off), _p(dbw), _p(dbv), _p(covis_off), _p(covis_idx), _p(state), _p(cand), 4)
+    s0 = np.float32(L.orc_bow_score(_p(w), _p(v), 4, _p(dbw[0:3]), _p(dbv[0:3]), 3))
+    s2 = np.float32(L.orc_bow_score(_p(w), _p(v), 4, _p(dbw[5:8]), _p(dbv[5:8]), 3))
+    assert state[0] == s0 and state[2] == s2 and state[1] == np.float32(0.25) and state[3] == 0
+    acc0 = np.float32(s0 + np.float32(0.25)); acc2 = np.float32(s2 + s0)
+    best0 = 1 if np.float32(0.25) > s0 else 0          # best keyframe of kf0's group
+    best2 = 0 if s0 > s2 else 2
+    expect = []
+    for a, b in ((acc0, best0), (acc2, best2)):
+        if a > np.float32(0.75) * max(acc0, acc2) and b not in expect:
+            expect.append(b)
+    assert cand[:n].tolist() == expect and n >= 1
