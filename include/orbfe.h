@@ -243,6 +243,19 @@ int orbfe_search_by_bow(orbfe_context *ctx,
                         const uint32_t *f_nodes, const int32_t *f_off, const int32_t *f_feat, int f_nnodes,
                         const uint8_t *f_desc, const float *f_angle, int n_f,
                         float nnratio, int check_ori, int32_t *f_match, int *nmatches);
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (src/ORBmatcher.cc:652-819, called by
+ * LocalMapping::CreateNewMapPoints): keypoints without a map point (has_mp == 0) paired inside shared vocabulary nodes
+ * (feature vectors of orbfe_bow_maps), Hamming <= TH_LOW, monocular pairs away from the epipole, CheckDistEpipolarLine
+ * (:138-155) against F12 (3x3 row major).  Cw1 = KF1's camera centre, T2w = KF2's [R|t] (3x4 row major), fx2.. = KF2's
+ * intrinsics; u_right < 0 marks a monocular keypoint.  match12[i1] = KF2 keypoint or -1; the reference's pair list is the
+ * non-negative entries in index order. */
+int orbfe_search_for_triangulation(orbfe_context *ctx,
+                                   const uint32_t *nodes1, const int32_t *off1, const int32_t *feat1, int nnodes1,
+                                   const orbfe_keypoint *keys1, const float *u_right1, const uint8_t *has_mp1, const uint8_t *desc1, int n1,
+                                   const uint32_t *nodes2, const int32_t *off2, const int32_t *feat2, int nnodes2,
+                                   const orbfe_keypoint *keys2, const float *u_right2, const uint8_t *has_mp2, const uint8_t *desc2, int n2,
+                                   const float *F12, const float *Cw1, const float *T2w, float fx2, float fy2, float cx2, float cy2,
+                                   int only_stereo, int check_ori, int32_t *match12, int *nmatches);
 /* ---- keyframe database (KeyFrameDatabase, src/KeyFrameDatabase.cc): the keyframes' BoW vectors stay in HBM ----
  * orbfe_kfdb_add = KeyFrameDatabase::add (:38-44) for one keyframe: its fBow as ascending word ids + weights
  * (orbfe_bow_maps); returns the keyframe's index (insertion order = inverted-file order).  orbfe_kfdb_erase (:46-62)

@@ -371,3 +371,99 @@ int orc_detect_reloc_candidates(const uint32_t *q_words, const float *q_w, int n
     free(inv_off); free(inv); free(cur); free(words); free(seen); free(sharing);
     return n_out;
 }
+
+/* ORBmatcher::CheckDistEpipolarLine (src/ORBmatcher.cc:138-155): float arithmetic left to right, the final comparison
+ * in double (3.84 is a double literal). */
+static int check_dist_epipolar_line(float x1, float y1, float x2, float y2, const float *F12 /*3x3 row major*/, float sigma2_kp2)
+{
+    const float a = x1 * F12[0] + y1 * F12[3] + F12[6];
+    const float b = x1 * F12[1] + y1 * F12[4] + F12[7];
+    const float c = x1 * F12[2] + y1 * F12[5] + F12[8];
+    const float num = a * x2 + b * y2 + c;
+    const float den = a * a + b * b;
+    if (den == 0) return 0;
+    const float dsqr = num * num / den;
+    return (double)dsqr < 3.84 * (double)sigma2_kp2;
+}
+
+/* ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:652-819): keypoints WITHOUT a map point in both keyframes,
+ * paired inside shared vocabulary nodes, Hamming <= TH_LOW, away from the epipole (monocular pairs) and close to the
+ * epipolar line of F12.  has_mp = the keypoint already has a map point; u_right < 0 = monocular keypoint.  Cw1 = camera
+ * centre of KF1, T2w = [R|t] of KF2 (3x4).  match12[idx1] = idx2 or -1; the reference's pair list is its non-negative
+ * entries in index order (:808-814). */
+int orc_search_for_triangulation(const uint32_t *n1, const int32_t *off1, const int32_t *feat1, int nn1,
+                                 const orc_keypoint *k1, const float *ur1, const uint8_t *has_mp1, const uint8_t *desc1, int nk1,
+                                 const uint32_t *n2, const int32_t *off2, const int32_t *feat2, int nn2,
+                                 const orc_keypoint *k2, const float *ur2, const uint8_t *has_mp2, const uint8_t *desc2, int nk2,
+                                 const float *F12, const float *Cw1, const float *T2w, float fx2, float fy2, float cx2, float cy2,
+                                 const float *scale_factors, const float *level_sigma2, int only_stereo, int check_ori, int32_t *match12)
+{
+    /* epipole in the second image (:658-664); cv::Mat R*x+t in float, small-matrix order */
+    float C2[3];
+    for (int i = 0; i < 3; i++) {
+        const float t = (T2w[4 * i] * Cw1[0] + T2w[4 * i + 1] * Cw1[1]) + T2w[4 * i + 2] * Cw1[2];
+        C2[i] = t + T2w[4 * i + 3];
+    }
+    const float invz = 1.0f / C2[2];
+    const float ex = fx2 * C2[0] * invz + cx2;
+    const float ey = fy2 * C2[1] * invz + cy2;
+    int nmatches = 0;
+    for (int i = 0; i < nk1; i++) match12[i] = -1;
+    uint8_t *matched2 = (uint8_t *)calloc((size_t)(nk2 > 0 ? nk2 : 1), 1);
+    int *hist[HISTO_LENGTH], hn[HISTO_LENGTH], hc[HISTO_LENGTH];
+    for (int b = 0; b < HISTO_LENGTH; b++) { hist[b] = NULL; hn[b] = 0; hc[b] = 0; }
+    int a = 0, b = 0;
+    while (a < nn1 && b < nn2) {
+        if (n1[a] == n2[b]) {
+            for (int i1 = off1[a]; i1 < off1[a + 1]; i1++) {
+                const int idx1 = feat1[i1];
+                if (has_mp1[idx1]) continue;
+                const int stereo1 = ur1[idx1] >= 0;
+                if (only_stereo && !stereo1) continue;
+                int best_dist = TH_LOW, best_idx2 = -1;
+                for (int i2 = off2[b]; i2 < off2[b + 1]; i2++) {
+                    const int idx2 = feat2[i2];
+                    if (matched2[idx2] || has_mp2[idx2]) continue;
+                    const int stereo2 = ur2[idx2] >= 0;
+                    if (only_stereo && !stereo2) continue;
+                    const int dist = orc_hamming256(desc1 + (size_t)32 * idx1, desc2 + (size_t)32 * idx2);
+                    if (dist > TH_LOW || dist > best_dist) continue;
+                    if (!stereo1 && !stereo2) {
+                        const float distex = ex - k2[idx2].x, distey = ey - k2[idx2].y;
+                        if (distex * distex + distey * distey < 100 * scale_factors[k2[idx2].octave]) continue;
+                    }
+                    if (check_dist_epipolar_line(k1[idx1].x, k1[idx1].y, k2[idx2].x, k2[idx2].y, F12, level_sigma2[k2[idx2].octave])) {
+                        best_idx2 = idx2;
+                        best_dist = dist;
+                    }
+                }
+                if (best_idx2 >= 0) {
+                    match12[idx1] = best_idx2;
+                    matched2[best_idx2] = 1;
+                    nmatches++;
+                    if (check_ori) {
+                        const int bin = rot_bin(k1[idx1].angle, k2[best_idx2].angle);
+                        if (hn[bin] == hc[bin]) { hc[bin] = hc[bin] ? 2 * hc[bin] : 64; hist[bin] = (int *)realloc(hist[bin], sizeof(int) * (size_t)hc[bin]); }
+                        hist[bin][hn[bin]++] = idx1;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (n1[a] < n2[b]) {
+            while (a < nn1 && n1[a] < n2[b]) a++;
+        } else {
+            while (b < nn2 && n2[b] < n1[a]) b++;
+        }
+    }
+    if (check_ori) {
+        int i1, i2, i3;
+        orc_three_maxima(hn, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int k = 0; k < HISTO_LENGTH; k++) {
+            if (k == i1 || k == i2 || k == i3) continue;
+            for (int j = 0; j < hn[k]; j++) { match12[hist[k][j]] = -1; nmatches--; }
+        }
+    }
+    for (int k = 0; k < HISTO_LENGTH; k++) free(hist[k]);
+    free(matched2);
+    return nmatches;
+}

@@ -27,6 +27,9 @@ def _bind():
     L.orbfe_search_by_bow_kf.restype = C.c_int
     L.orbfe_search_by_bow_kf.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int,
                                          C.c_float, C.c_int, vp, ip]
+    L.orbfe_search_for_triangulation.restype = C.c_int
+    L.orbfe_search_for_triangulation.argtypes = [vp] + ([vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int]) * 2 + [vp, vp, vp] + [C.c_float] * 4 + \
+        [C.c_int, C.c_int, vp, ip]
     L.orbfe_kfdb_clear.restype = C.c_int; L.orbfe_kfdb_clear.argtypes = [vp]
     L.orbfe_kfdb_add.restype = C.c_int; L.orbfe_kfdb_add.argtypes = [vp, vp, vp, C.c_int, ip]
     L.orbfe_kfdb_erase.restype = C.c_int; L.orbfe_kfdb_erase.argtypes = [vp, C.c_int]
@@ -89,6 +92,24 @@ def search_by_bow_kf(ctx, fv1, valid1, desc1, angle1, fv2, valid2, desc2, angle2
                                         _p(b_n), _p(b_o), _p(b_f), len(b_n), _p(v2), _p(d2), _p(g2), len(d2),
                                         nnratio, int(check_ori), _p(out), C.byref(nm)))
     return out[: len(d1)].copy(), nm.value
+
+
+def search_for_triangulation(ctx, fv1, keys1, ur1, has_mp1, desc1, fv2, keys2, ur2, has_mp2, desc2, F12, Cw1, T2w, fx2, fy2, cx2, cy2,
+                             only_stereo, check_ori):
+    """ORBmatcher::SearchForTriangulation: match12[i1] = KF2 keypoint or -1, and the count."""
+    from .api import KP_DTYPE
+    L = _bind()
+    a_n, a_o, a_f = (np.ascontiguousarray(a) for a in fv1); b_n, b_o, b_f = (np.ascontiguousarray(a) for a in fv2)
+    k1 = np.ascontiguousarray(keys1, KP_DTYPE); k2 = np.ascontiguousarray(keys2, KP_DTYPE)
+    u1 = np.ascontiguousarray(ur1, np.float32); u2 = np.ascontiguousarray(ur2, np.float32)
+    m1 = np.ascontiguousarray(has_mp1, np.uint8); m2 = np.ascontiguousarray(has_mp2, np.uint8)
+    d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+    F = np.ascontiguousarray(F12, np.float32); cw = np.ascontiguousarray(Cw1, np.float32); T = np.ascontiguousarray(T2w, np.float32)
+    out = np.zeros(max(len(k1), 1), np.int32); nm = C.c_int()
+    ctx._check(L.orbfe_search_for_triangulation(ctx.h, _p(a_n), _p(a_o), _p(a_f), len(a_n), _p(k1), _p(u1), _p(m1), _p(d1), len(k1),
+                                                _p(b_n), _p(b_o), _p(b_f), len(b_n), _p(k2), _p(u2), _p(m2), _p(d2), len(k2),
+                                                _p(F), _p(cw), _p(T), fx2, fy2, cx2, cy2, int(only_stereo), int(check_ori), _p(out), C.byref(nm)))
+    return out[: len(k1)].copy(), nm.value
 
 
 class KeyFrameDB:

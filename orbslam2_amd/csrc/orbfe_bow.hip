@@ -576,3 +576,140 @@ extern "C" int orbfe_detect_reloc_candidates(orbfe_context *ctx, const uint32_t 
     if (n > cap) return orbfe_fail(ctx, ORBFE_ERR_CAPACITY, "caller buffer holds %d candidates, %d found", cap, n);
     return ORBFE_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:652-819; LocalMapping::CreateNewMapPoints)
+// ---------------------------------------------------------------------------------------------
+// ORBmatcher::CheckDistEpipolarLine (:138-155): float arithmetic left to right, the last comparison in double
+static bool check_dist_epipolar_line(float x1, float y1, float x2, float y2, const float *F12, float sigma2_kp2)
+{
+    const float a = x1 * F12[0] + y1 * F12[3] + F12[6];
+    const float b = x1 * F12[1] + y1 * F12[4] + F12[7];
+    const float c = x1 * F12[2] + y1 * F12[5] + F12[8];
+    const float num = a * x2 + b * y2 + c;
+    const float den = a * a + b * b;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return (double)dsqr < 3.84 * (double)sigma2_kp2;
+}
+
+extern "C" int orbfe_search_for_triangulation(orbfe_context *ctx,
+                                              const uint32_t *nodes1, const int32_t *off1, const int32_t *feat1, int nnodes1,
+                                              const orbfe_keypoint *keys1, const float *u_right1, const uint8_t *has_mp1, const uint8_t *desc1, int n1,
+                                              const uint32_t *nodes2, const int32_t *off2, const int32_t *feat2, int nnodes2,
+                                              const orbfe_keypoint *keys2, const float *u_right2, const uint8_t *has_mp2, const uint8_t *desc2, int n2,
+                                              const float *F12, const float *Cw1, const float *T2w, float fx2, float fy2, float cx2, float cy2,
+                                              int only_stereo, int check_ori, int32_t *match12, int *nmatches)
+{
+    if (!ctx || !nmatches || n1 < 0 || n2 < 0 || nnodes1 < 0 || nnodes2 < 0 || (n1 > 0 && !match12) || !F12 || !Cw1 || !T2w ||
+        (nnodes1 > 0 && (!nodes1 || !off1 || !feat1 || !keys1 || !u_right1 || !has_mp1 || !desc1)) ||
+        (nnodes2 > 0 && (!nodes2 || !off2 || !feat2 || !keys2 || !u_right2 || !has_mp2 || !desc2)))
+        return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
+    if (!st) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "out of host memory");
+    const int nlevels = orbfe_ctx_params(ctx)->nlevels;
+    const float *scale = orbfe_ctx_scale_factors(ctx);
+    for (int j = 0; j < n1; j++) match12[j] = -1;
+    *nmatches = 0;
+    // epipole in the second image (:658-664): cv::Mat R*x+t in float, small-matrix evaluation order
+    float C2[3];
+    for (int i = 0; i < 3; i++) {
+        const float t = (T2w[4 * i] * Cw1[0] + T2w[4 * i + 1] * Cw1[1]) + T2w[4 * i + 2] * Cw1[2];
+        C2[i] = t + T2w[4 * i + 3];
+    }
+    const float invz = 1.0f / C2[2];
+    const float ex = fx2 * C2[0] * invz + cx2;
+    const float ey = fy2 * C2[1] * invz + cy2;
+    // pairs of the shared nodes whose endpoints pass the per-keypoint filters; Hamming distances on the device
+    struct Seg { int a, b, pair0; };
+    std::vector<Seg> segs;
+    std::vector<uint32_t> pa, pb;
+    auto usable1 = [&](int i) { return !has_mp1[i] && !(only_stereo && !(u_right1[i] >= 0)); };
+    auto usable2 = [&](int i) { return !has_mp2[i] && !(only_stereo && !(u_right2[i] >= 0)); };
+    for (int a = 0, b = 0; a < nnodes1 && b < nnodes2;) {
+        if (nodes1[a] == nodes2[b]) {
+            segs.push_back(Seg{a, b, (int)pa.size()});
+            for (int i1 = off1[a]; i1 < off1[a + 1]; i1++) {
+                if (feat1[i1] < 0 || feat1[i1] >= n1) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "KF1 feature index out of range");
+                if (!usable1(feat1[i1])) continue;
+                for (int i2 = off2[b]; i2 < off2[b + 1]; i2++) {
+                    if (feat2[i2] < 0 || feat2[i2] >= n2) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "KF2 feature index out of range");
+                    if (keys2[feat2[i2]].octave < 0 || keys2[feat2[i2]].octave >= nlevels) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "octave out of range");
+                    if (!usable2(feat2[i2])) continue;
+                    pa.push_back((uint32_t)feat1[i1]); pb.push_back((uint32_t)feat2[i2]);
+                }
+            }
+            a++; b++;
+        } else if (nodes1[a] < nodes2[b]) a++;
+        else b++;
+    }
+    const int np = (int)pa.size();
+    std::vector<uint16_t> dist(np > 0 ? np : 1);
+    if (np > 0) {
+        hipStream_t s = orbfe_ctx_stream(ctx);
+        BTRY(ctx, hipSetDevice(orbfe_ctx_device(ctx)));
+        const size_t need = (size_t)32 * n1 + (size_t)32 * n2 + (size_t)np * (4 + 4 + 2) + 64;
+        int rc = ensure_scratch(ctx, st, need);
+        if (rc != ORBFE_OK) return rc;
+        uint8_t *d_a = (uint8_t *)st->d_scratch, *d_b = d_a + (size_t)32 * n1;
+        uint32_t *d_pa = (uint32_t *)(d_b + (size_t)32 * n2), *d_pb = d_pa + np;
+        uint16_t *d_dist = (uint16_t *)(d_pb + np);
+        BTRY(ctx, hipMemcpyAsync(d_a, desc1, (size_t)32 * n1, hipMemcpyHostToDevice, s));
+        BTRY(ctx, hipMemcpyAsync(d_b, desc2, (size_t)32 * n2, hipMemcpyHostToDevice, s));
+        BTRY(ctx, hipMemcpyAsync(d_pa, pa.data(), sizeof(uint32_t) * np, hipMemcpyHostToDevice, s));
+        BTRY(ctx, hipMemcpyAsync(d_pb, pb.data(), sizeof(uint32_t) * np, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(pair_hamming_kernel, dim3((np + 255) / 256), dim3(256), 0, s, d_a, d_b, d_pa, d_pb, np, d_dist);
+        BTRY(ctx, hipMemcpyAsync(dist.data(), d_dist, sizeof(uint16_t) * np, hipMemcpyDeviceToHost, s));
+        BTRY(ctx, hipStreamSynchronize(s));
+        BTRY(ctx, hipGetLastError());
+    }
+    // sequential resolve in the reference's order (vbMatched2 makes it order dependent)
+    std::vector<uint8_t> matched2(n2 > 0 ? n2 : 1, 0);
+    std::vector<int> hist[HISTO_LENGTH];
+    std::vector<float> sigma2(nlevels);
+    for (int l = 0; l < nlevels; l++) sigma2[l] = scale[l] * scale[l]; // mvLevelSigma2 (src/ORBextractor.cc:419-423)
+    int nm = 0;
+    for (const Seg &sg : segs) {
+        int pi = sg.pair0;
+        for (int i1 = off1[sg.a]; i1 < off1[sg.a + 1]; i1++) {
+            const int idx1 = feat1[i1];
+            if (!usable1(idx1)) continue;
+            const bool stereo1 = u_right1[idx1] >= 0;
+            int best_dist = TH_LOW, best_idx2 = -1;
+            for (int i2 = off2[sg.b]; i2 < off2[sg.b + 1]; i2++) {
+                const int idx2 = feat2[i2];
+                if (!usable2(idx2)) continue;
+                const int d = dist[pi++];
+                if (matched2[idx2]) continue;
+                if (d > TH_LOW || d > best_dist) continue;
+                const bool stereo2 = u_right2[idx2] >= 0;
+                if (!stereo1 && !stereo2) {
+                    const float distex = ex - keys2[idx2].x, distey = ey - keys2[idx2].y;
+                    if (distex * distex + distey * distey < 100 * scale[keys2[idx2].octave]) continue;
+                }
+                if (check_dist_epipolar_line(keys1[idx1].x, keys1[idx1].y, keys2[idx2].x, keys2[idx2].y, F12, sigma2[keys2[idx2].octave])) {
+                    best_idx2 = idx2;
+                    best_dist = d;
+                }
+            }
+            if (best_idx2 >= 0) {
+                match12[idx1] = best_idx2;
+                matched2[best_idx2] = 1;
+                nm++;
+                if (check_ori) hist[rot_bin(keys1[idx1].angle, keys2[best_idx2].angle)].push_back(idx1);
+            }
+        }
+    }
+    if (check_ori) {
+        int32_t sizes[HISTO_LENGTH];
+        for (int b = 0; b < HISTO_LENGTH; b++) sizes[b] = (int32_t)hist[b].size();
+        int i1, i2, i3;
+        orbfe_three_maxima(sizes, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int b = 0; b < HISTO_LENGTH; b++) {
+            if (b == i1 || b == i2 || b == i3) continue;
+            for (int idx : hist[b]) { match12[idx] = -1; nm--; }
+        }
+    }
+    *nmatches = nm;
+    return ORBFE_OK;
+}

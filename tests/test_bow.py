@@ -230,3 +230,68 @@ def test_oracle_bow_score_and_reloc_known_answers():
         if a > np.float32(0.75) * max(acc0, acc2) and b not in expect:
             expect.append(b)
     assert cand[:n].tolist() == expect and n >= 1
+
+
+@pytest.mark.gpu
+def test_gpu_search_for_triangulation(vocab):
+    """ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:652-819) == oracle on two keyframes that see the same 3-D
+    points from poses 0.4 m apart: unmatched keypoints, epipole exclusion, epipolar-line gate, rotation pruning."""
+    from orbslam2_amd import api
+    L, v = _oracle_voc(vocab)
+    L.orc_search_for_triangulation.restype = C.c_int
+    L.orc_search_for_triangulation.argtypes = ([C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int]) * 2 + [C.c_void_p] * 3 + \
+        [C.c_float] * 4 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    fx = fy = 500.0; cx, cy = 320.0, 240.0
+    ctx = api.Context(width=640, height=480, nfeatures=1000, fx=fx, fy=fy, cx=cx, cy=cy, bf=40.0)
+    B.vocab_load(ctx, vocab)
+    t = ctx.tables()
+    rng = np.random.default_rng(21)
+    n = 1400
+    P = np.stack([rng.uniform(-6, 6, n), rng.uniform(-4, 4, n), rng.uniform(4, 30, n)], axis=1)
+    T1 = np.concatenate([np.eye(3), np.zeros((3, 1))], axis=1)
+    a = np.deg2rad(3.0)
+    R2 = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    T2 = np.concatenate([R2, np.array([[-0.4], [0.02], [0.05]])], axis=1)
+
+    def view(T, seed, desc_base):
+        r = np.random.default_rng(seed)
+        pc = (T[:, :3] @ P.T).T + T[:, 3]
+        k = np.zeros(n, api.KP_DTYPE)
+        k["x"] = fx * pc[:, 0] / pc[:, 2] + cx + r.normal(0, 0.4, n); k["y"] = fy * pc[:, 1] / pc[:, 2] + cy + r.normal(0, 0.4, n)
+        k["octave"] = r.integers(0, 8, n); k["angle"] = (desc_base[1] + r.normal(0, 4, n)) % 360; k["size"] = 31; k["class_id"] = -1
+        d = desc_base[0] ^ np.packbits(r.random((n, 256)) < 0.03, axis=1, bitorder="little")
+        ur = np.where(r.random(n) < 0.5, k["x"] - 40.0 / pc[:, 2], -1.0).astype(np.float32)
+        has_mp = (r.random(n) < 0.3).astype(np.uint8)
+        return k, d, ur, has_mp
+
+    base = (_descs(9, n), rng.uniform(0, 360, n))
+    k1, d1, ur1, mp1 = view(T1, 1, base)
+    k2, d2, ur2, mp2 = view(T2, 2, base)
+    _, _, fv1 = _oracle_transform(L, v, d1)
+    _, _, fv2 = _oracle_transform(L, v, d2)
+    # F12 = K^-T [t12]x R12 K^-1 (LocalMapping::ComputeF12), computed in double and handed over as float
+    R12 = T1[:, :3] @ T2[:, :3].T
+    t12 = -R12 @ T2[:, 3] + T1[:, 3]
+    tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    F12 = (np.linalg.inv(K).T @ tx @ R12 @ np.linalg.inv(K)).astype(np.float32)
+    Cw1 = (-T1[:, :3].T @ T1[:, 3]).astype(np.float32)
+    T2f = T2.astype(np.float32)
+    sf = np.ascontiguousarray(t["scale"], np.float32); s2 = np.ascontiguousarray(t["sigma2"], np.float32)
+    total = 0
+    for only_stereo, ori in ((False, True), (True, True), (False, False)):
+        ref = np.zeros(n, np.int32)
+        nref = L.orc_search_for_triangulation(_p(fv1[0]), _p(fv1[1]), _p(fv1[2]), len(fv1[0]), _p(k1), _p(ur1), _p(mp1), _p(d1), n,
+                                              _p(fv2[0]), _p(fv2[1]), _p(fv2[2]), len(fv2[0]), _p(k2), _p(ur2), _p(mp2), _p(d2), n,
+                                              _p(F12), _p(Cw1), _p(T2f), fx, fy, cx, cy, _p(sf), _p(s2), int(only_stereo), int(ori), _p(ref))
+        got, ngot = B.search_for_triangulation(ctx, fv1, k1, ur1, mp1, d1, fv2, k2, ur2, mp2, d2, F12, Cw1, T2f, fx, fy, cx, cy, only_stereo, ori)
+        assert ngot == nref and np.array_equal(got, ref)
+        ok = ref >= 0
+        assert nref == int(ok.sum()) and not mp1[ok].any() and not mp2[ref[ok]].any()
+        if only_stereo:
+            assert (ur1[ok] >= 0).all() and (ur2[ref[ok]] >= 0).all()
+        assert (ref[ok] == np.nonzero(ok)[0]).mean() > 0.9  # same 3-D point index on both sides
+        total += nref
+    assert total > 300
+    L.orc_vocab_destroy(v)
+    ctx.close()
