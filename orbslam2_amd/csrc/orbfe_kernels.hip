@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(OT_THREADS) void octree_generic_kernel(DeviceConfig
 // keypoint i is computed from LDS, so the global-load latency is off the critical path.
 #define DS_PATCH_W 40 // bytes per staged patch row (10 words: covers 31+3 / 37+3 px at any alignment)
 #define DS_KPW 4      // keypoint slots per wave
-#define DS_RAW_REGS 8 // prefetch registers for the raw patch (raw_rows * 10 words <= 512, i.e. half_patch <= 25)
+#define DS_RAW_REGS 5 // prefetch registers for the raw patch (raw_rows * 10 words <= 320, i.e. half_patch <= 15)
 #define DS_BLR_REGS 6 // 37 rows * 10 words = 370 words
 
 
@@ -1164,19 +1164,34 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, Devi
     const int r0 = lane / (DS_PATCH_W / 4), c0 = lane - r0 * (DS_PATCH_W / 4);
     const bool raw_in_regs = raw_words <= 64 * DS_RAW_REGS;
     uint32_t pr[DS_RAW_REGS], pb[DS_BLR_REGS];
-    // word i = lane + 64*k of a staged patch is (row i / 10, word i % 10); rows advance by 6 and words by 4
-    // per step, so the (quarter-rate) integer multiplies and the division stay out of the loops
-    auto fetch = [&](const uint8_t *img_base, const LevelInfo &L, int x_al, int y_top, uint32_t *dst, int nregs, int nwords) {
-        const uint8_t *gp = img_base + (ptrdiff_t)__mul24(y_top + r0, L.pitch) + x_al + 4 * c0;
-        const int step = 6 * L.pitch + 16, wrap = L.pitch - DS_PATCH_W;
-        int c = c0;
+    // Word i = lane + 64*k of a staged patch is (row i / 10, word i % 10).  The (row, 4 * word) pairs of this lane's words are
+    // computed once per wave and packed two per register (raw | blurred << 16, each row | 4 * word << 8); a patch word is then
+    // one mad away from a wave-uniform base address (scalar registers), instead of 64-bit per-lane pointer stepping with
+    // per-load predication -- that bookkeeping used to be 40 % of the kernel's VALU instructions.  Words past the end of a
+    // patch repeat its last word (same value to the same LDS slot), so nothing is predicated.
+    const int blr_words = 37 * (DS_PATCH_W / 4);
+    uint32_t wtab[DS_BLR_REGS];
+#pragma unroll
+    for (int k = 0; k < DS_BLR_REGS; k++) {
+        const int i = lane + 64 * k;
+        const int ir = i < raw_words ? i : raw_words - 1, ib = i < blr_words ? i : blr_words - 1;
+        const int rr = (ir * 6554) >> 16, rb = (ib * 6554) >> 16; // / 10 for i < 16384
+        wtab[k] = (uint32_t)(rr | ((4 * (ir - 10 * rr)) << 8)) | ((uint32_t)(rb | ((4 * (ib - 10 * rb)) << 8)) << 16);
+    }
+    const int lds_last_raw = 4 * (lane + 64 * (DS_RAW_REGS - 1) < raw_words ? lane + 64 * (DS_RAW_REGS - 1) : raw_words - 1);
+    const int lds_last_blr = 4 * (lane + 64 * (DS_BLR_REGS - 1) < blr_words ? lane + 64 * (DS_BLR_REGS - 1) : blr_words - 1);
+    auto fetch_raw = [&](const uint8_t *base /* uniform: patch origin */, int pitch) {
 #pragma unroll
         for (int k = 0; k < DS_RAW_REGS; k++) {
-            if (k < nregs) {
-                if (lane + 64 * k < nwords) dst[k] = *(const uint32_t *)gp;
-                gp += step; c += 4;
-                if (c >= DS_PATCH_W / 4) { c -= DS_PATCH_W / 4; gp += wrap; }
-            }
+            const unsigned e = wtab[k] & 0xffffu;
+            pr[k] = *(const uint32_t *)(base + (unsigned)__mul24(e & 0xffu, pitch) + (e >> 8));
+        }
+    };
+    auto fetch_blr = [&](const uint8_t *base, int pitch) {
+#pragma unroll
+        for (int k = 0; k < DS_BLR_REGS; k++) {
+            const unsigned e = wtab[k] >> 16;
+            pb[k] = *(const uint32_t *)(base + (unsigned)__mul24(e & 0xffu, pitch) + (e >> 8));
         }
     };
     // slot i of this wave: uniform keypoint data; returns false if the slot holds no keypoint
@@ -1196,13 +1211,14 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, Devi
     auto prefetch_raw = [&](int i) -> bool {
         if (i >= DS_KPW || !slot_data(i)) return false;
         const LevelInfo &L = cfg.lv[level];
-        if (raw_in_regs) fetch(buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off, L, (cx - hp) & ~3, cy - hp, pr, DS_RAW_REGS, raw_words);
+        if (raw_in_regs)
+            fetch_raw(buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (ptrdiff_t)(cy - hp) * L.pitch + ((cx - hp) & ~3), L.pitch);
         return true;
     };
     auto prefetch_blur = [&](int i) -> bool {
         if (i >= DS_KPW || !slot_data(i)) return false;
         const LevelInfo &L = cfg.lv[level];
-        fetch(buf.blur + (size_t)img * cfg.pyr_bytes + L.pyr_off, L, (cx - 18) & ~3, cy - 18, pb, DS_BLR_REGS, 37 * (DS_PATCH_W / 4));
+        fetch_blr(buf.blur + (size_t)img * cfg.pyr_bytes + L.pyr_off + (ptrdiff_t)(cy - 18) * L.pitch + ((cx - 18) & ~3), L.pitch);
         return true;
     };
 
@@ -1218,9 +1234,11 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, Devi
         if (cur) {
             slot_data(i);
             kx = cx; ky = cy; lv = level;
+            if (raw_in_regs) {
 #pragma unroll
-            for (int k = 0; k < DS_RAW_REGS; k++)
-                if (raw_in_regs && lane + 64 * k < raw_words) ((uint32_t *)s_raw)[lane + 64 * k] = pr[k];
+                for (int k = 0; k < DS_RAW_REGS - 1; k++) ((uint32_t *)s_raw)[lane + 64 * k] = pr[k];
+                *(uint32_t *)(s_raw + lds_last_raw) = pr[DS_RAW_REGS - 1];
+            }
             if (!raw_in_regs) { // big patches: straight through (no prefetch)
                 const LevelInfo &Lr = cfg.lv[lv];
                 const uint8_t *gp = buf.pyr + (size_t)img * cfg.pyr_bytes + Lr.pyr_off + (ptrdiff_t)__mul24(ky - hp + r0, Lr.pitch) + ((kx - hp) & ~3) + 4 * c0;
@@ -1268,8 +1286,8 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, Devi
             slot_data(i);
             lv = level; kx = cx; ky = cy; ksc = score; kout = out;
 #pragma unroll
-            for (int k = 0; k < DS_BLR_REGS; k++)
-                if (lane + 64 * k < 37 * (DS_PATCH_W / 4)) ((uint32_t *)s_blr)[lane + 64 * k] = pb[k];
+            for (int k = 0; k < DS_BLR_REGS - 1; k++) ((uint32_t *)s_blr)[lane + 64 * k] = pb[k];
+            *(uint32_t *)(s_blr + lds_last_blr) = pb[DS_BLR_REGS - 1];
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
