@@ -1126,7 +1126,8 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, Devi
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int img = (jb / bpi) * 8 + xcd;
     if (img >= n_images) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform values must be provably so: they feed scalar addresses
     const int slot0 = (jb % bpi) * (4 * DS_KPW) + wave * DS_KPW;
     const int hp = cfg.half_patch;
     const int raw_rows = 2 * hp + 1;
@@ -1184,14 +1185,14 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, Devi
 #pragma unroll
         for (int k = 0; k < DS_RAW_REGS; k++) {
             const unsigned e = wtab[k] & 0xffffu;
-            pr[k] = *(const uint32_t *)(base + (unsigned)__mul24(e & 0xffu, pitch) + (e >> 8));
+            pr[k] = *(const uint32_t *)(base + ((unsigned)__mul24(e & 0xffu, pitch) + (e >> 8))); // one 32-bit offset: saddr + voffset
         }
     };
     auto fetch_blr = [&](const uint8_t *base, int pitch) {
 #pragma unroll
         for (int k = 0; k < DS_BLR_REGS; k++) {
             const unsigned e = wtab[k] >> 16;
-            pb[k] = *(const uint32_t *)(base + (unsigned)__mul24(e & 0xffu, pitch) + (e >> 8));
+            pb[k] = *(const uint32_t *)(base + ((unsigned)__mul24(e & 0xffu, pitch) + (e >> 8)));
         }
     };
     // slot i of this wave: uniform keypoint data; returns false if the slot holds no keypoint
@@ -1202,8 +1203,8 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, Devi
         const uint32_t xy = (uint32_t)__builtin_amdgcn_readlane((int)xy_l, i);
         score = __builtin_amdgcn_readlane(score_l, i);
         const int k = slot0 + i - cfg.lv[level].sel_off;
-        if (k >= __shfl(c_l, level, 64)) return false;
-        out = k + __shfl(excl, level, 64);
+        if (k >= __builtin_amdgcn_readlane(c_l, level)) return false; // readlane (not a shuffle): the result is a scalar
+        out = k + __builtin_amdgcn_readlane(excl, level);
         cx = (int)(xy & 0xffffu) + cfg.min_border;
         cy = (int)(xy >> 16) + cfg.min_border;
         return true;
