@@ -32,11 +32,23 @@ __device__ __attribute__((aligned(16))) const int8_t g_pattern[1024] = {
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// Sum over the 64 lanes (all active) with DPP row operations: six v_add_u32_dpp and one v_readlane instead of six
+// ds_bpermute round trips with their address arithmetic.  Quad xor 1, quad xor 2, row_half_mirror, row_mirror leave every
+// 16-lane row holding its row sum; row_bcast:15 / row_bcast:31 then accumulate the rows into lane 63.
+__device__ __forceinline__ int row_sum_i32(int v) // every lane of a 16-lane row gets the row's sum
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true); // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true); // row_mirror
+    return v;
+}
 __device__ __forceinline__ int wave_sum_i32(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = row_sum_i32(v);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
 {
@@ -1385,12 +1397,7 @@ __device__ __forceinline__ unsigned group_min_u32(unsigned v)
     }
     return v;
 }
-__device__ __forceinline__ int group_sum_i32(int v)
-{
-#pragma unroll
-    for (int o = SM_G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ int group_sum_i32(int v) { return row_sum_i32(v); } // SM_G == 16 == one DPP row
 
 __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_pairs)
 {
