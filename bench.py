@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU (in flight in HBM; BASELINE.json config 4 batches 64 pairs)")
     ap.add_argument("--streams", type=int, default=1, help="stream groups the batch is cut into inside the library (1 keeps per-kernel times clean; 2 overlaps stages, ~+5%)")
-    ap.add_argument("--cpu-pairs", type=int, default=40, help="pairs in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-pairs", type=int, default=300, help="pairs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run oracle spot check")
     args = ap.parse_args()
