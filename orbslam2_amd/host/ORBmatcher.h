@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/orbfe.h"
@@ -155,6 +156,30 @@ public:
                                      feat2.feat.data(), (int)feat2.nodes.size(), valid2.data(), desc2.data(), angle2.data(), n2,
                                      mfNNratio, mbCheckOrientation ? 1 : 0, vnMatches12.data(), &n));
         vnMatches12.resize(n1);
+        return n;
+    }
+
+    // SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo), src/ORBmatcher.cc:652 (LocalMapping::CreateNewMapPoints).
+    // hasMapPoint = the keypoint already has a map point; Cw1 = pKF1->GetCameraCenter(), T2w = top 3x4 rows of pKF2's pose.
+    int SearchForTriangulation(const FeatVec &feat1, const std::vector<orbfe_keypoint> &keysUn1, const std::vector<float> &uRight1,
+                               const std::vector<uint8_t> &hasMapPoint1, const std::vector<uint8_t> &desc1,
+                               const FeatVec &feat2, const std::vector<orbfe_keypoint> &keysUn2, const std::vector<float> &uRight2,
+                               const std::vector<uint8_t> &hasMapPoint2, const std::vector<uint8_t> &desc2,
+                               const float F12[9], const float Cw1[3], const float T2w[12], float fx2, float fy2, float cx2, float cy2,
+                               std::vector<std::pair<size_t, size_t> > &vMatchedPairs, bool bOnlyStereo)
+    {
+        const int n1 = (int)keysUn1.size(), n2 = (int)keysUn2.size();
+        std::vector<int32_t> m12(n1 > 0 ? n1 : 1, -1);
+        int n = 0;
+        Check(orbfe_search_for_triangulation(mCtx, feat1.nodes.data(), feat1.off.data(), feat1.feat.data(), (int)feat1.nodes.size(),
+                                             keysUn1.data(), uRight1.data(), hasMapPoint1.data(), desc1.data(), n1,
+                                             feat2.nodes.data(), feat2.off.data(), feat2.feat.data(), (int)feat2.nodes.size(),
+                                             keysUn2.data(), uRight2.data(), hasMapPoint2.data(), desc2.data(), n2,
+                                             F12, Cw1, T2w, fx2, fy2, cx2, cy2, bOnlyStereo ? 1 : 0, mbCheckOrientation ? 1 : 0, m12.data(), &n));
+        vMatchedPairs.clear();
+        vMatchedPairs.reserve(n);
+        for (int i = 0; i < n1; i++)
+            if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[i]));
         return n;
     }
 

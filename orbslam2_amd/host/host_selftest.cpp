@@ -9,6 +9,7 @@
 
 #include "ORBextractor.h"
 #include "ORBmatcher.h"
+#include "KeyFrameDatabase.h"
 
 static std::vector<uint8_t> slurp(const char *path, size_t n)
 {
