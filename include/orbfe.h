@@ -243,6 +243,14 @@ int orbfe_search_by_bow(orbfe_context *ctx,
                         const uint32_t *f_nodes, const int32_t *f_off, const int32_t *f_feat, int f_nnodes,
                         const uint8_t *f_desc, const float *f_angle, int n_f,
                         float nnratio, int check_ori, int32_t *f_match, int *nmatches);
+/* Search part of ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, th) (src/ORBmatcher.cc:821-971, called by
+ * LocalMapping::SearchInNeighbors): best_idx[i] = keypoint of `kf` that map point i would be fused with, or -1.  The
+ * caller then replaces / adds observations exactly as :943-964 (that mutation never feeds back into the search).
+ * pt_valid = pMP && !isBad() && !IsInKeyFrame(pKF); max_distance / min_distance = mfMaxDistance / mfMinDistance; normal =
+ * GetNormal(); camera and pyramid parameters are the context's. */
+int orbfe_fuse(orbfe_context *ctx, const orbfe_frame_view *kf, const float *Tcw, int n_pts,
+               const float *pos, const float *normal, const float *max_distance, const float *min_distance,
+               const uint8_t *pt_desc, const int32_t *pt_valid, float th, int32_t *best_idx, int *n_fused);
 /* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (src/ORBmatcher.cc:652-819, called by
  * LocalMapping::CreateNewMapPoints): keypoints without a map point (has_mp == 0) paired inside shared vocabulary nodes
  * (feature vectors of orbfe_bow_maps), Hamming <= TH_LOW, monocular pairs away from the epipole, CheckDistEpipolarLine

@@ -216,6 +216,23 @@ def search_by_projection_kf(grid, desc_cur, scale_factors, cam, Tcw_cur, log_sca
     return out[: len(grid.keys)].copy(), n
 
 
+def fuse(grid, u_right_kf, desc_kf, scale_factors, inv_level_sigma2, cam, Tcw, log_scale_factor, n_levels, pos, normal,
+         max_distance, min_distance, pt_desc, pt_valid, th):
+    """Search part of ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th): (best keypoint per map point or -1, count)."""
+    L = lib()
+    L.orc_fuse.restype = C.c_int
+    L.orc_fuse.argtypes = [C.c_void_p] * 5 + [C.POINTER(Camera), C.c_void_p, C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_void_p]
+    ur = _opt(u_right_kf, np.float32); d = np.ascontiguousarray(desc_kf, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32); inv = np.ascontiguousarray(inv_level_sigma2, np.float32)
+    t = np.ascontiguousarray(Tcw, np.float32); p = np.ascontiguousarray(pos, np.float32); nrm = np.ascontiguousarray(normal, np.float32)
+    mx = np.ascontiguousarray(max_distance, np.float32); mn = np.ascontiguousarray(min_distance, np.float32)
+    pd = np.ascontiguousarray(pt_desc, np.uint8); ok = np.ascontiguousarray(pt_valid, np.int32)
+    out = np.zeros(max(len(ok), 1), np.int32)
+    n = L.orc_fuse(grid.h, None if ur is None else _ptr(ur), _ptr(d), _ptr(sf), _ptr(inv), C.byref(cam), _ptr(t), log_scale_factor, n_levels,
+                   len(ok), _ptr(p), _ptr(nrm), _ptr(mx), _ptr(mn), _ptr(pd), _ptr(ok), th, _ptr(out))
+    return out[: len(ok)].copy(), n
+
+
 def search_for_initialization(keys1, desc1, grid2, desc2, prev_matched, window_size, nnratio, check_ori):
     k1 = np.ascontiguousarray(keys1); d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
     pm = np.ascontiguousarray(prev_matched, np.float32).copy()

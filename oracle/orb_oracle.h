@@ -174,6 +174,10 @@ int orc_search_by_bow_kf(const uint32_t *n1, const int32_t *off1, const int32_t 
                          const uint32_t *n2, const int32_t *off2, const int32_t *feat2, int nn2,
                          const int32_t *valid2, const uint8_t *desc2, const float *angle2, int nk2,
                          float nnratio, int check_ori, int32_t *match12);
+int orc_fuse(const orc_grid *g, const float *u_right_kf, const uint8_t *desc_kf, const float *scale_factors, const float *inv_level_sigma2,
+             const orc_camera *cam, const float *Tcw, float log_scale_factor, int n_levels,
+             int n_pts, const float *pos, const float *normal, const float *max_distance, const float *min_distance,
+             const uint8_t *pt_desc, const int32_t *pt_valid, float th, int32_t *best_idx_out);
 double orc_bow_score(const uint32_t *w1, const float *v1, int n1, const uint32_t *w2, const float *v2, int n2);
 int orc_detect_reloc_candidates(const uint32_t *q_words, const float *q_w, int nq,
                                 int n_kf, const int32_t *kf_off, const uint32_t *db_words, const float *db_w,

@@ -440,3 +440,65 @@ int orc_search_for_initialization(const orc_keypoint *keys1, const uint8_t *desc
     rh_free(&rh); free(matched_dist); free(matches21); free(ind);
     return nmatches;
 }
+
+/* Search part of ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:821-971): for every
+ * candidate map point the keyframe keypoint it would be fused with (best_idx, -1 if none).  The map mutation that
+ * follows (Replace / AddObservation, :943-964) stays with the caller; it never feeds back into the search.
+ * pt_valid = pMP && !isBad() && !IsInKeyFrame(pKF).  max_distance / min_distance are mfMaxDistance / mfMinDistance
+ * (the 1.2 / 0.8 invariance factors are applied here, src/MapPoint.cc:373-383). */
+int orc_fuse(const orc_grid *g, const float *u_right_kf, const uint8_t *desc_kf, const float *scale_factors, const float *inv_level_sigma2,
+             const orc_camera *cam, const float *Tcw, float log_scale_factor, int n_levels,
+             int n_pts, const float *pos, const float *normal, const float *max_distance, const float *min_distance,
+             const uint8_t *pt_desc, const int32_t *pt_valid, float th, int32_t *best_idx_out)
+{
+    const int N = g->n;
+    int n_fused = 0;
+    int32_t *ind = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+    float ow[3];
+    camera_center(Tcw, ow);
+    for (int i = 0; i < n_pts; i++) {
+        best_idx_out[i] = -1;
+        if (!pt_valid[i]) continue;
+        float pc[3];
+        rt_apply(Tcw, pos + 3 * i, pc);
+        if (pc[2] < 0.0f) continue;
+        const float invz = 1 / pc[2];
+        const float x = pc[0] * invz, y = pc[1] * invz;
+        const float u = cam->fx * x + cam->cx;
+        const float v = cam->fy * y + cam->cy;
+        if (!(u >= g->min_x && u < g->max_x && v >= g->min_y && v < g->max_y)) continue; /* KeyFrame::IsInImage */
+        const float ur = u - cam->bf * invz;
+        const float max_d = 1.2f * max_distance[i], min_d = 0.8f * min_distance[i];
+        float po[3];
+        for (int k = 0; k < 3; k++) po[k] = pos[3 * i + k] - ow[k];
+        const float dist3d = (float)sqrt((double)po[0] * po[0] + (double)po[1] * po[1] + (double)po[2] * po[2]);
+        if (dist3d < min_d || dist3d > max_d) continue;
+        const double dot = (double)po[0] * normal[3 * i] + (double)po[1] * normal[3 * i + 1] + (double)po[2] * normal[3 * i + 2];
+        if (dot < 0.5 * (double)dist3d) continue; /* viewing angle below 60 degrees */
+        const int lvl = orc_predict_scale(max_distance[i], dist3d, log_scale_factor, n_levels);
+        const float radius = th * scale_factors[lvl];
+        const int nc = orc_features_in_area(g, u, v, radius, -1, -1, ind, N); /* KeyFrame::GetFeaturesInArea: no level filter */
+        if (nc == 0) continue;
+        int best_dist = 256, best_idx = -1;
+        for (int k = 0; k < nc; k++) {
+            const int idx = ind[k];
+            const orc_keypoint *kp = &g->keys_un[idx];
+            const int kp_level = kp->octave;
+            if (kp_level < lvl - 1 || kp_level > lvl) continue;
+            if (u_right_kf && u_right_kf[idx] >= 0) { /* reprojection error in stereo */
+                const float ex = u - kp->x, ey = v - kp->y, er = ur - u_right_kf[idx];
+                const float e2 = ex * ex + ey * ey + er * er;
+                if ((double)(e2 * inv_level_sigma2[kp_level]) > 7.8) continue;
+            } else {
+                const float ex = u - kp->x, ey = v - kp->y;
+                const float e2 = ex * ex + ey * ey;
+                if ((double)(e2 * inv_level_sigma2[kp_level]) > 5.99) continue;
+            }
+            const int dist = orc_hamming256(pt_desc + 32 * (size_t)i, desc_kf + 32 * (size_t)idx);
+            if (dist < best_dist) { best_dist = dist; best_idx = idx; }
+        }
+        if (best_dist <= TH_LOW) { best_idx_out[i] = best_idx; n_fused++; }
+    }
+    free(ind);
+    return n_fused;
+}

@@ -30,7 +30,7 @@ EXPORTS = [
     "orbfe_features_in_area", "orbfe_three_maxima", "orbfe_search_by_projection_last", "orbfe_is_in_frustum",
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_kf", "orbfe_search_for_initialization",
     "orbfe_vocab_load", "orbfe_bow_transform", "orbfe_bow_maps", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",  # bound in orbslam2_amd/bow.py
-    "orbfe_search_for_triangulation", "orbfe_kfdb_clear", "orbfe_kfdb_add", "orbfe_kfdb_erase", "orbfe_kfdb_size", "orbfe_kfdb_score", "orbfe_detect_reloc_candidates",
+    "orbfe_search_for_triangulation", "orbfe_fuse", "orbfe_kfdb_clear", "orbfe_kfdb_add", "orbfe_kfdb_erase", "orbfe_kfdb_size", "orbfe_kfdb_score", "orbfe_detect_reloc_candidates",
 ]
 NUM_STAGES = 8
 STAGE_NAMES = ["ingest", "pyramid", "blur", "fast", "octree", "describe", "stereo_match", "stereo_median"]  # orbfe_stage_name()
@@ -123,6 +123,8 @@ def load():
     L.orbfe_search_by_projection_points.argtypes = [vp, fvp, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float, vp, ip]
     L.orbfe_search_by_projection_kf.restype = C.c_int
     L.orbfe_search_by_projection_kf.argtypes = [vp, fvp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, ip]
+    L.orbfe_fuse.restype = C.c_int
+    L.orbfe_fuse.argtypes = [vp, fvp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float, vp, ip]
     L.orbfe_search_for_initialization.restype = C.c_int
     L.orbfe_search_for_initialization.argtypes = [vp, fvp, fvp, vp, C.c_int, C.c_float, C.c_int, vp, ip]
     _lib = L
@@ -328,6 +330,15 @@ class Context:
         self._check(self.L.orbfe_search_by_projection_kf(self.h, C.byref(view), _p(tc), len(kv), _p(kp), _p(kd), _p(kv), _p(ka), _p(kmx), _p(kmn),
                                                          None if hp is None else _p(hp), th, orb_dist, int(check_ori), _p(out), C.byref(nm)))
         return out[: view.n].copy(), nm.value
+
+    def fuse(self, view, Tcw, pos, normal, max_distance, min_distance, pt_desc, pt_valid, th):
+        """Search part of ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th): best keypoint per map point (-1: none), and the count."""
+        t = np.ascontiguousarray(Tcw, np.float32); p = np.ascontiguousarray(pos, np.float32); nrm = np.ascontiguousarray(normal, np.float32)
+        mx = np.ascontiguousarray(max_distance, np.float32); mn = np.ascontiguousarray(min_distance, np.float32)
+        d = np.ascontiguousarray(pt_desc, np.uint8); ok = np.ascontiguousarray(pt_valid, np.int32)
+        out = np.zeros(max(len(ok), 1), np.int32); nf = C.c_int()
+        self._check(self.L.orbfe_fuse(self.h, C.byref(view), _p(t), len(ok), _p(p), _p(nrm), _p(mx), _p(mn), _p(d), _p(ok), th, _p(out), C.byref(nf)))
+        return out[: len(ok)].copy(), nf.value
 
     def search_for_initialization(self, view1, view2, prev_matched, window_size, nnratio, check_ori):
         pm = np.ascontiguousarray(prev_matched, np.float32).copy()

@@ -631,6 +631,77 @@ extern "C" int orbfe_search_by_projection_kf(orbfe_context *ctx, const orbfe_fra
     return ORBFE_OK;
 }
 
+// Search part of ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th), src/ORBmatcher.cc:821-971: per candidate map
+// point the keyframe keypoint to fuse with.  The points do not interact (the map mutation that follows stays with the
+// caller), so this is one window query per point; the chi-square gates of :905-930 are applied to its candidates here.
+extern "C" int orbfe_fuse(orbfe_context *ctx, const orbfe_frame_view *kf, const float *Tcw, int n_pts,
+                          const float *pos, const float *normal, const float *max_distance, const float *min_distance,
+                          const uint8_t *pt_desc, const int32_t *pt_valid, float th, int32_t *best_idx, int *n_fused)
+{
+    int rc = check_view(ctx, kf);
+    if (rc != ORBFE_OK) return rc;
+    if (!Tcw || !n_fused || n_pts < 0 || (n_pts > 0 && (!pos || !normal || !max_distance || !min_distance || !pt_desc || !pt_valid || !best_idx)))
+        return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    const orbfe_params *P = orbfe_ctx_params(ctx);
+    const float *sf = orbfe_ctx_scale_factors(ctx);
+    const float log_sf = logf((float)(double)P->scale_factor);
+    float ow[3];
+    camera_center(Tcw, ow);
+    std::vector<MatchQuery> q(n_pts);
+    std::vector<uint8_t> qd((size_t)32 * (n_pts > 0 ? n_pts : 1));
+    std::vector<float> pu(n_pts > 0 ? n_pts : 1), pv(n_pts > 0 ? n_pts : 1), pur(n_pts > 0 ? n_pts : 1);
+    for (int i = 0; i < n_pts; i++) {
+        MatchQuery &Q = q[i];
+        Q = MatchQuery{0, 0, 0, 0, -1, 0, 0, 0};
+        best_idx[i] = -1;
+        if (!pt_valid[i]) continue;
+        float pc[3];
+        rt_apply(Tcw, pos + 3 * i, pc);
+        if (pc[2] < 0.0f) continue;
+        const float invz = 1 / pc[2];
+        const float x = pc[0] * invz, y = pc[1] * invz;
+        const float u = P->fx * x + P->cx;
+        const float v = P->fy * y + P->cy;
+        if (!(u >= kf->min_x && u < kf->max_x && v >= kf->min_y && v < kf->max_y)) continue; // KeyFrame::IsInImage
+        float po[3];
+        for (int k = 0; k < 3; k++) po[k] = pos[3 * i + k] - ow[k];
+        const float dist3d = (float)sqrt((double)po[0] * po[0] + (double)po[1] * po[1] + (double)po[2] * po[2]);
+        if (dist3d < 0.8f * min_distance[i] || dist3d > 1.2f * max_distance[i]) continue;
+        const double dot = (double)po[0] * normal[3 * i] + (double)po[1] * normal[3 * i + 1] + (double)po[2] * normal[3 * i + 2];
+        if (dot < 0.5 * (double)dist3d) continue;
+        const int lvl = predict_scale(max_distance[i], dist3d, log_sf, P->nlevels);
+        Q.u = u; Q.v = v; Q.r = th * sf[lvl]; Q.min_level = lvl - 1; Q.max_level = lvl; Q.flags = 1;
+        pu[i] = u; pv[i] = v; pur[i] = u - P->bf * invz;
+        memcpy(&qd[(size_t)32 * i], pt_desc + (size_t)32 * i, 32);
+    }
+    rc = run_window_queries(ctx, kf, q, qd);
+    if (rc != ORBFE_OK) return rc;
+    orbfe_match_state *st = match_state(ctx);
+    int nf = 0;
+    for (int i = 0; i < n_pts; i++) {
+        unsigned long long best = ~0ull;
+        for (int k = 0; k < st->h_cnt[i]; k++) {
+            const unsigned long long key = st->h_list[st->h_off[i] + k];
+            const int idx = key_idx(key), lv = key_level(key);
+            const orbfe_keypoint &kp = kf->keys_un[idx];
+            const float inv_sigma2 = 1.0f / (sf[lv] * sf[lv]); // mvInvLevelSigma2 (src/ORBextractor.cc:419-425)
+            if (kf->u_right && kf->u_right[idx] >= 0) { // reprojection error in stereo (:905-918)
+                const float ex = pu[i] - kp.x, ey = pv[i] - kp.y, er = pur[i] - kf->u_right[idx];
+                const float e2 = ex * ex + ey * ey + er * er;
+                if ((double)(e2 * inv_sigma2) > 7.8) continue;
+            } else {
+                const float ex = pu[i] - kp.x, ey = pv[i] - kp.y;
+                const float e2 = ex * ex + ey * ey;
+                if ((double)(e2 * inv_sigma2) > 5.99) continue;
+            }
+            if (key < best) best = key; // smallest (distance, GetFeaturesInArea order) = the loop's first minimum
+        }
+        if (best != ~0ull && key_dist(best) <= TH_LOW) { best_idx[i] = key_idx(best); nf++; }
+    }
+    *n_fused = nf;
+    return ORBFE_OK;
+}
+
 // ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:400-515
 extern "C" int orbfe_search_for_initialization(orbfe_context *ctx, const orbfe_frame_view *f1, const orbfe_frame_view *f2,
                                                float *prev_matched, int window_size, float nnratio, int check_ori,

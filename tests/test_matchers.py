@@ -276,3 +276,30 @@ def test_gpu_matchers_edge_cases(gpu):
     bad = ctx._view(s["k"], None, s["d"], (0.0, 0.0, 0.0, float(H)))  # degenerate bounds
     with pytest.raises(api.OrbfeError):
         ctx.features_in_area(bad, 1.0, 1.0, 5.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,th,stereo", [(40, 3.0, True), (41, 2.5, False), (42, 6.0, True)])
+def test_gpu_fuse(gpu, seed, th, stereo):
+    """Search part of ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (src/ORBmatcher.cc:821-971) == oracle: projection and range /
+    viewing-angle gates, predicted level window, chi-square reprojection gates (stereo and mono keypoints), best Hamming <= TH_LOW."""
+    api, ctx = gpu
+    s = _scene(seed, n_last=1500, n_distract=400)
+    rng = np.random.default_rng(seed)
+    n = len(s["pos"])
+    ow = np.zeros(3)  # map points were created from the last frame at the origin
+    dist0 = np.linalg.norm(s["pos"] - ow, axis=1).astype(np.float32)
+    lvl0 = s["octave"]
+    max_d = (dist0 * s["sf"][lvl0]).astype(np.float32)                 # mfMaxDistance = dist * levelScaleFactor (src/MapPoint.cc:356-361)
+    min_d = (max_d / s["sf"][NL - 1]).astype(np.float32)
+    normal = (s["pos"] / dist0[:, None] + rng.normal(0, 0.45, (n, 3))).astype(np.float32)  # PO . Pn >= 0.5 |PO| for most, not all
+    normal = (normal / np.linalg.norm(normal, axis=1, keepdims=True)).astype(np.float32)
+    valid = s["valid"]
+    ur = s["ur"] if stereo else None
+    g = O.Grid(s["k"], *s["bounds"])
+    ex = s["ex"]
+    ref, nref = O.fuse(g, ur, s["d"], s["sf"], ex.inv_sigma2(), CAM, s["T_cur"], LOG_SF, NL, s["pos"], normal, max_d, min_d, s["desc_last"], valid, th)
+    view = ctx._view(s["k"], ur, s["d"], s["bounds"])
+    got, ngot = ctx.fuse(view, s["T_cur"], s["pos"], normal, max_d, min_d, s["desc_last"], valid, th)
+    assert ngot == nref and np.array_equal(got, ref)
+    assert nref > 100 and (ref[valid == 0] == -1).all()
