@@ -129,3 +129,28 @@ def test_stereo_row_list_overflow():
     assert np.array_equal(out["kps_right"], kr.astype(api.KP_DTYPE))
     assert np.array_equal(out["u_right"], ur) and np.array_equal(out["depth"], dp)
     ctx.close()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(nlevels=5, scale_factor=1.5, nfeatures=1500),
+    dict(nlevels=12, scale_factor=1.1, nfeatures=3000),
+    dict(nlevels=3, scale_factor=2.0, nfeatures=800, ini_th_fast=30, min_th_fast=12),
+    dict(nlevels=8, scale_factor=1.2, nfeatures=1000, ini_th_fast=12, min_th_fast=5),
+    dict(nlevels=1, scale_factor=1.2, nfeatures=500),
+])
+def test_extractor_parameter_variants(kw):
+    """Pyramid depth, scale factor and FAST thresholds other than the ORB-SLAM2 defaults (stereo frame, bit-exact)."""
+    from orbslam2_amd import api
+    w, h = 800, 450
+    left, right = synth.stereo_pair(w, h, seed=77)
+    fx, bf = 520.0, 180.0
+    ctx = api.Context(width=w, height=h, fx=fx, fy=fx, cx=w / 2, cy=h / 2, bf=bf, **kw)
+    out = ctx.stereo_frame(left, right)
+    exl, exr = O.Extractor(**kw), O.Extractor(**kw)
+    kl, dl = exl.extract(left); kr, dr = exr.extract(right)
+    ur, dp, _ = O.stereo_matches(exl, exr, kl, dl, kr, dr, bf, fx)
+    assert np.array_equal(out["kps_left"], kl.astype(api.KP_DTYPE)) and np.array_equal(out["kps_right"], kr.astype(api.KP_DTYPE))
+    assert np.array_equal(out["desc_left"], dl) and np.array_equal(out["desc_right"], dr)
+    assert np.array_equal(out["u_right"], ur) and np.array_equal(out["depth"], dp)
+    assert len(kl) > 100
+    ctx.close()
