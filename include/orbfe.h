@@ -251,6 +251,19 @@ int orbfe_search_by_bow(orbfe_context *ctx,
 int orbfe_fuse(orbfe_context *ctx, const orbfe_frame_view *kf, const float *Tcw, int n_pts,
                const float *pos, const float *normal, const float *max_distance, const float *min_distance,
                const uint8_t *pt_desc, const int32_t *pt_valid, float th, int32_t *best_idx, int *n_fused);
+/* LoopClosing matchers on a Sim3 pose Scw = [sR|t] (3x4 row major; decomposed as src/ORBmatcher.cc:293-298):
+ * orbfe_search_by_projection_sim3 = ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (:285-398):
+ *   pt_match[i] = keypoint of `kf` matched to point i or -1; kf_matched[k] != 0 marks keypoints that already hold a match
+ *   (vpMatched[k] != NULL) -- those, and keypoints taken earlier in the loop, are skipped;
+ * orbfe_fuse_sim3 = search part of ORBmatcher::Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint) (:973-1096).
+ * pt_valid = !isBad() && not already in the keyframe / matched set. */
+int orbfe_search_by_projection_sim3(orbfe_context *ctx, const orbfe_frame_view *kf, const float *Scw, int n_pts,
+                                    const float *pos, const float *normal, const float *max_distance, const float *min_distance,
+                                    const uint8_t *pt_desc, const int32_t *pt_valid, const uint8_t *kf_matched, float th,
+                                    int32_t *pt_match, int *nmatches);
+int orbfe_fuse_sim3(orbfe_context *ctx, const orbfe_frame_view *kf, const float *Scw, int n_pts,
+                    const float *pos, const float *normal, const float *max_distance, const float *min_distance,
+                    const uint8_t *pt_desc, const int32_t *pt_valid, float th, int32_t *best_idx, int *n_fused);
 /* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (src/ORBmatcher.cc:652-819, called by
  * LocalMapping::CreateNewMapPoints): keypoints without a map point (has_mp == 0) paired inside shared vocabulary nodes
  * (feature vectors of orbfe_bow_maps), Hamming <= TH_LOW, monocular pairs away from the epipole, CheckDistEpipolarLine

@@ -233,6 +233,24 @@ def fuse(grid, u_right_kf, desc_kf, scale_factors, inv_level_sigma2, cam, Tcw, l
     return out[: len(ok)].copy(), n
 
 
+def sim3_projection(mode, grid, desc_kf, scale_factors, cam, Scw, log_scale_factor, n_levels, pos, normal, max_distance, min_distance,
+                    pt_desc, pt_valid, kf_matched, th):
+    """mode 0: SearchByProjection(KeyFrame*, Scw, ...); mode 1: search part of Fuse(KeyFrame*, Scw, ...)."""
+    L = lib()
+    L.orc_search_by_sim3_projection.restype = C.c_int
+    L.orc_search_by_sim3_projection.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.POINTER(Camera), C.c_void_p, C.c_float, C.c_int, C.c_int] + \
+        [C.c_void_p] * 7 + [C.c_float, C.c_void_p]
+    d = np.ascontiguousarray(desc_kf, np.uint8); sf = np.ascontiguousarray(scale_factors, np.float32)
+    t = np.ascontiguousarray(Scw, np.float32); p = np.ascontiguousarray(pos, np.float32); nrm = np.ascontiguousarray(normal, np.float32)
+    mx = np.ascontiguousarray(max_distance, np.float32); mn = np.ascontiguousarray(min_distance, np.float32)
+    pd = np.ascontiguousarray(pt_desc, np.uint8); ok = np.ascontiguousarray(pt_valid, np.int32)
+    km = _opt(kf_matched, np.uint8)
+    out = np.zeros(max(len(ok), 1), np.int32)
+    n = L.orc_search_by_sim3_projection(mode, grid.h, _ptr(d), _ptr(sf), C.byref(cam), _ptr(t), log_scale_factor, n_levels, len(ok), _ptr(p), _ptr(nrm),
+                                        _ptr(mx), _ptr(mn), _ptr(pd), _ptr(ok), None if km is None else _ptr(km), th, _ptr(out))
+    return out[: len(ok)].copy(), n
+
+
 def search_for_initialization(keys1, desc1, grid2, desc2, prev_matched, window_size, nnratio, check_ori):
     k1 = np.ascontiguousarray(keys1); d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
     pm = np.ascontiguousarray(prev_matched, np.float32).copy()

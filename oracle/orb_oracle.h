@@ -178,6 +178,10 @@ int orc_fuse(const orc_grid *g, const float *u_right_kf, const uint8_t *desc_kf,
              const orc_camera *cam, const float *Tcw, float log_scale_factor, int n_levels,
              int n_pts, const float *pos, const float *normal, const float *max_distance, const float *min_distance,
              const uint8_t *pt_desc, const int32_t *pt_valid, float th, int32_t *best_idx_out);
+int orc_search_by_sim3_projection(int mode, const orc_grid *g, const uint8_t *desc_kf, const float *scale_factors, const orc_camera *cam,
+                                  const float *Scw, float log_scale_factor, int n_levels,
+                                  int n_pts, const float *pos, const float *normal, const float *max_distance, const float *min_distance,
+                                  const uint8_t *pt_desc, const int32_t *pt_valid, const uint8_t *kf_matched_in, float th, int32_t *pt_match);
 double orc_bow_score(const uint32_t *w1, const float *v1, int n1, const uint32_t *w2, const float *v2, int n2);
 int orc_detect_reloc_candidates(const uint32_t *q_words, const float *q_w, int nq,
                                 int n_kf, const int32_t *kf_off, const uint32_t *db_words, const float *db_w,

@@ -502,3 +502,71 @@ int orc_fuse(const orc_grid *g, const float *u_right_kf, const uint8_t *desc_kf,
     free(ind);
     return n_fused;
 }
+
+/* Sim3 decomposition shared by the LoopClosing matchers (src/ORBmatcher.cc:293-298, 981-986): scw = sqrt(row0 . row0)
+ * (Mat::dot accumulates in double), Rcw = sRcw / scw and tcw = t / scw (OPENCV-4.5.5-SEMANTICS: Mat / scalar is a
+ * convertTo with alpha = 1 / scw, applied as a float multiply), packed as a 3x4 [R|t]. */
+static void sim3_to_rt(const float *Scw /*3x4 row major: [sR|t]*/, float *T)
+{
+    const double d = (double)Scw[0] * Scw[0] + (double)Scw[1] * Scw[1] + (double)Scw[2] * Scw[2];
+    const float scw = (float)sqrt(d);
+    const float alpha = (float)(1.0 / (double)scw);
+    for (int i = 0; i < 12; i++) T[i] = Scw[i] * alpha;
+}
+
+/* mode 0: ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (src/ORBmatcher.cc:285-398): greedy over
+ *         the points (a keypoint that already has a match -- kf_matched on entry or taken earlier in the loop -- is skipped);
+ * mode 1: search part of ORBmatcher::Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint) (:973-1096): points independent.
+ * pt_valid = !isBad() && !already found in the keyframe.  pt_match[i] = keypoint or -1. */
+int orc_search_by_sim3_projection(int mode, const orc_grid *g, const uint8_t *desc_kf, const float *scale_factors, const orc_camera *cam,
+                                  const float *Scw, float log_scale_factor, int n_levels,
+                                  int n_pts, const float *pos, const float *normal, const float *max_distance, const float *min_distance,
+                                  const uint8_t *pt_desc, const int32_t *pt_valid, const uint8_t *kf_matched_in, float th, int32_t *pt_match)
+{
+    const int N = g->n;
+    int nmatches = 0;
+    float T[12], ow[3];
+    sim3_to_rt(Scw, T);
+    camera_center(T, ow);
+    uint8_t *matched = (uint8_t *)malloc((size_t)(N > 0 ? N : 1));
+    for (int i = 0; i < N; i++) matched[i] = (mode == 0 && kf_matched_in) ? kf_matched_in[i] : 0;
+    int32_t *ind = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+    for (int i = 0; i < n_pts; i++) {
+        pt_match[i] = -1;
+        if (!pt_valid[i]) continue;
+        float pc[3];
+        rt_apply(T, pos + 3 * i, pc);
+        if (mode == 0 ? ((double)pc[2] < 0.0) : (pc[2] < 0.0f)) continue;
+        const float invz = mode == 0 ? 1 / pc[2] : (float)(1.0 / (double)pc[2]);
+        const float x = pc[0] * invz, y = pc[1] * invz;
+        const float u = cam->fx * x + cam->cx;
+        const float v = cam->fy * y + cam->cy;
+        if (!(u >= g->min_x && u < g->max_x && v >= g->min_y && v < g->max_y)) continue;
+        float po[3];
+        for (int k = 0; k < 3; k++) po[k] = pos[3 * i + k] - ow[k];
+        const float dist = (float)sqrt((double)po[0] * po[0] + (double)po[1] * po[1] + (double)po[2] * po[2]);
+        if (dist < 0.8f * min_distance[i] || dist > 1.2f * max_distance[i]) continue;
+        const double dot = (double)po[0] * normal[3 * i] + (double)po[1] * normal[3 * i + 1] + (double)po[2] * normal[3 * i + 2];
+        if (dot < 0.5 * (double)dist) continue;
+        const int lvl = orc_predict_scale(max_distance[i], dist, log_scale_factor, n_levels);
+        const float radius = th * scale_factors[lvl];
+        const int nc = orc_features_in_area(g, u, v, radius, -1, -1, ind, N);
+        if (nc == 0) continue;
+        int best_dist = 256, best_idx = -1;
+        for (int k = 0; k < nc; k++) {
+            const int idx = ind[k];
+            if (matched[idx]) continue;
+            const int kp_level = g->keys_un[idx].octave;
+            if (kp_level < lvl - 1 || kp_level > lvl) continue;
+            const int d = orc_hamming256(pt_desc + 32 * (size_t)i, desc_kf + 32 * (size_t)idx);
+            if (d < best_dist) { best_dist = d; best_idx = idx; }
+        }
+        if (best_dist <= TH_LOW) {
+            pt_match[i] = best_idx;
+            if (mode == 0) matched[best_idx] = 1;
+            nmatches++;
+        }
+    }
+    free(matched); free(ind);
+    return nmatches;
+}

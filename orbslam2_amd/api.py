@@ -30,7 +30,7 @@ EXPORTS = [
     "orbfe_features_in_area", "orbfe_three_maxima", "orbfe_search_by_projection_last", "orbfe_is_in_frustum",
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_kf", "orbfe_search_for_initialization",
     "orbfe_vocab_load", "orbfe_bow_transform", "orbfe_bow_maps", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",  # bound in orbslam2_amd/bow.py
-    "orbfe_search_for_triangulation", "orbfe_fuse", "orbfe_kfdb_clear", "orbfe_kfdb_add", "orbfe_kfdb_erase", "orbfe_kfdb_size", "orbfe_kfdb_score", "orbfe_detect_reloc_candidates",
+    "orbfe_search_for_triangulation", "orbfe_fuse", "orbfe_search_by_projection_sim3", "orbfe_fuse_sim3", "orbfe_kfdb_clear", "orbfe_kfdb_add", "orbfe_kfdb_erase", "orbfe_kfdb_size", "orbfe_kfdb_score", "orbfe_detect_reloc_candidates",
 ]
 NUM_STAGES = 8
 STAGE_NAMES = ["ingest", "pyramid", "blur", "fast", "octree", "describe", "stereo_match", "stereo_median"]  # orbfe_stage_name()
@@ -125,6 +125,10 @@ def load():
     L.orbfe_search_by_projection_kf.argtypes = [vp, fvp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, ip]
     L.orbfe_fuse.restype = C.c_int
     L.orbfe_fuse.argtypes = [vp, fvp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float, vp, ip]
+    L.orbfe_search_by_projection_sim3.restype = C.c_int
+    L.orbfe_search_by_projection_sim3.argtypes = [vp, fvp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, ip]
+    L.orbfe_fuse_sim3.restype = C.c_int
+    L.orbfe_fuse_sim3.argtypes = [vp, fvp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float, vp, ip]
     L.orbfe_search_for_initialization.restype = C.c_int
     L.orbfe_search_for_initialization.argtypes = [vp, fvp, fvp, vp, C.c_int, C.c_float, C.c_int, vp, ip]
     _lib = L
@@ -338,6 +342,20 @@ class Context:
         d = np.ascontiguousarray(pt_desc, np.uint8); ok = np.ascontiguousarray(pt_valid, np.int32)
         out = np.zeros(max(len(ok), 1), np.int32); nf = C.c_int()
         self._check(self.L.orbfe_fuse(self.h, C.byref(view), _p(t), len(ok), _p(p), _p(nrm), _p(mx), _p(mn), _p(d), _p(ok), th, _p(out), C.byref(nf)))
+        return out[: len(ok)].copy(), nf.value
+
+    def sim3_projection(self, mode, view, Scw, pos, normal, max_distance, min_distance, pt_desc, pt_valid, kf_matched, th):
+        """mode 0: SearchByProjection(KeyFrame*, Scw, ...); mode 1: search part of Fuse(KeyFrame*, Scw, ...): (match per point, count)."""
+        t = np.ascontiguousarray(Scw, np.float32); p = np.ascontiguousarray(pos, np.float32); nrm = np.ascontiguousarray(normal, np.float32)
+        mx = np.ascontiguousarray(max_distance, np.float32); mn = np.ascontiguousarray(min_distance, np.float32)
+        d = np.ascontiguousarray(pt_desc, np.uint8); ok = np.ascontiguousarray(pt_valid, np.int32)
+        out = np.zeros(max(len(ok), 1), np.int32); nf = C.c_int()
+        if mode == 0:
+            km = None if kf_matched is None else np.ascontiguousarray(kf_matched, np.uint8)
+            self._check(self.L.orbfe_search_by_projection_sim3(self.h, C.byref(view), _p(t), len(ok), _p(p), _p(nrm), _p(mx), _p(mn), _p(d), _p(ok),
+                                                               None if km is None else _p(km), th, _p(out), C.byref(nf)))
+        else:
+            self._check(self.L.orbfe_fuse_sim3(self.h, C.byref(view), _p(t), len(ok), _p(p), _p(nrm), _p(mx), _p(mn), _p(d), _p(ok), th, _p(out), C.byref(nf)))
         return out[: len(ok)].copy(), nf.value
 
     def search_for_initialization(self, view1, view2, prev_matched, window_size, nnratio, check_ori):

@@ -702,6 +702,97 @@ extern "C" int orbfe_fuse(orbfe_context *ctx, const orbfe_frame_view *kf, const 
     return ORBFE_OK;
 }
 
+// Sim3 decomposition of the LoopClosing matchers (src/ORBmatcher.cc:293-298, 981-986); see oracle/orb_oracle_match.c
+static void sim3_to_rt(const float *Scw, float *T)
+{
+    const double d = (double)Scw[0] * Scw[0] + (double)Scw[1] * Scw[1] + (double)Scw[2] * Scw[2];
+    const float scw = (float)sqrt(d);
+    const float alpha = (float)(1.0 / (double)scw);
+    for (int i = 0; i < 12; i++) T[i] = Scw[i] * alpha;
+}
+
+// mode 0: ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th), src/ORBmatcher.cc:285-398 (greedy over points);
+// mode 1: search part of ORBmatcher::Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint), :973-1096 (points independent).
+static int sim3_projection_impl(orbfe_context *ctx, int mode, const orbfe_frame_view *kf, const float *Scw, int n_pts,
+                                const float *pos, const float *normal, const float *max_distance, const float *min_distance,
+                                const uint8_t *pt_desc, const int32_t *pt_valid, const uint8_t *kf_matched, float th,
+                                int32_t *pt_match, int *nmatches)
+{
+    int rc = check_view(ctx, kf);
+    if (rc != ORBFE_OK) return rc;
+    if (!Scw || !nmatches || n_pts < 0 || (n_pts > 0 && (!pos || !normal || !max_distance || !min_distance || !pt_desc || !pt_valid || !pt_match)))
+        return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    const orbfe_params *P = orbfe_ctx_params(ctx);
+    const float *sf = orbfe_ctx_scale_factors(ctx);
+    const float log_sf = logf((float)(double)P->scale_factor);
+    const int N = kf->n;
+    float T[12], ow[3];
+    sim3_to_rt(Scw, T);
+    camera_center(T, ow);
+    std::vector<MatchQuery> q(n_pts);
+    std::vector<uint8_t> qd((size_t)32 * (n_pts > 0 ? n_pts : 1));
+    for (int i = 0; i < n_pts; i++) {
+        MatchQuery &Q = q[i];
+        Q = MatchQuery{0, 0, 0, 0, -1, 0, 0, 0};
+        pt_match[i] = -1;
+        if (!pt_valid[i]) continue;
+        float pc[3];
+        rt_apply(T, pos + 3 * i, pc);
+        if (mode == 0 ? ((double)pc[2] < 0.0) : (pc[2] < 0.0f)) continue;
+        const float invz = mode == 0 ? 1 / pc[2] : (float)(1.0 / (double)pc[2]);
+        const float x = pc[0] * invz, y = pc[1] * invz;
+        const float u = P->fx * x + P->cx;
+        const float v = P->fy * y + P->cy;
+        if (!(u >= kf->min_x && u < kf->max_x && v >= kf->min_y && v < kf->max_y)) continue;
+        float po[3];
+        for (int k = 0; k < 3; k++) po[k] = pos[3 * i + k] - ow[k];
+        const float dist = (float)sqrt((double)po[0] * po[0] + (double)po[1] * po[1] + (double)po[2] * po[2]);
+        if (dist < 0.8f * min_distance[i] || dist > 1.2f * max_distance[i]) continue;
+        const double dot = (double)po[0] * normal[3 * i] + (double)po[1] * normal[3 * i + 1] + (double)po[2] * normal[3 * i + 2];
+        if (dot < 0.5 * (double)dist) continue;
+        const int lvl = predict_scale(max_distance[i], dist, log_sf, P->nlevels);
+        Q.u = u; Q.v = v; Q.r = th * sf[lvl]; Q.min_level = lvl - 1; Q.max_level = lvl; Q.flags = 1;
+        memcpy(&qd[(size_t)32 * i], pt_desc + (size_t)32 * i, 32);
+    }
+    rc = run_window_queries(ctx, kf, q, qd);
+    if (rc != ORBFE_OK) return rc;
+    orbfe_match_state *st = match_state(ctx);
+    std::vector<uint8_t> matched(N > 0 ? N : 1, 0);
+    if (mode == 0 && kf_matched)
+        for (int i = 0; i < N; i++) matched[i] = kf_matched[i];
+    int nm = 0;
+    for (int i = 0; i < n_pts; i++) {
+        unsigned long long best = ~0ull;
+        for (int k = 0; k < st->h_cnt[i]; k++) {
+            const unsigned long long key = st->h_list[st->h_off[i] + k];
+            if (matched[key_idx(key)]) continue;
+            if (key < best) best = key;
+        }
+        if (best != ~0ull && key_dist(best) <= TH_LOW) {
+            pt_match[i] = key_idx(best);
+            if (mode == 0) matched[key_idx(best)] = 1;
+            nm++;
+        }
+    }
+    *nmatches = nm;
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_search_by_projection_sim3(orbfe_context *ctx, const orbfe_frame_view *kf, const float *Scw, int n_pts,
+                                               const float *pos, const float *normal, const float *max_distance, const float *min_distance,
+                                               const uint8_t *pt_desc, const int32_t *pt_valid, const uint8_t *kf_matched, float th,
+                                               int32_t *pt_match, int *nmatches)
+{
+    return sim3_projection_impl(ctx, 0, kf, Scw, n_pts, pos, normal, max_distance, min_distance, pt_desc, pt_valid, kf_matched, th, pt_match, nmatches);
+}
+
+extern "C" int orbfe_fuse_sim3(orbfe_context *ctx, const orbfe_frame_view *kf, const float *Scw, int n_pts,
+                               const float *pos, const float *normal, const float *max_distance, const float *min_distance,
+                               const uint8_t *pt_desc, const int32_t *pt_valid, float th, int32_t *best_idx, int *n_fused)
+{
+    return sim3_projection_impl(ctx, 1, kf, Scw, n_pts, pos, normal, max_distance, min_distance, pt_desc, pt_valid, nullptr, th, best_idx, n_fused);
+}
+
 // ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:400-515
 extern "C" int orbfe_search_for_initialization(orbfe_context *ctx, const orbfe_frame_view *f1, const orbfe_frame_view *f2,
                                                float *prev_matched, int window_size, float nnratio, int check_ori,

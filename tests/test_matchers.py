@@ -303,3 +303,31 @@ def test_gpu_fuse(gpu, seed, th, stereo):
     got, ngot = ctx.fuse(view, s["T_cur"], s["pos"], normal, max_d, min_d, s["desc_last"], valid, th)
     assert ngot == nref and np.array_equal(got, ref)
     assert nref > 100 and (ref[valid == 0] == -1).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,seed,th", [(0, 50, 10.0), (0, 51, 4.0), (1, 52, 4.0), (1, 53, 10.0)])
+def test_gpu_sim3_projection_matchers(gpu, mode, seed, th):
+    """LoopClosing matchers on a Sim3 pose: SearchByProjection(KeyFrame*, Scw, ...) (src/ORBmatcher.cc:285-398, greedy over the
+    points) and the search part of Fuse(KeyFrame*, Scw, ...) (:973-1096) == oracle."""
+    api, ctx = gpu
+    s = _scene(seed, n_last=1500, n_distract=400)
+    rng = np.random.default_rng(seed)
+    n = len(s["pos"])
+    dist0 = np.linalg.norm(s["pos"], axis=1).astype(np.float32)
+    max_d = (dist0 * s["sf"][s["octave"]]).astype(np.float32)
+    min_d = (max_d / s["sf"][NL - 1]).astype(np.float32)
+    normal = (s["pos"] / dist0[:, None] + rng.normal(0, 0.45, (n, 3))).astype(np.float32)
+    normal = (normal / np.linalg.norm(normal, axis=1, keepdims=True)).astype(np.float32)
+    scale = np.float32(1.07)
+    Scw = s["T_cur"].copy(); Scw *= scale  # [sR | s t]: the same camera pose, map scaled by 1.07
+    kf_matched = (rng.random(len(s["k"])) < 0.1).astype(np.uint8)
+    g = O.Grid(s["k"], *s["bounds"])
+    ref, nref = O.sim3_projection(mode, g, s["d"], s["sf"], CAM, Scw, LOG_SF, NL, s["pos"], normal, max_d, min_d, s["desc_last"], s["valid"], kf_matched, th)
+    view = ctx._view(s["k"], s["ur"], s["d"], s["bounds"])
+    got, ngot = ctx.sim3_projection(mode, view, Scw, s["pos"], normal, max_d, min_d, s["desc_last"], s["valid"], kf_matched, th)
+    assert ngot == nref and np.array_equal(got, ref)
+    assert nref > 100
+    m = ref[ref >= 0]
+    if mode == 0:
+        assert len(np.unique(m)) == len(m) and not kf_matched[m].any()  # one keypoint per point, none of the pre-matched ones
