@@ -264,6 +264,16 @@ int orbfe_search_by_projection_sim3(orbfe_context *ctx, const orbfe_frame_view *
 int orbfe_fuse_sim3(orbfe_context *ctx, const orbfe_frame_view *kf, const float *Scw, int n_pts,
                     const float *pos, const float *normal, const float *max_distance, const float *min_distance,
                     const uint8_t *pt_desc, const int32_t *pt_valid, float th, int32_t *best_idx, int *n_fused);
+/* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (src/ORBmatcher.cc:1098-1322): the map points of each
+ * keyframe (arrays with one entry per keypoint slot; valid = pMP && !isBad() && not already matched) are moved into the other
+ * camera with the Sim3 (R12 3x3 row major, t12, s12), searched there, and only mutually consistent pairs are kept:
+ * match12[i1] = keypoint of KF2 or -1.  T1w / T2w = the keyframes' [R|t] (3x4). */
+int orbfe_search_by_sim3(orbfe_context *ctx,
+                         const orbfe_frame_view *kf1, const float *T1w, const float *pos1, const float *max_distance1,
+                         const float *min_distance1, const uint8_t *pt_desc1, const int32_t *valid1,
+                         const orbfe_frame_view *kf2, const float *T2w, const float *pos2, const float *max_distance2,
+                         const float *min_distance2, const uint8_t *pt_desc2, const int32_t *valid2,
+                         float s12, const float *R12, const float *t12, float th, int32_t *match12, int *n_found);
 /* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (src/ORBmatcher.cc:652-819, called by
  * LocalMapping::CreateNewMapPoints): keypoints without a map point (has_mp == 0) paired inside shared vocabulary nodes
  * (feature vectors of orbfe_bow_maps), Hamming <= TH_LOW, monocular pairs away from the epipole, CheckDistEpipolarLine

@@ -251,6 +251,25 @@ def sim3_projection(mode, grid, desc_kf, scale_factors, cam, Scw, log_scale_fact
     return out[: len(ok)].copy(), n
 
 
+def search_by_sim3(grid1, desc_kf1, T1w, pts1, grid2, desc_kf2, T2w, pts2, scale_factors, cam, log_scale_factor, n_levels, s12, R12, t12, th):
+    """ORBmatcher::SearchBySim3; pts = (pos, max_distance, min_distance, desc, valid) per keypoint slot.  (match12, count)."""
+    L = lib()
+    L.orc_search_by_sim3.restype = C.c_int
+    L.orc_search_by_sim3.argtypes = [C.c_void_p] * 16 + [C.c_void_p, C.POINTER(Camera), C.c_float, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+
+    def prep(dkf, T, pts):
+        pos, mx, mn, d, ok = pts
+        return [np.ascontiguousarray(dkf, np.uint8), np.ascontiguousarray(T, np.float32), np.ascontiguousarray(pos, np.float32),
+                np.ascontiguousarray(mx, np.float32), np.ascontiguousarray(mn, np.float32), np.ascontiguousarray(d, np.uint8),
+                np.ascontiguousarray(ok, np.int32)]
+    a, b = prep(desc_kf1, T1w, pts1), prep(desc_kf2, T2w, pts2)
+    sf = np.ascontiguousarray(scale_factors, np.float32); R = np.ascontiguousarray(R12, np.float32); t = np.ascontiguousarray(t12, np.float32)
+    out = np.zeros(max(len(a[6]), 1), np.int32)
+    n = L.orc_search_by_sim3(grid1.h, *[_ptr(x) for x in a], grid2.h, *[_ptr(x) for x in b], _ptr(sf), C.byref(cam), log_scale_factor, n_levels,
+                             float(s12), _ptr(R), _ptr(t), th, _ptr(out))
+    return out[: len(a[6])].copy(), n
+
+
 def search_for_initialization(keys1, desc1, grid2, desc2, prev_matched, window_size, nnratio, check_ori):
     k1 = np.ascontiguousarray(keys1); d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
     pm = np.ascontiguousarray(prev_matched, np.float32).copy()

@@ -182,6 +182,12 @@ int orc_search_by_sim3_projection(int mode, const orc_grid *g, const uint8_t *de
                                   const float *Scw, float log_scale_factor, int n_levels,
                                   int n_pts, const float *pos, const float *normal, const float *max_distance, const float *min_distance,
                                   const uint8_t *pt_desc, const int32_t *pt_valid, const uint8_t *kf_matched_in, float th, int32_t *pt_match);
+int orc_search_by_sim3(const orc_grid *g1, const uint8_t *desc_kf1, const float *T1w, const float *pos1, const float *maxd1, const float *mind1,
+                       const uint8_t *pdesc1, const int32_t *valid1,
+                       const orc_grid *g2, const uint8_t *desc_kf2, const float *T2w, const float *pos2, const float *maxd2, const float *mind2,
+                       const uint8_t *pdesc2, const int32_t *valid2,
+                       const float *scale_factors, const orc_camera *cam, float log_scale_factor, int n_levels,
+                       float s12, const float *R12, const float *t12, float th, int32_t *match12);
 double orc_bow_score(const uint32_t *w1, const float *v1, int n1, const uint32_t *w2, const float *v2, int n2);
 int orc_detect_reloc_candidates(const uint32_t *q_words, const float *q_w, int nq,
                                 int n_kf, const int32_t *kf_off, const uint32_t *db_words, const float *db_w,

@@ -570,3 +570,73 @@ int orc_search_by_sim3_projection(int mode, const orc_grid *g, const uint8_t *de
     free(matched); free(ind);
     return nmatches;
 }
+
+/* one direction of ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1143-1216 / 1218-1291): map points of keyframe A (camera pose
+ * Taw) moved into camera B by [sR|t] and searched in B's grid; match[i] = keypoint of B or -1. */
+static void sim3_one_way(const float *Taw, const float *sRt /*3x4*/, const orc_grid *gb, const uint8_t *desc_b,
+                         const float *scale_factors, const orc_camera *cam, float log_scale_factor, int n_levels,
+                         int n, const float *pos, const float *max_distance, const float *min_distance, const uint8_t *desc,
+                         const int32_t *valid, float th, int32_t *match, int32_t *ind)
+{
+    for (int i = 0; i < n; i++) {
+        match[i] = -1;
+        if (!valid[i]) continue;
+        float pa[3], pb[3];
+        rt_apply(Taw, pos + 3 * i, pa);
+        rt_apply(sRt, pa, pb);
+        if ((double)pb[2] < 0.0) continue;
+        const float invz = (float)(1.0 / (double)pb[2]);
+        const float x = pb[0] * invz, y = pb[1] * invz;
+        const float u = cam->fx * x + cam->cx, v = cam->fy * y + cam->cy;
+        if (!(u >= gb->min_x && u < gb->max_x && v >= gb->min_y && v < gb->max_y)) continue;
+        const float dist = (float)sqrt((double)pb[0] * pb[0] + (double)pb[1] * pb[1] + (double)pb[2] * pb[2]);
+        if (dist < 0.8f * min_distance[i] || dist > 1.2f * max_distance[i]) continue;
+        const int lvl = orc_predict_scale(max_distance[i], dist, log_scale_factor, n_levels);
+        const int nc = orc_features_in_area(gb, u, v, th * scale_factors[lvl], -1, -1, ind, gb->n);
+        int best_dist = INT_MAX, best_idx = -1;
+        for (int k = 0; k < nc; k++) {
+            const int idx = ind[k];
+            const int oct = gb->keys_un[idx].octave;
+            if (oct < lvl - 1 || oct > lvl) continue;
+            const int d = orc_hamming256(desc + 32 * (size_t)i, desc_b + 32 * (size_t)idx);
+            if (d < best_dist) { best_dist = d; best_idx = idx; }
+        }
+        if (best_dist <= TH_HIGH) match[i] = best_idx;
+    }
+}
+
+/* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (src/ORBmatcher.cc:1098-1322).  Point arrays have one
+ * entry per keypoint slot of their keyframe; valid1[i] = pMP && !isBad() && !vbAlreadyMatched1[i] (same for 2).  Both
+ * keyframes use `cam`.  match12[i1] = i2 for mutually consistent pairs, else -1; returns their number. */
+int orc_search_by_sim3(const orc_grid *g1, const uint8_t *desc_kf1, const float *T1w, const float *pos1, const float *maxd1, const float *mind1,
+                       const uint8_t *pdesc1, const int32_t *valid1,
+                       const orc_grid *g2, const uint8_t *desc_kf2, const float *T2w, const float *pos2, const float *maxd2, const float *mind2,
+                       const uint8_t *pdesc2, const int32_t *valid2,
+                       const float *scale_factors, const orc_camera *cam, float log_scale_factor, int n_levels,
+                       float s12, const float *R12, const float *t12, float th, int32_t *match12)
+{
+    const int N1 = g1->n, N2 = g2->n;
+    /* sR12 = s12 * R12; sR21 = (1.0 / s12) * R12.t(); t21 = -sR21 * t12  (:1116-1119; MatExpr scale = float multiply by (float)alpha) */
+    float A12[12], A21[12];
+    const float inv_s = (float)(1.0 / (double)s12);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { A12[4 * i + j] = R12[3 * i + j] * s12; A21[4 * i + j] = R12[3 * j + i] * inv_s; }
+    for (int i = 0; i < 3; i++) {
+        A12[4 * i + 3] = t12[i];
+        const float t0 = (A21[4 * i] * t12[0] + A21[4 * i + 1] * t12[1]) + A21[4 * i + 2] * t12[2];
+        A21[4 * i + 3] = -t0;
+    }
+    int32_t *m1 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N1 > 0 ? N1 : 1));
+    int32_t *m2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(N2 > 0 ? N2 : 1));
+    int32_t *ind = (int32_t *)malloc(sizeof(int32_t) * (size_t)((N1 > N2 ? N1 : N2) > 0 ? (N1 > N2 ? N1 : N2) : 1));
+    sim3_one_way(T1w, A21, g2, desc_kf2, scale_factors, cam, log_scale_factor, n_levels, N1, pos1, maxd1, mind1, pdesc1, valid1, th, m1, ind);
+    sim3_one_way(T2w, A12, g1, desc_kf1, scale_factors, cam, log_scale_factor, n_levels, N2, pos2, maxd2, mind2, pdesc2, valid2, th, m2, ind);
+    int n_found = 0;
+    for (int i1 = 0; i1 < N1; i1++) {
+        match12[i1] = -1;
+        const int idx2 = m1[i1];
+        if (idx2 >= 0 && m2[idx2] == i1) { match12[i1] = idx2; n_found++; }
+    }
+    free(m1); free(m2); free(ind);
+    return n_found;
+}

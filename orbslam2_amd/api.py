@@ -30,7 +30,7 @@ EXPORTS = [
     "orbfe_features_in_area", "orbfe_three_maxima", "orbfe_search_by_projection_last", "orbfe_is_in_frustum",
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_kf", "orbfe_search_for_initialization",
     "orbfe_vocab_load", "orbfe_bow_transform", "orbfe_bow_maps", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",  # bound in orbslam2_amd/bow.py
-    "orbfe_search_for_triangulation", "orbfe_fuse", "orbfe_search_by_projection_sim3", "orbfe_fuse_sim3", "orbfe_kfdb_clear", "orbfe_kfdb_add", "orbfe_kfdb_erase", "orbfe_kfdb_size", "orbfe_kfdb_score", "orbfe_detect_reloc_candidates",
+    "orbfe_search_for_triangulation", "orbfe_fuse", "orbfe_search_by_projection_sim3", "orbfe_fuse_sim3", "orbfe_search_by_sim3", "orbfe_kfdb_clear", "orbfe_kfdb_add", "orbfe_kfdb_erase", "orbfe_kfdb_size", "orbfe_kfdb_score", "orbfe_detect_reloc_candidates",
 ]
 NUM_STAGES = 8
 STAGE_NAMES = ["ingest", "pyramid", "blur", "fast", "octree", "describe", "stereo_match", "stereo_median"]  # orbfe_stage_name()
@@ -129,6 +129,8 @@ def load():
     L.orbfe_search_by_projection_sim3.argtypes = [vp, fvp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, ip]
     L.orbfe_fuse_sim3.restype = C.c_int
     L.orbfe_fuse_sim3.argtypes = [vp, fvp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float, vp, ip]
+    L.orbfe_search_by_sim3.restype = C.c_int
+    L.orbfe_search_by_sim3.argtypes = [vp] + [fvp, vp, vp, vp, vp, vp, vp] * 2 + [C.c_float, vp, vp, C.c_float, vp, ip]
     L.orbfe_search_for_initialization.restype = C.c_int
     L.orbfe_search_for_initialization.argtypes = [vp, fvp, fvp, vp, C.c_int, C.c_float, C.c_int, vp, ip]
     _lib = L
@@ -357,6 +359,19 @@ class Context:
         else:
             self._check(self.L.orbfe_fuse_sim3(self.h, C.byref(view), _p(t), len(ok), _p(p), _p(nrm), _p(mx), _p(mn), _p(d), _p(ok), th, _p(out), C.byref(nf)))
         return out[: len(ok)].copy(), nf.value
+
+    def search_by_sim3(self, view1, T1w, pts1, view2, T2w, pts2, s12, R12, t12, th):
+        """ORBmatcher::SearchBySim3; pts = (pos, max_distance, min_distance, desc, valid) per keypoint slot.  (match12, count)."""
+        def prep(T, pts):
+            pos, mx, mn, d, ok = pts
+            return (np.ascontiguousarray(T, np.float32), np.ascontiguousarray(pos, np.float32), np.ascontiguousarray(mx, np.float32),
+                    np.ascontiguousarray(mn, np.float32), np.ascontiguousarray(d, np.uint8), np.ascontiguousarray(ok, np.int32))
+        a, b = prep(T1w, pts1), prep(T2w, pts2)
+        R = np.ascontiguousarray(R12, np.float32); t = np.ascontiguousarray(t12, np.float32)
+        out = np.zeros(max(view1.n, 1), np.int32); nf = C.c_int()
+        self._check(self.L.orbfe_search_by_sim3(self.h, C.byref(view1), *[_p(x) for x in a], C.byref(view2), *[_p(x) for x in b],
+                                                float(s12), _p(R), _p(t), th, _p(out), C.byref(nf)))
+        return out[: view1.n].copy(), nf.value
 
     def search_for_initialization(self, view1, view2, prev_matched, window_size, nnratio, check_ori):
         pm = np.ascontiguousarray(prev_matched, np.float32).copy()

@@ -793,6 +793,91 @@ extern "C" int orbfe_fuse_sim3(orbfe_context *ctx, const orbfe_frame_view *kf, c
     return sim3_projection_impl(ctx, 1, kf, Scw, n_pts, pos, normal, max_distance, min_distance, pt_desc, pt_valid, nullptr, th, best_idx, n_fused);
 }
 
+// One direction of ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1143-1216 / 1218-1291): keyframe A's map points moved into
+// camera B by [sR|t], one window query each against B; match[i] = keypoint of B or -1 (the points do not interact).
+static int sim3_one_way(orbfe_context *ctx, const float *Taw, const float *sRt, const orbfe_frame_view *kfb, int n,
+                        const float *pos, const float *max_distance, const float *min_distance, const uint8_t *desc,
+                        const int32_t *valid, float th, std::vector<int32_t> &match)
+{
+    const orbfe_params *P = orbfe_ctx_params(ctx);
+    const float *sf = orbfe_ctx_scale_factors(ctx);
+    const float log_sf = logf((float)(double)P->scale_factor);
+    std::vector<MatchQuery> q(n);
+    std::vector<uint8_t> qd((size_t)32 * (n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) {
+        MatchQuery &Q = q[i];
+        Q = MatchQuery{0, 0, 0, 0, -1, 0, 0, 0};
+        if (!valid[i]) continue;
+        float pa[3], pb[3];
+        rt_apply(Taw, pos + 3 * i, pa);
+        rt_apply(sRt, pa, pb);
+        if ((double)pb[2] < 0.0) continue;
+        const float invz = (float)(1.0 / (double)pb[2]);
+        const float x = pb[0] * invz, y = pb[1] * invz;
+        const float u = P->fx * x + P->cx, v = P->fy * y + P->cy;
+        if (!(u >= kfb->min_x && u < kfb->max_x && v >= kfb->min_y && v < kfb->max_y)) continue;
+        const float dist = (float)sqrt((double)pb[0] * pb[0] + (double)pb[1] * pb[1] + (double)pb[2] * pb[2]);
+        if (dist < 0.8f * min_distance[i] || dist > 1.2f * max_distance[i]) continue;
+        const int lvl = predict_scale(max_distance[i], dist, log_sf, P->nlevels);
+        Q.u = u; Q.v = v; Q.r = th * sf[lvl]; Q.min_level = lvl - 1; Q.max_level = lvl; Q.flags = 1;
+        memcpy(&qd[(size_t)32 * i], desc + (size_t)32 * i, 32);
+    }
+    int rc = run_window_queries(ctx, kfb, q, qd);
+    if (rc != ORBFE_OK) return rc;
+    orbfe_match_state *st = match_state(ctx);
+    match.assign(n > 0 ? n : 1, -1);
+    for (int i = 0; i < n; i++) {
+        unsigned long long best = ~0ull;
+        for (int k = 0; k < st->h_cnt[i]; k++) {
+            const unsigned long long key = st->h_list[st->h_off[i] + k];
+            if (key < best) best = key;
+        }
+        if (best != ~0ull && key_dist(best) <= TH_HIGH) match[i] = key_idx(best);
+    }
+    return ORBFE_OK;
+}
+
+// ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th), src/ORBmatcher.cc:1098-1322
+extern "C" int orbfe_search_by_sim3(orbfe_context *ctx,
+                                    const orbfe_frame_view *kf1, const float *T1w, const float *pos1, const float *max_distance1,
+                                    const float *min_distance1, const uint8_t *pt_desc1, const int32_t *valid1,
+                                    const orbfe_frame_view *kf2, const float *T2w, const float *pos2, const float *max_distance2,
+                                    const float *min_distance2, const uint8_t *pt_desc2, const int32_t *valid2,
+                                    float s12, const float *R12, const float *t12, float th, int32_t *match12, int *n_found)
+{
+    int rc = check_view(ctx, kf1);
+    if (rc != ORBFE_OK) return rc;
+    rc = check_view(ctx, kf2);
+    if (rc != ORBFE_OK) return rc;
+    const int N1 = kf1->n, N2 = kf2->n;
+    if (!T1w || !T2w || !R12 || !t12 || !n_found || (N1 > 0 && (!pos1 || !max_distance1 || !min_distance1 || !pt_desc1 || !valid1 || !match12)) ||
+        (N2 > 0 && (!pos2 || !max_distance2 || !min_distance2 || !pt_desc2 || !valid2)))
+        return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    // sR12 = s12 * R12; sR21 = (1.0 / s12) * R12.t(); t21 = -sR21 * t12 (:1116-1119)
+    float A12[12], A21[12];
+    const float inv_s = (float)(1.0 / (double)s12);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { A12[4 * i + j] = R12[3 * i + j] * s12; A21[4 * i + j] = R12[3 * j + i] * inv_s; }
+    for (int i = 0; i < 3; i++) {
+        A12[4 * i + 3] = t12[i];
+        const float t0 = (A21[4 * i] * t12[0] + A21[4 * i + 1] * t12[1]) + A21[4 * i + 2] * t12[2];
+        A21[4 * i + 3] = -t0;
+    }
+    std::vector<int32_t> m1, m2;
+    rc = sim3_one_way(ctx, T1w, A21, kf2, N1, pos1, max_distance1, min_distance1, pt_desc1, valid1, th, m1);
+    if (rc != ORBFE_OK) return rc;
+    rc = sim3_one_way(ctx, T2w, A12, kf1, N2, pos2, max_distance2, min_distance2, pt_desc2, valid2, th, m2);
+    if (rc != ORBFE_OK) return rc;
+    int nf = 0;
+    for (int i1 = 0; i1 < N1; i1++) { // check agreement (:1293-1308)
+        match12[i1] = -1;
+        const int idx2 = m1[i1];
+        if (idx2 >= 0 && m2[idx2] == i1) { match12[i1] = idx2; nf++; }
+    }
+    *n_found = nf;
+    return ORBFE_OK;
+}
+
 // ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:400-515
 extern "C" int orbfe_search_for_initialization(orbfe_context *ctx, const orbfe_frame_view *f1, const orbfe_frame_view *f2,
                                                float *prev_matched, int window_size, float nnratio, int check_ori,

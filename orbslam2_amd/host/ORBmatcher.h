@@ -183,6 +183,65 @@ public:
         return n;
     }
 
+    // Map points offered to a keyframe (Fuse, Sim3 matchers): one entry per candidate point
+    struct CandidatePoints {
+        std::vector<float> pos, normal;            // GetWorldPos(), GetNormal(), n x 3
+        std::vector<float> maxDistance, minDistance; // mfMaxDistance, mfMinDistance
+        std::vector<uint8_t> desc;                 // GetDescriptor(), n x 32
+        std::vector<int32_t> valid;                // pMP && !isBad() && not already in the keyframe / matched set
+        int size() const { return (int)valid.size(); }
+    };
+
+    // Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, th), src/ORBmatcher.cc:821: SEARCH PART.  bestIdx[i] = keypoint of
+    // pKF to fuse point i with, or -1; the caller then runs the reference's :943-964 (Replace / AddObservation) on it.
+    int Fuse(const FrameView &pKF, const float *Tcw, const CandidatePoints &pts, float th, std::vector<int32_t> &bestIdx)
+    {
+        const orbfe_frame_view v = pKF.c_view();
+        bestIdx.assign(pts.size() > 0 ? pts.size() : 1, -1);
+        int n = 0;
+        Check(orbfe_fuse(mCtx, &v, Tcw, pts.size(), pts.pos.data(), pts.normal.data(), pts.maxDistance.data(), pts.minDistance.data(),
+                         pts.desc.data(), pts.valid.data(), th, bestIdx.data(), &n));
+        bestIdx.resize(pts.size());
+        return n;
+    }
+    // Fuse(KeyFrame *pKF, cv::Mat Scw, vpPoints, th, vpReplacePoint), src/ORBmatcher.cc:973: search part, Scw = top 3x4 rows
+    int Fuse(const FrameView &pKF, const float *Scw, const CandidatePoints &pts, float th, std::vector<int32_t> &bestIdx, bool /*sim3*/)
+    {
+        const orbfe_frame_view v = pKF.c_view();
+        bestIdx.assign(pts.size() > 0 ? pts.size() : 1, -1);
+        int n = 0;
+        Check(orbfe_fuse_sim3(mCtx, &v, Scw, pts.size(), pts.pos.data(), pts.normal.data(), pts.maxDistance.data(), pts.minDistance.data(),
+                              pts.desc.data(), pts.valid.data(), th, bestIdx.data(), &n));
+        bestIdx.resize(pts.size());
+        return n;
+    }
+    // SearchByProjection(KeyFrame *pKF, cv::Mat Scw, vpPoints, vpMatched, th), src/ORBmatcher.cc:285; kfMatched[k] = vpMatched[k] != NULL
+    int SearchByProjection(const FrameView &pKF, const float *Scw, const CandidatePoints &pts, const std::vector<uint8_t> &kfMatched, int th,
+                           std::vector<int32_t> &ptMatch)
+    {
+        const orbfe_frame_view v = pKF.c_view();
+        ptMatch.assign(pts.size() > 0 ? pts.size() : 1, -1);
+        int n = 0;
+        Check(orbfe_search_by_projection_sim3(mCtx, &v, Scw, pts.size(), pts.pos.data(), pts.normal.data(), pts.maxDistance.data(),
+                                              pts.minDistance.data(), pts.desc.data(), pts.valid.data(),
+                                              kfMatched.empty() ? nullptr : kfMatched.data(), (float)th, ptMatch.data(), &n));
+        ptMatch.resize(pts.size());
+        return n;
+    }
+    // SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th), src/ORBmatcher.cc:1098; pts1 / pts2 have one entry per keypoint slot
+    int SearchBySim3(const FrameView &pKF1, const float *T1w, const CandidatePoints &pts1, const FrameView &pKF2, const float *T2w,
+                     const CandidatePoints &pts2, float s12, const float R12[9], const float t12[3], float th, std::vector<int32_t> &vnMatches12)
+    {
+        const orbfe_frame_view v1 = pKF1.c_view(), v2 = pKF2.c_view();
+        vnMatches12.assign(v1.n > 0 ? v1.n : 1, -1);
+        int n = 0;
+        Check(orbfe_search_by_sim3(mCtx, &v1, T1w, pts1.pos.data(), pts1.maxDistance.data(), pts1.minDistance.data(), pts1.desc.data(),
+                                   pts1.valid.data(), &v2, T2w, pts2.pos.data(), pts2.maxDistance.data(), pts2.minDistance.data(),
+                                   pts2.desc.data(), pts2.valid.data(), s12, R12, t12, th, vnMatches12.data(), &n));
+        vnMatches12.resize(v1.n);
+        return n;
+    }
+
     // ComputeThreeMaxima(histo, L, ind1, ind2, ind3), src/ORBmatcher.cc:1597
     void ComputeThreeMaxima(const std::vector<int> *histo, const int L, int &ind1, int &ind2, int &ind3)
     {

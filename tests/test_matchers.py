@@ -331,3 +331,54 @@ def test_gpu_sim3_projection_matchers(gpu, mode, seed, th):
     m = ref[ref >= 0]
     if mode == 0:
         assert len(np.unique(m)) == len(m) and not kf_matched[m].any()  # one keypoint per point, none of the pre-matched ones
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,th", [(60, 7.5), (61, 3.0)])
+def test_gpu_search_by_sim3(gpu, seed, th):
+    """ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1098-1322) == oracle: two keyframes of the same 3-D points whose maps differ by a
+    similarity; both projection directions and the mutual-consistency check."""
+    api, ctx = gpu
+    rng = np.random.default_rng(seed)
+    ex = O.Extractor()
+    sf = ex.scale_factors()
+    n = 1300
+    Pw = np.stack([rng.uniform(-8, 8, n), rng.uniform(-5, 5, n), rng.uniform(4, 35, n)], axis=1)
+    T1 = _se3(0.0, [0, 0, 0]).astype(np.float64)
+    T2 = _se3(4.0, [-0.5, 0.03, 0.1]).astype(np.float64)
+    base_d = rng.integers(0, 256, (n, 32)).astype(np.uint8)
+    bounds = (0.0, float(W), 0.0, float(H))
+
+    def keyframe(T, seed2, extra):
+        r = np.random.default_rng(seed2)
+        pc = (T[:, :3] @ Pw.T).T + T[:, 3]
+        k = np.zeros(n + extra, O.KP_DTYPE)
+        k["x"][:n] = FX * pc[:, 0] / pc[:, 2] + CX + r.normal(0, 0.8, n); k["y"][:n] = FY * pc[:, 1] / pc[:, 2] + CY + r.normal(0, 0.8, n)
+        k["x"][n:] = r.uniform(0, W, extra); k["y"][n:] = r.uniform(0, H, extra)
+        k["octave"] = r.integers(0, NL, n + extra); k["angle"] = r.uniform(0, 360, n + extra); k["size"] = 31; k["class_id"] = -1
+        d = np.concatenate([base_d ^ np.packbits(r.random((n, 256)) < 0.05, axis=1, bitorder="little"), r.integers(0, 256, (extra, 32)).astype(np.uint8)])
+        dist = np.linalg.norm(pc, axis=1)
+        pos = np.zeros((n + extra, 3), np.float32); pos[:n] = Pw
+        mx = np.ones(n + extra, np.float32); mx[:n] = dist * sf[k["octave"][:n]]
+        mn = (mx / sf[NL - 1]).astype(np.float32)
+        valid = np.zeros(n + extra, np.int32); valid[:n] = r.random(n) < 0.85
+        perm = r.permutation(n + extra)
+        return k[perm], d[perm], pos[perm], mx[perm], mn[perm], valid[perm], perm
+
+    k1, d1, pos1, mx1, mn1, v1, perm1 = keyframe(T1, seed * 7 + 1, 300)
+    k2, d2, pos2, mx2, mn2, v2, perm2 = keyframe(T2, seed * 7 + 2, 200)
+    # Sim3 from camera 2 to camera 1 (s12 = 1 here up to a small scale drift): X1 = s12 R12 X2 + t12
+    R12 = (T1[:, :3] @ T2[:, :3].T)
+    t12 = T1[:, 3] - R12 @ T2[:, 3]
+    s12 = np.float32(1.02)
+    g1, g2 = O.Grid(k1, *bounds), O.Grid(k2, *bounds)
+    pts1 = (pos1, mx1, mn1, d1, v1); pts2 = (pos2, mx2, mn2, d2, v2)  # GetDescriptor() = the observing keypoint's descriptor here
+    ref, nref = O.search_by_sim3(g1, d1, T1.astype(np.float32), pts1, g2, d2, T2.astype(np.float32), pts2, sf, CAM, LOG_SF, NL,
+                                 s12, R12.astype(np.float32), t12.astype(np.float32), th)
+    view1 = ctx._view(k1, None, d1, bounds); view2 = ctx._view(k2, None, d2, bounds)
+    got, ngot = ctx.search_by_sim3(view1, T1.astype(np.float32), pts1, view2, T2.astype(np.float32), pts2, s12, R12.astype(np.float32),
+                                   t12.astype(np.float32), th)
+    assert ngot == nref and np.array_equal(got, ref)
+    assert nref > 150
+    ok = np.nonzero(ref >= 0)[0]
+    assert (perm1[ok] == perm2[ref[ok]]).mean() > 0.9  # same 3-D point on both sides
