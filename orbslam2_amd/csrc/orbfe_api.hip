@@ -2,7 +2,7 @@
 //
 // Builds the level / cell / quota tables exactly as ORBextractor::ORBextractor and
 // ComputePyramid do (reference src/ORBextractor.cc:405-464,921-946), owns the HBM
-// buffers of one batch of images, and enqueues the kernels of orbfe_kernels.hip.
+// buffers of one batch of images, and enqueues the kernels of the stage files (orbfe_pyramid / fast / octree* / describe / stereo .hip).
 // There is no CPU compute path here: without a HIP device orbfe_create fails.
 #include "../../include/orbfe.h"
 #include "orbfe_device.h"
@@ -202,7 +202,7 @@ static int build_config(orbfe_context *ctx)
         L.w = cv_round_f((float)p.width * L.inv_scale);
         L.h = cv_round_f((float)p.height * L.inv_scale);
         if (L.w < 1 || L.h < 1) return fail(ctx, ORBFE_ERR_UNSUPPORTED, "level %d is empty (%dx%d)", l, L.w, L.h);
-        // reflect-101 margin: 4 px left, >= 12 px right, 3 rows above/below (see orbfe_kernels.hip)
+        // reflect-101 margin: 4 px left, >= 12 px right, 3 rows above/below (see orbfe_pyramid.hip)
         L.pitch = (L.w + 16 + 63) & ~63;
         L.pyr_off = (int)(pyr_off + (size_t)3 * L.pitch + 4);
         pyr_off += ((size_t)L.pitch * (L.h + 6) + 255) & ~(size_t)255;

@@ -1,0 +1,282 @@
+// orbfe_describe.hip -- IC_Angle + computeOrbDescriptor + keypoint records (src/ORBextractor.cc:72-142,831-846,909-915) and the stereo row lists.
+#include "orbfe_common.cuh"
+
+__device__ __attribute__((aligned(16))) const int8_t g_pattern[1024] = {
+#include "orb_pattern_31.inc"
+};
+
+// ---------------------------------------------------------------------------
+// orientation + descriptor + final keypoint record: one wave per keypoint slot
+// ---------------------------------------------------------------------------
+// The kernel is bound by vector-memory INSTRUCTION issue (a wave64 byte gather costs the texture
+// addresser ~16 cycles whatever it fetches), so everything is fetched as aligned dwords into LDS:
+// the block stages the two tables once, each wave stages a keypoint's 31-row raw patch (5 loads) and
+// 37-row blurred patch (6 loads), and all per-pixel / per-sample accesses become LDS byte reads.
+// A wave handles DS_KPW consecutive keypoint slots: the table staging and the slot bookkeeping are paid
+// once per 4 * DS_KPW keypoints, and the patch words of keypoint i+1 are fetched into registers while
+// keypoint i is computed from LDS, so the global-load latency is off the critical path.
+#define DS_PATCH_W 40 // bytes per staged patch row (10 words: covers 31+3 / 37+3 px at any alignment)
+#define DS_KPW 4      // keypoint slots per wave
+#define DS_RAW_REGS 5 // prefetch registers for the raw patch (raw_rows * 10 words <= 320, i.e. half_patch <= 15)
+#define DS_BLR_REGS 6 // 37 rows * 10 words = 370 words
+
+
+__global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int stereo, int dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dm[];
+    // XCD-aware block -> (image, block) map: workgroups are dealt round-robin over the 8 XCDs, so block
+    // b runs on XCD b % 8 (placement is a speed assumption only).  All blocks of one image are given to
+    // one XCD, whose 4 MiB L2 then holds that image's raw + blurred pyramid (3.3 MB) while its ~2000
+    // overlapping 31x31 / 37x37 patches are read, instead of every patch row coming from the MALL.
+    const int bpi = (cfg.sel_total + 4 * DS_KPW - 1) / (4 * DS_KPW); // blocks per image
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int img = (jb / bpi) * 8 + xcd;
+    if (img >= n_images) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform values must be provably so: they feed scalar addresses
+    const int slot0 = (jb % bpi) * (4 * DS_KPW) + wave * DS_KPW;
+    const int hp = cfg.half_patch;
+    const int raw_rows = 2 * hp + 1;
+    const int raw_words = raw_rows * (DS_PATCH_W / 4);
+    const int *sel_cnt = buf.sel_cnt + (size_t)img * cfg.nlevels;
+    if (jb % bpi == 0 && tid == 0) {
+        int tot = 0;
+        for (int l = 0; l < cfg.nlevels; l++) tot += sel_cnt[l];
+        buf.kp_cnt[img] = tot;
+    }
+    // block-shared tables: patch offsets (patch_n shorts) | pattern (256 words)
+    int16_t *s_uv = (int16_t *)s_dm;
+    int *s_pat = (int *)(s_dm + ((cfg.patch_n * 2 + 15) & ~15));
+    uint8_t *s_raw = (uint8_t *)(s_pat + 256) + wave * ((raw_rows + 37) * DS_PATCH_W);
+    uint8_t *s_blr = s_raw + raw_rows * DS_PATCH_W;
+    for (int i = tid; i < cfg.patch_n / 2; i += 256) ((int *)s_uv)[i] = ((const int *)buf.patch_uv)[i];
+    s_pat[tid] = ((const int *)g_pattern)[tid];
+    // per-wave slot data, one slot per lane (lanes < DS_KPW), issued before the barrier
+    const int my_slot = slot0 + (lane < DS_KPW ? lane : 0);
+    const bool my_in = lane < DS_KPW && my_slot < cfg.sel_total;
+    const int level_l = my_in ? buf.slot_level[my_slot] : 0;
+    const uint32_t xy_l = my_in ? buf.sel_xy[(size_t)img * cfg.sel_total + my_slot] : 0u;
+    const int score_l = my_in ? buf.sel_sc[(size_t)img * cfg.sel_total + my_slot] : 0;
+    const int c_l = lane < cfg.nlevels ? sel_cnt[lane] : 0;
+    __syncthreads();
+    int inc = c_l;
+#pragma unroll
+    for (int o = 1; o < ORBFE_MAX_LEVELS; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    const int excl = inc - c_l; // keypoints of the lower levels
+    if (dbg == 1) return;
+
+    const int r0 = lane / (DS_PATCH_W / 4), c0 = lane - r0 * (DS_PATCH_W / 4);
+    const bool raw_in_regs = raw_words <= 64 * DS_RAW_REGS;
+    uint32_t pr[DS_RAW_REGS], pb[DS_BLR_REGS];
+    // Word i = lane + 64*k of a staged patch is (row i / 10, word i % 10).  The (row, 4 * word) pairs of this lane's words are
+    // computed once per wave and packed two per register (raw | blurred << 16, each row | 4 * word << 8); a patch word is then
+    // one mad away from a wave-uniform base address (scalar registers), instead of 64-bit per-lane pointer stepping with
+    // per-load predication -- that bookkeeping used to be 40 % of the kernel's VALU instructions.  Words past the end of a
+    // patch repeat its last word (same value to the same LDS slot), so nothing is predicated.
+    const int blr_words = 37 * (DS_PATCH_W / 4);
+    uint32_t wtab[DS_BLR_REGS];
+#pragma unroll
+    for (int k = 0; k < DS_BLR_REGS; k++) {
+        const int i = lane + 64 * k;
+        const int ir = i < raw_words ? i : raw_words - 1, ib = i < blr_words ? i : blr_words - 1;
+        const int rr = (ir * 6554) >> 16, rb = (ib * 6554) >> 16; // / 10 for i < 16384
+        wtab[k] = (uint32_t)(rr | ((4 * (ir - 10 * rr)) << 8)) | ((uint32_t)(rb | ((4 * (ib - 10 * rb)) << 8)) << 16);
+    }
+    const int lds_last_raw = 4 * (lane + 64 * (DS_RAW_REGS - 1) < raw_words ? lane + 64 * (DS_RAW_REGS - 1) : raw_words - 1);
+    const int lds_last_blr = 4 * (lane + 64 * (DS_BLR_REGS - 1) < blr_words ? lane + 64 * (DS_BLR_REGS - 1) : blr_words - 1);
+    auto fetch_raw = [&](const uint8_t *base /* uniform: patch origin */, int pitch) {
+#pragma unroll
+        for (int k = 0; k < DS_RAW_REGS; k++) {
+            const unsigned e = wtab[k] & 0xffffu;
+            pr[k] = *(const uint32_t *)(base + ((unsigned)__mul24(e & 0xffu, pitch) + (e >> 8))); // one 32-bit offset: saddr + voffset
+        }
+    };
+    auto fetch_blr = [&](const uint8_t *base, int pitch) {
+#pragma unroll
+        for (int k = 0; k < DS_BLR_REGS; k++) {
+            const unsigned e = wtab[k] >> 16;
+            pb[k] = *(const uint32_t *)(base + ((unsigned)__mul24(e & 0xffu, pitch) + (e >> 8)));
+        }
+    };
+    // slot i of this wave: uniform keypoint data; returns false if the slot holds no keypoint
+    int level = 0, cx = 0, cy = 0, score = 0, out = 0;
+    auto slot_data = [&](int i) -> bool {
+        if (slot0 + i >= cfg.sel_total) return false;
+        level = __builtin_amdgcn_readlane(level_l, i);
+        const uint32_t xy = (uint32_t)__builtin_amdgcn_readlane((int)xy_l, i);
+        score = __builtin_amdgcn_readlane(score_l, i);
+        const int k = slot0 + i - cfg.lv[level].sel_off;
+        if (k >= __builtin_amdgcn_readlane(c_l, level)) return false; // readlane (not a shuffle): the result is a scalar
+        out = k + __builtin_amdgcn_readlane(excl, level);
+        cx = (int)(xy & 0xffffu) + cfg.min_border;
+        cy = (int)(xy >> 16) + cfg.min_border;
+        return true;
+    };
+    auto prefetch_raw = [&](int i) -> bool {
+        if (i >= DS_KPW || !slot_data(i)) return false;
+        const LevelInfo &L = cfg.lv[level];
+        if (raw_in_regs)
+            fetch_raw(buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (ptrdiff_t)(cy - hp) * L.pitch + ((cx - hp) & ~3), L.pitch);
+        return true;
+    };
+    auto prefetch_blur = [&](int i) -> bool {
+        if (i >= DS_KPW || !slot_data(i)) return false;
+        const LevelInfo &L = cfg.lv[level];
+        fetch_blr(buf.blur + (size_t)img * cfg.pyr_bytes + L.pyr_off + (ptrdiff_t)(cy - 18) * L.pitch + ((cx - 18) & ~3), L.pitch);
+        return true;
+    };
+
+    // Pass 1: raw patches -> IC_Angle moments of the wave's keypoints (lane i keeps keypoint i's);
+    // then fastAtan2 and the sin / cos ONCE for all of them (lane i computes keypoint i's: those ~150 scalar-like
+    // instructions, part of them double precision, would otherwise be repeated per keypoint by all 64 lanes);
+    // pass 2: blurred patches -> descriptors and keypoint records.
+    int m10_l = 0, m01_l = 0;
+    bool have = prefetch_raw(0);
+    for (int i = 0; i < DS_KPW; i++) {
+        const bool cur = have;
+        int kx = 0, ky = 0, lv = 0;
+        if (cur) {
+            slot_data(i);
+            kx = cx; ky = cy; lv = level;
+            if (raw_in_regs) {
+#pragma unroll
+                for (int k = 0; k < DS_RAW_REGS - 1; k++) ((uint32_t *)s_raw)[lane + 64 * k] = pr[k];
+                *(uint32_t *)(s_raw + lds_last_raw) = pr[DS_RAW_REGS - 1];
+            }
+            if (!raw_in_regs) { // big patches: straight through (no prefetch)
+                const LevelInfo &Lr = cfg.lv[lv];
+                const uint8_t *gp = buf.pyr + (size_t)img * cfg.pyr_bytes + Lr.pyr_off + (ptrdiff_t)__mul24(ky - hp + r0, Lr.pitch) + ((kx - hp) & ~3) + 4 * c0;
+                const int step = 6 * Lr.pitch + 16, wrap = Lr.pitch - DS_PATCH_W;
+                int c = c0;
+                for (int w = lane; w < raw_words; w += 64) {
+                    ((uint32_t *)s_raw)[w] = *(const uint32_t *)gp;
+                    gp += step; c += 4;
+                    if (c >= DS_PATCH_W / 4) { c -= DS_PATCH_W / 4; gp += wrap; }
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0); // LDS writes of this wave are visible to its own later reads in order
+        __builtin_amdgcn_wave_barrier();
+        have = prefetch_raw(i + 1); // in flight while keypoint i is computed
+        if (!cur || dbg == 2) continue;
+        // IC_Angle (src/ORBextractor.cc:72-99): integer moments over the circular patch (host-built offset
+        // table, padded with (0,0) entries that contribute nothing)
+        const int xr = (kx - hp) & ~3;
+        int m10 = 0, m01 = 0;
+        const uint8_t *pc = s_raw + hp * DS_PATCH_W + (kx - xr);
+        for (int kk = lane; kk < cfg.patch_n; kk += 64) {
+            const int uv = s_uv[kk];
+            const int u = (int)(int8_t)(uv & 0xff), v = (int)(int8_t)((uv >> 8) & 0xff);
+            const int I = pc[__mul24(v, DS_PATCH_W) + u];
+            m10 += u * I;
+            m01 += v * I;
+        }
+        m10 = wave_sum_i32(m10);
+        m01 = wave_sum_i32(m01);
+        if (lane == i) { m10_l = m10; m01_l = m01; }
+    }
+    have = prefetch_blur(0); // in flight during the angle arithmetic
+    const float angle_l = fast_atan2_deg((float)m01_l, (float)m10_l);
+    const float factor_pi = __uint_as_float(0x3c8efa35u); // (float)(CV_PI/180.f)
+    float a_l, b_l;
+    sincos_det(__fmul_rn(angle_l, factor_pi), &b_l, &a_l);
+
+    int rl_lv = -1;          // lane i < DS_KPW: level | index << 8 of the wave's i-th keypoint (-1: none), its x and y
+    float rl_x = 0.f, rl_y = 0.f;
+    for (int i = 0; i < DS_KPW; i++) {
+        const bool cur = have;
+        int lv = 0, kx = 0, ky = 0, ksc = 0, kout = 0;
+        if (cur) {
+            slot_data(i);
+            lv = level; kx = cx; ky = cy; ksc = score; kout = out;
+#pragma unroll
+            for (int k = 0; k < DS_BLR_REGS - 1; k++) ((uint32_t *)s_blr)[lane + 64 * k] = pb[k];
+            *(uint32_t *)(s_blr + lds_last_blr) = pb[DS_BLR_REGS - 1];
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        have = prefetch_blur(i + 1);
+        if (!cur || dbg == 2) continue;
+        const LevelInfo &L = cfg.lv[lv];
+        const int xb = (kx - 18) & ~3;
+        const float angle = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(angle_l), i));
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_l), i));
+        const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_l), i));
+        if (dbg == 3) { if (lane == 0) buf.depth[(size_t)img * cfg.sel_total + kout] = angle; continue; }
+
+        // computeOrbDescriptor (src/ORBextractor.cc:103-142)
+        const uint8_t *center = s_blr + 18 * DS_PATCH_W + (kx - xb);
+        unsigned long long *dout = (unsigned long long *)(buf.desc + ((size_t)img * cfg.sel_total + kout) * 32);
+        unsigned long long bits[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int pw = s_pat[r * 64 + lane]; // (x0, y0, x1, y1) as 4 signed bytes
+            const float x0 = (float)(int)(int8_t)(pw & 0xff), y0 = (float)(int)(int8_t)((pw >> 8) & 0xff);
+            const float x1 = (float)(int)(int8_t)((pw >> 16) & 0xff), y1 = (float)(pw >> 24);
+            const int rr0 = (int)rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+            const int cc0 = (int)rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+            const int rr1 = (int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+            const int cc1 = (int)rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+            const int t0 = center[__mul24(rr0, DS_PATCH_W) + cc0];
+            const int t1 = center[__mul24(rr1, DS_PATCH_W) + cc1];
+            bits[r] = __ballot(t0 < t1);
+        }
+        if (lane < 4) dout[lane] = lane == 0 ? bits[0] : (lane == 1 ? bits[1] : (lane == 2 ? bits[2] : bits[3]));
+        float px = (float)kx, py = (float)ky;
+        if (lv != 0) { px = __fmul_rn(px, L.scale); py = __fmul_rn(py, L.scale); }
+        if (lane == i) { rl_lv = lv | (kout << 8); rl_x = px; rl_y = py; } // for the stereo row lists below
+        if (lane == 0) {
+            KeyPointPOD kp;
+            kp.x = px; kp.y = py;
+            kp.size = (float)L.scaled_patch;
+            kp.angle = angle;
+            kp.response = (float)ksc;
+            kp.octave = lv;
+            kp.class_id = -1;
+            ((KeyPointPOD *)buf.kps)[(size_t)img * cfg.sel_total + kout] = kp;
+        }
+    }
+    if (stereo && (img & 1)) {
+        // right image of a pair: list each keypoint in the rows its band covers (vRowIndices, src/Frame.cc:474-491: rows
+        // floor(y - r) .. ceil(y + r), r = 2 * scale[octave]); the order inside a row list is irrelevant to
+        // stereo_match_kernel's arg-min.  All of the wave's atomics are issued before the first dependent store.
+        int *rcnt = buf.row_cnt + (size_t)(img >> 1) * cfg.height;
+        uint2 *rent = buf.row_ent + (size_t)(img >> 1) * cfg.height * cfg.row_cap;
+        int pos[DS_KPW], yy[DS_KPW];
+        uint2 e[DS_KPW];
+#pragma unroll
+        for (int i = 0; i < DS_KPW; i++) {
+            const int lvk = __builtin_amdgcn_readlane(rl_lv, i);
+            const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rl_x), i));
+            const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rl_y), i));
+            pos[i] = -1; yy[i] = 0;
+            e[i].x = (uint32_t)(lvk >> 8) | ((uint32_t)(lvk & 255) << 16); e[i].y = __float_as_uint(x);
+            if (lvk >= 0) {
+                const float r = __fmul_rn(2.0f, cfg.lv[lvk & 255].scale);
+                int maxr = (int)ceilf(__fadd_rn(y, r)), minr = (int)floorf(__fsub_rn(y, r));
+                minr = minr < 0 ? 0 : minr; maxr = maxr > cfg.height - 1 ? cfg.height - 1 : maxr;
+                yy[i] = minr + lane;
+                if (yy[i] <= maxr) pos[i] = atomicAdd(&rcnt[yy[i]], 1);
+                for (int y2 = yy[i] + 64; y2 <= maxr; y2 += 64) { // bands taller than a wave (large scale factors only)
+                    const int p2 = atomicAdd(&rcnt[y2], 1);
+                    if (p2 < cfg.row_cap) rent[(size_t)y2 * cfg.row_cap + p2] = e[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < DS_KPW; i++)
+            if (pos[i] >= 0 && pos[i] < cfg.row_cap) rent[(size_t)yy[i] * cfg.row_cap + pos[i]] = e[i];
+    }
+}
+
+
+void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool stereo, hipStream_t s)
+{
+    dim3 grid(((cfg.sel_total + 4 * DS_KPW - 1) / (4 * DS_KPW)) * ((n_images + 7) / 8) * 8);
+    const size_t lds = ((cfg.patch_n * 2 + 15) & ~15) + 256 * 4 + (size_t)4 * (2 * cfg.half_patch + 1 + 37) * DS_PATCH_W;
+    static const int dbg = getenv("ORBFE_DESC_DBG") ? atoi(getenv("ORBFE_DESC_DBG")) : 0; // profiling aid only
+    hipLaunchKernelGGL(describe_kernel, grid, dim3(256), lds, s, cfg, buf, n_images, stereo ? 1 : 0, dbg);
+}

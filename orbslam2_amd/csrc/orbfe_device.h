@@ -106,7 +106,7 @@ struct KeyPointPOD {
 };
 static_assert(sizeof(KeyPointPOD) == 28, "keypoint must match cv::KeyPoint");
 
-// launchers (orbfe_kernels.hip)
+// launchers (orbfe_pyramid.hip, orbfe_fast.hip, orbfe_octree*.hip, orbfe_describe.hip, orbfe_stereo.hip)
 void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, const uint8_t *d_images,
                          int n_images, hipStream_t s);
 void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);

@@ -1,0 +1,447 @@
+// orbfe_fast.hip -- cell-wise cv::FAST with two thresholds (src/ORBextractor.cc:783-823) + quadtree bucket accumulation.
+#include "orbfe_common.cuh"
+
+// ---------------------------------------------------------------------------
+// FAST-9/16 per cell: score map + 3x3 NMS inside the cell + two-threshold select
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int fast_score16(const uint8_t *t, int pitch, int minth)
+{
+    const int v = t[0];
+    int d[16];
+    d[0] = v - t[3 * pitch];       d[1] = v - t[3 * pitch + 1];   d[2] = v - t[2 * pitch + 2];   d[3] = v - t[pitch + 3];
+    d[4] = v - t[3];               d[5] = v - t[-pitch + 3];      d[6] = v - t[-2 * pitch + 2];  d[7] = v - t[-3 * pitch + 1];
+    d[8] = v - t[-3 * pitch];      d[9] = v - t[-3 * pitch - 1];  d[10] = v - t[-2 * pitch - 2]; d[11] = v - t[-pitch - 3];
+    d[12] = v - t[-3];             d[13] = v - t[pitch - 3];      d[14] = v - t[2 * pitch - 2];  d[15] = v - t[3 * pitch - 1];
+    int mn2[16], mx2[16], mn4[16], mx4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+    int a = -512, b = 512;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+        const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+        a = max(a, mn9);
+        b = min(b, mx9);
+    }
+    return max(minth, max(a, -b)) - 1;
+}
+
+// One wave (64-thread workgroup) per FAST cell (src/ORBextractor.cc:783-810): no inter-wave barriers,
+// and wave-ordered ballot compaction keeps every queue in row-major order, which is cv::FAST's
+// emission order.  Phases:
+//  0  aligned 32-bit loads of the (w+6)x(h+6) cell tile into LDS;
+//  A  cheap necessary test on the 4 cardinal ring pixels (a 9-arc always holds two adjacent
+//     cardinals)                                                        -> queue 1
+//  B  OpenCV's 8-opposite-pairs necessary test on the full ring         -> queue 2
+//  C  exact threshold-independent score (closed form of cornerScore<16>) for queue 2
+//  D  strict 3x3 NMS inside the cell interior; iniThFAST, or minThFAST if that leaves nothing
+//  E  ordered compaction of the survivors into the cell's slot.
+__device__ __forceinline__ void load_ring(const uint8_t *t, int pitch, int d[16])
+{
+    const int v = t[0];
+    d[0] = v - t[3 * pitch];       d[1] = v - t[3 * pitch + 1];   d[2] = v - t[2 * pitch + 2];   d[3] = v - t[pitch + 3];
+    d[4] = v - t[3];               d[5] = v - t[-pitch + 3];      d[6] = v - t[-2 * pitch + 2];  d[7] = v - t[-3 * pitch + 1];
+    d[8] = v - t[-3 * pitch];      d[9] = v - t[-3 * pitch - 1];  d[10] = v - t[-2 * pitch - 2]; d[11] = v - t[-pitch - 3];
+    d[12] = v - t[-3];             d[13] = v - t[pitch - 3];      d[14] = v - t[2 * pitch - 2];  d[15] = v - t[3 * pitch - 1];
+}
+
+// number of set bits of m below this lane, plus acc (v_mbcnt_lo/hi accumulate form)
+__device__ __forceinline__ unsigned mbcnt64(unsigned long long m, unsigned acc)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, acc));
+}
+
+// Two adjacent bytes P, P+1 of a 12-byte row window (w[0] | w[1] | w[2]), zero-extended into the two
+// 16-bit halves of a register: one v_perm_b32 with a constant selector (0x0c selects 0x00).
+template <int P> __device__ __forceinline__ pk16 row_pair(const unsigned (&w)[3])
+{
+    if constexpr (P + 1 <= 7)
+        return __builtin_bit_cast(pk16, __builtin_amdgcn_perm(w[1], w[0], (unsigned)P | 0x0c00u | ((unsigned)(P + 1) << 16) | 0x0c000000u));
+    else
+        return __builtin_bit_cast(pk16, __builtin_amdgcn_perm(w[2], w[1], (unsigned)(P - 4) | 0x0c00u | ((unsigned)(P - 3) << 16) | 0x0c000000u));
+}
+
+// TP = tile pitch in bytes as a compile-time constant (0: run-time value): with it every ring / row offset folds
+// into the immediate offset field of the LDS instructions instead of costing address VALU.
+// BK: also accumulate the quadtree bucket counts / best keys of the survivors (orbfe_octree3.hip) -- aggregated per
+// cell in LDS, then a few global atomics per cell.
+// the waves of a workgroup are independent; a wave's own LDS traffic only needs its outstanding LDS operations retired
+#define FAST_WAVE_SYNC() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); } while (0)
+template <int TP, bool BK>
+__global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int tile_pitch_rt, int tile_bytes, int sc_bytes, int q_bytes, int lds_per_wave, int dbg)
+{
+    const int tile_pitch = TP ? TP : tile_pitch_rt;
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_mem_all[];
+    // XCD-aware block -> (image, cell) map (same scheme as describe_kernel): consecutive cells of one image run
+    // on one XCD, so the 128-B lines that horizontally / vertically adjacent cell tiles share (a 37-row tile
+    // uses ~44 B of each line) are served by that XCD's L2 instead of being re-fetched from HBM by 8 XCDs.
+    // A workgroup is four independent waves = four consecutive cells (no workgroup barriers: FAST_WAVE_SYNC): horizontally
+    // adjacent cells share the 128-B lines of their tile rows, and on one CU those lines are fetched from L2 once.
+    const int bpi = (cfg.cells_total + 3) >> 2;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int img = (jb / bpi) * 8 + xcd;
+    if (img >= n_images) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int cell = (jb % bpi) * 4 + wave;
+    if (cell >= cfg.cells_total) return;
+    uint8_t *s_mem = s_mem_all + wave * lds_per_wave;
+    int level = 0;
+    for (int l = 1; l < cfg.nlevels; l++)
+        if (cell >= cfg.lv[l].cell_off) level = l;
+    const LevelInfo &L = cfg.lv[level];
+    const int ci = cell - L.cell_off;
+    const int ci_i = ci / L.n_cols, ci_j = ci - ci_i * L.n_cols;
+    const int lane = threadIdx.x & 63;
+    int *cnt_out = buf.cell_cnt + (size_t)img * cfg.cells_total + cell;
+
+    const int min_b = cfg.min_border;
+    const int max_bx = L.w - cfg.edge_threshold + 3;
+    const int max_by = L.h - cfg.edge_threshold + 3;
+    const int ini_y = min_b + ci_i * L.h_cell;
+    const int ini_x = min_b + ci_j * L.w_cell;
+    int max_y = ini_y + L.h_cell + 6;
+    int max_x = ini_x + L.w_cell + 6;
+    if (ini_y >= max_by - 3 || ini_x >= max_bx - 6) { // src/ORBextractor.cc:788-798
+        if (lane == 0) *cnt_out = 0;
+        return;
+    }
+    if (max_y > max_by) max_y = max_by;
+    if (max_x > max_bx) max_x = max_bx;
+    const int tw = max_x - ini_x, th = max_y - ini_y;
+    const int iw = tw - 6, ih = th - 6;
+    if (iw <= 0 || ih <= 0) {
+        if (lane == 0) *cnt_out = 0;
+        return;
+    }
+    // bucket tables of this cell's columns / rows (BK): issued now, consumed in phase E
+    unsigned tabx = 0u, taby = 0u;
+    if (BK) {
+        const uint32_t *bx_tab = buf.bk_tab + L.bk_xoff + 3 + ci_j * L.w_cell; // survivor x = c + 3 + j * wCell
+        const uint32_t *by_tab = buf.bk_tab + L.bk_yoff + 3 + ci_i * L.h_cell;
+        tabx = bx_tab[lane < iw ? lane : iw - 1];
+        taby = by_tab[lane < ih ? lane : ih - 1];
+    }
+    // LDS layout (sizes fixed by the host from the largest cell): tile | scores | queue.  Queue 2 is
+    // compacted in place over queue 1 (writes never pass the read cursor); the per-entry flags of
+    // phase D reuse the tile, which is dead after phase C.  4.7 KB per wave keeps 32 waves per CU.
+    uint8_t *s_tile = s_mem;                           // [th][tile_pitch], column 0 = pixel xa (4-aligned)
+    uint8_t *s_sc = s_mem + tile_bytes;                // [(ih+2)][(iw+2)], zero border
+    uint16_t *s_q1 = (uint16_t *)(s_sc + sc_bytes);    // packed (r << 8 | c), row-major ascending
+    uint16_t *s_q2 = s_q1;
+    uint8_t *s_qf = s_tile;                            // per queue-2 entry: 0 / 1 (local max, >= minTh) / 2 (>= iniTh)
+    const int scp = iw + 2;
+
+    const int xa = ini_x & ~3, ox = ini_x - xa;
+    const int wpr = (max_x - xa + 3) >> 2; // words per tile row
+    const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (size_t)ini_y * L.pitch + xa;
+    if (wpr <= 16) {
+        // tile rows of at most 16 words (cells up to ~55 px): a wave-load covers 4 rows x 16 words; lanes beyond the row /
+        // the last row repeat the last valid element (same value to the same LDS word), so nothing is predicated
+        const int c4 = 4 * ((lane & 15) < wpr ? (lane & 15) : wpr - 1);
+        const int rr = lane >> 4;
+        const int nu = (th + 3) >> 2;
+        for (int u0 = 0; u0 < nu; u0 += 4) { // 4 loads in flight per lane
+            uint32_t v[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                int r = rr + 4 * (u0 + u);
+                r = r < th ? r : th - 1;
+                dst[u] = __mul24(r, tile_pitch) + c4;
+                v[u] = *(const uint32_t *)(src + (unsigned)(__mul24(r, L.pitch) + c4));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) *(uint32_t *)(s_tile + dst[u]) = v[u];
+        }
+    } else {
+        // (row, word) of element i = lane, advanced by 64 per step; 32-bit offsets only (64-bit multiplies and a
+        // per-element division cost more VALU issue than the copy itself)
+        int r = (int)(((float)lane + 0.5f) * (1.0f / (float)wpr)), c = lane - r * wpr;
+        const int dr = 64 / wpr, dc = 64 - dr * wpr;
+        const int nw = th * wpr;
+        for (int i0 = lane; i0 < nw; i0 += 256) {
+            uint32_t v[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                dst[u] = __mul24(r, tile_pitch) + 4 * c;
+                if (i0 + 64 * u < nw) v[u] = *(const uint32_t *)(src + (unsigned)(__mul24(r, L.pitch) + 4 * c));
+                c += dc; r += dr;
+                if (c >= wpr) { c -= wpr; r++; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (i0 + 64 * u < nw) *(uint32_t *)(s_tile + dst[u]) = v[u];
+        }
+    }
+    for (int i = lane; i < sc_bytes / 4; i += 64) ((uint32_t *)s_sc)[i] = 0;
+    FAST_WAVE_SYNC();
+    const int t = cfg.min_th;
+    if (dbg == 1) { if (lane == 0) *cnt_out = 0; return; }
+    // Phases A and C work on TWO pixels per lane, one in each 16-bit half of a register, with packed
+    // v_pk_{sub,min,max}_i16 (ring differences are in [-255, 255]): integer VALU issue is what bounds
+    // this kernel (measured ~1 wave64 instruction / cycle / CU), so instructions are what is saved.
+    int roff[16]; // ring offsets inside the LDS tile (uniform)
+    roff[0] = 3 * tile_pitch;      roff[1] = 3 * tile_pitch + 1;   roff[2] = 2 * tile_pitch + 2;   roff[3] = tile_pitch + 3;
+    roff[4] = 3;                   roff[5] = -tile_pitch + 3;      roff[6] = -2 * tile_pitch + 2;  roff[7] = -3 * tile_pitch + 1;
+    roff[8] = -3 * tile_pitch;     roff[9] = -3 * tile_pitch - 1;  roff[10] = -2 * tile_pitch - 2; roff[11] = -tile_pitch - 3;
+    roff[12] = -3;                 roff[13] = tile_pitch - 3;      roff[14] = 2 * tile_pitch - 2;  roff[15] = 3 * tile_pitch - 1;
+    const pk16 tt = {(short)t, (short)t};
+    // ---- A: cv::FAST's quick test on the 8 opposite ring pairs, for every interior pixel: a dark
+    //      (bright) 9-arc needs one darker (brighter) pixel in every pair.  Passing BOTH polarities means
+    //      every pair straddles the centre, which excludes any 9-arc, so such pixels are dropped;
+    //      survivors are queued in row-major order with their polarity in bit 15.
+    //      A lane owns FOUR horizontally adjacent pixels whose tile bytes are 3..6 of a 12-byte window
+    //      (3 aligned LDS words per ring row, 21 per group): every ring column x-3..x+3 of the four pixels
+    //      lies inside the window, so each ring position is two v_perm_b32 with constant selectors, and the
+    //      test runs on raw ring values (with d = v - r: min_k max(d_k, d_k+8) = v - max_k min(r_k, r_k+8)). ----
+    int n2 = 0;
+    {
+        const int ng = (iw + ox + 3) >> 2;       // groups per interior row; group j covers c = 4j - ox .. 4j - ox + 3
+        const int G = ng * ih;
+        const float rcp_ng = 1.0f / (float)ng;
+        int rg = (int)(((float)lane + 0.5f) * rcp_ng), jg = lane - rg * ng;
+        const int dr = 64 / ng, dj = 64 - dr * ng;
+        const int pw = tile_pitch >> 2;
+        for (int g0 = 0; g0 < G; g0 += 64) {
+            const bool vg = g0 + lane < G;
+            const uint32_t *tw4 = (const uint32_t *)s_tile + (vg ? __mul24(rg, pw) + jg : 0);
+            unsigned w[7][3];
+#pragma unroll
+            for (int y = 0; y < 7; y++) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) w[y][i] = tw4[y * pw + i];
+            }
+            pk16 A01, A23, B01, B23;
+#define FAST_PAIR(first, ya, sa, yb, sb)                                                                          \
+    {                                                                                                             \
+        const pk16 a01 = row_pair<sa>(w[ya]), a23 = row_pair<sa + 2>(w[ya]);                                     \
+        const pk16 b01 = row_pair<sb>(w[yb]), b23 = row_pair<sb + 2>(w[yb]);                                     \
+        const pk16 n01 = __builtin_elementwise_min(a01, b01), x01 = __builtin_elementwise_max(a01, b01);          \
+        const pk16 n23 = __builtin_elementwise_min(a23, b23), x23 = __builtin_elementwise_max(a23, b23);          \
+        if (first) { A01 = n01; B01 = x01; A23 = n23; B23 = x23; }                                                \
+        else {                                                                                                    \
+            A01 = __builtin_elementwise_max(A01, n01); B01 = __builtin_elementwise_min(B01, x01);                 \
+            A23 = __builtin_elementwise_max(A23, n23); B23 = __builtin_elementwise_min(B23, x23);                 \
+        }                                                                                                         \
+    }
+            // ring pairs (k, k+8): (dx, dy) -> window start byte 3 + dx, tile row 3 + dy
+            FAST_PAIR(true, 6, 3, 0, 3)   // ( 0, 3) / ( 0,-3)
+            FAST_PAIR(false, 6, 4, 0, 2)  // ( 1, 3) / (-1,-3)
+            FAST_PAIR(false, 5, 5, 1, 1)  // ( 2, 2) / (-2,-2)
+            FAST_PAIR(false, 4, 6, 2, 0)  // ( 3, 1) / (-3,-1)
+            FAST_PAIR(false, 3, 6, 3, 0)  // ( 3, 0) / (-3, 0)
+            FAST_PAIR(false, 2, 6, 4, 0)  // ( 3,-1) / (-3, 1)
+            FAST_PAIR(false, 1, 5, 5, 1)  // ( 2,-2) / (-2, 2)
+            FAST_PAIR(false, 0, 4, 6, 2)  // ( 1,-3) / (-1, 3)
+#undef FAST_PAIR
+            const pk16 v01 = row_pair<3>(w[3]), v23 = row_pair<5>(w[3]);
+            const pk16 lo01 = v01 - A01, hi01 = v01 - B01, lo23 = v23 - A23, hi23 = v23 - B23;
+            const int c0 = 4 * jg - ox;
+            const bool d0 = lo01.x > t, b0 = hi01.x < -t, d1 = lo01.y > t, b1 = hi01.y < -t;
+            const bool d2 = lo23.x > t, b2 = hi23.x < -t, d3 = lo23.y > t, b3 = hi23.y < -t;
+            const bool p0 = vg & (c0 >= 0) & (d0 != b0);
+            const bool p1 = vg & (c0 + 1 >= 0) & (c0 + 1 < iw) & (d1 != b1);
+            const bool p2 = vg & (c0 + 2 >= 0) & (c0 + 2 < iw) & (d2 != b2);
+            const bool p3 = vg & (c0 + 3 < iw) & (d3 != b3);
+            const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1), m2 = __ballot(p2), m3 = __ballot(p3);
+            int pos = n2 + (int)mbcnt64(m3, mbcnt64(m2, mbcnt64(m1, mbcnt64(m0, 0u))));
+            const int e = (rg << 8) + c0; // c0 < 0 only for pixels that are never stored
+            if (p0) s_q2[pos] = (uint16_t)(e | (b0 ? 0x8000 : 0));
+            pos += p0;
+            if (p1) s_q2[pos] = (uint16_t)((e + 1) | (b1 ? 0x8000 : 0));
+            pos += p1;
+            if (p2) s_q2[pos] = (uint16_t)((e + 2) | (b2 ? 0x8000 : 0));
+            pos += p2;
+            if (p3) s_q2[pos] = (uint16_t)((e + 3) | (b3 ? 0x8000 : 0));
+            n2 += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+            jg += dj; rg += dr;
+            if (jg >= ng) { jg -= ng; rg++; }
+        }
+    }
+    FAST_WAVE_SYNC();
+    if (dbg == 3) { if (lane == 0) *cnt_out = 0; return; }
+    // ---- C: exact score for the entry's polarity: max over the 16 arcs of the min of 9 (sign-normalised)
+    //      differences; windows of 2, 4, 8 (+1) by doubling. ----
+    for (int q0 = 0; q0 < n2; q0 += 128) {
+        const int qa = q0 + lane, qb = q0 + 64 + lane;
+        const bool va = qa < n2, vb = qb < n2;
+        const unsigned ea = s_q2[va ? qa : 0], eb = s_q2[vb ? qb : 0];
+        const int ra = (ea >> 8) & 127, ca = ea & 255, rb = (eb >> 8) & 127, cb = eb & 255;
+        const uint8_t *pa = &s_tile[(ra + 3) * tile_pitch + ca + 3 + ox];
+        const uint8_t *pb = &s_tile[(rb + 3) * tile_pitch + cb + 3 + ox];
+        // sign-normalise by complementing bright entries (x -> -x-1 in both centre and ring keeps differences):
+        // score = max_arcs min_arc (v' - r'_k) = v' - min_arcs max_arc r'_k, so the arcs run on raw ring values
+        const pk16 sg = {(short)((ea & 0x8000u) ? -1 : 0), (short)((eb & 0x8000u) ? -1 : 0)};
+        const pk16 vv = (pk16){(short)pa[0], (short)pb[0]} ^ sg;
+        pk16 e[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) e[k] = (pk16){(short)pa[roff[k]], (short)pb[roff[k]]} ^ sg;
+        pk16 m2[16], m4[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_max(e[k], e[(k + 1) & 15]);
+#pragma unroll
+        for (int k = 0; k < 16; k++) m4[k] = __builtin_elementwise_max(m2[k], m2[(k + 2) & 15]);
+        pk16 worst = {512, 512};
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            worst = __builtin_elementwise_min(worst, __builtin_elementwise_max(__builtin_elementwise_max(m4[k], m4[(k + 4) & 15]), e[(k + 8) & 15]));
+        pk16 best = vv - worst;
+        best = __builtin_elementwise_max(best, tt);
+        const int sa = (int)best.x - 1, sb = (int)best.y - 1;
+        if (va && sa >= t) s_sc[(ra + 1) * scp + ca + 1] = (uint8_t)sa;
+        if (vb && sb >= t) s_sc[(rb + 1) * scp + cb + 1] = (uint8_t)sb;
+    }
+    FAST_WAVE_SYNC();
+    if (dbg == 4) { if (lane == 0) *cnt_out = 0; return; }
+    // ---- D: NMS + threshold choice.  The first 256 queue entries (all of them for ordinary cells) keep their flag and
+    //      coordinates in registers for the compaction of phase E; later ones go through the LDS flag array. ----
+    bool any = false;
+    auto nms_flag = [&](unsigned rc) {
+        const uint8_t *p = &s_sc[((rc >> 8) + 1) * scp + (rc & 255) + 1];
+        const int s = p[0];
+        // all nine reads issued together (a short-circuit chain would be nine dependent LDS round trips)
+        const int n0 = p[-scp - 1], n1 = p[-scp], n2_ = p[-scp + 1], n3 = p[-1], n4 = p[1], n5 = p[scp - 1], n6 = p[scp], n7 = p[scp + 1];
+        const int mx = max(max(max(n0, n1), max(n2_, n3)), max(max(n4, n5), max(n6, n7)));
+        return ((s > 0) & (s > mx)) ? ((s >= cfg.ini_th) ? 2 : 1) : 0;
+    };
+    unsigned rcq[4];
+    int fq[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int q = lane + 64 * k;
+        rcq[k] = 0u; fq[k] = 0;
+        if (q < n2) {
+            rcq[k] = s_q2[q] & 0x7fffu;
+            fq[k] = nms_flag(rcq[k]);
+            any |= (fq[k] == 2);
+        }
+    }
+    for (int q = lane + 256; q < n2; q += 64) {
+        const int f = nms_flag(s_q2[q] & 0x7fffu);
+        any |= (f == 2);
+        s_qf[q] = (uint8_t)f;
+    }
+    const int need = __ballot(any) != 0ull ? 2 : 1;
+    FAST_WAVE_SYNC();
+    (void)q_bytes;
+    // ---- E: ordered emission ----
+    uint32_t *oxy = buf.cell_xy + ((size_t)img * cfg.cells_total + cell) * cfg.cell_cap;
+    uint8_t *osc = buf.cell_sc + ((size_t)img * cfg.cells_total + cell) * cfg.cell_cap;
+    // BK: the cell's survivors fall into the bucket columns gx0..gx1 and rows by0..by1 (tables are monotone); when
+    // that rectangle has at most 64 buckets they are accumulated in LDS first
+    unsigned *s_ac = (unsigned *)(s_mem + tile_bytes + sc_bytes + q_bytes), *s_ab = s_ac + 64;
+    int gx0 = 0, by0 = 0, ncols = 1, nb = 0;
+    uint32_t *g_cnt = nullptr, *g_best = nullptr;
+    if (BK) {
+        gx0 = (int)(__builtin_amdgcn_readfirstlane(tabx) >> 16);
+        by0 = (int)(__builtin_amdgcn_readfirstlane(taby) >> 16);
+        ncols = (int)(__builtin_amdgcn_readlane(tabx, 63) >> 16) - gx0 + 1; // lanes >= iw hold the last column / row
+        nb = ncols * ((int)(__builtin_amdgcn_readlane(taby, 63) >> 16) - by0 + 1);
+        if (nb <= 64) { s_ac[lane] = 0u; s_ab[lane] = 0u; }
+        g_cnt = buf.bk_cnt + ((size_t)img * cfg.nlevels + level) * ORBFE_BK_BUCKETS;
+        g_best = buf.bk_best + ((size_t)img * cfg.nlevels + level) * ORBFE_BK_BUCKETS;
+        FAST_WAVE_SYNC();
+    }
+    // survivors are first compacted in place over the queue (a write never passes this iteration's reads), then
+    // emitted densely: one pass of 64 lanes per 64 survivors instead of one per 64 queue entries
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (64 * k < n2) {
+            const bool pred = fq[k] >= need; // fq = 0 beyond the queue
+            const unsigned long long m = __ballot(pred);
+            if (pred) s_q2[run + (int)mbcnt64(m, 0u)] = (uint16_t)rcq[k];
+            run += __popcll(m);
+        }
+    }
+    for (int q0 = 256; q0 < n2; q0 += 64) {
+        const int q = q0 + lane;
+        const bool pred = q < n2 && s_qf[q] >= need;
+        const unsigned long long m = __ballot(pred);
+        const uint16_t rc = q < n2 ? s_q2[q] : (uint16_t)0;
+        if (pred) s_q2[run + (int)mbcnt64(m, 0u)] = rc;
+        run += __popcll(m);
+    }
+    FAST_WAVE_SYNC();
+    const int n_out = run < cfg.cell_cap ? run : cfg.cell_cap;
+    for (int p0 = 0; p0 < n_out; p0 += 64) {
+        const int pos = p0 + lane;
+        const bool v = pos < n_out;
+        const unsigned rc = v ? (s_q2[pos] & 0x7fffu) : 0u;
+        const int r = rc >> 8, c = rc & 255;
+        unsigned tx = 0u, ty = 0u;
+        if (BK) { tx = (unsigned)__shfl((int)tabx, c, 64); ty = (unsigned)__shfl((int)taby, r, 64); }
+        if (v) {
+            // cell-local FAST coords (c+3, r+3) + (j*wCell, i*hCell): src/ORBextractor.cc:816-817
+            const unsigned x = (unsigned)(c + 3 + ci_j * L.w_cell);
+            const unsigned y = (unsigned)(r + 3 + ci_i * L.h_cell);
+            const unsigned sc = s_sc[(r + 1) * scp + c + 1];
+            oxy[pos] = x | (y << 16);
+            osc[pos] = (uint8_t)sc;
+            if (BK) {
+                const unsigned key = ORBFE_BK_KEY(sc, (unsigned)ci, (unsigned)pos);
+                if (nb <= 64) {
+                    const int li = ((int)(ty >> 16) - by0) * ncols + ((int)(tx >> 16) - gx0);
+                    atomicAdd(&s_ac[li], 1u);
+                    atomicMax(&s_ab[li], key);
+                } else {
+                    const unsigned b = (tx | ty) & 0xfffu;
+                    atomicAdd(&g_cnt[b], 1u);
+                    atomicMax(&g_best[b], key);
+                }
+            }
+        }
+    }
+    if (lane == 0) *cnt_out = run < cfg.cell_cap ? run : cfg.cell_cap;
+    if (BK && nb <= 64 && dbg != 5) {
+        FAST_WAVE_SYNC();
+        const unsigned cnt = lane < nb ? s_ac[lane] : 0u;
+        if (cnt) {
+            const int ly = (int)(((float)lane + 0.5f) / (float)ncols), lx = lane - ly * ncols;
+            const unsigned gx = (unsigned)(gx0 + lx), by = (unsigned)(by0 + ly);
+            auto spread5 = [](unsigned v) { return (v & 1u) | ((v & 2u) << 1) | ((v & 4u) << 2) | ((v & 8u) << 3) | ((v & 16u) << 4); };
+            const unsigned b = ((gx >> 5) << 10) | spread5(gx & 31u) | (spread5(by) << 1);
+            atomicAdd(&g_cnt[b], cnt);
+            atomicMax(&g_best[b], s_ab[lane]);
+        }
+    }
+}
+
+
+static inline int max_cell_w(const DeviceConfig &cfg) { int m = 0; for (int l = 0; l < cfg.nlevels; l++) m = cfg.lv[l].w_cell > m ? cfg.lv[l].w_cell : m; return m; }
+static inline int max_cell_h(const DeviceConfig &cfg) { int m = 0; for (int l = 0; l < cfg.nlevels; l++) m = cfg.lv[l].h_cell > m ? cfg.lv[l].h_cell : m; return m; }
+
+void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool buckets, hipStream_t s)
+{
+    const int mw = max_cell_w(cfg), mh = max_cell_h(cfg);
+    const int tile_pitch = (mw + 6 + 3 + 3 + 3) & ~3; // + alignment slack on both sides
+    const int tile_rows = mh + 6;
+    const int tile_bytes = (tile_pitch * tile_rows + 15) & ~15;
+    const int sc_bytes = ((mw + 2) * (mh + 2) + 15) & ~15;
+    const int q_bytes = (2 * mw * mh + 15) & ~15;
+    // flags alias the tile: it must hold one byte per interior pixel
+    // flags alias the tile region: tile_bytes passed to the kernel covers both; + 2 x 64 words of bucket accumulators
+    const int tile_region = tile_bytes > mw * mh ? tile_bytes : ((mw * mh + 15) & ~15);
+    const int lds_per_wave = tile_region + sc_bytes + q_bytes + 512;
+    const size_t lds = (size_t)4 * lds_per_wave;
+    dim3 grid(((cfg.cells_total + 3) / 4) * ((n_images + 7) / 8) * 8);
+    static const int dbg = getenv("ORBFE_FAST_DBG") ? atoi(getenv("ORBFE_FAST_DBG")) : 0; // profiling aid only
+#define FAST_LAUNCH(TP)                                                                                                                   \
+    do {                                                                                                                              \
+        if (buckets) hipLaunchKernelGGL((fast_cell_kernel<TP, true>), grid, dim3(256), lds, s, cfg, buf, n_images, tile_pitch, tile_region, sc_bytes, q_bytes, lds_per_wave, dbg); \
+        else hipLaunchKernelGGL((fast_cell_kernel<TP, false>), grid, dim3(256), lds, s, cfg, buf, n_images, tile_pitch, tile_region, sc_bytes, q_bytes, lds_per_wave, dbg); \
+    } while (0)
+    switch (tile_pitch) {
+    case 44: FAST_LAUNCH(44); break;
+    case 48: FAST_LAUNCH(48); break;
+    case 52: FAST_LAUNCH(52); break;
+    case 56: FAST_LAUNCH(56); break;
+    case 60: FAST_LAUNCH(60); break;
+    case 64: FAST_LAUNCH(64); break;
+    default: FAST_LAUNCH(0); break;
+    }
+#undef FAST_LAUNCH
+}

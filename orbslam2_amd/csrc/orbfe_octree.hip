@@ -1,7 +1,7 @@
 // orbfe_octree.hip -- point-parallel DistributeOctTree (reference src/ORBextractor.cc:533-757).
 //
 // One 512-thread workgroup per (image, level).  Same array formulation as the generic kernel in
-// orbfe_kernels.hip (validated on the CPU by tests/octree_model.py), but the per-pass work is
+// orbfe_octree_generic.hip (validated on the CPU by tests/octree_model.py), but the per-pass work is
 // parallel over POINTS instead of over nodes:
 //   * the candidates of the level live in one position-ordered array of (candidate id | owning node
 //     << 16) words; a node owns a contiguous range of positions.  When the level has at most

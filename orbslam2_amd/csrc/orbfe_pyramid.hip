@@ -1,0 +1,264 @@
+// orbfe_pyramid.hip -- ingest, cv::resize pyramid (src/ORBextractor.cc:921-946) and the 7x7 Gaussian (:899-900).
+#include "orbfe_common.cuh"
+
+// ---------------------------------------------------------------------------
+// Pyramid storage.  Every level is stored with a reflect-101 margin (PYR_MX px on the left, at
+// least 8 px on the right, PYR_MY rows above and below) written by its producer (ingest / resize),
+// and pixel (0,0) sits on a 4-byte boundary.  Consumers can therefore use aligned 32-bit loads and
+// need no border logic: the margin IS cv::GaussianBlur's BORDER_REFLECT_101 (src/ORBextractor.cc:900).
+// ---------------------------------------------------------------------------
+
+// ingest: packed images -> level 0 (+ margin); one thread = 4 px of the extended domain, block = 64 words x 4 rows.
+// Interior words are one (unaligned) 32-bit load of the packed source; only the margin words gather reflected bytes.
+// Also clears the image's status word (first kernel of every chain).
+__global__ __launch_bounds__(256) void ingest_kernel(DeviceConfig cfg, DeviceBuffers buf, const uint8_t *__restrict__ src)
+{
+    const int img = blockIdx.z;
+    const LevelInfo &L = cfg.lv[0];
+    if (blockIdx.x == 0 && blockIdx.y == 0) { // first kernel of every chain: clear the image's status word and, for a right image, its pair's stereo row counters
+        if (threadIdx.x == 0) buf.status[img] = 0;
+        if (img & 1)
+            for (int i = threadIdx.x; i < cfg.height; i += 256) buf.row_cnt[(size_t)(img >> 1) * cfg.height + i] = 0;
+    }
+    const int y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6)) - PYR_MY;
+    const int x0 = (int)(blockIdx.x * 64 + (threadIdx.x & 63)) * 4 - PYR_MX;
+    if (x0 >= L.w + 8 || y >= L.h + PYR_MY) return;
+    const uint8_t *s = src + (size_t)img * L.w * L.h + (size_t)reflect101(y, L.h) * L.w;
+    uint32_t v = 0;
+    if (x0 >= 0 && x0 + 3 < L.w) {
+        __builtin_memcpy(&v, s + x0, 4);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) v |= (uint32_t)s[reflect101(x0 + j, L.w)] << (8 * j);
+    }
+    uint8_t *d = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (ptrdiff_t)y * L.pitch + x0;
+    *(uint32_t *)d = v;
+}
+
+// pyramid: level l from level l-1 (cv::resize INTER_LINEAR, 8UC1 fixed point) over the extended (margin-
+// included) domain of level l.  The per-column / per-row source offsets and 11-bit weights (cv::resize's
+// xofs/ialpha, yofs/ibeta tables) are built once per context on the host with exactly the arithmetic of
+// resize.cpp and read here as packed words:
+//   X0 = sx | sx1 << 16, X1 = a0 | a1 << 16 (per extended column), Y0 = sy0 | sy1 << 16, Y1 = b0 | b1 << 16.
+// A 256-thread workgroup produces 4 * RW extended rows: the source rows they touch (a contiguous range,
+// margins index reflected rows) are staged in LDS with coalesced 32-bit loads; wave w then owns RW
+// consecutive output rows and a lane owns 4 output columns, whose column table entries stay in registers.
+// resize.cpp's horizontal pass of a source row, h = S[sx] * a0 + S[sx1] * a1, is kept in registers for the
+// two most recent source rows, so a source row shared by consecutive output rows is filtered once (the
+// 1.2 : 1 row ratio makes that 0.83 instead of 2 horizontal passes per output row).  The vertical pass
+// ((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) is two 24-bit high multiplies: (b << 12) * (h & ~15)
+// = b * (h >> 4) * 2^16, and the sum is <= 1020 so resize.cpp's saturating cast never clips.
+template <int RW>
+__global__ __launch_bounds__(256) void pyr_resize_kernel(DeviceConfig cfg, DeviceBuffers buf, int level, int src_words, int max_src_rows)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_src[]; // [max_src_rows][src_words * 4]
+    const int img = blockIdx.y;
+    const LevelInfo &D = cfg.lv[level];
+    const LevelInfo &S = cfg.lv[level - 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int y0 = blockIdx.x * (4 * RW); // first extended row of this block
+    const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + S.pyr_off;
+    uint8_t *dst = buf.pyr + (size_t)img * cfg.pyr_bytes + D.pyr_off;
+    const uint32_t *xt = buf.rs_tab + D.rs_xtab_off;
+    const uint32_t *yt = buf.rs_tab + D.rs_ytab_off;
+    const int total_rows = D.h + 2 * PYR_MY;
+    const int nrows = (total_rows - y0) < 4 * RW ? (total_rows - y0) : 4 * RW;
+    const int row_bytes = src_words * 4;
+    // table entries this wave needs after the barrier, requested now so that their latency overlaps the staging:
+    // the vertical entries of its rows (uniform) and the column entries of its first pass
+    const int nwords = (D.w + 12 + 3) >> 2; // extended row in 4-px words
+    const int k0 = wave * RW;
+    uint32_t Y0r[RW], Y1r[RW];
+#pragma unroll
+    for (int k = 0; k < RW; k++) {
+        const int yy = y0 + (k0 + k < nrows ? k0 + k : nrows - 1);
+        Y0r[k] = yt[yy]; Y1r[k] = yt[D.rs_ytab_n + yy];
+    }
+    const int xi_first = (lane < nwords ? lane : 0) * 4;
+    uint4 X0 = *(const uint4 *)(xt + xi_first);
+    uint4 X1 = *(const uint4 *)(xt + D.rs_xtab_n + xi_first);
+    // source row range of the block (every wave computes it: lanes < nrows hold one output row each)
+    const uint32_t Yl = yt[y0 + (lane < nrows ? lane : 0)];
+    int smin = (int)(Yl & 0xffffu), smax = (int)(Yl >> 16);
+    { const int t = smin < smax ? smin : smax; smax = smin < smax ? smax : smin; smin = t; }
+#pragma unroll
+    for (int o = 1; o < 4 * RW; o <<= 1) {
+        const int a = __shfl_xor(smin, o, 64), b = __shfl_xor(smax, o, 64);
+        smin = a < smin ? a : smin; smax = b > smax ? b : smax;
+    }
+    smin = __builtin_amdgcn_readfirstlane(smin); smax = __builtin_amdgcn_readfirstlane(smax);
+    int n_src = smax - smin + 1;
+    if (n_src > max_src_rows) n_src = max_src_rows; // cannot happen: the host sized max_src_rows from the same table
+    {
+        int r = (int)(((float)tid + 0.5f) * (1.0f / (float)src_words)), c = tid - r * src_words;
+        const int dr = 256 / src_words, dc = 256 - dr * src_words;
+        const uint8_t *sp = src + (size_t)smin * S.pitch;
+        const int nw = n_src * src_words;
+        for (int i0 = tid; i0 < nw; i0 += 1024) { // 4 loads in flight per thread
+            uint32_t v[4];
+            int di[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                di[u] = __mul24(r, src_words) + c;
+                if (i0 + 256 * u < nw) v[u] = *(const uint32_t *)(sp + (unsigned)(__mul24(r, S.pitch) + 4 * c));
+                c += dc; r += dr;
+                if (c >= src_words) { c -= src_words; r++; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (i0 + 256 * u < nw) ((uint32_t *)s_src)[di[u]] = v[u];
+        }
+    }
+    __syncthreads();
+    if (k0 >= nrows) return;
+    for (int xw = lane; xw < nwords; xw += 64) {
+        const int xi = xw * 4;
+        if (xw != lane) {
+            X0 = *(const uint4 *)(xt + xi);
+            X1 = *(const uint4 *)(xt + D.rs_xtab_n + xi);
+        }
+        const uint32_t x0v[4] = {X0.x, X0.y, X0.z, X0.w}, x1v[4] = {X1.x, X1.y, X1.z, X1.w};
+        int tagA = -1, tagB = -1;          // source rows held in hA / hB
+        unsigned hA[4], hB[4];             // (S[sx] * a0 + S[sx1] * a1) & ~15
+        auto hpass = [&](int sy, unsigned h[4]) {
+            const uint8_t *r = s_src + __mul24(sy - smin, row_bytes);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned p0 = r[x0v[j] & 0xffffu], p1 = r[x0v[j] >> 16];
+                h[j] = (__umul24(p0, x1v[j] & 0xffffu) + __umul24(p1, x1v[j] >> 16)) & ~15u;
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < RW; k++) {
+            if (k0 + k < nrows) {
+                const int sy0 = (int)(Y0r[k] & 0xffffu), sy1 = (int)(Y0r[k] >> 16);
+                // make hA = row sy0, hB = row sy1 (uniform branches: all lanes walk the same rows)
+                if (tagA != sy0) {
+                    if (tagB == sy0) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) { const unsigned t = hA[j]; hA[j] = hB[j]; hB[j] = t; }
+                        tagB = tagA; tagA = sy0;
+                    } else {
+                        hpass(sy0, hA); tagA = sy0;
+                    }
+                }
+                if (tagB != sy1) {
+                    if (sy1 == sy0) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) hB[j] = hA[j];
+                    } else {
+                        hpass(sy1, hB);
+                    }
+                    tagB = sy1;
+                }
+                const unsigned b0 = (Y1r[k] & 0xffffu) << 12, b1 = (Y1r[k] >> 16) << 12; // <= 2^23
+                uint32_t out = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const unsigned v0 = (unsigned)(((unsigned long long)(b0 & 0xffffffu) * (unsigned long long)(hA[j] & 0xffffffu)) >> 32);
+                    const unsigned v1 = (unsigned)(((unsigned long long)(b1 & 0xffffffu) * (unsigned long long)(hB[j] & 0xffffffu)) >> 32);
+                    out |= ((v0 + v1 + 2u) >> 2) << (8 * j);
+                }
+                *(uint32_t *)(dst + (ptrdiff_t)(y0 + k0 + k - PYR_MY) * D.pitch + (xi - PYR_MX)) = out;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Gaussian 7x7 (8.8 fixed point, separable), all levels in one launch.
+// Register sliding window: a lane owns 4 adjacent columns and walks down BL_ROWS rows; per input
+// row it loads three aligned words (12 px), forms the four 7-tap row sums with v_dot4_u32_u8, keeps
+// the last seven row-sum vectors in registers and emits one 4-px output word.  No LDS, no barriers;
+// HBM traffic = one read of the level (+6/BL_ROWS row halo, L2-served) and one write.
+// ---------------------------------------------------------------------------
+#define BL_ROWS 32  // rows per wave: 6 / BL_ROWS of the rows are loaded (and row-filtered) twice
+#define BL_COLS 256 // per wave: 64 lanes x 4 px
+__global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffers buf)
+{
+    // the waves of a workgroup are independent: wave u of the flattened (level, row band, 256-column strip) list
+    const int img = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int u = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (u >= cfg.blur_tiles_total) return;
+    int level = 0;
+    for (int l = 1; l < cfg.nlevels; l++)
+        if (u >= cfg.lv[l].blur_tile_off) level = l;
+    const LevelInfo &L = cfg.lv[level];
+    const int t = u - L.blur_tile_off;
+    const int x0 = (t % L.blur_tiles_x) * BL_COLS + lane * 4;
+    const int r0 = (t / L.blur_tiles_x) * BL_ROWS;
+    if (x0 >= L.w || r0 >= L.h) return;
+    const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + x0;
+    uint8_t *dst = buf.blur + (size_t)img * cfg.pyr_bytes + L.pyr_off + x0;
+    const unsigned k_lo = (unsigned)cfg.taps[0] | ((unsigned)cfg.taps[1] << 8) | ((unsigned)cfg.taps[2] << 16) | ((unsigned)cfg.taps[3] << 24);
+    const unsigned k_hi = (unsigned)cfg.taps[4] | ((unsigned)cfg.taps[5] << 8) | ((unsigned)cfg.taps[6] << 16);
+    const unsigned k0 = cfg.taps[0], k1 = cfg.taps[1], k2 = cfg.taps[2], k3 = cfg.taps[3];
+    const int y_max = L.h + PYR_MY - 1; // last materialised row
+    unsigned H[7][4];
+#pragma unroll
+    for (int i = 0; i < BL_ROWS + 6; i++) {
+        int y = r0 - 3 + i;
+        y = y > y_max ? y_max : y; // rows past the margin only feed outputs that are never stored
+        const uint32_t *row = (const uint32_t *)(src + (ptrdiff_t)y * L.pitch);
+        const unsigned w0 = row[-1], w1 = row[0], w2 = row[1];
+        unsigned hn[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned lo = j == 3 ? w1 : __builtin_amdgcn_alignbyte(w1, w0, j + 1);
+            const unsigned hi = j == 3 ? w2 : __builtin_amdgcn_alignbyte(w2, w1, j + 1);
+            hn[j] = __builtin_amdgcn_udot4(lo, k_lo, __builtin_amdgcn_udot4(hi, k_hi, 0u, false), false);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) H[i % 7][j] = hn[j];
+        if (i >= 6) {
+            const int yo = r0 + i - 6;
+            if (yo < L.h) {
+                // rows of the window in age order: oldest is slot (i+1)%7
+                unsigned o = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const unsigned acc = k0 * (H[(i + 1) % 7][j] + H[i % 7][j]) + k1 * (H[(i + 2) % 7][j] + H[(i + 6) % 7][j]) +
+                                         k2 * (H[(i + 3) % 7][j] + H[(i + 5) % 7][j]) + k3 * H[(i + 4) % 7][j];
+                    o |= ((acc + 32768u) >> 16) << (8 * j);
+                }
+                *(uint32_t *)(dst + (ptrdiff_t)yo * L.pitch) = o;
+            }
+        }
+    }
+}
+
+
+void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, const uint8_t *d_images, int n_images, hipStream_t s)
+{
+    const int words = (cfg.lv[0].w + 12 + 3) / 4;
+    dim3 grid((words + 63) / 64, (cfg.lv[0].h + 2 * PYR_MY + 3) / 4, n_images);
+    hipLaunchKernelGGL(ingest_kernel, grid, dim3(256), 0, s, cfg, buf, d_images);
+}
+
+void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
+{
+    for (int l = 1; l < cfg.nlevels; l++) {
+        const int src_words = (cfg.lv[l - 1].w + 3) / 4; // interior pixels of the source row (4-aligned start)
+        const int total_rows = cfg.lv[l].h + 2 * PYR_MY;
+        // rows per wave: the largest of 4, 2, 1 whose staged source rows fit 60 KB of LDS (rs_src_rows[i] = source
+        // row span of the worst block of 16 / 8 / 4 output rows, from the host's row table)
+        const int *span = cfg.lv[l].rs_src_rows;
+        if ((size_t)span[0] * src_words * 4 <= 60 * 1024) {
+            dim3 grid((total_rows + 15) / 16, n_images);
+            hipLaunchKernelGGL(pyr_resize_kernel<4>, grid, dim3(256), (size_t)span[0] * src_words * 4, s, cfg, buf, l, src_words, span[0]);
+        } else if ((size_t)span[1] * src_words * 4 <= 60 * 1024) {
+            dim3 grid((total_rows + 7) / 8, n_images);
+            hipLaunchKernelGGL(pyr_resize_kernel<2>, grid, dim3(256), (size_t)span[1] * src_words * 4, s, cfg, buf, l, src_words, span[1]);
+        } else {
+            dim3 grid((total_rows + 3) / 4, n_images);
+            hipLaunchKernelGGL(pyr_resize_kernel<1>, grid, dim3(256), (size_t)span[2] * src_words * 4, s, cfg, buf, l, src_words, span[2]);
+        }
+    }
+}
+
+void orbfe_launch_blur(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
+{
+    dim3 grid((cfg.blur_tiles_total + 3) / 4, n_images);
+    hipLaunchKernelGGL(blur_kernel, grid, dim3(256), 0, s, cfg, buf);
+}

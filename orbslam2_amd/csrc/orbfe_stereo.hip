@@ -1,0 +1,300 @@
+// orbfe_stereo.hip -- Frame::ComputeStereoMatches (src/Frame.cc:464-642), ComputeStereoFromRGBD (:645-666), batched DescriptorDistance.
+#include "orbfe_common.cuh"
+
+// ---------------------------------------------------------------------------
+// stereo: one wave per left keypoint (coarse Hamming band search + SAD + parabola)
+// ---------------------------------------------------------------------------
+// One 16-lane group per left keypoint (four keypoints per wave, sixteen per workgroup): a row list holds a few
+// dozen candidates of which ~10 pass the octave / disparity filter, so a whole wave per keypoint idles most lanes
+// and, with ~7 dependent global round trips per keypoint, needs 4x the waves to hide the same latency.
+//   coarse search: lanes stride the row list; arg-min key dist << 16 | iR (= the reference's first minimum);
+//   SAD: lane handles window pixels p = gl, gl + 16, .. < 121; the 11 shifted right-image bytes of a pixel are
+//        12 contiguous bytes = three unaligned dword loads; sums reduced over the group by xor shuffles.
+#define SM_G 16
+__device__ __forceinline__ unsigned group_min_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = SM_G / 2; o > 0; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)v, o, 64);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int group_sum_i32(int v) { return row_sum_i32(v); } // SM_G == 16 == one DPP row
+
+__global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_pairs)
+{
+    // XCD-aware block -> (pair, block) map: all blocks of a pair on one XCD (its L2 then holds the pair's
+    // descriptors, keypoints and the pyramid rows the SAD windows touch)
+    const int kpb = 256 / SM_G;
+    const int bpp = (cfg.sel_total + kpb - 1) / kpb;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int pair = (jb / bpp) * 8 + xcd;
+    if (pair >= n_pairs) return;
+    const int imgL = 2 * pair, imgR = 2 * pair + 1;
+    const int gl = threadIdx.x & (SM_G - 1);
+    const int iL = (jb % bpp) * kpb + (threadIdx.x / SM_G);
+    const int nL = buf.kp_cnt[imgL], nR = buf.kp_cnt[imgR];
+    if (iL >= nL) return; // whole group; the groups of a wave only meet in xor shuffles below the group size
+    const KeyPointPOD *kL = (const KeyPointPOD *)buf.kps + (size_t)imgL * cfg.sel_total;
+    const KeyPointPOD *kR = (const KeyPointPOD *)buf.kps + (size_t)imgR * cfg.sel_total;
+    const uint8_t *dL = buf.desc + (size_t)imgL * cfg.sel_total * 32;
+    const uint8_t *dR = buf.desc + (size_t)imgR * cfg.sel_total * 32;
+    float *u_right = buf.u_right + (size_t)imgL * cfg.sel_total;
+    float *depth = buf.depth + (size_t)imgL * cfg.sel_total;
+    int *sad_out = buf.sad + (size_t)imgL * cfg.sel_total;
+
+    const KeyPointPOD kp = kL[iL];
+    const int level_l = kp.octave;
+    const float uL = kp.x, vL = kp.y;
+    const int row = (int)vL;
+    const float min_z = cfg.mb;
+    const float max_d = __fdiv_rn(cfg.bf, min_z);
+    const float min_u = __fsub_rn(uL, max_d);
+    const float max_u = uL; // uL - minD, minD = 0
+
+    uint32_t dl[8];
+    {
+        const uint4 *p = (const uint4 *)(dL + (size_t)iL * 32);
+        const uint4 lo = p[0], hi = p[1];
+        dl[0] = lo.x; dl[1] = lo.y; dl[2] = lo.z; dl[3] = lo.w; dl[4] = hi.x; dl[5] = hi.y; dl[6] = hi.z; dl[7] = hi.w;
+    }
+    unsigned best = (100u << 16) | 0xffffu; // TH_HIGH; the index field only matters below it
+    float best_x = 0.f;
+    auto consider = [&](int iR, int oct, float xr) {
+        if (oct >= level_l - 1 && oct <= level_l + 1 && xr >= min_u && xr <= max_u) {
+            const uint4 *p = (const uint4 *)(dR + (size_t)iR * 32);
+            const uint4 lo = p[0], hi = p[1];
+            const uint32_t dr[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const unsigned key = ((unsigned)hamming256(dl, dr) << 16) | (unsigned)iR;
+            if (key < best) { best = key; best_x = xr; }
+        }
+    };
+    // candidates = right keypoints whose row band covers int(vL) (vRowIndices[vL], src/Frame.cc:513), listed per row by
+    // describe_kernel; the arg-min key (dist << 16 | iR) makes the result independent of the order inside a row list
+    int cnt = 0;
+    if (row >= 0 && row < cfg.height) cnt = buf.row_cnt[(size_t)pair * cfg.height + row];
+    if (cnt <= cfg.row_cap) {
+        const uint2 *rent = buf.row_ent + ((size_t)pair * cfg.height + row) * cfg.row_cap;
+        for (int j = gl; j < cnt; j += SM_G) {
+            const uint2 e = rent[j];
+            consider((int)(e.x & 0xffffu), (int)(e.x >> 16), __uint_as_float(e.y));
+        }
+    } else { // the row's list overflowed its capacity: test every right keypoint's band
+        for (int iR = gl; iR < nR; iR += SM_G) {
+            const KeyPointPOD kr = kR[iR];
+            const float r = __fmul_rn(2.0f, cfg.lv[kr.octave].scale);
+            const int maxr = (int)ceilf(__fadd_rn(kr.y, r));
+            const int minr = (int)floorf(__fsub_rn(kr.y, r));
+            if (row >= minr && row <= maxr) consider(iR, kr.octave, kr.x);
+        }
+    }
+    const unsigned gbest = group_min_u32(best);
+    const int best_dist = (int)(gbest >> 16);
+    // x of the winning candidate: held by the lane whose key won (keys are unique per iR)
+    float uR0 = best == gbest ? best_x : 0.f;
+    {
+        int bits = __float_as_int(uR0);
+#pragma unroll
+        for (int o = SM_G / 2; o > 0; o >>= 1) bits |= __shfl_xor(bits, o, 64); // one lane holds it, the others 0
+        uR0 = __int_as_float(bits);
+    }
+    float out_u = -1.0f, out_d = -1.0f;
+    int out_sad = -1;
+    if (best_dist < 75) { // (TH_HIGH + TH_LOW) / 2
+        const float sf = cfg.lv[level_l].inv_scale;
+        const float s_uL = roundf(__fmul_rn(kp.x, sf));
+        const float s_vL = roundf(__fmul_rn(kp.y, sf));
+        const float s_uR0 = roundf(__fmul_rn(uR0, sf));
+        const LevelInfo &L = cfg.lv[level_l];
+        const int cu = (int)s_uL, cv = (int)s_vL, cr = (int)s_uR0;
+        const float iniu = s_uR0;                        // scaleduR0 + L - w
+        const float endu = __fadd_rn(s_uR0, 11.0f);      // scaleduR0 + L + w + 1
+        const bool in_ref = !(iniu < 0 || endu >= (float)L.w);
+        // the reference would throw on a window outside the level image; unreachable for
+        // keypoints >= 19 px from the border, kept as a memory-safety guard
+        const bool safe = cu - 5 >= 0 && cu + 5 < L.w && cv - 5 >= 0 && cv + 5 < L.h && cr - 10 >= 0 && cr + 10 < L.w;
+        if (in_ref && safe) {
+            const uint8_t *imL = buf.pyr + (size_t)imgL * cfg.pyr_bytes + L.pyr_off;
+            const uint8_t *imR = buf.pyr + (size_t)imgR * cfg.pyr_bytes + L.pyr_off;
+            const int lc = imL[__mul24(cv, L.pitch) + cu];
+            // centre row of the right image: bytes cr-5 .. cr+5 (+1 spare) = rc of the 11 shifts
+            uint32_t rcw[3];
+            __builtin_memcpy(rcw, imR + __mul24(cv, L.pitch) + cr - 5, 12);
+            int dists[11];
+#pragma unroll
+            for (int t = 0; t < 11; t++) dists[t] = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int p = gl + SM_G * t;
+                if (p < 121) {
+                    const int py = (p * 745) >> 13, dy = py - 5, dx = p - py * 11 - 5; // p / 11 for p < 128
+                    const int a = (int)imL[__mul24(cv + dy, L.pitch) + cu + dx] - lc;
+                    uint32_t w[3];
+                    __builtin_memcpy(w, imR + __mul24(cv + dy, L.pitch) + cr + dx - 5, 12);
+#pragma unroll
+                    for (int i = 0; i < 11; i++) {
+                        const int rb = (int)((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+                        const int rc = (int)((rcw[i >> 2] >> (8 * (i & 3))) & 0xffu);
+                        dists[i] += abs(a - (rb - rc));
+                    }
+                }
+            }
+            int sad_best = 0x7fffffff, best_inc = 0;
+#pragma unroll
+            for (int i = 0; i < 11; i++) {
+                dists[i] = group_sum_i32(dists[i]);
+                if (dists[i] < sad_best) { sad_best = dists[i]; best_inc = i - 5; }
+            }
+            out_sad = -2 - sad_best; // coarse match without an accepted disparity (debug tap): negative
+            if (best_inc != -5 && best_inc != 5) {
+                float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+                for (int t = 1; t < 10; t++)
+                    if (t == best_inc + 5) { d1 = (float)dists[t - 1]; d2 = (float)dists[t]; d3 = (float)dists[t + 1]; }
+                const float delta = __fdiv_rn(__fsub_rn(d1, d3), __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
+                if (!(delta < -1.0f || delta > 1.0f)) {
+                    float best_ur = __fmul_rn(L.scale, __fadd_rn(__fadd_rn(s_uR0, (float)best_inc), delta));
+                    float disparity = __fsub_rn(uL, best_ur);
+                    if (disparity >= 0.0f && disparity < max_d) {
+                        if (disparity <= 0.0f) {
+                            disparity = 0.01f;
+                            best_ur = (float)__dsub_rn((double)uL, 0.01);
+                        }
+                        out_d = __fdiv_rn(cfg.bf, disparity);
+                        out_u = best_ur;
+                        out_sad = sad_best;
+                    }
+                }
+            }
+        }
+    }
+    if (gl == 0) {
+        u_right[iL] = out_u;
+        depth[iL] = out_d;
+        sad_out[iL] = out_sad;
+    }
+}
+
+// Median of the accepted SADs, then cut at 1.5*1.4*median (src/Frame.cc:628-641; Q2: skip when empty).
+// The reference sorts (SAD, iL) pairs and reads element size/2; only its SAD matters, so the median is
+// found by a 3-level radix select (8 bits per level, LDS histograms) instead of a sort.
+__global__ __launch_bounds__(256) void stereo_median_kernel(DeviceConfig cfg, DeviceBuffers buf)
+{
+    extern __shared__ int s_vals[]; // [sel_total] the pair's SADs, read from HBM once
+    __shared__ int s_hist[256];
+    __shared__ int s_sel[3]; // selected digit, rank inside the digit's bucket, count of valid entries
+    const int pair = blockIdx.x;
+    const int imgL = 2 * pair;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nL = buf.kp_cnt[imgL];
+    float *u_right = buf.u_right + (size_t)imgL * cfg.sel_total;
+    float *depth = buf.depth + (size_t)imgL * cfg.sel_total;
+    const int *sad = buf.sad + (size_t)imgL * cfg.sel_total;
+    for (int i = tid; i < nL; i += 256) s_vals[i] = sad[i];
+    unsigned prefix = 0, mask = 0;
+    for (int shift = 16; shift >= 0; shift -= 8) { // SAD < 2^24 (121 px * 510)
+        s_hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < nL; i += 256) {
+            const int v = s_vals[i];
+            if (v >= 0 && ((unsigned)v & mask) == prefix) atomicAdd(&s_hist[((unsigned)v >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        if (tid < 64) { // digit that holds the wanted rank: lane = 4 bins, wave scan, owner lane resolves its bins
+            const int h0 = s_hist[4 * lane], h1 = s_hist[4 * lane + 1], h2 = s_hist[4 * lane + 2], h3 = s_hist[4 * lane + 3];
+            const int sum = h0 + h1 + h2 + h3;
+            int inc = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += t;
+            }
+            const int total = __shfl(inc, 63, 64);
+            if (shift == 16 && lane == 0) s_sel[2] = total;
+            // vDistIdx[size/2] in ascending order; later digits continue with the rank left inside the chosen bucket
+            const int rank = shift == 16 ? total / 2 : s_sel[1];
+            const int before = inc - sum;
+            if (total > 0 && rank >= before && rank < inc) {
+                int r = rank - before, d = 4 * lane;
+                if (r >= h0) { r -= h0; d++; if (r >= h1) { r -= h1; d++; if (r >= h2) { r -= h2; d++; } } }
+                s_sel[0] = d;
+                s_sel[1] = r;
+            }
+        }
+        __syncthreads();
+        if (s_sel[2] == 0) return;
+        prefix |= (unsigned)s_sel[0] << shift;
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    const float median = (float)(int)prefix;
+    const float th_dist = __fmul_rn(__fmul_rn(1.5f, 1.4f), median);
+    for (int i = tid; i < nL; i += 256) {
+        const int v = s_vals[i];
+        if (v >= 0 && !((float)v < th_dist)) { u_right[i] = -1.0f; depth[i] = -1.0f; }
+    }
+}
+
+// Frame::ComputeStereoFromRGBD (src/Frame.cc:645-666), undistorted camera
+__global__ __launch_bounds__(256) void rgbd_kernel(DeviceConfig cfg, DeviceBuffers buf, const float *__restrict__ depth_img,
+                                                   size_t pitch_floats, int img)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = buf.kp_cnt[img];
+    if (i >= n) return;
+    const KeyPointPOD kp = ((const KeyPointPOD *)buf.kps)[(size_t)img * cfg.sel_total + i];
+    float u = -1.0f, dp = -1.0f;
+    const int v = (int)kp.y, uu = (int)kp.x;
+    if (uu >= 0 && v >= 0 && uu < cfg.width && v < cfg.height) {
+        const float d = depth_img[(size_t)v * pitch_floats + uu];
+        if (d > 0) { dp = d; u = __fsub_rn(kp.x, __fdiv_rn(cfg.bf, d)); }
+    }
+    buf.u_right[(size_t)img * cfg.sel_total + i] = u;
+    buf.depth[(size_t)img * cfg.sel_total + i] = dp;
+}
+
+// all-pairs Hamming distance: block (64 b-columns) x (4 a-rows per block.y step)
+__global__ __launch_bounds__(256) void hamming_matrix_kernel(const uint8_t *__restrict__ da, int na,
+                                                             const uint8_t *__restrict__ db, int nb, int *__restrict__ dist)
+{
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 16;
+    if (j >= nb) return;
+    uint32_t b[8];
+    const uint32_t *pb = (const uint32_t *)(db + (size_t)j * 32);
+#pragma unroll
+    for (int k = 0; k < 8; k++) b[k] = pb[k];
+    for (int i = i0; i < i0 + 16 && i < na; i++) {
+        const uint32_t *pa = (const uint32_t *)(da + (size_t)i * 32);
+        uint32_t a[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) a[k] = pa[k];
+        dist[(size_t)i * nb + j] = hamming256(a, b);
+    }
+}
+
+
+void orbfe_launch_stereo_match(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s)
+{
+    const int kpb = 256 / SM_G;
+    dim3 grid(((cfg.sel_total + kpb - 1) / kpb) * ((n_pairs + 7) / 8) * 8);
+    hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(256), 0, s, cfg, buf, n_pairs);
+}
+
+void orbfe_launch_stereo_median(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s)
+{
+    hipLaunchKernelGGL(stereo_median_kernel, dim3(n_pairs), dim3(256), (size_t)cfg.sel_total * sizeof(int), s, cfg, buf);
+}
+
+void orbfe_launch_rgbd(const DeviceConfig &cfg, const DeviceBuffers &buf, const float *d_depth, size_t depth_pitch_floats,
+                       int image, hipStream_t s)
+{
+    hipLaunchKernelGGL(rgbd_kernel, dim3((cfg.sel_total + 255) / 256), dim3(256), 0, s, cfg, buf, d_depth, depth_pitch_floats, image);
+}
+
+void orbfe_launch_hamming_matrix(const uint8_t *da, int na, const uint8_t *db, int nb, int *dist, hipStream_t s)
+{
+    dim3 grid((nb + 63) / 64, (na + 63) / 64);
+    hipLaunchKernelGGL(hamming_matrix_kernel, grid, dim3(256), 0, s, da, na, db, nb, dist);
+}
