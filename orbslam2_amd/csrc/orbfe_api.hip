@@ -35,6 +35,7 @@ struct orbfe_context {
     bool use_octree2 = false; // point-parallel quadtree (all levels have <= 4 roots and the LDS budget fits)
     bool use_octree3 = false; // bucket-pyramid quadtree (orbfe_octree3.hip); preferred when its limits hold
     size_t ot3_lds = 0;
+    bool ot3_nodes_in_hbm = false; // node tables of the bucket-pyramid quadtree in HBM scratch (large per-level quotas)
     int ot2_sort_cap = 0;
     int ot2_lds_pts = 0;      // candidates per level the quadtree keeps in LDS
     size_t ot2_lds = 0;
@@ -286,7 +287,8 @@ static int build_config(orbfe_context *ctx)
         {
             bool ok3 = roots_ok && c.cell_cap <= 4096; // key fields: 12-bit cell, 12-bit slot
             for (int l = 0; l < p.nlevels; l++) ok3 = ok3 && c.lv[l].n_cells <= 4096 && c.lv[l].w_cell <= 64 && c.lv[l].h_cell <= 64; // one lane per cell column / row
-            ctx->ot3_lds = orbfe_octree3_lds_bytes(c.max_nodes, sc);
+            ctx->ot3_nodes_in_hbm = orbfe_octree3_lds_bytes(c.max_nodes, sc, false) > 150 * 1024;
+            ctx->ot3_lds = orbfe_octree3_lds_bytes(c.max_nodes, sc, ctx->ot3_nodes_in_hbm);
             const char *force = getenv("ORBFE_OCTREE"); // test knob: 2 = point-parallel kernel, 1 = generic kernel
             ctx->use_octree3 = ok3 && ctx->ot3_lds <= 150 * 1024 && !(force && (atoi(force) == 2 || atoi(force) == 1));
             if (force && atoi(force) == 1) ctx->use_octree2 = false;
@@ -321,7 +323,7 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
     if (hipSetDevice(p.device) != hipSuccess) { delete ctx; return fail(nullptr, ORBFE_ERR_NO_DEVICE, "hipSetDevice failed"); }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return fail(nullptr, ORBFE_ERR_NO_DEVICE, "hipStreamCreate failed"); }
     if (ctx->use_octree2 && orbfe_octree2_prepare(ctx->ot2_lds) != 0) ctx->use_octree2 = false;
-    if (ctx->use_octree3 && orbfe_octree3_prepare(ctx->ot3_lds) != 0) ctx->use_octree3 = false;
+    if (ctx->use_octree3 && orbfe_octree3_prepare(ctx->ot3_lds, ctx->ot3_nodes_in_hbm) != 0) ctx->use_octree3 = false;
     const DeviceConfig &c = ctx->cfg;
     const size_t B = (size_t)p.max_images;
     DeviceBuffers &b = ctx->buf;
@@ -346,6 +348,8 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
     Z(b.bk_cnt, B * c.nlevels * 4096 * sizeof(uint32_t));
     Z(b.bk_best, B * c.nlevels * 4096 * sizeof(uint32_t));
     A(b.bk_end, B * c.nlevels * 4097);
+    b.ot3_scratch = nullptr;
+    if (ctx->use_octree3 && ctx->ot3_nodes_in_hbm) A(b.ot3_scratch, B * c.nlevels * orbfe_octree3_node_bytes(c.max_nodes, ctx->ot2_sort_cap));
     A(b.lvl_ncand, B * c.nlevels);
     A(b.sel_cnt, B * c.nlevels);
     A(b.sel_xy, B * c.sel_total);
@@ -616,6 +620,8 @@ extern "C" int orbfe_stage_times(orbfe_context *ctx, float *ms, int *calls, int 
     return ORBFE_OK;
 }
 
+static inline int ot_sort_cap_of(const DeviceConfig &c) { int p = 1; while (p < c.max_nodes) p <<= 1; return p; }
+
 // View of the per-image buffers starting at image img0 (kernels index images from 0).
 static DeviceBuffers shift_buffers(const DeviceBuffers &b, const DeviceConfig &c, int img0)
 {
@@ -628,6 +634,7 @@ static DeviceBuffers shift_buffers(const DeviceBuffers &b, const DeviceConfig &c
     o.idx0 += i * c.cand_total; o.idx1 += i * c.cand_total; o.ot_xy2 += i * c.cand_total; o.ot_sc3 += i * c.cand_total;
     o.lvl_ncand += i * c.nlevels; o.sel_cnt += i * c.nlevels;
     o.bk_cnt += i * c.nlevels * 4096; o.bk_best += i * c.nlevels * 4096; o.bk_end += i * c.nlevels * 4097;
+    if (o.ot3_scratch) o.ot3_scratch += i * c.nlevels * orbfe_octree3_node_bytes(c.max_nodes, ot_sort_cap_of(c));
     o.sel_xy += i * c.sel_total; o.sel_sc += i * c.sel_total;
     o.kps = (KeyPointPOD *)o.kps + i * c.sel_total; o.desc += i * c.sel_total * 32;
     o.kp_cnt += i; o.status += i;
@@ -651,7 +658,7 @@ static void run_chain(orbfe_context *ctx, const uint8_t *d_images, int img0, int
     prof_mark(ctx, group, 3, s);
     orbfe_launch_fast(cfg, buf, n_images, ctx->use_octree3, s);
     prof_mark(ctx, group, 4, s);
-    if (ctx->use_octree3) orbfe_launch_octree3(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot3_lds, s);
+    if (ctx->use_octree3) orbfe_launch_octree3(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot3_lds, ctx->ot3_nodes_in_hbm, s);
     else if (ctx->use_octree2) orbfe_launch_octree2(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot2_lds_pts, ctx->ot2_lds, s);
     else orbfe_launch_octree_generic(cfg, buf, n_images, s);
     prof_mark(ctx, group, 5, s);

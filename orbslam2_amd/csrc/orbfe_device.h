@@ -69,6 +69,7 @@ struct DeviceBuffers {
     uint32_t *bk_cnt;    // [img][nlevels][4096] quadtree bucket counts (orbfe_octree3.hip); zero between frames
     uint32_t *bk_best;   // [img][nlevels][4096] quadtree bucket best keys; zero between frames
     int *bk_end;         // [img][nlevels][4097] quadtree deep path: bucket ends of the counting sort
+    uint8_t *ot3_scratch; // [img][nlevels][node_bytes] quadtree node tables when they do not fit LDS (else null)
     int *lvl_ncand;      // [img][nlevels]
     int *sel_cnt;        // [img][nlevels]
     uint32_t *sel_xy;    // [img][sel_total]
@@ -117,10 +118,11 @@ void orbfe_launch_octree2(const DeviceConfig &cfg, const DeviceBuffers &buf, int
 size_t orbfe_octree2_lds_bytes(int max_nodes, int sort_cap, int lds_pts);
 int orbfe_octree2_prepare(size_t lds);
 // orbfe_octree3.hip
-void orbfe_launch_octree3(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, size_t lds, hipStream_t s);
+void orbfe_launch_octree3(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, size_t lds, bool nodes_in_hbm, hipStream_t s);
 void orbfe_launch_candidates_gather(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
-size_t orbfe_octree3_lds_bytes(int max_nodes, int sort_cap);
-int orbfe_octree3_prepare(size_t lds);
+size_t orbfe_octree3_node_bytes(int max_nodes, int sort_cap);
+size_t orbfe_octree3_lds_bytes(int max_nodes, int sort_cap, bool nodes_in_hbm);
+int orbfe_octree3_prepare(size_t lds, bool nodes_in_hbm);
 void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool stereo, hipStream_t s);
 void orbfe_launch_stereo_match(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s);
 void orbfe_launch_stereo_median(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s);

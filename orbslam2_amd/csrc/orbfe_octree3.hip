@@ -122,12 +122,18 @@ __device__ __forceinline__ void ot3_bind(Ot3Nodes &n, uint8_t *&p, int cap)
     p = (uint8_t *)(((uintptr_t)p + 7) & ~(uintptr_t)7);
 }
 
-size_t orbfe_octree3_lds_bytes(int max_nodes, int sort_cap)
+// bytes of the node tables (sort keys, two node arrays, per-node bookkeeping) of one workgroup
+size_t orbfe_octree3_node_bytes(int max_nodes, int sort_cap)
 {
     const size_t cap = (size_t)max_nodes;
     const size_t node = 3 * sizeof(int) * cap + 4 * sizeof(short) * cap + 8;
-    return 2 * sizeof(int) * OT3_PYR + sizeof(unsigned long long) * sort_cap + 2 * node +
-           sizeof(int) * cap * (4 + 1 + 1 + 1 + 1) + 64;
+    return ((sizeof(unsigned long long) * sort_cap + 2 * node + sizeof(int) * cap * (4 + 1 + 1 + 1 + 1) + 64) + 255) & ~(size_t)255;
+}
+
+// dynamic LDS of octree3_kernel: the two pyramids, plus the node tables unless they live in HBM
+size_t orbfe_octree3_lds_bytes(int max_nodes, int sort_cap, bool nodes_in_hbm)
+{
+    return 2 * sizeof(int) * OT3_PYR + (nodes_in_hbm ? 0 : orbfe_octree3_node_bytes(max_nodes, sort_cap)) + 64;
 }
 
 // root and quadrant path of a point down to `depth` (src/ORBextractor.cc:537-564 for the root, :145-209 for a split)
@@ -169,7 +175,8 @@ __device__ __forceinline__ void ot3_for_each_point(const int *cell_cnt, const ui
     }
 }
 
-__global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, DeviceBuffers buf, int sort_cap)
+template <bool NODES_IN_HBM>
+__global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, DeviceBuffers buf, int sort_cap, size_t node_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     __shared__ int s_w[4 * OT3_WAVES];
@@ -185,6 +192,9 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
     // deep path only: s_bend[1 + b] = end of bucket b in the sorted arrays.  Kept in HBM scratch so that the LDS
     // footprint lets two workgroups share a CU.
     int *s_bend = buf.bk_end + ((size_t)img * cfg.nlevels + level) * (OT3_BUCKETS + 1);
+    // Node tables: LDS when they fit beside the pyramids (NODES_IN_HBM = false); otherwise the workgroup's slice of an HBM
+    // scratch buffer -- many features on few levels (a level's node capacity ~ its quota) must not be a create-time error.
+    if (NODES_IN_HBM) p = buf.ot3_scratch + ((size_t)img * cfg.nlevels + level) * node_bytes;
     unsigned long long *s_key = (unsigned long long *)p; p += sizeof(unsigned long long) * sort_cap;
     Ot3Nodes A, B;
     ot3_bind(A, p, MAXN);
@@ -585,10 +595,12 @@ __global__ __launch_bounds__(OT3_THREADS) void candidates_gather_kernel(DeviceCo
     }
 }
 
-void orbfe_launch_octree3(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, size_t lds, hipStream_t s)
+void orbfe_launch_octree3(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, size_t lds, bool nodes_in_hbm, hipStream_t s)
 {
     dim3 grid(cfg.nlevels, n_images);
-    hipLaunchKernelGGL(octree3_kernel, grid, dim3(OT3_THREADS), lds, s, cfg, buf, sort_cap);
+    const size_t node_bytes = orbfe_octree3_node_bytes(cfg.max_nodes, sort_cap);
+    if (nodes_in_hbm) hipLaunchKernelGGL(octree3_kernel<true>, grid, dim3(OT3_THREADS), lds, s, cfg, buf, sort_cap, node_bytes);
+    else hipLaunchKernelGGL(octree3_kernel<false>, grid, dim3(OT3_THREADS), lds, s, cfg, buf, sort_cap, node_bytes);
 }
 
 void orbfe_launch_candidates_gather(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
@@ -597,8 +609,9 @@ void orbfe_launch_candidates_gather(const DeviceConfig &cfg, const DeviceBuffers
     hipLaunchKernelGGL(candidates_gather_kernel, grid, dim3(OT3_THREADS), 0, s, cfg, buf);
 }
 
-int orbfe_octree3_prepare(size_t lds)
+int orbfe_octree3_prepare(size_t lds, bool nodes_in_hbm)
 {
     if (lds <= 64 * 1024) return 0;
-    return hipFuncSetAttribute((const void *)octree3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1;
+    const void *f = nodes_in_hbm ? (const void *)octree3_kernel<true> : (const void *)octree3_kernel<false>;
+    return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1;
 }

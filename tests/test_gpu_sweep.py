@@ -154,3 +154,42 @@ def test_extractor_parameter_variants(kw):
     assert np.array_equal(out["u_right"], ur) and np.array_equal(out["depth"], dp)
     assert len(kl) > 100
     ctx.close()
+
+
+def _random_case(i):
+    rng = np.random.default_rng(1000 + i)
+    w = int(rng.integers(70, 1500)); h = int(rng.integers(70, 900))
+    nlevels = int(rng.integers(1, 11))
+    sf = float(np.float32(rng.choice([1.1, 1.15, 1.2, 1.25, 1.3, 1.5, 1.8, 2.0])))
+    nf = int(rng.integers(30, 4500))
+    ini = int(rng.integers(8, 40)); mn = int(rng.integers(3, ini + 1))
+    return dict(w=w, h=h, kw=dict(nlevels=nlevels, scale_factor=sf, nfeatures=nf, ini_th_fast=ini, min_th_fast=mn))
+
+
+@pytest.mark.parametrize("i", range(32))
+def test_random_geometry_and_parameters(i):
+    """Randomised (fixed seeds) image sizes and extractor parameters: stereo frame bit-exact against the oracle, whichever quadtree
+    kernel the geometry selects.  Catches rounding / indexing cases no hand-picked configuration covers."""
+    from orbslam2_amd import api
+    c = _random_case(i)
+    w, h, kw = c["w"], c["h"], c["kw"]
+    try:
+        exl, exr = O.Extractor(**kw), O.Extractor(**kw)
+    except ValueError:
+        pytest.skip("parameter set rejected by the oracle")
+    left, right = synth.stereo_pair(w, h, seed=2000 + i)
+    fx, bf = 0.7 * w, 0.2 * w
+    try:
+        ctx = api.Context(width=w, height=h, fx=fx, fy=fx, cx=w / 2, cy=h / 2, bf=bf, **kw)
+    except api.OrbfeError as e:
+        if e.code == api.ERR_UNSUPPORTED:
+            pytest.skip(str(e))
+        raise
+    out = ctx.stereo_frame(left, right)
+    kl, dl = exl.extract(left); kr, dr = exr.extract(right)
+    ur, dp, _ = O.stereo_matches(exl, exr, kl, dl, kr, dr, bf, fx)
+    assert np.array_equal(out["kps_left"], kl.astype(api.KP_DTYPE)), (c, ctx.quadtree_kernel())
+    assert np.array_equal(out["kps_right"], kr.astype(api.KP_DTYPE)), (c, ctx.quadtree_kernel())
+    assert np.array_equal(out["desc_left"], dl) and np.array_equal(out["desc_right"], dr), c
+    assert np.array_equal(out["u_right"], ur) and np.array_equal(out["depth"], dp), c
+    ctx.close()
