@@ -105,6 +105,16 @@ int orbfe_rgbd_frame(orbfe_context *ctx, const uint8_t *gray, const float *depth
                      orbfe_keypoint *kps, uint8_t *desc, int *n,
                      float *u_right, float *depth, int cap);
 
+/* The same with the sensor's raw CV_16U depth map: folds the conversion of Tracking::GrabImageRGBD
+ * (src/Tracking.cc:323-324, imDepth.convertTo(imDepth, CV_32F, mDepthMapFactor)) into the sampling, so
+ * half the bytes cross the bus and no full-image conversion runs.  depth_map_factor is Tracking's
+ * already inverted mDepthMapFactor (src/Tracking.cc:151-155: 1.0f / DepthMapFactor, or 1 when unset);
+ * depth_stride in bytes. */
+int orbfe_rgbd_frame_u16(orbfe_context *ctx, const uint8_t *gray, const uint16_t *depth_img, float depth_map_factor,
+                         int w, int h, size_t gray_stride, size_t depth_stride,
+                         orbfe_keypoint *kps, uint8_t *desc, int *n,
+                         float *u_right, float *depth, int cap);
+
 /* mvImagePyramid[level] of image slot `image` of the latest call (include/ORBextractor.h:84;
  * read by src/Frame.cc:471,565,577,582).  blurred!=0 returns the Gaussian-blurred
  * working copy (src/ORBextractor.cc:899-900).  Copies w*h bytes into dst (row stride dst_stride). */

@@ -23,7 +23,7 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED = 0, -1, 
 EXPORTS = [
     "orbfe_abi_version", "orbfe_last_error", "orbfe_create", "orbfe_destroy", "orbfe_levels",
     "orbfe_keypoint_capacity", "orbfe_get_tables", "orbfe_level_size", "orbfe_extract",
-    "orbfe_stereo_frame", "orbfe_rgbd_frame", "orbfe_fetch_pyramid", "orbfe_enqueue_extract",
+    "orbfe_stereo_frame", "orbfe_rgbd_frame", "orbfe_rgbd_frame_u16", "orbfe_fetch_pyramid", "orbfe_enqueue_extract",
     "orbfe_enqueue_stereo", "orbfe_synchronize", "orbfe_fetch_image", "orbfe_fetch_counts",
     "orbfe_device_buffers", "orbfe_fetch_candidates", "orbfe_hamming_matrix",
     "orbfe_set_profiling", "orbfe_stage_name", "orbfe_stage_times", "orbfe_set_streams", "orbfe_quadtree_kernel",
@@ -93,6 +93,8 @@ def load():
                                      vp, vp, C.POINTER(C.c_int), vp, vp, C.c_int]
     L.orbfe_rgbd_frame.restype = C.c_int
     L.orbfe_rgbd_frame.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, vp, vp, C.POINTER(C.c_int), vp, vp, C.c_int]
+    L.orbfe_rgbd_frame_u16.restype = C.c_int
+    L.orbfe_rgbd_frame_u16.argtypes = [vp, vp, vp, C.c_float, C.c_int, C.c_int, C.c_size_t, C.c_size_t, vp, vp, C.POINTER(C.c_int), vp, vp, C.c_int]
     L.orbfe_fetch_pyramid.restype = C.c_int
     L.orbfe_fetch_pyramid.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t]
     L.orbfe_enqueue_extract.restype = C.c_int; L.orbfe_enqueue_extract.argtypes = [vp, vp, C.c_int, vp]
@@ -190,8 +192,16 @@ class Context:
         return w.value, h.value
 
     # ---- host-image entry points ----
+    @staticmethod
+    def _rows(a, dtype):
+        """Row-strided views (a cv::Mat ROI) go through as they are; anything else is made contiguous."""
+        a = np.asarray(a, dtype)
+        if a.ndim == 2 and a.strides[1] == a.itemsize and a.strides[0] >= a.shape[1] * a.itemsize:
+            return a
+        return np.ascontiguousarray(a)
+
     def extract(self, img: np.ndarray):
-        img = np.ascontiguousarray(img, np.uint8)
+        img = self._rows(img, np.uint8)
         cap = self.capacity
         kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
         n = C.c_int()
@@ -199,8 +209,10 @@ class Context:
         return kps[: n.value].copy(), desc[: n.value].copy()
 
     def stereo_frame(self, left: np.ndarray, right: np.ndarray):
-        left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
+        left = self._rows(left, np.uint8); right = self._rows(right, np.uint8)
         assert left.shape == right.shape
+        if left.strides[0] != right.strides[0]:
+            left = np.ascontiguousarray(left); right = np.ascontiguousarray(right)
         cap = self.capacity
         kl = np.zeros(cap, KP_DTYPE); dl = np.zeros((cap, 32), np.uint8)
         kr = np.zeros(cap, KP_DTYPE); dr = np.zeros((cap, 32), np.uint8)
@@ -212,14 +224,21 @@ class Context:
         return dict(kps_left=kl[:a].copy(), desc_left=dl[:a].copy(), kps_right=kr[:b].copy(), desc_right=dr[:b].copy(),
                     u_right=ur[:a].copy(), depth=dp[:a].copy())
 
-    def rgbd_frame(self, gray: np.ndarray, depth_img: np.ndarray):
-        gray = np.ascontiguousarray(gray, np.uint8); depth_img = np.ascontiguousarray(depth_img, np.float32)
+    def rgbd_frame(self, gray: np.ndarray, depth_img: np.ndarray, depth_map_factor: float = 1.0):
+        """depth_img float32: the CV_32F map of Frame::Frame(rgbd).  depth_img uint16: the raw sensor map, converted
+        with Tracking's mDepthMapFactor (src/Tracking.cc:323-324) on the device."""
+        raw = np.asarray(depth_img).dtype == np.uint16
+        gray = self._rows(gray, np.uint8); depth_img = self._rows(depth_img, np.uint16 if raw else np.float32)
         cap = self.capacity
         k = np.zeros(cap, KP_DTYPE); d = np.zeros((cap, 32), np.uint8)
         ur = np.zeros(cap, np.float32); dp = np.zeros(cap, np.float32)
         n = C.c_int()
-        self._check(self.L.orbfe_rgbd_frame(self.h, _p(gray), _p(depth_img), gray.shape[1], gray.shape[0], gray.strides[0],
-                                            depth_img.strides[0], _p(k), _p(d), C.byref(n), _p(ur), _p(dp), cap))
+        if raw:
+            self._check(self.L.orbfe_rgbd_frame_u16(self.h, _p(gray), _p(depth_img), float(depth_map_factor), gray.shape[1], gray.shape[0],
+                                                    gray.strides[0], depth_img.strides[0], _p(k), _p(d), C.byref(n), _p(ur), _p(dp), cap))
+        else:
+            self._check(self.L.orbfe_rgbd_frame(self.h, _p(gray), _p(depth_img), gray.shape[1], gray.shape[0], gray.strides[0],
+                                                depth_img.strides[0], _p(k), _p(d), C.byref(n), _p(ur), _p(dp), cap))
         m = n.value
         return dict(kps=k[:m].copy(), desc=d[:m].copy(), u_right=ur[:m].copy(), depth=dp[:m].copy())
 

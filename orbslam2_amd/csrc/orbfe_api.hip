@@ -9,6 +9,7 @@
 #include "orbfe_host.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cfloat>
 #include <climits>
 #include <cmath>
@@ -29,6 +30,11 @@ struct orbfe_context {
     hipStream_t stream = nullptr;
     uint8_t *d_in = nullptr;      // staging for host-image entry points [max_images][w*h]
     float *d_depth_in = nullptr;  // staging for RGB-D depth
+    // pinned host staging of the single-frame entry points (lazily allocated): packed input rows, then one block of
+    // outputs per call so a frame costs one stream synchronisation instead of one blocking copy per array
+    uint8_t *h_in = nullptr;      // [min(max_images,2)][w*h]
+    float *h_depth_in = nullptr;  // [w*h]
+    uint8_t *h_out = nullptr;     // see HostOut
     uint8_t *d_ham = nullptr;     // scratch for orbfe_hamming_matrix
     size_t d_ham_bytes = 0;
     int last_images = 0;
@@ -531,6 +537,9 @@ extern "C" void orbfe_destroy(orbfe_context *ctx)
     if (ctx->match) orbfe_match_state_destroy(ctx->match);
     if (ctx->bow) orbfe_bow_state_destroy(ctx->bow);
     if (ctx->d_depth_in) hipFree(ctx->d_depth_in);
+    if (ctx->h_in) hipHostFree(ctx->h_in);
+    if (ctx->h_depth_in) hipHostFree(ctx->h_depth_in);
+    if (ctx->h_out) hipHostFree(ctx->h_out);
     if (ctx->d_ham) hipFree(ctx->d_ham);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -793,13 +802,91 @@ extern "C" int orbfe_device_buffers(orbfe_context *ctx, void **kps, void **desc,
     return ORBFE_OK;
 }
 
+// Layout of the pinned output block of the single-frame entry points: counts and status words of the (up to two)
+// images, then the keypoint / descriptor / uRight / depth arrays at their device capacity (sel_total per image).
+struct HostOut {
+    size_t cnt, status, kps, desc, ur, depth, bytes;
+};
+
+static HostOut host_out_layout(const orbfe_context *ctx)
+{
+    const size_t st = (size_t)ctx->cfg.sel_total, ni = ctx->params.max_images < 2 ? 1 : 2;
+    HostOut o;
+    o.cnt = 0;
+    o.status = 16;
+    o.kps = 32;
+    o.desc = o.kps + ((ni * st * sizeof(KeyPointPOD) + 15) & ~(size_t)15);
+    o.ur = o.desc + ni * st * 32;
+    o.depth = o.ur + ((st * sizeof(float) + 15) & ~(size_t)15);
+    o.bytes = o.depth + st * sizeof(float);
+    return o;
+}
+
+static int ensure_host_stage(orbfe_context *ctx, bool want_depth)
+{
+    const size_t px = (size_t)ctx->params.width * ctx->params.height, ni = ctx->params.max_images < 2 ? 1 : 2;
+    if (!ctx->h_in) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_in, ni * px, hipHostMallocDefault));
+    if (!ctx->h_out) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_out, host_out_layout(ctx).bytes, hipHostMallocDefault));
+    if (want_depth && !ctx->h_depth_in) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_depth_in, px * sizeof(float), hipHostMallocDefault));
+    if (want_depth && !ctx->d_depth_in) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_depth_in, px * sizeof(float)));
+    return ORBFE_OK;
+}
+
+// Packs the caller's rows into the pinned block and queues one linear copy (a pitched copy from pageable memory is
+// executed row by row by the runtime: 3 ms for a 1241x376 image; splitting the copy into chunks to overlap packing
+// and DMA costs more in submissions, about 15 us each, than it hides).
+static int stage_rows(orbfe_context *ctx, void *d_dst, uint8_t *h_stage, const void *src, size_t row, int h, size_t stride)
+{
+    if (stride == row) memcpy(h_stage, src, row * h);
+    else for (int y = 0; y < h; y++) memcpy(h_stage + (size_t)y * row, (const uint8_t *)src + (size_t)y * stride, row);
+    HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_stage, row * h, hipMemcpyHostToDevice, ctx->stream));
+    return ORBFE_OK;
+}
+
 static int upload_image(orbfe_context *ctx, int slot, const uint8_t *img, int w, int h, size_t stride)
 {
     if (w != ctx->params.width || h != ctx->params.height)
         return fail(ctx, ORBFE_ERR_UNSUPPORTED, "image is %dx%d, context was built for %dx%d", w, h, ctx->params.width, ctx->params.height);
     if (stride < (size_t)w) return fail(ctx, ORBFE_ERR_INVALID, "stride smaller than width");
-    HIP_TRY(ctx, hipMemcpy2DAsync(ctx->d_in + (size_t)slot * w * h, (size_t)w, img, stride, (size_t)w, (size_t)h,
-                                  hipMemcpyHostToDevice, ctx->stream));
+    const size_t px = (size_t)w * h;
+    return stage_rows(ctx, ctx->d_in + (size_t)slot * px, ctx->h_in + (size_t)slot * px, img, (size_t)w, h, stride);
+}
+
+// Queues the device-to-host copies of `nimg` images' results into the pinned block, waits once, and hands the
+// caller its arrays.  `with_depth`: image 0 carries uRight / depth.
+static int download_frame(orbfe_context *ctx, int nimg, bool with_depth)
+{
+    const HostOut o = host_out_layout(ctx);
+    const size_t st = (size_t)ctx->cfg.sel_total;
+    uint8_t *ho = ctx->h_out;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ho + o.cnt, ctx->buf.kp_cnt, sizeof(int) * nimg, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ho + o.status, ctx->buf.status, sizeof(int) * nimg, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ho + o.kps, ctx->buf.kps, sizeof(KeyPointPOD) * st * nimg, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ho + o.desc, ctx->buf.desc, (size_t)32 * st * nimg, hipMemcpyDeviceToHost, s));
+    if (with_depth) {
+        HIP_TRY(ctx, hipMemcpyAsync(ho + o.ur, ctx->buf.u_right, sizeof(float) * st, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemcpyAsync(ho + o.depth, ctx->buf.depth, sizeof(float) * st, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return ORBFE_OK;
+}
+
+static int hand_over(orbfe_context *ctx, int image, orbfe_keypoint *kps, uint8_t *desc, float *u_right, float *depth,
+                     int cap, int *n)
+{
+    const HostOut o = host_out_layout(ctx);
+    const size_t st = (size_t)ctx->cfg.sel_total;
+    const uint8_t *ho = ctx->h_out;
+    const int cnt = ((const int *)(ho + o.cnt))[image], status = ((const int *)(ho + o.status))[image];
+    if (status != 0) return fail(ctx, ORBFE_ERR_CAPACITY, "device-side capacity overflow (status %d) on image %d", status, image);
+    *n = cnt;
+    if (cnt > cap) return fail(ctx, ORBFE_ERR_CAPACITY, "caller buffers hold %d keypoints, image has %d", cap, cnt);
+    if (cnt <= 0) return ORBFE_OK;
+    if (kps) memcpy(kps, ho + o.kps + image * st * sizeof(KeyPointPOD), sizeof(KeyPointPOD) * cnt);
+    if (desc) memcpy(desc, ho + o.desc + image * st * 32, (size_t)32 * cnt);
+    if (u_right) memcpy(u_right, ho + o.ur, sizeof(float) * cnt);
+    if (depth) memcpy(depth, ho + o.depth, sizeof(float) * cnt);
     return ORBFE_OK;
 }
 
@@ -808,12 +895,15 @@ extern "C" int orbfe_extract(orbfe_context *ctx, const uint8_t *img, int w, int 
 {
     if (!ctx || !n) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
     if (!img || w <= 0 || h <= 0) { *n = 0; return ORBFE_OK; } // _image.empty(): src/ORBextractor.cc:861-862
-    int rc = upload_image(ctx, 0, img, w, h, stride);
+    int rc = ensure_host_stage(ctx, false);
+    if (rc != ORBFE_OK) return rc;
+    rc = upload_image(ctx, 0, img, w, h, stride);
     if (rc != ORBFE_OK) return rc;
     rc = orbfe_enqueue_extract(ctx, ctx->d_in, 1, nullptr);
     if (rc != ORBFE_OK) return rc;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return orbfe_fetch_image(ctx, 0, kps, desc, nullptr, nullptr, cap, n);
+    rc = download_frame(ctx, 1, false);
+    if (rc != ORBFE_OK) return rc;
+    return hand_over(ctx, 0, kps, desc, nullptr, nullptr, cap, n);
 }
 
 extern "C" int orbfe_stereo_frame(orbfe_context *ctx, const uint8_t *left, const uint8_t *right,
@@ -825,16 +915,61 @@ extern "C" int orbfe_stereo_frame(orbfe_context *ctx, const uint8_t *left, const
     if (!ctx || !n_left || !n_right) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
     if (!left || !right || w <= 0 || h <= 0) { *n_left = 0; *n_right = 0; return ORBFE_OK; }
     if (ctx->params.max_images < 2) return fail(ctx, ORBFE_ERR_CAPACITY, "stereo needs max_images >= 2");
-    int rc = upload_image(ctx, 0, left, w, h, stride);
+    int rc = ensure_host_stage(ctx, false);
+    if (rc != ORBFE_OK) return rc;
+    rc = upload_image(ctx, 0, left, w, h, stride);
     if (rc != ORBFE_OK) return rc;
     rc = upload_image(ctx, 1, right, w, h, stride);
     if (rc != ORBFE_OK) return rc;
     rc = orbfe_enqueue_stereo(ctx, ctx->d_in, 1, nullptr);
     if (rc != ORBFE_OK) return rc;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    rc = orbfe_fetch_image(ctx, 0, kps_left, desc_left, u_right, depth, cap, n_left);
+    rc = download_frame(ctx, 2, true);
     if (rc != ORBFE_OK) return rc;
-    return orbfe_fetch_image(ctx, 1, kps_right, desc_right, nullptr, nullptr, cap, n_right);
+    rc = hand_over(ctx, 0, kps_left, desc_left, u_right, depth, cap, n_left);
+    if (rc != ORBFE_OK) return rc;
+    return hand_over(ctx, 1, kps_right, desc_right, nullptr, nullptr, cap, n_right);
+}
+
+// Common body of the two RGB-D entry points.  The depth rows are packed while the extraction kernels already run:
+// the map is only sampled at the keypoints, at the very end of the chain.
+static double host_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static int rgbd_frame_impl(orbfe_context *ctx, const uint8_t *gray, const void *depth_img, size_t px_bytes, float factor,
+                           int w, int h, size_t gray_stride, size_t depth_stride,
+                           orbfe_keypoint *kps, uint8_t *desc, int *n, float *u_right, float *depth, int cap)
+{
+    if (!ctx || !n) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    if (!gray || !depth_img || w <= 0 || h <= 0) { *n = 0; return ORBFE_OK; }
+    const size_t row = px_bytes * (size_t)w;
+    if (depth_stride < row) return fail(ctx, ORBFE_ERR_INVALID, "depth stride smaller than a row");
+    static const bool trace = getenv("ORBFE_HOST_TRACE") != nullptr;
+    double t[6] = {};
+    t[0] = host_ms();
+    int rc = ensure_host_stage(ctx, true);
+    if (rc != ORBFE_OK) return rc;
+    rc = upload_image(ctx, 0, gray, w, h, gray_stride);
+    if (rc != ORBFE_OK) return rc;
+    t[1] = host_ms();
+    rc = orbfe_enqueue_extract(ctx, ctx->d_in, 1, nullptr);
+    if (rc != ORBFE_OK) return rc;
+    t[2] = host_ms();
+    rc = stage_rows(ctx, ctx->d_depth_in, (uint8_t *)ctx->h_depth_in, depth_img, row, h, depth_stride);
+    if (rc != ORBFE_OK) return rc;
+    t[3] = host_ms();
+    if (px_bytes == 2) orbfe_launch_rgbd_u16(ctx->cfg, ctx->buf, (const uint16_t *)ctx->d_depth_in, (size_t)w, factor, 0, ctx->stream);
+    else orbfe_launch_rgbd(ctx->cfg, ctx->buf, ctx->d_depth_in, (size_t)w, 0, ctx->stream);
+    rc = download_frame(ctx, 1, true);
+    if (rc != ORBFE_OK) return rc;
+    t[4] = host_ms();
+    rc = hand_over(ctx, 0, kps, desc, u_right, depth, cap, n);
+    t[5] = host_ms();
+    if (trace)
+        fprintf(stderr, "[orbfe] rgbd frame: gray upload %.3f  enqueue %.3f  depth upload %.3f  rgbd+download+wait %.3f  hand-over %.3f ms\n",
+                t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4]);
+    return rc;
 }
 
 extern "C" int orbfe_rgbd_frame(orbfe_context *ctx, const uint8_t *gray, const float *depth_img,
@@ -842,18 +977,15 @@ extern "C" int orbfe_rgbd_frame(orbfe_context *ctx, const uint8_t *gray, const f
                                 orbfe_keypoint *kps, uint8_t *desc, int *n,
                                 float *u_right, float *depth, int cap)
 {
-    if (!ctx || !n) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
-    if (!gray || !depth_img || w <= 0 || h <= 0) { *n = 0; return ORBFE_OK; }
-    int rc = upload_image(ctx, 0, gray, w, h, gray_stride);
-    if (rc != ORBFE_OK) return rc;
-    if (!ctx->d_depth_in) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_depth_in, sizeof(float) * (size_t)w * h));
-    HIP_TRY(ctx, hipMemcpy2DAsync(ctx->d_depth_in, sizeof(float) * (size_t)w, depth_img, depth_stride, sizeof(float) * (size_t)w,
-                                  (size_t)h, hipMemcpyHostToDevice, ctx->stream));
-    rc = orbfe_enqueue_extract(ctx, ctx->d_in, 1, nullptr);
-    if (rc != ORBFE_OK) return rc;
-    orbfe_launch_rgbd(ctx->cfg, ctx->buf, ctx->d_depth_in, (size_t)w, 0, ctx->stream);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return orbfe_fetch_image(ctx, 0, kps, desc, u_right, depth, cap, n);
+    return rgbd_frame_impl(ctx, gray, depth_img, sizeof(float), 1.0f, w, h, gray_stride, depth_stride, kps, desc, n, u_right, depth, cap);
+}
+
+extern "C" int orbfe_rgbd_frame_u16(orbfe_context *ctx, const uint8_t *gray, const uint16_t *depth_img, float depth_map_factor,
+                                    int w, int h, size_t gray_stride, size_t depth_stride,
+                                    orbfe_keypoint *kps, uint8_t *desc, int *n,
+                                    float *u_right, float *depth, int cap)
+{
+    return rgbd_frame_impl(ctx, gray, depth_img, sizeof(uint16_t), depth_map_factor, w, h, gray_stride, depth_stride, kps, desc, n, u_right, depth, cap);
 }
 
 extern "C" int orbfe_fetch_pyramid(orbfe_context *ctx, int image, int level, int blurred, uint8_t *dst, size_t dst_stride)

@@ -128,4 +128,6 @@ void orbfe_launch_stereo_match(const DeviceConfig &cfg, const DeviceBuffers &buf
 void orbfe_launch_stereo_median(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s);
 void orbfe_launch_rgbd(const DeviceConfig &cfg, const DeviceBuffers &buf, const float *d_depth,
                        size_t depth_pitch_floats, int image, hipStream_t s);
+void orbfe_launch_rgbd_u16(const DeviceConfig &cfg, const DeviceBuffers &buf, const uint16_t *d_depth, size_t depth_pitch_px,
+                           float factor, int image, hipStream_t s);
 void orbfe_launch_hamming_matrix(const uint8_t *da, int na, const uint8_t *db, int nb, int *dist, hipStream_t s);

@@ -237,8 +237,12 @@ __global__ __launch_bounds__(256) void stereo_median_kernel(DeviceConfig cfg, De
 }
 
 // Frame::ComputeStereoFromRGBD (src/Frame.cc:645-666), undistorted camera
-__global__ __launch_bounds__(256) void rgbd_kernel(DeviceConfig cfg, DeviceBuffers buf, const float *__restrict__ depth_img,
-                                                   size_t pitch_floats, int img)
+// T = float: the CV_32F map Frame::Frame receives.  T = uint16_t: the sensor's raw map; the conversion of
+// Tracking::GrabImageRGBD (src/Tracking.cc:323-324, convertTo(CV_32F, mDepthMapFactor): one rounded float multiply)
+// is applied to the sampled pixel only.
+template <typename T>
+__global__ __launch_bounds__(256) void rgbd_kernel(DeviceConfig cfg, DeviceBuffers buf, const T *__restrict__ depth_img,
+                                                   size_t pitch_floats, int img, float factor)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int n = buf.kp_cnt[img];
@@ -247,7 +251,9 @@ __global__ __launch_bounds__(256) void rgbd_kernel(DeviceConfig cfg, DeviceBuffe
     float u = -1.0f, dp = -1.0f;
     const int v = (int)kp.y, uu = (int)kp.x;
     if (uu >= 0 && v >= 0 && uu < cfg.width && v < cfg.height) {
-        const float d = depth_img[(size_t)v * pitch_floats + uu];
+        float d;
+        if constexpr (sizeof(T) == 2) d = __fmul_rn((float)depth_img[(size_t)v * pitch_floats + uu], factor);
+        else d = depth_img[(size_t)v * pitch_floats + uu];
         if (d > 0) { dp = d; u = __fsub_rn(kp.x, __fdiv_rn(cfg.bf, d)); }
     }
     buf.u_right[(size_t)img * cfg.sel_total + i] = u;
@@ -290,7 +296,13 @@ void orbfe_launch_stereo_median(const DeviceConfig &cfg, const DeviceBuffers &bu
 void orbfe_launch_rgbd(const DeviceConfig &cfg, const DeviceBuffers &buf, const float *d_depth, size_t depth_pitch_floats,
                        int image, hipStream_t s)
 {
-    hipLaunchKernelGGL(rgbd_kernel, dim3((cfg.sel_total + 255) / 256), dim3(256), 0, s, cfg, buf, d_depth, depth_pitch_floats, image);
+    hipLaunchKernelGGL(rgbd_kernel<float>, dim3((cfg.sel_total + 255) / 256), dim3(256), 0, s, cfg, buf, d_depth, depth_pitch_floats, image, 1.0f);
+}
+
+void orbfe_launch_rgbd_u16(const DeviceConfig &cfg, const DeviceBuffers &buf, const uint16_t *d_depth, size_t depth_pitch_px,
+                           float factor, int image, hipStream_t s)
+{
+    hipLaunchKernelGGL(rgbd_kernel<uint16_t>, dim3((cfg.sel_total + 255) / 256), dim3(256), 0, s, cfg, buf, d_depth, depth_pitch_px, image, factor);
 }
 
 void orbfe_launch_hamming_matrix(const uint8_t *da, int na, const uint8_t *db, int nb, int *dist, hipStream_t s)

@@ -155,3 +155,67 @@ def test_empty_and_flat_images():
     with pytest.raises(api.OrbfeError):
         ctx.extract(np.zeros((100, 100), np.uint8))  # size other than the context's
     ctx.close()
+
+
+def test_row_strided_inputs_match_contiguous(case):
+    """The reference hands cv::Mat headers that may be ROIs of a wider buffer (step > cols); the ABI takes the row
+    stride.  Results must not depend on it."""
+    L, R = case["left"], case["right"]
+    h, w = L.shape
+    big = np.full((2, h, w + 37), 255, np.uint8)
+    big[0, :, 5:5 + w] = L
+    big[1, :, 5:5 + w] = R
+    lv, rv = big[0, :, 5:5 + w], big[1, :, 5:5 + w]
+    assert lv.strides[0] == w + 37 and not lv.flags["C_CONTIGUOUS"]
+    out = case["ctx"].stereo_frame(lv, rv)
+    ref = case["out"]
+    for k in ("kps_left", "desc_left", "kps_right", "desc_right", "u_right", "depth"):
+        assert np.array_equal(out[k], ref[k]), k
+    k1, d1 = case["ctx"].extract(lv)
+    assert np.array_equal(k1, ref["kps_left"]) and np.array_equal(d1, ref["desc_left"])
+
+
+def test_rgbd_row_strided_depth():
+    cfg = SMALL
+    left, _, depth = synth.stereo_pair(cfg["width"], cfg["height"], seed=5, with_depth=True, bf=cfg["bf"])
+    ctx = _ctx(cfg, max_images=1)
+    ref = ctx.rgbd_frame(left, depth)
+    h, w = depth.shape
+    bigd = np.zeros((h, w + 11), np.float32)
+    bigd[:, 3:3 + w] = depth
+    bigg = np.zeros((h, w + 64), np.uint8)
+    bigg[:, 64:] = left
+    out = ctx.rgbd_frame(bigg[:, 64:], bigd[:, 3:3 + w])
+    for k in ref:
+        assert np.array_equal(out[k], ref[k]), k
+    assert len(ref["kps"]) > 50 and (ref["depth"] > 0).any()
+    ctx.close()
+
+
+def test_rgbd_raw_u16_depth_matches_converted_map():
+    """Tracking::GrabImageRGBD (src/Tracking.cc:323-324) converts the sensor's CV_16U map with
+    convertTo(CV_32F, mDepthMapFactor) -- one rounded float multiply per pixel -- before Frame::Frame; the u16 entry
+    point folds that into the sampling.  TUM factor 5000 (Examples/RGB-D/TUM1.yaml)."""
+    cfg = TUM1
+    left, _, depth = synth.stereo_pair(cfg["width"], cfg["height"], seed=21, with_depth=True, bf=cfg["bf"])
+    raw = np.clip(np.rint(depth * 5000.0), 0, 65535).astype(np.uint16)
+    factor = np.float32(1.0) / np.float32(5000.0)
+    conv = raw.astype(np.float32) * factor  # the oracle of convertTo for this type pair
+    ctx = _ctx(cfg, max_images=1)
+    got = ctx.rgbd_frame(left, raw, depth_map_factor=float(factor))
+    ex = O.Extractor(nfeatures=cfg["nfeatures"])
+    k, d = ex.extract(left)
+    ur, dp = O.stereo_from_rgbd(k, k, conv, cfg["bf"])
+    _assert_kps_equal(got["kps"], k, "rgbd u16")
+    assert np.array_equal(got["desc"], d)
+    assert np.array_equal(got["u_right"], ur) and np.array_equal(got["depth"], dp)
+    ref = ctx.rgbd_frame(left, conv)
+    for key in ref:
+        assert np.array_equal(got[key], ref[key]), key
+    wide = np.zeros((raw.shape[0], raw.shape[1] + 6), np.uint16)
+    wide[:, 2:2 + raw.shape[1]] = raw
+    got2 = ctx.rgbd_frame(left, wide[:, 2:2 + raw.shape[1]], depth_map_factor=float(factor))
+    for key in ref:
+        assert np.array_equal(got2[key], ref[key]), key
+    assert (dp > 0).sum() > 100
+    ctx.close()
