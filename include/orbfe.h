@@ -315,6 +315,29 @@ int orbfe_kfdb_score(orbfe_context *ctx, const uint32_t *q_words, const float *q
 int orbfe_detect_reloc_candidates(orbfe_context *ctx, const uint32_t *q_words, const float *q_w, int nq,
                                   const int32_t *covis_off, const int32_t *covis_idx, float *reloc_score,
                                   int32_t *cand, int cap, int *n_cand);
+/* Optimizer::PoseOptimization(Frame *pFrame) (src/Optimizer.cc:283-495): motion-only bundle adjustment with g2o's
+ * Levenberg solver (Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:59-157), 4 rounds x <= 10 iterations,
+ * Huber kernel in rounds 0-2, chi2 classification after every round.  Called after every Tracking matcher call
+ * (src/Tracking.cc:875,998,1040,1475,1555,1580).
+ *   Tcw       4x4 row-major float, in/out: pFrame->mTcw before, what pFrame->SetPose receives after (untouched when
+ *             fewer than 3 correspondences, :404-405)
+ *   keys_un   pFrame->mvKeysUn (pt and octave are read), u_right pFrame->mvuRight (< 0: monocular edge)
+ *   has_point pFrame->mvpMapPoints[i] != NULL; Xw[3*i..] = that point's GetWorldPos()
+ *   outlier   pFrame->mvbOutlier, in/out: written for entries with a point, others keep their value
+ *   n_inliers the return value, nInitialCorrespondences - nBad
+ * Camera (fx, fy, cx, cy, bf) and mvInvLevelSigma2 are the context's.  FP64 throughout like g2o; sums are reduced in a
+ * fixed tree order instead of edge order, so poses agree with the CPU path to rounding (about 1e-6 relative), not bit
+ * for bit.  The batch form runs one workgroup per problem (frames of independent sequences / relocalisation
+ * candidates); offsets[n_problems + 1] delimits each problem's slice of the per-keypoint arrays, Tcw is n_problems x 16. */
+int orbfe_pose_optimization(orbfe_context *ctx, float *Tcw, int n, const orbfe_keypoint *keys_un, const float *u_right,
+                            const uint8_t *has_point, const float *Xw, uint8_t *outlier, int *n_inliers);
+int orbfe_pose_optimization_batch(orbfe_context *ctx, int n_problems, const int32_t *offsets, float *Tcw,
+                                  const orbfe_keypoint *keys_un, const float *u_right, const uint8_t *has_point,
+                                  const float *Xw, uint8_t *outlier, int32_t *n_inliers);
+/* The same on device-resident arrays, asynchronous on `stream` (NULL: the context's stream). */
+int orbfe_enqueue_pose_optimization(orbfe_context *ctx, int n_problems, const int32_t *d_offsets,
+                                    const orbfe_keypoint *d_keys_un, const float *d_u_right, const uint8_t *d_has_point,
+                                    const float *d_Xw, float *d_Tcw, uint8_t *d_outlier, int32_t *d_n_inliers, void *stream);
 /* ORBmatcher::SearchByFboW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12) (src/ORBmatcher.cc:517-650; LoopClosing and
  * relocalisation).  valid1 / valid2 = the keypoint has a map point that is not bad.  match12[i1] receives the KF2
  * keypoint whose map point KF1 keypoint i1 got, or -1 (n1 entries). */

@@ -416,3 +416,17 @@ def stereo_from_rgbd(k, k_un, depth: np.ndarray, bf: float):
     ur = np.zeros(n, np.float32); dp = np.zeros(n, np.float32)
     lib().orc_stereo_from_rgbd(_ptr(k), _ptr(k_un), n, _ptr(depth), depth.shape[1], depth.shape[0], depth.strides[0] // 4, bf, _ptr(ur), _ptr(dp))
     return ur, dp
+
+
+def pose_optimization(Tcw, keys_un, u_right, has_point, Xw, inv_level_sigma2, fx, fy, cx, cy, bf, outlier=None):
+    """Optimizer::PoseOptimization (src/Optimizer.cc:283-495).  Returns (Tcw_out 4x4 float32, outlier uint8[N], n_inliers)."""
+    L = lib()
+    L.orc_pose_optimization.restype = C.c_int
+    L.orc_pose_optimization.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float] * 5 + [C.c_void_p]
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(4, 4).copy()
+    k = np.ascontiguousarray(keys_un); ur = np.ascontiguousarray(u_right, np.float32)
+    hp = np.ascontiguousarray(has_point, np.uint8); X = np.ascontiguousarray(Xw, np.float32)
+    s2 = np.ascontiguousarray(inv_level_sigma2, np.float32)
+    out = np.zeros(max(len(k), 1), np.uint8) if outlier is None else np.ascontiguousarray(outlier, np.uint8).copy()
+    n = L.orc_pose_optimization(_ptr(T), len(k), _ptr(k), _ptr(ur), _ptr(hp), _ptr(X), _ptr(s2), fx, fy, cx, cy, bf, _ptr(out))
+    return T, out[: len(k)].copy(), n

@@ -188,6 +188,10 @@ int orc_search_by_sim3(const orc_grid *g1, const uint8_t *desc_kf1, const float 
                        const uint8_t *pdesc2, const int32_t *valid2,
                        const float *scale_factors, const orc_camera *cam, float log_scale_factor, int n_levels,
                        float s12, const float *R12, const float *t12, float th, int32_t *match12);
+/* Optimizer::PoseOptimization (src/Optimizer.cc:283-495) with the vendored g2o Levenberg solver; see orb_oracle_pose.c */
+int orc_pose_optimization(float *Tcw, int N, const orc_keypoint *keys_un, const float *u_right, const uint8_t *has_point,
+                          const float *Xw, const float *inv_level_sigma2, float fx, float fy, float cx, float cy, float bf,
+                          uint8_t *outlier);
 double orc_bow_score(const uint32_t *w1, const float *v1, int n1, const uint32_t *w2, const float *v2, int n2);
 int orc_detect_reloc_candidates(const uint32_t *q_words, const float *q_w, int nq,
                                 int n_kf, const int32_t *kf_off, const uint32_t *db_words, const float *db_w,

@@ -31,6 +31,7 @@ EXPORTS = [
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_kf", "orbfe_search_for_initialization",
     "orbfe_vocab_load", "orbfe_bow_transform", "orbfe_bow_maps", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",  # bound in orbslam2_amd/bow.py
     "orbfe_search_for_triangulation", "orbfe_fuse", "orbfe_search_by_projection_sim3", "orbfe_fuse_sim3", "orbfe_search_by_sim3", "orbfe_kfdb_clear", "orbfe_kfdb_add", "orbfe_kfdb_erase", "orbfe_kfdb_size", "orbfe_kfdb_score", "orbfe_detect_reloc_candidates",
+    "orbfe_pose_optimization", "orbfe_pose_optimization_batch", "orbfe_enqueue_pose_optimization",
 ]
 NUM_STAGES = 8
 STAGE_NAMES = ["ingest", "pyramid", "blur", "fast", "octree", "describe", "stereo_match", "stereo_median"]  # orbfe_stage_name()
@@ -133,6 +134,12 @@ def load():
     L.orbfe_fuse_sim3.argtypes = [vp, fvp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float, vp, ip]
     L.orbfe_search_by_sim3.restype = C.c_int
     L.orbfe_search_by_sim3.argtypes = [vp] + [fvp, vp, vp, vp, vp, vp, vp] * 2 + [C.c_float, vp, vp, C.c_float, vp, ip]
+    L.orbfe_pose_optimization.restype = C.c_int
+    L.orbfe_pose_optimization.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, ip]
+    L.orbfe_pose_optimization_batch.restype = C.c_int
+    L.orbfe_pose_optimization_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.orbfe_enqueue_pose_optimization.restype = C.c_int
+    L.orbfe_enqueue_pose_optimization.argtypes = [vp, C.c_int] + [vp] * 9
     L.orbfe_search_for_initialization.restype = C.c_int
     L.orbfe_search_for_initialization.argtypes = [vp, fvp, fvp, vp, C.c_int, C.c_float, C.c_int, vp, ip]
     _lib = L
@@ -391,6 +398,27 @@ class Context:
         self._check(self.L.orbfe_search_by_sim3(self.h, C.byref(view1), *[_p(x) for x in a], C.byref(view2), *[_p(x) for x in b],
                                                 float(s12), _p(R), _p(t), th, _p(out), C.byref(nf)))
         return out[: view1.n].copy(), nf.value
+
+    def pose_optimization(self, Tcw, keys_un, u_right, has_point, Xw, outlier=None):
+        """Optimizer::PoseOptimization (src/Optimizer.cc:283-495).  Returns (Tcw 4x4 float32, outlier uint8[N], n_inliers)."""
+        T = np.ascontiguousarray(Tcw, np.float32).reshape(4, 4).copy()
+        k = np.ascontiguousarray(keys_un, KP_DTYPE); ur = np.ascontiguousarray(u_right, np.float32)
+        hp = np.ascontiguousarray(has_point, np.uint8); X = np.ascontiguousarray(Xw, np.float32)
+        out = np.zeros(max(len(k), 1), np.uint8) if outlier is None else np.ascontiguousarray(outlier, np.uint8).copy()
+        n = C.c_int()
+        self._check(self.L.orbfe_pose_optimization(self.h, _p(T), len(k), _p(k), _p(ur), _p(hp), _p(X), _p(out), C.byref(n)))
+        return T, out[: len(k)].copy(), n.value
+
+    def pose_optimization_batch(self, Tcw, offsets, keys_un, u_right, has_point, Xw, outlier=None):
+        """One problem per slice offsets[k]:offsets[k+1].  Returns (Tcw [P,4,4], outlier, n_inliers int32[P])."""
+        off = np.ascontiguousarray(offsets, np.int32); P = len(off) - 1
+        T = np.ascontiguousarray(Tcw, np.float32).reshape(P, 4, 4).copy()
+        k = np.ascontiguousarray(keys_un, KP_DTYPE); ur = np.ascontiguousarray(u_right, np.float32)
+        hp = np.ascontiguousarray(has_point, np.uint8); X = np.ascontiguousarray(Xw, np.float32)
+        out = np.zeros(max(len(k), 1), np.uint8) if outlier is None else np.ascontiguousarray(outlier, np.uint8).copy()
+        n = np.zeros(max(P, 1), np.int32)
+        self._check(self.L.orbfe_pose_optimization_batch(self.h, P, _p(off), _p(T), _p(k), _p(ur), _p(hp), _p(X), _p(out), _p(n)))
+        return T, out[: len(k)].copy(), n[:P].copy()
 
     def search_for_initialization(self, view1, view2, prev_matched, window_size, nnratio, check_ori):
         pm = np.ascontiguousarray(prev_matched, np.float32).copy()

@@ -62,6 +62,7 @@ struct orbfe_context {
     std::vector<void *> allocs;
     orbfe_match_state *match = nullptr;
     orbfe_bow_state *bow = nullptr;
+    orbfe_pose_state *pose = nullptr;
     char err[512];
 };
 
@@ -97,6 +98,12 @@ hipStream_t orbfe_ctx_stream(orbfe_context *ctx) { return ctx->stream; }
 int orbfe_ctx_device(const orbfe_context *ctx) { return ctx->params.device; }
 const orbfe_params *orbfe_ctx_params(const orbfe_context *ctx) { return &ctx->params; }
 const float *orbfe_ctx_scale_factors(const orbfe_context *ctx) { return ctx->scale; }
+const float *orbfe_ctx_inv_sigma2(const orbfe_context *ctx) { return ctx->inv_sigma2; }
+orbfe_pose_state *orbfe_ctx_pose_state(orbfe_context *ctx)
+{
+    if (!ctx->pose) ctx->pose = orbfe_pose_state_create();
+    return ctx->pose;
+}
 orbfe_bow_state *orbfe_ctx_bow_state(orbfe_context *ctx)
 {
     if (!ctx->bow) ctx->bow = orbfe_bow_state_create();
@@ -536,6 +543,7 @@ extern "C" void orbfe_destroy(orbfe_context *ctx)
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->match) orbfe_match_state_destroy(ctx->match);
     if (ctx->bow) orbfe_bow_state_destroy(ctx->bow);
+    if (ctx->pose) orbfe_pose_state_destroy(ctx->pose);
     if (ctx->d_depth_in) hipFree(ctx->d_depth_in);
     if (ctx->h_in) hipHostFree(ctx->h_in);
     if (ctx->h_depth_in) hipHostFree(ctx->h_depth_in);

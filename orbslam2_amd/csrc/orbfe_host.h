@@ -18,3 +18,9 @@ struct orbfe_bow_state;
 orbfe_bow_state *orbfe_bow_state_create();
 void orbfe_bow_state_destroy(orbfe_bow_state *s);
 orbfe_bow_state *orbfe_ctx_bow_state(orbfe_context *ctx);
+
+struct orbfe_pose_state;
+orbfe_pose_state *orbfe_pose_state_create();
+void orbfe_pose_state_destroy(orbfe_pose_state *s);
+orbfe_pose_state *orbfe_ctx_pose_state(orbfe_context *ctx);
+const float *orbfe_ctx_inv_sigma2(const orbfe_context *ctx);

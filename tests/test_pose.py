@@ -1,0 +1,177 @@
+"""Optimizer::PoseOptimization (src/Optimizer.cc:283-495).
+
+CPU part: first-principles known answers for the oracle restatement (oracle/orb_oracle_pose.c) -- a synthetic scene with
+a known camera pose must be recovered, gross outliers must be flagged, the degenerate cases must follow the reference.
+GPU part: the HIP kernel (orbslam2_amd/csrc/orbfe_pose.hip, through the C ABI) against the oracle.  The arithmetic is
+FP64 on both sides but the normal equations are summed in a different order (block tree vs edge order), so the poses are
+compared with a tolerance: 2e-6 absolute on the float32 pose entries (rotation entries are <= 1, translations here are
+below 1 m) -- the outlier flags and the inlier count are integers and must be equal.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+CAM = dict(fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, bf=386.1448)
+INV_SIGMA2 = (1.0 / (np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2).astype(np.float32)
+POSE_ATOL = 2e-6
+
+
+def _rot(rv):
+    th = np.linalg.norm(rv)
+    k = rv / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def scene(seed, n=1500, mono_frac=0.3, bad_frac=0.15, has_frac=0.8, noise_px=0.5, rv=(0.01, -0.03, 0.005), t=(0.12, -0.02, -0.55)):
+    """Points in front of a camera at pose (R|t); observations with level-scaled noise; a fraction gross outliers."""
+    rng = np.random.default_rng(seed)
+    R, t = _rot(np.array(rv)), np.array(t)
+    Xc = np.stack([rng.uniform(-20, 20, n), rng.uniform(-4, 3, n), rng.uniform(4, 60, n)], 1)
+    Xw = (Xc - t) @ R
+    u = CAM["fx"] * Xc[:, 0] / Xc[:, 2] + CAM["cx"]
+    v = CAM["fy"] * Xc[:, 1] / Xc[:, 2] + CAM["cy"]
+    ur = u - CAM["bf"] / Xc[:, 2]
+    lvl = rng.integers(0, 8, n)
+    nz = rng.normal(0, noise_px, (n, 3)) * (1.2 ** lvl)[:, None]
+    u, v, ur = u + nz[:, 0], v + nz[:, 1], ur + nz[:, 2]
+    mono = (rng.random(n) < mono_frac) | (ur < 0)  # a negative uRight means "no stereo observation" (src/Optimizer.cc:328)
+    ur = np.where(mono, -1.0, ur)
+    bad = rng.random(n) < bad_frac
+    u = u + np.where(bad, rng.uniform(20, 40, n) * rng.choice([-1, 1], n), 0)
+    keys = np.zeros(n, O.KP_DTYPE)
+    keys["x"], keys["y"], keys["octave"] = u, v, lvl
+    has = (rng.random(n) < has_frac).astype(np.uint8)
+    Ttrue = np.eye(4)
+    Ttrue[:3, :3], Ttrue[:3, 3] = R, t
+    return dict(keys=keys, ur=ur.astype(np.float32), has=has, Xw=Xw.astype(np.float32), bad=bad, T=Ttrue)
+
+
+def _oracle(s, T0, outlier=None):
+    return O.pose_optimization(T0, s["keys"], s["ur"], s["has"], s["Xw"], INV_SIGMA2, CAM["fx"], CAM["fy"], CAM["cx"], CAM["cy"], CAM["bf"], outlier)
+
+
+# ---------------------------------------------------------------- oracle known answers (CPU)
+
+def test_oracle_recovers_noiseless_pose_from_identity():
+    s = scene(1, noise_px=0.0, bad_frac=0.0)
+    T, out, n = _oracle(s, np.eye(4, dtype=np.float32))
+    assert n == int(s["has"].sum()) and out.sum() == 0
+    assert np.abs(T - s["T"]).max() < 2e-5  # float32 inputs (points, observations) bound the accuracy
+
+
+def test_oracle_flags_gross_outliers_and_keeps_pose():
+    s = scene(2)
+    T, out, n = _oracle(s, np.eye(4, dtype=np.float32))
+    has = s["has"] > 0
+    assert (out[has & s["bad"]] == 1).all()               # 20-40 px at sigma <= 2.5 px: chi2 far above 7.815
+    assert (out[has & ~s["bad"]] == 1).mean() < 0.05      # chi2(3 dof) > 7.815 happens for 5 % of honest edges at most
+    assert (out[~has] == 0).all()
+    assert n == int(has.sum()) - int(out.sum())
+    assert np.abs(T[:3, 3] - s["T"][:3, 3]).max() < 5e-3 and np.abs(T[:3, :3] - s["T"][:3, :3]).max() < 5e-4
+
+
+def test_oracle_degenerate_cases():
+    s = scene(3, n=40)
+    T0 = np.eye(4, dtype=np.float32)
+    s2 = dict(s, has=np.zeros(40, np.uint8))
+    s2["has"][[3, 17]] = 1
+    pre = np.full(40, 7, np.uint8)
+    T, out, n = _oracle(s2, T0, pre)
+    assert n == 0 and np.array_equal(T, T0)               # < 3 correspondences: return 0 before SetPose (:404-405)
+    assert out[3] == 0 and out[17] == 0 and (np.delete(out, [3, 17]) == 7).all()  # mvbOutlier cleared only where a point exists
+    s3 = dict(s, has=np.zeros(40, np.uint8))
+    s3["has"][:8] = 1                                     # < 10 edges: a single round (:457-458), still a valid pose
+    s3["bad"][:] = False
+    T, out, n = _oracle(scene(3, n=40, bad_frac=0.0, has_frac=1.0) | dict(has=s3["has"]), T0)
+    assert 0 < n <= 8 and np.isfinite(T).all() and abs(np.linalg.det(T[:3, :3].astype(np.float64)) - 1) < 1e-5
+
+
+def test_oracle_restarts_every_round_from_the_input_pose():
+    """vSE3->setEstimate(mTcw) at the top of each of the 4 rounds (:398): a good start and a poor start reach the same
+    optimum, and a start AT the optimum stays there."""
+    s = scene(4, noise_px=0.3, bad_frac=0.1)
+    Ta, oa, na = _oracle(s, np.eye(4, dtype=np.float32))
+    Tb, ob, nb = _oracle(s, Ta)
+    assert np.abs(Ta - Tb).max() < 1e-4 and na == nb and np.array_equal(oa, ob)
+
+
+# ---------------------------------------------------------------- HIP == oracle (GPU)
+
+def _ctx():
+    from orbslam2_amd import api
+    return api.Context(width=1241, height=376, nfeatures=2000, max_images=1, **CAM)
+
+
+def _compare(ctx, s, T0, outlier=None):
+    Tr, outr, nr = _oracle(s, T0, outlier)
+    Tg, outg, ng = ctx.pose_optimization(T0, s["keys"], s["ur"], s["has"], s["Xw"], outlier)
+    assert ng == nr, (ng, nr)
+    assert np.array_equal(outg, outr), np.nonzero(outg != outr)[0][:10]
+    assert np.abs(Tg - Tr).max() <= POSE_ATOL, np.abs(Tg - Tr).max()
+    return Tg, outg, ng
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,kw", [
+    (11, {}),
+    (12, dict(mono_frac=1.0)),                       # monocular: 2-d edges only
+    (13, dict(mono_frac=0.0)),                       # stereo / RGB-D: 3-d edges only
+    (14, dict(n=300, bad_frac=0.4)),                 # heavy contamination
+    (15, dict(n=4000, has_frac=0.5)),
+    (16, dict(n=64, bad_frac=0.0, noise_px=0.0)),
+    (17, dict(rv=(0.2, -0.1, 0.15), t=(0.8, -0.3, 0.9))),  # far from the identity start: rejected trials, lambda growth
+])
+def test_gpu_pose_optimization_matches_oracle(seed, kw):
+    ctx = _ctx()
+    s = scene(seed, **kw)
+    T, out, n = _compare(ctx, s, np.eye(4, dtype=np.float32))
+    assert n >= 3
+    # restart at the optimum
+    _compare(ctx, s, T)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_pose_optimization_degenerate_and_flags():
+    ctx = _ctx()
+    s = scene(3, n=40)
+    T0 = np.eye(4, dtype=np.float32)
+    two = dict(s, has=np.zeros(40, np.uint8))
+    two["has"][[3, 17]] = 1
+    _compare(ctx, two, T0, np.full(40, 7, np.uint8))
+    few = scene(3, n=40, bad_frac=0.0, has_frac=1.0)
+    few["has"][8:] = 0
+    _compare(ctx, few, T0)
+    none = dict(s, has=np.zeros(40, np.uint8))
+    _compare(ctx, none, T0, np.full(40, 1, np.uint8))
+    empty = dict(keys=s["keys"][:0], ur=s["ur"][:0], has=s["has"][:0], Xw=s["Xw"][:0])
+    T, out, n = ctx.pose_optimization(T0, empty["keys"], empty["ur"], empty["has"], empty["Xw"])
+    assert n == 0 and np.array_equal(T, T0) and len(out) == 0
+    from orbslam2_amd import api
+    bad = scene(5, n=20)
+    bad["keys"]["octave"][4] = 9
+    bad["has"][4] = 1
+    with pytest.raises(api.OrbfeError):
+        ctx.pose_optimization(T0, bad["keys"], bad["ur"], bad["has"], bad["Xw"])
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_pose_optimization_batch_is_per_problem():
+    """One workgroup per problem: a batch of differently sized problems equals the problems run one by one (bit for bit
+    -- same kernel, same reduction tree) and the oracle (tolerance)."""
+    ctx = _ctx()
+    scenes = [scene(30 + k, n=n) for k, n in enumerate([900, 5, 1500, 0, 257, 2000, 64])]
+    off = np.cumsum([0] + [len(s["keys"]) for s in scenes]).astype(np.int32)
+    cat = {k: np.concatenate([s[k] for s in scenes]) for k in ("keys", "ur", "has", "Xw")}
+    T0 = np.tile(np.eye(4, dtype=np.float32), (len(scenes), 1, 1))
+    T0[2, :3, 3] = [0.05, 0.0, -0.2]
+    Tb, outb, nb = ctx.pose_optimization_batch(T0, off, cat["keys"], cat["ur"], cat["has"], cat["Xw"])
+    for k, s in enumerate(scenes):
+        Tg, outg, ng = ctx.pose_optimization(T0[k], s["keys"], s["ur"], s["has"], s["Xw"])
+        assert np.array_equal(Tg, Tb[k]) and ng == nb[k] and np.array_equal(outg, outb[off[k]:off[k + 1]])
+        Tr, outr, nr = _oracle(s, T0[k])
+        assert nr == nb[k] and np.array_equal(outr, outb[off[k]:off[k + 1]]) and np.abs(Tr - Tb[k]).max() <= POSE_ATOL
+    ctx.close()
