@@ -334,10 +334,13 @@ int orbfe_pose_optimization(orbfe_context *ctx, float *Tcw, int n, const orbfe_k
 int orbfe_pose_optimization_batch(orbfe_context *ctx, int n_problems, const int32_t *offsets, float *Tcw,
                                   const orbfe_keypoint *keys_un, const float *u_right, const uint8_t *has_point,
                                   const float *Xw, uint8_t *outlier, int32_t *n_inliers);
-/* The same on device-resident arrays, asynchronous on `stream` (NULL: the context's stream). */
+/* The same on device-resident arrays, asynchronous on `stream` (NULL: the context's stream).  max_keypoints = an upper
+ * bound of offsets[k + 1] - offsets[k] (the host cannot see the device-resident offsets; it selects the kernel variant
+ * that keeps each problem's edges in LDS). */
 int orbfe_enqueue_pose_optimization(orbfe_context *ctx, int n_problems, const int32_t *d_offsets,
                                     const orbfe_keypoint *d_keys_un, const float *d_u_right, const uint8_t *d_has_point,
-                                    const float *d_Xw, float *d_Tcw, uint8_t *d_outlier, int32_t *d_n_inliers, void *stream);
+                                    const float *d_Xw, float *d_Tcw, uint8_t *d_outlier, int32_t *d_n_inliers,
+                                    int max_keypoints, void *stream);
 /* ORBmatcher::SearchByFboW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12) (src/ORBmatcher.cc:517-650; LoopClosing and
  * relocalisation).  valid1 / valid2 = the keypoint has a map point that is not bad.  match12[i1] receives the KF2
  * keypoint whose map point KF1 keypoint i1 got, or -1 (n1 entries). */

@@ -239,9 +239,13 @@ static void huber(const pose_edge *e, double chi, double rho[3])
     }
 }
 
+static int g_eval_count; /* diagnostic: computeActiveErrors calls of the last orc_pose_optimization */
+int orc_pose_eval_count(void) { return g_eval_count; }
+
 static double active_errors_and_chi(pose_edge *E, int ne, const se3q *est, const cam_d *c)
 {
     double chi = 0.0;
+    g_eval_count++;
     for (int k = 0; k < ne; k++) {
         if (E[k].level != 0) continue;
         edge_compute_error(&E[k], est, c);
@@ -371,6 +375,7 @@ int orc_pose_optimization(float *Tcw, int N, const orc_keypoint *keys_un, const 
                           uint8_t *outlier)
 {
     pose_edge *E = (pose_edge *)calloc((size_t)(N > 0 ? N : 1), sizeof(pose_edge));
+    g_eval_count = 0;
     const float delta_mono = (float)sqrt(5.991), delta_stereo = (float)sqrt(7.815);
     int ne = 0;
     for (int i = 0; i < N; i++) {

@@ -139,7 +139,7 @@ def load():
     L.orbfe_pose_optimization_batch.restype = C.c_int
     L.orbfe_pose_optimization_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     L.orbfe_enqueue_pose_optimization.restype = C.c_int
-    L.orbfe_enqueue_pose_optimization.argtypes = [vp, C.c_int] + [vp] * 9
+    L.orbfe_enqueue_pose_optimization.argtypes = [vp, C.c_int] + [vp] * 8 + [C.c_int, vp]
     L.orbfe_search_for_initialization.restype = C.c_int
     L.orbfe_search_for_initialization.argtypes = [vp, fvp, fvp, vp, C.c_int, C.c_float, C.c_int, vp, ip]
     _lib = L

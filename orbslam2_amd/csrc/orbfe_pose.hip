@@ -21,6 +21,7 @@
 //                the do/while         = OptimizationAlgorithmLevenberg::solve
 //                                       (core/optimization_algorithm_levenberg.cpp:59-157)
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cfloat>
 #include <cstdint>
 #include <cstring>
@@ -28,11 +29,13 @@
 #include "orbfe_device.h"
 #include "orbfe_host.h"
 
+// Contract Q4 (no FMA) governs the bit-exact integer / float stages; this stage is FP64 and compared with a tolerance, so
+// fused multiply-adds are allowed here: half the instructions in the per-edge products, one rounding less each.
+#pragma clang fp contract(fast)
+
 namespace {
 
-constexpr int PO_THREADS = 256;
-constexpr int PO_WAVES = PO_THREADS / 64;
-constexpr int PO_NV = 29; // 21 (upper triangle of H) + 6 (b) + chi + active count
+constexpr int PO_THREADS = 256; // one wave per SIMD (512 threads measured slower: every wave repeats the per-trial serial part)
 
 struct Se3 { double x, y, z, w, t[3]; };
 struct CamD { double fx, fy, cx, cy, bf; };
@@ -175,10 +178,78 @@ __device__ inline void se3_to_cv(const Se3 &q, float *T) // Converter::toCvMat(S
     T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
 }
 
-// LDLT with diagonal pivoting; returns isPositive().  x is left untouched when the factor is not positive.
-__device__ inline bool solve_ldlt6(const double *Hu /*21, upper triangle row-major*/, double lambda, const double *b, double *x)
+// Symmetric exchange of rows / columns K and C of a register-resident 6x6 matrix (compile-time indices only).
+template <int K, int C>
+__device__ __forceinline__ void sym_swap(double (&A)[6][6], double (&y)[6])
 {
-    double A[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) { const double t = A[K][j]; A[K][j] = A[C][j]; A[C][j] = t; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) { const double t = A[i][K]; A[i][K] = A[i][C]; A[i][C] = t; }
+    const double t = y[K]; y[K] = y[C]; y[C] = t;
+}
+
+// (Eigen divides the sub-column and the solve's D^-1 step by the pivot; here the pivot's reciprocal is formed once and
+// multiplied in -- 6 divisions per solve instead of 21, a last-bit difference that the tolerance of this stage covers.)
+template <int K>
+__device__ __forceinline__ void ldlt_step(double (&A)[6][6], double (&y)[6], double (&dinv)[6], int (&perm)[6], bool &positive)
+{
+    // largest remaining diagonal entry, first one wins (Eigen: maxCoeff over the tail of the diagonal)
+    int p = K;
+    double big = fabs(A[K][K]);
+#pragma unroll
+    for (int i = K + 1; i < 6; i++)
+        if (fabs(A[i][i]) > big) { big = fabs(A[i][i]); p = i; }
+    p = __builtin_amdgcn_readfirstlane(p); // the matrix is the same in every lane: a scalar branch, no dynamic register indexing
+    perm[K] = p;
+    // the right-hand side is permuted along (P b), which is what the forward substitution consumes
+    if constexpr (K < 5) {
+        switch (p) {
+        case 1: if constexpr (K < 1) sym_swap<K, 1>(A, y); break;
+        case 2: if constexpr (K < 2) sym_swap<K, 2>(A, y); break;
+        case 3: if constexpr (K < 3) sym_swap<K, 3>(A, y); break;
+        case 4: if constexpr (K < 4) sym_swap<K, 4>(A, y); break;
+        case 5: sym_swap<K, 5>(A, y); break;
+        default: break;
+        }
+    }
+    double d = A[K][K];
+#pragma unroll
+    for (int j = 0; j < K; j++) d -= A[K][j] * A[K][j] * A[j][j];
+    A[K][K] = d;
+    if (d < 0) positive = false;
+    const double di = (fabs(d) > DBL_MIN) ? 1.0 / d : 0.0;
+    dinv[K] = di;
+#pragma unroll
+    for (int i = K + 1; i < 6; i++) {
+        double sacc = A[i][K];
+#pragma unroll
+        for (int j = 0; j < K; j++) sacc -= A[i][j] * A[K][j] * A[j][j];
+        A[i][K] = sacc * di;
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void unpermute_step(double (&y)[6], const int (&perm)[6])
+{
+    if constexpr (K < 5) {
+        double t;
+        switch (perm[K]) { // scalar (readfirstlane'd above)
+        case 1: if constexpr (K < 1) { t = y[K]; y[K] = y[1]; y[1] = t; } break;
+        case 2: if constexpr (K < 2) { t = y[K]; y[K] = y[2]; y[2] = t; } break;
+        case 3: if constexpr (K < 3) { t = y[K]; y[K] = y[3]; y[3] = t; } break;
+        case 4: if constexpr (K < 4) { t = y[K]; y[K] = y[4]; y[4] = t; } break;
+        case 5: t = y[K]; y[K] = y[5]; y[5] = t; break;
+        default: break;
+        }
+    }
+}
+
+// LDLT with diagonal pivoting (Eigen::LDLT as LinearSolverDense uses it); returns isPositive().  x is left untouched
+// when the factor is not positive.  Everything is indexed at compile time so the matrix stays in registers.
+__device__ inline bool solve_ldlt6(const double *Hu /*21, upper triangle row-major, then b[6]*/, double lambda, double *x)
+{
+    double A[6][6], y[6];
     {
         int k = 0;
 #pragma unroll
@@ -186,103 +257,187 @@ __device__ inline bool solve_ldlt6(const double *Hu /*21, upper triangle row-maj
 #pragma unroll
             for (int j = i; j < 6; j++) { A[i][j] = Hu[k]; A[j][i] = Hu[k]; k++; }
 #pragma unroll
-        for (int i = 0; i < 6; i++) A[i][i] += lambda;
+        for (int i = 0; i < 6; i++) { A[i][i] += lambda; y[i] = Hu[21 + i]; }
     }
-    int perm[6];
+    int perm[6] = {0, 1, 2, 3, 4, 5};
+    double dinv[6];
     bool positive = true;
-    for (int k = 0; k < 6; k++) {
-        int p = k;
-        double big = fabs(A[k][k]);
-        for (int i = k + 1; i < 6; i++)
-            if (fabs(A[i][i]) > big) { big = fabs(A[i][i]); p = i; }
-        perm[k] = p;
-        if (p != k) {
-            for (int j = 0; j < 6; j++) { const double t = A[k][j]; A[k][j] = A[p][j]; A[p][j] = t; }
-            for (int i = 0; i < 6; i++) { const double t = A[i][k]; A[i][k] = A[i][p]; A[i][p] = t; }
-        }
-        double d = A[k][k];
-        for (int j = 0; j < k; j++) d -= A[k][j] * A[k][j] * A[j][j];
-        A[k][k] = d;
-        if (d < 0) positive = false;
-        for (int i = k + 1; i < 6; i++) {
-            double s = A[i][k];
-            for (int j = 0; j < k; j++) s -= A[i][j] * A[k][j] * A[j][j];
-            A[i][k] = (fabs(d) > DBL_MIN) ? s / d : 0.0;
-        }
-    }
+    ldlt_step<0>(A, y, dinv, perm, positive);
+    ldlt_step<1>(A, y, dinv, perm, positive);
+    ldlt_step<2>(A, y, dinv, perm, positive);
+    ldlt_step<3>(A, y, dinv, perm, positive);
+    ldlt_step<4>(A, y, dinv, perm, positive);
+    ldlt_step<5>(A, y, dinv, perm, positive);
     if (!positive) return false;
-    double y[6];
-    for (int i = 0; i < 6; i++) y[i] = b[i];
-    for (int k = 0; k < 6; k++) if (perm[k] != k) { const double t = y[k]; y[k] = y[perm[k]]; y[perm[k]] = t; }
+#pragma unroll
     for (int i = 0; i < 6; i++)
+#pragma unroll
         for (int j = 0; j < i; j++) y[i] -= A[i][j] * y[j];
-    for (int i = 0; i < 6; i++) y[i] = (fabs(A[i][i]) > DBL_MIN) ? y[i] / A[i][i] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) y[i] *= dinv[i];
+#pragma unroll
     for (int i = 5; i >= 0; i--)
+#pragma unroll
         for (int j = i + 1; j < 6; j++) y[i] -= A[j][i] * y[j];
-    for (int k = 5; k >= 0; k--) if (perm[k] != k) { const double t = y[k]; y[k] = y[perm[k]]; y[perm[k]] = t; }
+    unpermute_step<4>(y, perm);
+    unpermute_step<3>(y, perm);
+    unpermute_step<2>(y, perm);
+    unpermute_step<1>(y, perm);
+    unpermute_step<0>(y, perm);
+#pragma unroll
     for (int i = 0; i < 6; i++) x[i] = y[i];
     return true;
 }
 
-struct Problem {
+// Per-problem edge table.  EDGES_IN_LDS: seven floats and a state byte per keypoint slot staged once (Xw, observation,
+// information); otherwise the caller's arrays are re-read on every pass (frames with more slots than the LDS holds).
+// state: 0 = no map point, 1 = inlier (level 0), 2 = outlier (level 1).
+struct EdgeTable {
     const KeyPointPOD *keys;
     const float *u_right;
     const uint8_t *has_point;
     const float *Xw;
     uint8_t *outlier;
-    int n;
+    const float *inv_sigma2;
+    float *l_f;      // [7][cap]
+    uint8_t *l_st;   // [cap]
+    int n, cap;
 };
 
-// error vector of one edge at pose q (computeError of the two OnlyPose edges); returns chi2 (BaseEdge::chi2)
-__device__ inline double edge_error(const Se3 &q, const CamD &c, const double Xw[3], const double obs[3], bool stereo, double info,
-                                    double err[3], double p[3])
+template <bool IN_LDS>
+__device__ __forceinline__ int edge_state(const EdgeTable &E, int i)
 {
-    se3_map(q, Xw, p);
-    if (!stereo) {
-        const double u = p[0] / p[2], v = p[1] / p[2];
-        err[0] = obs[0] - (u * c.fx + c.cx);
-        err[1] = obs[1] - (v * c.fy + c.cy);
-        err[2] = 0.0;
-        return err[0] * (info * err[0]) + err[1] * (info * err[1]);
-    }
-    const double invz = (double)(float)(1.0 / p[2]); // `const float invz = 1.0f/trans_xyz[2]`, types_six_dof_expmap.cpp:300
-    const double r0 = p[0] * invz * c.fx + c.cx, r1 = p[1] * invz * c.fy + c.cy, r2 = r0 - c.bf * invz;
-    err[0] = obs[0] - r0;
-    err[1] = obs[1] - r1;
-    err[2] = obs[2] - r2;
-    return err[0] * (info * err[0]) + err[1] * (info * err[1]) + err[2] * (info * err[2]);
+    if constexpr (IN_LDS) return E.l_st[i];
+    else return E.has_point[i] ? (E.outlier[i] ? 2 : 1) : 0;
 }
 
-// One pass over the active edges at pose q: sums[0..20] = H (upper), [21..26] = b, [27] = robust chi2, [28] = #active.
-// Every lane returns the same totals.
-__device__ void eval_pass(const Problem &P, const Se3 &q, const CamD &c, const float *inv_sigma2, bool robust,
-                          double delta_mono, double delta_stereo, double (*part)[PO_NV], double *sums)
+template <bool IN_LDS>
+__device__ __forceinline__ void edge_set_outlier(const EdgeTable &E, int i, bool out)
 {
-    double acc[PO_NV];
+    if constexpr (IN_LDS) E.l_st[i] = out ? 2 : 1;
+    else E.outlier[i] = out ? 1 : 0;
+}
+
+template <bool IN_LDS>
+__device__ __forceinline__ void edge_load(const EdgeTable &E, int i, double Xw[3], double obs[3], bool &stereo, double &info)
+{
+    float f[7];
+    if constexpr (IN_LDS) {
 #pragma unroll
-    for (int k = 0; k < PO_NV; k++) acc[k] = 0.0;
-    for (int i = threadIdx.x; i < P.n; i += PO_THREADS) {
-        if (!P.has_point[i] || P.outlier[i]) continue;
-        const KeyPointPOD kp = P.keys[i];
-        const float ur = P.u_right[i];
-        const bool stereo = !(ur < 0);
-        const double info = (double)inv_sigma2[kp.octave];
-        const double Xw[3] = {(double)P.Xw[3 * (size_t)i], (double)P.Xw[3 * (size_t)i + 1], (double)P.Xw[3 * (size_t)i + 2]};
-        const double obs[3] = {(double)kp.x, (double)kp.y, stereo ? (double)ur : 0.0};
-        double err[3], p[3];
-        const double chi = edge_error(q, c, Xw, obs, stereo, info, err, p);
+        for (int k = 0; k < 7; k++) f[k] = E.l_f[k * E.cap + i];
+    } else {
+        const KeyPointPOD kp = E.keys[i];
+        f[0] = E.Xw[3 * (size_t)i]; f[1] = E.Xw[3 * (size_t)i + 1]; f[2] = E.Xw[3 * (size_t)i + 2];
+        f[3] = kp.x; f[4] = kp.y; f[5] = E.u_right[i]; f[6] = E.inv_sigma2[kp.octave];
+    }
+    stereo = !(f[5] < 0);
+    Xw[0] = (double)f[0]; Xw[1] = (double)f[1]; Xw[2] = (double)f[2];
+    obs[0] = (double)f[3]; obs[1] = (double)f[4]; obs[2] = stereo ? (double)f[5] : 0.0;
+    info = (double)f[6];
+}
+
+// error vector of one edge at pose q (computeError of the two OnlyPose edges); returns chi2 (BaseEdge::chi2)
+__device__ __forceinline__ double edge_error(const Se3 &q, const CamD &c, const double Xw[3], const double obs[3], bool stereo, double info,
+                                             double err[3], double p[3], double *invz_out = nullptr)
+{
+    se3_map(q, Xw, p);
+    // mono: project2d then fx, cx (types_six_dof_expmap.cpp:290-296); stereo: `const float invz = 1.0f/trans_xyz[2]` (:299-306).
+    // One division per edge: the mono path multiplies by 1/z where the reference divides by z (last-bit difference).
+    const double invz = 1.0 / p[2];
+    const double iz = stereo ? (double)(float)invz : invz;
+    const double r0 = p[0] * iz * c.fx + c.cx;
+    const double r1 = p[1] * iz * c.fy + c.cy;
+    const double invz_s = iz;
+    err[0] = obs[0] - r0;
+    err[1] = obs[1] - r1;
+    err[2] = stereo ? obs[2] - (r0 - c.bf * invz_s) : 0.0;
+    double chi = err[0] * (info * err[0]) + err[1] * (info * err[1]);
+    if (stereo) chi += err[2] * (info * err[2]);
+    if (invz_out) *invz_out = invz;
+    return chi;
+}
+
+// lane i of each 16-lane row exchanges with lane i ^ m (m = 8: row_mirror then half mirror ... see below)
+__device__ __forceinline__ double dpp_f64(double v, const int ctrl_sel)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    switch (ctrl_sel) {
+    case 0: lo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xf, 0xf, true); break; // row_mirror: i <-> 15 - i
+    case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xf, 0xf, true); break; // row_half_mirror: i <-> 7 - i
+    case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, true); break;   // quad_perm [2,3,0,1]
+    default: lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, true); break;  // quad_perm [1,0,3,2]
+    }
+    return __hiloint2double(hi, lo);
+}
+
+// Transposing reduction inside each 16-lane row: at every step a lane keeps one value of each pair (chosen by one bit of
+// its lane id), sends the other to its partner and adds what it receives.  32 values in, 2 out per lane, each the sum of
+// that value over the 16 lanes: 16 + 8 + 4 + 2 exchanges instead of 4 per value.  Fixed order: bit-reproducible.
+template <int NIN, int STEP>
+__device__ __forceinline__ void row_transpose_step(double *v, bool upper)
+{
+#pragma unroll
+    for (int k = 0; k < NIN / 2; k++) {
+        const double keep = upper ? v[2 * k + 1] : v[2 * k], give = upper ? v[2 * k] : v[2 * k + 1];
+        v[k] = keep + dpp_f64(give, STEP);
+    }
+}
+
+// One pass over the active edges at pose q: s_tot[0..20] = H (upper), [21..26] = b, [27] = robust chi2, [28] = #active,
+// left in LDS (the 6x6 solve reads them from there: they are the same for every lane and would cost 58 registers);
+// chi2 and the count are returned.  Costs two barriers.
+// sum over the three residual rows of (J^T W)[a][d] * J[d][b], skipping the rows whose entry in column a or b is
+// structurally zero (row 0 and row 2: column 4; row 1: column 3)
+template <int A, int B>
+__device__ __forceinline__ double h_term(const double (&jw)[3][6], const double (&J)[3][6])
+{
+    constexpr bool r02 = (A != 4 && B != 4), r1 = (A != 3 && B != 3);
+    if constexpr (r02 && r1) return jw[0][A] * J[0][B] + jw[1][A] * J[1][B] + jw[2][A] * J[2][B];
+    else if constexpr (r02) return jw[0][A] * J[0][B] + jw[2][A] * J[2][B];
+    else if constexpr (r1) return jw[1][A] * J[1][B];
+    else return 0.0;
+}
+
+#ifdef ORBFE_POSE_TIMING
+__device__ long long g_pose_cycles[8]; // [0] solve [1] exp+mul [2] edge loop [3] reduction [4] passes
+#define PO_T(var) const long long var = clock64()
+#define PO_ACC(slot, a, b) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_pose_cycles[slot] += (b) - (a); } while (0)
+#else
+#define PO_T(var)
+#define PO_ACC(slot, a, b)
+#endif
+
+template <int THREADS, bool IN_LDS>
+__device__ void eval_pass(const EdgeTable &E, const Se3 &q, const CamD &c, bool robust, double delta_mono, double delta_stereo,
+                          double *s_rows /*[THREADS/16][32]*/, double *s_tot /*[32]*/, double &chi_out, double &cnt_out)
+{
+    double acc[32];
+    PO_T(t_e0);
+#pragma unroll
+    for (int k = 0; k < 32; k++) acc[k] = 0.0;
+    for (int i = threadIdx.x; i < E.n; i += THREADS) {
+        if (edge_state<IN_LDS>(E, i) != 1) continue;
+        double Xw[3], obs[3], info, err[3], p[3];
+        bool stereo;
+        edge_load<IN_LDS>(E, i, Xw, obs, stereo, info);
+        double invz;
+        const double chi = edge_error(q, c, Xw, obs, stereo, info, err, p, &invz);
         double w = 1.0, rho0 = chi;
         if (robust) { // RobustKernelHuber::robustify, core/robust_kernel_impl.cpp:78-91
             const double delta = stereo ? delta_stereo : delta_mono, dsqr = delta * delta;
             if (chi > dsqr) {
-                const double s = sqrt(chi);
-                rho0 = 2 * s * delta - dsqr;
-                w = delta / s;
+                // 1/sqrt(chi): hardware estimate + two Newton steps (relative error below 1e-15) instead of an IEEE sqrt
+                // followed by an IEEE division
+                double rs = __builtin_amdgcn_rsq(chi);
+                rs = rs * (1.5 - 0.5 * chi * rs * rs);
+                rs = rs * (1.5 - 0.5 * chi * rs * rs);
+                rho0 = 2 * (chi * rs) * delta - dsqr;
+                w = delta * rs;
             }
         }
         acc[27] += rho0;
         acc[28] += 1.0;
-        const double x = p[0], y = p[1], invz = 1.0 / p[2], invz_2 = invz * invz;
+        const double x = p[0], y = p[1], invz_2 = invz * invz;
         double J[3][6];
         J[0][0] = x * y * invz_2 * c.fx;
         J[0][1] = -(1 + (x * x * invz_2)) * c.fx;
@@ -303,101 +458,139 @@ __device__ void eval_pass(const Problem &P, const Se3 &q, const CamD &c, const f
         J[2][4] = 0.0;
         J[2][5] = stereo ? J[0][5] - c.bf * invz_2 : 0.0;
         const double wi = w * info; // robustInformation: rho[1] * _information (core/base_edge.h:96-102)
-        int k = 0;
+        const double we[3] = {wi * err[0], wi * err[1], wi * err[2]};
+        // J[0][4], J[1][3] and J[2][4] are structurally zero: their products are left out (they would add exact zeros)
+        double jw[3][6];
 #pragma unroll
-        for (int a = 0; a < 6; a++) {
-            acc[21 + a] -= (w * J[0][a]) * info * err[0] + (w * J[1][a]) * info * err[1] + (w * J[2][a]) * info * err[2];
+        for (int a = 0; a < 6; a++) { jw[0][a] = J[0][a] * wi; jw[1][a] = J[1][a] * wi; jw[2][a] = J[2][a] * wi; }
+#define PO_H(k, a, b) acc[k] += h_term<a, b>(jw, J)
+        PO_H(0, 0, 0); PO_H(1, 0, 1); PO_H(2, 0, 2); PO_H(3, 0, 3); PO_H(4, 0, 4); PO_H(5, 0, 5);
+        PO_H(6, 1, 1); PO_H(7, 1, 2); PO_H(8, 1, 3); PO_H(9, 1, 4); PO_H(10, 1, 5);
+        PO_H(11, 2, 2); PO_H(12, 2, 3); PO_H(13, 2, 4); PO_H(14, 2, 5);
+        PO_H(15, 3, 3); PO_H(16, 3, 4); PO_H(17, 3, 5);
+        PO_H(18, 4, 4); PO_H(19, 4, 5);
+        PO_H(20, 5, 5);
+#undef PO_H
+        acc[21] -= J[0][0] * we[0] + J[1][0] * we[1] + J[2][0] * we[2];
+        acc[22] -= J[0][1] * we[0] + J[1][1] * we[1] + J[2][1] * we[2];
+        acc[23] -= J[0][2] * we[0] + J[1][2] * we[1] + J[2][2] * we[2];
+        acc[24] -= J[0][3] * we[0] + J[2][3] * we[2];
+        acc[25] -= J[1][4] * we[1];
+        acc[26] -= J[0][5] * we[0] + J[1][5] * we[1] + J[2][5] * we[2];
+    }
+    PO_T(t_e1);
+    PO_ACC(2, t_e0, t_e1);
+    const int lane16 = threadIdx.x & 15;
+    row_transpose_step<32, 0>(acc, (lane16 & 8) != 0);
+    row_transpose_step<16, 1>(acc, (lane16 & 4) != 0);
+    row_transpose_step<8, 2>(acc, (lane16 & 2) != 0);
+    row_transpose_step<4, 3>(acc, (lane16 & 1) != 0);
+    // acc[0], acc[1] now hold the row sums of values v0 and v0 + 1 with v0 = 2 * bitreverse4(lane16)... computed below
+    {
+        const int b3 = (lane16 >> 3) & 1, b2 = (lane16 >> 2) & 1, b1 = (lane16 >> 1) & 1, b0 = lane16 & 1;
+        // step 0 kept index 2k+b3 of 32 -> k; step 1 kept 2k+b2 of 16; step 2 kept 2k+b1 of 8; step 3 kept 2k+b0 of 4 -> 2 left (k = 0, 1)
+        // original index of the value now at position k: (((k * 2 + b0) * 2 + b1) * 2 + b2) * 2 + b3
+        const int row = threadIdx.x >> 4;
 #pragma unroll
-            for (int b = a; b < 6; b++) {
-                acc[k] += (J[0][a] * wi) * J[0][b] + (J[1][a] * wi) * J[1][b] + (J[2][a] * wi) * J[2][b];
-                k++;
-            }
+        for (int k = 0; k < 2; k++) {
+            const int orig = (((k * 2 + b0) * 2 + b1) * 2 + b2) * 2 + b3;
+            s_rows[row * 32 + orig] = acc[k];
         }
     }
-    // wave reduction (fixed butterfly), then the four wave partials are added in wave order by every lane
-#pragma unroll
-    for (int k = 0; k < PO_NV; k++) {
-        double v = acc[k];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-        acc[k] = v;
-    }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane < PO_NV) {
-        double v = 0.0;
-#pragma unroll
-        for (int k = 0; k < PO_NV; k++) if (lane == k) v = acc[k];
-        part[wave][lane] = v;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double t = 0.0;
+#pragma unroll 8
+        for (int r = 0; r < THREADS / 16; r++) t += s_rows[r * 32 + threadIdx.x];
+        s_tot[threadIdx.x] = t;
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < PO_NV; k++) {
-        double v = part[0][k];
-#pragma unroll
-        for (int wv = 1; wv < PO_WAVES; wv++) v += part[wv][k];
-        sums[k] = v;
-    }
+    chi_out = s_tot[27];
+    cnt_out = s_tot[28];
+    PO_T(t_e2);
+    PO_ACC(3, t_e1, t_e2);
+    PO_ACC(4, 0, 1);
 }
 
-__global__ __launch_bounds__(PO_THREADS) void pose_opt_kernel(const int32_t *__restrict__ offsets, const KeyPointPOD *__restrict__ keys,
-                                                               const float *__restrict__ u_right, const uint8_t *__restrict__ has_point,
-                                                               const float *__restrict__ Xw, float *__restrict__ Tcw,
-                                                               uint8_t *__restrict__ outlier, int32_t *__restrict__ n_inliers,
-                                                               const float *__restrict__ inv_sigma2, float fx, float fy, float cx,
-                                                               float cy, float bf)
+template <int THREADS, bool IN_LDS>
+__global__ __launch_bounds__(THREADS) void pose_opt_kernel(const int32_t *__restrict__ offsets, const KeyPointPOD *__restrict__ keys,
+                                                            const float *__restrict__ u_right, const uint8_t *__restrict__ has_point,
+                                                            const float *__restrict__ Xw, float *__restrict__ Tcw,
+                                                            uint8_t *__restrict__ outlier, int32_t *__restrict__ n_inliers,
+                                                            const float *__restrict__ inv_sigma2, float fx, float fy, float cx,
+                                                            float cy, float bf, int lds_cap)
 {
-    __shared__ double part[2][PO_WAVES][PO_NV]; // double-buffered: one barrier per pass
+    extern __shared__ double s_dyn[];
+    double *s_rows = s_dyn;                         // [2][THREADS/16][32]  (double-buffered across passes)
+    double *s_tot = s_rows + 2 * (THREADS / 16) * 32; // [2][32]
     __shared__ int s_cnt[2];
     const int prob = blockIdx.x;
     const int o0 = offsets[prob];
-    Problem P;
-    P.n = offsets[prob + 1] - o0;
-    P.keys = keys + o0; P.u_right = u_right + o0; P.has_point = has_point + o0; P.Xw = Xw + (size_t)3 * o0; P.outlier = outlier + o0;
+    EdgeTable E;
+    E.n = offsets[prob + 1] - o0;
+    E.keys = keys + o0; E.u_right = u_right + o0; E.has_point = has_point + o0; E.Xw = Xw + (size_t)3 * o0; E.outlier = outlier + o0;
+    E.inv_sigma2 = inv_sigma2;
+    E.cap = lds_cap;
+    E.l_f = (float *)(s_tot + 2 * 32);
+    E.l_st = (uint8_t *)(E.l_f + 7 * (size_t)lds_cap);
     float *T = Tcw + (size_t)16 * prob;
     const CamD cam = {(double)fx, (double)fy, (double)cx, (double)cy, (double)bf};
     const double delta_mono = (double)(float)sqrt(5.991), delta_stereo = (double)(float)sqrt(7.815); // src/Optimizer.cc:317-318
     const float chi2_mono = 5.991f, chi2_stereo = 7.815f;                                               // :408-409
 
     // edges start as inliers (:331,362)
-    for (int i = threadIdx.x; i < P.n; i += PO_THREADS)
-        if (P.has_point[i]) P.outlier[i] = 0;
-    // (each lane only ever reads the flags it wrote: the index -> lane mapping is fixed)
+    for (int i = threadIdx.x; i < E.n; i += THREADS) {
+        const bool has = E.has_point[i] != 0;
+        if constexpr (IN_LDS) {
+            const KeyPointPOD kp = E.keys[i];
+            E.l_f[0 * E.cap + i] = E.Xw[3 * (size_t)i];
+            E.l_f[1 * E.cap + i] = E.Xw[3 * (size_t)i + 1];
+            E.l_f[2 * E.cap + i] = E.Xw[3 * (size_t)i + 2];
+            E.l_f[3 * E.cap + i] = kp.x;
+            E.l_f[4 * E.cap + i] = kp.y;
+            E.l_f[5 * E.cap + i] = E.u_right[i];
+            E.l_f[6 * E.cap + i] = has ? inv_sigma2[kp.octave] : 0.f;
+            E.l_st[i] = has ? 1 : 0;
+        } else if (has) E.outlier[i] = 0;
+    }
+    // (each lane only ever touches the slots i = lane + k * THREADS: no barrier needed for the table itself)
 
     float Tin[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) Tin[k] = T[k];
 
-    int buf = 0;
-    double S[PO_NV];
+    // s_tot[cur] holds the normal equations of the accepted estimate, s_tot[cur ^ 1] receives the trial's; s_rows toggles
+    // every pass so that a fast wave's next pass cannot overwrite partials a slow wave still sums
+    int rbuf = 0, cur = 0;
+    double chi_s, cnt_s;
     double x[6] = {0, 0, 0, 0, 0, 0};
     Se3 est = se3_from_cv(Tin), last_eval = est;
     int ne = 0, n_bad = 0;
     bool robust = true;
+#define PO_EVAL(pose, which)                                                                                                               \
+    do {                                                                                                                                   \
+        eval_pass<THREADS, IN_LDS>(E, pose, cam, robust, delta_mono, delta_stereo, s_rows + rbuf * (THREADS / 16) * 32, s_tot + (which) * 32, \
+                                   chi_s, cnt_s);                                                                                          \
+        rbuf ^= 1;                                                                                                                         \
+    } while (0)
     for (int round = 0; round < 4; round++) {
         est = se3_from_cv(Tin); // :398
-        eval_pass(P, est, cam, inv_sigma2, robust, delta_mono, delta_stereo, part[buf], S);
-        buf ^= 1;
+        PO_EVAL(est, cur);
         if (round == 0) {
-            ne = (int)S[28];
-            if (ne < 3) { // :404-405
-                if (threadIdx.x == 0) n_inliers[prob] = 0;
-                return;
-            }
+            ne = (int)cnt_s;
+            if (ne < 3) break; // :404-405
         }
-        if (S[28] > 0.0) { // otherwise optimize() returns before doing anything (no active vertex)
+        if (cnt_s > 0.0) { // otherwise optimize() returns before doing anything (no active vertex)
             last_eval = est;
-            double H[21], b[6], current_chi = S[27];
-#pragma unroll
-            for (int k = 0; k < 21; k++) H[k] = S[k];
-#pragma unroll
-            for (int k = 0; k < 6; k++) b[k] = S[21 + k];
+            double current_chi = chi_s;
             double lambda = -1.0, ni = 2.0;
             int lm_bad = 0;
             for (int it = 0; it < 10; it++) {
                 last_eval = est; // computeActiveErrors at the current estimate
                 const double ini_chi = current_chi;
+                const double *Hb = s_tot + cur * 32;
                 if (it == 0) {
-                    const double dg[6] = {H[0], H[6], H[11], H[15], H[18], H[20]};
+                    const double dg[6] = {Hb[0], Hb[6], Hb[11], Hb[15], Hb[18], Hb[20]};
                     double mx = 0.0;
 #pragma unroll
                     for (int j = 0; j < 6; j++) mx = fmax(fabs(dg[j]), mx);
@@ -408,29 +601,31 @@ __global__ __launch_bounds__(PO_THREADS) void pose_opt_kernel(const int32_t *__r
                 double rho = 0.0;
                 int qmax = 0;
                 do {
-                    const bool ok2 = solve_ldlt6(H, lambda, b, x);
-                    const Se3 trial = se3_mul(se3_exp(x), est);
-                    eval_pass(P, trial, cam, inv_sigma2, robust, delta_mono, delta_stereo, part[buf], S);
-                    buf ^= 1;
-                    last_eval = trial;
-                    const double temp_chi = ok2 ? S[27] : DBL_MAX;
-                    rho = current_chi - temp_chi;
-                    double scale = 0.0;
+                    PO_T(t_s0);
+                    const bool ok2 = solve_ldlt6(Hb, lambda, x);
+                    PO_T(t_s1);
+                    PO_ACC(0, t_s0, t_s1);
+                    double scale = 0.0; // computeScale(), with the b of the system that produced x
 #pragma unroll
-                    for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
+                    for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + Hb[21 + j]);
                     scale += 1e-3;
-                    rho /= scale;
+                    const Se3 trial = se3_mul(se3_exp(x), est);
+                    PO_T(t_s2);
+                    PO_ACC(1, t_s1, t_s2);
+                    PO_EVAL(trial, cur ^ 1);
+                    last_eval = trial;
+                    const double temp_chi = ok2 ? chi_s : DBL_MAX;
+                    rho = (current_chi - temp_chi) / scale;
                     if (rho > 0 && isfinite(temp_chi)) {
-                        double alpha = 1.0 - pow(2 * rho - 1, 3.0);
+                        const double r21 = 2 * rho - 1;
+                        double alpha = 1.0 - r21 * r21 * r21; // pow(2*rho-1, 3)
                         alpha = fmin(alpha, 2.0 / 3.0);
                         lambda *= fmax(1.0 / 3.0, alpha);
                         ni = 2;
                         current_chi = temp_chi;
                         est = trial;
-#pragma unroll
-                        for (int k = 0; k < 21; k++) H[k] = S[k];
-#pragma unroll
-                        for (int k = 0; k < 6; k++) b[k] = S[21 + k];
+                        cur ^= 1;
+                        Hb = s_tot + cur * 32;
                     } else {
                         lambda *= ni;
                         ni *= 2;
@@ -445,37 +640,48 @@ __global__ __launch_bounds__(PO_THREADS) void pose_opt_kernel(const int32_t *__r
         }
         // classification (:401-455); inliers keep the error of the last evaluated pose (Q11), outliers are recomputed
         int bad = 0;
-        for (int i = threadIdx.x; i < P.n; i += PO_THREADS) {
-            if (!P.has_point[i]) continue;
-            const KeyPointPOD kp = P.keys[i];
-            const float ur = P.u_right[i];
-            const bool stereo = !(ur < 0);
-            const double info = (double)inv_sigma2[kp.octave];
-            const double Xw3[3] = {(double)P.Xw[3 * (size_t)i], (double)P.Xw[3 * (size_t)i + 1], (double)P.Xw[3 * (size_t)i + 2]};
-            const double obs[3] = {(double)kp.x, (double)kp.y, stereo ? (double)ur : 0.0};
-            double err[3], p[3];
-            const float chi2 = (float)edge_error(P.outlier[i] ? est : last_eval, cam, Xw3, obs, stereo, info, err, p);
+        for (int i = threadIdx.x; i < E.n; i += THREADS) {
+            const int st = edge_state<IN_LDS>(E, i);
+            if (st == 0) continue;
+            double Xw3[3], obs[3], info, err[3], p[3];
+            bool stereo;
+            edge_load<IN_LDS>(E, i, Xw3, obs, stereo, info);
+            const float chi2 = (float)edge_error(st == 2 ? est : last_eval, cam, Xw3, obs, stereo, info, err, p);
             const bool out = chi2 > (stereo ? chi2_stereo : chi2_mono);
-            P.outlier[i] = out ? 1 : 0;
+            edge_set_outlier<IN_LDS>(E, i, out);
             bad += out;
         }
         if (threadIdx.x == 0) s_cnt[round & 1] = 0;
         __syncthreads();
         for (int off = 32; off >= 1; off >>= 1) bad += __shfl_xor(bad, off, 64);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt[round & 1], bad);
+        if ((threadIdx.x & 63) == 0 && bad) atomicAdd(&s_cnt[round & 1], bad);
         __syncthreads();
         n_bad = s_cnt[round & 1];
         if (round == 2) robust = false; // :429-430
         if (ne < 10) break;             // :457-458
     }
+#undef PO_EVAL
+    if constexpr (IN_LDS) { // pFrame->mvbOutlier: written where a map point exists (cleared at edge creation even when ne < 3)
+        for (int i = threadIdx.x; i < E.n; i += THREADS) {
+            const int st = E.l_st[i];
+            if (st) E.outlier[i] = st == 2 ? 1 : 0;
+        }
+    }
     if (threadIdx.x == 0) {
-        float Tout[16];
-        se3_to_cv(est, Tout);
+        if (ne >= 3) {
+            float Tout[16];
+            se3_to_cv(est, Tout);
 #pragma unroll
-        for (int k = 0; k < 16; k++) T[k] = Tout[k];
-        n_inliers[prob] = ne - n_bad;
+            for (int k = 0; k < 16; k++) T[k] = Tout[k];
+            n_inliers[prob] = ne - n_bad;
+        } else n_inliers[prob] = 0;
     }
 }
+
+constexpr int PO_LDS_CAP_MAX = 4096; // keypoint slots per problem the LDS edge table holds (29 B each)
+
+template <int THREADS>
+size_t pose_lds_bytes(int cap) { return sizeof(double) * (2 * (THREADS / 16) * 32 + 2 * 32) + (size_t)cap * (7 * sizeof(float) + 1) + 16; }
 
 struct DevBuf {
     void *p = nullptr;
@@ -505,7 +711,8 @@ void orbfe_pose_state_destroy(orbfe_pose_state *s) { delete s; }
 
 extern "C" int orbfe_enqueue_pose_optimization(orbfe_context *ctx, int n_problems, const int32_t *d_offsets,
                                                const orbfe_keypoint *d_keys_un, const float *d_u_right, const uint8_t *d_has_point,
-                                               const float *d_Xw, float *d_Tcw, uint8_t *d_outlier, int32_t *d_n_inliers, void *stream)
+                                               const float *d_Xw, float *d_Tcw, uint8_t *d_outlier, int32_t *d_n_inliers,
+                                               int max_keypoints, void *stream)
 {
     if (!ctx || n_problems < 0) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     if (n_problems == 0) return ORBFE_OK;
@@ -518,11 +725,33 @@ extern "C" int orbfe_enqueue_pose_optimization(orbfe_context *ctx, int n_problem
         if (st->sig.ensure(sizeof(float) * ORBFE_MAX_LEVELS)) return orbfe_fail(ctx, ORBFE_ERR_HIP, "pose scratch allocation failed");
         PTRY(ctx, hipMemcpy(st->sig.p, orbfe_ctx_inv_sigma2(ctx), sizeof(float) * p->nlevels, hipMemcpyHostToDevice));
     }
-    hipLaunchKernelGGL(pose_opt_kernel, dim3(n_problems), dim3(PO_THREADS), 0, s, d_offsets, (const KeyPointPOD *)d_keys_un, d_u_right,
-                       d_has_point, d_Xw, d_Tcw, d_outlier, d_n_inliers, (const float *)st->sig.p, p->fx, p->fy, p->cx, p->cy, p->bf);
+    constexpr int TH = PO_THREADS;
+    if (max_keypoints <= PO_LDS_CAP_MAX) {
+        const int cap = (std::max(max_keypoints, 1) + 3) & ~3;
+        const size_t lds = pose_lds_bytes<TH>(cap);
+        static bool attr_set = false;
+        if (!attr_set) {
+            PTRY(ctx, hipFuncSetAttribute((const void *)pose_opt_kernel<TH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pose_lds_bytes<TH>(PO_LDS_CAP_MAX)));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((pose_opt_kernel<TH, true>), dim3(n_problems), dim3(TH), lds, s, d_offsets, (const KeyPointPOD *)d_keys_un, d_u_right,
+                           d_has_point, d_Xw, d_Tcw, d_outlier, d_n_inliers, (const float *)st->sig.p, p->fx, p->fy, p->cx, p->cy, p->bf, cap);
+    } else {
+        hipLaunchKernelGGL((pose_opt_kernel<TH, false>), dim3(n_problems), dim3(TH), pose_lds_bytes<TH>(0), s, d_offsets, (const KeyPointPOD *)d_keys_un,
+                           d_u_right, d_has_point, d_Xw, d_Tcw, d_outlier, d_n_inliers, (const float *)st->sig.p, p->fx, p->fy, p->cx, p->cy, p->bf, 0);
+    }
     PTRY(ctx, hipGetLastError());
     return ORBFE_OK;
 }
+
+#ifdef ORBFE_POSE_TIMING
+extern "C" int orbfe_pose_debug_cycles(long long *dst, int reset)
+{
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pose_cycles), sizeof(long long) * 8) != hipSuccess) return -1;
+    if (reset) { long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pose_cycles), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 extern "C" int orbfe_pose_optimization_batch(orbfe_context *ctx, int n_problems, const int32_t *offsets, float *Tcw,
                                              const orbfe_keypoint *keys_un, const float *u_right, const uint8_t *has_point,
@@ -533,8 +762,11 @@ extern "C" int orbfe_pose_optimization_batch(orbfe_context *ctx, int n_problems,
     if (!offsets || !Tcw || !outlier || !n_inliers) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
     const int total = offsets[n_problems];
     const orbfe_params *p = orbfe_ctx_params(ctx);
-    for (int k = 0; k < n_problems; k++)
+    int max_n = 0;
+    for (int k = 0; k < n_problems; k++) {
         if (offsets[k + 1] < offsets[k] || offsets[0] != 0) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "offsets must start at 0 and not decrease");
+        max_n = std::max(max_n, offsets[k + 1] - offsets[k]);
+    }
     if (total > 0 && (!keys_un || !u_right || !has_point || !Xw)) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
     for (int i = 0; i < total; i++)
         if (has_point[i] && (keys_un[i].octave < 0 || keys_un[i].octave >= p->nlevels))
@@ -558,7 +790,7 @@ extern "C" int orbfe_pose_optimization_batch(orbfe_context *ctx, int n_problems,
     }
     int rc = orbfe_enqueue_pose_optimization(ctx, n_problems, (const int32_t *)st->off.p, (const orbfe_keypoint *)st->keys.p, (const float *)st->ur.p,
                                              (const uint8_t *)st->has.p, (const float *)st->xw.p, (float *)st->T.p, (uint8_t *)st->out.p,
-                                             (int32_t *)st->ninl.p, nullptr);
+                                             (int32_t *)st->ninl.p, max_n, nullptr);
     if (rc != ORBFE_OK) return rc;
     // problems with fewer than 3 correspondences leave their pose untouched on the device (the reference returns
     // before SetPose, src/Optimizer.cc:404-405)

@@ -10,6 +10,7 @@
 #include "ORBextractor.h"
 #include "ORBmatcher.h"
 #include "KeyFrameDatabase.h"
+#include "Optimizer.h"
 
 static std::vector<uint8_t> slurp(const char *path, size_t n)
 {
@@ -67,6 +68,26 @@ int main(int argc, char **argv)
         dump(prefix + ".kl", out.mvKeys); dump(prefix + ".dl", out.mDescriptors);
         dump(prefix + ".kr", out.mvKeysRight); dump(prefix + ".dr", out.mDescriptorsRight);
         dump(prefix + ".ur", out.mvuRight); dump(prefix + ".dp", out.mvDepth);
+        // Optimizer mirror: map points = the stereo keypoints back-projected at the identity pose (Frame::UnprojectStereo,
+        // src/Frame.cc:668-682); start 5 cm off; the optimiser has to come back to the identity
+        {
+            const size_t N = out.mvKeys.size();
+            std::vector<uint8_t> has(N, 0), outlier;
+            std::vector<float> Xw(3 * N, 0.f);
+            for (size_t i = 0; i < N; i++) {
+                const float z = out.mvDepth[i];
+                if (z <= 0) continue;
+                has[i] = 1;
+                Xw[3 * i] = (out.mvKeys[i].x - cam.cx) * z / cam.fx;
+                Xw[3 * i + 1] = (out.mvKeys[i].y - cam.cy) * z / cam.fy;
+                Xw[3 * i + 2] = z;
+            }
+            float Tcw[16] = {1, 0, 0, 0.05f, 0, 1, 0, -0.02f, 0, 0, 1, 0.03f, 0, 0, 0, 1};
+            const int nInl = ORB_SLAM2::Optimizer::PoseOptimization(extractorLeft.Context(), Tcw, out.mvKeys, out.mvuRight, has, Xw, outlier);
+            dump(prefix + ".Tcw", std::vector<float>(Tcw, Tcw + 16)); dump(prefix + ".outl", outlier);
+            dump(prefix + ".has", has); dump(prefix + ".Xw", Xw);
+            std::printf("pose inliers=%d\n", nInl);
+        }
         std::printf("N=%d NR=%zu levels=%d scale1=%.9g\n", out.N, out.mvKeysRight.size(), extractorLeft.GetLevels(),
                     (double)extractorLeft.GetScaleFactors()[1]);
     } catch (const std::exception &e) {

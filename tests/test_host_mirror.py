@@ -19,6 +19,7 @@ def test_mirror_headers_keep_the_reference_names():
                  "GetInverseScaleSigmaSquares", "mvImagePyramid", "int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST"):
         assert name in ex, name
     m = open(os.path.join(ROOT, "orbslam2_amd", "host", "ORBmatcher.h")).read()
+    assert "PoseOptimization" in open(os.path.join(ROOT, "orbslam2_amd", "host", "Optimizer.h")).read()
     for name in ("class ORBmatcher", "TH_LOW = 50", "TH_HIGH = 100", "HISTO_LENGTH = 30", "DescriptorDistance", "SearchByProjection",
                  "SearchForInitialization", "ComputeThreeMaxima"):
         assert name in m, name
@@ -45,3 +46,11 @@ def test_cpp_selftest_matches_oracle(tmp_path):
     m12, pm, n = O.search_for_initialization(kl, dl, g2, dr, prev, 100, 0.9, True)
     assert np.array_equal(np.fromfile(pre + ".m12", np.int32), m12) and np.array_equal(np.fromfile(pre + ".pm", np.float32).reshape(-1, 2), pm)
     assert ("init matches=%d" % n) in r.stdout and n > 20
+    # Optimizer mirror: same inputs through the oracle
+    has = np.fromfile(pre + ".has", np.uint8); Xw = np.fromfile(pre + ".Xw", np.float32).reshape(-1, 3)
+    T0 = np.eye(4, dtype=np.float32); T0[:3, 3] = [0.05, -0.02, 0.03]
+    Tr, outr, nr = O.pose_optimization(T0, kl, ur, has, Xw, exl.inv_sigma2(), fx, fx, w * 0.5, h * 0.5, bf)
+    Tg = np.fromfile(pre + ".Tcw", np.float32).reshape(4, 4)
+    assert ("pose inliers=%d" % nr) in r.stdout and nr > 50
+    assert np.array_equal(np.fromfile(pre + ".outl", np.uint8), outr)
+    assert np.abs(Tg - Tr).max() <= 2e-6 and np.abs(Tg - np.eye(4)).max() < 2e-3
