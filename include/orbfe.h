@@ -97,6 +97,14 @@ int orbfe_stereo_frame(orbfe_context *ctx, const uint8_t *left, const uint8_t *r
                        orbfe_keypoint *kps_right, uint8_t *desc_right, int *n_right,
                        float *u_right, float *depth, int cap);
 
+/* Input pixel format of every image entry point of this context (host and device-resident), default CV_8UC1.
+ * channels = 3 / 4 makes ingest perform the grey conversion Tracking::GrabImageMonocular / Stereo / RGBD do before they
+ * build the Frame (src/Tracking.cc:269-294,305-321,335-351): cv::cvtColor(im, im, COLOR_RGB2GRAY / BGR2GRAY / RGBA2GRAY /
+ * BGRA2GRAY); rgb_order = Tracking's mbRGB (channel 0 is red).  Images are then w * channels bytes per packed row
+ * (stride arguments count bytes of such rows; orbfe_enqueue_* read [image][h][w][channels]).  legacy_weights != 0 selects
+ * OpenCV 3.x's 14-bit weights (4899, 9617, 1868) instead of 4.x's 15-bit ones (9798, 19235, 3735). */
+int orbfe_set_input_format(orbfe_context *ctx, int channels, int rgb_order, int legacy_weights);
+
 /* Frame::Frame(rgbd) body (src/Frame.cc:120-172) for an undistorted camera:
  * ExtractORB + ComputeStereoFromRGBD (src/Frame.cc:645-666).  depth_img is CV_32F
  * metres, row stride in bytes; kps_un may be NULL (then kps are used: k1 == 0). */

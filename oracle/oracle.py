@@ -430,3 +430,15 @@ def pose_optimization(Tcw, keys_un, u_right, has_point, Xw, inv_level_sigma2, fx
     out = np.zeros(max(len(k), 1), np.uint8) if outlier is None else np.ascontiguousarray(outlier, np.uint8).copy()
     n = L.orc_pose_optimization(_ptr(T), len(k), _ptr(k), _ptr(ur), _ptr(hp), _ptr(X), _ptr(s2), fx, fy, cx, cy, bf, _ptr(out))
     return T, out[: len(k)].copy(), n
+
+
+def cvt_gray(img, rgb=True, legacy14=False):
+    """cv::cvtColor(img, COLOR_{RGB,BGR}[A]2GRAY) for uint8 HxWx{3,4} (src/Tracking.cc:269-294)."""
+    a = np.ascontiguousarray(img, np.uint8)
+    h, w, cn = a.shape
+    out = np.zeros((h, w), np.uint8)
+    L = lib()
+    L.orc_cvt_gray.restype = None
+    L.orc_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    L.orc_cvt_gray(_ptr(a), w, h, a.strides[0], cn, int(rgb), int(legacy14), _ptr(out), out.strides[0])
+    return out

@@ -1081,3 +1081,23 @@ void orc_stereo_from_rgbd(const orc_keypoint *k, const orc_keypoint *k_un, int n
         }
     }
 }
+
+
+/* cv::cvtColor(src, dst, COLOR_{RGB,BGR,RGBA,BGRA}2GRAY) for CV_8U, as Tracking::GrabImage{Monocular,Stereo,RGBD} call it
+ * (src/Tracking.cc:269-294,305-321,335-351).  OPENCV-4.5.5-SEMANTICS: color_rgb.simd.hpp RGB2Gray<uchar> --
+ * gray = (R*RY15 + G*GY15 + B*BY15 + (1 << 14)) >> 15 with RY15 = 9798, GY15 = 19235, BY15 = 3735 (sum 32768; alpha
+ * ignored; the SIMD and scalar paths are bit-identical by construction).  OpenCV 3.x used 14-bit weights 4899 / 9617 / 1868
+ * (sum 16384): `legacy14` selects those, so a build against an older OpenCV can be matched -- a configurable constant like
+ * the Gaussian taps.  cn = 3 or 4; rgb != 0: channel 0 is red (mbRGB), else blue. */
+void orc_cvt_gray(const uint8_t *src, int w, int h, size_t stride, int cn, int rgb, int legacy14, uint8_t *dst, size_t dst_stride)
+{
+    const int cr = legacy14 ? 4899 : 9798, cg = legacy14 ? 9617 : 19235, cb = legacy14 ? 1868 : 3735, shift = legacy14 ? 14 : 15;
+    for (int y = 0; y < h; y++) {
+        const uint8_t *s = src + (size_t)y * stride;
+        uint8_t *d = dst + (size_t)y * dst_stride;
+        for (int x = 0; x < w; x++, s += cn) {
+            const int r = rgb ? s[0] : s[2], g = s[1], b = rgb ? s[2] : s[0];
+            d[x] = (uint8_t)((unsigned)(r * cr + g * cg + b * cb + (1 << (shift - 1))) >> shift);
+        }
+    }
+}

@@ -51,6 +51,9 @@ typedef struct orc_params {
 
 typedef struct orc_extractor orc_extractor;
 
+/* cv::cvtColor(..., COLOR_{RGB,BGR,RGBA,BGRA}2GRAY), 8-bit (src/Tracking.cc:269-294); see orb_oracle.c */
+void orc_cvt_gray(const uint8_t *src, int w, int h, size_t stride, int cn, int rgb, int legacy14, uint8_t *dst, size_t dst_stride);
+
 /* ---- scalar helpers (OpenCV semantics) ---- */
 int orc_cv_round_f(float v);            /* cvRound(float): round-half-even */
 int orc_cv_round_d(double v);           /* cvRound(double) */

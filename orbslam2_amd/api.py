@@ -31,7 +31,7 @@ EXPORTS = [
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_kf", "orbfe_search_for_initialization",
     "orbfe_vocab_load", "orbfe_bow_transform", "orbfe_bow_maps", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",  # bound in orbslam2_amd/bow.py
     "orbfe_search_for_triangulation", "orbfe_fuse", "orbfe_search_by_projection_sim3", "orbfe_fuse_sim3", "orbfe_search_by_sim3", "orbfe_kfdb_clear", "orbfe_kfdb_add", "orbfe_kfdb_erase", "orbfe_kfdb_size", "orbfe_kfdb_score", "orbfe_detect_reloc_candidates",
-    "orbfe_pose_optimization", "orbfe_pose_optimization_batch", "orbfe_enqueue_pose_optimization",
+    "orbfe_pose_optimization", "orbfe_pose_optimization_batch", "orbfe_enqueue_pose_optimization", "orbfe_set_input_format",
 ]
 NUM_STAGES = 8
 STAGE_NAMES = ["ingest", "pyramid", "blur", "fast", "octree", "describe", "stereo_match", "stereo_median"]  # orbfe_stage_name()
@@ -134,6 +134,8 @@ def load():
     L.orbfe_fuse_sim3.argtypes = [vp, fvp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float, vp, ip]
     L.orbfe_search_by_sim3.restype = C.c_int
     L.orbfe_search_by_sim3.argtypes = [vp] + [fvp, vp, vp, vp, vp, vp, vp] * 2 + [C.c_float, vp, vp, C.c_float, vp, ip]
+    L.orbfe_set_input_format.restype = C.c_int
+    L.orbfe_set_input_format.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.orbfe_pose_optimization.restype = C.c_int
     L.orbfe_pose_optimization.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, ip]
     L.orbfe_pose_optimization_batch.restype = C.c_int
@@ -201,11 +203,18 @@ class Context:
     # ---- host-image entry points ----
     @staticmethod
     def _rows(a, dtype):
-        """Row-strided views (a cv::Mat ROI) go through as they are; anything else is made contiguous."""
+        """Row-strided views (a cv::Mat ROI) go through as they are; anything else is made contiguous.  HxWxC colour
+        images (orbfe_set_input_format) must have packed pixels."""
         a = np.asarray(a, dtype)
         if a.ndim == 2 and a.strides[1] == a.itemsize and a.strides[0] >= a.shape[1] * a.itemsize:
             return a
+        if a.ndim == 3 and a.strides[2] == a.itemsize and a.strides[1] == a.shape[2] * a.itemsize and a.strides[0] >= a.shape[1] * a.strides[1]:
+            return a
         return np.ascontiguousarray(a)
+
+    def set_input_format(self, channels=1, rgb=True, legacy_weights=False):
+        """cv::cvtColor(..., COLOR_{RGB,BGR}[A]2GRAY) of Tracking::GrabImage* folded into ingest (src/Tracking.cc:269-294)."""
+        self._check(self.L.orbfe_set_input_format(self.h, channels, int(rgb), int(legacy_weights)))
 
     def extract(self, img: np.ndarray):
         img = self._rows(img, np.uint8)

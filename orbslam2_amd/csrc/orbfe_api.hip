@@ -175,6 +175,7 @@ static int build_config(orbfe_context *ctx)
     c.half_patch = p.half_patch_size;
     c.bf = p.bf; c.fx = p.fx;
     c.mb = p.fx != 0.f ? p.bf / p.fx : 0.f; // mb := mbf / fx
+    c.in_cn = 1; c.in_coef[0] = c.in_coef[1] = c.in_coef[2] = 0; c.in_shift = 15;
 
     const double sf_d = (double)p.scale_factor; // member is double, initialised from float
     ctx->scale[0] = 1.0f; ctx->sigma2[0] = 1.0f;
@@ -665,7 +666,7 @@ static void run_chain(orbfe_context *ctx, const uint8_t *d_images, int img0, int
 {
     const DeviceConfig &cfg = ctx->cfg;
     const DeviceBuffers buf = shift_buffers(ctx->buf, cfg, img0);
-    const uint8_t *src = d_images + (size_t)img0 * cfg.width * cfg.height;
+    const uint8_t *src = d_images + (size_t)img0 * cfg.width * cfg.height * cfg.in_cn;
     prof_mark(ctx, group, 0, s);
     orbfe_launch_ingest(cfg, buf, src, n_images, s);
     prof_mark(ctx, group, 1, s);
@@ -758,6 +759,31 @@ extern "C" int orbfe_enqueue_stereo(orbfe_context *ctx, const uint8_t *d_images,
     return enqueue_batch(ctx, d_images, n_pairs, 2, stream);
 }
 
+extern "C" int orbfe_set_input_format(orbfe_context *ctx, int channels, int rgb_order, int legacy_weights)
+{
+    if (!ctx) return ORBFE_ERR_INVALID;
+    if (channels != 1 && channels != 3 && channels != 4) return fail(ctx, ORBFE_ERR_INVALID, "channels must be 1, 3 or 4");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (channels != ctx->cfg.in_cn) { // the staging of the host entry points is sized by the format
+        const size_t need = (size_t)ctx->params.max_images * ctx->params.width * ctx->params.height * channels;
+        uint8_t *nd = nullptr;
+        HIP_TRY(ctx, hipMalloc((void **)&nd, need));
+        for (void *&q : ctx->allocs)
+            if (q == ctx->d_in) q = nd;
+        (void)hipFree(ctx->d_in);
+        ctx->d_in = nd;
+        if (ctx->h_in) { (void)hipHostFree(ctx->h_in); ctx->h_in = nullptr; }
+    }
+    // color_rgb.simd.hpp RGB2Gray<uchar>: RY15 / GY15 / BY15 with 15 fraction bits; OpenCV 3.x: R2Y / G2Y / B2Y with 14
+    const int cr = legacy_weights ? 4899 : 9798, cg = legacy_weights ? 9617 : 19235, cb = legacy_weights ? 1868 : 3735;
+    ctx->cfg.in_cn = channels;
+    ctx->cfg.in_coef[0] = rgb_order ? cr : cb;
+    ctx->cfg.in_coef[1] = cg;
+    ctx->cfg.in_coef[2] = rgb_order ? cb : cr;
+    ctx->cfg.in_shift = legacy_weights ? 14 : 15;
+    return ORBFE_OK;
+}
+
 extern "C" int orbfe_synchronize(orbfe_context *ctx, void *stream)
 {
     if (!ctx) return ORBFE_ERR_INVALID;
@@ -833,7 +859,7 @@ static HostOut host_out_layout(const orbfe_context *ctx)
 static int ensure_host_stage(orbfe_context *ctx, bool want_depth)
 {
     const size_t px = (size_t)ctx->params.width * ctx->params.height, ni = ctx->params.max_images < 2 ? 1 : 2;
-    if (!ctx->h_in) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_in, ni * px, hipHostMallocDefault));
+    if (!ctx->h_in) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_in, ni * px * ctx->cfg.in_cn, hipHostMallocDefault));
     if (!ctx->h_out) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_out, host_out_layout(ctx).bytes, hipHostMallocDefault));
     if (want_depth && !ctx->h_depth_in) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_depth_in, px * sizeof(float), hipHostMallocDefault));
     if (want_depth && !ctx->d_depth_in) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_depth_in, px * sizeof(float)));
@@ -855,9 +881,10 @@ static int upload_image(orbfe_context *ctx, int slot, const uint8_t *img, int w,
 {
     if (w != ctx->params.width || h != ctx->params.height)
         return fail(ctx, ORBFE_ERR_UNSUPPORTED, "image is %dx%d, context was built for %dx%d", w, h, ctx->params.width, ctx->params.height);
-    if (stride < (size_t)w) return fail(ctx, ORBFE_ERR_INVALID, "stride smaller than width");
-    const size_t px = (size_t)w * h;
-    return stage_rows(ctx, ctx->d_in + (size_t)slot * px, ctx->h_in + (size_t)slot * px, img, (size_t)w, h, stride);
+    const size_t row = (size_t)w * ctx->cfg.in_cn; // bytes per packed row of the context's input format
+    if (stride < row) return fail(ctx, ORBFE_ERR_INVALID, "stride smaller than a row (%d px x %d channels)", w, ctx->cfg.in_cn);
+    const size_t px = row * h;
+    return stage_rows(ctx, ctx->d_in + (size_t)slot * px, ctx->h_in + (size_t)slot * px, img, row, h, stride);
 }
 
 // Queues the device-to-host copies of `nimg` images' results into the pinned block, waits once, and hands the

@@ -49,6 +49,9 @@ struct DeviceConfig {
     int taps[7];           // Gaussian 8.8 fixed-point taps
     size_t pyr_bytes;      // per image
     float bf, fx, mb;
+    // input pixel format (orbfe_set_input_format): 1 = CV_8UC1; 3 / 4 = interleaved colour converted by ingest with
+    // cv::cvtColor's fixed-point weights for channels 0, 1, 2 (in_coef) and in_shift fraction bits
+    int in_cn, in_coef[3], in_shift;
     LevelInfo lv[ORBFE_MAX_LEVELS];
 };
 

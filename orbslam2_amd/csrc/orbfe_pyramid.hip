@@ -11,6 +11,9 @@
 // ingest: packed images -> level 0 (+ margin); one thread = 4 px of the extended domain, block = 64 words x 4 rows.
 // Interior words are one (unaligned) 32-bit load of the packed source; only the margin words gather reflected bytes.
 // Also clears the image's status word (first kernel of every chain).
+// CN = 3 / 4: interleaved colour input, converted on the fly with cv::cvtColor's 8-bit fixed-point arithmetic
+// (Tracking::GrabImage*, src/Tracking.cc:269-294: gray = (c0*k0 + c1*k1 + c2*k2 + half) >> shift; alpha ignored).
+template <int CN>
 __global__ __launch_bounds__(256) void ingest_kernel(DeviceConfig cfg, DeviceBuffers buf, const uint8_t *__restrict__ src)
 {
     const int img = blockIdx.z;
@@ -23,13 +26,34 @@ __global__ __launch_bounds__(256) void ingest_kernel(DeviceConfig cfg, DeviceBuf
     const int y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6)) - PYR_MY;
     const int x0 = (int)(blockIdx.x * 64 + (threadIdx.x & 63)) * 4 - PYR_MX;
     if (x0 >= L.w + 8 || y >= L.h + PYR_MY) return;
-    const uint8_t *s = src + (size_t)img * L.w * L.h + (size_t)reflect101(y, L.h) * L.w;
+    const uint8_t *s = src + ((size_t)img * L.h + (size_t)reflect101(y, L.h)) * L.w * CN;
     uint32_t v = 0;
-    if (x0 >= 0 && x0 + 3 < L.w) {
-        __builtin_memcpy(&v, s + x0, 4);
-    } else {
+    if constexpr (CN == 1) {
+        if (x0 >= 0 && x0 + 3 < L.w) {
+            __builtin_memcpy(&v, s + x0, 4);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; j++) v |= (uint32_t)s[reflect101(x0 + j, L.w)] << (8 * j);
+            for (int j = 0; j < 4; j++) v |= (uint32_t)s[reflect101(x0 + j, L.w)] << (8 * j);
+        }
+    } else {
+        const int k0 = cfg.in_coef[0], k1 = cfg.in_coef[1], k2 = cfg.in_coef[2], sh = cfg.in_shift, half = 1 << (sh - 1);
+        if (x0 >= 0 && x0 + 3 < L.w) {
+            uint32_t wds[CN]; // 4 px = 3 or 4 words
+            __builtin_memcpy(wds, s + (size_t)x0 * CN, 4 * CN);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t c[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const int byte = j * CN + k; c[k] = (wds[byte >> 2] >> (8 * (byte & 3))) & 0xffu; }
+                v |= ((c[0] * k0 + c[1] * k1 + c[2] * k2 + half) >> sh) << (8 * j);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint8_t *p = s + (size_t)reflect101(x0 + j, L.w) * CN;
+                v |= (((uint32_t)p[0] * k0 + (uint32_t)p[1] * k1 + (uint32_t)p[2] * k2 + half) >> sh) << (8 * j);
+            }
+        }
     }
     uint8_t *d = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (ptrdiff_t)y * L.pitch + x0;
     *(uint32_t *)d = v;
@@ -233,7 +257,9 @@ void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, cons
 {
     const int words = (cfg.lv[0].w + 12 + 3) / 4;
     dim3 grid((words + 63) / 64, (cfg.lv[0].h + 2 * PYR_MY + 3) / 4, n_images);
-    hipLaunchKernelGGL(ingest_kernel, grid, dim3(256), 0, s, cfg, buf, d_images);
+    if (cfg.in_cn == 3) hipLaunchKernelGGL(ingest_kernel<3>, grid, dim3(256), 0, s, cfg, buf, d_images);
+    else if (cfg.in_cn == 4) hipLaunchKernelGGL(ingest_kernel<4>, grid, dim3(256), 0, s, cfg, buf, d_images);
+    else hipLaunchKernelGGL(ingest_kernel<1>, grid, dim3(256), 0, s, cfg, buf, d_images);
 }
 
 void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)

@@ -219,3 +219,42 @@ def test_rgbd_raw_u16_depth_matches_converted_map():
         assert np.array_equal(got2[key], ref[key]), key
     assert (dp > 0).sum() > 100
     ctx.close()
+
+
+@pytest.mark.parametrize("cn,rgb,legacy", [(3, True, False), (3, False, False), (4, True, False), (4, False, True)])
+def test_colour_input_is_converted_like_cvtcolor(cn, rgb, legacy):
+    """Tracking::GrabImageStereo converts 3- / 4-channel input with cv::cvtColor(COLOR_{RGB,BGR}[A]2GRAY) before the Frame is
+    built (src/Tracking.cc:269-294); orbfe_set_input_format folds that into ingest.  The result must equal the grey path fed
+    with the oracle's conversion, on packed and on row-strided colour buffers, and switching back to grey must work."""
+    cfg = SMALL
+    w, h = cfg["width"], cfg["height"]
+    planes = [synth.stereo_pair(w, h, seed=300 + k) for k in range(3)]
+    rng = np.random.default_rng(9)
+    def colour(side):
+        c = np.stack([planes[k][side] for k in range(3)], axis=2)
+        if cn == 4:
+            c = np.concatenate([c, rng.integers(0, 256, (h, w, 1), dtype=np.uint8)], axis=2)  # alpha: ignored
+        return np.ascontiguousarray(c)
+    cl, cr = colour(0), colour(1)
+    gl, gr = O.cvt_gray(cl, rgb, legacy), O.cvt_gray(cr, rgb, legacy)
+    assert gl.std() > 10 and not np.array_equal(gl, O.cvt_gray(cl, not rgb, legacy))
+    ctx = _ctx(cfg)
+    ref = ctx.stereo_frame(gl, gr)
+    assert len(ref["kps_left"]) > 100
+    ctx.set_input_format(cn, rgb, legacy)
+    out = ctx.stereo_frame(cl, cr)
+    for k in ref:
+        assert np.array_equal(out[k], ref[k]), k
+    assert np.array_equal(ctx.fetch_pyramid(0, 0), gl) and np.array_equal(ctx.fetch_pyramid(1, 0), gr)
+    wide = np.zeros((2, h, w + 9, cn), np.uint8)
+    wide[0, :, 4:4 + w], wide[1, :, 4:4 + w] = cl, cr
+    out2 = ctx.stereo_frame(wide[0, :, 4:4 + w], wide[1, :, 4:4 + w])
+    for k in ref:
+        assert np.array_equal(out2[k], ref[k]), k
+    k1, d1 = ctx.extract(cr)
+    assert np.array_equal(k1, ref["kps_right"]) and np.array_equal(d1, ref["desc_right"])
+    ctx.set_input_format(1)
+    out3 = ctx.stereo_frame(gl, gr)
+    for k in ref:
+        assert np.array_equal(out3[k], ref[k]), k
+    ctx.close()

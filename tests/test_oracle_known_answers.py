@@ -276,3 +276,21 @@ def test_stereo_on_synthetic_layers(small_pair):
     # no match possible against an unrelated image
     ur2, _, m2 = O.stereo_matches(exl, exr, kl, dl, kr[:0], dr[:0], 120.0, 300.0)
     assert m2 == 0 and (ur2 == -1).all()
+
+
+def test_cvt_gray_known_answers():
+    """cv::cvtColor 8-bit RGB->GRAY: (R*9798 + G*19235 + B*3735 + 2^14) >> 15 (OpenCV 4.x), weights sum to 2^15."""
+    a = np.zeros((1, 6, 3), np.uint8)
+    a[0, 0] = 255; a[0, 1] = (255, 0, 0); a[0, 2] = (0, 255, 0); a[0, 3] = (0, 0, 255); a[0, 4] = (10, 200, 97); a[0, 5] = (1, 1, 1)
+    g = O.cvt_gray(a, rgb=True)
+    assert g.tolist() == [[255, 76, 150, 29, (10 * 9798 + 200 * 19235 + 97 * 3735 + 16384) >> 15, 1]]
+    assert O.cvt_gray(a, rgb=False).tolist()[0][1:4] == [29, 150, 76]          # BGR: channel 0 is blue
+    assert 9798 + 19235 + 3735 == 1 << 15 and 4899 + 9617 + 1868 == 1 << 14
+    grey = np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, axis=2)  # R = G = B = v  ->  v exactly
+    assert np.array_equal(O.cvt_gray(grey)[0], np.arange(256)) and np.array_equal(O.cvt_gray(grey, legacy14=True)[0], np.arange(256))
+    rgba = np.concatenate([a, np.full((1, 6, 1), 77, np.uint8)], axis=2)        # alpha ignored
+    assert np.array_equal(O.cvt_gray(rgba), g)
+    rng = np.random.default_rng(0)
+    r = rng.integers(0, 256, (7, 13, 3), dtype=np.uint8)
+    f = 0.299 * r[..., 0] + 0.587 * r[..., 1] + 0.114 * r[..., 2]
+    assert np.abs(O.cvt_gray(r).astype(float) - f).max() <= 0.51 + 1e-9         # within half a grey level + weight rounding
