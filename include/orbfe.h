@@ -105,9 +105,22 @@ int orbfe_stereo_frame(orbfe_context *ctx, const uint8_t *left, const uint8_t *r
  * OpenCV 3.x's 14-bit weights (4899, 9617, 1868) instead of 4.x's 15-bit ones (9798, 19235, 3735). */
 int orbfe_set_input_format(orbfe_context *ctx, int channels, int rgb_order, int legacy_weights);
 
+/* Lens distortion of the context's camera: Tracking's mDistCoef = k1 k2 p1 p2 [k3] (src/Tracking.cc:67-78), n = 0 / 4 / 5.
+ * With k1 != 0 the RGB-D entry points build mvuRight from the UNDISTORTED keypoint x as Frame::ComputeStereoFromRGBD does
+ * (src/Frame.cc:652-664), and the three functions below reproduce Frame::UndistortKeyPoints / ComputeImageBounds
+ * (src/Frame.cc:402-462): cv::undistortPoints(pts, K, D, Mat(), K) -- five fixed-point iterations in double.
+ * k1 == 0 means "no distortion" exactly as the reference tests it (:404,436). */
+int orbfe_set_distortion(orbfe_context *ctx, const float *dist, int n);
+/* mvKeysUn from mvKeys: copies every field, replaces pt (host arrays). */
+int orbfe_undistort_keypoints(orbfe_context *ctx, const orbfe_keypoint *kps, int n, orbfe_keypoint *kps_un);
+/* mvKeysUn of image slot `image` of the latest call, undistorted on the device before the download. */
+int orbfe_fetch_keys_un(orbfe_context *ctx, int image, orbfe_keypoint *kps_un, int cap, int *n);
+/* bounds[4] = mnMinX, mnMaxX, mnMinY, mnMaxY for the context's image size. */
+int orbfe_image_bounds(orbfe_context *ctx, float *bounds);
+
 /* Frame::Frame(rgbd) body (src/Frame.cc:120-172) for an undistorted camera:
  * ExtractORB + ComputeStereoFromRGBD (src/Frame.cc:645-666).  depth_img is CV_32F
- * metres, row stride in bytes; kps_un may be NULL (then kps are used: k1 == 0). */
+ * metres, row stride in bytes.  uRight uses the undistorted x when orbfe_set_distortion gave k1 != 0. */
 int orbfe_rgbd_frame(orbfe_context *ctx, const uint8_t *gray, const float *depth_img,
                      int w, int h, size_t gray_stride, size_t depth_stride,
                      orbfe_keypoint *kps, uint8_t *desc, int *n,

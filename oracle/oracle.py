@@ -442,3 +442,26 @@ def cvt_gray(img, rgb=True, legacy14=False):
     L.orc_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     L.orc_cvt_gray(_ptr(a), w, h, a.strides[0], cn, int(rgb), int(legacy14), _ptr(out), out.strides[0])
     return out
+
+
+def undistort_points(xy, fx, fy, cx, cy, dist):
+    """cv::undistortPoints(xy, K, D, Mat(), K) (src/Frame.cc:420): float32 [n,2] in and out."""
+    a = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    d = np.ascontiguousarray(dist, np.float32)
+    out = np.zeros_like(a)
+    L = lib()
+    L.orc_undistort_points.restype = None
+    L.orc_undistort_points.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_undistort_points(_ptr(a), len(a), fx, fy, cx, cy, _ptr(d), len(d), _ptr(out))
+    return out
+
+
+def image_bounds(cols, rows, fx, fy, cx, cy, dist):
+    """Frame::ComputeImageBounds: (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+    d = np.ascontiguousarray(dist, np.float32)
+    out = np.zeros(4, np.float32)
+    L = lib()
+    L.orc_image_bounds.restype = None
+    L.orc_image_bounds.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_image_bounds(cols, rows, fx, fy, cx, cy, _ptr(d), len(d), _ptr(out))
+    return out

@@ -1101,3 +1101,49 @@ void orc_cvt_gray(const uint8_t *src, int w, int h, size_t stride, int cn, int r
         }
     }
 }
+
+
+/* cv::undistortPoints(src, dst, K, D, cv::Mat(), K) as Frame::UndistortKeyPoints / ComputeImageBounds call it
+ * (src/Frame.cc:402-462).  OPENCV-4.5.5-SEMANTICS: calib3d/undistort.dispatch.cpp cvUndistortPointsInternal with the
+ * 6-argument overload's TermCriteria(MAX_ITER, 5, 0.01): exactly five fixed-point iterations in double, no error test;
+ * K and D are CV_32F there and are widened to double; R = I, P = K so the re-projection is fx*x + 0*y + cx (w = 1).
+ * dist = k1 k2 p1 p2 [k3] (ndist = 4 or 5, src/Tracking.cc:67-77).  The caller skips the call when k1 == 0 (:404-408). */
+void orc_undistort_points(const float *src_xy, int n, float fx, float fy, float cx, float cy, const float *dist, int ndist, float *dst_xy)
+{
+    double k[14] = {0};
+    for (int i = 0; i < ndist && i < 14; i++) k[i] = dist[i];
+    const double dfx = fx, dfy = fy, dcx = cx, dcy = cy, ifx = 1. / dfx, ify = 1. / dfy;
+    for (int i = 0; i < n; i++) {
+        const double u = src_xy[2 * i], v = src_xy[2 * i + 1];
+        double x = (u - dcx) * ifx, y = (v - dcy) * ify;
+        const double x0 = x, y0 = y; /* tilt model absent (k[12] = k[13] = 0): invMatTilt is the identity */
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            if (icdist < 0) { x = (u - dcx) * ifx; y = (v - dcy) * ify; break; }
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        const double xx = dfx * x + 0.0 * y + dcx, yy = 0.0 * x + dfy * y + dcy, ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+        dst_xy[2 * i] = (float)(xx * ww);
+        dst_xy[2 * i + 1] = (float)(yy * ww);
+    }
+}
+
+/* Frame::ComputeImageBounds (src/Frame.cc:434-462): bounds[4] = mnMinX, mnMaxX, mnMinY, mnMaxY */
+void orc_image_bounds(int cols, int rows, float fx, float fy, float cx, float cy, const float *dist, int ndist, float *bounds)
+{
+    if (ndist > 0 && dist[0] != 0.0f) {
+        const float c[8] = {0.f, 0.f, (float)cols, 0.f, 0.f, (float)rows, (float)cols, (float)rows};
+        float o[8];
+        orc_undistort_points(c, 4, fx, fy, cx, cy, dist, ndist, o);
+        bounds[0] = o[0] < o[4] ? o[0] : o[4];  /* min(mat(0,0), mat(2,0)) */
+        bounds[1] = o[2] > o[6] ? o[2] : o[6];  /* max(mat(1,0), mat(3,0)) */
+        bounds[2] = o[1] < o[3] ? o[1] : o[3];  /* min(mat(0,1), mat(1,1)) */
+        bounds[3] = o[5] > o[7] ? o[5] : o[7];  /* max(mat(2,1), mat(3,1)) */
+    } else {
+        bounds[0] = 0.f; bounds[1] = (float)cols; bounds[2] = 0.f; bounds[3] = (float)rows;
+    }
+}

@@ -54,6 +54,10 @@ typedef struct orc_extractor orc_extractor;
 /* cv::cvtColor(..., COLOR_{RGB,BGR,RGBA,BGRA}2GRAY), 8-bit (src/Tracking.cc:269-294); see orb_oracle.c */
 void orc_cvt_gray(const uint8_t *src, int w, int h, size_t stride, int cn, int rgb, int legacy14, uint8_t *dst, size_t dst_stride);
 
+/* cv::undistortPoints(src, dst, K, D, Mat(), K) of Frame::UndistortKeyPoints / ComputeImageBounds (src/Frame.cc:402-462) */
+void orc_undistort_points(const float *src_xy, int n, float fx, float fy, float cx, float cy, const float *dist, int ndist, float *dst_xy);
+void orc_image_bounds(int cols, int rows, float fx, float fy, float cx, float cy, const float *dist, int ndist, float *bounds);
+
 /* ---- scalar helpers (OpenCV semantics) ---- */
 int orc_cv_round_f(float v);            /* cvRound(float): round-half-even */
 int orc_cv_round_d(double v);           /* cvRound(double) */

@@ -31,7 +31,7 @@ EXPORTS = [
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_kf", "orbfe_search_for_initialization",
     "orbfe_vocab_load", "orbfe_bow_transform", "orbfe_bow_maps", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",  # bound in orbslam2_amd/bow.py
     "orbfe_search_for_triangulation", "orbfe_fuse", "orbfe_search_by_projection_sim3", "orbfe_fuse_sim3", "orbfe_search_by_sim3", "orbfe_kfdb_clear", "orbfe_kfdb_add", "orbfe_kfdb_erase", "orbfe_kfdb_size", "orbfe_kfdb_score", "orbfe_detect_reloc_candidates",
-    "orbfe_pose_optimization", "orbfe_pose_optimization_batch", "orbfe_enqueue_pose_optimization", "orbfe_set_input_format",
+    "orbfe_pose_optimization", "orbfe_pose_optimization_batch", "orbfe_enqueue_pose_optimization", "orbfe_set_input_format", "orbfe_set_distortion", "orbfe_undistort_keypoints", "orbfe_fetch_keys_un", "orbfe_image_bounds",
 ]
 NUM_STAGES = 8
 STAGE_NAMES = ["ingest", "pyramid", "blur", "fast", "octree", "describe", "stereo_match", "stereo_median"]  # orbfe_stage_name()
@@ -134,6 +134,14 @@ def load():
     L.orbfe_fuse_sim3.argtypes = [vp, fvp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float, vp, ip]
     L.orbfe_search_by_sim3.restype = C.c_int
     L.orbfe_search_by_sim3.argtypes = [vp] + [fvp, vp, vp, vp, vp, vp, vp] * 2 + [C.c_float, vp, vp, C.c_float, vp, ip]
+    L.orbfe_set_distortion.restype = C.c_int
+    L.orbfe_set_distortion.argtypes = [vp, vp, C.c_int]
+    L.orbfe_undistort_keypoints.restype = C.c_int
+    L.orbfe_undistort_keypoints.argtypes = [vp, vp, C.c_int, vp]
+    L.orbfe_fetch_keys_un.restype = C.c_int
+    L.orbfe_fetch_keys_un.argtypes = [vp, C.c_int, vp, C.c_int, ip]
+    L.orbfe_image_bounds.restype = C.c_int
+    L.orbfe_image_bounds.argtypes = [vp, vp]
     L.orbfe_set_input_format.restype = C.c_int
     L.orbfe_set_input_format.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.orbfe_pose_optimization.restype = C.c_int
@@ -211,6 +219,27 @@ class Context:
         if a.ndim == 3 and a.strides[2] == a.itemsize and a.strides[1] == a.shape[2] * a.itemsize and a.strides[0] >= a.shape[1] * a.strides[1]:
             return a
         return np.ascontiguousarray(a)
+
+    def set_distortion(self, dist):
+        """mDistCoef = k1 k2 p1 p2 [k3] (src/Tracking.cc:67-78); empty: no distortion."""
+        d = np.ascontiguousarray(dist, np.float32)
+        self._check(self.L.orbfe_set_distortion(self.h, _p(d) if len(d) else None, len(d)))
+
+    def undistort_keypoints(self, kps):
+        k = np.ascontiguousarray(kps, KP_DTYPE); out = np.zeros(max(len(k), 1), KP_DTYPE)
+        self._check(self.L.orbfe_undistort_keypoints(self.h, _p(k), len(k), _p(out)))
+        return out[: len(k)].copy()
+
+    def fetch_keys_un(self, image=0):
+        cap = self.capacity
+        out = np.zeros(cap, KP_DTYPE); n = C.c_int()
+        self._check(self.L.orbfe_fetch_keys_un(self.h, image, _p(out), cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    def image_bounds(self):
+        b = np.zeros(4, np.float32)
+        self._check(self.L.orbfe_image_bounds(self.h, _p(b)))
+        return b
 
     def set_input_format(self, channels=1, rgb=True, legacy_weights=False):
         """cv::cvtColor(..., COLOR_{RGB,BGR}[A]2GRAY) of Tracking::GrabImage* folded into ingest (src/Tracking.cc:269-294)."""

@@ -36,6 +36,8 @@ struct orbfe_context {
     float *h_depth_in = nullptr;  // [w*h]
     uint8_t *h_out = nullptr;     // see HostOut
     uint8_t *d_ham = nullptr;     // scratch for orbfe_hamming_matrix
+    void *d_und = nullptr;        // scratch for the undistortion entry points
+    size_t d_und_bytes = 0;
     size_t d_ham_bytes = 0;
     int last_images = 0;
     bool use_octree2 = false; // point-parallel quadtree (all levels have <= 4 roots and the LDS budget fits)
@@ -176,6 +178,8 @@ static int build_config(orbfe_context *ctx)
     c.bf = p.bf; c.fx = p.fx;
     c.mb = p.fx != 0.f ? p.bf / p.fx : 0.f; // mb := mbf / fx
     c.in_cn = 1; c.in_coef[0] = c.in_coef[1] = c.in_coef[2] = 0; c.in_shift = 15;
+    c.n_dist = 0; for (int i = 0; i < 5; i++) c.dist[i] = 0.f;
+    c.cam[0] = p.fx; c.cam[1] = p.fy; c.cam[2] = p.cx; c.cam[3] = p.cy;
 
     const double sf_d = (double)p.scale_factor; // member is double, initialised from float
     ctx->scale[0] = 1.0f; ctx->sigma2[0] = 1.0f;
@@ -550,6 +554,7 @@ extern "C" void orbfe_destroy(orbfe_context *ctx)
     if (ctx->h_depth_in) hipHostFree(ctx->h_depth_in);
     if (ctx->h_out) hipHostFree(ctx->h_out);
     if (ctx->d_ham) hipFree(ctx->d_ham);
+    if (ctx->d_und) hipFree(ctx->d_und);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -781,6 +786,70 @@ extern "C" int orbfe_set_input_format(orbfe_context *ctx, int channels, int rgb_
     ctx->cfg.in_coef[1] = cg;
     ctx->cfg.in_coef[2] = rgb_order ? cb : cr;
     ctx->cfg.in_shift = legacy_weights ? 14 : 15;
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_set_distortion(orbfe_context *ctx, const float *dist, int n)
+{
+    if (!ctx || (n != 0 && n != 4 && n != 5) || (n > 0 && !dist)) return fail(ctx, ORBFE_ERR_INVALID, "distortion needs 0, 4 or 5 coefficients (k1 k2 p1 p2 [k3])");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->cfg.n_dist = n;
+    for (int i = 0; i < 5; i++) ctx->cfg.dist[i] = i < n ? dist[i] : 0.f;
+    return ORBFE_OK;
+}
+
+// scratch for the undistortion entry points: [0, n) input keypoints, [n, 2n) output
+static int undistort_on_device(orbfe_context *ctx, const orbfe_keypoint *kps, const KeyPointPOD *d_src, int n, orbfe_keypoint *kps_un)
+{
+    if (n <= 0) return ORBFE_OK;
+    const size_t need = sizeof(KeyPointPOD) * (size_t)n * 2;
+    if (ctx->d_und_bytes < need) {
+        if (ctx->d_und) (void)hipFree(ctx->d_und);
+        ctx->d_und = nullptr; ctx->d_und_bytes = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_und, need));
+        ctx->d_und_bytes = need;
+    }
+    KeyPointPOD *d_in = (KeyPointPOD *)ctx->d_und, *d_out = d_in + n;
+    if (kps) { HIP_TRY(ctx, hipMemcpyAsync(d_in, kps, sizeof(KeyPointPOD) * n, hipMemcpyHostToDevice, ctx->stream)); d_src = d_in; }
+    orbfe_launch_undistort(ctx->cfg, d_src, d_out, n, ctx->stream);
+    HIP_TRY(ctx, hipMemcpyAsync(kps_un, d_out, sizeof(KeyPointPOD) * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_undistort_keypoints(orbfe_context *ctx, const orbfe_keypoint *kps, int n, orbfe_keypoint *kps_un)
+{
+    if (!ctx || n < 0 || (n > 0 && (!kps || !kps_un))) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
+    return undistort_on_device(ctx, kps, nullptr, n, kps_un);
+}
+
+extern "C" int orbfe_fetch_keys_un(orbfe_context *ctx, int image, orbfe_keypoint *kps_un, int cap, int *n)
+{
+    if (!ctx || image < 0 || image >= ctx->params.max_images || !n) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
+    int cnt = 0;
+    HIP_TRY(ctx, hipMemcpy(&cnt, ctx->buf.kp_cnt + image, sizeof(int), hipMemcpyDeviceToHost));
+    *n = cnt;
+    if (cnt > cap) return fail(ctx, ORBFE_ERR_CAPACITY, "caller buffer holds %d keypoints, image has %d", cap, cnt);
+    if (cnt > 0 && !kps_un) return fail(ctx, ORBFE_ERR_INVALID, "null output");
+    return undistort_on_device(ctx, nullptr, (const KeyPointPOD *)ctx->buf.kps + (size_t)image * ctx->cfg.sel_total, cnt, kps_un);
+}
+
+extern "C" int orbfe_image_bounds(orbfe_context *ctx, float *bounds)
+{
+    if (!ctx || !bounds) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
+    const float cols = (float)ctx->params.width, rows = (float)ctx->params.height;
+    if (ctx->cfg.n_dist == 0 || ctx->cfg.dist[0] == 0.0f) { // src/Frame.cc:455-461
+        bounds[0] = 0.f; bounds[1] = cols; bounds[2] = 0.f; bounds[3] = rows;
+        return ORBFE_OK;
+    }
+    orbfe_keypoint c[4] = {}, o[4];
+    c[1].x = cols; c[2].y = rows; c[3].x = cols; c[3].y = rows; // :439-442
+    const int rc = undistort_on_device(ctx, c, nullptr, 4, o);
+    if (rc != ORBFE_OK) return rc;
+    bounds[0] = std::min(o[0].x, o[2].x);
+    bounds[1] = std::max(o[1].x, o[3].x);
+    bounds[2] = std::min(o[0].y, o[1].y);
+    bounds[3] = std::max(o[2].y, o[3].y);
     return ORBFE_OK;
 }
 
@@ -1069,6 +1138,7 @@ extern "C" int orbfe_hamming_matrix(orbfe_context *ctx, const uint8_t *desc_a, i
     const size_t need = (size_t)32 * na + (size_t)32 * nb + sizeof(int) * (size_t)na * nb;
     if (need > ctx->d_ham_bytes) {
         if (ctx->d_ham) hipFree(ctx->d_ham);
+    if (ctx->d_und) hipFree(ctx->d_und);
         ctx->d_ham = nullptr; ctx->d_ham_bytes = 0;
         HIP_TRY(ctx, hipMalloc((void **)&ctx->d_ham, need));
         ctx->d_ham_bytes = need;

@@ -52,6 +52,10 @@ struct DeviceConfig {
     // input pixel format (orbfe_set_input_format): 1 = CV_8UC1; 3 / 4 = interleaved colour converted by ingest with
     // cv::cvtColor's fixed-point weights for channels 0, 1, 2 (in_coef) and in_shift fraction bits
     int in_cn, in_coef[3], in_shift;
+    // lens distortion of Frame::UndistortKeyPoints (orbfe_set_distortion): k1 k2 p1 p2 k3; n_dist == 0 or dist[0] == 0: none
+    int n_dist;
+    float dist[5];
+    float cam[4];          // fx fy cx cy
     LevelInfo lv[ORBFE_MAX_LEVELS];
 };
 
@@ -131,6 +135,7 @@ void orbfe_launch_stereo_match(const DeviceConfig &cfg, const DeviceBuffers &buf
 void orbfe_launch_stereo_median(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s);
 void orbfe_launch_rgbd(const DeviceConfig &cfg, const DeviceBuffers &buf, const float *d_depth,
                        size_t depth_pitch_floats, int image, hipStream_t s);
+void orbfe_launch_undistort(const DeviceConfig &cfg, const void *d_keys_in, void *d_keys_out, int n, hipStream_t s);
 void orbfe_launch_rgbd_u16(const DeviceConfig &cfg, const DeviceBuffers &buf, const uint16_t *d_depth, size_t depth_pitch_px,
                            float factor, int image, hipStream_t s);
 void orbfe_launch_hamming_matrix(const uint8_t *da, int na, const uint8_t *db, int nb, int *dist, hipStream_t s);

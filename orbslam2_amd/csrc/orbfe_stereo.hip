@@ -237,6 +237,45 @@ __global__ __launch_bounds__(256) void stereo_median_kernel(DeviceConfig cfg, De
 }
 
 // Frame::ComputeStereoFromRGBD (src/Frame.cc:645-666), undistorted camera
+// cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK) of Frame::UndistortKeyPoints (src/Frame.cc:402-432):
+// five fixed-point iterations in double (the overload's TermCriteria(MAX_ITER, 5, 0.01)), K and D widened from float,
+// re-projection with P = K.  Plain IEEE double operations in the oracle's order: bit-exact.  OPENCV-4.5.5-SEMANTICS.
+__device__ inline void undistort_point(const DeviceConfig &cfg, float uf, float vf, float &uo, float &vo)
+{
+    if (cfg.n_dist == 0 || cfg.dist[0] == 0.0f) { uo = uf; vo = vf; return; } // :404-408
+    const double k0 = cfg.dist[0], k1 = cfg.dist[1], k2 = cfg.dist[2], k3 = cfg.dist[3], k4 = cfg.n_dist > 4 ? (double)cfg.dist[4] : 0.0;
+    const double fx = cfg.cam[0], fy = cfg.cam[1], cx = cfg.cam[2], cy = cfg.cam[3], ifx = 1. / fx, ify = 1. / fy;
+    const double u = uf, v = vf;
+    double x = (u - cx) * ifx, y = (v - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((0.0 * r2 + 0.0) * r2 + 0.0) * r2) / (1 + ((k4 * r2 + k1) * r2 + k0) * r2);
+        if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+        const double deltaX = 2 * k2 * x * y + k3 * (r2 + 2 * x * x) + 0.0 * r2 + 0.0 * r2 * r2;
+        const double deltaY = k2 * (r2 + 2 * y * y) + 2 * k3 * x * y + 0.0 * r2 + 0.0 * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = fx * x + 0.0 * y + cx, yy = 0.0 * x + fy * y + cy, ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+    uo = (float)(xx * ww);
+    vo = (float)(yy * ww);
+}
+
+__global__ __launch_bounds__(256) void undistort_kernel(DeviceConfig cfg, const KeyPointPOD *__restrict__ in, KeyPointPOD *__restrict__ out, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    KeyPointPOD kp = in[i];
+    undistort_point(cfg, kp.x, kp.y, kp.x, kp.y);
+    out[i] = kp;
+}
+
+void orbfe_launch_undistort(const DeviceConfig &cfg, const void *d_keys_in, void *d_keys_out, int n, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(undistort_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cfg, (const KeyPointPOD *)d_keys_in, (KeyPointPOD *)d_keys_out, n);
+}
+
 // T = float: the CV_32F map Frame::Frame receives.  T = uint16_t: the sensor's raw map; the conversion of
 // Tracking::GrabImageRGBD (src/Tracking.cc:323-324, convertTo(CV_32F, mDepthMapFactor): one rounded float multiply)
 // is applied to the sampled pixel only.
@@ -254,7 +293,12 @@ __global__ __launch_bounds__(256) void rgbd_kernel(DeviceConfig cfg, DeviceBuffe
         float d;
         if constexpr (sizeof(T) == 2) d = __fmul_rn((float)depth_img[(size_t)v * pitch_floats + uu], factor);
         else d = depth_img[(size_t)v * pitch_floats + uu];
-        if (d > 0) { dp = d; u = __fsub_rn(kp.x, __fdiv_rn(cfg.bf, d)); }
+        if (d > 0) { // depth is read at the distorted keypoint, uRight is built from the undistorted x (src/Frame.cc:652-664)
+            float xu, yu;
+            undistort_point(cfg, kp.x, kp.y, xu, yu);
+            dp = d;
+            u = __fsub_rn(xu, __fdiv_rn(cfg.bf, d));
+        }
     }
     buf.u_right[(size_t)img * cfg.sel_total + i] = u;
     buf.depth[(size_t)img * cfg.sel_total + i] = dp;

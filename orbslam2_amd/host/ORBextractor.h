@@ -40,6 +40,8 @@ struct ImageView {
 
 struct CameraParams {
     float fx = 0.f, fy = 0.f, cx = 0.f, cy = 0.f, bf = 0.f;
+    std::vector<float> distCoef; // Tracking's mDistCoef: k1 k2 p1 p2 [k3] (src/Tracking.cc:67-78); empty = none
+    bool rgb = true;             // Tracking's mbRGB (colour input order)
 };
 
 class ORBextractor
@@ -151,7 +153,23 @@ public:
         mParams.fx = mCam.fx; mParams.fy = mCam.fy; mParams.cx = mCam.cx; mParams.cy = mCam.cy; mParams.bf = mCam.bf;
         const int rc = orbfe_create(&mParams, &mCtx);
         if (rc != ORBFE_OK) throw std::runtime_error(std::string("orbfe_create: ") + orbfe_last_error(nullptr));
+        if (!mCam.distCoef.empty()) Check(orbfe_set_distortion(mCtx, mCam.distCoef.data(), (int)mCam.distCoef.size()));
     }
+
+    // Frame::UndistortKeyPoints (src/Frame.cc:402-432) and ComputeImageBounds (:434-462) for this camera
+    void UndistortKeyPoints(const std::vector<orbfe_keypoint> &vKeys, std::vector<orbfe_keypoint> &vKeysUn)
+    {
+        vKeysUn.resize(vKeys.size());
+        Check(orbfe_undistort_keypoints(mCtx, vKeys.data(), (int)vKeys.size(), vKeysUn.data()));
+    }
+    void ComputeImageBounds(float &mnMinX, float &mnMaxX, float &mnMinY, float &mnMaxY)
+    {
+        float b[4];
+        Check(orbfe_image_bounds(mCtx, b));
+        mnMinX = b[0]; mnMaxX = b[1]; mnMinY = b[2]; mnMaxY = b[3];
+    }
+    // Tracking::GrabImage*'s cvtColor (src/Tracking.cc:269-294): feed 3- / 4-channel frames as they are
+    void SetInputChannels(int channels) { Check(orbfe_set_input_format(mCtx, channels, mCam.rgb ? 1 : 0, 0)); }
 
 protected:
     void Check(int rc)
@@ -209,6 +227,39 @@ inline void ComputeStereoFrame(ORBextractor &extractorLeft, const ImageView &imL
     out.mvKeys.resize(nl); out.mDescriptors.resize((size_t)nl * 32);
     out.mvKeysRight.resize(nr); out.mDescriptorsRight.resize((size_t)nr * 32);
     out.mvuRight.resize(nl); out.mvDepth.resize(nl);
+}
+
+// Frame::Frame(rgbd) (src/Frame.cc:120-172): ExtractORB, UndistortKeyPoints, ComputeStereoFromRGBD.  imDepth is the CV_32F
+// map the constructor receives; the u16 overload takes the sensor's raw map and Tracking's mDepthMapFactor
+// (src/Tracking.cc:323-324).
+struct RGBDFrameOutput {
+    std::vector<orbfe_keypoint> mvKeys, mvKeysUn;
+    std::vector<uint8_t> mDescriptors;
+    std::vector<float> mvuRight, mvDepth;
+    int N = 0;
+};
+
+inline void ComputeRGBDFrame(ORBextractor &extractor, const ImageView &imGray, const void *imDepth, size_t depthStep, bool depthIsU16,
+                             float depthMapFactor, RGBDFrameOutput &out)
+{
+    if (imGray.empty() || !imDepth) { out = RGBDFrameOutput(); return; }
+    extractor.EnsureContext(imGray.cols, imGray.rows, 1);
+    orbfe_context *ctx = extractor.Context();
+    const int cap = orbfe_keypoint_capacity(ctx);
+    out.mvKeys.resize(cap); out.mvKeysUn.resize(cap); out.mDescriptors.resize((size_t)cap * 32);
+    out.mvuRight.assign(cap, -1.0f); out.mvDepth.assign(cap, -1.0f);
+    int n = 0, n2 = 0;
+    const int rc = depthIsU16
+        ? orbfe_rgbd_frame_u16(ctx, imGray.data, (const uint16_t *)imDepth, depthMapFactor, imGray.cols, imGray.rows, imGray.step, depthStep,
+                               out.mvKeys.data(), out.mDescriptors.data(), &n, out.mvuRight.data(), out.mvDepth.data(), cap)
+        : orbfe_rgbd_frame(ctx, imGray.data, (const float *)imDepth, imGray.cols, imGray.rows, imGray.step, depthStep,
+                           out.mvKeys.data(), out.mDescriptors.data(), &n, out.mvuRight.data(), out.mvDepth.data(), cap);
+    if (rc != ORBFE_OK) throw std::runtime_error(std::string("orbfe_rgbd_frame: ") + orbfe_last_error(ctx));
+    if (orbfe_fetch_keys_un(ctx, 0, out.mvKeysUn.data(), cap, &n2) != ORBFE_OK || n2 != n)
+        throw std::runtime_error(std::string("orbfe_fetch_keys_un: ") + orbfe_last_error(ctx));
+    out.N = n;
+    out.mvKeys.resize(n); out.mvKeysUn.resize(n); out.mDescriptors.resize((size_t)n * 32);
+    out.mvuRight.resize(n); out.mvDepth.resize(n);
 }
 
 } // namespace ORB_SLAM2

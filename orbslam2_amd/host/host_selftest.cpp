@@ -9,6 +9,7 @@
 
 #include "ORBextractor.h"
 #include "ORBmatcher.h"
+#include <cstring>
 #include "KeyFrameDatabase.h"
 #include "Optimizer.h"
 
@@ -87,6 +88,20 @@ int main(int argc, char **argv)
             dump(prefix + ".Tcw", std::vector<float>(Tcw, Tcw + 16)); dump(prefix + ".outl", outlier);
             dump(prefix + ".has", has); dump(prefix + ".Xw", Xw);
             std::printf("pose inliers=%d\n", nInl);
+        }
+        // RGB-D frame mirror on a distorted camera (TUM1 coefficients): constant 2 m depth map
+        {
+            ORB_SLAM2::ORBextractor rgbd(nf, 1.2f, 8, 20, 7, 31, 15, 19);
+            ORB_SLAM2::CameraParams c2 = cam;
+            c2.distCoef = {0.262383f, -0.953104f, -0.005358f, 0.002628f, 1.163314f};
+            rgbd.SetCamera(c2);
+            std::vector<float> depth((size_t)w * h, 2.0f);
+            ORB_SLAM2::RGBDFrameOutput ro;
+            ORB_SLAM2::ComputeRGBDFrame(rgbd, ORB_SLAM2::ImageView{left.data(), w, h, (size_t)w}, depth.data(), sizeof(float) * w, false, 1.0f, ro);
+            float b[4];
+            rgbd.ComputeImageBounds(b[0], b[1], b[2], b[3]);
+            dump(prefix + ".kun", ro.mvKeysUn); dump(prefix + ".urd", ro.mvuRight); dump(prefix + ".bounds", std::vector<float>(b, b + 4));
+            if (ro.mvKeys.size() != out.mvKeys.size() || std::memcmp(ro.mvKeys.data(), out.mvKeys.data(), sizeof(orbfe_keypoint) * ro.mvKeys.size()) != 0) { std::cerr << "rgbd keypoints differ from the stereo left image\n"; return 7; }
         }
         std::printf("N=%d NR=%zu levels=%d scale1=%.9g\n", out.N, out.mvKeysRight.size(), extractorLeft.GetLevels(),
                     (double)extractorLeft.GetScaleFactors()[1]);

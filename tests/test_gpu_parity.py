@@ -258,3 +258,48 @@ def test_colour_input_is_converted_like_cvtcolor(cn, rgb, legacy):
     for k in ref:
         assert np.array_equal(out3[k], ref[k]), k
     ctx.close()
+
+
+TUM1_DIST = [0.262383, -0.953104, -0.005358, 0.002628, 1.163314]     # Config/RGB-D-TUM1.yaml
+D435I_DIST = [9.8300891329190163e-02, 2.9249092034088525e-01, 0.0, 0.0, -1.6417657631343097e+00]  # Config/RealSense-D435i-RGBD.yaml
+
+
+@pytest.mark.parametrize("name,dist", [("tum1", TUM1_DIST), ("d435i", D435I_DIST), ("tum1-4", TUM1_DIST[:4])])
+def test_undistortion_matches_oracle(name, dist):
+    """Frame::UndistortKeyPoints / ComputeImageBounds (src/Frame.cc:402-462): cv::undistortPoints in double on the device,
+    bit for bit; RGB-D uRight from the undistorted x (:652-664)."""
+    cfg = TUM1 if name.startswith("tum1") else D435I
+    ctx = _ctx(cfg, max_images=1)
+    ctx.set_distortion(dist)
+    rng = np.random.default_rng(4)
+    k = np.zeros(5000, O.KP_DTYPE)
+    k["x"] = rng.uniform(-5, cfg["width"] + 5, 5000); k["y"] = rng.uniform(-5, cfg["height"] + 5, 5000)
+    k["x"][:4] = [0, cfg["width"], 0, cfg["width"]]; k["y"][:4] = [0, 0, cfg["height"], cfg["height"]]
+    k["octave"] = rng.integers(0, 8, 5000); k["angle"] = rng.uniform(0, 360, 5000); k["size"] = 31; k["response"] = 40; k["class_id"] = -1
+    ref = O.undistort_points(np.stack([k["x"], k["y"]], 1), cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], dist)
+    got = ctx.undistort_keypoints(k)
+    assert np.array_equal(got["x"], ref[:, 0]) and np.array_equal(got["y"], ref[:, 1])
+    for f in ("size", "angle", "response", "octave", "class_id"):
+        assert np.array_equal(got[f], k[f])
+    assert np.abs(got["x"] - k["x"]).max() > 1.0
+    assert np.array_equal(ctx.image_bounds(), O.image_bounds(cfg["width"], cfg["height"], cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], dist))
+    # RGB-D frame: depth sampled at the distorted keypoint, uRight from the undistorted x
+    left, _, depth = synth.stereo_pair(cfg["width"], cfg["height"], seed=31, with_depth=True, bf=cfg["bf"])
+    out = ctx.rgbd_frame(left, depth)
+    ex = O.Extractor(nfeatures=cfg["nfeatures"])
+    kk, dd = ex.extract(left)
+    und = O.undistort_points(np.stack([kk["x"], kk["y"]], 1), cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], dist)
+    kun = kk.copy(); kun["x"], kun["y"] = und[:, 0], und[:, 1]
+    ur, dp = O.stereo_from_rgbd(kk, kun, depth, cfg["bf"])
+    _assert_kps_equal(out["kps"], kk, "rgbd distorted")
+    assert np.array_equal(out["u_right"], ur) and np.array_equal(out["depth"], dp)
+    ur0, _ = O.stereo_from_rgbd(kk, kk, depth, cfg["bf"])
+    assert not np.array_equal(ur, ur0)
+    got_un = ctx.fetch_keys_un(0)
+    assert np.array_equal(got_un, kun)
+    # k1 == 0 => identity, bounds = image
+    ctx.set_distortion([0.0, 0.3, 0.0, 0.0])
+    assert np.array_equal(ctx.undistort_keypoints(k), k) and ctx.image_bounds().tolist() == [0, cfg["width"], 0, cfg["height"]]
+    ctx.set_distortion([])
+    assert np.array_equal(ctx.rgbd_frame(left, depth)["u_right"], ur0)
+    ctx.close()

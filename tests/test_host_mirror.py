@@ -54,3 +54,10 @@ def test_cpp_selftest_matches_oracle(tmp_path):
     assert ("pose inliers=%d" % nr) in r.stdout and nr > 50
     assert np.array_equal(np.fromfile(pre + ".outl", np.uint8), outr)
     assert np.abs(Tg - Tr).max() <= 2e-6 and np.abs(Tg - np.eye(4)).max() < 2e-3
+    # RGB-D mirror on a distorted camera
+    dist = [0.262383, -0.953104, -0.005358, 0.002628, 1.163314]
+    und = O.undistort_points(np.stack([kl["x"], kl["y"]], 1), fx, fx, w * 0.5, h * 0.5, dist)
+    kun = kl.copy(); kun["x"], kun["y"] = und[:, 0], und[:, 1]
+    urd, _ = O.stereo_from_rgbd(kl, kun, np.full((h, w), 2.0, np.float32), bf)
+    assert np.array_equal(np.fromfile(pre + ".kun", O.KP_DTYPE), kun) and np.array_equal(np.fromfile(pre + ".urd", np.float32), urd)
+    assert np.array_equal(np.fromfile(pre + ".bounds", np.float32), O.image_bounds(w, h, fx, fx, w * 0.5, h * 0.5, dist))

@@ -294,3 +294,28 @@ def test_cvt_gray_known_answers():
     r = rng.integers(0, 256, (7, 13, 3), dtype=np.uint8)
     f = 0.299 * r[..., 0] + 0.587 * r[..., 1] + 0.114 * r[..., 2]
     assert np.abs(O.cvt_gray(r).astype(float) - f).max() <= 0.51 + 1e-9         # within half a grey level + weight rounding
+
+
+def test_undistort_points_known_answers():
+    """cv::undistortPoints(pts, K, D, Mat(), K): inverting the Brown-Conrady forward model (TUM1 coefficients,
+    Config/RGB-D-TUM1.yaml) recovers the ideal pixel; zero coefficients are the identity up to the float round trip."""
+    fx, fy, cx, cy = 517.3, 516.5, 318.6, 255.3
+    D = [0.262383, -0.953104, -0.005358, 0.002628, 1.163314]
+    xs = np.linspace(-0.5, 0.5, 9)
+    X, Y = np.meshgrid(xs, xs * 0.75)
+    x, y = X.ravel(), Y.ravel()
+    r2 = x * x + y * y
+    k1, k2, p1, p2, k3 = D
+    cd = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+    xd = x * cd + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * cd + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    pix = np.stack([fx * xd + cx, fy * yd + cy], 1).astype(np.float32)
+    ideal = np.stack([fx * x + cx, fy * y + cy], 1)
+    und = O.undistort_points(pix, fx, fy, cx, cy, D)
+    assert np.abs(pix - ideal).max() > 5 and np.abs(und - ideal).max() < 2e-3   # five iterations: converged to ~1e-4 px here
+    same = O.undistort_points(pix, fx, fy, cx, cy, [0, 0, 0, 0])
+    assert np.abs(same - pix).max() < 1e-4
+    b = O.image_bounds(640, 480, fx, fy, cx, cy, D)
+    assert b[0] > 0 and b[1] < 640 and b[2] > 0 and b[3] < 480                  # pincushion-free TUM1: the corners move inwards
+    assert O.image_bounds(640, 480, fx, fy, cx, cy, [0, 0, 0, 0]).tolist() == [0, 640, 0, 480]
+    assert O.image_bounds(640, 480, fx, fy, cx, cy, [0, 0.5, 0, 0]).tolist() == [0, 640, 0, 480]  # k1 == 0: the reference skips undistortion
