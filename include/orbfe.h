@@ -118,6 +118,14 @@ int orbfe_fetch_keys_un(orbfe_context *ctx, int image, orbfe_keypoint *kps_un, i
 /* bounds[4] = mnMinX, mnMaxX, mnMinY, mnMaxY for the context's image size. */
 int orbfe_image_bounds(orbfe_context *ctx, float *bounds);
 
+/* Stereo rectification in front of the pipeline: level 0 = cv::remap(raw, map1, map2, INTER_LINEAR) as the EuRoC
+ * drivers do before TrackStereo (Test/Replay/Stereo/stereo_euroc.cc:98-99,136-137).  map_x / map_y are the CV_32FC1 maps
+ * of cv::initUndistortRectifyMap (width x height of the context, row major); src_w x src_h is the raw image size the
+ * entry points then expect (host and device-resident: [image][src_h][src_w] bytes).  side 0 = left / monocular, side 1 =
+ * right (slot parity of orbfe_*_stereo); without a right map every image uses the left one.  NULL maps clear a side
+ * (side 0: rectification off).  Single-channel input only. */
+int orbfe_set_rectification(orbfe_context *ctx, int side, const float *map_x, const float *map_y, int src_w, int src_h);
+
 /* Frame::Frame(rgbd) body (src/Frame.cc:120-172) for an undistorted camera:
  * ExtractORB + ComputeStereoFromRGBD (src/Frame.cc:645-666).  depth_img is CV_32F
  * metres, row stride in bytes.  uRight uses the undistorted x when orbfe_set_distortion gave k1 != 0. */

@@ -465,3 +465,16 @@ def image_bounds(cols, rows, fx, fy, cx, cy, dist):
     L.orc_image_bounds.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p]
     L.orc_image_bounds(cols, rows, fx, fy, cx, cy, _ptr(d), len(d), _ptr(out))
     return out
+
+
+def remap_bilinear(src, mapx, mapy):
+    """cv::remap(src, map1, map2, INTER_LINEAR) for uint8 HxW, float32 maps (EuRoC rectification)."""
+    a = np.ascontiguousarray(src, np.uint8); mx = np.ascontiguousarray(mapx, np.float32); my = np.ascontiguousarray(mapy, np.float32)
+    assert mx.shape == my.shape
+    dh, dw = mx.shape
+    out = np.zeros((dh, dw), np.uint8)
+    L = lib()
+    L.orc_remap_bilinear.restype = None
+    L.orc_remap_bilinear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    L.orc_remap_bilinear(_ptr(a), a.shape[1], a.shape[0], a.strides[0], _ptr(mx), _ptr(my), dw, dh, _ptr(out), out.strides[0])
+    return out

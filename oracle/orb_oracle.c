@@ -1147,3 +1147,41 @@ void orc_image_bounds(int cols, int rows, float fx, float fy, float cx, float cy
         bounds[0] = 0.f; bounds[1] = (float)cols; bounds[2] = 0.f; bounds[3] = (float)rows;
     }
 }
+
+
+/* cv::remap(src, dst, map1, map2, INTER_LINEAR) for CV_8UC1 with CV_32FC1 maps and the default BORDER_CONSTANT / Scalar()
+ * (EuRoC rectification, Test/Replay/Stereo/stereo_euroc.cc:136-137, maps from initUndistortRectifyMap :98-99).
+ * OPENCV-4.5.5-SEMANTICS (imgproc/src/imgwarp.cpp RemapInvoker + remapBilinear<FixedPtCast<int, uchar, 15>>): the float
+ * maps become fixed point with 5 fraction bits, sx = cvRound(mapx * 32) (integer part saturated to short); the four taps
+ * are weighted with BilinearTab_i = {(32-fx)(32-fy), fx(32-fy), (32-fx)fy, fx*fy} * 32 (exact integers, sum 2^15, so the
+ * table's sum-correction step never fires) and the result is (sum + 2^14) >> 15.  A tap outside the source reads 0; a
+ * destination pixel whose whole 2x2 footprint is outside is 0. */
+static short sat_short(int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+
+void orc_remap_fixed(const float *mapx, const float *mapy, int n, int16_t *sx, int16_t *sy, uint16_t *alpha)
+{
+    for (int i = 0; i < n; i++) {
+        const int ix = orc_cv_round_f(mapx[i] * 32.0f), iy = orc_cv_round_f(mapy[i] * 32.0f);
+        sx[i] = sat_short(ix >> 5);
+        sy[i] = sat_short(iy >> 5);
+        alpha[i] = (uint16_t)((iy & 31) * 32 + (ix & 31));
+    }
+}
+
+void orc_remap_bilinear(const uint8_t *src, int sw, int sh, size_t sstride, const float *mapx, const float *mapy,
+                        int dw, int dh, uint8_t *dst, size_t dstride)
+{
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            int16_t sx, sy; uint16_t a;
+            orc_remap_fixed(mapx + (size_t)y * dw + x, mapy + (size_t)y * dw + x, 1, &sx, &sy, &a);
+            const int fx = a & 31, fy = a >> 5;
+            const int w[4] = {(32 - fx) * (32 - fy) * 32, fx * (32 - fy) * 32, (32 - fx) * fy * 32, fx * fy * 32};
+            int v[4];
+            for (int k = 0; k < 4; k++) {
+                const int xx = sx + (k & 1), yy = sy + (k >> 1);
+                v[k] = (xx >= 0 && xx < sw && yy >= 0 && yy < sh) ? src[(size_t)yy * sstride + xx] : 0;
+            }
+            dst[(size_t)y * dstride + x] = (uint8_t)((v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3] + (1 << 14)) >> 15);
+        }
+}

@@ -58,6 +58,11 @@ void orc_cvt_gray(const uint8_t *src, int w, int h, size_t stride, int cn, int r
 void orc_undistort_points(const float *src_xy, int n, float fx, float fy, float cx, float cy, const float *dist, int ndist, float *dst_xy);
 void orc_image_bounds(int cols, int rows, float fx, float fy, float cx, float cy, const float *dist, int ndist, float *bounds);
 
+/* cv::remap(..., INTER_LINEAR), 8UC1, float maps, constant zero border (Test/Replay/Stereo/stereo_euroc.cc:136-137) */
+void orc_remap_fixed(const float *mapx, const float *mapy, int n, int16_t *sx, int16_t *sy, uint16_t *alpha);
+void orc_remap_bilinear(const uint8_t *src, int sw, int sh, size_t sstride, const float *mapx, const float *mapy,
+                        int dw, int dh, uint8_t *dst, size_t dstride);
+
 /* ---- scalar helpers (OpenCV semantics) ---- */
 int orc_cv_round_f(float v);            /* cvRound(float): round-half-even */
 int orc_cv_round_d(double v);           /* cvRound(double) */

@@ -31,7 +31,7 @@ EXPORTS = [
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_kf", "orbfe_search_for_initialization",
     "orbfe_vocab_load", "orbfe_bow_transform", "orbfe_bow_maps", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",  # bound in orbslam2_amd/bow.py
     "orbfe_search_for_triangulation", "orbfe_fuse", "orbfe_search_by_projection_sim3", "orbfe_fuse_sim3", "orbfe_search_by_sim3", "orbfe_kfdb_clear", "orbfe_kfdb_add", "orbfe_kfdb_erase", "orbfe_kfdb_size", "orbfe_kfdb_score", "orbfe_detect_reloc_candidates",
-    "orbfe_pose_optimization", "orbfe_pose_optimization_batch", "orbfe_enqueue_pose_optimization", "orbfe_set_input_format", "orbfe_set_distortion", "orbfe_undistort_keypoints", "orbfe_fetch_keys_un", "orbfe_image_bounds",
+    "orbfe_pose_optimization", "orbfe_pose_optimization_batch", "orbfe_enqueue_pose_optimization", "orbfe_set_input_format", "orbfe_set_rectification", "orbfe_set_distortion", "orbfe_undistort_keypoints", "orbfe_fetch_keys_un", "orbfe_image_bounds",
 ]
 NUM_STAGES = 8
 STAGE_NAMES = ["ingest", "pyramid", "blur", "fast", "octree", "describe", "stereo_match", "stereo_median"]  # orbfe_stage_name()
@@ -142,6 +142,8 @@ def load():
     L.orbfe_fetch_keys_un.argtypes = [vp, C.c_int, vp, C.c_int, ip]
     L.orbfe_image_bounds.restype = C.c_int
     L.orbfe_image_bounds.argtypes = [vp, vp]
+    L.orbfe_set_rectification.restype = C.c_int
+    L.orbfe_set_rectification.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int]
     L.orbfe_set_input_format.restype = C.c_int
     L.orbfe_set_input_format.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.orbfe_pose_optimization.restype = C.c_int
@@ -240,6 +242,16 @@ class Context:
         b = np.zeros(4, np.float32)
         self._check(self.L.orbfe_image_bounds(self.h, _p(b)))
         return b
+
+    def set_rectification(self, side, map_x=None, map_y=None, src_size=None):
+        """cv::remap(raw, map1, map2, INTER_LINEAR) in front of the pipeline (stereo_euroc.cc:136-137); None clears."""
+        if map_x is None:
+            self._check(self.L.orbfe_set_rectification(self.h, side, None, None, 0, 0))
+            return
+        mx = np.ascontiguousarray(map_x, np.float32); my = np.ascontiguousarray(map_y, np.float32)
+        assert mx.shape == my.shape
+        sw, sh = src_size if src_size is not None else (mx.shape[1], mx.shape[0])
+        self._check(self.L.orbfe_set_rectification(self.h, side, _p(mx), _p(my), sw, sh))
 
     def set_input_format(self, channels=1, rgb=True, legacy_weights=False):
         """cv::cvtColor(..., COLOR_{RGB,BGR}[A]2GRAY) of Tracking::GrabImage* folded into ingest (src/Tracking.cc:269-294)."""

@@ -178,6 +178,8 @@ static int build_config(orbfe_context *ctx)
     c.bf = p.bf; c.fx = p.fx;
     c.mb = p.fx != 0.f ? p.bf / p.fx : 0.f; // mb := mbf / fx
     c.in_cn = 1; c.in_coef[0] = c.in_coef[1] = c.in_coef[2] = 0; c.in_shift = 15;
+    c.in_image_bytes = (size_t)p.width * p.height;
+    c.rm_on = 0; c.rm_sw = c.rm_sh = 0; c.rm_xy[0] = c.rm_xy[1] = nullptr; c.rm_a[0] = c.rm_a[1] = nullptr;
     c.n_dist = 0; for (int i = 0; i < 5; i++) c.dist[i] = 0.f;
     c.cam[0] = p.fx; c.cam[1] = p.fy; c.cam[2] = p.cx; c.cam[3] = p.cy;
 
@@ -554,6 +556,7 @@ extern "C" void orbfe_destroy(orbfe_context *ctx)
     if (ctx->h_depth_in) hipHostFree(ctx->h_depth_in);
     if (ctx->h_out) hipHostFree(ctx->h_out);
     if (ctx->d_ham) hipFree(ctx->d_ham);
+    for (int sd = 0; sd < 2; sd++) { if (ctx->cfg.rm_xy[sd]) hipFree((void *)ctx->cfg.rm_xy[sd]); if (ctx->cfg.rm_a[sd]) hipFree((void *)ctx->cfg.rm_a[sd]); }
     if (ctx->d_und) hipFree(ctx->d_und);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -671,7 +674,7 @@ static void run_chain(orbfe_context *ctx, const uint8_t *d_images, int img0, int
 {
     const DeviceConfig &cfg = ctx->cfg;
     const DeviceBuffers buf = shift_buffers(ctx->buf, cfg, img0);
-    const uint8_t *src = d_images + (size_t)img0 * cfg.width * cfg.height * cfg.in_cn;
+    const uint8_t *src = d_images + (size_t)img0 * cfg.in_image_bytes;
     prof_mark(ctx, group, 0, s);
     orbfe_launch_ingest(cfg, buf, src, n_images, s);
     prof_mark(ctx, group, 1, s);
@@ -764,20 +767,74 @@ extern "C" int orbfe_enqueue_stereo(orbfe_context *ctx, const uint8_t *d_images,
     return enqueue_batch(ctx, d_images, n_pairs, 2, stream);
 }
 
+// the staging of the host entry points is sized by the input format: one packed image = image_bytes
+static int resize_input_staging(orbfe_context *ctx, size_t image_bytes)
+{
+    uint8_t *nd = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&nd, (size_t)ctx->params.max_images * image_bytes));
+    for (void *&q : ctx->allocs)
+        if (q == ctx->d_in) q = nd;
+    (void)hipFree(ctx->d_in);
+    ctx->d_in = nd;
+    if (ctx->h_in) { (void)hipHostFree(ctx->h_in); ctx->h_in = nullptr; }
+    ctx->cfg.in_image_bytes = image_bytes;
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_set_rectification(orbfe_context *ctx, int side, const float *map_x, const float *map_y, int src_w, int src_h)
+{
+    if (!ctx || side < 0 || side > 1) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    DeviceConfig &c = ctx->cfg;
+    if (!map_x || !map_y) { // clear this side; the left side switches rectification off
+        if (c.rm_xy[side]) { (void)hipFree((void *)c.rm_xy[side]); (void)hipFree((void *)c.rm_a[side]); c.rm_xy[side] = nullptr; c.rm_a[side] = nullptr; }
+        if (side == 0 && c.rm_on) {
+            if (c.rm_xy[1]) { (void)hipFree((void *)c.rm_xy[1]); (void)hipFree((void *)c.rm_a[1]); c.rm_xy[1] = nullptr; c.rm_a[1] = nullptr; }
+            c.rm_on = 0;
+            return resize_input_staging(ctx, (size_t)ctx->params.width * ctx->params.height * c.in_cn);
+        }
+        return ORBFE_OK;
+    }
+    if (c.in_cn != 1) return fail(ctx, ORBFE_ERR_UNSUPPORTED, "rectification takes single-channel input");
+    if (src_w < 1 || src_h < 1 || src_w > 32767 || src_h > 32767) return fail(ctx, ORBFE_ERR_INVALID, "bad source size");
+    if (side == 1 && !c.rm_on) return fail(ctx, ORBFE_ERR_INVALID, "set the left (side 0) maps first");
+    if (c.rm_on && (src_w != c.rm_sw || src_h != c.rm_sh)) {
+        if (side == 1 || c.rm_xy[1]) return fail(ctx, ORBFE_ERR_UNSUPPORTED, "both sides must share one source size");
+    }
+    // RemapInvoker's conversion of the float maps (imgwarp.cpp): sx = cvRound(mapx * INTER_TAB_SIZE), integer part
+    // saturated to short, fraction index = (sy & 31) * 32 + (sx & 31)
+    const size_t n = (size_t)ctx->params.width * ctx->params.height;
+    std::vector<uint32_t> xy(n);
+    std::vector<uint16_t> al(n);
+    for (size_t i = 0; i < n; i++) {
+        const int ix = (int)lrintf(map_x[i] * 32.0f), iy = (int)lrintf(map_y[i] * 32.0f);
+        const int sx = std::min(std::max(ix >> 5, -32768), 32767), sy = std::min(std::max(iy >> 5, -32768), 32767);
+        xy[i] = (uint32_t)(uint16_t)(int16_t)sx | ((uint32_t)(uint16_t)(int16_t)sy << 16);
+        al[i] = (uint16_t)((iy & 31) * 32 + (ix & 31));
+    }
+    uint32_t *dxy = nullptr; uint16_t *da = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&dxy, n * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc((void **)&da, n * sizeof(uint16_t)));
+    HIP_TRY(ctx, hipMemcpy(dxy, xy.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(da, al.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice));
+    if (c.rm_xy[side]) { (void)hipFree((void *)c.rm_xy[side]); (void)hipFree((void *)c.rm_a[side]); }
+    c.rm_xy[side] = dxy; c.rm_a[side] = da;
+    if (side == 0) {
+        c.rm_on = 1; c.rm_sw = src_w; c.rm_sh = src_h;
+        return resize_input_staging(ctx, (size_t)src_w * src_h);
+    }
+    return ORBFE_OK;
+}
+
 extern "C" int orbfe_set_input_format(orbfe_context *ctx, int channels, int rgb_order, int legacy_weights)
 {
     if (!ctx) return ORBFE_ERR_INVALID;
     if (channels != 1 && channels != 3 && channels != 4) return fail(ctx, ORBFE_ERR_INVALID, "channels must be 1, 3 or 4");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (channels != ctx->cfg.in_cn) { // the staging of the host entry points is sized by the format
-        const size_t need = (size_t)ctx->params.max_images * ctx->params.width * ctx->params.height * channels;
-        uint8_t *nd = nullptr;
-        HIP_TRY(ctx, hipMalloc((void **)&nd, need));
-        for (void *&q : ctx->allocs)
-            if (q == ctx->d_in) q = nd;
-        (void)hipFree(ctx->d_in);
-        ctx->d_in = nd;
-        if (ctx->h_in) { (void)hipHostFree(ctx->h_in); ctx->h_in = nullptr; }
+    if (ctx->cfg.rm_on && channels != 1) return fail(ctx, ORBFE_ERR_UNSUPPORTED, "rectification takes single-channel input");
+    if (channels != ctx->cfg.in_cn) {
+        const int rc = resize_input_staging(ctx, (size_t)ctx->params.width * ctx->params.height * channels);
+        if (rc != ORBFE_OK) return rc;
     }
     // color_rgb.simd.hpp RGB2Gray<uchar>: RY15 / GY15 / BY15 with 15 fraction bits; OpenCV 3.x: R2Y / G2Y / B2Y with 14
     const int cr = legacy_weights ? 4899 : 9798, cg = legacy_weights ? 9617 : 19235, cb = legacy_weights ? 1868 : 3735;
@@ -928,7 +985,7 @@ static HostOut host_out_layout(const orbfe_context *ctx)
 static int ensure_host_stage(orbfe_context *ctx, bool want_depth)
 {
     const size_t px = (size_t)ctx->params.width * ctx->params.height, ni = ctx->params.max_images < 2 ? 1 : 2;
-    if (!ctx->h_in) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_in, ni * px * ctx->cfg.in_cn, hipHostMallocDefault));
+    if (!ctx->h_in) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_in, ni * ctx->cfg.in_image_bytes, hipHostMallocDefault));
     if (!ctx->h_out) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_out, host_out_layout(ctx).bytes, hipHostMallocDefault));
     if (want_depth && !ctx->h_depth_in) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_depth_in, px * sizeof(float), hipHostMallocDefault));
     if (want_depth && !ctx->d_depth_in) HIP_TRY(ctx, hipMalloc((void **)&ctx->d_depth_in, px * sizeof(float)));
@@ -948,8 +1005,9 @@ static int stage_rows(orbfe_context *ctx, void *d_dst, uint8_t *h_stage, const v
 
 static int upload_image(orbfe_context *ctx, int slot, const uint8_t *img, int w, int h, size_t stride)
 {
-    if (w != ctx->params.width || h != ctx->params.height)
-        return fail(ctx, ORBFE_ERR_UNSUPPORTED, "image is %dx%d, context was built for %dx%d", w, h, ctx->params.width, ctx->params.height);
+    const int ew = ctx->cfg.rm_on ? ctx->cfg.rm_sw : ctx->params.width, eh = ctx->cfg.rm_on ? ctx->cfg.rm_sh : ctx->params.height;
+    if (w != ew || h != eh)
+        return fail(ctx, ORBFE_ERR_UNSUPPORTED, "image is %dx%d, context expects %dx%d%s", w, h, ew, eh, ctx->cfg.rm_on ? " (unrectified source size)" : "");
     const size_t row = (size_t)w * ctx->cfg.in_cn; // bytes per packed row of the context's input format
     if (stride < row) return fail(ctx, ORBFE_ERR_INVALID, "stride smaller than a row (%d px x %d channels)", w, ctx->cfg.in_cn);
     const size_t px = row * h;
@@ -1138,6 +1196,7 @@ extern "C" int orbfe_hamming_matrix(orbfe_context *ctx, const uint8_t *desc_a, i
     const size_t need = (size_t)32 * na + (size_t)32 * nb + sizeof(int) * (size_t)na * nb;
     if (need > ctx->d_ham_bytes) {
         if (ctx->d_ham) hipFree(ctx->d_ham);
+    for (int sd = 0; sd < 2; sd++) { if (ctx->cfg.rm_xy[sd]) hipFree((void *)ctx->cfg.rm_xy[sd]); if (ctx->cfg.rm_a[sd]) hipFree((void *)ctx->cfg.rm_a[sd]); }
     if (ctx->d_und) hipFree(ctx->d_und);
         ctx->d_ham = nullptr; ctx->d_ham_bytes = 0;
         HIP_TRY(ctx, hipMalloc((void **)&ctx->d_ham, need));

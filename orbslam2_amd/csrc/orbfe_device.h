@@ -52,6 +52,12 @@ struct DeviceConfig {
     // input pixel format (orbfe_set_input_format): 1 = CV_8UC1; 3 / 4 = interleaved colour converted by ingest with
     // cv::cvtColor's fixed-point weights for channels 0, 1, 2 (in_coef) and in_shift fraction bits
     int in_cn, in_coef[3], in_shift;
+    size_t in_image_bytes; // bytes of one packed input image (w * h * in_cn, or rm_sw * rm_sh with rectification)
+    // rectification (orbfe_set_rectification): cv::remap's fixed-point form of the float maps, one pair per side
+    // (index = image slot & 1 when the right map is set, else 0): rm_xy = sx | sy << 16 (int16 each), rm_a = fy * 32 + fx
+    int rm_on, rm_sw, rm_sh;
+    const uint32_t *rm_xy[2];
+    const uint16_t *rm_a[2];
     // lens distortion of Frame::UndistortKeyPoints (orbfe_set_distortion): k1 k2 p1 p2 k3; n_dist == 0 or dist[0] == 0: none
     int n_dist;
     float dist[5];

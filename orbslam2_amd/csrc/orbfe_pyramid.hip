@@ -13,7 +13,24 @@
 // Also clears the image's status word (first kernel of every chain).
 // CN = 3 / 4: interleaved colour input, converted on the fly with cv::cvtColor's 8-bit fixed-point arithmetic
 // (Tracking::GrabImage*, src/Tracking.cc:269-294: gray = (c0*k0 + c1*k1 + c2*k2 + half) >> shift; alpha ignored).
-template <int CN>
+// REMAP: the packed input is an unrectified rm_sw x rm_sh image and level 0 is cv::remap(src, map1, map2, INTER_LINEAR)
+// of it (EuRoC rectification, Test/Replay/Stereo/stereo_euroc.cc:136-137): 5-bit fixed-point coordinates, the four taps
+// weighted with {(32-fx)(32-fy), fx(32-fy), (32-fx)fy, fx*fy} * 32, (sum + 2^14) >> 15, taps outside the source read 0.
+__device__ __forceinline__ uint32_t remap_px(const DeviceConfig &cfg, const uint8_t *__restrict__ simg, int side, int x, int y)
+{
+    const size_t idx = (size_t)y * cfg.width + x;
+    const uint32_t xy = cfg.rm_xy[side][idx];
+    const int a = cfg.rm_a[side][idx];
+    const int sx = (int)(int16_t)(xy & 0xffffu), sy = (int)(int16_t)(xy >> 16), fx = a & 31, fy = a >> 5;
+    const int sw = cfg.rm_sw, sh = cfg.rm_sh;
+    const bool x0in = sx >= 0 && sx < sw, x1in = sx + 1 >= 0 && sx + 1 < sw, y0in = sy >= 0 && sy < sh, y1in = sy + 1 >= 0 && sy + 1 < sh;
+    const uint8_t *r0 = simg + (ptrdiff_t)sy * sw + sx, *r1 = r0 + sw;
+    const int v00 = (x0in && y0in) ? r0[0] : 0, v01 = (x1in && y0in) ? r0[1] : 0, v10 = (x0in && y1in) ? r1[0] : 0, v11 = (x1in && y1in) ? r1[1] : 0;
+    const int s = v00 * (32 - fx) * (32 - fy) + v01 * fx * (32 - fy) + v10 * (32 - fx) * fy + v11 * fx * fy; // weights / 32
+    return (uint32_t)((s * 32 + (1 << 14)) >> 15);
+}
+
+template <int CN, bool REMAP = false>
 __global__ __launch_bounds__(256) void ingest_kernel(DeviceConfig cfg, DeviceBuffers buf, const uint8_t *__restrict__ src)
 {
     const int img = blockIdx.z;
@@ -26,8 +43,17 @@ __global__ __launch_bounds__(256) void ingest_kernel(DeviceConfig cfg, DeviceBuf
     const int y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6)) - PYR_MY;
     const int x0 = (int)(blockIdx.x * 64 + (threadIdx.x & 63)) * 4 - PYR_MX;
     if (x0 >= L.w + 8 || y >= L.h + PYR_MY) return;
-    const uint8_t *s = src + ((size_t)img * L.h + (size_t)reflect101(y, L.h)) * L.w * CN;
     uint32_t v = 0;
+    if constexpr (REMAP) {
+        const uint8_t *simg = src + (size_t)img * cfg.in_image_bytes;
+        const int side = cfg.rm_xy[1] ? (img & 1) : 0, yy = reflect101(y, L.h);
+#pragma unroll
+        for (int j = 0; j < 4; j++) v |= remap_px(cfg, simg, side, reflect101(x0 + j, L.w), yy) << (8 * j);
+        uint8_t *dr = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (ptrdiff_t)y * L.pitch + x0;
+        *(uint32_t *)dr = v;
+        return;
+    }
+    const uint8_t *s = src + ((size_t)img * L.h + (size_t)reflect101(y, L.h)) * L.w * CN;
     if constexpr (CN == 1) {
         if (x0 >= 0 && x0 + 3 < L.w) {
             __builtin_memcpy(&v, s + x0, 4);
@@ -257,7 +283,8 @@ void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, cons
 {
     const int words = (cfg.lv[0].w + 12 + 3) / 4;
     dim3 grid((words + 63) / 64, (cfg.lv[0].h + 2 * PYR_MY + 3) / 4, n_images);
-    if (cfg.in_cn == 3) hipLaunchKernelGGL(ingest_kernel<3>, grid, dim3(256), 0, s, cfg, buf, d_images);
+    if (cfg.rm_on) hipLaunchKernelGGL((ingest_kernel<1, true>), grid, dim3(256), 0, s, cfg, buf, d_images);
+    else if (cfg.in_cn == 3) hipLaunchKernelGGL(ingest_kernel<3>, grid, dim3(256), 0, s, cfg, buf, d_images);
     else if (cfg.in_cn == 4) hipLaunchKernelGGL(ingest_kernel<4>, grid, dim3(256), 0, s, cfg, buf, d_images);
     else hipLaunchKernelGGL(ingest_kernel<1>, grid, dim3(256), 0, s, cfg, buf, d_images);
 }

@@ -303,3 +303,51 @@ def test_undistortion_matches_oracle(name, dist):
     ctx.set_distortion([])
     assert np.array_equal(ctx.rgbd_frame(left, depth)["u_right"], ur0)
     ctx.close()
+
+
+def _rectify_maps(w, h, sw, sh, seed):
+    """Smooth synthetic stand-ins for initUndistortRectifyMap's output: a small rotation + radial term, partly leaving
+    the source so the constant border is exercised."""
+    X, Y = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    rng = np.random.default_rng(seed)
+    th, k = rng.uniform(-0.02, 0.02), rng.uniform(-2e-7, 2e-7)
+    xc, yc = X - w / 2, Y - h / 2
+    r2 = xc * xc + yc * yc
+    mx = (np.cos(th) * xc - np.sin(th) * yc) * (1 + k * r2) + sw / 2 + rng.uniform(-3, 3)
+    my = (np.sin(th) * xc + np.cos(th) * yc) * (1 + k * r2) + sh / 2 + rng.uniform(-3, 3)
+    return mx.astype(np.float32), my.astype(np.float32)
+
+
+def test_rectified_ingest_matches_remap_then_extract():
+    """EuRoC flow (Test/Replay/Stereo/stereo_euroc.cc:136-137): remap both raw images, then the stereo Frame.  Folded into
+    ingest, the result must equal the oracle's remap followed by the plain pipeline, with a raw size that differs from the
+    rectified one."""
+    cfg = SMALL
+    w, h = cfg["width"], cfg["height"]
+    sw, sh = w + 16, h + 8
+    rawl, rawr = synth.stereo_pair(sw, sh, seed=71)
+    mxl, myl = _rectify_maps(w, h, sw, sh, 1)
+    mxr, myr = _rectify_maps(w, h, sw, sh, 2)
+    rl, rr = O.remap_bilinear(rawl, mxl, myl), O.remap_bilinear(rawr, mxr, myr)
+    assert (rl == 0).sum() > 0 and rl.std() > 20
+    ctx = _ctx(cfg)
+    ref = ctx.stereo_frame(rl, rr)
+    ctx.set_rectification(0, mxl, myl, (sw, sh))
+    mono = ctx.extract(rawl)                                  # without a right map every slot uses the left one
+    assert np.array_equal(mono[0], ref["kps_left"]) and np.array_equal(mono[1], ref["desc_left"])
+    ctx.set_rectification(1, mxr, myr, (sw, sh))
+    out = ctx.stereo_frame(rawl, rawr)
+    assert np.array_equal(ctx.fetch_pyramid(0, 0), rl) and np.array_equal(ctx.fetch_pyramid(1, 0), rr)
+    for k in ref:
+        assert np.array_equal(out[k], ref[k]), k
+    assert len(ref["kps_left"]) > 100
+    from orbslam2_amd import api
+    with pytest.raises(api.OrbfeError):
+        ctx.stereo_frame(rl, rr)                              # rectified-size input is refused while rectification is on
+    with pytest.raises(api.OrbfeError):
+        ctx.set_input_format(3)
+    ctx.set_rectification(0)                                   # off again
+    out2 = ctx.stereo_frame(rl, rr)
+    for k in ref:
+        assert np.array_equal(out2[k], ref[k]), k
+    ctx.close()

@@ -319,3 +319,24 @@ def test_undistort_points_known_answers():
     assert b[0] > 0 and b[1] < 640 and b[2] > 0 and b[3] < 480                  # pincushion-free TUM1: the corners move inwards
     assert O.image_bounds(640, 480, fx, fy, cx, cy, [0, 0, 0, 0]).tolist() == [0, 640, 0, 480]
     assert O.image_bounds(640, 480, fx, fy, cx, cy, [0, 0.5, 0, 0]).tolist() == [0, 640, 0, 480]  # k1 == 0: the reference skips undistortion
+
+
+def test_remap_bilinear_known_answers():
+    """cv::remap INTER_LINEAR 8UC1, zero constant border: identity, integer shift, half-pixel average, 1/32 quantisation."""
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (20, 30), dtype=np.uint8)
+    X, Y = np.meshgrid(np.arange(30, dtype=np.float32), np.arange(20, dtype=np.float32))
+    assert np.array_equal(O.remap_bilinear(img, X, Y), img)
+    s = O.remap_bilinear(img, X + 3, Y - 2)
+    assert np.array_equal(s[2:, :27], img[:-2, 3:]) and (s[:2] == 0).all() and (s[:, 27:] == 0).all()
+    h = O.remap_bilinear(img, X + 0.5, Y)
+    assert np.array_equal(h[:, :-1], (img[:, :-1].astype(int) + img[:, 1:] + 1) >> 1)
+    assert np.array_equal(h[:, -1], (img[:, -1].astype(int) + 1) >> 1)             # right tap outside: reads 0
+    q = O.remap_bilinear(img, X + 0.01, Y)                                           # 0.01 * 32 rounds to 0: no interpolation
+    assert np.array_equal(q, img)
+    f = O.remap_bilinear(img, X + 0.25, Y + 0.75)[:-1, :-1].astype(float)
+    a = img.astype(float)
+    ref = 0.75 * 0.25 * a[:-1, :-1] + 0.25 * 0.25 * a[:-1, 1:] + 0.75 * 0.75 * a[1:, :-1] + 0.25 * 0.75 * a[1:, 1:]
+    assert np.abs(f - ref).max() <= 0.5 + 1e-9
+    big = O.remap_bilinear(img, X + 1e6, Y)                                          # coordinates saturate: all outside
+    assert (big == 0).all()
