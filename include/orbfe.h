@@ -225,6 +225,11 @@ typedef struct orbfe_track_point {
  * result in the reference's order. */
 int orbfe_features_in_area(orbfe_context *ctx, const orbfe_frame_view *frame, float x, float y, float r,
                            int min_level, int max_level, int32_t *out, int cap, int *n);
+/* nq queries against the same frame in one call (the frame is uploaded and bucketed once): query i's indices are
+ * out[out_off[i] .. out_off[i + 1]), in GetFeaturesInArea's order; min_level / max_level may be NULL (-1 for all). */
+int orbfe_features_in_area_batch(orbfe_context *ctx, const orbfe_frame_view *fv, int nq, const float *x, const float *y,
+                                 const float *r, const int32_t *min_level, const int32_t *max_level,
+                                 int32_t *out_off, int32_t *out, int cap);
 /* ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:1597-1638) on the sizes of the rotation histogram bins. */
 int orbfe_three_maxima(const int32_t *histo_sizes, int L, int *ind1, int *ind2, int *ind3);
 /* ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) (src/ORBmatcher.cc:1324-1466).

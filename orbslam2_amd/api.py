@@ -27,7 +27,7 @@ EXPORTS = [
     "orbfe_enqueue_stereo", "orbfe_synchronize", "orbfe_fetch_image", "orbfe_fetch_counts",
     "orbfe_device_buffers", "orbfe_fetch_candidates", "orbfe_hamming_matrix",
     "orbfe_set_profiling", "orbfe_stage_name", "orbfe_stage_times", "orbfe_set_streams", "orbfe_quadtree_kernel",
-    "orbfe_features_in_area", "orbfe_three_maxima", "orbfe_search_by_projection_last", "orbfe_is_in_frustum",
+    "orbfe_features_in_area", "orbfe_features_in_area_batch", "orbfe_three_maxima", "orbfe_search_by_projection_last", "orbfe_is_in_frustum",
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_kf", "orbfe_search_for_initialization",
     "orbfe_vocab_load", "orbfe_bow_transform", "orbfe_bow_maps", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",  # bound in orbslam2_amd/bow.py
     "orbfe_search_for_triangulation", "orbfe_fuse", "orbfe_search_by_projection_sim3", "orbfe_fuse_sim3", "orbfe_search_by_sim3", "orbfe_kfdb_clear", "orbfe_kfdb_add", "orbfe_kfdb_erase", "orbfe_kfdb_size", "orbfe_kfdb_score", "orbfe_detect_reloc_candidates",
@@ -117,6 +117,8 @@ def load():
     fvp, ip = C.POINTER(FrameView), C.POINTER(C.c_int)
     L.orbfe_features_in_area.restype = C.c_int
     L.orbfe_features_in_area.argtypes = [vp, fvp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, vp, C.c_int, ip]
+    L.orbfe_features_in_area_batch.restype = C.c_int
+    L.orbfe_features_in_area_batch.argtypes = [vp, fvp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int]
     L.orbfe_three_maxima.restype = C.c_int; L.orbfe_three_maxima.argtypes = [vp, C.c_int, ip, ip, ip]
     L.orbfe_search_by_projection_last.restype = C.c_int
     L.orbfe_search_by_projection_last.argtypes = [vp, fvp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_int, C.c_int, vp, ip]
@@ -367,6 +369,18 @@ class Context:
         fv = FrameView(len(k), _p(k), None if ur is None else _p(ur), _p(d), *[float(b) for b in bounds])
         fv._keep = (k, d, ur)
         return fv
+
+    def features_in_area_batch(self, view, x, y, r, min_level=None, max_level=None):
+        """List of index arrays, one per query (Frame::GetFeaturesInArea order)."""
+        x = np.ascontiguousarray(x, np.float32); y = np.ascontiguousarray(y, np.float32); r = np.ascontiguousarray(r, np.float32)
+        nq = len(x)
+        lo = None if min_level is None else np.ascontiguousarray(min_level, np.int32)
+        hi = None if max_level is None else np.ascontiguousarray(max_level, np.int32)
+        off = np.zeros(nq + 1, np.int32); cap = max(view.n * max(nq, 1), 1)
+        out = np.zeros(cap, np.int32)
+        self._check(self.L.orbfe_features_in_area_batch(self.h, C.byref(view), nq, _p(x), _p(y), _p(r), None if lo is None else _p(lo),
+                                                        None if hi is None else _p(hi), _p(off), _p(out), cap))
+        return [out[off[i]:off[i + 1]].copy() for i in range(nq)]
 
     def features_in_area(self, view, x, y, r, min_level=-1, max_level=-1):
         out = np.zeros(max(view.n, 1), np.int32); n = C.c_int()

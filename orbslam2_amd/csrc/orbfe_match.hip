@@ -388,6 +388,36 @@ extern "C" int orbfe_features_in_area(orbfe_context *ctx, const orbfe_frame_view
     return ORBFE_OK;
 }
 
+// Many GetFeaturesInArea queries against one frame: the frame is uploaded and its grid built once.
+extern "C" int orbfe_features_in_area_batch(orbfe_context *ctx, const orbfe_frame_view *fv, int nq, const float *x, const float *y,
+                                            const float *r, const int32_t *min_level, const int32_t *max_level,
+                                            int32_t *out_off, int32_t *out, int cap)
+{
+    int rc = check_view(ctx, fv);
+    if (rc != ORBFE_OK) return rc;
+    if (nq < 0 || !out_off || (nq > 0 && (!x || !y || !r))) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    std::vector<MatchQuery> q(nq);
+    for (int i = 0; i < nq; i++) q[i] = MatchQuery{x[i], y[i], r[i], min_level ? min_level[i] : -1, max_level ? max_level[i] : -1, 0.f, 0.f, 1};
+    std::vector<uint8_t> qd((size_t)32 * std::max(nq, 1), 0);
+    rc = run_window_queries(ctx, fv, q, qd);
+    if (rc != ORBFE_OK) return rc;
+    orbfe_match_state *st = match_state(ctx);
+    int total = 0;
+    out_off[0] = 0;
+    std::vector<unsigned long long> keys;
+    for (int i = 0; i < nq; i++) {
+        keys.assign(st->h_list.begin() + st->h_off[i], st->h_list.begin() + st->h_off[i] + st->h_cnt[i]);
+        for (auto &k : keys) k &= ((1ull << 36) - 1); // drop the distance: order = (ix, iy, idx)
+        std::sort(keys.begin(), keys.end());
+        if (total + (int)keys.size() <= cap && out)
+            for (size_t j = 0; j < keys.size(); j++) out[total + j] = key_idx(keys[j]);
+        total += (int)keys.size();
+        out_off[i + 1] = total;
+    }
+    if (total > cap) return orbfe_fail(ctx, ORBFE_ERR_CAPACITY, "the windows hold %d keypoints, caller buffer %d", total, cap);
+    return ORBFE_OK;
+}
+
 // ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono), src/ORBmatcher.cc:1324-1466
 extern "C" int orbfe_search_by_projection_last(orbfe_context *ctx, const orbfe_frame_view *cur,
                                                const float *Tcw_cur, const float *Tcw_last, int n_last,

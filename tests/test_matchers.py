@@ -173,6 +173,14 @@ def test_gpu_features_in_area(gpu):
         x, y, r = float(rng.uniform(-30, W + 30)), float(rng.uniform(-30, H + 30)), float(rng.uniform(1, 120))
         lo, hi = int(rng.integers(-1, 5)), int(rng.integers(-1, 8))
         assert ctx.features_in_area(view, x, y, r, lo, hi).tolist() == g.features_in_area(x, y, r, lo, hi).tolist()
+    # the batch form: one upload, many windows, same lists
+    qs = [(float(rng.uniform(-30, W + 30)), float(rng.uniform(-30, H + 30)), float(rng.uniform(1, 120)), int(rng.integers(-1, 5)), int(rng.integers(-1, 8)))
+          for _ in range(100)]
+    got = ctx.features_in_area_batch(view, [q[0] for q in qs], [q[1] for q in qs], [q[2] for q in qs], [q[3] for q in qs], [q[4] for q in qs])
+    for q, lst in zip(qs, got):
+        assert lst.tolist() == g.features_in_area(*q).tolist()
+    assert sum(len(x) for x in got) > 1000
+    assert ctx.features_in_area_batch(view, [], [], []) == []
     a, b, c = C.c_int(), C.c_int(), C.c_int()
     h = np.array([0, 9, 2, 9, 1] + [0] * 25, np.int32)
     assert ctx.L.orbfe_three_maxima(h.ctypes.data_as(C.c_void_p), 30, C.byref(a), C.byref(b), C.byref(c)) == 0

@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""BASELINE.json's secondary configurations as single-GPU sanity points: per-frame time of the
+whole chain through the host entry points (host buffers in and out) beside the CPU oracle on one thread.
+    python3 tools/bench_configs.py > gpurun_out/configs.json
+  config 2: Mono-EuRoC 752x480, 1200 features: extract + fbow transform + 500-keyframe database query + SearchByBoW
+  config 4: RealSense-D435i RGB-D 1280x720, 2500 features: extract + ComputeStereoFromRGBD + SearchByProjection(last frame)
+  config 0: Mono-TUM1 640x480, 1000 features: extract (the reference's plumbing case)"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from orbslam2_amd import api, bow as B, synth  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from tests import test_bow as TB  # noqa: E402
+
+
+def med(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return round(float(np.median(ts)), 4)
+
+
+out = {"unit": "ms per frame, median; GPU = host entry points with copies, CPU = oracle on one thread"}
+
+# ---- config 0
+W, H, NF = 640, 480, 1000
+ctx = api.Context(width=W, height=H, nfeatures=NF, fx=517.3, fy=516.5, cx=318.6, cy=255.3, bf=40.0, max_images=1)
+img = synth.mono_image(W, H, seed=5)
+ex = O.Extractor(nfeatures=NF)
+out["config 0 Mono-TUM1 640x480/1000: extract"] = {"gpu_ms": med(lambda: ctx.extract(img), 50), "cpu_ms": med(lambda: ex.extract(img), 10, 1)}
+ctx.close()
+
+# ---- config 2
+W, H, NF, NKF = 752, 480, 1200, 500
+ctx = api.Context(width=W, height=H, nfeatures=NF, fx=458.654, fy=457.296, cx=367.215, cy=248.375, bf=47.9, max_images=1)
+ex = O.Extractor(nfeatures=NF)
+imgs = [synth.mono_image(W, H, seed=900 + i) for i in range(NKF)]
+kf_kd = [ctx.extract(im) for im in imgs]
+blob = B.build_vocabulary(np.concatenate([d for _, d in kf_kd[:8]]), k=10, levels=4, seed=3)
+B.vocab_load(ctx, blob)
+L, v = TB._oracle_voc(blob)
+L.orc_detect_reloc_candidates.restype = C.c_int
+L.orc_detect_reloc_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int]
+db = B.KeyFrameDB(ctx)
+kf_bow, kf_fv = [], []
+for _, d in kf_kd:
+    w, wt, nd = B.transform(ctx, d, 4)
+    words, ww, nodes, off, feat = B.maps(w, wt, nd)
+    db.add(words, ww)
+    kf_bow.append((words, ww)); kf_fv.append((nodes, off, feat))
+rng = np.random.default_rng(1)
+q_img = np.clip(imgs[5].astype(np.int16) + rng.normal(0, 2.0, imgs[5].shape).round().astype(np.int16), 0, 255).astype(np.uint8)
+covis_off = np.arange(NKF + 1, dtype=np.int32) * 2
+covis_idx = np.stack([(np.arange(NKF) + 1) % NKF, (np.arange(NKF) - 1) % NKF], axis=1).astype(np.int32).ravel()
+kf_off = np.zeros(NKF + 1, np.int32); kf_off[1:] = np.cumsum([len(a) for a, _ in kf_bow])
+dbw = np.concatenate([a for a, _ in kf_bow]); dbv = np.concatenate([b for _, b in kf_bow])
+res = {}
+
+
+def gpu_chain():
+    qk, qd = ctx.extract(q_img)
+    gw, gwt, gnd = B.transform(ctx, qd, 4)
+    q_words, q_ww, qn, qo, qf = B.maps(gw, gwt, gnd)
+    st = np.zeros(NKF, np.float32)
+    cand = db.detect_reloc_candidates(q_words, q_ww, covis_off, covis_idx, st)
+    kfi = int(cand[0])
+    kfk, kfd = kf_kd[kfi]
+    m, nm = B.search_by_bow(ctx, kf_fv[kfi], np.ones(len(kfd), np.int32), kfd, kfk["angle"].copy(), (qn, qo, qf), qd, qk["angle"].copy(), 0.75, True)
+    res["gpu"] = (cand.tolist(), nm)
+
+
+def cpu_chain():
+    qk, qd = ex.extract(q_img)
+    (w, wt, nd), (q_words, q_ww), q_fv = TB._oracle_transform(L, v, qd)
+    st = np.zeros(NKF, np.float32); cand = np.zeros(NKF, np.int32)
+    n = L.orc_detect_reloc_candidates(TB._p(q_words), TB._p(q_ww), len(q_words), NKF, TB._p(kf_off), TB._p(dbw), TB._p(dbv),
+                                      TB._p(covis_off), TB._p(covis_idx), TB._p(st), TB._p(cand), NKF)
+    kfi = int(cand[0])
+    kfk, kfd = kf_kd[kfi]
+    fv = kf_fv[kfi]
+    ref = np.zeros(len(qd), np.int32)
+    nref = L.orc_search_by_bow(TB._p(fv[0]), TB._p(fv[1]), TB._p(fv[2]), len(fv[0]), TB._p(np.ones(len(kfd), np.int32)), TB._p(kfd),
+                               TB._p(kfk["angle"].copy()), TB._p(q_fv[0]), TB._p(q_fv[1]), TB._p(q_fv[2]), len(q_fv[0]), TB._p(qd),
+                               TB._p(qk["angle"].copy()), len(qd), 0.75, 1, TB._p(ref))
+    res["cpu"] = (cand[:n].tolist(), nref)
+
+
+g, c = med(gpu_chain, 30), med(cpu_chain, 5, 1)
+out["config 2 Mono-EuRoC 752x480/1200: extract + BoW transform + 500-KF database query + SearchByBoW"] = {
+    "gpu_ms": g, "cpu_ms": c, "same_candidates_and_matches": res["gpu"] == res["cpu"], "matches": res["gpu"][1]}
+L.orc_vocab_destroy(v)
+ctx.close()
+
+# ---- config 4
+W, H, NF = 1280, 720, 2500
+fx = fy = 911.0; cx, cy, bf = 640.0, 360.0, 45.5
+ctx = api.Context(width=W, height=H, nfeatures=NF, fx=fx, fy=fy, cx=cx, cy=cy, bf=bf, max_images=1)
+ex = O.Extractor(nfeatures=NF)
+img1, img2, depth = synth.stereo_pair(W, H, seed=321, with_depth=True, bf=bf)
+f1 = ctx.rgbd_frame(img1, depth)
+z = f1["depth"]
+valid = (z > 0).astype(np.int32)
+pos = np.stack([(f1["kps"]["x"] - cx) * z / fx, (f1["kps"]["y"] - cy) * z / fy, z], axis=1).astype(np.float32)
+obs = np.ones(len(z), np.int32)
+T_last = np.concatenate([np.eye(3), np.zeros((3, 1))], axis=1).astype(np.float32)
+T_cur = T_last.copy(); T_cur[0, 3] = -bf / fx
+bounds = (0.0, float(W), 0.0, float(H))
+cam = O.Camera(fx, fy, cx, cy, bf, bf / fx)
+k1o, d1o = ex.extract(img1)
+
+
+def gpu4():
+    f2 = ctx.rgbd_frame(img2, depth)
+    view = ctx._view(f2["kps"], f2["u_right"], f2["desc"], bounds)
+    got, n = ctx.search_by_projection_last(view, T_cur, T_last, pos, f1["desc"], valid, obs, f1["kps"]["octave"].copy(),
+                                           f1["kps"]["angle"].copy(), None, 7.0, False, True)
+    res["g4"] = (n, got)
+
+
+def cpu4():
+    k2, d2 = ex.extract(img2)
+    ur2, dp2 = O.stereo_from_rgbd(k2, k2, depth, bf)
+    g = O.Grid(k2, *bounds)
+    ref, n = O.search_by_projection_last(g, ur2, d2, ex.scale_factors(), cam, T_cur, T_last, pos, d1o, valid, obs,
+                                         k1o["octave"].copy(), k1o["angle"].copy(), None, 7.0, False, True)
+    res["c4"] = (n, ref)
+
+
+g, c = med(gpu4, 30), med(cpu4, 5, 1)
+out["config 4 D435i RGB-D 1280x720/2500: extract + ComputeStereoFromRGBD + SearchByProjection(last frame)"] = {
+    "gpu_ms": g, "cpu_ms": c, "same_matches": bool(res["g4"][0] == res["c4"][0] and np.array_equal(res["g4"][1], res["c4"][1])), "matches": int(res["g4"][0])}
+ctx.close()
+print(json.dumps(out, indent=1))

@@ -47,7 +47,7 @@ def main():
     rng = np.random.default_rng(5)
     qs = [(float(rng.uniform(0, TM.W)), float(rng.uniform(0, TM.H)), float(rng.uniform(5, 60))) for _ in range(64)]
     row("GetFeaturesInArea x64 [rows 13]",
-        lambda: [ctx.features_in_area(view, x, y, r, -1, -1) for x, y, r in qs],
+        lambda: ctx.features_in_area_batch(view, [q[0] for q in qs], [q[1] for q in qs], [q[2] for q in qs]),
         lambda: [g.features_in_area(x, y, r, -1, -1) for x, y, r in qs], reps=5)
     # mono initialisation: frame 1 = level-0 keypoints, frame 2 = the scene's current frame
     k1 = s["k"].copy(); k1["octave"] = 0
