@@ -313,7 +313,7 @@ static int build_config(orbfe_context *ctx)
             ctx->use_octree3 = ok3 && ctx->ot3_lds <= 150 * 1024 && !(force && (atoi(force) == 2 || atoi(force) == 1));
             if (force && atoi(force) == 1) ctx->use_octree2 = false;
         }
-        if (!ctx->use_octree3 && !ctx->use_octree2 && orbfe_octree_lds_bytes(c) > 64 * 1024)
+        if (!ctx->use_octree3 && !ctx->use_octree2 && orbfe_octree_lds_bytes(c) > 150 * 1024)
             return fail(ctx, ORBFE_ERR_UNSUPPORTED, "nfeatures too large for the quadtree LDS budget");
     }
     return ORBFE_OK;
