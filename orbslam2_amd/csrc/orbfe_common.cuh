@@ -44,6 +44,26 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
     return v;
 }
 
+// XCD-aware block -> (unit, block-of-unit) map shared by the kernels whose workgroups of one image (or pair) should share
+// an L2: workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8; placement is a speed assumption
+// only).  With 5 or more units in flight every unit gets one XCD; with fewer, a unit is spread over 2 / 4 / 8 XCDs so
+// that a single frame still uses the whole chip (a lone image on one XCD would leave 7/8 of the CUs idle).
+__host__ __device__ __forceinline__ int xcd_split_log2(int n_units) { return n_units >= 5 ? 0 : n_units >= 3 ? 1 : n_units == 2 ? 2 : 3; }
+__host__ __forceinline__ int xcd_grid(int blocks_per_unit, int n_units)
+{
+    const int lg = xcd_split_log2(n_units), per_xcd = (blocks_per_unit + (1 << lg) - 1) >> lg, side = 8 >> lg;
+    return per_xcd * ((n_units + side - 1) / side) * 8;
+}
+__device__ __forceinline__ bool xcd_map(int blocks_per_unit, int n_units, int &unit, int &blk)
+{
+    const int lg = xcd_split_log2(n_units), xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int per_xcd = (blocks_per_unit + (1 << lg) - 1) >> lg;
+    const int round = jb / per_xcd;
+    unit = round * (8 >> lg) + (xcd >> lg);
+    blk = ((jb - round * per_xcd) << lg) + (xcd & ((1 << lg) - 1));
+    return unit < n_units && blk < blocks_per_unit;
+}
+
 __device__ __forceinline__ int reflect101(int p, int len)
 {
     if (len == 1) return 0;

@@ -29,17 +29,16 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, Devi
     // one XCD, whose 4 MiB L2 then holds that image's raw + blurred pyramid (3.3 MB) while its ~2000
     // overlapping 31x31 / 37x37 patches are read, instead of every patch row coming from the MALL.
     const int bpi = (cfg.sel_total + 4 * DS_KPW - 1) / (4 * DS_KPW); // blocks per image
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int img = (jb / bpi) * 8 + xcd;
-    if (img >= n_images) return;
+    int img, blk;
+    if (!xcd_map(bpi, n_images, img, blk)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform values must be provably so: they feed scalar addresses
-    const int slot0 = (jb % bpi) * (4 * DS_KPW) + wave * DS_KPW;
+    const int slot0 = blk * (4 * DS_KPW) + wave * DS_KPW;
     const int hp = cfg.half_patch;
     const int raw_rows = 2 * hp + 1;
     const int raw_words = raw_rows * (DS_PATCH_W / 4);
     const int *sel_cnt = buf.sel_cnt + (size_t)img * cfg.nlevels;
-    if (jb % bpi == 0 && tid == 0) {
+    if (blk == 0 && tid == 0) {
         int tot = 0;
         for (int l = 0; l < cfg.nlevels; l++) tot += sel_cnt[l];
         buf.kp_cnt[img] = tot;
@@ -275,7 +274,7 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, Devi
 
 void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool stereo, hipStream_t s)
 {
-    dim3 grid(((cfg.sel_total + 4 * DS_KPW - 1) / (4 * DS_KPW)) * ((n_images + 7) / 8) * 8);
+    dim3 grid(xcd_grid((cfg.sel_total + 4 * DS_KPW - 1) / (4 * DS_KPW), n_images));
     const size_t lds = ((cfg.patch_n * 2 + 15) & ~15) + 256 * 4 + (size_t)4 * (2 * cfg.half_patch + 1 + 37) * DS_PATCH_W;
     static const int dbg = getenv("ORBFE_DESC_DBG") ? atoi(getenv("ORBFE_DESC_DBG")) : 0; // profiling aid only
     hipLaunchKernelGGL(describe_kernel, grid, dim3(256), lds, s, cfg, buf, n_images, stereo ? 1 : 0, dbg);

@@ -80,11 +80,10 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
     // A workgroup is four independent waves = four consecutive cells (no workgroup barriers: FAST_WAVE_SYNC): horizontally
     // adjacent cells share the 128-B lines of their tile rows, and on one CU those lines are fetched from L2 once.
     const int bpi = (cfg.cells_total + 3) >> 2;
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int img = (jb / bpi) * 8 + xcd;
-    if (img >= n_images) return;
+    int img, blk;
+    if (!xcd_map(bpi, n_images, img, blk)) return;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int cell = (jb % bpi) * 4 + wave;
+    const int cell = blk * 4 + wave;
     if (cell >= cfg.cells_total) return;
     uint8_t *s_mem = s_mem_all + wave * lds_per_wave;
     int level = 0;
@@ -427,7 +426,7 @@ void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_
     const int tile_region = tile_bytes > mw * mh ? tile_bytes : ((mw * mh + 15) & ~15);
     const int lds_per_wave = tile_region + sc_bytes + q_bytes + 512;
     const size_t lds = (size_t)4 * lds_per_wave;
-    dim3 grid(((cfg.cells_total + 3) / 4) * ((n_images + 7) / 8) * 8);
+    dim3 grid(xcd_grid((cfg.cells_total + 3) / 4, n_images));
     static const int dbg = getenv("ORBFE_FAST_DBG") ? atoi(getenv("ORBFE_FAST_DBG")) : 0; // profiling aid only
 #define FAST_LAUNCH(TP)                                                                                                                   \
     do {                                                                                                                              \

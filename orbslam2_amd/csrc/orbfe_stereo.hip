@@ -28,12 +28,11 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, Dev
     // descriptors, keypoints and the pyramid rows the SAD windows touch)
     const int kpb = 256 / SM_G;
     const int bpp = (cfg.sel_total + kpb - 1) / kpb;
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int pair = (jb / bpp) * 8 + xcd;
-    if (pair >= n_pairs) return;
+    int pair, blk;
+    if (!xcd_map(bpp, n_pairs, pair, blk)) return;
     const int imgL = 2 * pair, imgR = 2 * pair + 1;
     const int gl = threadIdx.x & (SM_G - 1);
-    const int iL = (jb % bpp) * kpb + (threadIdx.x / SM_G);
+    const int iL = blk * kpb + (threadIdx.x / SM_G);
     const int nL = buf.kp_cnt[imgL], nR = buf.kp_cnt[imgR];
     if (iL >= nL) return; // whole group; the groups of a wave only meet in xor shuffles below the group size
     const KeyPointPOD *kL = (const KeyPointPOD *)buf.kps + (size_t)imgL * cfg.sel_total;
@@ -328,7 +327,7 @@ __global__ __launch_bounds__(256) void hamming_matrix_kernel(const uint8_t *__re
 void orbfe_launch_stereo_match(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s)
 {
     const int kpb = 256 / SM_G;
-    dim3 grid(((cfg.sel_total + kpb - 1) / kpb) * ((n_pairs + 7) / 8) * 8);
+    dim3 grid(xcd_grid((cfg.sel_total + kpb - 1) / kpb, n_pairs));
     hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(256), 0, s, cfg, buf, n_pairs);
 }
 
