@@ -701,11 +701,17 @@ struct DevBuf {
 } // namespace
 
 struct orbfe_pose_state {
-    DevBuf off, keys, ur, has, xw, T, out, ninl, sig;
+    DevBuf blk, sig;          // one device block for all arrays of a host call
+    uint8_t *h_blk = nullptr; // its pinned host image: one copy up, one copy down
+    size_t h_bytes = 0;
 };
 
 orbfe_pose_state *orbfe_pose_state_create() { return new orbfe_pose_state(); }
-void orbfe_pose_state_destroy(orbfe_pose_state *s) { delete s; }
+void orbfe_pose_state_destroy(orbfe_pose_state *s)
+{
+    if (s && s->h_blk) (void)hipHostFree(s->h_blk);
+    delete s;
+}
 
 #define PTRY(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return orbfe_fail(ctx, ORBFE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
@@ -775,29 +781,41 @@ extern "C" int orbfe_pose_optimization_batch(orbfe_context *ctx, int n_problems,
     hipStream_t s = orbfe_ctx_stream(ctx);
     PTRY(ctx, hipSetDevice(orbfe_ctx_device(ctx)));
     const size_t tn = (size_t)(total > 0 ? total : 1);
-    if (st->off.ensure(sizeof(int32_t) * (n_problems + 1)) || st->keys.ensure(sizeof(KeyPointPOD) * tn) || st->ur.ensure(sizeof(float) * tn) ||
-        st->has.ensure(tn) || st->xw.ensure(sizeof(float) * 3 * tn) || st->T.ensure(sizeof(float) * 16 * n_problems) || st->out.ensure(tn) ||
-        st->ninl.ensure(sizeof(int32_t) * n_problems))
-        return orbfe_fail(ctx, ORBFE_ERR_HIP, "pose scratch allocation failed");
-    PTRY(ctx, hipMemcpyAsync(st->off.p, offsets, sizeof(int32_t) * (n_problems + 1), hipMemcpyHostToDevice, s));
-    PTRY(ctx, hipMemcpyAsync(st->T.p, Tcw, sizeof(float) * 16 * n_problems, hipMemcpyHostToDevice, s));
-    if (total > 0) {
-        PTRY(ctx, hipMemcpyAsync(st->keys.p, keys_un, sizeof(KeyPointPOD) * tn, hipMemcpyHostToDevice, s));
-        PTRY(ctx, hipMemcpyAsync(st->ur.p, u_right, sizeof(float) * tn, hipMemcpyHostToDevice, s));
-        PTRY(ctx, hipMemcpyAsync(st->has.p, has_point, tn, hipMemcpyHostToDevice, s));
-        PTRY(ctx, hipMemcpyAsync(st->xw.p, Xw, sizeof(float) * 3 * tn, hipMemcpyHostToDevice, s));
-        PTRY(ctx, hipMemcpyAsync(st->out.p, outlier, tn, hipMemcpyHostToDevice, s)); // entries without a point keep the caller's value
+    // block layout: results first ([Tcw | n_inliers | outlier], copied back in one piece), then the inputs
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_T = 0, o_n = up16(o_T + sizeof(float) * 16 * n_problems), o_out = up16(o_n + sizeof(int32_t) * n_problems);
+    const size_t o_off = up16(o_out + tn), o_keys = up16(o_off + sizeof(int32_t) * (n_problems + 1));
+    const size_t o_ur = up16(o_keys + sizeof(KeyPointPOD) * tn), o_has = up16(o_ur + sizeof(float) * tn), o_xw = up16(o_has + tn);
+    const size_t bytes = up16(o_xw + sizeof(float) * 3 * tn), down = o_off;
+    if (st->blk.ensure(bytes)) return orbfe_fail(ctx, ORBFE_ERR_HIP, "pose scratch allocation failed");
+    if (st->h_bytes < bytes) {
+        if (st->h_blk) (void)hipHostFree(st->h_blk);
+        st->h_blk = nullptr; st->h_bytes = 0;
+        PTRY(ctx, hipHostMalloc((void **)&st->h_blk, bytes, hipHostMallocDefault));
+        st->h_bytes = bytes;
     }
-    int rc = orbfe_enqueue_pose_optimization(ctx, n_problems, (const int32_t *)st->off.p, (const orbfe_keypoint *)st->keys.p, (const float *)st->ur.p,
-                                             (const uint8_t *)st->has.p, (const float *)st->xw.p, (float *)st->T.p, (uint8_t *)st->out.p,
-                                             (int32_t *)st->ninl.p, max_n, nullptr);
+    uint8_t *hb = st->h_blk, *db = (uint8_t *)st->blk.p;
+    memcpy(hb + o_T, Tcw, sizeof(float) * 16 * n_problems);
+    memcpy(hb + o_off, offsets, sizeof(int32_t) * (n_problems + 1));
+    if (total > 0) {
+        memcpy(hb + o_out, outlier, tn); // entries without a point keep the caller's value
+        memcpy(hb + o_keys, keys_un, sizeof(KeyPointPOD) * tn);
+        memcpy(hb + o_ur, u_right, sizeof(float) * tn);
+        memcpy(hb + o_has, has_point, tn);
+        memcpy(hb + o_xw, Xw, sizeof(float) * 3 * tn);
+    }
+    PTRY(ctx, hipMemcpyAsync(db, hb, bytes, hipMemcpyHostToDevice, s));
+    int rc = orbfe_enqueue_pose_optimization(ctx, n_problems, (const int32_t *)(db + o_off), (const orbfe_keypoint *)(db + o_keys), (const float *)(db + o_ur),
+                                             (const uint8_t *)(db + o_has), (const float *)(db + o_xw), (float *)(db + o_T), db + o_out,
+                                             (int32_t *)(db + o_n), max_n, nullptr);
     if (rc != ORBFE_OK) return rc;
+    PTRY(ctx, hipMemcpyAsync(hb, db, down, hipMemcpyDeviceToHost, s));
+    PTRY(ctx, hipStreamSynchronize(s));
     // problems with fewer than 3 correspondences leave their pose untouched on the device (the reference returns
     // before SetPose, src/Optimizer.cc:404-405)
-    PTRY(ctx, hipMemcpyAsync(Tcw, st->T.p, sizeof(float) * 16 * n_problems, hipMemcpyDeviceToHost, s));
-    PTRY(ctx, hipMemcpyAsync(n_inliers, st->ninl.p, sizeof(int32_t) * n_problems, hipMemcpyDeviceToHost, s));
-    if (total > 0) PTRY(ctx, hipMemcpyAsync(outlier, st->out.p, tn, hipMemcpyDeviceToHost, s));
-    PTRY(ctx, hipStreamSynchronize(s));
+    memcpy(Tcw, hb + o_T, sizeof(float) * 16 * n_problems);
+    memcpy(n_inliers, hb + o_n, sizeof(int32_t) * n_problems);
+    if (total > 0) memcpy(outlier, hb + o_out, tn);
     return ORBFE_OK;
 }
 
