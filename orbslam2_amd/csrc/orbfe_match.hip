@@ -213,9 +213,12 @@ struct DevBuf {
 } // namespace
 
 struct orbfe_match_state {
-    DevBuf keys, desc, uright, cells, cell_of, queries, qdesc, qoff, qcnt, list, cursor;
+    DevBuf in_blk, out_blk, cells, cell_of, list; // inputs of a call in one block (one pinned copy up), [cursor | qoff | qcnt] in another
+    uint8_t *h_in = nullptr, *h_out = nullptr;     // pinned images of in_blk / out_blk
+    size_t h_in_bytes = 0, h_out_bytes = 0;
     std::vector<int> h_off, h_cnt;
     std::vector<unsigned long long> h_list;
+    ~orbfe_match_state() { if (h_in) (void)hipHostFree(h_in); if (h_out) (void)hipHostFree(h_out); }
 };
 
 static orbfe_match_state *match_state(orbfe_context *ctx) { return orbfe_ctx_match_state(ctx); }
@@ -235,23 +238,39 @@ static int run_window_queries(orbfe_context *ctx, const orbfe_frame_view *fv, co
     if (n > 65535) return orbfe_fail(ctx, ORBFE_ERR_UNSUPPORTED, "frames with more than 65535 keypoints are not supported by the matchers");
     MTRY(ctx, hipSetDevice(orbfe_ctx_device(ctx)));
     const size_t ncell = GRID_COLS * GRID_ROWS;
-    if (st->keys.ensure(sizeof(KeyPointPOD) * n) || st->desc.ensure((size_t)32 * n) || st->uright.ensure(sizeof(float) * n) ||
-        st->cells.ensure(sizeof(int) * (2 * ncell + 2 + n)) || st->cell_of.ensure(sizeof(int) * n) ||
-        st->queries.ensure(sizeof(MatchQuery) * nq) || st->qdesc.ensure((size_t)32 * nq) || st->qoff.ensure(sizeof(int) * nq) ||
-        st->qcnt.ensure(sizeof(int) * nq) || st->cursor.ensure(sizeof(int)))
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t i_keys = 0, i_desc = up16(i_keys + sizeof(KeyPointPOD) * n), i_ur = up16(i_desc + (size_t)32 * n);
+    const size_t i_q = up16(i_ur + sizeof(float) * n), i_qd = up16(i_q + sizeof(MatchQuery) * nq), in_bytes = up16(i_qd + (size_t)32 * nq);
+    const size_t o_cur = 0, o_off = 16, o_cnt = up16(o_off + sizeof(int) * nq), out_bytes = up16(o_cnt + sizeof(int) * nq);
+    if (st->in_blk.ensure(in_bytes) || st->out_blk.ensure(out_bytes) || st->cells.ensure(sizeof(int) * (2 * ncell + 2 + n)) ||
+        st->cell_of.ensure(sizeof(int) * n))
         return orbfe_fail(ctx, ORBFE_ERR_HIP, "matcher scratch allocation failed");
+    if (st->h_in_bytes < in_bytes) {
+        if (st->h_in) (void)hipHostFree(st->h_in);
+        st->h_in = nullptr; st->h_in_bytes = 0;
+        MTRY(ctx, hipHostMalloc((void **)&st->h_in, in_bytes, hipHostMallocDefault));
+        st->h_in_bytes = in_bytes;
+    }
+    if (st->h_out_bytes < out_bytes) {
+        if (st->h_out) (void)hipHostFree(st->h_out);
+        st->h_out = nullptr; st->h_out_bytes = 0;
+        MTRY(ctx, hipHostMalloc((void **)&st->h_out, out_bytes, hipHostMallocDefault));
+        st->h_out_bytes = out_bytes;
+    }
+    uint8_t *din = (uint8_t *)st->in_blk.p, *dout = (uint8_t *)st->out_blk.p;
     MatchFrame f;
-    f.keys = (const KeyPointPOD *)st->keys.p; f.desc = (const uint8_t *)st->desc.p;
-    f.u_right = fv->u_right ? (const float *)st->uright.p : nullptr;
+    f.keys = (const KeyPointPOD *)(din + i_keys); f.desc = din + i_desc;
+    f.u_right = fv->u_right ? (const float *)(din + i_ur) : nullptr;
     f.n = n; f.min_x = fv->min_x; f.min_y = fv->min_y;
     f.inv_w = (float)GRID_COLS / (fv->max_x - fv->min_x); // mfGridElementWidthInv, src/Frame.cc:99
     f.inv_h = (float)GRID_ROWS / (fv->max_y - fv->min_y);
     f.cell_cnt = (int *)st->cells.p; f.cell_off = f.cell_cnt + ncell; f.cell_idx = f.cell_off + ncell + 1;
-    MTRY(ctx, hipMemcpyAsync(st->keys.p, fv->keys_un, sizeof(KeyPointPOD) * n, hipMemcpyHostToDevice, s));
-    MTRY(ctx, hipMemcpyAsync(st->desc.p, fv->descriptors, (size_t)32 * n, hipMemcpyHostToDevice, s));
-    if (fv->u_right) MTRY(ctx, hipMemcpyAsync(st->uright.p, fv->u_right, sizeof(float) * n, hipMemcpyHostToDevice, s));
-    MTRY(ctx, hipMemcpyAsync(st->queries.p, queries.data(), sizeof(MatchQuery) * nq, hipMemcpyHostToDevice, s));
-    MTRY(ctx, hipMemcpyAsync(st->qdesc.p, qdesc.data(), (size_t)32 * nq, hipMemcpyHostToDevice, s));
+    memcpy(st->h_in + i_keys, fv->keys_un, sizeof(KeyPointPOD) * n);
+    memcpy(st->h_in + i_desc, fv->descriptors, (size_t)32 * n);
+    if (fv->u_right) memcpy(st->h_in + i_ur, fv->u_right, sizeof(float) * n);
+    memcpy(st->h_in + i_q, queries.data(), sizeof(MatchQuery) * nq);
+    memcpy(st->h_in + i_qd, qdesc.data(), (size_t)32 * nq);
+    MTRY(ctx, hipMemcpyAsync(din, st->h_in, in_bytes, hipMemcpyHostToDevice, s));
     MTRY(ctx, hipMemsetAsync(f.cell_cnt, 0, sizeof(int) * ncell, s));
     hipLaunchKernelGGL(grid_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, f, (int *)st->cell_of.p);
     hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, s, f);
@@ -261,18 +280,18 @@ static int run_window_queries(orbfe_context *ctx, const orbfe_frame_view *fv, co
     if (cap < (size_t)nq * 64) cap = (size_t)nq * 64;
     for (int attempt = 0; attempt < 2; attempt++) {
         if (st->list.ensure(cap * 8)) return orbfe_fail(ctx, ORBFE_ERR_HIP, "candidate list allocation failed");
-        MTRY(ctx, hipMemsetAsync(st->cursor.p, 0, sizeof(int), s));
-        hipLaunchKernelGGL(window_candidates_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, f, (const MatchQuery *)st->queries.p,
-                           (const uint8_t *)st->qdesc.p, nq, (int *)st->qoff.p, (int *)st->qcnt.p,
-                           (unsigned long long *)st->list.p, (int *)st->cursor.p, (int)std::min<size_t>(cap, INT_MAX));
-        int total = 0;
-        MTRY(ctx, hipMemcpyAsync(&total, st->cursor.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        MTRY(ctx, hipMemsetAsync(dout + o_cur, 0, sizeof(int), s));
+        hipLaunchKernelGGL(window_candidates_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, f, (const MatchQuery *)(din + i_q),
+                           (const uint8_t *)(din + i_qd), nq, (int *)(dout + o_off), (int *)(dout + o_cnt),
+                           (unsigned long long *)st->list.p, (int *)(dout + o_cur), (int)std::min<size_t>(cap, INT_MAX));
+        MTRY(ctx, hipMemcpyAsync(st->h_out, dout, out_bytes, hipMemcpyDeviceToHost, s));
         MTRY(ctx, hipStreamSynchronize(s));
         MTRY(ctx, hipGetLastError());
+        const int total = *(const int *)(st->h_out + o_cur);
         if ((size_t)total <= cap) {
             st->h_list.resize(total);
-            MTRY(ctx, hipMemcpy(st->h_off.data(), st->qoff.p, sizeof(int) * nq, hipMemcpyDeviceToHost));
-            MTRY(ctx, hipMemcpy(st->h_cnt.data(), st->qcnt.p, sizeof(int) * nq, hipMemcpyDeviceToHost));
+            memcpy(st->h_off.data(), st->h_out + o_off, sizeof(int) * nq);
+            memcpy(st->h_cnt.data(), st->h_out + o_cnt, sizeof(int) * nq);
             if (total > 0) MTRY(ctx, hipMemcpy(st->h_list.data(), st->list.p, sizeof(unsigned long long) * total, hipMemcpyDeviceToHost));
             return ORBFE_OK;
         }
