@@ -42,5 +42,34 @@ def main():
         print(name, len(kl), len(kr), m)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--widenings" not in sys.argv:
     main()
+
+
+def make_widenings(path):
+    """Golden vectors of the section 8(f) widenings: PoseOptimization, undistortPoints, cvtColor->GRAY, remap.  Inputs are
+    regenerated from seeds by tests/test_golden.py; only the expected outputs (and input digests) are stored."""
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_pose as tp
+    s = tp.scene(4242, n=600)
+    T, outl, ninl = tp._oracle(s, np.eye(4, dtype=np.float32))
+    rng = np.random.default_rng(77)
+    pts = rng.uniform(-10, 650, (200, 2)).astype(np.float32)
+    dist = np.array([0.262383, -0.953104, -0.005358, 0.002628, 1.163314], np.float32)
+    und = O.undistort_points(pts, 517.3, 516.5, 318.6, 255.3, dist)
+    bounds = O.image_bounds(640, 480, 517.3, 516.5, 318.6, 255.3, dist)
+    rgb = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    gray = O.cvt_gray(rgb, True)
+    gray_bgr14 = O.cvt_gray(rgb, False, True)
+    X, Y = np.meshgrid(np.arange(64, dtype=np.float32), np.arange(48, dtype=np.float32))
+    mx = (X * 0.97 + 0.013 * Y + 1.37).astype(np.float32); my = (Y * 1.02 - 0.011 * X - 0.81).astype(np.float32)
+    rem = O.remap_bilinear(gray, mx, my)
+    np.savez_compressed(path, pose_T=T, pose_outlier=outl, pose_ninl=np.int32(ninl),
+                        pose_in_sha=np.frombuffer(hashlib.sha256(s["keys"].tobytes() + s["Xw"].tobytes()).digest(), np.uint8),
+                        und=und, bounds=bounds, gray=gray, gray_bgr14=gray_bgr14, remap=rem)
+
+
+if __name__ == "__main__" and "--widenings" in __import__("sys").argv:
+    make_widenings(os.path.join(ROOT, "tests", "golden", "widenings_r01.npz"))
