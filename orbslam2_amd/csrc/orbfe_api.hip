@@ -528,6 +528,33 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
         b.patch_uv = d_uv;
         ctx->cfg.patch_n = (int)uv.size();
     }
+    {   // the same patch as byte-dot-product weights for describe_kernel's hp == 15 path: the 31 x 31 window as 31 rows x 8
+        // four-pixel words (u = -15 .. 16), grid word s = lane + 64 k; per (k, lane): [0..3] weights (u + 16) inside the
+        // circle else 0, [4..7] weights 1 / 0, [8..11] row offset r * 40 + 4 w | (v & 0xff) << 16
+        std::vector<uint32_t> mt(12 * 64, 0u);
+        if (p.half_patch_size == 15)
+            for (int k = 0; k < 4; k++)
+                for (int lane = 0; lane < 64; lane++) {
+                    const int sidx = lane + 64 * k, r = sidx >> 3, w = sidx & 7;
+                    if (r >= 31) continue;
+                    const int v = r - 15, um = c.umax[v < 0 ? -v : v];
+                    uint32_t wu = 0, w1 = 0;
+                    for (int j = 0; j < 4; j++) {
+                        const int u = 4 * w + j - 15;
+                        if (u >= -um && u <= um) { wu |= (uint32_t)(u + 16) << (8 * j); w1 |= 1u << (8 * j); }
+                    }
+                    mt[(size_t)k * 64 + lane] = wu;
+                    mt[(size_t)(4 + k) * 64 + lane] = w1;
+                    mt[(size_t)(8 + k) * 64 + lane] = (uint32_t)(r * 40 + 4 * w) | ((uint32_t)(v & 0xff) << 16);
+                }
+        uint32_t *d_mt = nullptr;
+        A(d_mt, mt.size());
+        if (hipMemcpy(d_mt, mt.data(), mt.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            orbfe_destroy(ctx);
+            return fail(nullptr, ORBFE_ERR_HIP, "moment table upload failed");
+        }
+        b.mom_tab = d_mt;
+    }
     Z(b.kp_cnt, sizeof(int) * B);
     Z(b.sel_cnt, sizeof(int) * B * c.nlevels);
     Z(b.status, sizeof(int) * B);

@@ -133,6 +133,23 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, Devi
     // instructions, part of them double precision, would otherwise be repeated per keypoint by all 64 lanes);
     // pass 2: blurred patches -> descriptors and keypoint records.
     int m10_l = 0, m01_l = 0;
+    // hp == 15 (the reference's HALF_PATCH_SIZE): the 31 x 31 patch is read as 31 rows x 8 four-pixel words (u = -15 .. 16),
+    // word s = lane + 64 k of that grid per lane, and the moments come from byte dot products against per-lane constant
+    // weight words: m10 = sum (u + 16) I - 16 sum I, m01 = sum_rows v * (row sum I), the circle mask folded into the weights
+    // (0 outside |u| <= umax[|v|]).  Integer sums: the order does not matter, the result is IC_Angle's exactly.
+    const bool dot_moments = hp == 15;
+    uint32_t mw_u[4] = {0, 0, 0, 0}, mw_1[4] = {0, 0, 0, 0};
+    int mw_v[4] = {0, 0, 0, 0}, mw_off[4] = {0, 0, 0, 0};
+    if (dot_moments) { // host-built per-lane constants (orbfe_api.hip): 12 coalesced loads per wave
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            mw_u[k] = buf.mom_tab[k * 64 + lane];
+            mw_1[k] = buf.mom_tab[(4 + k) * 64 + lane];
+            const uint32_t e = buf.mom_tab[(8 + k) * 64 + lane];
+            mw_off[k] = (int)(e & 0xffffu);
+            mw_v[k] = (int)(int8_t)(e >> 16);
+        }
+    }
     bool have = prefetch_raw(0);
     for (int i = 0; i < DS_KPW; i++) {
         const bool cur = have;
@@ -165,13 +182,29 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, Devi
         // table, padded with (0,0) entries that contribute nothing)
         const int xr = (kx - hp) & ~3;
         int m10 = 0, m01 = 0;
-        const uint8_t *pc = s_raw + hp * DS_PATCH_W + (kx - xr);
-        for (int kk = lane; kk < cfg.patch_n; kk += 64) {
-            const int uv = s_uv[kk];
-            const int u = (int)(int8_t)(uv & 0xff), v = (int)(int8_t)((uv >> 8) & 0xff);
-            const int I = pc[__mul24(v, DS_PATCH_W) + u];
-            m10 += u * I;
-            m01 += v * I;
+        if (dot_moments) {
+            const unsigned a = (unsigned)(kx - hp - xr); // byte of u = -15 inside its aligned word (wave-uniform)
+            unsigned acc_u = 0;
+            int acc_1 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t lo = *(const uint32_t *)(s_raw + mw_off[k]), hi = *(const uint32_t *)(s_raw + mw_off[k] + 4);
+                const uint32_t px = __builtin_amdgcn_alignbyte(hi, lo, a);
+                acc_u = __builtin_amdgcn_udot4(px, mw_u[k], acc_u, false);
+                const int t = (int)__builtin_amdgcn_udot4(px, mw_1[k], 0u, false);
+                acc_1 += t;
+                m01 += mw_v[k] * t;
+            }
+            m10 = (int)acc_u - 16 * acc_1;
+        } else {
+            const uint8_t *pc = s_raw + hp * DS_PATCH_W + (kx - xr);
+            for (int kk = lane; kk < cfg.patch_n; kk += 64) {
+                const int uv = s_uv[kk];
+                const int u = (int)(int8_t)(uv & 0xff), v = (int)(int8_t)((uv >> 8) & 0xff);
+                const int I = pc[__mul24(v, DS_PATCH_W) + u];
+                m10 += u * I;
+                m01 += v * I;
+            }
         }
         m10 = wave_sum_i32(m10);
         m01 = wave_sum_i32(m01);
