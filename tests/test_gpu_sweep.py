@@ -13,6 +13,7 @@ CASES = [
     (777, 333, 1500, 1), (1241, 376, 500, 2), (1241, 376, 4000, 3), (640, 480, 3000, 4), (200, 160, 300, 5),
     (131, 97, 200, 6), (1920, 1080, 2000, 7), (1241, 376, 37, 8), (410, 1000, 800, 9), (1241, 376, 2000, 10),
     (1241, 376, 2000, 11), (96, 64, 100, 12), (64, 62, 50, 13),
+    (3840, 2160, 8000, 14), (2560, 1440, 15000, 15),  # 4K frame; feature budget far above the reference's configurations
 ]
 
 
