@@ -43,7 +43,7 @@ def lib(target: str = "liborb_oracle.so"):
     if target in _libs:
         return _libs[target]
     path = os.path.join(HERE, target)
-    srcs = [os.path.join(HERE, f) for f in ("orb_oracle.c", "orb_oracle_match.c", "orb_oracle.h")]
+    srcs = [os.path.join(HERE, f) for f in ("orb_oracle.c", "orb_oracle_match.c", "orb_oracle_bow.c", "orb_oracle_pose.c", "orb_oracle.h")]
     if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs if os.path.exists(s)):
         build(target)
     L = C.CDLL(path)
