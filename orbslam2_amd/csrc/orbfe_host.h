@@ -3,6 +3,25 @@
 #include <hip/hip_runtime.h>
 #include "../../include/orbfe.h"
 
+// growable device scratch buffer shared by the host-side entry points (matchers, BoW, pose)
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        if (hipMalloc(&p, need) != hipSuccess) return -1;
+        bytes = need;
+        return 0;
+    }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
 struct orbfe_match_state;
 orbfe_match_state *orbfe_match_state_create();
 void orbfe_match_state_destroy(orbfe_match_state *s);

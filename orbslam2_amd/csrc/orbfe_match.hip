@@ -195,21 +195,6 @@ __global__ __launch_bounds__(256) void window_candidates_kernel(MatchFrame f, co
 // ---------------------------------------------------------------------------------------------
 namespace {
 
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-    int ensure(size_t need)
-    {
-        if (need <= bytes) return 0;
-        if (p) hipFree(p);
-        p = nullptr; bytes = 0;
-        if (hipMalloc(&p, need) != hipSuccess) return -1;
-        bytes = need;
-        return 0;
-    }
-    ~DevBuf() { if (p) hipFree(p); }
-};
-
 } // namespace
 
 struct orbfe_match_state {

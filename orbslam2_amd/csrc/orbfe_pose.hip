@@ -683,21 +683,6 @@ constexpr int PO_LDS_CAP_MAX = 4096; // keypoint slots per problem the LDS edge 
 template <int THREADS>
 size_t pose_lds_bytes(int cap) { return sizeof(double) * (2 * (THREADS / 16) * 32 + 2 * 32) + (size_t)cap * (7 * sizeof(float) + 1) + 16; }
 
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-    int ensure(size_t need)
-    {
-        if (need <= bytes) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr; bytes = 0;
-        if (hipMalloc(&p, need) != hipSuccess) return -1;
-        bytes = need;
-        return 0;
-    }
-    ~DevBuf() { if (p) (void)hipFree(p); }
-};
-
 } // namespace
 
 struct orbfe_pose_state {
