@@ -68,6 +68,22 @@ def traffic_bytes(stage: str, pairs: int, launches: int):
         return None
 
 
+def valu_issue(pairs: int, launches: int, launch_ms: float):
+    """Context for the roofline: the dominant kernel is bound by integer-VALU issue, not by HBM.  SQ_INSTS_VALU of the kernel
+    from the committed rocprofv3 pass (profiles/r01_pmc_sq.txt, per launch of 64 pairs), scaled to this run's batch, against
+    the chip's issue rate: 256 CUs x 4 SIMDs x one wave64 instruction per 4 cycles at 2.4 GHz (MI355X_MICROARCH.md)."""
+    try:
+        for line in open(os.path.join(ROOT, "profiles", "r01_pmc_sq.txt")):
+            if "fast_cell_kernel" in line:
+                d = eval(line[line.index("{"):line.rindex("}") + 1], {"__builtins__": {}})
+                insts = d["SQ_INSTS_VALU"] * (pairs / launches) / 64.0
+                peak = 256 * 4 * 2.4e9 / 4
+                return {"wave_insts_per_launch": insts, "peak_wave_insts_per_s": peak, "frac": insts / (launch_ms * 1e-3) / peak}
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(n_pairs: int):
     """Oracle (kind=port) timed with the reference's threading: 2 threads per pair (src/Frame.cc:78-81)."""
     from oracle import oracle as O
@@ -245,6 +261,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bytes(dom, P, launches),
                          "launch_ms": dom_ms, "alg_bytes_per_launch": alg[dom] * P / launches,
+                         "valu_issue": valu_issue(P, launches, dom_ms),
                          "whole_pipeline": {"alg_bytes_per_pair": B_PAIR, "achieved": B_PAIR * value / world / 1e9,
                                             "frac": B_PAIR * value / world / 1e9 / HBM_PEAK_GBS},
                          "stage_ms_per_step_summed_over_groups": per_launch_ms,
