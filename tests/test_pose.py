@@ -175,3 +175,34 @@ def test_gpu_pose_optimization_batch_is_per_problem():
         Tr, outr, nr = _oracle(s, T0[k])
         assert nr == nb[k] and np.array_equal(outr, outb[off[k]:off[k + 1]]) and np.abs(Tr - Tb[k]).max() <= POSE_ATOL
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_pose_optimization_device_resident_matches_host_entry():
+    """orbfe_enqueue_pose_optimization on device-resident arrays (torch tensors, a caller-owned stream) gives exactly what the
+    host entry point gives, for the LDS edge table (max_keypoints <= 4096) and the HBM variant (a larger bound)."""
+    import torch
+    ctx = _ctx()
+    scenes = [scene(60 + k, n=n) for k, n in enumerate([700, 1800, 33])]
+    off = np.cumsum([0] + [len(s["keys"]) for s in scenes]).astype(np.int32)
+    cat = {k: np.concatenate([s[k] for s in scenes]) for k in ("keys", "ur", "has", "Xw")}
+    T0 = np.tile(np.eye(4, dtype=np.float32), (len(scenes), 1, 1))
+    Th, outh, nh = ctx.pose_optimization_batch(T0, off, cat["keys"], cat["ur"], cat["has"], cat["Xw"])
+    dev = torch.device("cuda:0")
+    d = {k: torch.from_numpy(v.view(np.uint8).reshape(-1) if v.dtype.fields else v).to(dev) for k, v in cat.items()}
+    d_off = torch.from_numpy(off).to(dev)
+    st = torch.cuda.Stream()
+    for bound in (int(max(len(s["keys"]) for s in scenes)), 5000):
+        d_T = torch.from_numpy(T0).to(dev)
+        d_out = torch.full((int(off[-1]),), 9, dtype=torch.uint8, device=dev)
+        d_n = torch.zeros(len(scenes), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctx._check(ctx.L.orbfe_enqueue_pose_optimization(ctx.h, len(scenes), d_off.data_ptr(), d["keys"].data_ptr(), d["ur"].data_ptr(),
+                                                         d["has"].data_ptr(), d["Xw"].data_ptr(), d_T.data_ptr(), d_out.data_ptr(),
+                                                         d_n.data_ptr(), bound, st.cuda_stream))
+        st.synchronize()
+        assert np.array_equal(d_T.cpu().numpy(), Th) and np.array_equal(d_n.cpu().numpy(), nh)
+        got = d_out.cpu().numpy()
+        has = cat["has"] > 0
+        assert np.array_equal(got[has], outh[has]) and (got[~has] == 9).all()  # slots without a map point keep the caller's value
+    ctx.close()
