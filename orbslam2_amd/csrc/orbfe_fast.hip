@@ -135,6 +135,18 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
     const int xa = ini_x & ~3, ox = ini_x - xa;
     const int wpr = (max_x - xa + 3) >> 2; // words per tile row
     const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (size_t)ini_y * L.pitch + xa;
+    // The reference runs FAST at iniThFAST and, only when that yields no keypoint in the cell, again at minThFAST
+    // (src/ORBextractor.cc:803-810).  Same here: the first attempt queues and scores only what passes the quick test at
+    // iniTh (about 0.6 of what passes at minTh on the benchmark images, so phases C-E shrink accordingly); a cell without a
+    // survivor re-stages its tile (phase D may have overwritten it with flags) and repeats everything at minTh.  Both
+    // attempts compute exactly cv::FAST(cell, t, true) for their t: scores are threshold-free and a neighbour below t can
+    // never suppress a corner at t.
+    int t = cfg.ini_th;
+    int n2 = 0;
+    unsigned rcq[4];
+    int fq[4];
+    for (int attempt = 0; attempt < 2; attempt++) {
+    n2 = 0;
     if (wpr <= 16) {
         // tile rows of at most 16 words (cells up to ~55 px): a wave-load covers 4 rows x 16 words; lanes beyond the row /
         // the last row repeat the last valid element (same value to the same LDS word), so nothing is predicated
@@ -177,7 +189,6 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
     }
     for (int i = lane; i < sc_bytes / 4; i += 64) ((uint32_t *)s_sc)[i] = 0;
     FAST_WAVE_SYNC();
-    const int t = cfg.min_th;
     if (dbg == 1) { if (lane == 0) *cnt_out = 0; return; }
     // Phases A and C work on TWO pixels per lane, one in each 16-bit half of a register, with packed
     // v_pk_{sub,min,max}_i16 (ring differences are in [-255, 255]): integer VALU issue is what bounds
@@ -196,7 +207,6 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
     //      (3 aligned LDS words per ring row, 21 per group): every ring column x-3..x+3 of the four pixels
     //      lies inside the window, so each ring position is two v_perm_b32 with constant selectors, and the
     //      test runs on raw ring values (with d = v - r: min_k max(d_k, d_k+8) = v - max_k min(r_k, r_k+8)). ----
-    int n2 = 0;
     {
         const int ng = (iw + ox + 3) >> 2;       // groups per interior row; group j covers c = 4j - ox .. 4j - ox + 3
         const int G = ng * ih;
@@ -304,10 +314,8 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
         // all nine reads issued together (a short-circuit chain would be nine dependent LDS round trips)
         const int n0 = p[-scp - 1], n1 = p[-scp], n2_ = p[-scp + 1], n3 = p[-1], n4 = p[1], n5 = p[scp - 1], n6 = p[scp], n7 = p[scp + 1];
         const int mx = max(max(max(n0, n1), max(n2_, n3)), max(max(n4, n5), max(n6, n7)));
-        return ((s > 0) & (s > mx)) ? ((s >= cfg.ini_th) ? 2 : 1) : 0;
+        return ((s > 0) & (s > mx)) ? 1 : 0; // every stored score is >= t
     };
-    unsigned rcq[4];
-    int fq[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int q = lane + 64 * k;
@@ -315,16 +323,19 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
         if (q < n2) {
             rcq[k] = s_q2[q] & 0x7fffu;
             fq[k] = nms_flag(rcq[k]);
-            any |= (fq[k] == 2);
+            any |= (fq[k] != 0);
         }
     }
     for (int q = lane + 256; q < n2; q += 64) {
         const int f = nms_flag(s_q2[q] & 0x7fffu);
-        any |= (f == 2);
+        any |= (f != 0);
         s_qf[q] = (uint8_t)f;
     }
-    const int need = __ballot(any) != 0ull ? 2 : 1;
     FAST_WAVE_SYNC();
+    if (__ballot(any) != 0ull || attempt == 1) break;
+    t = cfg.min_th; // nothing at iniTh: FAST(cell, minThFAST, true)
+    } // attempts
+    const int need = 1;
     (void)q_bytes;
     // ---- E: ordered emission ----
     uint32_t *oxy = buf.cell_xy + ((size_t)img * cfg.cells_total + cell) * cfg.cell_cap;

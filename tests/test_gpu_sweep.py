@@ -194,3 +194,45 @@ def test_random_geometry_and_parameters(i):
     assert np.array_equal(out["desc_left"], dl) and np.array_equal(out["desc_right"], dr), c
     assert np.array_equal(out["u_right"], ur) and np.array_equal(out["depth"], dp), c
     ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["low_contrast", "checker4", "checker3_mixed", "stripes"])
+def test_fast_threshold_fallback_cells(kind):
+    """ComputeKeyPointsOctTree runs FAST at iniThFAST and, for a cell without keypoints, again at minThFAST
+    (src/ORBextractor.cc:803-810).  The kernel does the same per cell (first attempt at iniTh, tile re-staged for the second):
+    low-contrast scenes send most cells through the fallback; periodic patterns give hundreds of equal scores per cell
+    (no strict local maximum at iniTh although many pixels pass it), the case where the first attempt's flags have
+    overwritten the tile."""
+    from orbslam2_amd import api
+    w, h, nf = 640, 360, 1500
+    base_l, base_r = synth.stereo_pair(w, h, seed=91)
+    yy, xx = np.mgrid[0:h, 0:w]
+    if kind == "low_contrast":
+        f = lambda a: np.clip((a.astype(np.float32) - 128.0) * 0.12 + 128.0, 0, 255).astype(np.uint8)
+        left, right = f(base_l), f(base_r)
+    elif kind == "checker4":
+        left = (((xx // 4 + yy // 4) & 1) * 60 + 90).astype(np.uint8)
+        right = np.roll(left, -8, axis=1)
+    elif kind == "checker3_mixed":
+        c = (((xx // 3 + yy // 3) & 1) * 40 + 100).astype(np.uint8)
+        left = np.where(xx < w // 2, c, base_l).astype(np.uint8)
+        right = np.where(xx < w // 2, np.roll(c, -6, axis=1), base_r).astype(np.uint8)
+    else:
+        s = (((xx // 5) & 1) * 50 + ((yy // 7) & 1) * 25 + 80).astype(np.uint8)
+        left, right = s, np.roll(s, -10, axis=1)
+    fx, bf = 0.6 * w, 0.25 * w
+    ctx = api.Context(width=w, height=h, nfeatures=nf, fx=fx, fy=fx, cx=w / 2, cy=h / 2, bf=bf)
+    out = ctx.stereo_frame(left, right)
+    exl, exr = O.Extractor(nfeatures=nf), O.Extractor(nfeatures=nf)
+    kl, dl = exl.extract(left); kr, dr = exr.extract(right)
+    ur, dp, _ = O.stereo_matches(exl, exr, kl, dl, kr, dr, bf, fx)
+    for l in range(8):
+        for a, b in zip(ctx.fetch_candidates(0, l), exl.level_candidates(l)):
+            assert np.array_equal(a, b), "candidates level %d" % l
+    assert np.array_equal(out["kps_left"], kl.astype(api.KP_DTYPE)) and np.array_equal(out["kps_right"], kr.astype(api.KP_DTYPE))
+    assert np.array_equal(out["desc_left"], dl) and np.array_equal(out["desc_right"], dr)
+    assert np.array_equal(out["u_right"], ur) and np.array_equal(out["depth"], dp)
+    if kind == "low_contrast":
+        sc = np.concatenate([exl.level_candidates(l)[2] for l in range(8)])
+        assert (sc < 20).mean() > 0.3 and (sc >= 20).any() and len(kl) > 200  # both kinds of cells occur
+    ctx.close()
