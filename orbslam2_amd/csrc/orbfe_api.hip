@@ -215,7 +215,7 @@ static int build_config(orbfe_context *ctx)
     }
     gaussian_taps_q8(7, 2.0, c.taps);
 
-    size_t pyr_off = 0;
+    size_t pyr_off = 0, blur_off = 0;
     int cell_off = 0, cand_off = 0, sel_off = 0, tile_off = 0, cell_cap = 1, max_nodes = 8;
     for (int l = 0; l < p.nlevels; l++) {
         LevelInfo &L = c.lv[l];
@@ -227,6 +227,11 @@ static int build_config(orbfe_context *ctx)
         L.pitch = (L.w + 16 + 63) & ~63;
         L.pyr_off = (int)(pyr_off + (size_t)3 * L.pitch + 4);
         pyr_off += ((size_t)L.pitch * (L.h + 6) + 255) & ~(size_t)255;
+        // blurred copy: 32 x 4 px tiles (one 128-B line each), only the image itself (describe never leaves it by more than
+        // the 2 px its aligned 40-byte patch rows overshoot: one spare tile column)
+        L.blur_off = (int)blur_off;
+        L.blur_tx = (L.w + 31) / 32 + 1;
+        blur_off += (size_t)L.blur_tx * ((L.h + 3) / 4) * 128;
         if (l > 0) {
             L.rs_scale_x = 1.0 / ((double)L.w / (double)c.lv[l - 1].w);
             L.rs_scale_y = 1.0 / ((double)L.h / (double)c.lv[l - 1].h);
@@ -281,6 +286,7 @@ static int build_config(orbfe_context *ctx)
         tile_off += L.blur_tiles_x * L.blur_tiles_y;
     }
     c.pyr_bytes = pyr_off;
+    c.blur_bytes = blur_off + 256;
     c.cells_total = cell_off > 0 ? cell_off : 1;
     c.cand_total = cand_off > 0 ? cand_off : 4;
     c.sel_total = sel_off;
@@ -351,7 +357,7 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
 #define A(ptr, count) do { rc = dev_alloc(ctx, &(ptr), (count)); if (rc != ORBFE_OK) { orbfe_destroy(ctx); return rc; } } while (0)
 #define Z(ptr, bytes) do { if (hipMemset((ptr), 0, (bytes)) != hipSuccess) { orbfe_destroy(ctx); return fail(nullptr, ORBFE_ERR_HIP, "hipMemset failed"); } } while (0)
     A(b.pyr, B * c.pyr_bytes);
-    A(b.blur, B * c.pyr_bytes);
+    A(b.blur, B * c.blur_bytes);
     A(b.cell_cnt, B * c.cells_total);
     A(b.cell_xy, B * c.cells_total * c.cell_cap);
     A(b.cell_sc, B * c.cells_total * c.cell_cap);
@@ -680,7 +686,7 @@ static DeviceBuffers shift_buffers(const DeviceBuffers &b, const DeviceConfig &c
 {
     DeviceBuffers o = b;
     const size_t i = (size_t)img0;
-    o.pyr += i * c.pyr_bytes; o.blur += i * c.pyr_bytes;
+    o.pyr += i * c.pyr_bytes; o.blur += i * c.blur_bytes;
     o.cell_cnt += i * c.cells_total; o.cell_base += i * c.cells_total;
     o.cell_xy += i * c.cells_total * c.cell_cap; o.cell_sc += i * c.cells_total * c.cell_cap;
     o.cand_xy += i * c.cand_total; o.cand_sc += i * c.cand_total; o.cand_sc2 += i * c.cand_total;
@@ -1183,7 +1189,18 @@ extern "C" int orbfe_fetch_pyramid(orbfe_context *ctx, int image, int level, int
         return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     const LevelInfo &L = ctx->cfg.lv[level];
     if (dst_stride < (size_t)L.w) return fail(ctx, ORBFE_ERR_INVALID, "dst_stride smaller than level width");
-    const uint8_t *src = (blurred ? ctx->buf.blur : ctx->buf.pyr) + (size_t)image * ctx->cfg.pyr_bytes + L.pyr_off;
+    if (blurred) { // tiled on the device (32 x 4 px tiles): download the level's tiles and lay the rows out
+        const size_t bytes = (size_t)L.blur_tx * ((L.h + 3) / 4) * 128;
+        std::vector<uint8_t> t(bytes);
+        HIP_TRY(ctx, hipMemcpy(t.data(), ctx->buf.blur + (size_t)image * ctx->cfg.blur_bytes + L.blur_off, bytes, hipMemcpyDeviceToHost));
+        for (int y = 0; y < L.h; y++)
+            for (int x = 0; x < L.w; x += 32) {
+                const size_t off = ((size_t)(y >> 2) * L.blur_tx + (x >> 5)) * 128 + (size_t)(y & 3) * 32;
+                memcpy(dst + (size_t)y * dst_stride + x, t.data() + off, (size_t)std::min(32, L.w - x));
+            }
+        return ORBFE_OK;
+    }
+    const uint8_t *src = ctx->buf.pyr + (size_t)image * ctx->cfg.pyr_bytes + L.pyr_off;
     HIP_TRY(ctx, hipMemcpy2D(dst, dst_stride, src, (size_t)L.pitch, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost));
     return ORBFE_OK;
 }

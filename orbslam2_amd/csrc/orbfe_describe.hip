@@ -93,11 +93,14 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, Devi
             pr[k] = *(const uint32_t *)(base + ((unsigned)__mul24(e & 0xffu, pitch) + (e >> 8))); // one 32-bit offset: saddr + voffset
         }
     };
-    auto fetch_blr = [&](const uint8_t *base, int pitch) {
+    // the blurred pyramid is stored in 32 x 4 px tiles of 128 B (blur_kernel): pixel (X, Y) of a level is at
+    // ((Y >> 2) * tiles_per_row + (X >> 5)) * 128 + (Y & 3) * 32 + (X & 31)
+    auto fetch_blr = [&](const uint8_t *base /* uniform: level origin */, int tx, int x0, int y0) {
 #pragma unroll
         for (int k = 0; k < DS_BLR_REGS; k++) {
             const unsigned e = wtab[k] >> 16;
-            pb[k] = *(const uint32_t *)(base + ((unsigned)__mul24(e & 0xffu, pitch) + (e >> 8)));
+            const unsigned Y = (unsigned)y0 + (e & 0xffu), X = (unsigned)x0 + (e >> 8);
+            pb[k] = *(const uint32_t *)(base + ((((Y >> 2) * (unsigned)tx + (X >> 5)) << 7) + ((Y & 3u) << 5) + (X & 31u)));
         }
     };
     // slot i of this wave: uniform keypoint data; returns false if the slot holds no keypoint
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, Devi
     auto prefetch_blur = [&](int i) -> bool {
         if (i >= DS_KPW || !slot_data(i)) return false;
         const LevelInfo &L = cfg.lv[level];
-        fetch_blr(buf.blur + (size_t)img * cfg.pyr_bytes + L.pyr_off + (ptrdiff_t)(cy - 18) * L.pitch + ((cx - 18) & ~3), L.pitch);
+        fetch_blr(buf.blur + (size_t)img * cfg.blur_bytes + L.blur_off, L.blur_tx, (cx - 18) & ~3, cy - 18);
         return true;
     };
 

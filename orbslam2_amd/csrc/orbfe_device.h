@@ -20,6 +20,7 @@ struct LevelInfo {
     float hx;              // root width (float, as the reference)
     int cand_off, cand_cap;// candidate array range inside one image's candidate arrays
     int sel_off, sel_cap;  // selected-keypoint slot range inside one image's slot arrays
+    int blur_off, blur_tx; // blurred level: byte offset inside one image's blurred pyramid and 32-px tiles per tile row (tiled layout)
     int blur_tile_off;     // first blur tile of this level in the fused all-level grid
     int blur_tiles_x, blur_tiles_y;
     int scaled_patch;      // int(patchSize * scale)
@@ -48,6 +49,7 @@ struct DeviceConfig {
     int umax[64];
     int taps[7];           // Gaussian 8.8 fixed-point taps
     size_t pyr_bytes;      // per image
+    size_t blur_bytes;     // per image: blurred pyramid, 32 x 4 px tiles of 128 B (see orbfe_pyramid.hip)
     float bf, fx, mb;
     // input pixel format (orbfe_set_input_format): 1 = CV_8UC1; 3 / 4 = interleaved colour converted by ingest with
     // cv::cvtColor's fixed-point weights for channels 0, 1, 2 (in_coef) and in_shift fraction bits

@@ -240,7 +240,9 @@ __global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffe
     const int r0 = (t / L.blur_tiles_x) * BL_ROWS;
     if (x0 >= L.w || r0 >= L.h) return;
     const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + x0;
-    uint8_t *dst = buf.blur + (size_t)img * cfg.pyr_bytes + L.pyr_off + x0;
+    // output in 32 x 4 px tiles of 128 B: describe_kernel's 37-row patches then touch about half as many cache lines
+    uint8_t *dst = buf.blur + (size_t)img * cfg.blur_bytes + L.blur_off + (((unsigned)(r0 >> 2) * L.blur_tx + (x0 >> 5)) << 7) + (x0 & 31);
+    const unsigned tile_row_bytes = (unsigned)L.blur_tx << 7;
     const unsigned k_lo = (unsigned)cfg.taps[0] | ((unsigned)cfg.taps[1] << 8) | ((unsigned)cfg.taps[2] << 16) | ((unsigned)cfg.taps[3] << 24);
     const unsigned k_hi = (unsigned)cfg.taps[4] | ((unsigned)cfg.taps[5] << 8) | ((unsigned)cfg.taps[6] << 16);
     const unsigned k0 = cfg.taps[0], k1 = cfg.taps[1], k2 = cfg.taps[2], k3 = cfg.taps[3];
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffe
                                          k2 * (H[(i + 3) % 7][j] + H[(i + 5) % 7][j]) + k3 * H[(i + 4) % 7][j];
                     o |= ((acc + 32768u) >> 16) << (8 * j);
                 }
-                *(uint32_t *)(dst + (ptrdiff_t)yo * L.pitch) = o;
+                *(uint32_t *)(dst + ((unsigned)((i - 6) >> 2) * tile_row_bytes + (unsigned)(((i - 6) & 3) << 5))) = o;
             }
         }
     }
