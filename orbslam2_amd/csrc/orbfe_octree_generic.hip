@@ -325,10 +325,14 @@ size_t orbfe_octree_lds_bytes(const DeviceConfig &cfg)
 void orbfe_launch_octree_generic(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
 {
     dim3 grid(cfg.nlevels, n_images);
-    static bool attr_set = false; // node tables beyond the default 64 KB of dynamic LDS (wide-aspect images with large quotas)
-    if (!attr_set) {
+    // node tables beyond the default 64 KB of dynamic LDS (wide-aspect images with large quotas); the attribute is per
+    // device, so it is remembered per device ordinal
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
         (void)hipFuncSetAttribute((const void *)octree_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL(octree_generic_kernel, grid, dim3(OT_THREADS), orbfe_octree_lds_bytes(cfg), s, cfg, buf, ot_sort_cap(cfg));
 }

@@ -712,6 +712,7 @@ extern "C" int orbfe_enqueue_pose_optimization(orbfe_context *ctx, int n_problem
     orbfe_pose_state *st = orbfe_ctx_pose_state(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : orbfe_ctx_stream(ctx);
     const orbfe_params *p = orbfe_ctx_params(ctx);
+    PTRY(ctx, hipSetDevice(orbfe_ctx_device(ctx)));
     if (!st->sig.p) { // mvInvLevelSigma2 of the context's pyramid
         if (st->sig.ensure(sizeof(float) * ORBFE_MAX_LEVELS)) return orbfe_fail(ctx, ORBFE_ERR_HIP, "pose scratch allocation failed");
         PTRY(ctx, hipMemcpy(st->sig.p, orbfe_ctx_inv_sigma2(ctx), sizeof(float) * p->nlevels, hipMemcpyHostToDevice));
@@ -720,10 +721,11 @@ extern "C" int orbfe_enqueue_pose_optimization(orbfe_context *ctx, int n_problem
     if (max_keypoints <= PO_LDS_CAP_MAX) {
         const int cap = (std::max(max_keypoints, 1) + 3) & ~3;
         const size_t lds = pose_lds_bytes<TH>(cap);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static bool attr_set[64] = {}; // the attribute is per device
+        const int dev = orbfe_ctx_device(ctx);
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
             PTRY(ctx, hipFuncSetAttribute((const void *)pose_opt_kernel<TH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pose_lds_bytes<TH>(PO_LDS_CAP_MAX)));
-            attr_set = true;
+            attr_set[dev] = true;
         }
         hipLaunchKernelGGL((pose_opt_kernel<TH, true>), dim3(n_problems), dim3(TH), lds, s, d_offsets, (const KeyPointPOD *)d_keys_un, d_u_right,
                            d_has_point, d_Xw, d_Tcw, d_outlier, d_n_inliers, (const float *)st->sig.p, p->fx, p->fy, p->cx, p->cy, p->bf, cap);
