@@ -120,25 +120,35 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, Dev
             // centre row of the right image: bytes cr-5 .. cr+5 (+1 spare) = rc of the 11 shifts
             uint32_t rcw[3];
             __builtin_memcpy(rcw, imR + __mul24(cv, L.pitch) + cr - 5, 12);
-            int dists[11];
+            // |(IL - lc) - (IR_i - rc_i)| for the 11 shifts i, two shifts per register in packed int16 (v_pk_sub / v_pk_max /
+            // v_pk_add; byte pairs zero-extended by one constant-selector v_perm_b32): values are below 511, a lane's sum over
+            // its 8 window pixels below 4088 and the group's over 121 pixels below 61 710, so 16 bits are exact throughout
+            auto pair16 = [](const uint32_t (&w)[3], int j) { // bytes 2j, 2j+1 of the 12-byte window
+                const uint32_t word = w[j >> 1];
+                return __builtin_bit_cast(pk16, (j & 1) ? __builtin_amdgcn_perm(0u, word, 0x0c030c02u) : __builtin_amdgcn_perm(0u, word, 0x0c010c00u));
+            };
+            pk16 kk[6], acc[6];
 #pragma unroll
-            for (int t = 0; t < 11; t++) dists[t] = 0;
+            for (int j = 0; j < 6; j++) { kk[j] = pair16(rcw, j); acc[j] = (pk16){0, 0}; }
 #pragma unroll
             for (int t = 0; t < 8; t++) {
                 const int p = gl + SM_G * t;
                 if (p < 121) {
                     const int py = (p * 745) >> 13, dy = py - 5, dx = p - py * 11 - 5; // p / 11 for p < 128
-                    const int a = (int)imL[__mul24(cv + dy, L.pitch) + cu + dx] - lc;
+                    const short a = (short)((int)imL[__mul24(cv + dy, L.pitch) + cu + dx] - lc);
+                    const pk16 aa = {a, a};
                     uint32_t w[3];
                     __builtin_memcpy(w, imR + __mul24(cv + dy, L.pitch) + cr + dx - 5, 12);
 #pragma unroll
-                    for (int i = 0; i < 11; i++) {
-                        const int rb = (int)((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
-                        const int rc = (int)((rcw[i >> 2] >> (8 * (i & 3))) & 0xffu);
-                        dists[i] += abs(a - (rb - rc));
+                    for (int j = 0; j < 6; j++) {
+                        const pk16 d = aa - (pair16(w, j) - kk[j]);
+                        acc[j] += __builtin_elementwise_max(d, (pk16){0, 0} - d);
                     }
                 }
             }
+            int dists[11];
+#pragma unroll
+            for (int i = 0; i < 11; i++) dists[i] = (i & 1) ? (int)(unsigned short)acc[i >> 1].y : (int)(unsigned short)acc[i >> 1].x;
             int sad_best = 0x7fffffff, best_inc = 0;
 #pragma unroll
             for (int i = 0; i < 11; i++) {
