@@ -245,9 +245,14 @@ __global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffe
     const unsigned tile_row_bytes = (unsigned)L.blur_tx << 7;
     const unsigned k_lo = (unsigned)cfg.taps[0] | ((unsigned)cfg.taps[1] << 8) | ((unsigned)cfg.taps[2] << 16) | ((unsigned)cfg.taps[3] << 24);
     const unsigned k_hi = (unsigned)cfg.taps[4] | ((unsigned)cfg.taps[5] << 8) | ((unsigned)cfg.taps[6] << 16);
-    const unsigned k0 = cfg.taps[0], k1 = cfg.taps[1], k2 = cfg.taps[2], k3 = cfg.taps[3];
+    const unsigned k6 = cfg.taps[6];
     const int y_max = L.h + PYR_MY - 1; // last materialised row
-    unsigned H[7][4];
+    // column pass on consecutive-row pairs: P[i % 6][j] = H_i | H_(i+1) << 16 (row sums fit 16 bits: <= 255 * 256), so the
+    // seven taps are three v_dot2_u32_u16 and one v_mad: k0 H_(i-6) + k1 H_(i-5) | k2 H_(i-4) + k3 H_(i-3) | k4 H_(i-2) + k5 H_(i-1) | k6 H_i
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 t01 = {(unsigned short)cfg.taps[0], (unsigned short)cfg.taps[1]}, t23 = {(unsigned short)cfg.taps[2], (unsigned short)cfg.taps[3]};
+    const u16x2 t45 = {(unsigned short)cfg.taps[4], (unsigned short)cfg.taps[5]};
+    unsigned P[6][4], hp[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < BL_ROWS + 6; i++) {
         int y = r0 - 3 + i;
@@ -261,22 +266,27 @@ __global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffe
             const unsigned hi = j == 3 ? w2 : __builtin_amdgcn_alignbyte(w2, w1, j + 1);
             hn[j] = __builtin_amdgcn_udot4(lo, k_lo, __builtin_amdgcn_udot4(hi, k_hi, 0u, false), false);
         }
-#pragma unroll
-        for (int j = 0; j < 4; j++) H[i % 7][j] = hn[j];
         if (i >= 6) {
             const int yo = r0 + i - 6;
             if (yo < L.h) {
-                // rows of the window in age order: oldest is slot (i+1)%7
                 unsigned o = 0;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const unsigned acc = k0 * (H[(i + 1) % 7][j] + H[i % 7][j]) + k1 * (H[(i + 2) % 7][j] + H[(i + 6) % 7][j]) +
-                                         k2 * (H[(i + 3) % 7][j] + H[(i + 5) % 7][j]) + k3 * H[(i + 4) % 7][j];
-                    o |= ((acc + 32768u) >> 16) << (8 * j);
+                    unsigned acc = k6 * hn[j] + 32768u;
+                    acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, P[(i - 6) % 6][j]), t01, acc, false);
+                    acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, P[(i - 4) % 6][j]), t23, acc, false);
+                    acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, P[(i - 2) % 6][j]), t45, acc, false);
+                    o |= (acc >> 16) << (8 * j);
                 }
                 *(uint32_t *)(dst + ((unsigned)((i - 6) >> 2) * tile_row_bytes + (unsigned)(((i - 6) & 3) << 5))) = o;
             }
         }
+        if (i >= 1) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) P[(i - 1) % 6][j] = hp[j] | (hn[j] << 16); // pair (i-1, i); the slot's previous pair (i-7, i-6) is dead
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) hp[j] = hn[j];
     }
 }
 
