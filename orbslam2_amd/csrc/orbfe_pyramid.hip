@@ -30,6 +30,7 @@ __device__ __forceinline__ uint32_t remap_px(const DeviceConfig &cfg, const uint
     return (uint32_t)((s * 32 + (1 << 14)) >> 15);
 }
 
+#define ING_ROWS 4
 template <int CN, bool REMAP = false>
 __global__ __launch_bounds__(256) void ingest_kernel(DeviceConfig cfg, DeviceBuffers buf, const uint8_t *__restrict__ src)
 {
@@ -40,9 +41,14 @@ __global__ __launch_bounds__(256) void ingest_kernel(DeviceConfig cfg, DeviceBuf
         if (img & 1)
             for (int i = threadIdx.x; i < cfg.height; i += 256) buf.row_cnt[(size_t)(img >> 1) * cfg.height + i] = 0;
     }
-    const int y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6)) - PYR_MY;
     const int x0 = (int)(blockIdx.x * 64 + (threadIdx.x & 63)) * 4 - PYR_MX;
-    if (x0 >= L.w + 8 || y >= L.h + PYR_MY) return;
+    if (x0 >= L.w + 8) return;
+    // a wave copies ING_ROWS consecutive rows of its 64-word strip (one word per lane and row): four times fewer, longer
+    // waves than one row per wave
+#pragma unroll
+    for (int rr = 0; rr < ING_ROWS; rr++) {
+    const int y = (int)(blockIdx.y * (4 * ING_ROWS) + (threadIdx.x >> 6) * ING_ROWS + rr) - PYR_MY;
+    if (y >= L.h + PYR_MY) break;
     uint32_t v = 0;
     if constexpr (REMAP) {
         const uint8_t *simg = src + (size_t)img * cfg.in_image_bytes;
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(DeviceConfig cfg, DeviceBuf
         for (int j = 0; j < 4; j++) v |= remap_px(cfg, simg, side, reflect101(x0 + j, L.w), yy) << (8 * j);
         uint8_t *dr = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (ptrdiff_t)y * L.pitch + x0;
         *(uint32_t *)dr = v;
-        return;
+        continue;
     }
     const uint8_t *s = src + ((size_t)img * L.h + (size_t)reflect101(y, L.h)) * L.w * CN;
     if constexpr (CN == 1) {
@@ -83,6 +89,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(DeviceConfig cfg, DeviceBuf
     }
     uint8_t *d = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (ptrdiff_t)y * L.pitch + x0;
     *(uint32_t *)d = v;
+    } // rows
 }
 
 // pyramid: level l from level l-1 (cv::resize INTER_LINEAR, 8UC1 fixed point) over the extended (margin-
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffe
 void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, const uint8_t *d_images, int n_images, hipStream_t s)
 {
     const int words = (cfg.lv[0].w + 12 + 3) / 4;
-    dim3 grid((words + 63) / 64, (cfg.lv[0].h + 2 * PYR_MY + 3) / 4, n_images);
+    dim3 grid((words + 63) / 64, (cfg.lv[0].h + 2 * PYR_MY + 4 * ING_ROWS - 1) / (4 * ING_ROWS), n_images);
     if (cfg.rm_on) hipLaunchKernelGGL((ingest_kernel<1, true>), grid, dim3(256), 0, s, cfg, buf, d_images);
     else if (cfg.in_cn == 3) hipLaunchKernelGGL(ingest_kernel<3>, grid, dim3(256), 0, s, cfg, buf, d_images);
     else if (cfg.in_cn == 4) hipLaunchKernelGGL(ingest_kernel<4>, grid, dim3(256), 0, s, cfg, buf, d_images);
