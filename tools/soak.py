@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""One-off soak: many random scenes / sizes / thresholds, stereo frame HIP vs oracle, bit for bit.  python3 tools/soak.py [n]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from orbslam2_amd import api, synth  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+bad = 0
+for i in range(n):
+    rng = np.random.default_rng(7000 + i)
+    w, h = int(rng.integers(120, 700)), int(rng.integers(100, 420))
+    nf = int(rng.integers(50, 2500))
+    ini = int(rng.integers(8, 45)); mn = int(rng.integers(3, ini + 1))
+    left, right = synth.stereo_pair(w, h, seed=9000 + i)
+    if i % 3 == 1:  # low contrast: many cells fall back to minTh
+        f = float(rng.uniform(0.05, 0.4))
+        left = np.clip((left.astype(np.float32) - 128) * f + 128, 0, 255).astype(np.uint8)
+        right = np.clip((right.astype(np.float32) - 128) * f + 128, 0, 255).astype(np.uint8)
+    fx, bf = 0.7 * w, 0.2 * w
+    kw = dict(nfeatures=nf, ini_th_fast=ini, min_th_fast=mn)
+    ctx = api.Context(width=w, height=h, fx=fx, fy=fx, cx=w / 2, cy=h / 2, bf=bf, **kw)
+    out = ctx.stereo_frame(left, right)
+    exl, exr = O.Extractor(**kw), O.Extractor(**kw)
+    kl, dl = exl.extract(left); kr, dr = exr.extract(right)
+    ur, dp, _ = O.stereo_matches(exl, exr, kl, dl, kr, dr, bf, fx)
+    ok = (np.array_equal(out["kps_left"], kl.astype(api.KP_DTYPE)) and np.array_equal(out["kps_right"], kr.astype(api.KP_DTYPE)) and
+          np.array_equal(out["desc_left"], dl) and np.array_equal(out["desc_right"], dr) and np.array_equal(out["u_right"], ur) and
+          np.array_equal(out["depth"], dp))
+    if not ok:
+        bad += 1
+        print("MISMATCH case", i, w, h, kw)
+    ctx.close()
+print("soak: %d cases, %d mismatches" % (n, bad))
+sys.exit(1 if bad else 0)
