@@ -360,8 +360,8 @@ int orbfe_detect_reloc_candidates(orbfe_context *ctx, const uint32_t *q_words, c
  *   outlier   pFrame->mvbOutlier, in/out: written for entries with a point, others keep their value
  *   n_inliers the return value, nInitialCorrespondences - nBad
  * Camera (fx, fy, cx, cy, bf) and mvInvLevelSigma2 are the context's.  FP64 throughout like g2o; sums are reduced in a
- * fixed tree order instead of edge order, so poses agree with the CPU path to rounding (about 1e-6 relative), not bit
- * for bit.  The batch form runs one workgroup per problem (frames of independent sequences / relocalisation
+ * fixed tree order instead of edge order, so poses agree with the CPU path to about 1e-5 absolute (usually exactly; the
+ * solver's stop rules can differ by one tiny iteration), not bit for bit.  The batch form runs one workgroup per problem (frames of independent sequences / relocalisation
  * candidates); offsets[n_problems + 1] delimits each problem's slice of the per-keypoint arrays, Tcw is n_problems x 16. */
 int orbfe_pose_optimization(orbfe_context *ctx, float *Tcw, int n, const orbfe_keypoint *keys_un, const float *u_right,
                             const uint8_t *has_point, const float *Xw, uint8_t *outlier, int *n_inliers);

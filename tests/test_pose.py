@@ -4,8 +4,11 @@ CPU part: first-principles known answers for the oracle restatement (oracle/orb_
 a known camera pose must be recovered, gross outliers must be flagged, the degenerate cases must follow the reference.
 GPU part: the HIP kernel (orbslam2_amd/csrc/orbfe_pose.hip, through the C ABI) against the oracle.  The arithmetic is
 FP64 on both sides but the normal equations are summed in a different order (block tree vs edge order), so the poses are
-compared with a tolerance: 2e-6 absolute on the float32 pose entries (rotation entries are <= 1, translations here are
-below 1 m) -- the outlier flags and the inlier count are integers and must be equal.
+compared with a tolerance: 1e-5 absolute on the float32 pose entries (rotation entries are <= 1, translations here are
+below 1 m).  Typical differences are 0 to a few 1e-7; the bound is set by the solver's stop rules, which compare nearly equal
+chi2 values (gain ratio > 0, improvement < 0.1 % three times): a last-bit difference in a sum can end a round one iteration
+earlier or later, and the poses then differ by that last, tiny step (3e-6 in 1 of 300 random scenes, tools/soak_pose.py).
+The outlier flags and the inlier count are integers and must be equal.
 """
 import numpy as np
 import pytest
@@ -14,7 +17,7 @@ from oracle import oracle as O
 
 CAM = dict(fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, bf=386.1448)
 INV_SIGMA2 = (1.0 / (np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2).astype(np.float32)
-POSE_ATOL = 2e-6
+POSE_ATOL = 1e-5
 
 
 def _rot(rv):
