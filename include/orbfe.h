@@ -169,6 +169,12 @@ int orbfe_fetch_image(orbfe_context *ctx, int image, orbfe_keypoint *kps, uint8_
                       float *u_right, float *depth, int cap, int *n);
 /* Per-image keypoint counts of the latest batch (n_images ints). */
 int orbfe_fetch_counts(orbfe_context *ctx, int32_t *counts, int n_images);
+/* Results of the latest batched call for image slots 0 .. n_images-1, copied asynchronously on `stream` (NULL: the context's)
+ * into caller buffers laid out like the device arrays: [image][orbfe_keypoint_capacity()] records (kps 28 B, desc 32 B,
+ * u_right / depth float; left-image slots only carry the last two) and counts[n_images].  Pinned host memory makes the
+ * copies overlap other streams' work; any pointer may be NULL.  Synchronise the stream before reading. */
+int orbfe_fetch_batch_async(orbfe_context *ctx, int n_images, orbfe_keypoint *kps, uint8_t *desc, int32_t *counts,
+                            float *u_right, float *depth, void *stream);
 /* Device pointers to the result buffers (for consumers that stay on the GPU):
  * keypoints [max_images][capacity], descriptors [max_images][capacity][32],
  * counts [max_images], u_right/depth [max_images][capacity]. */

@@ -31,7 +31,7 @@ EXPORTS = [
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_kf", "orbfe_search_for_initialization",
     "orbfe_vocab_load", "orbfe_bow_transform", "orbfe_bow_maps", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",  # bound in orbslam2_amd/bow.py
     "orbfe_search_for_triangulation", "orbfe_fuse", "orbfe_search_by_projection_sim3", "orbfe_fuse_sim3", "orbfe_search_by_sim3", "orbfe_kfdb_clear", "orbfe_kfdb_add", "orbfe_kfdb_erase", "orbfe_kfdb_size", "orbfe_kfdb_score", "orbfe_detect_reloc_candidates",
-    "orbfe_pose_optimization", "orbfe_pose_optimization_batch", "orbfe_enqueue_pose_optimization", "orbfe_set_input_format", "orbfe_set_rectification", "orbfe_set_distortion", "orbfe_undistort_keypoints", "orbfe_fetch_keys_un", "orbfe_image_bounds",
+    "orbfe_pose_optimization", "orbfe_pose_optimization_batch", "orbfe_enqueue_pose_optimization", "orbfe_set_input_format", "orbfe_fetch_batch_async", "orbfe_set_rectification", "orbfe_set_distortion", "orbfe_undistort_keypoints", "orbfe_fetch_keys_un", "orbfe_image_bounds",
 ]
 NUM_STAGES = 8
 STAGE_NAMES = ["ingest", "pyramid", "blur", "fast", "octree", "describe", "stereo_match", "stereo_median"]  # orbfe_stage_name()
@@ -144,6 +144,8 @@ def load():
     L.orbfe_fetch_keys_un.argtypes = [vp, C.c_int, vp, C.c_int, ip]
     L.orbfe_image_bounds.restype = C.c_int
     L.orbfe_image_bounds.argtypes = [vp, vp]
+    L.orbfe_fetch_batch_async.restype = C.c_int
+    L.orbfe_fetch_batch_async.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.orbfe_set_rectification.restype = C.c_int
     L.orbfe_set_rectification.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int]
     L.orbfe_set_input_format.restype = C.c_int
@@ -325,6 +327,11 @@ class Context:
 
     def synchronize(self, stream: int = 0):
         self._check(self.L.orbfe_synchronize(self.h, C.c_void_p(stream)))
+
+    def fetch_batch_async(self, n_images, kps_ptr, desc_ptr, counts_ptr, u_right_ptr, depth_ptr, stream=0):
+        """Raw-pointer form (pinned host buffers owned by the caller); see include/orbfe.h."""
+        self._check(self.L.orbfe_fetch_batch_async(self.h, n_images, C.c_void_p(kps_ptr), C.c_void_p(desc_ptr), C.c_void_p(counts_ptr),
+                                                   C.c_void_p(u_right_ptr), C.c_void_p(depth_ptr), C.c_void_p(stream)))
 
     def fetch_counts(self, n_images):
         c = np.zeros(n_images, np.int32)

@@ -957,6 +957,20 @@ extern "C" int orbfe_fetch_counts(orbfe_context *ctx, int32_t *counts, int n_ima
     return ORBFE_OK;
 }
 
+extern "C" int orbfe_fetch_batch_async(orbfe_context *ctx, int n_images, orbfe_keypoint *kps, uint8_t *desc, int32_t *counts,
+                                       float *u_right, float *depth, void *stream)
+{
+    if (!ctx || n_images < 1 || n_images > ctx->params.max_images) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
+    hipStream_t s = pick_stream(ctx, stream);
+    const size_t n = (size_t)n_images * ctx->cfg.sel_total;
+    if (kps) HIP_TRY(ctx, hipMemcpyAsync(kps, ctx->buf.kps, sizeof(KeyPointPOD) * n, hipMemcpyDeviceToHost, s));
+    if (desc) HIP_TRY(ctx, hipMemcpyAsync(desc, ctx->buf.desc, (size_t)32 * n, hipMemcpyDeviceToHost, s));
+    if (counts) HIP_TRY(ctx, hipMemcpyAsync(counts, ctx->buf.kp_cnt, sizeof(int32_t) * n_images, hipMemcpyDeviceToHost, s));
+    if (u_right) HIP_TRY(ctx, hipMemcpyAsync(u_right, ctx->buf.u_right, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+    if (depth) HIP_TRY(ctx, hipMemcpyAsync(depth, ctx->buf.depth, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+    return ORBFE_OK;
+}
+
 extern "C" int orbfe_fetch_image(orbfe_context *ctx, int image, orbfe_keypoint *kps, uint8_t *desc,
                                  float *u_right, float *depth, int cap, int *n)
 {

@@ -58,3 +58,32 @@ def test_batched_extract_and_profiling(batch):
     with pytest.raises(api.OrbfeError):
         ctx.enqueue_extract(batch["dev"].data_ptr(), 11, 0)  # more than max_images
     ctx.close()
+
+
+def test_fetch_batch_async_into_pinned_buffers(batch):
+    """orbfe_fetch_batch_async: the whole batch's results land in caller (pinned) buffers laid out like the device arrays, on
+    the caller's stream; equal to the per-image fetches."""
+    api, torch = batch["api"], batch["torch"]
+    ctx = api.Context(max_images=10, **CFG)
+    cap = ctx.capacity
+    st = torch.cuda.Stream()
+    h_k = torch.empty(10 * cap * 28, dtype=torch.uint8).pin_memory()
+    h_d = torch.empty(10 * cap * 32, dtype=torch.uint8).pin_memory()
+    h_c = torch.empty(10, dtype=torch.int32).pin_memory()
+    h_u = torch.empty(10 * cap, dtype=torch.float32).pin_memory()
+    h_z = torch.empty(10 * cap, dtype=torch.float32).pin_memory()
+    torch.cuda.synchronize()
+    ctx.enqueue_stereo(batch["dev"].data_ptr(), 5, st.cuda_stream)
+    ctx.fetch_batch_async(10, h_k.data_ptr(), h_d.data_ptr(), h_c.data_ptr(), h_u.data_ptr(), h_z.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    kps = np.frombuffer(h_k.numpy().tobytes(), api.KP_DTYPE).reshape(10, cap)
+    desc = h_d.numpy().reshape(10, cap, 32)
+    cnt = h_c.numpy()
+    ur = h_u.numpy().reshape(10, cap); dp = h_z.numpy().reshape(10, cap)
+    for i, ref in enumerate(batch["ref"]):
+        nl, nr = len(ref["kps_left"]), len(ref["kps_right"])
+        assert cnt[2 * i] == nl and cnt[2 * i + 1] == nr
+        assert np.array_equal(kps[2 * i, :nl], ref["kps_left"]) and np.array_equal(kps[2 * i + 1, :nr], ref["kps_right"])
+        assert np.array_equal(desc[2 * i, :nl], ref["desc_left"]) and np.array_equal(desc[2 * i + 1, :nr], ref["desc_right"])
+        assert np.array_equal(ur[2 * i, :nl], ref["u_right"]) and np.array_equal(dp[2 * i, :nl], ref["depth"])
+    ctx.close()
