@@ -351,3 +351,34 @@ def test_rectified_ingest_matches_remap_then_extract():
     for k in ref:
         assert np.array_equal(out2[k], ref[k]), k
     ctx.close()
+
+
+def test_new_entry_points_reject_bad_arguments():
+    """Error behaviour of the round's new entry points: invalid arguments come back as error codes with a message, never as
+    a crash or a silent default."""
+    from orbslam2_amd import api
+    import ctypes as C
+    ctx = _ctx(SMALL, max_images=2)
+    L = ctx.L
+    assert L.orbfe_set_distortion(ctx.h, None, 3) == api.ERR_INVALID
+    assert L.orbfe_set_distortion(ctx.h, None, 0) == api.OK
+    assert L.orbfe_set_input_format(ctx.h, 2, 1, 0) == api.ERR_INVALID
+    mx = np.zeros((SMALL["height"], SMALL["width"]), np.float32)
+    assert L.orbfe_set_rectification(ctx.h, 1, mx.ctypes.data_as(C.c_void_p), mx.ctypes.data_as(C.c_void_p), 100, 100) == api.ERR_INVALID  # right before left
+    assert L.orbfe_set_rectification(ctx.h, 2, None, None, 0, 0) == api.ERR_INVALID
+    assert L.orbfe_set_rectification(ctx.h, 0, mx.ctypes.data_as(C.c_void_p), mx.ctypes.data_as(C.c_void_p), 0, 10) == api.ERR_INVALID
+    assert L.orbfe_fetch_batch_async(ctx.h, 3, None, None, None, None, None, None) == api.ERR_INVALID                                 # more than max_images
+    assert L.orbfe_fetch_batch_async(ctx.h, 2, None, None, None, None, None, None) == api.OK                                          # all outputs optional
+    assert b"" != L.orbfe_last_error(ctx.h)
+    n = C.c_int()
+    assert L.orbfe_pose_optimization(ctx.h, None, 5, None, None, None, None, None, C.byref(n)) == api.ERR_INVALID
+    off = np.array([0, 5, 3], np.int32)  # decreasing offsets
+    T = np.tile(np.eye(4, dtype=np.float32), (2, 1, 1))
+    k = np.zeros(5, api.KP_DTYPE); f = np.zeros(5, np.float32); h = np.zeros(5, np.uint8); X = np.zeros(15, np.float32); ninl = np.zeros(2, np.int32)
+    assert L.orbfe_pose_optimization_batch(ctx.h, 2, off.ctypes.data_as(C.c_void_p), T.ctypes.data_as(C.c_void_p), k.ctypes.data_as(C.c_void_p),
+                                           f.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p), X.ctypes.data_as(C.c_void_p),
+                                           h.ctypes.data_as(C.c_void_p), ninl.ctypes.data_as(C.c_void_p)) == api.ERR_INVALID
+    # the context still works afterwards
+    left, right = synth.stereo_pair(SMALL["width"], SMALL["height"], seed=3)
+    assert len(ctx.stereo_frame(left, right)["kps_left"]) > 50
+    ctx.close()
