@@ -417,3 +417,37 @@ int orc_pose_optimization(float *Tcw, int N, const orc_keypoint *keys_un, const 
     free(E);
     return ne - n_bad;
 }
+
+
+/* ---- test hooks (tests/test_pose.py): the Eigen / g2o building blocks restated above, one at a time ---- */
+void orc_test_quat_roundtrip(const double *R9, double *q4 /* x y z w, normalised as SE3Quat does */, double *Rout9)
+{
+    double m[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) m[i][j] = R9[i * 3 + j];
+    se3q q;
+    q.t[0] = q.t[1] = q.t[2] = 0;
+    quat_from_matrix(m, &q);
+    normalize_rotation(&q);
+    q4[0] = q.x; q4[1] = q.y; q4[2] = q.z; q4[3] = q.w;
+    float T[16];
+    se3_to_cv(&q, T); /* float output of Converter::toCvMat; enough for a 1e-6 round trip */
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rout9[i * 3 + j] = T[i * 4 + j];
+}
+
+void orc_test_se3_exp(const double *u6, double *T12 /* 3x4 row major */)
+{
+    se3q q;
+    se3_exp(u6, &q);
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x, tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    const double R[3][3] = {{1 - (tyy + tzz), txy - twz, txz + twy}, {txy + twz, 1 - (txx + tzz), tyz - twx}, {txz - twy, tyz + twx, 1 - (txx + tyy)}};
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T12[i * 4 + j] = R[i][j]; T12[i * 4 + 3] = q.t[i]; }
+}
+
+int orc_test_ldlt6(const double *H36, const double *b6, double *x6)
+{
+    double H[6][6];
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) H[i][j] = H36[i * 6 + j];
+    return ldlt_solve6(H, b6, x6);
+}

@@ -209,3 +209,63 @@ def test_gpu_pose_optimization_device_resident_matches_host_entry():
         has = cat["has"] > 0
         assert np.array_equal(got[has], outh[has]) and (got[~has] == 9).all()  # slots without a map point keep the caller's value
     ctx.close()
+
+
+# ---------------------------------------------------------------- the Eigen / g2o building blocks of the oracle (CPU)
+
+def _hooks():
+    import ctypes as C
+    L = O.lib()
+    L.orc_test_quat_roundtrip.restype = None; L.orc_test_quat_roundtrip.argtypes = [C.c_void_p] * 3
+    L.orc_test_se3_exp.restype = None; L.orc_test_se3_exp.argtypes = [C.c_void_p] * 2
+    L.orc_test_ldlt6.restype = C.c_int; L.orc_test_ldlt6.argtypes = [C.c_void_p] * 3
+    return L
+
+
+def test_oracle_quaternion_from_matrix_all_branches():
+    """Quaternion(Matrix3) has four branches (trace > 0; largest diagonal entry 0 / 1 / 2): rotations by ~180 degrees about
+    each axis hit the last three.  The quaternion must be unit, have w >= 0 (normalizeRotation) and reproduce the matrix."""
+    L = _hooks()
+    cases = [(0.3, -0.2, 0.1), (3.1, 0.05, -0.02), (0.04, 3.12, 0.03), (-0.03, 0.02, 3.13), (2.2, 2.2, 0.1), (1.5, -1.7, 2.0)]
+    seen = set()
+    for rv in cases:
+        R = np.ascontiguousarray(_rot(np.array(rv)), np.float64)
+        q = np.zeros(4); Ro = np.zeros(9)
+        L.orc_test_quat_roundtrip(R.ctypes.data, q.ctypes.data, Ro.ctypes.data)
+        assert abs(np.linalg.norm(q) - 1) < 1e-12 and q[3] >= 0
+        assert np.abs(Ro.reshape(3, 3) - R).max() < 2e-7, rv
+        d = np.diag(R)
+        seen.add("trace" if np.trace(R) > 0 else int(np.argmax(d)))
+    assert seen == {"trace", 0, 1, 2}
+
+
+def test_oracle_se3_exp_matches_matrix_exponential():
+    """SE3Quat::exp(omega, upsilon) = expm([[skew(omega), upsilon], [0, 0]]) (Rodrigues + the V matrix); below theta = 1e-5 g2o
+    uses I + Omega + Omega^2 for both R and V, kept as it is (its own TODO says so) -- there the two agree to second order only."""
+    from scipy.linalg import expm
+    L = _hooks()
+    rng = np.random.default_rng(2)
+    for _ in range(20):
+        u = np.concatenate([rng.uniform(-1.5, 1.5, 3), rng.uniform(-2, 2, 3)])
+        T = np.zeros(12)
+        L.orc_test_se3_exp(u.ctypes.data, T.ctypes.data)
+        w = u[:3]
+        A = np.zeros((4, 4)); A[:3, :3] = [[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]; A[:3, 3] = u[3:]
+        assert np.abs(T.reshape(3, 4) - expm(A)[:3]).max() < 1e-12
+    tiny = np.array([3e-6, -2e-6, 1e-6, 0.5, -0.25, 0.125])
+    T = np.zeros(12)
+    L.orc_test_se3_exp(tiny.ctypes.data, T.ctypes.data)
+    assert np.abs(T.reshape(3, 4)[:, 3] - tiny[3:]).max() < 1e-5 and np.abs(T.reshape(3, 4)[:, :3] - np.eye(3)).max() < 1e-5
+
+
+def test_oracle_ldlt_solves_and_detects_indefinite():
+    L = _hooks()
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        M = rng.normal(size=(6, 6)) * rng.uniform(0.1, 100, 6)   # badly scaled columns: pivoting is exercised
+        H = np.ascontiguousarray(M @ M.T + 1e-3 * np.eye(6)); b = rng.normal(size=6); x = np.zeros(6)
+        assert L.orc_test_ldlt6(H.ctypes.data, b.ctypes.data, x.ctypes.data) == 1
+        ref = np.linalg.solve(H, b)
+        assert np.abs(x - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()) * np.linalg.cond(H) * 1e-3 + 1e-12
+    H = np.diag([4.0, 1.0, -2.0, 3.0, 5.0, 6.0]); b = np.ones(6); x = np.full(6, 7.0)
+    assert L.orc_test_ldlt6(H.ctypes.data, b.ctypes.data, x.ctypes.data) == 0 and (x == 7.0).all()  # isPositive() false: x untouched
