@@ -269,3 +269,35 @@ def test_oracle_ldlt_solves_and_detects_indefinite():
         assert np.abs(x - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()) * np.linalg.cond(H) * 1e-3 + 1e-12
     H = np.diag([4.0, 1.0, -2.0, 3.0, 5.0, 6.0]); b = np.ones(6); x = np.full(6, 7.0)
     assert L.orc_test_ldlt6(H.ctypes.data, b.ctypes.data, x.ctypes.data) == 0 and (x == 7.0).all()  # isPositive() false: x untouched
+
+
+def test_oracle_pose_is_a_least_squares_optimum():
+    """First-principles check of the whole solver: the last round runs without the robust kernel on the edges classified as
+    inliers, so the returned pose must (nearly) minimise the information-weighted reprojection error over that inlier set.
+    An independent optimiser (scipy least_squares on rotation vector + translation) started from the oracle's pose must not
+    find a noticeably smaller cost."""
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation
+    s = scene(8, n=800, noise_px=0.6, bad_frac=0.2)
+    T, out, n = _oracle(s, np.eye(4, dtype=np.float32))
+    sel = (s["has"] > 0) & (out == 0)
+    assert sel.sum() == n and n > 300
+    X = s["Xw"][sel].astype(np.float64); k = s["keys"][sel]; ur = s["ur"][sel].astype(np.float64)
+    w = np.sqrt(INV_SIGMA2[k["octave"]].astype(np.float64))
+    stereo = ur >= 0
+
+    def resid(p):
+        R = Rotation.from_rotvec(p[:3]).as_matrix()
+        Xc = X @ R.T + p[3:]
+        u = CAM["fx"] * Xc[:, 0] / Xc[:, 2] + CAM["cx"]
+        v = CAM["fy"] * Xc[:, 1] / Xc[:, 2] + CAM["cy"]
+        r = [w * (k["x"] - u), w * (k["y"] - v), np.where(stereo, w * (ur - (u - CAM["bf"] / Xc[:, 2])), 0.0)]
+        return np.concatenate(r)
+
+    p0 = np.concatenate([Rotation.from_matrix(T[:3, :3].astype(np.float64)).as_rotvec(), T[:3, 3].astype(np.float64)])
+    c0 = float((resid(p0) ** 2).sum())
+    sol = least_squares(resid, p0, method="lm", xtol=1e-14, ftol=1e-14)
+    c1 = float((sol.fun ** 2).sum())
+    assert c1 <= c0 * (1 + 1e-9)
+    assert c0 - c1 <= 2e-3 * c0, (c0, c1)                      # the oracle's pose is within 0.2 % of the optimum's cost
+    assert np.abs(sol.x - p0).max() < 2e-4                     # and within 0.2 mm / 0.01 degrees of it
