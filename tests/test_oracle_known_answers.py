@@ -340,3 +340,45 @@ def test_remap_bilinear_known_answers():
     assert np.abs(f - ref).max() <= 0.5 + 1e-9
     big = O.remap_bilinear(img, X + 1e6, Y)                                          # coordinates saturate: all outside
     assert (big == 0).all()
+
+
+def test_blur_resize_and_angle_against_float_reimplementations(small_pair):
+    """Independent float re-implementations (scipy / numpy, written from the definitions, not from the oracle's code) bound
+    the three fixed-point stages on a real image: Gaussian 7x7 sigma 2 with mirror borders, bilinear resize with OpenCV's
+    pixel-centre convention, and the intensity-centroid angle over the circular 31-px patch."""
+    from scipy import ndimage
+    left, _ = small_pair
+    # --- GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101): exact normalised taps, 'mirror' = reflect-101
+    x = np.arange(-3, 4, dtype=np.float64)
+    g = np.exp(-x * x / 8.0); g /= g.sum()
+    ref = ndimage.correlate1d(ndimage.correlate1d(left.astype(np.float64), g, axis=1, mode="mirror"), g, axis=0, mode="mirror")
+    got = O.gaussian7(left).astype(np.float64)
+    assert np.abs(got - ref).max() <= 1.5 and np.abs(got - ref).mean() < 0.45   # 8.8 fixed-point taps + two roundings
+    # --- resize INTER_LINEAR: source coordinate (d + 0.5) * scale - 0.5, clamped at the edges
+    h, w = left.shape
+    dw, dh = int(round(w / 1.2)), int(round(h / 1.2))
+    sx = np.clip((np.arange(dw) + 0.5) * (w / dw) - 0.5, 0, w - 1); sy = np.clip((np.arange(dh) + 0.5) * (h / dh) - 0.5, 0, h - 1)
+    x0 = np.floor(sx).astype(int); y0 = np.floor(sy).astype(int)
+    x1 = np.minimum(x0 + 1, w - 1); y1 = np.minimum(y0 + 1, h - 1)
+    fx = (sx - x0)[None, :]; fy = (sy - y0)[:, None]
+    a = left.astype(np.float64)
+    ref = (a[y0][:, x0] * (1 - fx) + a[y0][:, x1] * fx) * (1 - fy) + (a[y1][:, x0] * (1 - fx) + a[y1][:, x1] * fx) * fy
+    got = O.resize_linear(left, dw, dh).astype(np.float64)
+    assert np.abs(got - ref).max() <= 1.01 and np.abs(got - ref).mean() < 0.5   # 11-bit weights, floor / round of resize.cpp
+    # --- IC_Angle: atan2(m01, m10) over |v| <= 15, |u| <= umax[|v|], umax from the circle of radius 15 (rounded as the reference)
+    ex = O.Extractor(nfeatures=300)
+    k, _ = ex.extract(left)
+    um = ex.umax()
+    assert um[0] == 15 and um[15] == 3 and sum(2 * int(u) + 1 for u in um[1:16]) * 2 + 31 == 749
+    worst = 0.0
+    for kp in k[k["octave"] == 0][:60]:
+        cx, cy = int(round(float(kp["x"]))), int(round(float(kp["y"])))
+        m10 = m01 = 0.0
+        for v in range(-15, 16):
+            d = int(um[abs(v)])
+            row = left[cy + v, cx - d:cx + d + 1].astype(np.float64)
+            m10 += (np.arange(-d, d + 1) * row).sum(); m01 += v * row.sum()
+        ang = np.degrees(np.arctan2(m01, m10)) % 360.0
+        diff = abs(ang - float(kp["angle"])); diff = min(diff, 360 - diff)
+        worst = max(worst, diff)
+    assert worst < 0.3                                                             # cv::fastAtan2's documented accuracy
