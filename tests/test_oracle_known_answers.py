@@ -382,3 +382,29 @@ def test_blur_resize_and_angle_against_float_reimplementations(small_pair):
         diff = abs(ang - float(kp["angle"])); diff = min(diff, 360 - diff)
         worst = max(worst, diff)
     assert worst < 0.3                                                             # cv::fastAtan2's documented accuracy
+
+
+def test_descriptor_against_numpy_reimplementation(small_pair):
+    """computeOrbDescriptor (src/ORBextractor.cc:103-142) written again in numpy float32 from the reference text: rotate the
+    256 point pairs of bit_pattern_31_ by the keypoint angle (x*b + y*a, x*a - y*b, each product and sum rounded to float,
+    cvRound half-even), sample the blurred level, bit = t0 < t1, LSB first.  Octave-0 keypoints (integer coordinates)."""
+    left, _ = small_pair
+    ex = O.Extractor(nfeatures=400)
+    k, d = ex.extract(left)
+    blur = O.gaussian7(left).astype(np.int32)
+    p = L.orc_bit_pattern()
+    pat = np.array([p[i] for i in range(1024)], np.float32).reshape(256, 4)     # x0 y0 x1 y1
+    factor = np.float32(np.pi / np.float64(np.float32(180.0)))                   # (float)(CV_PI / 180.f)
+    sel = np.nonzero(k["octave"] == 0)[0][:120]
+    assert len(sel) >= 60
+    for i in sel:
+        cx, cy = int(k["x"][i]), int(k["y"][i])
+        rad = np.float32(k["angle"][i] * factor)
+        a = np.float32(np.cos(np.float64(rad))); b = np.float32(np.sin(np.float64(rad)))   # Q4: correctly rounded
+        def samp(x, y):
+            r = np.rint(np.float32(x * b) + np.float32(y * a)).astype(np.int32)
+            c = np.rint(np.float32(x * a) - np.float32(y * b)).astype(np.int32)
+            return blur[cy + r, cx + c]
+        bits = (samp(pat[:, 0], pat[:, 1]) < samp(pat[:, 2], pat[:, 3])).astype(np.uint8)
+        ref = np.packbits(bits.reshape(32, 8)[:, ::-1], axis=1).ravel()                      # bit k of byte j = test 8j + k
+        assert np.array_equal(ref, d[i]), i
