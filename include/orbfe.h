@@ -381,6 +381,13 @@ int orbfe_enqueue_pose_optimization(orbfe_context *ctx, int n_problems, const in
                                     const orbfe_keypoint *d_keys_un, const float *d_u_right, const uint8_t *d_has_point,
                                     const float *d_Xw, float *d_Tcw, uint8_t *d_outlier, int32_t *d_n_inliers,
                                     int max_keypoints, void *stream);
+/* KeyFrameDatabase::DetectLoopCandidates(KeyFrame *pKF, float minScore) (src/KeyFrameDatabase.cc:73-194; LoopClosing::DetectLoop,
+ * src/LoopClosing.cc:131).  connected[k] != 0 marks the keyframes of pKF->GetConnectedKeyFrames() (may be NULL: none); covisibility
+ * lists as for the relocalisation query.  Stateless: mLoopScore is only read for keyframes scored by the same call. */
+int orbfe_detect_loop_candidates(orbfe_context *ctx, const uint32_t *q_words, const float *q_w, int nq,
+                                 const uint8_t *connected, float min_score,
+                                 const int32_t *covis_off, const int32_t *covis_idx,
+                                 int32_t *cand, int cap, int *n_cand);
 /* ORBmatcher::SearchByFboW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12) (src/ORBmatcher.cc:517-650; LoopClosing and
  * relocalisation).  valid1 / valid2 = the keypoint has a map point that is not bad.  match12[i1] receives the KF2
  * keypoint whose map point KF1 keypoint i1 got, or -1 (n1 entries). */

@@ -208,6 +208,10 @@ double orc_bow_score(const uint32_t *w1, const float *v1, int n1, const uint32_t
 int orc_detect_reloc_candidates(const uint32_t *q_words, const float *q_w, int nq,
                                 int n_kf, const int32_t *kf_off, const uint32_t *db_words, const float *db_w,
                                 const int32_t *covis_off, const int32_t *covis_idx, float *reloc_score, int32_t *cand, int cap);
+int orc_detect_loop_candidates(const uint32_t *q_words, const float *q_w, int nq,
+                               int n_kf, const int32_t *kf_off, const uint32_t *db_words, const float *db_w,
+                               const uint8_t *connected, float min_score,
+                               const int32_t *covis_off, const int32_t *covis_idx, int32_t *cand, int cap);
 int orc_search_for_triangulation(const uint32_t *n1, const int32_t *off1, const int32_t *feat1, int nn1,
                                  const orc_keypoint *k1, const float *ur1, const uint8_t *has_mp1, const uint8_t *desc1, int nk1,
                                  const uint32_t *n2, const int32_t *off2, const int32_t *feat2, int nn2,

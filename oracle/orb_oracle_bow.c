@@ -467,3 +467,89 @@ int orc_search_for_triangulation(const uint32_t *n1, const int32_t *off1, const 
     free(matched2);
     return nmatches;
 }
+
+
+/* KeyFrameDatabase::DetectLoopCandidates(KeyFrame *pKF, float minScore) (src/KeyFrameDatabase.cc:73-194).  connected[k] != 0:
+ * keyframe k is in pKF->GetConnectedKeyFrames() (never a candidate, never counted in the covisibility accumulation);
+ * covis lists = every keyframe's GetBestCovisibilityKeyFrames(10).  Unlike the relocalisation query no state survives the
+ * call: mLoopScore is only read for keyframes scored in this query (mnLoopQuery == id && mnLoopWords > minCommonWords). */
+int orc_detect_loop_candidates(const uint32_t *q_words, const float *q_w, int nq,
+                               int n_kf, const int32_t *kf_off, const uint32_t *db_words, const float *db_w,
+                               const uint8_t *connected, float min_score,
+                               const int32_t *covis_off, const int32_t *covis_idx, int32_t *cand, int cap)
+{
+    uint32_t max_word = 0;
+    for (int i = 0; i < kf_off[n_kf]; i++) if (db_words[i] > max_word) max_word = db_words[i];
+    for (int i = 0; i < nq; i++) if (q_words[i] > max_word) max_word = q_words[i];
+    const size_t nw = (size_t)max_word + 2;
+    int *inv_off = (int *)calloc(nw + 1, sizeof(int));
+    for (int i = 0; i < kf_off[n_kf]; i++) inv_off[db_words[i] + 1]++;
+    for (size_t w = 0; w < nw; w++) inv_off[w + 1] += inv_off[w];
+    int *inv = (int *)malloc(sizeof(int) * (size_t)(kf_off[n_kf] > 0 ? kf_off[n_kf] : 1));
+    int *cur = (int *)malloc(sizeof(int) * (nw + 1));
+    memcpy(cur, inv_off, sizeof(int) * (nw + 1));
+    for (int k = 0; k < n_kf; k++)
+        for (int i = kf_off[k]; i < kf_off[k + 1]; i++) inv[cur[db_words[i]]++] = k;
+    const size_t nk = (size_t)(n_kf > 0 ? n_kf : 1);
+    int *words = (int *)calloc(nk, sizeof(int));
+    uint8_t *listed = (uint8_t *)calloc(nk, 1);      /* mnLoopQuery == pKF->mnId */
+    uint8_t *scored = (uint8_t *)calloc(nk, 1);
+    float *loop_score = (float *)calloc(nk, sizeof(float));
+    int *sharing = (int *)malloc(sizeof(int) * nk);
+    int n_sh = 0, n_out = 0;
+    for (int i = 0; i < nq; i++)
+        for (int j = inv_off[q_words[i]]; j < inv_off[q_words[i] + 1]; j++) { /* :82-102 */
+            const int k = inv[j];
+            if (connected && connected[k]) continue;
+            if (!listed[k]) { listed[k] = 1; words[k] = 0; sharing[n_sh++] = k; }
+            words[k]++;
+        }
+    if (n_sh > 0) {
+        int max_common = 0;
+        for (int i = 0; i < n_sh; i++) if (words[sharing[i]] > max_common) max_common = words[sharing[i]];
+        const int min_common = (int)((float)max_common * 0.8f);
+        int *sm_kf = (int *)malloc(sizeof(int) * (size_t)n_sh);
+        float *sm_s = (float *)malloc(sizeof(float) * (size_t)n_sh);
+        int n_sm = 0;
+        for (int i = 0; i < n_sh; i++) { /* :121-137 */
+            const int k = sharing[i];
+            if (words[k] > min_common) {
+                const float si = (float)orc_bow_score(q_words, q_w, nq, db_words + kf_off[k], db_w + kf_off[k], kf_off[k + 1] - kf_off[k]);
+                loop_score[k] = si; scored[k] = 1;
+                if (si >= min_score) { sm_kf[n_sm] = k; sm_s[n_sm] = si; n_sm++; }
+            }
+        }
+        if (n_sm > 0) {
+            float *acc = (float *)malloc(sizeof(float) * (size_t)n_sm);
+            int *best_kf = (int *)malloc(sizeof(int) * (size_t)n_sm);
+            float best_acc = min_score;
+            for (int i = 0; i < n_sm; i++) { /* :146-171 */
+                const int k = sm_kf[i];
+                float best = sm_s[i], a = sm_s[i];
+                int bk = k;
+                int nn = covis_off[k + 1] - covis_off[k];
+                if (nn > 10) nn = 10;
+                for (int j = 0; j < nn; j++) {
+                    const int k2 = covis_idx[covis_off[k] + j];
+                    if (!scored[k2]) continue;
+                    a += loop_score[k2];
+                    if (loop_score[k2] > best) { bk = k2; best = loop_score[k2]; }
+                }
+                acc[i] = a; best_kf[i] = bk;
+                if (a > best_acc) best_acc = a;
+            }
+            const float min_retain = 0.75f * best_acc;
+            uint8_t *added = (uint8_t *)calloc(nk, 1);
+            for (int i = 0; i < n_sm; i++)
+                if (acc[i] > min_retain && !added[best_kf[i]]) {
+                    added[best_kf[i]] = 1;
+                    if (n_out < cap) cand[n_out] = best_kf[i];
+                    n_out++;
+                }
+            free(added); free(acc); free(best_kf);
+        }
+        free(sm_kf); free(sm_s);
+    }
+    free(inv_off); free(inv); free(cur); free(words); free(listed); free(scored); free(loop_score); free(sharing);
+    return n_out;
+}

@@ -30,7 +30,7 @@ EXPORTS = [
     "orbfe_features_in_area", "orbfe_features_in_area_batch", "orbfe_three_maxima", "orbfe_search_by_projection_last", "orbfe_is_in_frustum",
     "orbfe_search_by_projection_points", "orbfe_search_by_projection_kf", "orbfe_search_for_initialization",
     "orbfe_vocab_load", "orbfe_bow_transform", "orbfe_bow_maps", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",  # bound in orbslam2_amd/bow.py
-    "orbfe_search_for_triangulation", "orbfe_fuse", "orbfe_search_by_projection_sim3", "orbfe_fuse_sim3", "orbfe_search_by_sim3", "orbfe_kfdb_clear", "orbfe_kfdb_add", "orbfe_kfdb_erase", "orbfe_kfdb_size", "orbfe_kfdb_score", "orbfe_detect_reloc_candidates",
+    "orbfe_search_for_triangulation", "orbfe_fuse", "orbfe_search_by_projection_sim3", "orbfe_fuse_sim3", "orbfe_search_by_sim3", "orbfe_kfdb_clear", "orbfe_kfdb_add", "orbfe_kfdb_erase", "orbfe_kfdb_size", "orbfe_kfdb_score", "orbfe_detect_reloc_candidates", "orbfe_detect_loop_candidates",
     "orbfe_pose_optimization", "orbfe_pose_optimization_batch", "orbfe_enqueue_pose_optimization", "orbfe_set_input_format", "orbfe_fetch_batch_async", "orbfe_set_rectification", "orbfe_set_distortion", "orbfe_undistort_keypoints", "orbfe_fetch_keys_un", "orbfe_image_bounds",
 ]
 NUM_STAGES = 8

@@ -148,6 +148,23 @@ class KeyFrameDB:
         return cand[: n.value].copy()
 
 
+def _kfdb_detect_loop_candidates(self, q_words, q_w, connected, min_score, covis_off, covis_idx):
+    """KeyFrameDatabase::DetectLoopCandidates(pKF, minScore): connected = uint8 flag per database keyframe (or None)."""
+    w = np.ascontiguousarray(q_words, np.uint32); v = np.ascontiguousarray(q_w, np.float32)
+    co = np.ascontiguousarray(covis_off, np.int32); ci = np.ascontiguousarray(covis_idx, np.int32)
+    cn = None if connected is None else np.ascontiguousarray(connected, np.uint8)
+    cand = np.zeros(max(len(self), 1), np.int32); n = C.c_int()
+    self.L.orbfe_detect_loop_candidates.restype = C.c_int
+    self.L.orbfe_detect_loop_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    self.ctx._check(self.L.orbfe_detect_loop_candidates(self.ctx.h, _p(w), _p(v), len(w), None if cn is None else _p(cn), float(min_score),
+                                                        _p(co), _p(ci), _p(cand), len(cand), C.byref(n)))
+    return cand[: n.value].copy()
+
+
+KeyFrameDB.detect_loop_candidates = _kfdb_detect_loop_candidates
+
+
 def build_vocabulary(desc: np.ndarray, k: int = 10, levels: int = 3, seed: int = 7) -> bytes:
     """Hierarchical k-majority clustering of binary descriptors, serialised in the fbow file format
     (alignment 8; block = u16 N, u16 isLeaf, u32 parent, k x 32 B descriptors, k x {u32 id|leafbit, f32 weight})."""

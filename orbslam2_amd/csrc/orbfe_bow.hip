@@ -577,6 +577,72 @@ extern "C" int orbfe_detect_reloc_candidates(orbfe_context *ctx, const uint32_t 
     return ORBFE_OK;
 }
 
+// KeyFrameDatabase::DetectLoopCandidates(KeyFrame *pKF, float minScore) (src/KeyFrameDatabase.cc:73-194): same device scoring
+// pass as the relocalisation query; the selection differs (connected keyframes excluded, minScore filter, accumulated score
+// starts from minScore) and keeps no state between calls.
+extern "C" int orbfe_detect_loop_candidates(orbfe_context *ctx, const uint32_t *q_words, const float *q_w, int nq,
+                                            const uint8_t *connected, float min_score,
+                                            const int32_t *covis_off, const int32_t *covis_idx,
+                                            int32_t *cand, int cap, int *n_cand)
+{
+    if (!ctx || !n_cand || nq < 0 || (nq > 0 && (!q_words || !q_w)) || !covis_off || cap < 0 || (cap > 0 && !cand))
+        return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
+    if (!st) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "out of host memory");
+    *n_cand = 0;
+    const int n_kf = (int)st->db_off.size();
+    std::vector<int> common; std::vector<uint32_t> first; std::vector<float> score;
+    int rc = kfdb_scores(ctx, st, q_words, q_w, nq, common, first, score);
+    if (rc != ORBFE_OK) return rc;
+    std::vector<int> sharing; // lKFsSharingWords: shares a word, not connected, first-encounter order (:82-102)
+    for (int k = 0; k < n_kf; k++)
+        if (common[k] > 0 && !(connected && connected[k])) sharing.push_back(k);
+    if (sharing.empty()) return ORBFE_OK;
+    std::stable_sort(sharing.begin(), sharing.end(), [&](int a, int b) { return first[a] < first[b]; });
+    int max_common = 0;
+    for (int k : sharing) max_common = common[k] > max_common ? common[k] : max_common;
+    const int min_common = (int)((float)max_common * 0.8f);
+    std::vector<uint8_t> scored(n_kf, 0);
+    std::vector<int> sm_kf;
+    for (int k : sharing)
+        if (common[k] > min_common) {
+            scored[k] = 1;                                  // mLoopScore = si (:131)
+            if (score[k] >= min_score) sm_kf.push_back(k);  // :132-133
+        }
+    if (sm_kf.empty()) return ORBFE_OK;
+    std::vector<float> acc(sm_kf.size());
+    std::vector<int> best_kf(sm_kf.size());
+    float best_acc = min_score;
+    for (size_t i = 0; i < sm_kf.size(); i++) { // :146-171
+        const int k = sm_kf[i];
+        float best = score[k], a = score[k];
+        int bk = k;
+        int nn = covis_off[k + 1] - covis_off[k];
+        if (nn > 10) nn = 10;
+        for (int j = 0; j < nn; j++) {
+            const int k2 = covis_idx[covis_off[k] + j];
+            if (k2 < 0 || k2 >= n_kf) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "covisibility index out of range");
+            if (!scored[k2]) continue;
+            a += score[k2];
+            if (score[k2] > best) { bk = k2; best = score[k2]; }
+        }
+        acc[i] = a; best_kf[i] = bk;
+        if (a > best_acc) best_acc = a;
+    }
+    const float min_retain = 0.75f * best_acc;
+    std::vector<uint8_t> added(n_kf, 0);
+    int n = 0;
+    for (size_t i = 0; i < sm_kf.size(); i++)
+        if (acc[i] > min_retain && !added[best_kf[i]]) {
+            added[best_kf[i]] = 1;
+            if (n < cap) cand[n] = best_kf[i];
+            n++;
+        }
+    *n_cand = n;
+    if (n > cap) return orbfe_fail(ctx, ORBFE_ERR_CAPACITY, "caller buffer holds %d candidates, %d found", cap, n);
+    return ORBFE_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:652-819; LocalMapping::CreateNewMapPoints)
 // ---------------------------------------------------------------------------------------------

@@ -43,6 +43,20 @@ public:
         return cand;
     }
 
+    // DetectLoopCandidates(KeyFrame *pKF, float minScore) (:73-194): pKF's fBow, a flag per database keyframe for
+    // pKF->GetConnectedKeyFrames(), and the covisibility lists -> candidate indices in the reference's order
+    std::vector<int32_t> DetectLoopCandidates(const std::vector<uint32_t> &words, const std::vector<float> &weights,
+                                              const std::vector<uint8_t> &connected, float minScore,
+                                              const std::vector<int32_t> &covisOff, const std::vector<int32_t> &covisIdx)
+    {
+        std::vector<int32_t> cand(mRelocScore.size() ? mRelocScore.size() : 1);
+        int n = 0;
+        Check(orbfe_detect_loop_candidates(mCtx, words.data(), weights.data(), (int)words.size(), connected.empty() ? nullptr : connected.data(),
+                                           minScore, covisOff.data(), covisIdx.data(), cand.data(), (int)cand.size(), &n));
+        cand.resize(n);
+        return cand;
+    }
+
 protected:
     void Check(int rc)
     {

@@ -150,6 +150,8 @@ def test_gpu_keyframe_database_relocalisation(vocab):
     L.orc_bow_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     L.orc_detect_reloc_candidates.restype = C.c_int
     L.orc_detect_reloc_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int]
+    L.orc_detect_loop_candidates.restype = C.c_int
+    L.orc_detect_loop_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 3 + [C.c_int]
     ctx = api.Context(width=752, height=480, nfeatures=1200)
     B.vocab_load(ctx, vocab)
     rng = np.random.default_rng(11)
@@ -188,6 +190,20 @@ def test_gpu_keyframe_database_relocalisation(vocab):
         assert got.tolist() == cand_ref[:n_ref].tolist(), q
         assert np.array_equal(state_gpu, state_ref)
         assert n_ref >= 1 and (cand_ref[:n_ref] % 25 == place).mean() > 0.8  # the query's place wins
+        # DetectLoopCandidates(pKF, minScore) on the same database: a random third of the keyframes of the query's place are
+        # "connected" (excluded), minScore = the score of a mid-ranked keyframe so that the filter bites
+        connected = np.zeros(n_kf, np.uint8)
+        connected[[k for k in range(n_kf) if k % 25 == place and rng.random() < 0.33]] = 1
+        live = np.array([len(w) > 0 for w in kf_words])
+        min_score = float(np.sort(score[live])[int(0.9 * live.sum())])
+        cl_ref = np.zeros(n_kf, np.int32)
+        nl_ref = L.orc_detect_loop_candidates(_p(qw), _p(qv), len(qw), n_kf, _p(kf_off), _p(db_words), _p(db_w), _p(connected), min_score,
+                                              _p(covis_off), _p(covis_idx), _p(cl_ref), n_kf)
+        gl = db.detect_loop_candidates(qw, qv, connected, min_score, covis_off, covis_idx)
+        assert gl.tolist() == cl_ref[:nl_ref].tolist(), q
+        assert nl_ref >= 1 and not connected[cl_ref[:nl_ref]].any() and (score[cl_ref[:nl_ref]] >= 0).all()
+        none = db.detect_loop_candidates(qw, qv, np.ones(n_kf, np.uint8), 0.0, covis_off, covis_idx)   # everything connected
+        assert len(none) == 0
         if q == 2:  # KeyFrameDatabase::erase: the best candidate leaves the database (both sides)
             gone = int(cand_ref[0])
             db.erase(gone)
@@ -230,6 +246,52 @@ def test_oracle_bow_score_and_reloc_known_answers():
         if a > np.float32(0.75) * max(acc0, acc2) and b not in expect:
             expect.append(b)
     assert cand[:n].tolist() == expect and n >= 1
+
+
+def test_oracle_loop_candidates_known_answers():
+    """DetectLoopCandidates (src/KeyFrameDatabase.cc:73-194) on a hand-made database: connected keyframes never appear, the
+    minScore filter and the 0.75 * bestAccScore cut follow the reference, the accumulated score starts from minScore."""
+    L = O.lib()
+    L.orc_bow_score.restype = C.c_double
+    L.orc_bow_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_detect_loop_candidates.restype = C.c_int
+    L.orc_detect_loop_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 3 + [C.c_int]
+    w = np.array([3, 7, 9, 20], np.uint32); v = np.array([0.5, 0.5, 0.5, 0.5], np.float32)
+    kfs = [([3, 7, 9], [0.6, 0.6, 0.5]), ([3, 7, 9, 20], [0.5, 0.5, 0.5, 0.5]), ([3, 7, 20], [0.5, 0.5, 0.7]), ([50], [1.0]), ([3, 9, 20], [0.1, 0.1, 0.99])]
+    n = len(kfs)
+    kf_off = np.zeros(n + 1, np.int32); kf_off[1:] = np.cumsum([len(a) for a, _ in kfs])
+    dbw = np.concatenate([np.array(a, np.uint32) for a, _ in kfs]); dbv = np.concatenate([np.array(b, np.float32) for _, b in kfs])
+    sc = [np.float32(L.orc_bow_score(_p(w), _p(v), 4, _p(dbw[kf_off[k]:kf_off[k + 1]].copy()), _p(dbv[kf_off[k]:kf_off[k + 1]].copy()),
+                                     int(kf_off[k + 1] - kf_off[k]))) for k in range(n)]
+    covis_off = np.array([0, 1, 1, 2, 2, 2], np.int32); covis_idx = np.array([2, 0], np.int32)  # kf0 -> [kf2], kf2 -> [kf0]
+    cand = np.zeros(n, np.int32)
+
+    def run(connected, min_score):
+        c = np.asarray(connected, np.uint8)
+        m = L.orc_detect_loop_candidates(_p(w), _p(v), 4, n, _p(kf_off), _p(dbw), _p(dbv), _p(c), float(min_score), _p(covis_off), _p(covis_idx), _p(cand), n)
+        return cand[:m].tolist()
+
+    assert sc[1] == 1.0 and sc[3] == 0.0
+    # kf1 (identical vector, 4 common words) is connected: max common among the rest = 3 -> minCommon = int(2.4) = 2 -> kf0, kf2, kf4 scored
+    got = run([0, 1, 0, 0, 0], 0.0)
+    assert 1 not in got and 3 not in got and len(got) >= 1
+    acc = {0: np.float32(sc[0] + sc[2]), 2: np.float32(sc[2] + sc[0]), 4: sc[4]}
+    best = {0: 2 if sc[2] > sc[0] else 0, 2: 0 if sc[0] > sc[2] else 2, 4: 4}
+    top = max(acc.values())
+    expect = []
+    for k in (0, 2, 4):                      # first-encounter order: word 3 lists kf0, kf1, kf2, kf4
+        if acc[k] > np.float32(0.75) * top and best[k] not in expect:
+            expect.append(best[k])
+    assert got == expect
+    # nothing connected: kf1 shares 4 words -> minCommon = 3 -> only kf1 is scored and returned
+    assert run([0, 0, 0, 0, 0], 0.0) == [1]
+    # minScore above every score: no candidate; everything connected: no candidate
+    assert run([0, 1, 0, 0, 0], 2.0) == [] and run([1, 1, 1, 1, 1], 0.0) == []
+    # minScore between: a keyframe below it is dropped from the list but still feeds its neighbour's accumulated score
+    lo, hi = sorted([float(sc[0]), float(sc[2])])
+    if lo < hi:
+        got = run([0, 1, 0, 0, 1], (lo + hi) / 2)
+        assert got == [0 if sc[0] > sc[2] else 2]
 
 
 @pytest.mark.gpu
