@@ -1154,6 +1154,7 @@ static int rgbd_frame_impl(orbfe_context *ctx, const uint8_t *gray, const void *
     if (!gray || !depth_img || w <= 0 || h <= 0) { *n = 0; return ORBFE_OK; }
     const size_t row = px_bytes * (size_t)w;
     if (depth_stride < row) return fail(ctx, ORBFE_ERR_INVALID, "depth stride smaller than a row");
+    if (ctx->cfg.rm_on) return fail(ctx, ORBFE_ERR_UNSUPPORTED, "RGB-D frames with rectification maps are not supported (the depth map would need the same warp)");
     static const bool trace = getenv("ORBFE_HOST_TRACE") != nullptr;
     double t[6] = {};
     t[0] = host_ms();
