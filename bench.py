@@ -6,9 +6,15 @@
 One process per GPU (the driver launches N>1 through torch.distributed.run).  A "step"
 is one pass of the hot path (extract left + extract right + ComputeStereoMatches) over
 one batch of P synthetic KITTI-geometry stereo pairs that are already resident in HBM.
-Frame pairs are independent, so ranks shard them with no data-path collective (weak
-scaling); the only RCCL traffic is a one-time broadcast of the extractor parameters and
-pattern checksum from rank 0 at start-up.  Rank 0 prints ONE JSON line.
+Frame pairs are independent, so ranks shard them with no data-path collective; the only
+RCCL traffic is a one-time broadcast of the extractor parameters, pattern checksum and a
+(synthetic) fbow vocabulary from rank 0 at start-up.  Rank 0 prints ONE JSON line.
+
+Two sharding modes (BASELINE.json config 4 = "64 frame pairs in flight, sharded across 8x"):
+  --mode weak   (default, the headline `value`): P pairs per step PER GPU, "scaling": "weak";
+  --mode strong : P pairs per step IN TOTAL, dealt round-robin by dist.shard_pairs (8 per GPU at N = 8),
+                  "scaling": "strong".  A weak run on N > 1 GPUs also times a short strong pass and reports it
+                  under config.strong_scaling, so one driver run shows both regimes.
 """
 from __future__ import annotations
 
@@ -84,6 +90,49 @@ def valu_issue(pairs: int, launches: int, launch_ms: float):
     return None
 
 
+def host_fed(api, torch, dev, host, P, ctx0, steps=10):
+    """PCIe-inclusive rate (never `value`): every step's P pairs start in PINNED host memory and the results (keypoints,
+    descriptors, counts, uRight, depth at device capacity) end there.  serial = upload -> chain -> download on one stream;
+    overlapped = two contexts on two streams, so one step's copies run beside the other's kernels."""
+    h_in = torch.from_numpy(host).pin_memory()
+
+    class Lane:
+        def __init__(self, ctx):
+            self.ctx = ctx
+            self.stream = torch.cuda.Stream()
+            self.d_in = torch.empty(h_in.shape, dtype=torch.uint8, device=dev)
+            cap = ctx.capacity
+            self.sizes = [2 * P * cap * 28, 2 * P * cap * 32, 2 * P * 4, 2 * P * cap * 4, 2 * P * cap * 4]
+            self.h_out = [torch.empty(n, dtype=torch.uint8).pin_memory() for n in self.sizes]
+
+        def step(self):
+            with torch.cuda.stream(self.stream):
+                self.d_in.copy_(h_in, non_blocking=True)
+                self.ctx.enqueue_stereo(self.d_in.data_ptr(), P, self.stream.cuda_stream)
+                self.ctx.fetch_batch_async(2 * P, *[h.data_ptr() for h in self.h_out], self.stream.cuda_stream)
+
+    def run(lanes):
+        for l in lanes:
+            l.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            lanes[k % len(lanes)].step()
+        torch.cuda.synchronize()
+        return P * steps / (time.perf_counter() - t0)
+
+    p = ctx0.params
+    ctx1 = api.Context(width=p.width, height=p.height, nfeatures=p.nfeatures, scale_factor=p.scale_factor, nlevels=p.nlevels,
+                       ini_th_fast=p.ini_th_fast, min_th_fast=p.min_th_fast, patch_size=p.patch_size, half_patch_size=p.half_patch_size,
+                       edge_threshold=p.edge_threshold, fx=p.fx, fy=p.fy, cx=p.cx, cy=p.cy, bf=p.bf, device=p.device, max_images=2 * P)
+    a, b = Lane(ctx0), Lane(ctx1)
+    out = {"unit": "frames/s", "serial": run([a]), "overlapped": run([a, b]),
+           "bytes_up_per_step": int(h_in.numel()), "bytes_down_per_step": int(sum(a.sizes)),
+           "note": "pinned host memory in and out; serial = one stream, overlapped = two contexts on two streams"}
+    ctx1.close()
+    return out
+
+
 def cpu_baseline(n_pairs: int):
     """Oracle (kind=port) timed with the reference's threading: 2 threads per pair (src/Frame.cc:78-81)."""
     from oracle import oracle as O
@@ -149,6 +198,9 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=300, help="pairs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run oracle spot check")
+    ap.add_argument("--mode", default="weak", choices=["weak", "strong"], help="weak: --pairs per GPU; strong: --pairs in total, sharded by dist.shard_pairs")
+    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pairs the batch cycles through")
+    ap.add_argument("--host-fed", type=int, default=1, help="1: after the timed region also measure the PCIe-inclusive rate (N = 1 only; never `value`)")
     args = ap.parse_args()
 
     import torch
@@ -174,22 +226,48 @@ def main():
     blob = D.broadcast_params(D.pack_params(NFEAT, 1.2, NLEVELS, 20, 7, 31, 15, 19, FX, FY, CX, CY, BF), cdev)
     nf, sf, nl, ini, mn, ps, hps, et, fx, fy, cx, cy, bf = D.unpack_params(blob)
 
-    P = args.pairs
+    # one-time RCCL broadcast of the vocabulary (fbow file format) from rank 0 into every rank's HBM: the only other
+    # xGMI traffic north_star allows.  Synthetic k = 10 / L = 3 tree here (no vocabulary file ships with the repo).
+    voc_blob = None
+    if world > 1:
+        from orbslam2_amd import bow as BOW
+        if rank == 0:
+            rng = np.random.default_rng(99)
+            voc_blob = BOW.build_vocabulary(rng.integers(0, 256, (4000, 32), dtype=np.uint8), k=10, levels=3)
+        voc_blob = D.broadcast_blob(voc_blob, cdev)
+
+    P_total = args.pairs
+    mine = D.shard_pairs(P_total, rank, world)  # strong-scaling share of this rank
+    P = args.pairs if args.mode == "weak" else len(mine)
+    if P < 1:
+        raise SystemExit("bench: --mode strong needs --pairs >= number of GPUs")
     ctx = api.Context(width=W, height=H, nfeatures=nf, scale_factor=sf, nlevels=nl, ini_th_fast=ini, min_th_fast=mn,
                       patch_size=ps, half_patch_size=hps, edge_threshold=et, fx=fx, fy=fy, cx=cx, cy=cy, bf=bf,
                       device=gpu_index, max_images=2 * P)
     G = max(1, min(args.streams, P, 8))
     ctx.set_streams(G)
-    n_distinct = min(P, 4)
+    if voc_blob is not None:
+        BOW.vocab_load(ctx, voc_blob)
     host = np.empty((2 * P, H, W), np.uint8)
-    distinct = [synth.stereo_pair(W, H, seed=1234 + rank * 100 + i) for i in range(n_distinct)]
-    for i in range(P):
-        host[2 * i], host[2 * i + 1] = distinct[i % n_distinct]
+    if args.mode == "weak":  # every rank its own pairs
+        n_distinct = max(1, min(P, args.distinct))
+        distinct = [synth.stereo_pair(W, H, seed=1234 + rank * 100 + i) for i in range(n_distinct)]
+        for i in range(P):
+            host[2 * i], host[2 * i + 1] = distinct[i % n_distinct]
+    else:  # one global list of P_total pairs, rank r extracts pairs r, r + world, ...
+        n_distinct = max(1, min(P_total, args.distinct))
+        cache = {}
+        for j, gi in enumerate(mine):
+            k = gi % n_distinct
+            if k not in cache:
+                cache[k] = synth.stereo_pair(W, H, seed=1234 + k)
+            host[2 * j], host[2 * j + 1] = cache[k]
     d_images = torch.from_numpy(host).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
+    n_step = [P]
 
     def step():
-        ctx.enqueue_stereo(d_images.data_ptr(), P, stream)
+        ctx.enqueue_stereo(d_images.data_ptr(), n_step[0], stream)
 
     def barrier():
         D.barrier()
@@ -217,6 +295,25 @@ def main():
     ctx.set_profiling(0)
     dt = D.max_over_ranks(dt, cdev)
 
+    # strong-scaling pass beside a weak run on several GPUs: P_total pairs in total, this rank's share per step
+    strong = None
+    if args.mode == "weak" and world > 1 and len(mine) >= 1:
+        n_step[0] = len(mine)
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dts = D.max_over_ranks(time.perf_counter() - t0, cdev)
+        strong = {"pairs_per_step_total": P_total, "pairs_per_step_per_gpu": [len(D.shard_pairs(P_total, r, world)) for r in range(world)],
+                  "value": P_total * args.steps / dts, "ms_per_step": dts / args.steps * 1e3,
+                  "note": "same timing protocol; every rank runs the first len(shard) pairs of its resident batch"}
+        n_step[0] = P
+        step()  # leave the full batch's results in the context for the checks below
+        barrier()
+
     counts = ctx.fetch_counts(2 * P)
     n_cand = 0
     if rank == 0:
@@ -233,7 +330,7 @@ def main():
                 raise SystemExit("bench: HIP output differs from the oracle -- result invalid")
 
     if rank == 0:
-        total_pairs = P * args.steps * world
+        total_pairs = (P * world if args.mode == "weak" else P_total) * args.steps
         value = total_pairs / dt
         alg = stage_alg_bytes_per_pair(n_cand)
         # stage time per step, summed over the G stream groups (they overlap in wall time)
@@ -253,10 +350,12 @@ def main():
         out = {
             "metric": metric, "value": value, "unit": "frames/s (1 frame = 1 stereo pair)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.mode,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "Stereo-KITTI00-02 1241x376, 2000 features, 8 levels: extract L+R + ComputeStereoMatches",
-                       "pairs_per_step_per_gpu": P, "stream_groups": G, "quadtree_kernel": ctx.quadtree_kernel(), "parallelism": "frame-pair sharding, no data-path collective",
+            "config": {"workload": "Stereo-KITTI00-02 1241x376, 2000 features, 8 levels: extract L+R + ComputeStereoMatches"
+                                   + (" (%d pairs per step per GPU, weak scaling)" % P if args.mode == "weak"
+                                      else " (%d pairs per step in total, sharded round-robin over %d GPUs, strong scaling)" % (P_total, world)),
+                       "sharding": args.mode, "pairs_per_step_per_gpu": P, "distinct_pairs": n_distinct, "stream_groups": G, "quadtree_kernel": ctx.quadtree_kernel(), "parallelism": "frame-pair sharding, no data-path collective",
                        "keypoints_left_right_pair0": [int(counts[0]), int(counts[1])]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bytes(dom, P, launches),
@@ -267,6 +366,12 @@ def main():
                          "stage_ms_per_step_summed_over_groups": per_launch_ms,
                          "stage_ms_note": "per-stage table from a separate untimed pass with events at every stage boundary; launch_ms from the timed region"},
         }
+        if strong is not None:
+            out["config"]["strong_scaling"] = strong
+        if voc_blob is not None:
+            out["config"]["vocabulary_broadcast_bytes"] = len(voc_blob)
+        if world == 1 and args.host_fed:
+            out["config"]["host_fed"] = host_fed(api, torch, dev, host, P, ctx)
         if world == 1 and args.cpu_pairs > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
         else:

@@ -164,7 +164,9 @@ int orbfe_set_streams(orbfe_context *ctx, int groups);
 /* Which DistributeOctTree kernel this context uses (src/ORBextractor.cc:533-757): 3 = bucket pyramid,
  * 2 = point-parallel, 1 = generic node-parallel (chosen at create time from the geometry / LDS limits). */
 int orbfe_quadtree_kernel(const orbfe_context *ctx);
-/* Copy the results of image slot `image` to host.  u_right/depth may be NULL. */
+/* Copy the results of image slot `image` to host.  u_right/depth may be NULL.  The blocking fetch functions
+ * (orbfe_fetch_image / _counts / _keys_un / _pyramid / _candidates) first wait for the stream of the latest
+ * orbfe_enqueue_* call, so no orbfe_synchronize is needed in between; orbfe_fetch_batch_async does not wait. */
 int orbfe_fetch_image(orbfe_context *ctx, int image, orbfe_keypoint *kps, uint8_t *desc,
                       float *u_right, float *depth, int cap, int *n);
 /* Per-image keypoint counts of the latest batch (n_images ints). */

@@ -622,6 +622,15 @@ extern "C" int orbfe_level_size(const orbfe_context *ctx, int level, int *w, int
 
 static hipStream_t pick_stream(orbfe_context *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
 
+// The blocking fetch entry points copy on the null stream, which does not wait for the non-blocking streams the
+// enqueue calls run on: wait for the stream of the latest enqueue (and the context's own) first.
+static int wait_latest(orbfe_context *ctx)
+{
+    if (ctx->prof_stream && ctx->prof_stream != ctx->stream) (void)hipStreamSynchronize(ctx->prof_stream); // caller-owned: may be gone
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ORBFE_OK;
+}
+
 #define PROF_RING 64
 static const char *k_stage_names[ORBFE_NUM_STAGES] = {"ingest", "pyramid", "blur", "fast", "octree", "describe",
                                                       "stereo_match", "stereo_median"};
@@ -916,6 +925,7 @@ extern "C" int orbfe_undistort_keypoints(orbfe_context *ctx, const orbfe_keypoin
 extern "C" int orbfe_fetch_keys_un(orbfe_context *ctx, int image, orbfe_keypoint *kps_un, int cap, int *n)
 {
     if (!ctx || image < 0 || image >= ctx->params.max_images || !n) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
+    { const int rcw = wait_latest(ctx); if (rcw != ORBFE_OK) return rcw; }
     int cnt = 0;
     HIP_TRY(ctx, hipMemcpy(&cnt, ctx->buf.kp_cnt + image, sizeof(int), hipMemcpyDeviceToHost));
     *n = cnt;
@@ -953,6 +963,7 @@ extern "C" int orbfe_synchronize(orbfe_context *ctx, void *stream)
 extern "C" int orbfe_fetch_counts(orbfe_context *ctx, int32_t *counts, int n_images)
 {
     if (!ctx || !counts || n_images < 1 || n_images > ctx->params.max_images) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
+    { const int rcw = wait_latest(ctx); if (rcw != ORBFE_OK) return rcw; }
     HIP_TRY(ctx, hipMemcpy(counts, ctx->buf.kp_cnt, sizeof(int32_t) * n_images, hipMemcpyDeviceToHost));
     return ORBFE_OK;
 }
@@ -975,6 +986,7 @@ extern "C" int orbfe_fetch_image(orbfe_context *ctx, int image, orbfe_keypoint *
                                  float *u_right, float *depth, int cap, int *n)
 {
     if (!ctx || image < 0 || image >= ctx->params.max_images || !n) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
+    { const int rcw = wait_latest(ctx); if (rcw != ORBFE_OK) return rcw; }
     int cnt = 0, status = 0;
     HIP_TRY(ctx, hipMemcpy(&cnt, ctx->buf.kp_cnt + image, sizeof(int), hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(&status, ctx->buf.status + image, sizeof(int), hipMemcpyDeviceToHost));
@@ -1202,6 +1214,7 @@ extern "C" int orbfe_fetch_pyramid(orbfe_context *ctx, int image, int level, int
 {
     if (!ctx || !dst || image < 0 || image >= ctx->params.max_images || level < 0 || level >= ctx->cfg.nlevels)
         return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
+    { const int rcw = wait_latest(ctx); if (rcw != ORBFE_OK) return rcw; }
     const LevelInfo &L = ctx->cfg.lv[level];
     if (dst_stride < (size_t)L.w) return fail(ctx, ORBFE_ERR_INVALID, "dst_stride smaller than level width");
     if (blurred) { // tiled on the device (32 x 4 px tiles): download the level's tiles and lay the rows out
@@ -1225,6 +1238,7 @@ extern "C" int orbfe_fetch_candidates(orbfe_context *ctx, int image, int level, 
 {
     if (!ctx || !n || image < 0 || image >= ctx->params.max_images || level < 0 || level >= ctx->cfg.nlevels)
         return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
+    { const int rcw = wait_latest(ctx); if (rcw != ORBFE_OK) return rcw; }
     const DeviceConfig &c = ctx->cfg;
     const LevelInfo &L = c.lv[level];
     if (ctx->use_octree3) { // this path never materialises the emission-order arrays; build them for the tap
@@ -1254,9 +1268,7 @@ extern "C" int orbfe_hamming_matrix(orbfe_context *ctx, const uint8_t *desc_a, i
     if (na == 0 || nb == 0) return ORBFE_OK;
     const size_t need = (size_t)32 * na + (size_t)32 * nb + sizeof(int) * (size_t)na * nb;
     if (need > ctx->d_ham_bytes) {
-        if (ctx->d_ham) hipFree(ctx->d_ham);
-    for (int sd = 0; sd < 2; sd++) { if (ctx->cfg.rm_xy[sd]) hipFree((void *)ctx->cfg.rm_xy[sd]); if (ctx->cfg.rm_a[sd]) hipFree((void *)ctx->cfg.rm_a[sd]); }
-    if (ctx->d_und) hipFree(ctx->d_und);
+        if (ctx->d_ham) (void)hipFree(ctx->d_ham); // only this entry point's own scratch
         ctx->d_ham = nullptr; ctx->d_ham_bytes = 0;
         HIP_TRY(ctx, hipMalloc((void **)&ctx->d_ham, need));
         ctx->d_ham_bytes = need;

@@ -22,6 +22,7 @@
 
 #define HISTO_LENGTH 30
 #define TH_LOW 50
+#define BOW_MAX_DEPTH 32 // node ids are 32-bit paths of ceil(log2 k) bits per level: deeper trees cannot be addressed anyway
 
 struct FbowParams { // fbow::Vocabulary::params, Thirdparty/fbow/src/fbow.h:118-129
     char desc_name[50];
@@ -43,7 +44,9 @@ struct orbfe_bow_state {
     float *d_db_w = nullptr;
     size_t db_cap = 0;                 // entries allocated
     std::vector<int> db_off, db_len;   // per keyframe: first entry, number of words (0 after erase)
+    std::vector<uint8_t> db_dead;      // erased keyframes: never scored again, their words are reclaimed by kfdb_compact
     size_t db_used = 0;
+    size_t db_dead_words = 0;          // words of erased keyframes still occupying the CSR
     ~orbfe_bow_state()
     {
         if (d_data) hipFree(d_data);
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256) void bow_descend_kernel(const uint8_t *__restr
         blk = data + (size_t)child * block_size;
         cur_node = (cur_node << nbits) | best_i;
         level++;
-        if (child == 0) break;
+        if (child == 0 || level > BOW_MAX_DEPTH) break; // orbfe_vocab_load rejects deeper / cyclic trees; never spin on a bad blob
     }
     word_id[f] = wid; weight[f] = w; node_id[f] = nid;
 }
@@ -151,6 +154,28 @@ extern "C" int orbfe_vocab_load(orbfe_context *ctx, const uint8_t *blob, size_t 
             uint32_t ic;
             memcpy(&ic, blk + p.child_off_start + (size_t)c * 8, 4);
             if (!(ic & 0x80000000u) && ic >= p.nblocks) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "block %u links to block %u", b, ic);
+        }
+    }
+    {   // the links must form a tree of bounded depth below block 0: a cycle (or a block reached twice) would make the
+        // descent kernel loop, so walk every link once and refuse anything else
+        std::vector<uint8_t> depth(p.nblocks, 0); // 0 = not reached
+        std::vector<uint32_t> stack(1, 0u);
+        depth[0] = 1;
+        while (!stack.empty()) {
+            const uint32_t b = stack.back();
+            stack.pop_back();
+            const uint8_t *blk = data + (size_t)b * p.block_size_bytes_wp;
+            const unsigned N = *(const uint16_t *)blk;
+            for (unsigned c = 0; c < N; c++) {
+                uint32_t ic;
+                memcpy(&ic, blk + p.child_off_start + (size_t)c * 8, 4);
+                if (ic & 0x80000000u) continue; // leaf: word id
+                if (ic == 0) continue;          // the descent stops at a zero link
+                if (depth[ic]) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "block %u is linked twice (cycle or shared subtree)", ic);
+                if (depth[b] >= BOW_MAX_DEPTH) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "vocabulary deeper than %d levels", BOW_MAX_DEPTH);
+                depth[ic] = (uint8_t)(depth[b] + 1);
+                stack.push_back(ic);
+            }
         }
     }
     BTRY(ctx, hipSetDevice(orbfe_ctx_device(ctx)));
@@ -361,7 +386,8 @@ extern "C" int orbfe_search_by_bow_kf(orbfe_context *ctx,
 // first-encounter order = ascending (first shared word, keyframe index)), score.
 __global__ __launch_bounds__(256) void kfdb_score_kernel(const uint32_t *__restrict__ q_words, const float *__restrict__ q_w, int nq,
                                                          const int *__restrict__ kf_off, const int *__restrict__ kf_len,
-                                                         const uint32_t *__restrict__ db_words, const float *__restrict__ db_w, int n_kf,
+                                                         const uint32_t *__restrict__ db_words, const float *__restrict__ db_w, int n_kf, // n_kf = LIVE keyframes
+
                                                          int *__restrict__ common, uint32_t *__restrict__ first_word, float *__restrict__ score)
 {
     __shared__ uint32_t s_qw[KFDB_Q_LDS];
@@ -420,7 +446,7 @@ extern "C" int orbfe_kfdb_clear(orbfe_context *ctx)
     if (!ctx) return ORBFE_ERR_INVALID;
     orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
     if (!st) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "out of host memory");
-    st->db_off.clear(); st->db_len.clear(); st->db_used = 0;
+    st->db_off.clear(); st->db_len.clear(); st->db_dead.clear(); st->db_used = 0; st->db_dead_words = 0;
     return ORBFE_OK;
 }
 
@@ -453,8 +479,39 @@ extern "C" int orbfe_kfdb_add(orbfe_context *ctx, const uint32_t *words, const f
         BTRY(ctx, hipStreamSynchronize(s));
     }
     if (kf_index) *kf_index = (int)st->db_off.size();
-    st->db_off.push_back((int)st->db_used); st->db_len.push_back(n);
+    st->db_off.push_back((int)st->db_used); st->db_len.push_back(n); st->db_dead.push_back(0);
     st->db_used += (size_t)n;
+    return ORBFE_OK;
+}
+
+// Reclaims the words of erased keyframes: the live segments are moved to the front of the CSR (keyframe indices stay).
+// Rare (once the dead words outnumber the live ones), so it goes through the host.
+static int kfdb_compact(orbfe_context *ctx, orbfe_bow_state *st)
+{
+    BTRY(ctx, hipSetDevice(orbfe_ctx_device(ctx)));
+    hipStream_t s = orbfe_ctx_stream(ctx);
+    std::vector<uint32_t> w(st->db_used ? st->db_used : 1);
+    std::vector<float> v(st->db_used ? st->db_used : 1);
+    if (st->db_used) {
+        BTRY(ctx, hipMemcpyAsync(w.data(), st->d_db_words, st->db_used * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        BTRY(ctx, hipMemcpyAsync(v.data(), st->d_db_w, st->db_used * sizeof(float), hipMemcpyDeviceToHost, s));
+        BTRY(ctx, hipStreamSynchronize(s));
+    }
+    size_t o = 0;
+    for (size_t k = 0; k < st->db_off.size(); k++) {
+        if (st->db_dead[k]) { st->db_off[k] = 0; continue; }
+        const size_t from = (size_t)st->db_off[k], len = (size_t)st->db_len[k];
+        if (from != o) { memmove(&w[o], &w[from], len * sizeof(uint32_t)); memmove(&v[o], &v[from], len * sizeof(float)); }
+        st->db_off[k] = (int)o;
+        o += len;
+    }
+    if (o) {
+        BTRY(ctx, hipMemcpyAsync(st->d_db_words, w.data(), o * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        BTRY(ctx, hipMemcpyAsync(st->d_db_w, v.data(), o * sizeof(float), hipMemcpyHostToDevice, s));
+        BTRY(ctx, hipStreamSynchronize(s));
+    }
+    st->db_used = o;
+    st->db_dead_words = 0;
     return ORBFE_OK;
 }
 
@@ -463,7 +520,14 @@ extern "C" int orbfe_kfdb_erase(orbfe_context *ctx, int kf_index)
     if (!ctx) return ORBFE_ERR_INVALID;
     orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
     if (!st || kf_index < 0 || kf_index >= (int)st->db_len.size()) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "keyframe index out of range");
-    st->db_len[kf_index] = 0; // KeyFrameDatabase::erase: the keyframe leaves every inverted-file list
+    if (st->db_dead[kf_index]) return ORBFE_OK;
+    // KeyFrameDatabase::erase: the keyframe leaves every inverted-file list.  It is dropped from the launch list of every
+    // later query, and its words are reclaimed once the dead ones outnumber the live ones (culling in a long session must
+    // not grow HBM use or query cost with the number of keyframes ever added).
+    st->db_dead[kf_index] = 1;
+    st->db_dead_words += (size_t)st->db_len[kf_index];
+    st->db_len[kf_index] = 0;
+    if (st->db_dead_words > 1024 && 2 * st->db_dead_words > st->db_used) return kfdb_compact(ctx, st);
     return ORBFE_OK;
 }
 
@@ -481,27 +545,37 @@ static int kfdb_scores(orbfe_context *ctx, orbfe_bow_state *st, const uint32_t *
     const int n_kf = (int)st->db_off.size();
     common.assign(n_kf > 0 ? n_kf : 1, 0); first.assign(n_kf > 0 ? n_kf : 1, 0xffffffffu); score.assign(n_kf > 0 ? n_kf : 1, 0.f);
     if (n_kf == 0 || nq == 0) return ORBFE_OK;
+    // launch list: live keyframes only (an erased one costs neither a wave nor a result slot)
+    std::vector<int> live, l_off, l_len;
+    for (int k = 0; k < n_kf; k++)
+        if (!st->db_dead[k]) { live.push_back(k); l_off.push_back(st->db_off[k]); l_len.push_back(st->db_len[k]); }
+    const int n_live = (int)live.size();
+    if (n_live == 0) return ORBFE_OK;
     BTRY(ctx, hipSetDevice(orbfe_ctx_device(ctx)));
     hipStream_t s = orbfe_ctx_stream(ctx);
-    const size_t need = (size_t)nq * 8 + (size_t)n_kf * 20 + 64;
+    const size_t need = (size_t)nq * 8 + (size_t)n_live * 20 + 64;
     int rc = ensure_scratch(ctx, st, need);
     if (rc != ORBFE_OK) return rc;
     uint32_t *d_qw = (uint32_t *)st->d_scratch;
     float *d_qv = (float *)(d_qw + nq);
-    int *d_off = (int *)(d_qv + nq), *d_len = d_off + n_kf, *d_common = d_len + n_kf;
-    uint32_t *d_first = (uint32_t *)(d_common + n_kf);
-    float *d_score = (float *)(d_first + n_kf);
+    int *d_off = (int *)(d_qv + nq), *d_len = d_off + n_live, *d_common = d_len + n_live;
+    uint32_t *d_first = (uint32_t *)(d_common + n_live);
+    float *d_score = (float *)(d_first + n_live);
+    std::vector<int> l_common(n_live);
+    std::vector<uint32_t> l_first(n_live);
+    std::vector<float> l_score(n_live);
     BTRY(ctx, hipMemcpyAsync(d_qw, q_words, sizeof(uint32_t) * nq, hipMemcpyHostToDevice, s));
     BTRY(ctx, hipMemcpyAsync(d_qv, q_w, sizeof(float) * nq, hipMemcpyHostToDevice, s));
-    BTRY(ctx, hipMemcpyAsync(d_off, st->db_off.data(), sizeof(int) * n_kf, hipMemcpyHostToDevice, s));
-    BTRY(ctx, hipMemcpyAsync(d_len, st->db_len.data(), sizeof(int) * n_kf, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(kfdb_score_kernel, dim3((n_kf + 3) / 4), dim3(256), 0, s, d_qw, d_qv, nq, d_off, d_len, st->d_db_words, st->d_db_w, n_kf,
+    BTRY(ctx, hipMemcpyAsync(d_off, l_off.data(), sizeof(int) * n_live, hipMemcpyHostToDevice, s));
+    BTRY(ctx, hipMemcpyAsync(d_len, l_len.data(), sizeof(int) * n_live, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(kfdb_score_kernel, dim3((n_live + 3) / 4), dim3(256), 0, s, d_qw, d_qv, nq, d_off, d_len, st->d_db_words, st->d_db_w, n_live,
                        d_common, d_first, d_score);
-    BTRY(ctx, hipMemcpyAsync(common.data(), d_common, sizeof(int) * n_kf, hipMemcpyDeviceToHost, s));
-    BTRY(ctx, hipMemcpyAsync(first.data(), d_first, sizeof(uint32_t) * n_kf, hipMemcpyDeviceToHost, s));
-    BTRY(ctx, hipMemcpyAsync(score.data(), d_score, sizeof(float) * n_kf, hipMemcpyDeviceToHost, s));
+    BTRY(ctx, hipMemcpyAsync(l_common.data(), d_common, sizeof(int) * n_live, hipMemcpyDeviceToHost, s));
+    BTRY(ctx, hipMemcpyAsync(l_first.data(), d_first, sizeof(uint32_t) * n_live, hipMemcpyDeviceToHost, s));
+    BTRY(ctx, hipMemcpyAsync(l_score.data(), d_score, sizeof(float) * n_live, hipMemcpyDeviceToHost, s));
     BTRY(ctx, hipStreamSynchronize(s));
     BTRY(ctx, hipGetLastError());
+    for (int i = 0; i < n_live; i++) { common[live[i]] = l_common[i]; first[live[i]] = l_first[i]; score[live[i]] = l_score[i]; }
     return ORBFE_OK;
 }
 

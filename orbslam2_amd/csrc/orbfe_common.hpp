@@ -1,4 +1,4 @@
-// orbfe_common.cuh -- device helpers shared by the kernel translation units of liborbfe.so (gfx950, wave64).
+// orbfe_common.hpp -- device helpers shared by the kernel translation units of liborbfe.so (gfx950, wave64).
 //
 // Floating point follows contract Q4: compiled with -ffp-contract=off, every float product / sum is
 // individually rounded (IEEE), divisions are correctly rounded, cos / sin come from the deterministic routine below.

@@ -1,5 +1,5 @@
 // orbfe_describe.hip -- IC_Angle + computeOrbDescriptor + keypoint records (src/ORBextractor.cc:72-142,831-846,909-915) and the stereo row lists.
-#include "orbfe_common.cuh"
+#include "orbfe_common.hpp"
 
 __device__ __attribute__((aligned(16))) const int8_t g_pattern[1024] = {
 #include "orb_pattern_31.inc"
@@ -21,7 +21,7 @@ __device__ __attribute__((aligned(16))) const int8_t g_pattern[1024] = {
 #define DS_BLR_REGS 6 // 37 rows * 10 words = 370 words
 
 
-__global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int stereo, int dbg)
+__global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int stereo ORBFE_CUT_PARAM)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dm[];
     // XCD-aware block -> (image, block) map: workgroups are dealt round-robin over the 8 XCDs, so block
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, Devi
         if (lane >= o) inc += t;
     }
     const int excl = inc - c_l; // keypoints of the lower levels
-    if (dbg == 1) return;
+    if (ORBFE_CUT(1)) return;
 
     const int r0 = lane / (DS_PATCH_W / 4), c0 = lane - r0 * (DS_PATCH_W / 4);
     const bool raw_in_regs = raw_words <= 64 * DS_RAW_REGS;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, Devi
         __builtin_amdgcn_s_waitcnt(0); // LDS writes of this wave are visible to its own later reads in order
         __builtin_amdgcn_wave_barrier();
         have = prefetch_raw(i + 1); // in flight while keypoint i is computed
-        if (!cur || dbg == 2) continue;
+        if (!cur || ORBFE_CUT(2)) continue;
         // IC_Angle (src/ORBextractor.cc:72-99): integer moments over the circular patch (host-built offset
         // table, padded with (0,0) entries that contribute nothing)
         const int xr = (kx - hp) & ~3;
@@ -234,13 +234,13 @@ __global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, Devi
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         have = prefetch_blur(i + 1);
-        if (!cur || dbg == 2) continue;
+        if (!cur || ORBFE_CUT(2)) continue;
         const LevelInfo &L = cfg.lv[lv];
         const int xb = (kx - 18) & ~3;
         const float angle = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(angle_l), i));
         const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_l), i));
         const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_l), i));
-        if (dbg == 3) { if (lane == 0) buf.depth[(size_t)img * cfg.sel_total + kout] = angle; continue; }
+        if (ORBFE_CUT(3)) { if (lane == 0) buf.depth[(size_t)img * cfg.sel_total + kout] = angle; continue; }
 
         // computeOrbDescriptor (src/ORBextractor.cc:103-142)
         const uint8_t *center = s_blr + 18 * DS_PATCH_W + (kx - xb);
@@ -312,6 +312,5 @@ void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, in
 {
     dim3 grid(xcd_grid((cfg.sel_total + 4 * DS_KPW - 1) / (4 * DS_KPW), n_images));
     const size_t lds = ((cfg.patch_n * 2 + 15) & ~15) + 256 * 4 + (size_t)4 * (2 * cfg.half_patch + 1 + 37) * DS_PATCH_W;
-    static const int dbg = getenv("ORBFE_DESC_DBG") ? atoi(getenv("ORBFE_DESC_DBG")) : 0; // profiling aid only
-    hipLaunchKernelGGL(describe_kernel, grid, dim3(256), lds, s, cfg, buf, n_images, stereo ? 1 : 0, dbg);
+    hipLaunchKernelGGL(describe_kernel, grid, dim3(256), lds, s, cfg, buf, n_images, stereo ? 1 : 0 ORBFE_CUT_ARG("ORBFE_DESC_DBG"));
 }

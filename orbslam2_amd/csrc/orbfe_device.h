@@ -4,9 +4,24 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #define ORBFE_MAX_LEVELS 16
 #define ORBFE_WAVE 64
+
+// Profiling cut points (tools/*_phases.sh, tools/*_insts.sh): an extra kernel argument that makes a kernel return after a
+// given phase so that phases can be timed / counted.  They exist ONLY in the -DORBFE_PROFILE_CUTS build (make cuts ->
+// tools/ab/cuts.so); the shipped liborbfe.so has neither the argument nor the branches nor the getenv.
+#ifdef ORBFE_PROFILE_CUTS
+#define ORBFE_CUT_PARAM , int dbg
+#define ORBFE_CUT(n) (dbg == (n))
+#define ORBFE_CUT_ARG(env) , orbfe_cut_value(env)
+static inline int orbfe_cut_value(const char *env) { const char *v = getenv(env); return v ? atoi(v) : 0; }
+#else
+#define ORBFE_CUT_PARAM
+#define ORBFE_CUT(n) false
+#define ORBFE_CUT_ARG(env)
+#endif
 
 // Per-level geometry (reference: src/ORBextractor.cc:759-781,925-926,533-557).
 struct LevelInfo {

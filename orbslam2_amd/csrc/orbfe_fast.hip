@@ -1,5 +1,5 @@
 // orbfe_fast.hip -- cell-wise cv::FAST with two thresholds (src/ORBextractor.cc:783-823) + quadtree bucket accumulation.
-#include "orbfe_common.cuh"
+#include "orbfe_common.hpp"
 
 // ---------------------------------------------------------------------------
 // FAST-9/16 per cell: score map + 3x3 NMS inside the cell + two-threshold select
@@ -70,7 +70,7 @@ template <int P> __device__ __forceinline__ pk16 row_pair(const unsigned (&w)[3]
 // the waves of a workgroup are independent; a wave's own LDS traffic only needs its outstanding LDS operations retired
 #define FAST_WAVE_SYNC() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); } while (0)
 template <int TP, bool BK>
-__global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int tile_pitch_rt, int tile_bytes, int sc_bytes, int q_bytes, int lds_per_wave, int dbg)
+__global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int tile_pitch_rt, int tile_bytes, int sc_bytes, int q_bytes, int lds_per_wave ORBFE_CUT_PARAM)
 {
     const int tile_pitch = TP ? TP : tile_pitch_rt;
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem_all[];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
     }
     for (int i = lane; i < sc_bytes / 4; i += 64) ((uint32_t *)s_sc)[i] = 0;
     FAST_WAVE_SYNC();
-    if (dbg == 1) { if (lane == 0) *cnt_out = 0; return; }
+    if (ORBFE_CUT(1)) { if (lane == 0) *cnt_out = 0; return; }
     // Phases A and C work on TWO pixels per lane, one in each 16-bit half of a register, with packed
     // v_pk_{sub,min,max}_i16 (ring differences are in [-255, 255]): integer VALU issue is what bounds
     // this kernel (measured ~1 wave64 instruction / cycle / CU), so instructions are what is saved.
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
         }
     }
     FAST_WAVE_SYNC();
-    if (dbg == 3) { if (lane == 0) *cnt_out = 0; return; }
+    if (ORBFE_CUT(3)) { if (lane == 0) *cnt_out = 0; return; }
     // ---- C: exact score for the entry's polarity: max over the 16 arcs of the min of 9 (sign-normalised)
     //      differences; windows of 2, 4, 8 (+1) by doubling. ----
     for (int q0 = 0; q0 < n2; q0 += 128) {
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
         if (vb && sb >= t) s_sc[(rb + 1) * scp + cb + 1] = (uint8_t)sb;
     }
     FAST_WAVE_SYNC();
-    if (dbg == 4) { if (lane == 0) *cnt_out = 0; return; }
+    if (ORBFE_CUT(4)) { if (lane == 0) *cnt_out = 0; return; }
     // ---- D: NMS + threshold choice.  The first 256 queue entries (all of them for ordinary cells) keep their flag and
     //      coordinates in registers for the compaction of phase E; later ones go through the LDS flag array. ----
     bool any = false;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
         }
     }
     if (lane == 0) *cnt_out = run < cfg.cell_cap ? run : cfg.cell_cap;
-    if (BK && nb <= 64 && dbg != 5) {
+    if (BK && nb <= 64 && !ORBFE_CUT(5)) {
         FAST_WAVE_SYNC();
         const unsigned cnt = lane < nb ? s_ac[lane] : 0u;
         if (cnt) {
@@ -438,11 +438,10 @@ void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_
     const int lds_per_wave = tile_region + sc_bytes + q_bytes + 512;
     const size_t lds = (size_t)4 * lds_per_wave;
     dim3 grid(xcd_grid((cfg.cells_total + 3) / 4, n_images));
-    static const int dbg = getenv("ORBFE_FAST_DBG") ? atoi(getenv("ORBFE_FAST_DBG")) : 0; // profiling aid only
 #define FAST_LAUNCH(TP)                                                                                                                   \
     do {                                                                                                                              \
-        if (buckets) hipLaunchKernelGGL((fast_cell_kernel<TP, true>), grid, dim3(256), lds, s, cfg, buf, n_images, tile_pitch, tile_region, sc_bytes, q_bytes, lds_per_wave, dbg); \
-        else hipLaunchKernelGGL((fast_cell_kernel<TP, false>), grid, dim3(256), lds, s, cfg, buf, n_images, tile_pitch, tile_region, sc_bytes, q_bytes, lds_per_wave, dbg); \
+        if (buckets) hipLaunchKernelGGL((fast_cell_kernel<TP, true>), grid, dim3(256), lds, s, cfg, buf, n_images, tile_pitch, tile_region, sc_bytes, q_bytes, lds_per_wave ORBFE_CUT_ARG("ORBFE_FAST_DBG")); \
+        else hipLaunchKernelGGL((fast_cell_kernel<TP, false>), grid, dim3(256), lds, s, cfg, buf, n_images, tile_pitch, tile_region, sc_bytes, q_bytes, lds_per_wave ORBFE_CUT_ARG("ORBFE_FAST_DBG")); \
     } while (0)
     switch (tile_pitch) {
     case 44: FAST_LAUNCH(44); break;

@@ -624,8 +624,13 @@ __device__ __forceinline__ void ot2_run_level(const DeviceConfig &cfg, const Dev
 // A workgroup handles levels p and nlevels-1-p of one image back to back: candidates shrink ~1.44x per
 // level, so the pairs (0,7), (1,6), ... are balanced, and a batch of 32 stereo pairs is exactly one
 // workgroup per CU (the LDS footprint allows only one) instead of two unbalanced rounds.
-__global__ __launch_bounds__(OT2_THREADS) void octree2_kernel(DeviceConfig cfg, DeviceBuffers buf, int sort_cap, int lds_pts, int dbg_stop)
+__global__ __launch_bounds__(OT2_THREADS) void octree2_kernel(DeviceConfig cfg, DeviceBuffers buf, int sort_cap, int lds_pts ORBFE_CUT_PARAM)
 {
+#ifdef ORBFE_PROFILE_CUTS
+    const int dbg_stop = dbg;
+#else
+    const int dbg_stop = 0; // the stop / timestamp branches fold away in the shipped build
+#endif
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     __shared__ int s_w[4 * OT2_WAVES];
     __shared__ int s_scal[8];
@@ -640,8 +645,7 @@ __global__ __launch_bounds__(OT2_THREADS) void octree2_kernel(DeviceConfig cfg, 
 void orbfe_launch_octree2(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, int lds_pts, size_t lds, hipStream_t s)
 {
     dim3 grid((cfg.nlevels + 1) / 2, n_images);
-    static const int dbg_stop = getenv("ORBFE_OT2_STOP") ? atoi(getenv("ORBFE_OT2_STOP")) : 0; // profiling aid only
-    hipLaunchKernelGGL(octree2_kernel, grid, dim3(OT2_THREADS), lds, s, cfg, buf, sort_cap, lds_pts, dbg_stop);
+    hipLaunchKernelGGL(octree2_kernel, grid, dim3(OT2_THREADS), lds, s, cfg, buf, sort_cap, lds_pts ORBFE_CUT_ARG("ORBFE_OT2_STOP"));
 }
 
 int orbfe_octree2_prepare(size_t lds)

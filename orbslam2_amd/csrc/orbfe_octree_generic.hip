@@ -1,5 +1,5 @@
 // orbfe_octree_generic.hip -- DistributeOctTree (src/ORBextractor.cc:533-757), generic node-parallel kernel: last fallback of orbfe_octree3.hip / orbfe_octree.hip.
-#include "orbfe_common.cuh"
+#include "orbfe_common.hpp"
 
 #define OT_THREADS 512
 

@@ -1,5 +1,5 @@
 // orbfe_pyramid.hip -- ingest, cv::resize pyramid (src/ORBextractor.cc:921-946) and the 7x7 Gaussian (:899-900).
-#include "orbfe_common.cuh"
+#include "orbfe_common.hpp"
 
 // ---------------------------------------------------------------------------
 // Pyramid storage.  Every level is stored with a reflect-101 margin (PYR_MX px on the left, at

@@ -1,5 +1,5 @@
 // orbfe_stereo.hip -- Frame::ComputeStereoMatches (src/Frame.cc:464-642), ComputeStereoFromRGBD (:645-666), batched DescriptorDistance.
-#include "orbfe_common.cuh"
+#include "orbfe_common.hpp"
 
 // ---------------------------------------------------------------------------
 // stereo: one wave per left keypoint (coarse Hamming band search + SAD + parabola)

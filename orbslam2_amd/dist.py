@@ -53,6 +53,34 @@ def broadcast_params(blob: bytes, device) -> bytes:
     return bytes(t.cpu().numpy().tobytes())
 
 
+def broadcast_blob(blob, device) -> bytes:
+    """A byte string held by rank 0 (the fbow vocabulary file, Thirdparty/fbow/src/fbow.cpp:172-191 format; `blob` is
+    ignored on the other ranks and may be None) on every rank: one 8-byte length broadcast, then the payload in one
+    collective (backend "nccl" = RCCL over xGMI, device tensors; gloo: CPU tensors).  Every rank then hands the bytes to
+    orbfe_vocab_load, which keeps the tree in its GPU's HBM.  A sha256 travels with the payload and is checked."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        if blob is None:
+            raise ValueError("broadcast_blob: rank 0 must supply the blob")
+        return bytes(blob)
+    rank = dist.get_rank()
+    if rank == 0 and blob is None:
+        raise ValueError("broadcast_blob: rank 0 must supply the blob")
+    n = torch.tensor([len(blob) if rank == 0 else 0], dtype=torch.int64, device=device)
+    dist.broadcast(n, src=0)
+    size = int(n.item())
+    if rank == 0:
+        payload = bytes(blob) + hashlib.sha256(bytes(blob)).digest()
+        t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
+    else:
+        t = torch.empty(size + 32, dtype=torch.uint8, device=device)
+    dist.broadcast(t, src=0)
+    raw = t.cpu().numpy().tobytes()
+    body, digest = raw[:size], raw[size:]
+    if hashlib.sha256(body).digest() != digest:
+        raise RuntimeError("rank %d: vocabulary blob corrupted in the broadcast" % rank)
+    return body
+
+
 def shard_pairs(total_pairs: int, rank: int, world: int):
     """Round-robin by frame index: pair i goes to rank i % world."""
     return list(range(rank, total_pairs, world))

@@ -9,8 +9,9 @@
 // reference declares (include/ORBextractor.h:58-60).
 //
 // Differences a maintainer must know (also in INTEGRATION.md):
-//  * the image size is bound when the first frame arrives (one camera model per
-//    extractor, as the reference assumes through Frame's statics, src/Frame.cc:29-33);
+//  * the image size is bound when the first frame arrives, or by BindImageSize() (one camera
+//    model per extractor, as the reference assumes through Frame's statics, src/Frame.cc:29-33);
+//    the device context is created once and never re-created (see Context());
 //  * mvImagePyramid is materialised on the host only if KeepHostPyramid(true) is set
 //    (the reference's own ComputeStereoMatches needs it; orbfe_stereo_frame does not).
 #pragma once
@@ -78,12 +79,25 @@ public:
         }
     }
 
-    ~ORBextractor() { if (mCtx) orbfe_destroy(mCtx); }
+    ~ORBextractor()
+    {
+        if (mCtx && DefaultContext() == mCtx) DefaultContext() = nullptr;
+        if (mCtx) orbfe_destroy(mCtx);
+    }
     ORBextractor(const ORBextractor &) = delete;
     ORBextractor &operator=(const ORBextractor &) = delete;
 
-    void SetCamera(const CameraParams &c) { mCam = c; }
-    void SetDevice(int device) { mParams.device = device; }
+    // camera and device must be set before the first frame (they are baked into the device context)
+    void SetCamera(const CameraParams &c)
+    {
+        if (mCtx) throw std::logic_error("ORBextractor::SetCamera after the device context was created");
+        mCam = c;
+    }
+    void SetDevice(int device)
+    {
+        if (mCtx) throw std::logic_error("ORBextractor::SetDevice after the device context was created");
+        mParams.device = device;
+    }
     void KeepHostPyramid(bool keep) { mKeepPyramid = keep; }
 
     // ORBextractor::operator() (src/ORBextractor.cc:858-919).  mask is ignored, as in the
@@ -141,19 +155,44 @@ public:
     std::vector<cv::Mat> mvImagePyramid; // include/ORBextractor.h:84
 #endif
 
+    // The device context of this extractor.  LIFETIME RULE: it is created ONCE -- by the first frame (whose size it takes),
+    // or earlier by BindImageSize() -- and lives until the extractor is destroyed.  ORBmatcher, KeyFrameDatabase and the
+    // vocabulary keep this pointer (and state inside it), so it is never re-created behind their back: a later frame of
+    // another size, or a batch beyond the capacity fixed at creation, throws instead.
     orbfe_context *Context() { return mCtx; }
 
-    // Creates (or re-creates) the device context for this image size / batch.
+    // Fix the image size (and, optionally, the number of images per batched call) before the first frame, e.g. right
+    // after construction in Tracking::Tracking, so that Context() can be handed to the matchers / database at once.
+    void BindImageSize(int width, int height, int maxImages = 2) { EnsureContext(width, height, maxImages); }
+
+    // Creates the device context on first use: always room for a stereo pair (max_images >= 2), so operator() followed by
+    // ComputeStereoFrame never needs a second context.
     void EnsureContext(int width, int height, int maxImages)
     {
-        if (mCtx && mParams.width == width && mParams.height == height && mParams.max_images >= maxImages) return;
-        if (mCtx) { orbfe_destroy(mCtx); mCtx = nullptr; }
+        if (mCtx) {
+            if (mParams.width != width || mParams.height != height)
+                throw std::invalid_argument("ORBextractor: image is " + std::to_string(width) + "x" + std::to_string(height) + ", this extractor is bound to " +
+                                            std::to_string(mParams.width) + "x" + std::to_string(mParams.height) + " (one camera model per extractor)");
+            if (mParams.max_images < maxImages)
+                throw std::invalid_argument("ORBextractor: " + std::to_string(maxImages) + " images per call exceed the capacity fixed at creation (" +
+                                            std::to_string(mParams.max_images) + "); call BindImageSize(w, h, maxImages) before the first frame");
+            return;
+        }
         mParams.width = width; mParams.height = height;
-        if (maxImages > mParams.max_images) mParams.max_images = maxImages;
+        mParams.max_images = maxImages > 2 ? maxImages : 2;
         mParams.fx = mCam.fx; mParams.fy = mCam.fy; mParams.cx = mCam.cx; mParams.cy = mCam.cy; mParams.bf = mCam.bf;
         const int rc = orbfe_create(&mParams, &mCtx);
         if (rc != ORBFE_OK) throw std::runtime_error(std::string("orbfe_create: ") + orbfe_last_error(nullptr));
         if (!mCam.distCoef.empty()) Check(orbfe_set_distortion(mCtx, mCam.distCoef.data(), (int)mCam.distCoef.size()));
+        DefaultContext() = mCtx;
+    }
+
+    // The context of the extractor created last in this process: what the keyframe-only ORBmatcher overloads (no Frame at
+    // hand to reach mpORBextractorLeft) and KeyFrameDatabase use.  A SLAM system has one left extractor (src/Tracking.cc:125).
+    static orbfe_context *&DefaultContext()
+    {
+        static orbfe_context *ctx = nullptr;
+        return ctx;
     }
 
     // Frame::UndistortKeyPoints (src/Frame.cc:402-432) and ComputeImageBounds (:434-462) for this camera

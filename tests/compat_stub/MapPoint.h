@@ -1,0 +1,43 @@
+// tests/compat_stub/MapPoint.h -- TEST-ONLY declaration stand-in for the reference's include/MapPoint.h: exactly the members
+// orbslam2_amd/compat/ORBmatcher.cc uses, same names and types, trivial storage.  Never shipped.
+#pragma once
+#include <map>
+#include "cvstub.h"
+
+namespace ORB_SLAM2
+{
+class KeyFrame;
+class MapPoint
+{
+public:
+    MapPoint() : mTrackProjX(0), mTrackProjY(0), mTrackProjXR(0), mbTrackInView(false), mnTrackScaleLevel(0), mTrackViewCos(0), mnLastFrameSeen(0),
+                 mbBad(false), mpReplaced(NULL), mfMinDistance(0), mfMaxDistance(0) {}
+    cv::Mat GetWorldPos() { return mWorldPos.clone(); }
+    cv::Mat GetNormal() { return mNormalVector.clone(); }
+    cv::Mat GetDescriptor() { return mDescriptor.clone(); }
+    int Observations() { return nObs; }
+    bool isBad() { return mbBad; }
+    float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
+    float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
+    bool IsInKeyFrame(KeyFrame *pKF) { return mObservations.count(pKF) != 0; }
+    int GetIndexInKeyFrame(KeyFrame *pKF) { return mObservations.count(pKF) ? (int)mObservations[pKF] : -1; }
+    void AddObservation(KeyFrame *pKF, size_t idx) { if (!mObservations.count(pKF)) { mObservations[pKF] = idx; nObs++; } }
+    void Replace(MapPoint *pMP) { if (pMP != this) { mbBad = true; mpReplaced = pMP; } }
+    MapPoint *GetReplaced() { return mpReplaced; }
+
+    int nObs = 0;
+    // Variables used by the tracking
+    float mTrackProjX, mTrackProjY, mTrackProjXR;
+    bool mbTrackInView;
+    int mnTrackScaleLevel;
+    float mTrackViewCos;
+    long unsigned int mnLastFrameSeen;
+
+    // test fixture access (the reference keeps these protected)
+    cv::Mat mWorldPos, mNormalVector, mDescriptor;
+    std::map<KeyFrame *, size_t> mObservations;
+    bool mbBad;
+    MapPoint *mpReplaced;
+    float mfMinDistance, mfMaxDistance;
+};
+} // namespace ORB_SLAM2

@@ -357,3 +357,81 @@ def test_gpu_search_for_triangulation(vocab):
     assert total > 300
     L.orc_vocab_destroy(v)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_keyframe_database_culling_compacts_and_keeps_scores(vocab):
+    """Keyframe culling in a long session (round-1 advisor finding): erased keyframes must leave the launch list and their
+    words must be reclaimed.  300 keyframes, 220 erased in random order (crosses the compaction threshold several times),
+    more added in between; after every phase the scores of the survivors equal a fresh database holding only them."""
+    from orbslam2_amd import api
+    L, v = _oracle_voc(vocab)
+    ctx = api.Context(width=752, height=480, nfeatures=1200)
+    B.vocab_load(ctx, vocab)
+    rng = np.random.default_rng(21)
+    db = B.KeyFrameDB(ctx)
+    vecs = {}
+
+    def add(seed):
+        _, (w, ww), _ = _oracle_transform(L, v, _descs(seed, 600))
+        k = db.add(w, ww)
+        vecs[k] = (w.copy(), ww.copy())
+        return k
+
+    for k in range(300):
+        assert add(9000 + k) == k
+    _, (qw, qv), _ = _oracle_transform(L, v, _descs(9000 + 17, 600))
+    alive = set(range(300))
+    order = rng.permutation(300)[:220]
+    for step, gone in enumerate(order):
+        db.erase(int(gone)); alive.discard(int(gone))
+        db.erase(int(gone))  # idempotent
+        if step in (60, 150):
+            alive.add(add(20000 + step))  # indices keep growing: never reused
+        if step % 55 == 54 or step == len(order) - 1:
+            common, score = db.score(qw, qv)
+            fresh = B.KeyFrameDB(api.Context(width=752, height=480, nfeatures=1200)); B.vocab_load(fresh.ctx, vocab)
+            ids = sorted(alive)
+            for k in ids:
+                fresh.add(*vecs[k])
+            c2, s2 = fresh.score(qw, qv)
+            assert np.array_equal(common[ids], c2) and np.array_equal(score[ids], s2)
+            dead = sorted(set(range(len(db))) - alive)
+            assert not common[dead].any() and not score[dead].any()
+            fresh.ctx.close()
+    assert len(db) == 302
+    L.orc_vocab_destroy(v)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_vocab_load_rejects_cyclic_and_shared_links(vocab):
+    """A corrupt blob whose child links form a cycle (block 1 -> 2 -> 1) or reach a block twice must be refused at load time:
+    the descent kernel would otherwise never terminate (round-1 advisor finding)."""
+    from orbslam2_amd import api
+    ctx = api.Context(width=320, height=240, nfeatures=300)
+    blob = bytearray(vocab)
+    hdr = 8 + 120
+    name, al, nblocks, desc_wp, block_size, feat_off, child_off, total, dtype, dsize, k = struct.unpack("<50s2xII4x5QiiI4x", bytes(blob[8:hdr]))
+
+    def link(b, c):
+        return struct.unpack_from("<I", blob, hdr + b * block_size + child_off + 8 * c)[0]
+
+    # find an inner block b (not the root) with a non-leaf link to block ch; point one of ch's non-leaf links back at b
+    inner = [(b, c, link(b, c)) for b in range(1, nblocks) for c in range(struct.unpack_from("<H", blob, hdr + b * block_size)[0])
+             if not (link(b, c) & 0x80000000)]
+    b, c, ch = inner[0]
+    back = [cc for cc in range(struct.unpack_from("<H", blob, hdr + ch * block_size)[0])]
+    bad = bytearray(blob)
+    struct.pack_into("<I", bad, hdr + ch * block_size + child_off + 8 * back[0], b)  # ch -> b -> ch ...
+    with pytest.raises(api.OrbfeError):
+        B.vocab_load(ctx, bytes(bad))
+    bad2 = bytearray(blob)  # two parents share one child block
+    b2, c2, ch2 = inner[1]
+    struct.pack_into("<I", bad2, hdr + b2 * block_size + child_off + 8 * c2, ch)
+    with pytest.raises(api.OrbfeError):
+        B.vocab_load(ctx, bytes(bad2))
+    B.vocab_load(ctx, vocab)  # the intact blob still loads
+    w, wt, nd = B.transform(ctx, _descs(5, 50))
+    assert len(w) == 50
+    ctx.close()

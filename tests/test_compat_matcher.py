@@ -1,0 +1,189 @@
+"""Reference-signature ORBmatcher shim (orbslam2_amd/compat/ORBmatcher.{h,cc}: `ORBmatcher matcher(0.9,true)`,
+SearchByProjection(Frame&, const Frame&, th, bMono), SearchByFboW(KeyFrame*, Frame&, vector<MapPoint*>&), ... exactly as
+include/ORBmatcher.h:42-70 of the reference declares them).
+
+CPU: the shim keeps the reference's declarations and compiles against declaration stand-ins of Frame / KeyFrame / MapPoint
+(tests/compat_stub, test-only: OpenCV and the reference tree are absent from the image).
+GPU: tests/compat_stub/compat_selftest drives six overloads the way src/Tracking.cc / src/LocalMapping.cc do, on a scene
+written here; what the calls leave in the Frame / KeyFrame / MapPoint objects must equal the CPU oracle on the same arrays."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.test_matchers import BF, CAM, CX, CY, FX, FY, H, LOG_SF, NL, W, _scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUB = os.path.join(ROOT, "tests", "compat_stub")
+EXE = os.path.join(STUB, "compat_selftest")
+REF_DECLS = [  # include/ORBmatcher.h:42-83 of the reference, whitespace-normalised
+    "ORBmatcher(float nnratio=0.6, bool checkOri=true);",
+    "static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b);",
+    "int SearchByProjection(Frame &F, const std::vector<MapPoint*> &vpMapPoints, const float th=3);",
+    "int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono);",
+    "int SearchByProjection(Frame &CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*> &sAlreadyFound, const float th, const int ORBdist);",
+    "int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*> &vpPoints, std::vector<MapPoint*> &vpMatched, int th);",
+    "int SearchByFboW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches);",
+    "int SearchByFboW(KeyFrame *pKF1, KeyFrame* pKF2, std::vector<MapPoint*> &vpMatches12);",
+    "int SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize=10);",
+    "int SearchForTriangulation(KeyFrame *pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo);",
+    "int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint *> &vpMatches12, const float &s12, const cv::Mat &R12, const cv::Mat &t12, const float th);",
+    "int Fuse(KeyFrame* pKF, const vector<MapPoint *> &vpMapPoints, const float th=3.0);",
+    "int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*> &vpPoints, float th, vector<MapPoint *> &vpReplacePoint);",
+]
+
+
+def _norm(decl):
+    """Canonical form of a C++ declaration: std:: dropped (the reference header has `using namespace std`), no blanks."""
+    return re.sub(r"\s+", "", decl.replace("std::", ""))
+
+
+def test_shim_declares_the_reference_signatures():
+    text = open(os.path.join(ROOT, "orbslam2_amd", "compat", "ORBmatcher.h")).read()
+    body = _norm(re.sub(r"//[^\n]*", "", text))
+    for d in REF_DECLS:
+        assert _norm(d) in body, d
+    for name in ("static const int TH_LOW;", "static const int TH_HIGH;", "static const int HISTO_LENGTH;"):
+        assert _norm(name) in body
+
+
+def test_shim_compiles_against_the_declaration_stubs(tmp_path):
+    """g++ -fsyntax-only of the shim alone (no driver): every member it touches exists in the stand-ins with the reference's
+    name; and the shim contains no matching arithmetic of its own (it must go through the C ABI)."""
+    src = os.path.join(ROOT, "orbslam2_amd", "compat", "ORBmatcher.cc")
+    r = subprocess.run(["g++", "-std=c++14", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", STUB, "-I", os.path.dirname(src), src],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    text = open(src).read()
+    for call in ("orbfe_search_by_projection_points", "orbfe_search_by_projection_last", "orbfe_search_by_projection_kf", "orbfe_search_by_bow(",
+                 "orbfe_search_by_bow_kf", "orbfe_search_for_initialization", "orbfe_search_for_triangulation", "orbfe_search_by_sim3",
+                 "orbfe_fuse(", "orbfe_fuse_sim3", "orbfe_search_by_projection_sim3"):
+        assert call in text, call
+    assert "GetFeaturesInArea" not in text and "oracle" not in text
+
+
+def _bow_nodes(n, rng, shared):
+    """Synthetic fBow2 maps: keypoint i of both frames mostly falls into the same vocabulary node."""
+    node = (np.arange(n) * 7919 % 61).astype(np.uint32)
+    node2 = node.copy()
+    flip = rng.random(n) > shared
+    node2[flip] = rng.integers(0, 61, int(flip.sum()))
+
+    def csr(nd):
+        nodes = np.unique(nd)
+        off = [0]; feat = []
+        for v in nodes:
+            idx = np.nonzero(nd == v)[0]
+            feat.extend(idx.tolist()); off.append(len(feat))
+        return nodes.astype(np.uint32), np.array(off, np.int32), np.array(feat, np.int32)
+    return csr(node), csr(node2)
+
+
+@pytest.mark.gpu
+def test_reference_signature_calls_match_the_oracle(tmp_path):
+    assert os.path.exists(EXE), "compat_selftest not built (make -C tests/compat_stub)"
+    s = _scene(77, n_last=1100, n_distract=450)
+    rng = np.random.default_rng(78)
+    m, n = len(s["pos"]), len(s["k"])
+    valid3 = s["valid"].copy()                      # 0: no map point, 1: usable, 2: present but outlier / bad
+    valid3[(valid3 == 1) & (rng.random(m) < 0.1)] = 2
+    usable = (valid3 == 1).astype(np.int32)
+    dist0 = np.linalg.norm(s["pos"], axis=1).astype(np.float32)
+    max_d = (dist0 * s["sf"][s["octave"]]).astype(np.float32)
+    min_d = (max_d / s["sf"][NL - 1]).astype(np.float32)
+    normal = (s["pos"] / dist0[:, None] + rng.normal(0, 0.4, (m, 3))).astype(np.float32)
+    normal = (normal / np.linalg.norm(normal, axis=1, keepdims=True)).astype(np.float32)
+    tp = O.is_in_frustum(s["T_cur"], CAM, s["bounds"], s["pos"], normal, max_d, min_d, 0.5, LOG_SF, NL)
+    found = (rng.random(m) < 0.15).astype(np.uint8)
+    k1 = s["k"].copy(); k1["octave"] = np.where(np.arange(n) % 4 == 0, 1, 0)
+    k2 = k1.copy(); k2["x"] += rng.normal(5, 2, n).astype(np.float32); k2["y"] += rng.normal(-3, 2, n).astype(np.float32)
+    k2["octave"] = np.where(np.arange(n) % 7 == 0, 2, 0)
+    d2 = s["d"] ^ np.packbits(rng.random((n, 256)) < 0.05, axis=1, bitorder="little")
+    kf_fv, f_fv = _bow_nodes(n, rng, 0.9)
+    bow_valid = rng.choice([0, 1, 1, 1, 2], n).astype(np.int32)
+    fuse_kf_obs = np.where(rng.random(n) < 0.4, rng.integers(0, 4, n), -1).astype(np.int32)
+    d = tmp_path
+    files = {"cam.f32": np.array([FX, FY, CX, CY, BF, W, H], np.float32), "bounds.f32": np.array(s["bounds"], np.float32),
+             "cur_k.bin": s["k"], "cur_d.bin": s["d"], "cur_ur.bin": s["ur"], "cur_has_obs.bin": s["cur_has_obs"],
+             "last_pos.bin": s["pos"], "last_oct.bin": s["octave"], "last_ang.bin": s["angle"], "last_desc.bin": s["desc_last"],
+             "last_valid.bin": valid3, "last_obs.bin": s["obs"], "T_last.bin": s["T_last"], "T_cur.bin": s["T_cur"],
+             "normal.bin": normal, "max_d.bin": max_d, "min_d.bin": min_d, "tp.bin": tp, "already_found.bin": found,
+             "init_k1.bin": k1, "init_d1.bin": s["d"], "init_k2.bin": k2, "init_d2.bin": d2,
+             "bow_kf_valid.bin": bow_valid, "bow_kf_nodes.bin": kf_fv[0], "bow_kf_off.bin": kf_fv[1], "bow_kf_feat.bin": kf_fv[2],
+             "bow_f_nodes.bin": f_fv[0], "bow_f_off.bin": f_fv[1], "bow_f_feat.bin": f_fv[2], "fuse_kf_obs.bin": fuse_kf_obs}
+    for name, a in files.items():
+        np.ascontiguousarray(a).tofile(d / name)
+    r = subprocess.run([EXE, str(d)], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0 and "compat selftest ok" in r.stdout, r.stdout + r.stderr
+
+    def out(name, dt=np.int32):
+        return np.fromfile(d / name, dt)
+
+    g = O.Grid(s["k"], *s["bounds"])
+    # 1. SearchByProjection(CurrentFrame, LastFrame, 7, false) with ORBmatcher(0.9, true)
+    ref, nref = O.search_by_projection_last(g, s["ur"], s["d"], s["sf"], CAM, s["T_cur"], s["T_last"], s["pos"], s["desc_last"], usable,
+                                            s["obs"], s["octave"], s["angle"], s["cur_has_obs"], 7.0, False, True)
+    assert out("n_last.bin")[0] == nref and np.array_equal(out("out_last.bin"), ref) and nref > 100
+    # 2. SearchByProjection(F, vpMapPoints, 3) with ORBmatcher(0.8): every point is offered, mbTrackInView decides
+    ref, nref = O.search_by_projection_points(g, s["ur"], s["d"], s["sf"], tp, s["desc_last"], s["obs"], s["cur_has_obs"], 3.0, 0.8)
+    assert out("n_pts.bin")[0] == nref and np.array_equal(out("out_pts.bin"), ref) and nref > 100
+    # 3. SearchByProjection(CurrentFrame, pKF, sAlreadyFound, 10, 100): raw mfMax/MinDistance recovered from the *Invariance getters
+    kf_ok = (usable == 1) & (found == 0)
+    ref, nref = O.search_by_projection_kf(g, s["d"], s["sf"], CAM, s["T_cur"], LOG_SF, NL, s["pos"], s["desc_last"], kf_ok.astype(np.int32), s["angle"],
+                                          max_d, min_d, s["cur_has_obs"], 10.0, 100, True)
+    assert out("n_kf.bin")[0] == nref and np.array_equal(out("out_kf.bin"), ref) and nref > 30
+    # 4. SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, 100) with ORBmatcher(0.9, true)
+    g2 = O.Grid(k2, *s["bounds"])
+    prev = np.stack([k1["x"], k1["y"]], axis=1)
+    ref, pm_ref, nref = O.search_for_initialization(k1, s["d"], g2, d2, prev, 100, 0.9, True)
+    assert out("n_init.bin")[0] == nref and np.array_equal(out("out_init.bin"), ref) and nref > 100
+    assert np.array_equal(out("out_prev.bin", np.float32).reshape(-1, 2), pm_ref)
+    # 5. SearchByFboW(pKF, F, vpMapPointMatches) with ORBmatcher(0.7, true)
+    L = O.lib()
+    L.orc_search_by_bow.restype = C.c_int
+    L.orc_search_by_bow.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 2 + \
+        [C.c_int, C.c_float, C.c_int, C.c_void_p]
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    kf_valid = (bow_valid == 1).astype(np.int32)
+    kd = np.ascontiguousarray(s["d"]); ka = np.ascontiguousarray(k1["angle"]); fa = np.ascontiguousarray(k2["angle"]); fd = np.ascontiguousarray(d2)
+    ref = np.zeros(n, np.int32)
+    nref = L.orc_search_by_bow(p(kf_fv[0]), p(kf_fv[1]), p(kf_fv[2]), len(kf_fv[0]), p(kf_valid), p(kd), p(ka),
+                               p(f_fv[0]), p(f_fv[1]), p(f_fv[2]), len(f_fv[0]), p(fd), p(fa), n, 0.7, 1, p(ref))
+    got = out("out_bow.bin")
+    assert out("n_bow.bin")[0] == nref and nref > 100
+    # map points of the driver are shared by keypoints i and i + M: compare through the map point, as the reference returns it
+    assert np.array_equal(np.where(got >= 0, got % m, -1), np.where(ref >= 0, ref % m, -1))
+    # 6. Fuse(pKF, vpMapPoints, 3.0): search == oracle, then the reference's own bookkeeping (src/ORBmatcher.cc:943-964)
+    best, _ = O.fuse(g, s["ur"], s["d"], s["sf"], s["ex"].inv_sigma2(), CAM, s["T_cur"], LOG_SF, NL, s["pos"], normal, max_d, min_d, s["desc_last"], usable, 3.0)
+    held = {k: ("held", k) for k in range(n) if fuse_kf_obs[k] >= 0}
+    obs = {("held", k): int(fuse_kf_obs[k]) for k in held}
+    obs.update({("pt", i): int(s["obs"][i]) for i in range(m)})
+    bad, kfmap = set(), dict(held)
+    added = np.full(m, -1, np.int32); pt_repl = np.full(m, -1, np.int32); held_repl = np.full(n, -1, np.int32)
+    nfused = 0
+    for i in range(m):
+        b = int(best[i])
+        if b < 0:
+            continue
+        me, cur = ("pt", i), kfmap.get(b)
+        if cur is not None:
+            if cur not in bad:
+                if obs[cur] > obs[me]:
+                    bad.add(me)
+                    if cur[0] == "held":
+                        pt_repl[i] = cur[1]
+                else:
+                    bad.add(cur)
+                    if cur[0] == "held":
+                        held_repl[cur[1]] = i
+        else:
+            added[i] = b; obs[me] += 1; kfmap[b] = me
+        nfused += 1
+    assert out("n_fuse.bin")[0] == nfused and nfused > 50
+    assert np.array_equal(out("out_fuse_added.bin"), added)
+    assert np.array_equal(out("out_fuse_pt_replaced.bin"), pt_repl) and np.array_equal(out("out_fuse_held_replaced.bin"), held_repl)
+    assert (added >= 0).sum() > 10 and (pt_repl >= 0).sum() + (held_repl >= 0).sum() > 10

@@ -87,3 +87,71 @@ def test_fetch_batch_async_into_pinned_buffers(batch):
         assert np.array_equal(desc[2 * i, :nl], ref["desc_left"]) and np.array_equal(desc[2 * i + 1, :nr], ref["desc_right"])
         assert np.array_equal(ur[2 * i, :nl], ref["u_right"]) and np.array_equal(dp[2 * i, :nl], ref["depth"])
     ctx.close()
+
+
+KITTI = dict(width=1241, height=376, nfeatures=2000, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, bf=386.1448)
+
+
+def test_kitti_batch_of_64_pairs_every_distinct_pair_vs_oracle():
+    """BASELINE.json config 4 at its stated size: 64 KITTI-geometry stereo pairs in flight in ONE orbfe_enqueue_stereo call
+    (what bench.py times), built from 16 distinct seeds; EVERY slot's keypoints (all fields), descriptors, uRight and depth
+    are compared with the CPU oracle of its pair, bit for bit (uRight / depth: north_star's 1e-4 is met with margin 0)."""
+    import torch
+    from oracle import oracle as O
+    from orbslam2_amd import api
+    P, ND = 64, 16
+    distinct = [synth.stereo_pair(KITTI["width"], KITTI["height"], seed=7100 + 13 * i) for i in range(ND)]
+    refs = []
+    for l, r in distinct:
+        exl, exr = O.Extractor(nfeatures=KITTI["nfeatures"]), O.Extractor(nfeatures=KITTI["nfeatures"])
+        kl, dl = exl.extract(l); kr, dr = exr.extract(r)
+        ur, dp, m = O.stereo_matches(exl, exr, kl, dl, kr, dr, KITTI["bf"], KITTI["fx"])
+        assert m > 100
+        refs.append((kl, dl, kr, dr, ur, dp))
+    order = [(5 * i + 3) % ND for i in range(P)]  # neighbouring slots hold different pairs
+    host = np.empty((2 * P, KITTI["height"], KITTI["width"]), np.uint8)
+    for i, k in enumerate(order):
+        host[2 * i], host[2 * i + 1] = distinct[k]
+    dev = torch.from_numpy(host).cuda()
+    ctx = api.Context(max_images=2 * P, **KITTI)
+    for groups in (1, 2):
+        ctx.set_streams(groups)
+        ctx.enqueue_stereo(dev.data_ptr(), P, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        counts = ctx.fetch_counts(2 * P)
+        for i, k in enumerate(order):
+            kl, dl, kr, dr, ur, dp = refs[k]
+            left = ctx.fetch_image(2 * i, stereo=True)
+            right = ctx.fetch_image(2 * i + 1)
+            what = "groups %d slot %d (pair %d)" % (groups, i, k)
+            assert counts[2 * i] == len(kl) and counts[2 * i + 1] == len(kr), what
+            for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+                assert np.array_equal(left["kps"][f], kl[f]), what + " left " + f
+                assert np.array_equal(right["kps"][f], kr[f]), what + " right " + f
+            assert np.array_equal(left["desc"], dl) and np.array_equal(right["desc"], dr), what
+            assert np.array_equal(left["u_right"], ur) and np.array_equal(left["depth"], dp), what
+    ctx.close()
+
+
+def test_sharded_batch_on_two_ranks_covers_every_pair_once(batch):
+    """Strong-scaling layout of bench.py --mode strong on one GPU: two contexts play ranks 0 and 1 of world size 2, each
+    extracts dist.shard_pairs(5, rank, 2) of one global list; the union is every pair exactly once, equal to the
+    single-frame results."""
+    from orbslam2_amd import dist as D
+    api, torch = batch["api"], batch["torch"]
+    seen = {}
+    for rank in range(2):
+        mine = D.shard_pairs(5, rank, 2)
+        host = np.stack([im for i in mine for im in batch["pairs"][i]])
+        dev = torch.from_numpy(host).cuda()
+        ctx = api.Context(max_images=2 * len(mine), **CFG)
+        ctx.enqueue_stereo(dev.data_ptr(), len(mine), 0)
+        for j, i in enumerate(mine):
+            assert i not in seen
+            seen[i] = (ctx.fetch_image(2 * j, stereo=True), ctx.fetch_image(2 * j + 1))  # fetch waits for the enqueue stream
+        ctx.close()
+    assert sorted(seen) == list(range(5))
+    for i, ref in enumerate(batch["ref"]):
+        left, right = seen[i]
+        assert np.array_equal(left["kps"], ref["kps_left"]) and np.array_equal(left["desc"], ref["desc_left"])
+        assert np.array_equal(right["kps"], ref["kps_right"]) and np.array_equal(left["u_right"], ref["u_right"])

@@ -353,6 +353,35 @@ def test_rectified_ingest_matches_remap_then_extract():
     ctx.close()
 
 
+def test_hamming_matrix_leaves_rectification_and_undistortion_state_alone():
+    """Regression (round-1 advisor finding): orbfe_hamming_matrix used to free the rectification maps and the undistortion
+    scratch when it grew its own scratch, so the next rectified frame read freed memory.  Sequence from the finding:
+    set_rectification + fetch_keys_un, then hamming_matrix (first call always grows), then the same frame again."""
+    cfg = SMALL
+    w, h = cfg["width"], cfg["height"]
+    sw, sh = w + 16, h + 8
+    rawl, rawr = synth.stereo_pair(sw, sh, seed=72)
+    mxl, myl = _rectify_maps(w, h, sw, sh, 3)
+    mxr, myr = _rectify_maps(w, h, sw, sh, 4)
+    ctx = _ctx(cfg)
+    ctx.set_distortion([-0.28, 0.07, 1e-4, 2e-5, 0.0])
+    ctx.set_rectification(0, mxl, myl, (sw, sh))
+    ctx.set_rectification(1, mxr, myr, (sw, sh))
+    ref = ctx.stereo_frame(rawl, rawr)
+    un0, b0 = ctx.fetch_keys_un(0), ctx.image_bounds()
+    rng = np.random.default_rng(5)
+    for na, nb in ((40, 70), (300, 500), (16, 16)):  # grows twice, then reuses
+        a = rng.integers(0, 256, (na, 32), dtype=np.uint8); b = rng.integers(0, 256, (nb, 32), dtype=np.uint8)
+        d = ctx.hamming_matrix(a, b)
+        assert np.array_equal(d, np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(axis=2))
+        out = ctx.stereo_frame(rawl, rawr)
+        for k in ref:
+            assert np.array_equal(out[k], ref[k]), k
+        assert np.array_equal(ctx.fetch_keys_un(0), un0) and np.array_equal(ctx.image_bounds(), b0)
+    ctx.set_rectification(0)  # clearing and destroying must not double-free
+    ctx.close()
+
+
 def test_new_entry_points_reject_bad_arguments():
     """Error behaviour of the round's new entry points: invalid arguments come back as error codes with a message, never as
     a crash or a silent default."""

@@ -37,6 +37,27 @@ def _worker(rank, world, port, q):
     blob = D.broadcast_params(mine, dev)
     p = D.unpack_params(blob)
     assert p[0] == NF and p[2] == 8 and abs(p[8] - FX) < 1e-6, p
+    # vocabulary: only rank 0 holds the fbow blob; every rank must end up with the same bytes (what orbfe_vocab_load gets),
+    # and the oracle's loader must accept them on every rank
+    import hashlib
+    voc = None
+    if rank == 0:
+        from orbslam2_amd import bow as B
+        rng = np.random.default_rng(3)
+        voc = B.build_vocabulary(rng.integers(0, 256, (1500, 32), dtype=np.uint8), k=10, levels=3)
+    voc = D.broadcast_blob(voc, dev)
+    digests = [None] * world
+    dist.all_gather_object(digests, (len(voc), hashlib.sha256(voc).hexdigest()))
+    assert len(set(digests)) == 1 and digests[0][0] > 10000, digests
+    import ctypes as C
+    from oracle import oracle as O
+    OL = O.lib()
+    OL.orc_vocab_from_blob.restype = C.c_void_p; OL.orc_vocab_from_blob.argtypes = [C.c_void_p, C.c_size_t]
+    OL.orc_vocab_destroy.argtypes = [C.c_void_p]; OL.orc_vocab_destroy.restype = None
+    buf = np.frombuffer(voc, np.uint8)
+    hv = OL.orc_vocab_from_blob(buf.ctypes.data_as(C.c_void_p), len(buf))
+    assert hv
+    OL.orc_vocab_destroy(hv)
     my_pairs = D.shard_pairs(TOTAL_PAIRS, rank, world)
     res = {i: _pair_result(i) for i in my_pairs}
     gathered = [None] * world
