@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ORBFE_ABI_VERSION 1
+#define ORBFE_ABI_VERSION 2 /* 2: orbfe_frame_view.device_slot_plus1 */
 
 enum {
     ORBFE_OK = 0,
@@ -219,6 +219,16 @@ typedef struct orbfe_frame_view { /* what the matchers read from a Frame (includ
     const float *u_right;           /* mvuRight, or NULL for monocular */
     const uint8_t *descriptors;     /* mDescriptors, n x 32 */
     float min_x, max_x, min_y, max_y; /* mnMinX, mnMaxX, mnMinY, mnMaxY (ComputeImageBounds) */
+    /* 0: the arrays above are uploaded and bucketed on every call (any frame or keyframe).
+     * k + 1: the frame IS image slot k of this context's latest extraction call (orbfe_extract / _stereo_frame / _rgbd_frame:
+     * slot 0; batched calls: any slot): keypoints (undistorted on the device when orbfe_set_distortion is active) and
+     * descriptors are read where the extraction left them in HBM, and the 64 x 48 grid is built once per frame and reused by
+     * every later matcher call on it.  n must be that slot's keypoint count; keys_un must still point to the host copy (the
+     * host-side accept rules read angles from it), u_right (n floats, or NULL) is uploaded with every call, descriptors may
+     * be NULL.  What Tracking matches against
+     * is always the current frame, so this is the Tracking-thread fast path; zero-initialise the struct to stay on the
+     * upload path. */
+    int32_t device_slot_plus1;
 } orbfe_frame_view;
 
 /* what Frame::isInFrustum (src/Frame.cc:270-326) leaves in a MapPoint for SearchLocalPoints */

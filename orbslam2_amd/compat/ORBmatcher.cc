@@ -54,7 +54,7 @@ const orbfe_keypoint *keys_of(const std::vector<cv::KeyPoint> &v) { return reint
 // what the matchers read from a Frame (include/Frame.h:131-185)
 orbfe_frame_view view_of(const Frame &F)
 {
-    orbfe_frame_view v;
+    orbfe_frame_view v = orbfe_frame_view(); // upload path; see device_view_of() for the resident one
     v.n = F.N;
     v.keys_un = keys_of(F.mvKeysUn);
     v.u_right = F.mvuRight.empty() ? nullptr : F.mvuRight.data();
@@ -63,10 +63,20 @@ orbfe_frame_view view_of(const Frame &F)
     return v;
 }
 
+// The frame every Tracking matcher searches IN is the current one, i.e. the latest extraction of its extractor: if F is that
+// frame (ORBextractor::IsResidentFrame: same count, same leading descriptors) the matchers read it where the extraction left
+// it in HBM and build its grid once; any other frame takes the upload path.
+orbfe_frame_view device_view_of(const Frame &F)
+{
+    orbfe_frame_view v = view_of(F);
+    if (F.mpORBextractorLeft && F.mpORBextractorLeft->IsResidentFrame(F.N, F.mDescriptors.ptr<uchar>(0))) v.device_slot_plus1 = 1;
+    return v;
+}
+
 // ... and from a KeyFrame (include/KeyFrame.h:160-199; the bounds are ints there)
 orbfe_frame_view view_of(const KeyFrame *pKF)
 {
-    orbfe_frame_view v;
+    orbfe_frame_view v = orbfe_frame_view();
     v.n = pKF->N;
     v.keys_un = keys_of(pKF->mvKeysUn);
     v.u_right = pKF->mvuRight.empty() ? nullptr : pKF->mvuRight.data();
@@ -202,7 +212,7 @@ int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMa
     }
     std::vector<uint8_t> has_obs(F.N > 0 ? F.N : 1, 0); // :85-87
     for (int k = 0; k < F.N; k++) has_obs[k] = F.mvpMapPoints[k] && F.mvpMapPoints[k]->Observations() > 0;
-    const orbfe_frame_view v = view_of(F);
+    const orbfe_frame_view v = device_view_of(F);
     std::vector<int32_t> match(F.N > 0 ? F.N : 1, -1);
     int nmatches = 0;
     check(ctx, orbfe_search_by_projection_points(ctx, &v, (int)n, pts.data(), desc.data(), obs.data(), has_obs.data(), th, mfNNratio, match.data(), &nmatches));
@@ -230,7 +240,7 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
     float Tc[12], Tl[12];
     pose_3x4(CurrentFrame.mTcw, Tc);
     pose_3x4(LastFrame.mTcw, Tl);
-    const orbfe_frame_view v = view_of(CurrentFrame);
+    const orbfe_frame_view v = device_view_of(CurrentFrame);
     std::vector<int32_t> match(CurrentFrame.N > 0 ? CurrentFrame.N : 1, -1);
     int nmatches = 0;
     check(ctx, orbfe_search_by_projection_last(ctx, &v, Tc, Tl, nl, last.pos.data(), last.desc.data(), last.valid.data(), last.obs.data(),
@@ -259,7 +269,7 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std
     for (int k = 0; k < CurrentFrame.N; k++) has_pt[k] = CurrentFrame.mvpMapPoints[k] != NULL;
     float Tc[12];
     pose_3x4(CurrentFrame.mTcw, Tc);
-    const orbfe_frame_view v = view_of(CurrentFrame);
+    const orbfe_frame_view v = device_view_of(CurrentFrame);
     std::vector<int32_t> match(CurrentFrame.N > 0 ? CurrentFrame.N : 1, -1);
     int nmatches = 0;
     check(ctx, orbfe_search_by_projection_kf(ctx, &v, Tc, (int)n, kf.pos.data(), kf.desc.data(), kf.valid.data(), angle.data(), kf.maxd.data(),
@@ -346,7 +356,7 @@ int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Po
     orbfe_context *ctx = context_of(F2);
     vnMatches12 = std::vector<int>(F1.mvKeysUn.size(), -1); // :403
     if (vbPrevMatched.size() < F1.mvKeysUn.size()) throw std::invalid_argument("SearchForInitialization: vbPrevMatched is shorter than F1.mvKeysUn");
-    const orbfe_frame_view v1 = view_of(F1), v2 = view_of(F2);
+    const orbfe_frame_view v1 = view_of(F1), v2 = device_view_of(F2);
     std::vector<int32_t> m12(F1.mvKeysUn.size() ? F1.mvKeysUn.size() : 1, -1);
     int nmatches = 0;
     check(ctx, orbfe_search_for_initialization(ctx, &v1, &v2, reinterpret_cast<float *>(vbPrevMatched.data()), windowSize, mfNNratio,

@@ -40,6 +40,7 @@ struct orbfe_context {
     size_t d_und_bytes = 0;
     size_t d_ham_bytes = 0;
     int last_images = 0;
+    unsigned epoch = 0;       // extraction calls enqueued so far (device-resident frame caches key on it)
     bool use_octree2 = false; // point-parallel quadtree (all levels have <= 4 roots and the LDS budget fits)
     bool use_octree3 = false; // bucket-pyramid quadtree (orbfe_octree3.hip); preferred when its limits hold
     size_t ot3_lds = 0;
@@ -101,6 +102,14 @@ int orbfe_ctx_device(const orbfe_context *ctx) { return ctx->params.device; }
 const orbfe_params *orbfe_ctx_params(const orbfe_context *ctx) { return &ctx->params; }
 const float *orbfe_ctx_scale_factors(const orbfe_context *ctx) { return ctx->scale; }
 const float *orbfe_ctx_inv_sigma2(const orbfe_context *ctx) { return ctx->inv_sigma2; }
+const DeviceConfig *orbfe_ctx_config(const orbfe_context *ctx) { return &ctx->cfg; }
+const DeviceBuffers *orbfe_ctx_buffers(const orbfe_context *ctx) { return &ctx->buf; }
+unsigned orbfe_ctx_epoch(const orbfe_context *ctx) { return ctx->epoch; }
+int orbfe_ctx_wait_foreign_stream(orbfe_context *ctx)
+{
+    if (ctx->prof_stream && ctx->prof_stream != ctx->stream) (void)hipStreamSynchronize(ctx->prof_stream); // caller-owned: may be gone
+    return ORBFE_OK;
+}
 orbfe_pose_state *orbfe_ctx_pose_state(orbfe_context *ctx)
 {
     if (!ctx->pose) ctx->pose = orbfe_pose_state_create();
@@ -767,6 +776,7 @@ static int enqueue_batch(orbfe_context *ctx, const uint8_t *d_images, int n_unit
     }
     HIP_TRY(ctx, hipGetLastError());
     ctx->last_images = n_images;
+    ctx->epoch++;
     ctx->prof_groups = G;
     ctx->prof_stream = s;
     if (ctx->profiling) ctx->prof_calls++;

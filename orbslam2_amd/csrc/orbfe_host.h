@@ -32,6 +32,13 @@ hipStream_t orbfe_ctx_stream(orbfe_context *ctx);
 int orbfe_ctx_device(const orbfe_context *ctx);
 const orbfe_params *orbfe_ctx_params(const orbfe_context *ctx);
 const float *orbfe_ctx_scale_factors(const orbfe_context *ctx);
+// device-resident frames of the latest extraction call (orbfe_match.hip, orbfe_bow.hip)
+struct DeviceConfig;
+struct DeviceBuffers;
+const DeviceConfig *orbfe_ctx_config(const orbfe_context *ctx);
+const DeviceBuffers *orbfe_ctx_buffers(const orbfe_context *ctx);
+unsigned orbfe_ctx_epoch(const orbfe_context *ctx);          // counts the extraction calls enqueued on this context
+int orbfe_ctx_wait_foreign_stream(orbfe_context *ctx);      // waits for the latest extraction if it ran on a caller's stream
 
 struct orbfe_bow_state;
 orbfe_bow_state *orbfe_bow_state_create();

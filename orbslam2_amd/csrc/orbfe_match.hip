@@ -14,6 +14,7 @@
 #include "../../include/orbfe.h"
 #include "orbfe_device.h"
 #include "orbfe_host.h"
+#include "orbfe_match_resolve.h"
 
 #include <algorithm>
 #include <climits>
@@ -24,16 +25,13 @@
 
 #define GRID_COLS 64 // FRAME_GRID_COLS include/Frame.h:36
 #define GRID_ROWS 48 // FRAME_GRID_ROWS include/Frame.h:37
-#define HISTO_LENGTH 30
-#define TH_LOW 50
-#define TH_HIGH 100
+using orbfe_resolve::HISTO_LENGTH;
+using orbfe_resolve::TH_HIGH;
+using orbfe_resolve::TH_LOW;
+#define MATCH_TOPK 4       // orbfe_resolve::TOPK
+#define MATCH_TOPK_LDS 256 // candidates per query the top-K selection stages in LDS; longer lists fall back to the full list
 
-struct MatchQuery { // 32 bytes
-    float u, v, r;
-    int min_level, max_level;
-    float ur, ur_rad; // right-image check (mvuRight), used when flags & 2
-    int flags;        // bit0: valid query, bit1: apply the u_right check
-};
+using orbfe_resolve::MatchQuery;
 
 struct MatchFrame {
     const KeyPointPOD *keys; // mvKeysUn
@@ -119,10 +117,15 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane)
 }
 
 // One wave per query: Frame::GetFeaturesInArea + DescriptorDistance of every hit.
+// With topk != null the wave also selects the MATCH_TOPK smallest keys that pass the call's STATIC filters (blocked0[idx] == 0;
+// gate_drop: dist < 256) and reports how many passed: the host replays the greedy rules on that prefix (orbfe_match_resolve.h).
 __global__ __launch_bounds__(256) void window_candidates_kernel(MatchFrame f, const MatchQuery *__restrict__ q, const uint8_t *__restrict__ qdesc,
                                                                 int nq, int *__restrict__ q_off, int *__restrict__ q_cnt,
-                                                                unsigned long long *__restrict__ list, int *__restrict__ cursor, int list_cap)
+                                                                unsigned long long *__restrict__ list, int *__restrict__ cursor, int list_cap,
+                                                                unsigned long long *__restrict__ topk, int *__restrict__ n_static,
+                                                                const uint8_t *__restrict__ blocked0, int gate_drop)
 {
+    __shared__ unsigned long long s_keys[4][MATCH_TOPK_LDS];
     const int iq = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (iq >= nq) return;
@@ -162,8 +165,16 @@ __global__ __launch_bounds__(256) void window_candidates_kernel(MatchFrame f, co
         q_cnt[iq] = (base + total <= list_cap) ? total : -total; // negative: list capacity exceeded
     }
     base = __shfl(base, 0, 64);
+    if (topk && (total == 0 || base + total > list_cap)) { // nothing (or nothing usable): an empty prefix, the host re-runs on overflow
+        if (lane < MATCH_TOPK) topk[(size_t)iq * MATCH_TOPK + lane] = ~0ull;
+        if (lane == 0) n_static[iq] = 0;
+    }
     if (total == 0 || base + total > list_cap) return;
-    int pos = base + wave_excl_scan(mine, lane);
+    const int rel0 = wave_excl_scan(mine, lane);
+    int pos = base + rel0;
+    unsigned long long *sk = s_keys[threadIdx.x >> 6];
+    const bool stage = topk && total <= MATCH_TOPK_LDS;
+    int rel = rel0;
     uint32_t qd[8];
     {
         const uint32_t *p = (const uint32_t *)(qdesc + (size_t)iq * 32);
@@ -184,25 +195,65 @@ __global__ __launch_bounds__(256) void window_candidates_kernel(MatchFrame f, co
             for (int k = 0; k < 8; k++) dist += __popc(qd[k] ^ p[k]);
             // the mvuRight gate (src/ORBmatcher.cc:93-98,1403-1409) is a pure function of the pair: mark it
             if ((Q.flags & 2) && f.u_right && f.u_right[idx] > 0 && fabsf(__fsub_rn(Q.ur, f.u_right[idx])) > Q.ur_rad) dist = 511;
-            list[pos++] = ((unsigned long long)dist << 36) | ((unsigned long long)ix << 30) | ((unsigned long long)iy << 24) |
-                          ((unsigned long long)idx << 8) | (unsigned long long)(kp.octave & 255);
+            const unsigned long long key = ((unsigned long long)dist << 36) | ((unsigned long long)ix << 30) | ((unsigned long long)iy << 24) |
+                                           ((unsigned long long)idx << 8) | (unsigned long long)(kp.octave & 255);
+            list[pos++] = key;
+            if (stage) sk[rel++] = ((gate_drop && dist >= 256) || (blocked0 && blocked0[idx])) ? ~0ull : key; // static filters
         }
     }
+    if (!topk) return;
+    if (!stage) { // too long for the LDS stage: the host takes this query from the full list
+        if (lane < MATCH_TOPK) topk[(size_t)iq * MATCH_TOPK + lane] = ~0ull;
+        if (lane == 0) n_static[iq] = INT_MAX;
+        return;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // each lane owns keys lane, lane + 64, ...; MATCH_TOPK rounds of (lane minimum, wave minimum, owner retires its key)
+    unsigned long long mykeys[MATCH_TOPK_LDS / 64];
+    int passed = 0;
+#pragma unroll
+    for (int j = 0; j < MATCH_TOPK_LDS / 64; j++) {
+        mykeys[j] = (lane + 64 * j < total) ? sk[lane + 64 * j] : ~0ull;
+        passed += mykeys[j] != ~0ull;
+    }
+    passed = wave_sum(passed);
+    for (int r = 0; r < MATCH_TOPK; r++) {
+        unsigned long long m = mykeys[0];
+#pragma unroll
+        for (int j = 1; j < MATCH_TOPK_LDS / 64; j++) m = mykeys[j] < m ? mykeys[j] : m;
+        unsigned long long w = m;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)w, o, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(w >> 32), o, 64);
+            const unsigned long long t = ((unsigned long long)hi << 32) | lo;
+            w = t < w ? t : w;
+        }
+        if (lane == 0) topk[(size_t)iq * MATCH_TOPK + r] = w;
+        if (w != ~0ull) { // keys are unique within a query (they carry the keypoint index): exactly one lane retires it
+#pragma unroll
+            for (int j = 0; j < MATCH_TOPK_LDS / 64; j++)
+                if (mykeys[j] == w) mykeys[j] = ~0ull;
+        }
+    }
+    if (lane == 0) n_static[iq] = passed;
 }
 
 // ---------------------------------------------------------------------------------------------
 // host: device session for one frame + candidate query
 // ---------------------------------------------------------------------------------------------
-namespace {
-
-} // namespace
-
 struct orbfe_match_state {
-    DevBuf in_blk, out_blk, cells, cell_of, list; // inputs of a call in one block (one pinned copy up), [cursor | qoff | qcnt] in another
-    uint8_t *h_in = nullptr, *h_out = nullptr;     // pinned images of in_blk / out_blk
+    DevBuf in_blk, out_blk, cells, cell_of, list, keys_un; // inputs of a call in one block (one pinned copy up), results in another
+    uint8_t *h_in = nullptr, *h_out = nullptr;               // pinned images of in_blk / out_blk
     size_t h_in_bytes = 0, h_out_bytes = 0;
-    std::vector<int> h_off, h_cnt;
-    std::vector<unsigned long long> h_list;
+    std::vector<int> h_off, h_cnt, h_nstatic;
+    std::vector<unsigned long long> h_list, h_topk;
+    bool list_on_host = false; // h_list holds the device list of the latest query
+    int list_total = 0;
+    // grid of a device-resident frame (image slot of the latest extraction call): built once per frame
+    unsigned grid_epoch = 0;
+    int grid_slot = -1, grid_n = -1;
+    float grid_bounds[4] = {0, 0, 0, 0};
     ~orbfe_match_state() { if (h_in) (void)hipHostFree(h_in); if (h_out) (void)hipHostFree(h_out); }
 };
 
@@ -210,56 +261,109 @@ static orbfe_match_state *match_state(orbfe_context *ctx) { return orbfe_ctx_mat
 
 #define MTRY(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return orbfe_fail(ctx, ORBFE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
-// Uploads the frame, builds its grid on the device, runs the window query for `nq` queries and leaves the
-// per-query candidate keys in st->h_list / h_off / h_cnt.
+static int ensure_pinned(orbfe_context *ctx, uint8_t *&h, size_t &have, size_t need)
+{
+    if (have >= need) return ORBFE_OK;
+    if (h) (void)hipHostFree(h);
+    h = nullptr; have = 0;
+    MTRY(ctx, hipHostMalloc((void **)&h, need, hipHostMallocDefault));
+    have = need;
+    return ORBFE_OK;
+}
+
+// Static filters of a Tracking matcher call, applied on the device before the top-K selection (orbfe_match_resolve.h)
+struct TopkRequest {
+    const uint8_t *blocked0 = nullptr; // [frame n] keypoints blocked before the call, or null
+    bool gate_drop = false;            // drop keys that failed the mvuRight gate (dist marked 511)
+};
+
+// Runs the window query for `nq` queries against the frame and leaves the per-query results on the host:
+//   topk == null : every candidate key (st->h_list / h_off / h_cnt), as the keyframe-side matchers want them;
+//   topk != null : the MATCH_TOPK best statically admissible keys per query (st->h_topk / h_nstatic); the full list stays in
+//                  HBM and is fetched by fetch_full_list() only if a replay runs out of its prefix.
+// Frame source: fv->device_slot_plus1 == 0: the host arrays of the view are uploaded and bucketed (any frame, any keyframe);
+// > 0: image slot (value - 1) of the LATEST extraction call of this context -- keypoints and descriptors are read where the
+// extraction left them in HBM, the grid is built once per frame and reused by every later call on that frame.
 static int run_window_queries(orbfe_context *ctx, const orbfe_frame_view *fv, const std::vector<MatchQuery> &queries,
-                              const std::vector<uint8_t> &qdesc)
+                              const std::vector<uint8_t> &qdesc, const TopkRequest *topk = nullptr)
 {
     orbfe_match_state *st = match_state(ctx);
     hipStream_t s = orbfe_ctx_stream(ctx);
     const int n = fv->n, nq = (int)queries.size();
     st->h_off.assign(nq, 0); st->h_cnt.assign(nq, 0); st->h_list.clear();
+    st->h_topk.assign((size_t)nq * MATCH_TOPK, ~0ull); st->h_nstatic.assign(nq, 0);
+    st->list_on_host = true; st->list_total = 0;
     if (n <= 0 || nq == 0) return ORBFE_OK;
     if (n > 65535) return orbfe_fail(ctx, ORBFE_ERR_UNSUPPORTED, "frames with more than 65535 keypoints are not supported by the matchers");
     MTRY(ctx, hipSetDevice(orbfe_ctx_device(ctx)));
     const size_t ncell = GRID_COLS * GRID_ROWS;
+    const bool resident = fv->device_slot_plus1 > 0;
+    const int slot = fv->device_slot_plus1 - 1;
+    const DeviceConfig *cfg = orbfe_ctx_config(ctx);
+    const DeviceBuffers *buf = orbfe_ctx_buffers(ctx);
+    if (resident) {
+        if (slot >= orbfe_ctx_params(ctx)->max_images) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "device slot %d out of range", slot);
+        int rc = orbfe_ctx_wait_foreign_stream(ctx); // the extraction may have been enqueued on a caller stream
+        if (rc != ORBFE_OK) return rc;
+        if (n > cfg->sel_total) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "frame view holds %d keypoints, a device slot at most %d", n, cfg->sel_total);
+    }
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
-    const size_t i_keys = 0, i_desc = up16(i_keys + sizeof(KeyPointPOD) * n), i_ur = up16(i_desc + (size_t)32 * n);
-    const size_t i_q = up16(i_ur + sizeof(float) * n), i_qd = up16(i_q + sizeof(MatchQuery) * nq), in_bytes = up16(i_qd + (size_t)32 * nq);
-    const size_t o_cur = 0, o_off = 16, o_cnt = up16(o_off + sizeof(int) * nq), out_bytes = up16(o_cnt + sizeof(int) * nq);
-    if (st->in_blk.ensure(in_bytes) || st->out_blk.ensure(out_bytes) || st->cells.ensure(sizeof(int) * (2 * ncell + 2 + n)) ||
-        st->cell_of.ensure(sizeof(int) * n))
+    const size_t fn = resident ? 0 : (size_t)n; // frame rows in the upload block
+    const size_t i_keys = 0, i_desc = up16(i_keys + sizeof(KeyPointPOD) * fn), i_ur = up16(i_desc + (size_t)32 * fn);
+    const size_t i_q = up16(i_ur + (fv->u_right ? sizeof(float) * (size_t)n : 0)), i_qd = up16(i_q + sizeof(MatchQuery) * nq), i_blk = up16(i_qd + (size_t)32 * nq);
+    const size_t in_bytes = up16(i_blk + (topk && topk->blocked0 ? (size_t)n : 0));
+    const size_t o_cur = 0, o_off = 16, o_cnt = up16(o_off + sizeof(int) * nq), o_ns = up16(o_cnt + sizeof(int) * nq);
+    const size_t o_tk = up16(o_ns + sizeof(int) * nq), out_bytes = up16(o_tk + sizeof(unsigned long long) * MATCH_TOPK * nq);
+    if (st->in_blk.ensure(in_bytes) || st->out_blk.ensure(out_bytes) || st->cells.ensure(sizeof(int) * (2 * ncell + 2 + cfg->sel_total + n)) ||
+        st->cell_of.ensure(sizeof(int) * (size_t)(n > cfg->sel_total ? n : cfg->sel_total)))
         return orbfe_fail(ctx, ORBFE_ERR_HIP, "matcher scratch allocation failed");
-    if (st->h_in_bytes < in_bytes) {
-        if (st->h_in) (void)hipHostFree(st->h_in);
-        st->h_in = nullptr; st->h_in_bytes = 0;
-        MTRY(ctx, hipHostMalloc((void **)&st->h_in, in_bytes, hipHostMallocDefault));
-        st->h_in_bytes = in_bytes;
-    }
-    if (st->h_out_bytes < out_bytes) {
-        if (st->h_out) (void)hipHostFree(st->h_out);
-        st->h_out = nullptr; st->h_out_bytes = 0;
-        MTRY(ctx, hipHostMalloc((void **)&st->h_out, out_bytes, hipHostMallocDefault));
-        st->h_out_bytes = out_bytes;
-    }
+    int rc = ensure_pinned(ctx, st->h_in, st->h_in_bytes, in_bytes);
+    if (rc != ORBFE_OK) return rc;
+    rc = ensure_pinned(ctx, st->h_out, st->h_out_bytes, out_bytes);
+    if (rc != ORBFE_OK) return rc;
     uint8_t *din = (uint8_t *)st->in_blk.p, *dout = (uint8_t *)st->out_blk.p;
     MatchFrame f;
-    f.keys = (const KeyPointPOD *)(din + i_keys); f.desc = din + i_desc;
-    f.u_right = fv->u_right ? (const float *)(din + i_ur) : nullptr;
     f.n = n; f.min_x = fv->min_x; f.min_y = fv->min_y;
     f.inv_w = (float)GRID_COLS / (fv->max_x - fv->min_x); // mfGridElementWidthInv, src/Frame.cc:99
     f.inv_h = (float)GRID_ROWS / (fv->max_y - fv->min_y);
     f.cell_cnt = (int *)st->cells.p; f.cell_off = f.cell_cnt + ncell; f.cell_idx = f.cell_off + ncell + 1;
-    memcpy(st->h_in + i_keys, fv->keys_un, sizeof(KeyPointPOD) * n);
-    memcpy(st->h_in + i_desc, fv->descriptors, (size_t)32 * n);
+    bool build_grid = true;
+    if (resident) {
+        const size_t so = (size_t)slot * cfg->sel_total;
+        const KeyPointPOD *raw = (const KeyPointPOD *)buf->kps + so;
+        const bool distorted = cfg->n_dist > 0 && cfg->dist[0] != 0.0f;
+        const unsigned epoch = orbfe_ctx_epoch(ctx);
+        build_grid = !(st->grid_epoch == epoch && st->grid_slot == slot && st->grid_n == n && st->grid_bounds[0] == fv->min_x &&
+                       st->grid_bounds[1] == fv->max_x && st->grid_bounds[2] == fv->min_y && st->grid_bounds[3] == fv->max_y);
+        if (distorted) { // mvKeysUn: undistorted on the device once per frame (Frame::UndistortKeyPoints)
+            if (st->keys_un.ensure(sizeof(KeyPointPOD) * (size_t)cfg->sel_total)) return orbfe_fail(ctx, ORBFE_ERR_HIP, "matcher scratch allocation failed");
+            if (build_grid) orbfe_launch_undistort(*cfg, raw, st->keys_un.p, n, s);
+            f.keys = (const KeyPointPOD *)st->keys_un.p;
+        } else f.keys = raw;
+        f.desc = buf->desc + so * 32;
+        // mvuRight travels with the call (n floats): Frame::ComputeStereoMatches may have run on the host in an integration
+        // that keeps the reference's Frame.cc, and then the device copy of this slot is not the frame's mvuRight
+        f.u_right = fv->u_right ? (const float *)(din + i_ur) : nullptr;
+        st->grid_epoch = epoch; st->grid_slot = slot; st->grid_n = n;
+        st->grid_bounds[0] = fv->min_x; st->grid_bounds[1] = fv->max_x; st->grid_bounds[2] = fv->min_y; st->grid_bounds[3] = fv->max_y;
+    } else {
+        f.keys = (const KeyPointPOD *)(din + i_keys); f.desc = din + i_desc;
+        f.u_right = fv->u_right ? (const float *)(din + i_ur) : nullptr;
+        memcpy(st->h_in + i_keys, fv->keys_un, sizeof(KeyPointPOD) * n);
+        memcpy(st->h_in + i_desc, fv->descriptors, (size_t)32 * n);
+        st->grid_slot = -1; // the grid buffers now describe a host frame
+    }
     if (fv->u_right) memcpy(st->h_in + i_ur, fv->u_right, sizeof(float) * n);
     memcpy(st->h_in + i_q, queries.data(), sizeof(MatchQuery) * nq);
     memcpy(st->h_in + i_qd, qdesc.data(), (size_t)32 * nq);
+    if (topk && topk->blocked0) memcpy(st->h_in + i_blk, topk->blocked0, (size_t)n);
     MTRY(ctx, hipMemcpyAsync(din, st->h_in, in_bytes, hipMemcpyHostToDevice, s));
-    MTRY(ctx, hipMemsetAsync(f.cell_cnt, 0, sizeof(int) * ncell, s));
-    hipLaunchKernelGGL(grid_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, f, (int *)st->cell_of.p);
-    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, s, f);
-    hipLaunchKernelGGL(grid_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, s, f, (const int *)st->cell_of.p);
+    if (build_grid) {
+        MTRY(ctx, hipMemsetAsync(f.cell_cnt, 0, sizeof(int) * ncell, s));
+        hipLaunchKernelGGL(grid_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, f, (int *)st->cell_of.p);
+        hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, s, f);
+        hipLaunchKernelGGL(grid_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, s, f, (const int *)st->cell_of.p);
+    }
     // candidate list capacity: grown and the query re-run if a frame overflows it
     size_t cap = st->list.bytes / 8;
     if (cap < (size_t)nq * 64) cap = (size_t)nq * 64;
@@ -268,15 +372,24 @@ static int run_window_queries(orbfe_context *ctx, const orbfe_frame_view *fv, co
         MTRY(ctx, hipMemsetAsync(dout + o_cur, 0, sizeof(int), s));
         hipLaunchKernelGGL(window_candidates_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, f, (const MatchQuery *)(din + i_q),
                            (const uint8_t *)(din + i_qd), nq, (int *)(dout + o_off), (int *)(dout + o_cnt),
-                           (unsigned long long *)st->list.p, (int *)(dout + o_cur), (int)std::min<size_t>(cap, INT_MAX));
-        MTRY(ctx, hipMemcpyAsync(st->h_out, dout, out_bytes, hipMemcpyDeviceToHost, s));
+                           (unsigned long long *)st->list.p, (int *)(dout + o_cur), (int)std::min<size_t>(cap, INT_MAX),
+                           topk ? (unsigned long long *)(dout + o_tk) : nullptr, (int *)(dout + o_ns),
+                           topk && topk->blocked0 ? (const uint8_t *)(din + i_blk) : nullptr, topk && topk->gate_drop ? 1 : 0);
+        MTRY(ctx, hipMemcpyAsync(st->h_out, dout, topk ? out_bytes : o_ns, hipMemcpyDeviceToHost, s));
         MTRY(ctx, hipStreamSynchronize(s));
         MTRY(ctx, hipGetLastError());
         const int total = *(const int *)(st->h_out + o_cur);
         if ((size_t)total <= cap) {
-            st->h_list.resize(total);
             memcpy(st->h_off.data(), st->h_out + o_off, sizeof(int) * nq);
             memcpy(st->h_cnt.data(), st->h_out + o_cnt, sizeof(int) * nq);
+            st->list_total = total;
+            if (topk) {
+                memcpy(st->h_nstatic.data(), st->h_out + o_ns, sizeof(int) * nq);
+                memcpy(st->h_topk.data(), st->h_out + o_tk, sizeof(unsigned long long) * MATCH_TOPK * nq);
+                st->list_on_host = total == 0;
+                return ORBFE_OK;
+            }
+            st->h_list.resize(total);
             if (total > 0) MTRY(ctx, hipMemcpy(st->h_list.data(), st->list.p, sizeof(unsigned long long) * total, hipMemcpyDeviceToHost));
             return ORBFE_OK;
         }
@@ -285,87 +398,56 @@ static int run_window_queries(orbfe_context *ctx, const orbfe_frame_view *fv, co
     return orbfe_fail(ctx, ORBFE_ERR_CAPACITY, "candidate list overflow");
 }
 
-static inline int key_dist(unsigned long long k) { return (int)(k >> 36); }
-static inline int key_idx(unsigned long long k) { return (int)((k >> 8) & 0xffffu); }
-static inline int key_level(unsigned long long k) { return (int)(k & 0xffu); }
-
-// ---------------------------------------------------------------------------------------------
-// host arithmetic shared by the projection matchers (reference evaluation order, no contraction)
-// ---------------------------------------------------------------------------------------------
-// OPENCV-4.5.5-SEMANTICS: cv::Mat R*x+t for 3x3 * 3x1 CV_32F (small-matrix gemm path)
-static void rt_apply(const float *T, const float *x, float *out)
+// CandidateSource::full of the top-K replays: the device list of the latest query, downloaded once on first use
+struct FullListCtx { orbfe_context *ctx; orbfe_match_state *st; };
+static int fetch_full_list(void *user, int q, std::vector<orbfe_resolve::ckey_t> &out)
 {
-    for (int i = 0; i < 3; i++) {
-        const float t = (T[4 * i] * x[0] + T[4 * i + 1] * x[1]) + T[4 * i + 2] * x[2];
-        out[i] = t + T[4 * i + 3];
+    FullListCtx *c = (FullListCtx *)user;
+    orbfe_match_state *st = c->st;
+    if (!st->list_on_host) {
+        st->h_list.resize(st->list_total);
+        if (st->list_total > 0 &&
+            hipMemcpy(st->h_list.data(), st->list.p, sizeof(unsigned long long) * st->list_total, hipMemcpyDeviceToHost) != hipSuccess)
+            return -1;
+        st->list_on_host = true;
     }
+    out.assign(st->h_list.begin() + st->h_off[q], st->h_list.begin() + st->h_off[q] + st->h_cnt[q]);
+    return 0;
 }
-static void camera_center(const float *T, float *ow) // -Rcw.t()*tcw
+
+static orbfe_resolve::CandidateSource topk_source(orbfe_match_state *st, FullListCtx *fl, const TopkRequest &req)
 {
-    for (int i = 0; i < 3; i++) ow[i] = ((-T[i]) * T[3] + (-T[4 + i]) * T[7]) + (-T[8 + i]) * T[11];
+    orbfe_resolve::CandidateSource src;
+    src.topk = st->h_topk.data();
+    src.n_static = st->h_nstatic.data();
+    src.blocked0 = req.blocked0;
+    src.drop_gated = req.gate_drop;
+    src.user = fl;
+    src.full = fetch_full_list;
+    return src;
 }
-// deterministic log for MapPoint::PredictScale (contract Q4)
-static float log_det(float xf)
-{
-    double x = (double)xf;
-    int e;
-    double m = frexp(x, &e);
-    if (m < 0.70710678118654752440) { m *= 2.0; e -= 1; }
-    const double s = (m - 1.0) / (m + 1.0);
-    const double z = s * s;
-    double p = 1.0 / 27.0;
-    for (int k = 25; k >= 3; k -= 2) p = p * z + 1.0 / (double)k;
-    p = p * z + 1.0;
-    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
-    return (float)((double)e * LN2_HI + (2.0 * s * p + (double)e * LN2_LO));
-}
-static int predict_scale(float max_distance, float current_dist, float log_sf, int n_levels) // src/MapPoint.cc:402-417
-{
-    const float ratio = max_distance / current_dist;
-    int n_scale = (int)ceilf(log_det(ratio) / log_sf);
-    if (n_scale < 0) n_scale = 0;
-    else if (n_scale >= n_levels) n_scale = n_levels - 1;
-    return n_scale;
-}
-static int rot_bin(float a1, float a2) // Q8: 30 slots, bin = round(rot / 30)
-{
-    const float factor = 1.0f / HISTO_LENGTH;
-    float rot = a1 - a2;
-    if (rot < 0.0) rot += 360.0f;
-    int bin = (int)roundf(rot * factor);
-    if (bin == HISTO_LENGTH) bin = 0;
-    return bin;
-}
+
+using orbfe_resolve::key_dist;
+using orbfe_resolve::key_idx;
+using orbfe_resolve::key_level;
+
+using orbfe_resolve::camera_center;
+using orbfe_resolve::predict_scale;
+using orbfe_resolve::rt_apply;
+using orbfe_resolve::RotHist;
+using orbfe_resolve::rot_bin;
 
 extern "C" int orbfe_three_maxima(const int32_t *histo_sizes, int L, int *ind1, int *ind2, int *ind3)
 {
     if (!histo_sizes || !ind1 || !ind2 || !ind3 || L < 0) return ORBFE_ERR_INVALID;
-    int max1 = 0, max2 = 0, max3 = 0; // ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1597-1638
-    *ind1 = *ind2 = *ind3 = -1;
-    for (int i = 0; i < L; i++) {
-        const int s = histo_sizes[i];
-        if (s > max1) { max3 = max2; max2 = max1; max1 = s; *ind3 = *ind2; *ind2 = *ind1; *ind1 = i; }
-        else if (s > max2) { max3 = max2; max2 = s; *ind3 = *ind2; *ind2 = i; }
-        else if (s > max3) { max3 = s; *ind3 = i; }
-    }
-    if ((float)max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
-    else if ((float)max3 < 0.1f * (float)max1) { *ind3 = -1; }
+    orbfe_resolve::three_maxima(histo_sizes, L, ind1, ind2, ind3); // ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1597-1638
     return ORBFE_OK;
 }
 
-struct RotHist {
-    std::vector<int> v[HISTO_LENGTH];
-    void three(int &i1, int &i2, int &i3) const
-    {
-        int32_t sizes[HISTO_LENGTH];
-        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int32_t)v[i].size();
-        orbfe_three_maxima(sizes, HISTO_LENGTH, &i1, &i2, &i3);
-    }
-};
-
 static int check_view(orbfe_context *ctx, const orbfe_frame_view *fv)
 {
-    if (!ctx || !fv || fv->n < 0 || (fv->n > 0 && (!fv->keys_un || !fv->descriptors)) || !(fv->max_x > fv->min_x) || !(fv->max_y > fv->min_y))
+    if (!ctx || !fv || fv->n < 0 || (fv->n > 0 && (!fv->keys_un || (!fv->descriptors && fv->device_slot_plus1 <= 0))) || fv->device_slot_plus1 < 0 ||
+        !(fv->max_x > fv->min_x) || !(fv->max_y > fv->min_y))
         return orbfe_fail(ctx, ORBFE_ERR_INVALID, "bad frame view");
     return ORBFE_OK;
 }
@@ -436,67 +518,25 @@ extern "C" int orbfe_search_by_projection_last(orbfe_context *ctx, const orbfe_f
         (n_last > 0 && (!last_pos || !last_desc || !last_valid || !last_obs || !last_octave || !last_angle)))
         return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
     const orbfe_params *P = orbfe_ctx_params(ctx);
-    const float *sf = orbfe_ctx_scale_factors(ctx);
-    const float mb = P->fx != 0.f ? P->bf / P->fx : 0.f;
     const int N = cur->n;
-    float twc[3], tlc[3];
-    camera_center(Tcw_cur, twc);
-    rt_apply(Tcw_last, twc, tlc);
-    const bool forward = tlc[2] > mb && !mono, backward = -tlc[2] > mb && !mono;
-    std::vector<MatchQuery> q(n_last);
-    std::vector<uint8_t> qd((size_t)32 * (n_last > 0 ? n_last : 1));
-    for (int i = 0; i < n_last; i++) {
-        MatchQuery &Q = q[i];
-        Q = MatchQuery{0, 0, 0, 0, -1, 0, 0, 0};
-        if (!last_valid[i]) continue;
-        if (last_octave[i] < 0 || last_octave[i] >= P->nlevels) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "octave out of range");
-        float xc[3];
-        rt_apply(Tcw_cur, last_pos + 3 * i, xc);
-        const float invzc = (float)(1.0 / (double)xc[2]);
-        if (invzc < 0) continue;
-        const float u = P->fx * xc[0] * invzc + P->cx;
-        const float v = P->fy * xc[1] * invzc + P->cy;
-        if (u < cur->min_x || u > cur->max_x) continue;
-        if (v < cur->min_y || v > cur->max_y) continue;
-        const int oct = last_octave[i];
-        const float radius = th * sf[oct];
-        Q.u = u; Q.v = v; Q.r = radius; Q.flags = 1 | 2;
-        Q.ur = u - P->bf * invzc; Q.ur_rad = radius;
-        if (forward) { Q.min_level = oct; Q.max_level = -1; }
-        else if (backward) { Q.min_level = 0; Q.max_level = oct; }
-        else { Q.min_level = oct - 1; Q.max_level = oct + 1; }
-        memcpy(&qd[(size_t)32 * i], last_desc + (size_t)32 * i, 32);
-    }
-    rc = run_window_queries(ctx, cur, q, qd);
+    std::vector<MatchQuery> q;
+    std::vector<uint8_t> qd;
+    if (orbfe_resolve::build_queries_last(orbfe_resolve::camera_of(P), orbfe_ctx_scale_factors(ctx), P->nlevels, cur->min_x, cur->max_x, cur->min_y, cur->max_y,
+                                          Tcw_cur, Tcw_last, n_last, last_pos, last_desc, last_valid, last_octave, th, mono, q, qd) != 0)
+        return orbfe_fail(ctx, ORBFE_ERR_INVALID, "octave out of range");
+    std::vector<uint8_t> has_obs(N > 0 ? N : 1, 0);
+    for (int i = 0; i < N; i++) has_obs[i] = cur_has_obs ? (cur_has_obs[i] != 0) : 0;
+    std::vector<uint8_t> blocked0(has_obs); // the static filter is the state BEFORE the replay mutates has_obs
+    TopkRequest req;
+    req.blocked0 = cur_has_obs ? blocked0.data() : nullptr;
+    req.gate_drop = true; // 511 = failed the mvuRight gate
+    rc = run_window_queries(ctx, cur, q, qd, &req);
     if (rc != ORBFE_OK) return rc;
     orbfe_match_state *st = match_state(ctx);
-    std::vector<uint8_t> has_obs(N > 0 ? N : 1, 0);
-    for (int i = 0; i < N; i++) { has_obs[i] = cur_has_obs ? cur_has_obs[i] : 0; cur_match[i] = -1; }
-    RotHist rh;
-    int nm = 0;
-    for (int i = 0; i < n_last; i++) { // sequential greedy resolve
-        unsigned long long best = ~0ull;
-        for (int k = 0; k < st->h_cnt[i]; k++) {
-            const unsigned long long key = st->h_list[st->h_off[i] + k];
-            if (key_dist(key) >= 256 || has_obs[key_idx(key)]) continue; // 511 = failed the mvuRight gate
-            if (key < best) best = key;
-        }
-        if (best != ~0ull && key_dist(best) <= TH_HIGH) {
-            const int bi = key_idx(best);
-            cur_match[bi] = i;
-            has_obs[bi] = last_obs[i] > 0;
-            nm++;
-            if (check_ori) rh.v[rot_bin(last_angle[i], cur->keys_un[bi].angle)].push_back(bi);
-        }
-    }
-    if (check_ori) {
-        int i1, i2, i3;
-        rh.three(i1, i2, i3);
-        for (int b = 0; b < HISTO_LENGTH; b++)
-            if (b != i1 && b != i2 && b != i3)
-                for (int idx : rh.v[b]) { cur_match[idx] = -1; nm--; }
-    }
-    *nmatches = nm;
+    FullListCtx fl{ctx, st};
+    orbfe_resolve::CandidateSource src = topk_source(st, &fl, req);
+    *nmatches = orbfe_resolve::resolve_last(src, n_last, last_obs, last_angle, N, &cur->keys_un[0].angle, sizeof(orbfe_keypoint), has_obs, check_ori, cur_match);
+    if (src.error) return orbfe_fail(ctx, ORBFE_ERR_HIP, "candidate list download failed");
     return ORBFE_OK;
 }
 
@@ -509,31 +549,8 @@ extern "C" int orbfe_is_in_frustum(orbfe_context *ctx, const float *Tcw, float m
         return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
     const orbfe_params *P = orbfe_ctx_params(ctx);
     const float log_sf = logf((float)(double)P->scale_factor); // mfLogScaleFactor = log(mfScaleFactor), src/Frame.cc:71
-    float ow[3];
-    camera_center(Tcw, ow);
-    for (int i = 0; i < n; i++) {
-        orbfe_track_point &o = out[i];
-        o.in_view = 0; o.proj_x = o.proj_y = o.proj_xr = 0.f; o.level = 0; o.view_cos = 0.f;
-        float pc[3];
-        rt_apply(Tcw, pos + 3 * i, pc);
-        if (pc[2] < 0.0f) continue;
-        const float invz = 1.0f / pc[2];
-        const float u = P->fx * pc[0] * invz + P->cx;
-        const float v = P->fy * pc[1] * invz + P->cy;
-        if (u < min_x || u > max_x) continue;
-        if (v < min_y || v > max_y) continue;
-        float po[3];
-        for (int k = 0; k < 3; k++) po[k] = pos[3 * i + k] - ow[k];
-        const float dist = (float)sqrt((double)po[0] * po[0] + (double)po[1] * po[1] + (double)po[2] * po[2]);
-        if (dist < 0.8f * min_distance[i] || dist > 1.2f * max_distance[i]) continue;
-        const double dot = (double)po[0] * normal[3 * i] + (double)po[1] * normal[3 * i + 1] + (double)po[2] * normal[3 * i + 2];
-        const float view_cos = (float)(dot / (double)dist);
-        if (view_cos < viewing_cos_limit) continue;
-        o.in_view = 1;
-        o.proj_x = u; o.proj_xr = u - P->bf * invz; o.proj_y = v;
-        o.level = predict_scale(max_distance[i], dist, log_sf, P->nlevels);
-        o.view_cos = view_cos;
-    }
+    orbfe_resolve::is_in_frustum(orbfe_resolve::camera_of(P), P->nlevels, log_sf, Tcw, min_x, max_x, min_y, max_y, n, pos, normal, max_distance, min_distance,
+                                 viewing_cos_limit, out);
     return ORBFE_OK;
 }
 
@@ -547,49 +564,24 @@ extern "C" int orbfe_search_by_projection_points(orbfe_context *ctx, const orbfe
     if (rc != ORBFE_OK) return rc;
     if (!cur_match || !nmatches || n_pts < 0 || (n_pts > 0 && (!pts || !pt_desc || !pt_obs))) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
     const orbfe_params *P = orbfe_ctx_params(ctx);
-    const float *sf = orbfe_ctx_scale_factors(ctx);
     const int N = cur->n;
-    const bool b_factor = th != 1.0;
-    std::vector<MatchQuery> q(n_pts);
-    std::vector<uint8_t> qd((size_t)32 * (n_pts > 0 ? n_pts : 1));
-    for (int i = 0; i < n_pts; i++) {
-        MatchQuery &Q = q[i];
-        Q = MatchQuery{0, 0, 0, 0, -1, 0, 0, 0};
-        if (!pts[i].in_view) continue;
-        const int lvl = pts[i].level;
-        if (lvl < 0 || lvl >= P->nlevels) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "predicted level out of range");
-        float r = pts[i].view_cos > 0.998 ? 2.5f : 4.0f; // RadiusByViewingCos, :129-135
-        if (b_factor) r *= th;
-        Q.u = pts[i].proj_x; Q.v = pts[i].proj_y; Q.r = r * sf[lvl];
-        Q.min_level = lvl - 1; Q.max_level = lvl; Q.flags = 1 | 2;
-        Q.ur = pts[i].proj_xr; Q.ur_rad = r * sf[lvl];
-        memcpy(&qd[(size_t)32 * i], pt_desc + (size_t)32 * i, 32);
-    }
-    rc = run_window_queries(ctx, cur, q, qd);
+    std::vector<MatchQuery> q;
+    std::vector<uint8_t> qd;
+    if (orbfe_resolve::build_queries_points(orbfe_ctx_scale_factors(ctx), P->nlevels, n_pts, pts, pt_desc, th, q, qd) != 0)
+        return orbfe_fail(ctx, ORBFE_ERR_INVALID, "predicted level out of range");
+    std::vector<uint8_t> has_obs(N > 0 ? N : 1, 0);
+    for (int i = 0; i < N; i++) has_obs[i] = cur_has_obs ? (cur_has_obs[i] != 0) : 0;
+    std::vector<uint8_t> blocked0(has_obs);
+    TopkRequest req;
+    req.blocked0 = cur_has_obs ? blocked0.data() : nullptr;
+    req.gate_drop = true;
+    rc = run_window_queries(ctx, cur, q, qd, &req);
     if (rc != ORBFE_OK) return rc;
     orbfe_match_state *st = match_state(ctx);
-    std::vector<uint8_t> has_obs(N > 0 ? N : 1, 0);
-    for (int i = 0; i < N; i++) { has_obs[i] = cur_has_obs ? cur_has_obs[i] : 0; cur_match[i] = -1; }
-    int nm = 0;
-    for (int i = 0; i < n_pts; i++) {
-        unsigned long long best = ~0ull, second = ~0ull; // two smallest (dist, order) keys == best / second of the loop
-        for (int k = 0; k < st->h_cnt[i]; k++) {
-            const unsigned long long key = st->h_list[st->h_off[i] + k];
-            if (key_dist(key) >= 256 || has_obs[key_idx(key)]) continue;
-            if (key < best) { second = best; best = key; }
-            else if (key < second) second = key;
-        }
-        if (best == ~0ull) continue;
-        const int best_dist = key_dist(best), best_level = key_level(best);
-        const int best_dist2 = second != ~0ull ? key_dist(second) : 256, best_level2 = second != ~0ull ? key_level(second) : -1;
-        if (best_dist <= TH_HIGH) {
-            if (best_level == best_level2 && (float)best_dist > nnratio * (float)best_dist2) continue;
-            cur_match[key_idx(best)] = i;
-            has_obs[key_idx(best)] = pt_obs[i] > 0;
-            nm++;
-        }
-    }
-    *nmatches = nm;
+    FullListCtx fl{ctx, st};
+    orbfe_resolve::CandidateSource src = topk_source(st, &fl, req);
+    *nmatches = orbfe_resolve::resolve_points(src, n_pts, pt_obs, N, has_obs, nnratio, cur_match);
+    if (src.error) return orbfe_fail(ctx, ORBFE_ERR_HIP, "candidate list download failed");
     return ORBFE_OK;
 }
 
@@ -606,62 +598,24 @@ extern "C" int orbfe_search_by_projection_kf(orbfe_context *ctx, const orbfe_fra
         (n_kf > 0 && (!kf_pos || !kf_desc || !kf_valid || !kf_angle || !kf_max_distance || !kf_min_distance)))
         return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
     const orbfe_params *P = orbfe_ctx_params(ctx);
-    const float *sf = orbfe_ctx_scale_factors(ctx);
-    const float log_sf = logf((float)(double)P->scale_factor);
     const int N = cur->n;
-    float ow[3];
-    camera_center(Tcw_cur, ow);
-    std::vector<MatchQuery> q(n_kf);
-    std::vector<uint8_t> qd((size_t)32 * (n_kf > 0 ? n_kf : 1));
-    for (int i = 0; i < n_kf; i++) {
-        MatchQuery &Q = q[i];
-        Q = MatchQuery{0, 0, 0, 0, -1, 0, 0, 0};
-        if (!kf_valid[i]) continue;
-        float xc[3];
-        rt_apply(Tcw_cur, kf_pos + 3 * i, xc);
-        const float invzc = (float)(1.0 / (double)xc[2]);
-        const float u = P->fx * xc[0] * invzc + P->cx;
-        const float v = P->fy * xc[1] * invzc + P->cy;
-        if (u < cur->min_x || u > cur->max_x) continue;
-        if (v < cur->min_y || v > cur->max_y) continue;
-        float po[3];
-        for (int k = 0; k < 3; k++) po[k] = kf_pos[3 * i + k] - ow[k];
-        const float dist3d = (float)sqrt((double)po[0] * po[0] + (double)po[1] * po[1] + (double)po[2] * po[2]);
-        if (dist3d < 0.8f * kf_min_distance[i] || dist3d > 1.2f * kf_max_distance[i]) continue;
-        const int lvl = predict_scale(kf_max_distance[i], dist3d, log_sf, P->nlevels);
-        Q.u = u; Q.v = v; Q.r = th * sf[lvl]; Q.min_level = lvl - 1; Q.max_level = lvl + 1; Q.flags = 1;
-        memcpy(&qd[(size_t)32 * i], kf_desc + (size_t)32 * i, 32);
-    }
-    rc = run_window_queries(ctx, cur, q, qd);
+    std::vector<MatchQuery> q;
+    std::vector<uint8_t> qd;
+    orbfe_resolve::build_queries_kf(orbfe_resolve::camera_of(P), orbfe_ctx_scale_factors(ctx), P->nlevels, logf((float)(double)P->scale_factor), cur->min_x, cur->max_x,
+                                    cur->min_y, cur->max_y, Tcw_cur, n_kf, kf_pos, kf_desc, kf_valid, kf_max_distance, kf_min_distance, th, q, qd);
+    std::vector<uint8_t> has_pt(N > 0 ? N : 1, 0);
+    for (int i = 0; i < N; i++) has_pt[i] = cur_has_point ? (cur_has_point[i] != 0) : 0;
+    std::vector<uint8_t> blocked0(has_pt);
+    TopkRequest req;
+    req.blocked0 = cur_has_point ? blocked0.data() : nullptr;
+    req.gate_drop = false; // this overload has no mvuRight gate
+    rc = run_window_queries(ctx, cur, q, qd, &req);
     if (rc != ORBFE_OK) return rc;
     orbfe_match_state *st = match_state(ctx);
-    std::vector<uint8_t> has_pt(N > 0 ? N : 1, 0);
-    for (int i = 0; i < N; i++) { has_pt[i] = cur_has_point ? cur_has_point[i] : 0; cur_match[i] = -1; }
-    RotHist rh;
-    int nm = 0;
-    for (int i = 0; i < n_kf; i++) {
-        unsigned long long best = ~0ull;
-        for (int k = 0; k < st->h_cnt[i]; k++) {
-            const unsigned long long key = st->h_list[st->h_off[i] + k];
-            if (has_pt[key_idx(key)]) continue;
-            if (key < best) best = key;
-        }
-        if (best != ~0ull && key_dist(best) <= orb_dist) {
-            const int bi = key_idx(best);
-            cur_match[bi] = i;
-            has_pt[bi] = 1;
-            nm++;
-            if (check_ori) rh.v[rot_bin(kf_angle[i], cur->keys_un[bi].angle)].push_back(bi);
-        }
-    }
-    if (check_ori) {
-        int i1, i2, i3;
-        rh.three(i1, i2, i3);
-        for (int b = 0; b < HISTO_LENGTH; b++)
-            if (b != i1 && b != i2 && b != i3)
-                for (int idx : rh.v[b]) { cur_match[idx] = -1; nm--; }
-    }
-    *nmatches = nm;
+    FullListCtx fl{ctx, st};
+    orbfe_resolve::CandidateSource src = topk_source(st, &fl, req);
+    *nmatches = orbfe_resolve::resolve_kf(src, n_kf, kf_angle, N, &cur->keys_un[0].angle, sizeof(orbfe_keypoint), has_pt, orb_dist, check_ori, cur_match);
+    if (src.error) return orbfe_fail(ctx, ORBFE_ERR_HIP, "candidate list download failed");
     return ORBFE_OK;
 }
 
@@ -922,58 +876,20 @@ extern "C" int orbfe_search_for_initialization(orbfe_context *ctx, const orbfe_f
     if (!f1 || f1->n < 0 || (f1->n > 0 && (!f1->keys_un || !f1->descriptors || !prev_matched)) || !matches12 || !nmatches)
         return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
     const int n1 = f1->n, n2 = f2->n;
-    std::vector<MatchQuery> q(n1);
-    std::vector<uint8_t> qd((size_t)32 * (n1 > 0 ? n1 : 1));
-    for (int i = 0; i < n1; i++) {
-        MatchQuery &Q = q[i];
-        Q = MatchQuery{0, 0, 0, 0, -1, 0, 0, 0};
-        const int level1 = f1->keys_un[i].octave;
-        if (level1 > 0) continue;
-        Q.u = prev_matched[2 * i]; Q.v = prev_matched[2 * i + 1]; Q.r = (float)window_size;
-        Q.min_level = level1; Q.max_level = level1; Q.flags = 1;
-        memcpy(&qd[(size_t)32 * i], f1->descriptors + (size_t)32 * i, 32);
-    }
-    rc = run_window_queries(ctx, f2, q, qd);
+    std::vector<MatchQuery> q;
+    std::vector<uint8_t> qd;
+    orbfe_resolve::build_queries_initialization(n1, f1->keys_un, f1->descriptors, prev_matched, window_size, q, qd);
+    TopkRequest req; // no static filter: the stealing rule (vMatchedDistance) is dynamic
+    rc = run_window_queries(ctx, f2, q, qd, &req);
     if (rc != ORBFE_OK) return rc;
     orbfe_match_state *st = match_state(ctx);
-    std::vector<int> matched_dist(n2 > 0 ? n2 : 1, INT_MAX), matches21(n2 > 0 ? n2 : 1, -1);
-    for (int i = 0; i < n1; i++) matches12[i] = -1;
-    RotHist rh;
-    int nm = 0;
-    for (int i1 = 0; i1 < n1; i1++) {
-        unsigned long long best = ~0ull, second = ~0ull;
-        for (int k = 0; k < st->h_cnt[i1]; k++) {
-            const unsigned long long key = st->h_list[st->h_off[i1] + k];
-            if (matched_dist[key_idx(key)] <= key_dist(key)) continue; // :437-438
-            if (key < best) { second = best; best = key; }
-            else if (key < second) second = key;
-        }
-        if (best == ~0ull) continue;
-        const int best_dist = key_dist(best), best_dist2 = second != ~0ull ? key_dist(second) : INT_MAX, bi = key_idx(best);
-        if (best_dist <= TH_LOW && (float)best_dist < (float)best_dist2 * nnratio) {
-            if (matches21[bi] >= 0) { matches12[matches21[bi]] = -1; nm--; }
-            matches12[i1] = bi;
-            matches21[bi] = i1;
-            matched_dist[bi] = best_dist;
-            nm++;
-            if (check_ori) rh.v[rot_bin(f1->keys_un[i1].angle, f2->keys_un[bi].angle)].push_back(i1);
-        }
-    }
-    if (check_ori) {
-        int i1, i2, i3;
-        rh.three(i1, i2, i3);
-        for (int b = 0; b < HISTO_LENGTH; b++) {
-            if (b == i1 || b == i2 || b == i3) continue;
-            for (int idx1 : rh.v[b])
-                if (matches12[idx1] >= 0) { matches12[idx1] = -1; nm--; }
-        }
-    }
-    for (int i1 = 0; i1 < n1; i1++)
-        if (matches12[i1] >= 0) {
-            prev_matched[2 * i1] = f2->keys_un[matches12[i1]].x;
-            prev_matched[2 * i1 + 1] = f2->keys_un[matches12[i1]].y;
-        }
-    *nmatches = nm;
+    FullListCtx fl{ctx, st};
+    orbfe_resolve::CandidateSource src = topk_source(st, &fl, req);
+    static const orbfe_keypoint none = {};
+    *nmatches = orbfe_resolve::resolve_initialization(src, n1, n2, n1 > 0 ? &f1->keys_un[0].angle : &none.angle, sizeof(orbfe_keypoint),
+                                                      n2 > 0 ? &f2->keys_un[0].angle : &none.angle, sizeof(orbfe_keypoint),
+                                                      n2 > 0 ? &f2->keys_un[0].x : &none.x, nnratio, check_ori, prev_matched, matches12);
+    if (src.error) return orbfe_fail(ctx, ORBFE_ERR_HIP, "candidate list download failed");
     return ORBFE_OK;
 }
 

@@ -113,8 +113,22 @@ public:
         Check(orbfe_extract(mCtx, image.data, image.cols, image.rows, image.step, keypoints.data(), descriptors.data(), cap, &n));
         keypoints.resize(n);
         descriptors.resize((size_t)n * 32);
+        NoteResidentFrame(n, descriptors.data());
         if (mKeepPyramid) FetchPyramid();
     }
+
+    // Identity of the frame that currently sits in image slot 0 of the device context (the latest extraction): keypoint count +
+    // a hash of its first descriptors.  The reference-signature ORBmatcher (compat/ORBmatcher.cc) compares a Frame against it to
+    // decide whether the matchers may read that frame in HBM (orbfe_frame_view.device_slot_plus1) instead of uploading it.
+    static uint64_t FrameFingerprint(int n, const uint8_t *descriptors)
+    {
+        uint64_t h = 1469598103934665603ull ^ (uint64_t)(uint32_t)n;
+        const int bytes = (n < 8 ? n : 8) * 32;
+        for (int i = 0; i < bytes; i++) { h ^= descriptors[i]; h *= 1099511628211ull; }
+        return h;
+    }
+    bool IsResidentFrame(int n, const uint8_t *descriptors) const { return mCtx && n > 0 && mResidentN == n && mResidentFp == FrameFingerprint(n, descriptors); }
+    void NoteResidentFrame(int n, const uint8_t *descriptors) { mResidentN = n; mResidentFp = n > 0 ? FrameFingerprint(n, descriptors) : 0; }
 
     int inline GetLevels() { return mParams.nlevels; }
     float inline GetScaleFactor() { return (float)(double)mParams.scale_factor; }
@@ -232,6 +246,8 @@ protected:
     CameraParams mCam;
     orbfe_context *mCtx = nullptr;
     bool mKeepPyramid = false;
+    int mResidentN = -1;
+    uint64_t mResidentFp = 0;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
 };
 
@@ -263,6 +279,7 @@ inline void ComputeStereoFrame(ORBextractor &extractorLeft, const ImageView &imL
                                       out.mvuRight.data(), out.mvDepth.data(), cap);
     if (rc != ORBFE_OK) throw std::runtime_error(std::string("orbfe_stereo_frame: ") + orbfe_last_error(ctx));
     out.N = nl;
+    extractorLeft.NoteResidentFrame(nl, out.mDescriptors.data());
     out.mvKeys.resize(nl); out.mDescriptors.resize((size_t)nl * 32);
     out.mvKeysRight.resize(nr); out.mDescriptorsRight.resize((size_t)nr * 32);
     out.mvuRight.resize(nl); out.mvDepth.resize(nl);
@@ -297,6 +314,7 @@ inline void ComputeRGBDFrame(ORBextractor &extractor, const ImageView &imGray, c
     if (orbfe_fetch_keys_un(ctx, 0, out.mvKeysUn.data(), cap, &n2) != ORBFE_OK || n2 != n)
         throw std::runtime_error(std::string("orbfe_fetch_keys_un: ") + orbfe_last_error(ctx));
     out.N = n;
+    extractor.NoteResidentFrame(n, out.mDescriptors.data());
     out.mvKeys.resize(n); out.mvKeysUn.resize(n); out.mDescriptors.resize((size_t)n * 32);
     out.mvuRight.resize(n); out.mvDepth.resize(n);
 }

@@ -23,9 +23,11 @@ struct FrameView {
     std::vector<float> mvuRight;          // empty for monocular
     std::vector<uint8_t> mDescriptors;    // N x 32
     float mnMinX = 0.f, mnMaxX = 0.f, mnMinY = 0.f, mnMaxY = 0.f;
+    int deviceSlot = -1; // >= 0: this frame is image slot deviceSlot of the extractor's latest call (matchers read it in HBM)
     orbfe_frame_view c_view() const
     {
-        orbfe_frame_view v;
+        orbfe_frame_view v = orbfe_frame_view();
+        v.device_slot_plus1 = deviceSlot + 1;
         v.n = (int32_t)mvKeysUn.size();
         v.keys_un = mvKeysUn.data();
         v.u_right = mvuRight.empty() ? nullptr : mvuRight.data();

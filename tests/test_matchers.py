@@ -390,3 +390,114 @@ def test_gpu_search_by_sim3(gpu, seed, th):
     assert nref > 150
     ok = np.nonzero(ref >= 0)[0]
     assert (perm1[ok] == perm2[ref[ok]]).mean() > 0.9  # same 3-D point on both sides
+
+
+def _frame_scene(k, d, ur, seed):
+    """Map points for a REAL extracted frame (k, d, ur): the stereo keypoints back-projected at the identity pose, seen again
+    from a camera 0.25 m further on; a `last frame` whose rows are those points."""
+    rng = np.random.default_rng(seed)
+    good = np.nonzero(ur > 0)[0]
+    z = (BF / (k["x"][good] - ur[good])).astype(np.float32)
+    pos = np.stack([(k["x"][good] - CX) * z / FX, (k["y"][good] - CY) * z / FY, z], axis=1).astype(np.float32)
+    m = len(good)
+    desc = d[good] ^ np.packbits(rng.random((m, 256)) < 0.05, axis=1, bitorder="little")
+    return dict(pos=pos, desc=desc, valid=(rng.random(m) < 0.9).astype(np.int32), obs=rng.integers(0, 3, m).astype(np.int32),
+                octave=k["octave"][good].astype(np.int32), angle=((k["angle"][good] + rng.normal(0, 5, m)) % 360).astype(np.float32),
+                T_last=_se3(0.0, [0, 0, 0]), T_cur=_se3(0.6, [0.01, -0.005, -0.25]), has=(rng.random(len(k)) < 0.05).astype(np.uint8), rng=rng)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("distorted", [False, True])
+def test_gpu_matchers_on_the_device_resident_frame(distorted):
+    """orbfe_frame_view.device_slot_plus1: the Tracking matchers read the CURRENT frame where the extraction left it in HBM
+    (keypoints undistorted on the device, grid built once per frame) -- same results as the upload path and as the oracle,
+    on the first call, on a cached-grid call, and after the next extraction replaced the frame."""
+    from orbslam2_amd import api, synth
+    ctx = api.Context(width=W, height=H, nfeatures=1500, fx=FX, fy=FY, cx=CX, cy=CY, bf=BF)
+    dist = [-0.28, 0.07, 2e-4, 1e-5, 0.0]
+    if distorted:
+        ctx.set_distortion(dist)
+    for rep, seed in enumerate((501, 502)):
+        left, right = synth.stereo_pair(W, H, seed=seed)
+        out = ctx.stereo_frame(left, right)
+        k, d, ur = out["kps_left"], out["desc_left"], out["u_right"]
+        kun = ctx.fetch_keys_un(0) if distorted else k
+        bounds = tuple(float(b) for b in ctx.image_bounds()) if distorted else (0.0, float(W), 0.0, float(H))
+        if distorted:
+            und = O.undistort_points(np.stack([k["x"], k["y"]], 1), FX, FY, CX, CY, dist)
+            ref_un = k.copy(); ref_un["x"], ref_un["y"] = und[:, 0], und[:, 1]
+            assert np.array_equal(kun, ref_un)
+        s = _frame_scene(kun, d, ur, seed)
+        sf = O.Extractor().scale_factors()
+        g = O.Grid(kun, *bounds)
+        up = ctx._view(kun, ur, d, bounds); dev = ctx._view(kun, ur, d, bounds, device_slot=0)
+        for th, mono, ori in ((7.0, False, True), (15.0, True, False)):
+            u = None if mono else ur
+            vu = ctx._view(kun, u, d, bounds); vd = ctx._view(kun, u, d, bounds, device_slot=0)
+            ref, nref = O.search_by_projection_last(g, u, d, sf, CAM, s["T_cur"], s["T_last"], s["pos"], s["desc"], s["valid"], s["obs"],
+                                                    s["octave"], s["angle"], s["has"], th, mono, ori)
+            for v in (vu, vd, vd):  # the second resident call reuses the grid
+                got, ngot = ctx.search_by_projection_last(v, s["T_cur"], s["T_last"], s["pos"], s["desc"], s["valid"], s["obs"], s["octave"],
+                                                          s["angle"], s["has"], th, mono, ori)
+                assert ngot == nref and np.array_equal(got, ref), (rep, th)
+            assert nref > 40
+        n = len(s["pos"])
+        dist0 = np.linalg.norm(s["pos"], axis=1).astype(np.float32)
+        max_d = (dist0 * sf[s["octave"]]).astype(np.float32); min_d = (max_d / sf[NL - 1]).astype(np.float32)
+        normal = (s["pos"] / dist0[:, None]).astype(np.float32)
+        tp = O.is_in_frustum(s["T_cur"], CAM, bounds, s["pos"], normal, max_d, min_d, 0.5, LOG_SF, NL)
+        ref, nref = O.search_by_projection_points(g, ur, d, sf, tp, s["desc"], s["obs"], s["has"], 3.0, 0.8)
+        for v in (up, dev):
+            got, ngot = ctx.search_by_projection_points(v, tp, s["desc"], s["obs"], s["has"], 3.0, 0.8)
+            assert ngot == nref and np.array_equal(got, ref)
+        assert nref > 40
+        ref, nref = O.search_by_projection_kf(g, d, sf, CAM, s["T_cur"], LOG_SF, NL, s["pos"], s["desc"], s["valid"], s["angle"], max_d, min_d, s["has"], 10.0, 100, True)
+        for v in (ctx._view(kun, None, d, bounds), ctx._view(kun, None, d, bounds, device_slot=0)):
+            got, ngot = ctx.search_by_projection_kf(v, s["T_cur"], s["pos"], s["desc"], s["valid"], s["angle"], max_d, min_d, s["has"], 10.0, 100, True)
+            assert ngot == nref and np.array_equal(got, ref)
+        assert nref > 40
+        # SearchForInitialization: frame 1 = a jittered copy (host arrays), frame 2 = the resident frame
+        rng = s["rng"]
+        k1 = kun.copy(); k1["x"] += rng.normal(3, 2, len(k1)).astype(np.float32); k1["y"] += rng.normal(-2, 2, len(k1)).astype(np.float32)
+        d1 = d ^ np.packbits(rng.random((len(k1), 256)) < 0.04, axis=1, bitorder="little")
+        prev = np.stack([k1["x"], k1["y"]], axis=1)
+        ref, pm_ref, nref = O.search_for_initialization(k1, d1, g, d, prev, 100, 0.9, True)
+        v1 = ctx._view(k1, None, d1, bounds)
+        for v2 in (ctx._view(kun, None, d, bounds), ctx._view(kun, None, d, bounds, device_slot=0)):
+            got, pm, ngot = ctx.search_for_initialization(v1, v2, prev, 100, 0.9, True)
+            assert ngot == nref and np.array_equal(got, ref) and np.array_equal(pm, pm_ref)
+        assert nref > 40
+    with pytest.raises(api.OrbfeError):
+        ctx.search_by_projection_points(ctx._view(kun, ur, d, bounds, device_slot=5), tp, s["desc"], s["obs"], s["has"], 3.0, 0.8)  # no such slot
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_topk_prefix_runs_out_and_the_full_list_takes_over(gpu):
+    """The device hands the host the 4 best statically admissible keys per query; when earlier queries have taken all of them
+    the replay must continue on the full list (orbfe_match_resolve.h: first_two).  Forced here with 12 copies of every map point
+    (each copy takes the best keypoint still free, so copies 5.. need candidates beyond the prefix) and with windows of more
+    than 256 candidates (the LDS stage of the top-K selection gives up and the whole query goes to the full list)."""
+    api, ctx = gpu
+    s = _scene(90, n_last=120, n_distract=900)
+    rep = 12
+    pos = np.repeat(s["pos"], rep, axis=0); desc = np.repeat(s["desc_last"], rep, axis=0)
+    valid = np.repeat(s["valid"], rep); obs = np.ones(len(pos), np.int32)  # Observations() > 0: every match blocks its keypoint
+    octave = np.repeat(s["octave"], rep); angle = np.repeat(s["angle"], rep)
+    g = O.Grid(s["k"], *s["bounds"])
+    view = ctx._view(s["k"], s["ur"], s["d"], s["bounds"])
+    for th in (25.0, 120.0):  # 120 px x scale: windows with hundreds of candidates
+        ref, nref = O.search_by_projection_last(g, s["ur"], s["d"], s["sf"], CAM, s["T_cur"], s["T_last"], pos, desc, valid, obs, octave, angle,
+                                                s["cur_has_obs"], th, False, False)
+        got, ngot = ctx.search_by_projection_last(view, s["T_cur"], s["T_last"], pos, desc, valid, obs, octave, angle, s["cur_has_obs"], th, False, False)
+        assert ngot == nref and np.array_equal(got, ref), th
+        assert nref > 300
+    # SearchForInitialization: many frame-1 keypoints compete for the same frame-2 keypoints (stealing rule, :437-438, :460-464)
+    k1 = np.repeat(s["k"][:150], 8); d1 = np.repeat(s["d"][:150], 8, axis=0) ^ np.packbits(np.random.default_rng(91).random((1200, 256)) < 0.02, axis=1, bitorder="little")
+    k1["octave"] = 0
+    k2 = s["k"].copy(); k2["octave"] = 0
+    g2 = O.Grid(k2, *s["bounds"])
+    prev = np.stack([k1["x"], k1["y"]], axis=1)
+    ref, pm_ref, nref = O.search_for_initialization(k1, d1, g2, s["d"], prev, 100, 0.9, False)
+    got, pm, ngot = ctx.search_for_initialization(ctx._view(k1, None, d1, s["bounds"]), ctx._view(k2, None, s["d"], s["bounds"]), prev, 100, 0.9, False)
+    assert ngot == nref and np.array_equal(got, ref) and np.array_equal(pm, pm_ref)

@@ -44,6 +44,25 @@ def main():
                                               s["angle"], s["cur_has_obs"], 7.0, False, True),
         lambda: O.search_by_projection_last(g, s["ur"], s["d"], s["sf"], TM.CAM, s["T_cur"], s["T_last"], s["pos"], s["desc_last"],
                                             s["valid"], s["obs"], s["octave"], s["angle"], s["cur_has_obs"], 7.0, False, True))
+    # the same matcher on a REAL extracted frame: upload path against the device-resident frame (orbfe_frame_view.device_slot_plus1:
+    # keypoints / descriptors read where the extraction left them in HBM, grid built once per frame)
+    from orbslam2_amd import synth
+    ctx2 = api.Context(width=TM.W, height=TM.H, nfeatures=2000, fx=TM.FX, fy=TM.FY, cx=TM.CX, cy=TM.CY, bf=TM.BF)
+    left, right = synth.stereo_pair(TM.W, TM.H, seed=77)
+    fr = ctx2.stereo_frame(left, right)
+    fk, fd, fur = fr["kps_left"], fr["desc_left"], fr["u_right"]
+    fs = TM._frame_scene(fk, fd, fur, 77)
+    fb = (0.0, float(TM.W), 0.0, float(TM.H))
+    fg = O.Grid(fk, *fb)
+    v_up = ctx2._view(fk, fur, fd, fb); v_dev = ctx2._view(fk, fur, fd, fb, device_slot=0)
+    out["resident_scene"] = "%d keypoints extracted from a synthetic 640x480 pair, %d map points" % (len(fk), len(fs["pos"]))
+    for name, v in (("SearchByProjection(Frame, LastFrame), extracted frame, upload path", v_up),
+                    ("SearchByProjection(Frame, LastFrame), extracted frame, device-resident [row 14]", v_dev)):
+        row(name,
+            lambda v=v: ctx2.search_by_projection_last(v, fs["T_cur"], fs["T_last"], fs["pos"], fs["desc"], fs["valid"], fs["obs"], fs["octave"],
+                                                       fs["angle"], fs["has"], 7.0, False, True),
+            lambda: O.search_by_projection_last(fg, fur, fd, s["sf"], TM.CAM, fs["T_cur"], fs["T_last"], fs["pos"], fs["desc"], fs["valid"],
+                                                fs["obs"], fs["octave"], fs["angle"], fs["has"], 7.0, False, True), reps=50)
     rng = np.random.default_rng(5)
     qs = [(float(rng.uniform(0, TM.W)), float(rng.uniform(0, TM.H)), float(rng.uniform(5, 60))) for _ in range(64)]
     row("GetFeaturesInArea x64 [rows 13]",

@@ -5,9 +5,9 @@
 // (packed int16 min / max / sub, v_perm_b32, v_dot4, alignbyte, mbcnt, ...), fp32 controls (v_fma_f32, v_pk_fma_f32) and
 // the packed-f16 candidates (v_pk_min/max_f16, v_pk_maximum3_f16) this runs a long stream of INDEPENDENT instructions
 // (8 accumulators, inline asm so the compiler cannot fold them) at 1 / 2 / 4 / 8 waves per SIMD on every CU and reports
-//   cycles per wave-instruction per SIMD = shader cycles (s_memtime) of the slowest wave / instructions issued on its SIMD
-//   the shader clock actually held      = d(s_memtime) / d(s_memrealtime) x 100 MHz
-//   chip-wide wave-instructions per second = 256 CUs x 4 SIMDs x clock / cycles-per-instruction
+//   chip-wide wave-instructions per second = all instructions / (last wave's end - first wave's start), s_memrealtime ticks
+//   the shader clock actually held         = d(s_memtime) / d(s_memrealtime) x 100 MHz (median over the waves)
+//   cycles per wave-instruction per SIMD   = 256 CUs x 4 SIMDs x clock / that rate
 // NOT run under rocprofv3 (profiled passes clock lower).  Output: one JSON document on stdout.
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_peak tools/ubench/valu_peak.hip && /tmp/valu_peak > profiles/r02_valu_peak.json
 #include <hip/hip_runtime.h>
@@ -20,9 +20,13 @@
 #define UNROLL 16 // x 8 accumulators = 128 instructions per loop iteration
 
 enum Op { ADD_U32, MIN_I32, PK_MIN_I16, PK_MAX_I16, PK_SUB_I16, PERM_B32, ALIGNBYTE, DOT4_U32_U8, MAD_U32_U24, LSHL_OR, MBCNT_LO, BFE_U32,
+          AND_B32, XOR_B32, LSHLREV_B32, SUB_U32, MAX_I32, MIN_U32, CNDMASK_B32, MOV_B32, ADD3_U32, MUL_LO_U32, MUL_U32_U24, SAD_U8, MAX_F32, MAX3_F32, MUL_F32, ADD_F32, PK_ADD_U16, PK_MAD_I16, PK_LSHLREV_B16, CVT_F32_UBYTE0, MED3_I32, ADD_LSHL_U32,
           FMA_F32, PK_FMA_F32, PK_MIN_F16, PK_MAX_F16, PK_MAXIMUM3_F16, PK_MINIMUM3_F16, PK_ADD_F16, MAX3_I32, MIN3_I32, NUM_OPS };
 static const char *k_names[NUM_OPS] = {"v_add_u32", "v_min_i32", "v_pk_min_i16", "v_pk_max_i16", "v_pk_sub_i16", "v_perm_b32", "v_alignbyte_b32",
                                        "v_dot4_u32_u8", "v_mad_u32_u24", "v_lshl_or_b32", "v_mbcnt_lo_u32_b32", "v_bfe_u32",
+                                       "v_and_b32", "v_xor_b32", "v_lshlrev_b32", "v_sub_u32", "v_max_i32", "v_min_u32", "v_cndmask_b32", "v_mov_b32", "v_add3_u32",
+                                       "v_mul_lo_u32", "v_mul_u32_u24", "v_sad_u8", "v_max_f32", "v_max3_f32", "v_mul_f32", "v_add_f32", "v_pk_add_u16", "v_pk_mad_i16",
+                                       "v_pk_lshlrev_b16", "v_cvt_f32_ubyte0", "v_med3_i32", "v_add_lshl_u32",
                                        "v_fma_f32", "v_pk_fma_f32", "v_pk_min_f16", "v_pk_max_f16", "v_pk_maximum3_f16", "v_pk_minimum3_f16",
                                        "v_pk_add_f16", "v_max3_i32", "v_min3_i32"};
 
@@ -54,6 +58,28 @@ __global__ __launch_bounds__(256) void issue_kernel(unsigned *sink, long long *s
             else if (OP == LSHL_OR) { EIGHT("v_lshl_or_b32 %0, %0, 1, %1") }
             else if (OP == MBCNT_LO) { EIGHT("v_mbcnt_lo_u32_b32 %0, %1, %0") }
             else if (OP == BFE_U32) { EIGHT("v_bfe_u32 %0, %0, 1, 31") }
+            else if (OP == AND_B32) { EIGHT("v_and_b32 %0, %0, %1") }
+            else if (OP == XOR_B32) { EIGHT("v_xor_b32 %0, %0, %1") }
+            else if (OP == LSHLREV_B32) { EIGHT("v_lshlrev_b32 %0, 1, %0") }
+            else if (OP == SUB_U32) { EIGHT("v_sub_u32 %0, %0, %1") }
+            else if (OP == MAX_I32) { EIGHT("v_max_i32 %0, %0, %1") }
+            else if (OP == MIN_U32) { EIGHT("v_min_u32 %0, %0, %1") }
+            else if (OP == CNDMASK_B32) { EIGHT("v_cndmask_b32 %0, %0, %1, vcc") }
+            else if (OP == MOV_B32) { EIGHT("v_mov_b32 %0, %1") }
+            else if (OP == ADD3_U32) { EIGHT("v_add3_u32 %0, %0, %1, %2") }
+            else if (OP == MUL_LO_U32) { EIGHT("v_mul_lo_u32 %0, %0, %1") }
+            else if (OP == MUL_U32_U24) { EIGHT("v_mul_u32_u24 %0, %0, %1") }
+            else if (OP == SAD_U8) { EIGHT("v_sad_u8 %0, %1, %2, %0") }
+            else if (OP == MAX_F32) { EIGHT("v_max_f32 %0, %0, %1") }
+            else if (OP == MAX3_F32) { EIGHT("v_max3_f32 %0, %0, %1, %2") }
+            else if (OP == MUL_F32) { EIGHT("v_mul_f32 %0, %0, %1") }
+            else if (OP == ADD_F32) { EIGHT("v_add_f32 %0, %0, %1") }
+            else if (OP == PK_ADD_U16) { EIGHT("v_pk_add_u16 %0, %0, %1") }
+            else if (OP == PK_MAD_I16) { EIGHT("v_pk_mad_i16 %0, %0, %1, %2") }
+            else if (OP == PK_LSHLREV_B16) { EIGHT("v_pk_lshlrev_b16 %0, 1, %0") }
+            else if (OP == CVT_F32_UBYTE0) { EIGHT("v_cvt_f32_ubyte0 %0, %0") }
+            else if (OP == MED3_I32) { EIGHT("v_med3_i32 %0, %0, %1, %2") }
+            else if (OP == ADD_LSHL_U32) { EIGHT("v_add_lshl_u32 %0, %0, %1, 1") }
             else if (OP == FMA_F32) { EIGHT("v_fma_f32 %0, %0, %1, %2") }
             else if (OP == PK_MIN_F16) { EIGHT("v_pk_min_f16 %0, %0, %1") }
             else if (OP == PK_MAX_F16) { EIGHT("v_pk_max_f16 %0, %0, %1") }
@@ -102,20 +128,23 @@ static Result run(int waves_per_simd, unsigned *d_sink, long long *d_stamps, int
         float ms = 0.f;
         hipEventElapsedTime(&ms, e0, e1);
         hipMemcpy(st.data(), d_stamps, sizeof(long long) * 16 * blocks, hipMemcpyDeviceToHost);
-        // median wave: shader cycles and wall ticks (100 MHz) of its instruction stream
-        std::vector<double> cyc, clk;
+        // chip-wide span of the instruction streams in wall ticks (s_memrealtime, 100 MHz; the counter is shared by the chip) and the
+        // shader clock each wave saw (its own cycles / its own ticks); waves of a SIMD do not all overlap for their whole life, so
+        // a per-wave cycle count over-states the issue rate -- the span of ALL waves does not
+        long long r_first = st[2], r_last = st[3];
+        std::vector<double> clk;
         for (int w = 0; w < 4 * blocks; w++) {
+            r_first = std::min(r_first, st[4 * w + 2]); r_last = std::max(r_last, st[4 * w + 3]);
             const double dc = (double)(st[4 * w + 1] - st[4 * w + 0]), dr = (double)(st[4 * w + 3] - st[4 * w + 2]);
-            cyc.push_back(dc);
             if (dr > 0) clk.push_back(dc / dr * 100.0);
         }
-        std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
-        const double med_cyc = cyc[cyc.size() / 2], med_clk = clk.empty() ? 0.0 : clk[clk.size() / 2];
-        const double insts_per_wave = (double)iters * UNROLL * 8;
-        // all waves of a SIMD run concurrently for (about) the same span: instructions issued on the SIMD in that span
-        const double cpi = med_cyc / (insts_per_wave * waves_per_simd);
-        if (rep > 0 && cpi < best.cyc_per_inst)
-            best = {cpi, med_clk, (double)n_cu * 4.0 * med_clk * 1e6 / cpi / 1e9, (double)ms};
+        std::sort(clk.begin(), clk.end());
+        const double med_clk = clk.empty() ? 0.0 : clk[clk.size() / 2];
+        const double span_s = (double)(r_last - r_first) * 1e-8;
+        const double insts_total = (double)iters * UNROLL * 8 * 4.0 * blocks;
+        const double rate = insts_total / span_s;                        // wave-instructions per second, whole chip
+        const double cpi = (double)n_cu * 4.0 * med_clk * 1e6 / rate;    // shader cycles per wave-instruction per SIMD
+        if (rep > 0 && cpi < best.cyc_per_inst) best = {cpi, med_clk, rate / 1e9, (double)ms};
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
     return best;
@@ -144,7 +173,7 @@ int main()
     hipMalloc(&d_sink, (size_t)n_cu * 8 * 256 * 4);
     hipMalloc(&d_stamps, (size_t)n_cu * 8 * 16 * sizeof(long long));
     printf("{\n \"device\": \"%s\", \"compute_units\": %d, \"method\": \"independent inline-asm instruction streams, 8 accumulators, %d instructions per wave; "
-           "keys 1/2/4/8 = waves per SIMD on every CU; cycles from s_memtime of the median wave, clock = d(s_memtime)/d(s_memrealtime) x 100 MHz; not under rocprofv3\",\n \"ops\": {\n",
+           "keys 1/2/4/8 = waves per SIMD on every CU; rate = all instructions / (last end - first start) in s_memrealtime ticks (100 MHz), clock = median of d(s_memtime)/d(s_memrealtime) x 100 MHz per wave, cycles_per_wave_inst_per_simd = CUs x 4 x clock / rate; not under rocprofv3\",\n \"ops\": {\n",
            prop.name, n_cu, 1024 * UNROLL * 8);
     report<ADD_U32>(d_sink, d_stamps, n_cu, false);
     report<MIN_I32>(d_sink, d_stamps, n_cu, false);
@@ -160,6 +189,28 @@ int main()
     report<BFE_U32>(d_sink, d_stamps, n_cu, false);
     report<MAX3_I32>(d_sink, d_stamps, n_cu, false);
     report<MIN3_I32>(d_sink, d_stamps, n_cu, false);
+    report<AND_B32>(d_sink, d_stamps, n_cu, false);
+    report<XOR_B32>(d_sink, d_stamps, n_cu, false);
+    report<LSHLREV_B32>(d_sink, d_stamps, n_cu, false);
+    report<SUB_U32>(d_sink, d_stamps, n_cu, false);
+    report<MAX_I32>(d_sink, d_stamps, n_cu, false);
+    report<MIN_U32>(d_sink, d_stamps, n_cu, false);
+    report<CNDMASK_B32>(d_sink, d_stamps, n_cu, false);
+    report<MOV_B32>(d_sink, d_stamps, n_cu, false);
+    report<ADD3_U32>(d_sink, d_stamps, n_cu, false);
+    report<MUL_LO_U32>(d_sink, d_stamps, n_cu, false);
+    report<MUL_U32_U24>(d_sink, d_stamps, n_cu, false);
+    report<SAD_U8>(d_sink, d_stamps, n_cu, false);
+    report<MAX_F32>(d_sink, d_stamps, n_cu, false);
+    report<MAX3_F32>(d_sink, d_stamps, n_cu, false);
+    report<MUL_F32>(d_sink, d_stamps, n_cu, false);
+    report<ADD_F32>(d_sink, d_stamps, n_cu, false);
+    report<PK_ADD_U16>(d_sink, d_stamps, n_cu, false);
+    report<PK_MAD_I16>(d_sink, d_stamps, n_cu, false);
+    report<PK_LSHLREV_B16>(d_sink, d_stamps, n_cu, false);
+    report<CVT_F32_UBYTE0>(d_sink, d_stamps, n_cu, false);
+    report<MED3_I32>(d_sink, d_stamps, n_cu, false);
+    report<ADD_LSHL_U32>(d_sink, d_stamps, n_cu, false);
     report<FMA_F32>(d_sink, d_stamps, n_cu, false);
     report<PK_FMA_F32>(d_sink, d_stamps, n_cu, false);
     report<PK_MIN_F16>(d_sink, d_stamps, n_cu, false);
