@@ -410,6 +410,23 @@ int orbfe_search_by_bow_kf(orbfe_context *ctx,
                            const int32_t *valid2, const uint8_t *desc2, const float *angle2, int n2,
                            float nnratio, int check_ori, int32_t *match12, int *nmatches);
 
+/* ---- input side: cv::imread(path, cv::IMREAD_UNCHANGED) for PNG files, the per-frame call of every
+ * replay driver (Test/Replay/Stereo/stereo_kitti.cc:69-70, stereo_euroc.cc:119-120, RGBD/rgbd_tum.cc:80-81).  Host code
+ * (a PNG is one bit-serial DEFLATE stream + neighbour-dependent scanline filters); no context, no GPU needed, thread safe.
+ * Output = what imread returns: grey -> 1 channel (1/2/4-bit scaled to 8), RGB -> B,G,R, RGBA and grey+alpha -> B,G,R,A,
+ * palette -> B,G,R (B,G,R,A with tRNS), 16-bit samples stay 16 bit in host byte order; Adam7 interlacing supported.
+ * A file imread would refuse (bad signature / CRC / stream) returns ORBFE_ERR_INVALID; orbfe_png_last_error() says why
+ * (per thread). */
+const char *orbfe_png_last_error(void);
+int orbfe_png_info(const uint8_t *file, size_t size, int *width, int *height, int *channels, int *bit_depth);
+/* dst receives height rows of width * channels * (bit_depth / 8) bytes, dst_stride bytes apart (0 = tightly packed). */
+int orbfe_png_decode(const uint8_t *file, size_t size, uint8_t *dst, size_t dst_bytes, size_t dst_stride,
+                     int *width, int *height, int *channels, int *bit_depth);
+/* n files of one camera stream (common geometry, checked) decoded by `threads` host threads (0 = all cores) into
+ * dst[i * image_bytes ..]: pinned memory here is the staging block of the upload that feeds orbfe_enqueue_*. */
+int orbfe_png_decode_batch(const uint8_t *const *files, const size_t *sizes, int n, uint8_t *dst, size_t image_bytes,
+                           int width, int height, int channels, int bit_depth, int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,7 @@ EXPORTS = [
     "orbfe_vocab_load", "orbfe_bow_transform", "orbfe_bow_maps", "orbfe_search_by_bow", "orbfe_search_by_bow_kf",  # bound in orbslam2_amd/bow.py
     "orbfe_search_for_triangulation", "orbfe_fuse", "orbfe_search_by_projection_sim3", "orbfe_fuse_sim3", "orbfe_search_by_sim3", "orbfe_kfdb_clear", "orbfe_kfdb_add", "orbfe_kfdb_erase", "orbfe_kfdb_size", "orbfe_kfdb_score", "orbfe_detect_reloc_candidates", "orbfe_detect_loop_candidates",
     "orbfe_pose_optimization", "orbfe_pose_optimization_batch", "orbfe_enqueue_pose_optimization", "orbfe_set_input_format", "orbfe_fetch_batch_async", "orbfe_set_rectification", "orbfe_set_distortion", "orbfe_undistort_keypoints", "orbfe_fetch_keys_un", "orbfe_image_bounds",
+    "orbfe_png_last_error", "orbfe_png_info", "orbfe_png_decode", "orbfe_png_decode_batch",
 ]
 NUM_STAGES = 8
 STAGE_NAMES = ["ingest", "pyramid", "blur", "fast", "octree", "describe", "stereo_match", "stereo_median"]  # orbfe_stage_name()
@@ -507,3 +508,48 @@ class Context:
         out = np.zeros((len(a), len(b)), np.int32)
         self._check(self.L.orbfe_hamming_matrix(self.h, _p(a), len(a), _p(b), len(b), _p(out)))
         return out
+
+
+# ---- PNG input (orbfe_png_*): no context, no GPU ----
+def png_info(data: bytes):
+    """(width, height, channels, bit_depth) cv::imread(..., IMREAD_UNCHANGED) would return for this PNG file."""
+    L = load()
+    buf = np.frombuffer(data, np.uint8)
+    w, h, ch, bd = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rc = L.orbfe_png_info(_p(buf), len(buf), C.byref(w), C.byref(h), C.byref(ch), C.byref(bd))
+    if rc != OK:
+        L.orbfe_png_last_error.restype = C.c_char_p
+        raise OrbfeError(rc, L.orbfe_png_last_error().decode())
+    return w.value, h.value, ch.value, bd.value
+
+
+def png_decode(data: bytes) -> np.ndarray:
+    """cv::imread(path, IMREAD_UNCHANGED) of a PNG file held in memory: HxW or HxWxC array, uint8 or uint16."""
+    L = load()
+    w, h, ch, bd = png_info(data)
+    out = np.zeros((h, w, ch), np.uint16 if bd == 16 else np.uint8)
+    buf = np.frombuffer(data, np.uint8)
+    L.orbfe_png_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t] + [C.POINTER(C.c_int)] * 4
+    rc = L.orbfe_png_decode(_p(buf), len(buf), _p(out), out.nbytes, 0, None, None, None, None)
+    if rc != OK:
+        L.orbfe_png_last_error.restype = C.c_char_p
+        raise OrbfeError(rc, L.orbfe_png_last_error().decode())
+    return out[:, :, 0] if ch == 1 else out
+
+
+def png_decode_batch(files, width, height, channels=1, bit_depth=8, threads=0, out=None) -> np.ndarray:
+    """n PNG files of one geometry -> [n, H, W(, C)] array (optionally a caller buffer, e.g. pinned memory)."""
+    L = load()
+    n = len(files)
+    shape = (n, height, width) if channels == 1 else (n, height, width, channels)
+    if out is None:
+        out = np.zeros(shape, np.uint16 if bit_depth == 16 else np.uint8)
+    bufs = [np.frombuffer(f, np.uint8) for f in files]
+    ptrs = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
+    sizes = (C.c_size_t * max(n, 1))(*[len(b) for b in bufs])
+    L.orbfe_png_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t] + [C.c_int] * 5
+    rc = L.orbfe_png_decode_batch(ptrs, sizes, n, _p(out), out.nbytes // max(n, 1), width, height, channels, bit_depth, threads)
+    if rc != OK:
+        L.orbfe_png_last_error.restype = C.c_char_p
+        raise OrbfeError(rc, L.orbfe_png_last_error().decode())
+    return out

@@ -475,29 +475,51 @@ def test_gpu_matchers_on_the_device_resident_frame(distorted):
 @pytest.mark.gpu
 def test_gpu_topk_prefix_runs_out_and_the_full_list_takes_over(gpu):
     """The device hands the host the 4 best statically admissible keys per query; when earlier queries have taken all of them
-    the replay must continue on the full list (orbfe_match_resolve.h: first_two).  Forced here with 12 copies of every map point
-    (each copy takes the best keypoint still free, so copies 5.. need candidates beyond the prefix) and with windows of more
-    than 256 candidates (the LDS stage of the top-K selection gives up and the whole query goes to the full list)."""
+    the replay must continue on the full list (orbfe_match_resolve.h: first_two).  Forced here: every map point appears 10 times
+    and the frame holds a cluster of 8 near-copies of its keypoint (Hamming distance 0 .. 7), so copy j takes the j-th best
+    keypoint and copies 5 .. 8 need candidates beyond the prefix; and with windows of more than 256 candidates the LDS stage of
+    the top-K selection gives up and the whole query goes to the full list."""
     api, ctx = gpu
-    s = _scene(90, n_last=120, n_distract=900)
-    rep = 12
+    s = _scene(90, n_last=150, n_distract=700)
+    rng = np.random.default_rng(91)
+    T = s["T_cur"].astype(np.float64)
+    pc = (T[:, :3] @ s["pos"].T.astype(np.float64)).T + T[:, 3]
+    uu = FX * pc[:, 0] / pc[:, 2] + CX; vv = FY * pc[:, 1] / pc[:, 2] + CY
+    ok = np.nonzero((s["valid"] == 1) & (pc[:, 2] > 0.5) & (uu > 30) & (uu < W - 30) & (vv > 30) & (vv < H - 30))[0][:60]
+    extra_k = np.zeros(len(ok) * 8, O.KP_DTYPE); extra_d = np.zeros((len(ok) * 8, 32), np.uint8)
+    for a_, i in enumerate(ok):
+        for j in range(8):
+            e = a_ * 8 + j
+            extra_k["x"][e] = uu[i] + rng.uniform(-1, 1); extra_k["y"][e] = vv[i] + rng.uniform(-1, 1)
+            extra_k["octave"][e] = s["octave"][i]; extra_k["angle"][e] = s["angle"][i]
+            bits = np.zeros(256, bool); bits[rng.permutation(256)[:j]] = True  # j bits away from the map point's descriptor
+            extra_d[e] = s["desc_last"][i] ^ np.packbits(bits, bitorder="little")
+    extra_k["size"] = 31; extra_k["class_id"] = -1
+    k = np.concatenate([s["k"], extra_k]); d = np.concatenate([s["d"], extra_d]); ur = np.concatenate([s["ur"], np.full(len(extra_k), -1.0, np.float32)])
+    has = np.concatenate([s["cur_has_obs"], np.zeros(len(extra_k), np.uint8)])
+    rep = 10
     pos = np.repeat(s["pos"], rep, axis=0); desc = np.repeat(s["desc_last"], rep, axis=0)
     valid = np.repeat(s["valid"], rep); obs = np.ones(len(pos), np.int32)  # Observations() > 0: every match blocks its keypoint
     octave = np.repeat(s["octave"], rep); angle = np.repeat(s["angle"], rep)
-    g = O.Grid(s["k"], *s["bounds"])
-    view = ctx._view(s["k"], s["ur"], s["d"], s["bounds"])
-    for th in (25.0, 120.0):  # 120 px x scale: windows with hundreds of candidates
-        ref, nref = O.search_by_projection_last(g, s["ur"], s["d"], s["sf"], CAM, s["T_cur"], s["T_last"], pos, desc, valid, obs, octave, angle,
-                                                s["cur_has_obs"], th, False, False)
-        got, ngot = ctx.search_by_projection_last(view, s["T_cur"], s["T_last"], pos, desc, valid, obs, octave, angle, s["cur_has_obs"], th, False, False)
+    g = O.Grid(k, *s["bounds"])
+    view = ctx._view(k, ur, d, s["bounds"])
+    for th in (7.0, 120.0):  # 120 px x scale: windows with hundreds of candidates
+        ref, nref = O.search_by_projection_last(g, ur, d, s["sf"], CAM, s["T_cur"], s["T_last"], pos, desc, valid, obs, octave, angle, has, th, False, False)
+        got, ngot = ctx.search_by_projection_last(view, s["T_cur"], s["T_last"], pos, desc, valid, obs, octave, angle, has, th, False, False)
         assert ngot == nref and np.array_equal(got, ref), th
-        assert nref > 300
+        assert nref > 8 * len(ok) - 20  # the clusters were used up: copies 5 .. 8 found their keypoint beyond the prefix
+    tp = np.zeros(len(pos), O.TP_DTYPE)  # the same through SearchByProjection(F, points): best AND second beyond the prefix
+    tp["in_view"] = valid; tp["proj_x"] = np.repeat(uu, rep); tp["proj_y"] = np.repeat(vv, rep); tp["proj_xr"] = -1; tp["level"] = octave; tp["view_cos"] = 0.9
+    tp["in_view"][(tp["proj_x"] < 0) | (tp["proj_x"] > W) | (tp["proj_y"] < 0) | (tp["proj_y"] > H)] = 0
+    ref, nref = O.search_by_projection_points(g, ur, d, s["sf"], tp, desc, obs, has, 3.0, 0.99)
+    got, ngot = ctx.search_by_projection_points(view, tp, desc, obs, has, 3.0, 0.99)
+    assert ngot == nref and np.array_equal(got, ref) and nref > 200
     # SearchForInitialization: many frame-1 keypoints compete for the same frame-2 keypoints (stealing rule, :437-438, :460-464)
-    k1 = np.repeat(s["k"][:150], 8); d1 = np.repeat(s["d"][:150], 8, axis=0) ^ np.packbits(np.random.default_rng(91).random((1200, 256)) < 0.02, axis=1, bitorder="little")
+    k1 = np.repeat(k[-len(extra_k):], 3); d1 = np.repeat(d[-len(extra_k):], 3, axis=0) ^ np.packbits(rng.random((3 * len(extra_k), 256)) < 0.01, axis=1, bitorder="little")
     k1["octave"] = 0
-    k2 = s["k"].copy(); k2["octave"] = 0
+    k2 = k.copy(); k2["octave"] = 0
     g2 = O.Grid(k2, *s["bounds"])
     prev = np.stack([k1["x"], k1["y"]], axis=1)
-    ref, pm_ref, nref = O.search_for_initialization(k1, d1, g2, s["d"], prev, 100, 0.9, False)
-    got, pm, ngot = ctx.search_for_initialization(ctx._view(k1, None, d1, s["bounds"]), ctx._view(k2, None, s["d"], s["bounds"]), prev, 100, 0.9, False)
-    assert ngot == nref and np.array_equal(got, ref) and np.array_equal(pm, pm_ref)
+    ref, pm_ref, nref = O.search_for_initialization(k1, d1, g2, d, prev, 100, 0.99, False)
+    got, pm, ngot = ctx.search_for_initialization(ctx._view(k1, None, d1, s["bounds"]), ctx._view(k2, None, d, s["bounds"]), prev, 100, 0.99, False)
+    assert ngot == nref and np.array_equal(got, ref) and np.array_equal(pm, pm_ref) and nref > 50
