@@ -392,12 +392,13 @@ def test_gpu_search_by_sim3(gpu, seed, th):
     assert (perm1[ok] == perm2[ref[ok]]).mean() > 0.9  # same 3-D point on both sides
 
 
-def _frame_scene(k, d, ur, seed):
+def _frame_scene(k, d, ur, seed, all_points=False):
     """Map points for a REAL extracted frame (k, d, ur): the stereo keypoints back-projected at the identity pose, seen again
-    from a camera 0.25 m further on; a `last frame` whose rows are those points."""
+    from a camera 0.25 m further on; a `last frame` whose rows are those points.  all_points: monocular keypoints get a
+    random depth too (bench: one map point per keypoint)."""
     rng = np.random.default_rng(seed)
-    good = np.nonzero(ur > 0)[0]
-    z = (BF / (k["x"][good] - ur[good])).astype(np.float32)
+    good = np.nonzero(ur > 0)[0] if not all_points else np.arange(len(k))
+    z = np.where(ur[good] > 0, BF / np.maximum(k["x"][good] - ur[good], 1e-3), rng.uniform(3.0, 30.0, len(good))).astype(np.float32)
     pos = np.stack([(k["x"][good] - CX) * z / FX, (k["y"][good] - CY) * z / FY, z], axis=1).astype(np.float32)
     m = len(good)
     desc = d[good] ^ np.packbits(rng.random((m, 256)) < 0.05, axis=1, bitorder="little")

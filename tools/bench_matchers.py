@@ -51,7 +51,7 @@ def main():
     left, right = synth.stereo_pair(TM.W, TM.H, seed=77)
     fr = ctx2.stereo_frame(left, right)
     fk, fd, fur = fr["kps_left"], fr["desc_left"], fr["u_right"]
-    fs = TM._frame_scene(fk, fd, fur, 77)
+    fs = TM._frame_scene(fk, fd, fur, 77, all_points=True)
     fb = (0.0, float(TM.W), 0.0, float(TM.H))
     fg = O.Grid(fk, *fb)
     v_up = ctx2._view(fk, fur, fd, fb); v_dev = ctx2._view(fk, fur, fd, fb, device_slot=0)
