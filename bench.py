@@ -75,16 +75,30 @@ def traffic_bytes(stage: str, pairs: int, launches: int):
 
 
 def valu_issue(pairs: int, launches: int, launch_ms: float):
-    """Context for the roofline: the dominant kernel is bound by integer-VALU issue, not by HBM.  SQ_INSTS_VALU of the kernel
-    from the committed rocprofv3 pass (profiles/r01_pmc_sq.txt, per launch of 64 pairs), scaled to this run's batch, against
-    the chip's issue rate: 256 CUs x 4 SIMDs x one wave64 instruction per 4 cycles at 2.4 GHz (MI355X_MICROARCH.md)."""
+    """Context for the roofline: the dominant kernel is bound by VALU issue, not by HBM.  SQ_INSTS_VALU of the kernel from the
+    committed rocprofv3 pass (per launch of 64 pairs), scaled to this run's batch, against the issue rate MEASURED on this chip
+    for the opcode class the kernel is made of (profiles/r02_valu_peak.json, tools/ubench/valu_peak.hip, outside rocprofv3):
+    gfx950 issues packed / integer min-max, v_perm, shifts, v_dot4, mbcnt ... once per ~4.1 cycles per SIMD (590 G wave-
+    instructions/s chip-wide at the clock it holds), and only add / sub / and / xor / mov / fp32 mul-add-fma once per ~2.3."""
     try:
-        for line in open(os.path.join(ROOT, "profiles", "r01_pmc_sq.txt")):
-            if "fast_cell_kernel" in line:
-                d = eval(line[line.index("{"):line.rindex("}") + 1], {"__builtins__": {}})
-                insts = d["SQ_INSTS_VALU"] * (pairs / launches) / 64.0
-                peak = 256 * 4 * 2.4e9 / 4
-                return {"wave_insts_per_launch": insts, "peak_wave_insts_per_s": peak, "frac": insts / (launch_ms * 1e-3) / peak}
+        insts = None
+        for name in ("r02_pmc_sq.txt", "r01_pmc_sq.txt"):
+            path = os.path.join(ROOT, "profiles", name)
+            if not os.path.exists(path):
+                continue
+            for line in open(path):
+                if "fast_cell_kernel" in line and "SQ_INSTS_VALU" in line:
+                    d = eval(line[line.index("{"):line.rindex("}") + 1], {"__builtins__": {}})
+                    insts = d["SQ_INSTS_VALU"] * (pairs / launches) / 64.0
+                    break
+            if insts is not None:
+                break
+        ops = json.load(open(os.path.join(ROOT, "profiles", "r02_valu_peak.json")))["ops"]
+        half_rate = ops["v_pk_max_i16"]["8"]["chip_G_wave_inst_per_s"] * 1e9   # the class FAST is made of (pk min / max, perm)
+        full_rate = ops["v_add_u32"]["8"]["chip_G_wave_inst_per_s"] * 1e9      # add / sub / and / xor / mov / fp32 fma
+        return {"wave_insts_per_launch": insts, "peak_wave_insts_per_s": half_rate, "frac": insts / (launch_ms * 1e-3) / half_rate,
+                "peak_source": "profiles/r02_valu_peak.json: v_pk_max_i16 at 8 waves per SIMD (measured, %.2f cycles per wave-instruction per SIMD); "
+                               "full-rate class (v_add_u32 ...) %.0f G/s" % (ops["v_pk_max_i16"]["8"]["cycles_per_wave_inst_per_simd"], full_rate / 1e9)}
     except Exception:
         pass
     return None

@@ -248,8 +248,10 @@ struct orbfe_match_state {
     size_t h_in_bytes = 0, h_out_bytes = 0;
     std::vector<int> h_off, h_cnt, h_nstatic;
     std::vector<unsigned long long> h_list, h_topk;
-    bool list_on_host = false; // h_list holds the device list of the latest query
+    bool list_on_host = false; // h_list / h_off / h_cnt hold the device list of the latest query
     int list_total = 0;
+    size_t lazy_off = 0, lazy_cnt = 0; // where the offsets / counts of a top-K query sit in out_blk (downloaded on demand)
+    int lazy_nq = 0;
     // grid of a device-resident frame (image slot of the latest extraction call): built once per frame
     unsigned grid_epoch = 0;
     int grid_slot = -1, grid_n = -1;
@@ -312,8 +314,11 @@ static int run_window_queries(orbfe_context *ctx, const orbfe_frame_view *fv, co
     const size_t i_keys = 0, i_desc = up16(i_keys + sizeof(KeyPointPOD) * fn), i_ur = up16(i_desc + (size_t)32 * fn);
     const size_t i_q = up16(i_ur + (fv->u_right ? sizeof(float) * (size_t)n : 0)), i_qd = up16(i_q + sizeof(MatchQuery) * nq), i_blk = up16(i_qd + (size_t)32 * nq);
     const size_t in_bytes = up16(i_blk + (topk && topk->blocked0 ? (size_t)n : 0));
-    const size_t o_cur = 0, o_off = 16, o_cnt = up16(o_off + sizeof(int) * nq), o_ns = up16(o_cnt + sizeof(int) * nq);
-    const size_t o_tk = up16(o_ns + sizeof(int) * nq), out_bytes = up16(o_tk + sizeof(unsigned long long) * MATCH_TOPK * nq);
+    // results: [cursor | n_static | top-K keys] are what a top-K replay needs; [offsets | counts] follow and are only downloaded
+    // with the full list
+    const size_t o_cur = 0, o_ns = 16, o_tk = up16(o_ns + sizeof(int) * nq), o_off = up16(o_tk + sizeof(unsigned long long) * MATCH_TOPK * nq);
+    const size_t o_cnt = up16(o_off + sizeof(int) * nq), out_bytes = up16(o_cnt + sizeof(int) * nq);
+    const size_t topk_bytes = o_off; // prefix of the result block a top-K replay downloads
     if (st->in_blk.ensure(in_bytes) || st->out_blk.ensure(out_bytes) || st->cells.ensure(sizeof(int) * (2 * ncell + 2 + cfg->sel_total + n)) ||
         st->cell_of.ensure(sizeof(int) * (size_t)(n > cfg->sel_total ? n : cfg->sel_total)))
         return orbfe_fail(ctx, ORBFE_ERR_HIP, "matcher scratch allocation failed");
@@ -375,20 +380,21 @@ static int run_window_queries(orbfe_context *ctx, const orbfe_frame_view *fv, co
                            (unsigned long long *)st->list.p, (int *)(dout + o_cur), (int)std::min<size_t>(cap, INT_MAX),
                            topk ? (unsigned long long *)(dout + o_tk) : nullptr, (int *)(dout + o_ns),
                            topk && topk->blocked0 ? (const uint8_t *)(din + i_blk) : nullptr, topk && topk->gate_drop ? 1 : 0);
-        MTRY(ctx, hipMemcpyAsync(st->h_out, dout, topk ? out_bytes : o_ns, hipMemcpyDeviceToHost, s));
+        MTRY(ctx, hipMemcpyAsync(st->h_out, dout, topk ? topk_bytes : out_bytes, hipMemcpyDeviceToHost, s));
         MTRY(ctx, hipStreamSynchronize(s));
         MTRY(ctx, hipGetLastError());
         const int total = *(const int *)(st->h_out + o_cur);
         if ((size_t)total <= cap) {
-            memcpy(st->h_off.data(), st->h_out + o_off, sizeof(int) * nq);
-            memcpy(st->h_cnt.data(), st->h_out + o_cnt, sizeof(int) * nq);
             st->list_total = total;
             if (topk) {
                 memcpy(st->h_nstatic.data(), st->h_out + o_ns, sizeof(int) * nq);
                 memcpy(st->h_topk.data(), st->h_out + o_tk, sizeof(unsigned long long) * MATCH_TOPK * nq);
                 st->list_on_host = total == 0;
+                st->lazy_off = o_off; st->lazy_cnt = o_cnt; st->lazy_nq = nq;
                 return ORBFE_OK;
             }
+            memcpy(st->h_off.data(), st->h_out + o_off, sizeof(int) * nq);
+            memcpy(st->h_cnt.data(), st->h_out + o_cnt, sizeof(int) * nq);
             st->h_list.resize(total);
             if (total > 0) MTRY(ctx, hipMemcpy(st->h_list.data(), st->list.p, sizeof(unsigned long long) * total, hipMemcpyDeviceToHost));
             return ORBFE_OK;
@@ -406,6 +412,10 @@ static int fetch_full_list(void *user, int q, std::vector<orbfe_resolve::ckey_t>
     orbfe_match_state *st = c->st;
     if (!st->list_on_host) {
         st->h_list.resize(st->list_total);
+        const uint8_t *dout = (const uint8_t *)st->out_blk.p;
+        if (hipMemcpy(st->h_off.data(), dout + st->lazy_off, sizeof(int) * st->lazy_nq, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(st->h_cnt.data(), dout + st->lazy_cnt, sizeof(int) * st->lazy_nq, hipMemcpyDeviceToHost) != hipSuccess)
+            return -1;
         if (st->list_total > 0 &&
             hipMemcpy(st->h_list.data(), st->list.p, sizeof(unsigned long long) * st->list_total, hipMemcpyDeviceToHost) != hipSuccess)
             return -1;
