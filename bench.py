@@ -63,11 +63,14 @@ def stage_alg_bytes_per_pair(n_cand_per_image: float):
 
 
 def traffic_bytes(stage: str, pairs: int, launches: int):
-    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (profiles/r01_traffic.json:
+    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (profiles/r02_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate passes of this same command, gfx950 correction 2 x FETCH_SIZE as
     MI355X_MICROARCH.md prescribes), scaled from the profiled batch to this run's batch; None if not profiled."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"][stage]
+        path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        if not os.path.exists(path):
+            path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        t = json.load(open(path))["kernels"][stage]
         per_pair = (2.0 * t["fetch_kb_per_pair"] + t["write_kb_per_pair"]) * 1024.0
         return per_pair * pairs / launches
     except Exception:

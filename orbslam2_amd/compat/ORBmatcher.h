@@ -3,12 +3,12 @@
 //
 // Replace the reference's include/ORBmatcher.h + src/ORBmatcher.cc by this header + compat/ORBmatcher.cc and
 // Tracking / LocalMapping / LoopClosing compile unchanged:
-//     ORBmatcher matcher(0.9,true);                                                    // src/Tracking.cc:698,862,969,1283,1455,1496
+//     ORBmatcher matcher(0.9,true);                                                    // src/Tracking.cc:698 (and :862,969,1283,1455,1496 with their ratios)
 //     int nmatches = matcher.SearchForInitialization(mInitialFrame,mCurrentFrame,...);  // :699
 //     int nmatches = matcher.SearchByFboW(mpReferenceKF,mCurrentFrame,vpMapPointMatches);// :867,1476
 //     int nmatches = matcher.SearchByProjection(mCurrentFrame,mLastFrame,th,...);       // :985-992
-//     matcher.SearchByProjection(mCurrentFrame,vpMapPoints,th);                          // :1290
-//     matcher2.SearchByProjection(mCurrentFrame,vpCandidateKFs[i],sFound,10,100);        // :1552
+//     matcher.SearchByProjection(mCurrentFrame,mvpLocalMapPoints,th);                    // :1290
+//     matcher2.SearchByProjection(mCurrentFrame,vpCandidateKFs[i],sFound,10,100);        // Relocalization
 // It needs the reference's Frame.h / KeyFrame.h / MapPoint.h (and therefore OpenCV) on the include path, with
 // ORBextractor.h being the mirror in orbslam2_amd/host/ (Frame::mpORBextractorLeft->Context() is where the device context
 // comes from; keyframe-only overloads use ORBextractor::DefaultContext()).  This repository cannot compile it against the

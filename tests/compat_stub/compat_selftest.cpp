@@ -224,7 +224,7 @@ int main(int argc, char **argv)
             wr("out_bow.bin", out);
             wr("n_bow.bin", std::vector<int32_t>(1, nbow));
         }
-        // ---- 6. Fuse(pKF, vpMapPoints, th): src/LocalMapping.cc:605-614 (SearchInNeighbors), with the map mutation
+        // ---- 6. Fuse(pKF, vpMapPoints, th): src/LocalMapping.cc:482-512 (SearchInNeighbors), with the map mutation
         {
             std::vector<MapPoint *> pts = make_points();
             for (int i = 0; i < M; i++) if (valid[i] == 0) pts[i] = NULL; else if (valid[i] == 2) pts[i]->mbBad = true;
@@ -252,6 +252,45 @@ int main(int argc, char **argv)
                 if (held[k]) { held_bad[k] = held[k]->isBad(); if (held[k]->GetReplaced()) held_replaced_by_pt[k] = index_of.at(held[k]->GetReplaced()); }
             wr("out_fuse_added.bin", added); wr("out_fuse_pt_replaced.bin", pt_replaced_by_held); wr("out_fuse_held_replaced.bin", held_replaced_by_pt);
             wr("n_fuse.bin", std::vector<int32_t>(1, nFused));
+        }
+        // ---- 7. the RESIDENT path: a real extraction (ORBextractor::operator() of the mirror), a Frame built from its output, and
+        //         SearchByProjection(F, vpMapPoints, th) on it: the shim must recognise the frame as the extractor's latest one
+        //         (keypoints / descriptors read in HBM, grid built once) and a second call must reuse the grid
+        {
+            const std::vector<uchar> img = rd<uchar>("real_image.bin");
+            std::vector<orbfe_keypoint> rk;
+            std::vector<uint8_t> rd_;
+            extractor(ImageView{img.data(), W, H, (size_t)W}, rk, rd_);
+            std::vector<cv::KeyPoint> ck(rk.size());
+            std::memcpy((void *)ck.data(), rk.data(), rk.size() * sizeof(orbfe_keypoint));
+            Frame F;
+            fill_frame(F, &extractor, ck, rd_, std::vector<float>(), T_cur.data());
+            if (!extractor.IsResidentFrame(F.N, F.mDescriptors.ptr<uchar>(0))) { std::cerr << "extracted frame not recognised as resident\n"; return 3; }
+            Frame other; // a frame of the scene is NOT the resident one
+            fill_frame(other, &extractor, cur_k, cur_d, cur_ur, T_cur.data());
+            if (extractor.IsResidentFrame(other.N, other.mDescriptors.ptr<uchar>(0))) { std::cerr << "foreign frame taken for the resident one\n"; return 4; }
+            // map points = the frame's own keypoints seen again (descriptor of the keypoint, predicted level = its octave)
+            std::vector<std::unique_ptr<MapPoint> > own;
+            std::vector<MapPoint *> pts;
+            for (int i = 0; i < F.N; i += 2) {
+                own.emplace_back(new MapPoint());
+                MapPoint *p = own.back().get();
+                p->mDescriptor = cv::Mat(1, 32, CV_8U);
+                std::memcpy(p->mDescriptor.ptr<uchar>(0), &rd_[(size_t)32 * i], 32);
+                p->nObs = 1; p->mbTrackInView = true;
+                p->mTrackProjX = ck[i].pt.x + 1.5f; p->mTrackProjY = ck[i].pt.y - 1.0f; p->mTrackProjXR = -1.f;
+                p->mnTrackScaleLevel = ck[i].octave; p->mTrackViewCos = 0.9f;
+                index_of[p] = i;
+                pts.push_back(p);
+            }
+            ORBmatcher matcher(0.8);
+            const int n1 = matcher.SearchByProjection(F, pts, 3);
+            dump_matches(F, "out_resident.bin");
+            F.mvpMapPoints.assign(F.N, static_cast<MapPoint *>(NULL));
+            const int n2 = matcher.SearchByProjection(F, pts, 3); // same frame again: cached grid
+            dump_matches(F, "out_resident2.bin");
+            wr("n_resident.bin", std::vector<int32_t>{n1, n2, F.N});
+            wr("resident_k.bin", rk); wr("resident_d.bin", rd_);
         }
         std::printf("compat selftest ok\n");
     } catch (const std::exception &e) {

@@ -144,3 +144,20 @@ def test_reference_signature_calls_match_the_oracle(tmp_path):
     assert np.array_equal(out("out_fuse_added.bin"), added)
     assert np.array_equal(out("out_fuse_pt_replaced.bin"), pt_repl) and np.array_equal(out("out_fuse_held_replaced.bin"), held_repl)
     assert (added >= 0).sum() > 10 and (pt_repl >= 0).sum() + (held_repl >= 0).sum() > 10
+    # 7. resident path: a real extraction inside the driver; SearchByProjection(F, points) on the extractor's latest frame
+    rk = np.fromfile(d / "resident_k.bin", O.KP_DTYPE); rdesc = np.fromfile(d / "resident_d.bin", np.uint8).reshape(-1, 32)
+    n1, n2, nF = out("n_resident.bin")
+    assert nF == len(rk) > 500
+    ex = O.Extractor()
+    kref, dref = ex.extract(np.fromfile(d / "real_image.bin", np.uint8).reshape(int(s["bounds"][3]), int(s["bounds"][1])))
+    assert np.array_equal(rk, kref) and np.array_equal(rdesc, dref)  # the mirror's operator() == oracle
+    idx = np.arange(0, nF, 2)
+    tpr = np.zeros(len(idx), O.TP_DTYPE)
+    tpr["in_view"] = 1; tpr["proj_x"] = rk["x"][idx] + np.float32(1.5); tpr["proj_y"] = rk["y"][idx] - np.float32(1.0); tpr["proj_xr"] = -1
+    tpr["level"] = rk["octave"][idx]; tpr["view_cos"] = 0.9
+    gr = O.Grid(rk, *s["bounds"])
+    ref, nref = O.search_by_projection_points(gr, np.full(nF, -1.0, np.float32), rdesc, s["sf"], tpr, rdesc[idx], np.ones(len(idx), np.int32),
+                                              np.zeros(nF, np.uint8), 3.0, 0.8)
+    want = np.where(ref >= 0, idx[np.maximum(ref, 0)], -1)
+    assert n1 == nref == n2 and nref > 200
+    assert np.array_equal(out("out_resident.bin"), want) and np.array_equal(out("out_resident2.bin"), want)

@@ -122,7 +122,7 @@ k1o, d1o = ex.extract(img1)
 
 def gpu4():
     f2 = ctx.rgbd_frame(img2, depth)
-    view = ctx._view(f2["kps"], f2["u_right"], f2["desc"], bounds)
+    view = ctx._view(f2["kps"], f2["u_right"], f2["desc"], bounds, device_slot=0)  # the frame just extracted, matched where it lies in HBM
     got, n = ctx.search_by_projection_last(view, T_cur, T_last, pos, f1["desc"], valid, obs, f1["kps"]["octave"].copy(),
                                            f1["kps"]["angle"].copy(), None, 7.0, False, True)
     res["g4"] = (n, got)
