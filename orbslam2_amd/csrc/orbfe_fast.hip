@@ -63,6 +63,20 @@ template <int P> __device__ __forceinline__ pk16 row_pair(const unsigned (&w)[3]
         return __builtin_bit_cast(pk16, __builtin_amdgcn_perm(w[2], w[1], (unsigned)(P - 4) | 0x0c00u | ((unsigned)(P - 3) << 16) | 0x0c000000u));
 }
 
+// ---- packed half-precision min / max for the exact score (phase C) ------------------------------------------------------
+// gfx950 issues every min / max opcode -- integer, packed, float alike -- once per ~4 cycles per SIMD, and a few plain ops (add, sub,
+// and, xor, mov, fp32 fma) once per ~2 (profiles/r02_valu_peak.json).  The packed opcode that does more per issue slot is
+// CDNA4's three-operand v_pk_maximum3_f16 / v_pk_minimum3_f16: two comparisons in each 16-bit half.  A pixel p becomes the
+// half-precision number 1024 + p by XOR-ing 0x6400 into its zero-extended 16-bit lane (integers up to 2048 are exact in f16, and
+// so is every difference formed below) -- the XOR that sign-normalises the entry anyway, so the conversion costs nothing.
+// Inline asm: the f16 min / max builtins make the compiler quiet signalling NaNs first (an extra op per operand).
+__device__ __forceinline__ unsigned h2min(unsigned a, unsigned b) { unsigned d; asm("v_pk_min_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ unsigned h2max(unsigned a, unsigned b) { unsigned d; asm("v_pk_max_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ unsigned h2min3(unsigned a, unsigned b, unsigned c) { unsigned d; asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ unsigned h2max3(unsigned a, unsigned b, unsigned c) { unsigned d; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ unsigned h2add(unsigned a, unsigned b) { unsigned d; asm("v_pk_add_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ unsigned h2sub(unsigned a, unsigned b) { unsigned d; asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+
 // TP = tile pitch in bytes as a compile-time constant (0: run-time value): with it every ring / row offset folds
 // into the immediate offset field of the LDS instructions instead of costing address VALU.
 // BK: also accumulate the quadtree bucket counts / best keys of the survivors (orbfe_octree3.hip) -- aggregated per
@@ -198,7 +212,6 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
     roff[4] = 3;                   roff[5] = -tile_pitch + 3;      roff[6] = -2 * tile_pitch + 2;  roff[7] = -3 * tile_pitch + 1;
     roff[8] = -3 * tile_pitch;     roff[9] = -3 * tile_pitch - 1;  roff[10] = -2 * tile_pitch - 2; roff[11] = -tile_pitch - 3;
     roff[12] = -3;                 roff[13] = tile_pitch - 3;      roff[14] = 2 * tile_pitch - 2;  roff[15] = 3 * tile_pitch - 1;
-    const pk16 tt = {(short)t, (short)t};
     // ---- A: cv::FAST's quick test on the 8 opposite ring pairs, for every interior pixel: a dark
     //      (bright) 9-arc needs one darker (brighter) pixel in every pair.  Passing BOTH polarities means
     //      every pair straddles the centre, which excludes any 9-arc, so such pixels are dropped;
@@ -272,8 +285,12 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
     }
     FAST_WAVE_SYNC();
     if (ORBFE_CUT(3)) { if (lane == 0) *cnt_out = 0; return; }
-    // ---- C: exact score for the entry's polarity: max over the 16 arcs of the min of 9 (sign-normalised)
-    //      differences; windows of 2, 4, 8 (+1) by doubling. ----
+    // ---- C: exact score for the entry's polarity: max over the 16 arcs of the min of the arc's 9 differences v - r_k
+    //      = v' - min over arcs of (max of the arc's ring values); the maximum of a 9-arc is the maximum of three 3-arc maxima,
+    //      so the whole score is 16 + 16 three-way maxima and 8 three-way minima (v_pk_maximum3_f16 / v_pk_minimum3_f16, two
+    //      queue entries per lane, one in each half) instead of 80 two-way ones.  Bright entries are negated (centre and ring),
+    //      which maps their score onto the dark formula; both the negation and the byte -> f16 conversion are ONE xor. ----
+    const unsigned tt16 = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(float)t) * 0x10001u; // t in both halves
     for (int q0 = 0; q0 < n2; q0 += 128) {
         const int qa = q0 + lane, qb = q0 + 64 + lane;
         const bool va = qa < n2, vb = qb < n2;
@@ -281,25 +298,28 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
         const int ra = (ea >> 8) & 127, ca = ea & 255, rb = (eb >> 8) & 127, cb = eb & 255;
         const uint8_t *pa = &s_tile[(ra + 3) * tile_pitch + ca + 3 + ox];
         const uint8_t *pb = &s_tile[(rb + 3) * tile_pitch + cb + 3 + ox];
-        // sign-normalise by complementing bright entries (x -> -x-1 in both centre and ring keeps differences):
-        // score = max_arcs min_arc (v' - r'_k) = v' - min_arcs max_arc r'_k, so the arcs run on raw ring values
-        const pk16 sg = {(short)((ea & 0x8000u) ? -1 : 0), (short)((eb & 0x8000u) ? -1 : 0)};
-        const pk16 vv = (pk16){(short)pa[0], (short)pb[0]} ^ sg;
-        pk16 e[16];
+        // 0x6400: p -> 1024 + p; 0x8000 more for a bright entry: -> -(1024 + p)
+        const unsigned fx = 0x64006400u ^ ((ea & 0x8000u) ? 0x8000u : 0u) ^ ((eb & 0x8000u) ? 0x80000000u : 0u);
+        // one v_perm_b32 packs the two bytes into the two halves, one full-rate v_xor_b32 converts / negates (spelled this way
+        // because the compiler otherwise picks a shift + a three-input or: two half-rate ops)
+        auto pack = [&](unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x0c040c00u) ^ fx; };
+        const unsigned vv = pack(pa[0], pb[0]);
+        unsigned e[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) e[k] = (pk16){(short)pa[roff[k]], (short)pb[roff[k]]} ^ sg;
-        pk16 m2[16], m4[16];
+        for (int k = 0; k < 16; k++) e[k] = pack(pa[roff[k]], pb[roff[k]]);
+        unsigned m3[16], m9[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_max(e[k], e[(k + 1) & 15]);
+        for (int k = 0; k < 16; k++) m3[k] = h2max3(e[k], e[(k + 1) & 15], e[(k + 2) & 15]);
 #pragma unroll
-        for (int k = 0; k < 16; k++) m4[k] = __builtin_elementwise_max(m2[k], m2[(k + 2) & 15]);
-        pk16 worst = {512, 512};
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            worst = __builtin_elementwise_min(worst, __builtin_elementwise_max(__builtin_elementwise_max(m4[k], m4[(k + 4) & 15]), e[(k + 8) & 15]));
-        pk16 best = vv - worst;
-        best = __builtin_elementwise_max(best, tt);
-        const int sa = (int)best.x - 1, sb = (int)best.y - 1;
+        for (int k = 0; k < 16; k++) m9[k] = h2max3(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
+        unsigned worst = h2min3(m9[0], m9[1], m9[2]);
+        worst = h2min3(worst, m9[3], m9[4]); worst = h2min3(worst, m9[5], m9[6]); worst = h2min3(worst, m9[7], m9[8]);
+        worst = h2min3(worst, m9[9], m9[10]); worst = h2min3(worst, m9[11], m9[12]); worst = h2min3(worst, m9[13], m9[14]);
+        worst = h2min(worst, m9[15]);
+        // best = max(v' - worst, t): an exact f16 integer in [t, 255]; + 1023 puts score = best - 1 into the low mantissa bits
+        const unsigned best = h2max(h2sub(vv, worst), tt16);
+        const unsigned sc2 = h2add(best, 0x63fe63feu);
+        const int sa = (int)(sc2 & 0xffu), sb = (int)((sc2 >> 16) & 0xffu);
         if (va && sa >= t) s_sc[(ra + 1) * scp + ca + 1] = (uint8_t)sa;
         if (vb && sb >= t) s_sc[(rb + 1) * scp + cb + 1] = (uint8_t)sb;
     }
