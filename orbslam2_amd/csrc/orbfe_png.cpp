@@ -123,12 +123,6 @@ int parse(const uint8_t *file, size_t size, Chunks &c, bool want_data)
     return ORBFE_OK;
 }
 
-inline int paeth(int a, int b, int c)
-{
-    const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
-    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-}
-
 // Reverses the scanline filter of one row in place (cur has the filter-type byte at cur[-1]; prev = reconstructed previous row
 // of the same pass, or null for the first row); bpp = bytes per complete pixel, at least 1.
 int unfilter_row(uint8_t *cur, const uint8_t *prev, size_t n, int bpp)
@@ -149,9 +143,20 @@ int unfilter_row(uint8_t *cur, const uint8_t *prev, size_t n, int bpp)
         }
         break;
     case 4:
-        for (size_t i = 0; i < n; i++) {
-            const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev ? prev[i] : 0, c = (prev && i >= (size_t)bpp) ? prev[i - bpp] : 0;
-            cur[i] = (uint8_t)(cur[i] + paeth(a, b, c));
+        if (!prev) { // first row: b = c = 0, the predictor is a
+            for (size_t i = (size_t)bpp; i < n; i++) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]);
+            break;
+        }
+        for (size_t i = 0; i < (size_t)bpp && i < n; i++) cur[i] = (uint8_t)(cur[i] + prev[i]); // a = c = 0: the predictor is b
+        for (size_t i = (size_t)bpp; i < n; i++) { // the same decision as paeth(), with the shared differences formed once
+            int a = cur[i - bpp];
+            const int b = prev[i], c = prev[i - bpp];
+            const int p = b - c, q = a - c;
+            int pa = p < 0 ? -p : p;
+            const int pb = q < 0 ? -q : q, pc = (p + q) < 0 ? -(p + q) : (p + q);
+            if (pb < pa) { pa = pb; a = b; }
+            if (pc < pa) a = c;
+            cur[i] = (uint8_t)(cur[i] + a);
         }
         break;
     default: return png_fail("invalid filter type");
