@@ -1,0 +1,96 @@
+"""C oracle == literal Python transcription of the reference's extractor / stereo loops (oracle/literal_extractor.py).
+
+The C oracle restates ORBextractor.cc and Frame::ComputeStereoMatches with arrays and index lists; the literal file replays
+the reference's own containers (std::list push_front / erase, per-row candidate vectors, 11x11 float SAD) in Python on top of
+the same OpenCV-primitive routines.  Whole-image equality of keypoints (all six fields, float bits), descriptors, mvuRight and
+mvDepth says the two independent restatements of the reference's control flow agree.  CPU only, small images."""
+import numpy as np
+import pytest
+
+from oracle import literal_extractor as LX
+from oracle import oracle as O
+from orbslam2_amd import synth
+
+
+def _lit_table(keys):
+    return np.array([(k.x, k.y, k.size, k.angle, k.response, k.octave) for k in keys], np.float32).reshape(-1, 6)
+
+
+def _orc_table(k):
+    return np.stack([k["x"], k["y"], k["size"], k["angle"], k["response"], k["octave"].astype(np.float32)], 1)
+
+
+CASES = [
+    # (width, height, seed, nfeatures, scale, levels, iniTh, minTh)
+    (400, 240, 5, 500, 1.2, 8, 20, 7),     # default parameters
+    (400, 240, 6, 60, 1.2, 8, 20, 7),      # few features: the quadtree stops in its size-ordered inner loop at every level
+    (320, 200, 7, 4000, 1.2, 4, 20, 7),    # more features than corners: every node ends with one point
+    (360, 250, 8, 300, 1.5, 4, 12, 5),     # other scale factor / thresholds
+    (250, 380, 9, 300, 1.2, 6, 40, 7),     # portrait image (one initial node), high iniTh so cells fall back to minTh
+]
+
+
+@pytest.mark.parametrize("w,h,seed,nf,sf,nl,ini,mn", CASES)
+def test_extractor_literal_vs_oracle(w, h, seed, nf, sf, nl, ini, mn):
+    left, _ = synth.stereo_pair(w, h, seed=seed, bf=60.0)
+    lit = LX.LiteralExtractor(nf, sf, nl, ini, mn)
+    orc = O.Extractor(nf, sf, nl, ini, mn)
+    assert lit.mnFeaturesPerLevel == list(orc.features_per_level())
+    assert lit.umax == list(orc.umax())
+    assert np.array_equal(np.array(lit.mvScaleFactor, np.float32), orc.scale_factors())
+    assert np.array_equal(np.array(lit.mvInvScaleFactor, np.float32), orc.inv_scale_factors())
+    assert np.array_equal(np.array(lit.mvLevelSigma2, np.float32), orc.sigma2())
+    assert np.array_equal(np.array(lit.mvInvLevelSigma2, np.float32), orc.inv_sigma2())
+    keys, desc = lit(left)
+    k, d = orc.extract(left)
+    assert len(keys) == len(k) and len(k) > 30
+    assert np.array_equal(_lit_table(keys).view(np.uint32), _orc_table(k).view(np.uint32))
+    assert np.array_equal(desc, d)
+    for level in range(nl):
+        assert np.array_equal(lit.mvImagePyramid[level], orc.pyramid_level(level))
+
+
+@pytest.mark.parametrize("w,h,seed,nf,bf,fx", [(400, 240, 5, 500, 60.0, 300.0), (480, 260, 11, 800, 120.0, 400.0)])
+def test_stereo_matches_literal_vs_oracle(w, h, seed, nf, bf, fx):
+    left, right = synth.stereo_pair(w, h, seed=seed, bf=bf)
+    litL, litR = LX.LiteralExtractor(nf), LX.LiteralExtractor(nf)
+    kL, dL = litL(left)
+    kR, dR = litR(right)
+    orcL, orcR = O.Extractor(nf), O.Extractor(nf)
+    okL, odL = orcL.extract(left)
+    okR, odR = orcR.extract(right)
+    ur, dp = LX.compute_stereo_matches(litL, litR, kL, dL, kR, dR, bf, fx)
+    ur2, dp2, m = O.stereo_matches(orcL, orcR, okL, odL, okR, odR, bf, fx)
+    assert m > 50 and int((ur >= 0).sum()) == m
+    assert np.array_equal(ur.view(np.uint32), ur2.view(np.uint32))
+    assert np.array_equal(dp.view(np.uint32), dp2.view(np.uint32))
+
+
+def test_quadtree_literal_vs_oracle_on_adversarial_points():
+    """Clustered, duplicated and tied-response points straight into DistributeOctTree (both formulations)."""
+    rng = np.random.default_rng(3)
+    for trial in range(12):
+        n = int(rng.integers(1, 400))
+        min_x, min_y = 16, 16
+        max_x, max_y = 16 + int(rng.integers(60, 500)), 16 + int(rng.integers(40, 200))
+        if round((max_x - min_x) / (max_y - min_y)) < 1:
+            max_x = min_x + (max_y - min_y)
+        xs = rng.integers(0, max_x - min_x, n)
+        ys = rng.integers(0, max_y - min_y, n)
+        if trial % 3 == 0:  # heavy clustering: many points in a few pixels
+            xs = (xs // 40) * 40 + rng.integers(0, 3, n)
+            ys = (ys // 40) * 40 + rng.integers(0, 3, n)
+            xs = np.minimum(xs, max_x - min_x - 1); ys = np.minimum(ys, max_y - min_y - 1)
+        # cv::FAST never emits the same pixel twice and the cell loop does not overlap emission areas: keep positions unique
+        _, first = np.unique(xs * 10000 + ys, return_index=True)
+        first.sort()
+        xs, ys = xs[first].astype(np.int32), ys[first].astype(np.int32)
+        sc = rng.integers(7, 12 if trial % 2 else 120, len(xs)).astype(np.int32)  # many equal responses on odd trials
+        target = int(rng.integers(1, 300))
+        lit = LX.LiteralExtractor(1000)
+        keys = [LX.KeyPoint(float(x), float(y), 7.0, -1.0, float(s), 0) for x, y, s in zip(xs, ys, sc)]
+        res = lit.DistributeOctTree(keys, min_x, max_x, min_y, max_y, target, 0)
+        sel = O.distribute_octtree(xs, ys, sc, min_x, max_x, min_y, max_y, target)
+        got = [(float(k.x), float(k.y), float(k.response)) for k in res]
+        want = [(float(xs[i]), float(ys[i]), float(sc[i])) for i in sel]
+        assert got == want, (trial, len(got), len(want))
