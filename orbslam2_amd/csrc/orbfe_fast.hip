@@ -32,10 +32,9 @@ __device__ __forceinline__ int fast_score16(const uint8_t *t, int pitch, int min
 // and wave-ordered ballot compaction keeps every queue in row-major order, which is cv::FAST's
 // emission order.  Phases:
 //  0  aligned 32-bit loads of the (w+6)x(h+6) cell tile into LDS;
-//  A  cheap necessary test on the 4 cardinal ring pixels (a 9-arc always holds two adjacent
-//     cardinals)                                                        -> queue 1
-//  B  OpenCV's 8-opposite-pairs necessary test on the full ring         -> queue 2
-//  C  exact threshold-independent score (closed form of cornerScore<16>) for queue 2
+//  A  a necessary test on the four even opposite ring pairs for every interior pixel (a 9-arc holds one pixel of every
+//     opposite pair) -> ordered queue (+ a side list for pixels that pass both polarities)
+//  C  exact threshold-independent score (closed form of cornerScore<16>) for the queue
 //  D  strict 3x3 NMS inside the cell interior; iniThFAST, or minThFAST if that leaves nothing
 //  E  ordered compaction of the survivors into the cell's slot.
 __device__ __forceinline__ void load_ring(const uint8_t *t, int pitch, int d[16])
@@ -61,6 +60,31 @@ template <int P> __device__ __forceinline__ pk16 row_pair(const unsigned (&w)[3]
         return __builtin_bit_cast(pk16, __builtin_amdgcn_perm(w[1], w[0], (unsigned)P | 0x0c00u | ((unsigned)(P + 1) << 16) | 0x0c000000u));
     else
         return __builtin_bit_cast(pk16, __builtin_amdgcn_perm(w[2], w[1], (unsigned)(P - 4) | 0x0c00u | ((unsigned)(P - 3) << 16) | 0x0c000000u));
+}
+
+// x + (bit `lane` of m): one v_addc_co_u32 with the ballot as carry-in (the compiler's own `x += pred` is a select plus an add)
+__device__ __forceinline__ int add_lane_bit(int x, unsigned long long m)
+{
+    int r;
+    unsigned long long c;
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r), "=s"(c) : "v"(x), "s"(m));
+    return r;
+}
+
+// ballots of "the low / high 16-bit half is negative", one compare each (spelled in C they cost an extraction per low half, and
+// a ballot plus an `if` on the same condition is lowered twice), and a 16-bit LDS store under such a ballot
+__device__ __forceinline__ unsigned long long neg_lo16(unsigned v) { unsigned long long m; asm("v_cmp_gt_i16_e64 %0, 0, %1" : "=s"(m) : "v"(v)); return m; }
+__device__ __forceinline__ unsigned long long neg_hi16(unsigned v) { unsigned long long m; asm("v_cmp_gt_i32_e64 %0, 0, %1" : "=s"(m) : "v"(v)); return m; }
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void *)p; }
+__device__ __forceinline__ void lds_store_lo16(unsigned long long m, unsigned addr, unsigned v)
+{
+    unsigned long long save;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16 %2, %3\n\ts_or_b64 exec, exec, %0" : "=&s"(save) : "s"(m), "v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_store_hi16(unsigned long long m, unsigned addr, unsigned v)
+{
+    unsigned long long save;
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16_d16_hi %2, %3\n\ts_or_b64 exec, exec, %0" : "=&s"(save) : "s"(m), "v"(addr), "v"(v) : "memory");
 }
 
 // ---- packed half-precision min / max for the exact score (phase C) ------------------------------------------------------
@@ -212,124 +236,163 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
     roff[4] = 3;                   roff[5] = -tile_pitch + 3;      roff[6] = -2 * tile_pitch + 2;  roff[7] = -3 * tile_pitch + 1;
     roff[8] = -3 * tile_pitch;     roff[9] = -3 * tile_pitch - 1;  roff[10] = -2 * tile_pitch - 2; roff[11] = -tile_pitch - 3;
     roff[12] = -3;                 roff[13] = tile_pitch - 3;      roff[14] = 2 * tile_pitch - 2;  roff[15] = 3 * tile_pitch - 1;
-    // ---- A: cv::FAST's quick test on the 8 opposite ring pairs, for every interior pixel: a dark
-    //      (bright) 9-arc needs one darker (brighter) pixel in every pair.  Passing BOTH polarities means
-    //      every pair straddles the centre, which excludes any 9-arc, so such pixels are dropped;
-    //      survivors are queued in row-major order with their polarity in bit 15.
-    //      A lane owns FOUR horizontally adjacent pixels whose tile bytes are 3..6 of a 12-byte window
-    //      (3 aligned LDS words per ring row, 21 per group): every ring column x-3..x+3 of the four pixels
-    //      lies inside the window, so each ring position is two v_perm_b32 with constant selectors, and the
-    //      test runs on raw ring values (with d = v - r: min_k max(d_k, d_k+8) = v - max_k min(r_k, r_k+8)). ----
+    // ---- C (defined first: phase A calls it when its side list fills up): exact score for the entry's polarity: max over the
+    //      16 arcs of the min of the arc's 9 differences v - r_k = v' - min over arcs of (max of the arc's ring values); the
+    //      maximum of a 9-arc is the maximum of three 3-arc maxima, so the whole score is 16 + 16 three-way maxima and 8 three-way
+    //      minima (v_pk_maximum3_f16 / v_pk_minimum3_f16, two queue entries per lane, one in each half) instead of 80 two-way
+    //      ones.  Bright entries are negated (centre and ring), which maps their score onto the dark formula; both the negation
+    //      and the byte -> f16 conversion are ONE xor.  Entries: c | (r + 1) << 8 | bright << 15. ----
+    const unsigned tt16 = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(float)t) * 0x10001u; // t in both halves
+    auto score_entries = [&](int count, auto fetch) {
+        for (int q0 = 0; q0 < count; q0 += 128) {
+            const int qa = q0 + lane, qb = q0 + 64 + lane;
+            const bool va = qa < count, vb = qb < count;
+            const unsigned ea = fetch(va ? qa : 0), eb = fetch(vb ? qb : 0);
+            const int ra = (ea >> 8) & 63, ca = ea & 255, rb = (eb >> 8) & 63, cb = eb & 255; // ra, rb = row + 1
+            const uint8_t *pa = &s_tile[(ra + 2) * tile_pitch + ca + 3 + ox];
+            const uint8_t *pb = &s_tile[(rb + 2) * tile_pitch + cb + 3 + ox];
+            // 0x6400: p -> 1024 + p; 0x8000 more for a bright entry: -> -(1024 + p)
+            const unsigned fx = 0x64006400u ^ ((ea & 0x8000u) ? 0x8000u : 0u) ^ ((eb & 0x8000u) ? 0x80000000u : 0u);
+            // one v_perm_b32 packs the two bytes into the two halves, one full-rate v_xor_b32 converts / negates (spelled this
+            // way because the compiler otherwise picks a shift + a three-input or: two half-rate ops)
+            auto pack = [&](unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x0c040c00u) ^ fx; };
+            const unsigned vv = pack(pa[0], pb[0]);
+            unsigned e[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) e[k] = pack(pa[roff[k]], pb[roff[k]]);
+            unsigned m3[16], m9[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) m3[k] = h2max3(e[k], e[(k + 1) & 15], e[(k + 2) & 15]);
+#pragma unroll
+            for (int k = 0; k < 16; k++) m9[k] = h2max3(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
+            unsigned worst = h2min3(m9[0], m9[1], m9[2]);
+            worst = h2min3(worst, m9[3], m9[4]); worst = h2min3(worst, m9[5], m9[6]); worst = h2min3(worst, m9[7], m9[8]);
+            worst = h2min3(worst, m9[9], m9[10]); worst = h2min3(worst, m9[11], m9[12]); worst = h2min3(worst, m9[13], m9[14]);
+            worst = h2min(worst, m9[15]);
+            // best = max(v' - worst, t): an exact f16 integer in [t, 255]; + 1023 puts score = best - 1 into the low mantissa bits
+            const unsigned best = h2max(h2sub(vv, worst), tt16);
+            const unsigned sc2 = h2add(best, 0x63fe63feu);
+            const int sa = (int)(sc2 & 0xffu), sb = (int)((sc2 >> 16) & 0xffu);
+            if (va && sa >= t) s_sc[ra * scp + ca + 1] = (uint8_t)sa;
+            if (vb && sb >= t) s_sc[rb * scp + cb + 1] = (uint8_t)sb;
+        }
+    };
+    // ---- A: a quick NECESSARY test for every interior pixel on the four EVEN opposite ring pairs (0/8, 2/10, 4/12, 6/14): a dark
+    //      (bright) 9-arc holds one pixel of every opposite pair, so it needs one darker (brighter) pixel in each of the four.
+    //      cv::FAST's own quick test uses all eight pairs; half of them admit 15 % more pixels on the benchmark images (all of
+    //      which the exact score of phase C then rejects) for half the extraction and min / max work, and only tile rows
+    //      0, 1, 3, 5, 6 of a pixel's 7-row window are read.  With four pairs a pixel can pass BOTH polarities and still be a
+    //      corner of one of them (with eight it cannot): it is queued as bright, and once more as dark on a side list that phase
+    //      C scores too but phases D / E never see (0.2 % of the pixels).  Survivors are queued in row-major order.
+    //      A lane owns FOUR horizontally adjacent pixels whose tile bytes are 3..6 of a 12-byte window (3 aligned LDS words per
+    //      ring row): every ring column x-3..x+3 of the four pixels lies inside the window, so each ring position is two
+    //      v_perm_b32 with constant selectors, and the test runs on raw ring values (with d = v - r:
+    //      min_k max(d_k, d_k+8) = v - max_k min(r_k, r_k+8)); a zero-extended byte is also a half-precision denormal that
+    //      orders like the byte, so the two three-way reductions are one v_pk_maximum3_f16 / v_pk_minimum3_f16 each. ----
+    uint16_t *s_xq = (uint16_t *)(s_mem + tile_bytes + sc_bytes + q_bytes); // side list, 256 entries (phase E's accumulators later)
+    int nx = 0;
     {
+        // lane -> (row rl of the iteration's band, group jg) with jg FIXED per lane: a band is dr = 64 / ng whole rows (ng <= 16
+        // because FAST cells are < 60 px wide, src/ORBextractor.cc:766-775; 8-10 for every level of the usual cameras, so 94-100 %
+        // of the lanes work), which makes the column range checks, the entry's column part and the LDS column offset loop
+        // invariants and leaves one add each for the address and the entries per iteration
         const int ng = (iw + ox + 3) >> 2;       // groups per interior row; group j covers c = 4j - ox .. 4j - ox + 3
-        const int G = ng * ih;
-        const float rcp_ng = 1.0f / (float)ng;
-        int rg = (int)(((float)lane + 0.5f) * rcp_ng), jg = lane - rg * ng;
-        const int dr = 64 / ng, dj = 64 - dr * ng;
+        const int dr = 64 / ng;
+        const int rl = (int)(((float)lane + 0.5f) * (1.0f / (float)ng)), jg = lane - rl * ng;
         const int pw = tile_pitch >> 2;
-        for (int g0 = 0; g0 < G; g0 += 64) {
-            const bool vg = g0 + lane < G;
-            const uint32_t *tw4 = (const uint32_t *)s_tile + (vg ? __mul24(rg, pw) + jg : 0);
-            unsigned w[7][3];
+        const pk16 tp = {(short)t, (short)t};
+        const int c0 = 4 * jg - ox;
+        const bool act = rl < dr;
+        const bool b0 = act & (c0 >= 0), b1 = act & ((unsigned)(c0 + 1) < (unsigned)iw);
+        const bool b2 = act & ((unsigned)(c0 + 2) < (unsigned)iw), b3 = act & (c0 + 3 < iw);
+        // which of the lane's four pixels exist, as sign bits of the halves (a ballot of `value & mask != 0` is one compare; a
+        // ballot of a boolean expression is a select plus a compare); the last band may be cut by the cell's bottom
+        unsigned vm01 = (b0 ? 0x8000u : 0u) | (b1 ? 0x80000000u : 0u), vm23 = (b2 ? 0x8000u : 0u) | (b3 ? 0x80000000u : 0u);
+        const int r0_last = ((ih - 1) / dr) * dr;
+        const bool in_last = r0_last + rl < ih;
+        const unsigned vl01 = in_last ? vm01 : 0u, vl23 = in_last ? vm23 : 0u;
+        // entries c | (r + 1) << 8 of the pixel pairs in the two halves (the row bias keeps the word positive when c0 < 0, which
+        // only happens for pixels that are never stored)
+        unsigned e01 = __umul24((unsigned)(((rl + 1) << 8) + c0), 0x10001u) + 0x10000u;
+        const unsigned e_step = (unsigned)(dr << 8) * 0x10001u;
+        const uint32_t *tw4 = (const uint32_t *)s_tile + (__mul24(rl, pw) + jg);
+        for (int r0 = 0; r0 < ih; r0 += dr, tw4 += dr * pw, e01 += e_step) {
+            if (r0 == r0_last) { vm01 = vl01; vm23 = vl23; } // rows past the cell read LDS beyond the tile (still this wave's region)
+            unsigned w0[3], w1[3], w3[3], w5[3], w6[3];
 #pragma unroll
-            for (int y = 0; y < 7; y++) {
-#pragma unroll
-                for (int i = 0; i < 3; i++) w[y][i] = tw4[y * pw + i];
+            for (int i = 0; i < 3; i++) {
+                w0[i] = tw4[i]; w1[i] = tw4[pw + i]; w3[i] = tw4[3 * pw + i]; w5[i] = tw4[5 * pw + i]; w6[i] = tw4[6 * pw + i];
             }
-            pk16 A01, A23, B01, B23;
-#define FAST_PAIR(first, ya, sa, yb, sb)                                                                          \
+            pk16 n01[4], x01[4], n23[4], x23[4];
+#define FAST_PAIR(i, wa, sa, wb, sb)                                                                              \
     {                                                                                                             \
-        const pk16 a01 = row_pair<sa>(w[ya]), a23 = row_pair<sa + 2>(w[ya]);                                     \
-        const pk16 b01 = row_pair<sb>(w[yb]), b23 = row_pair<sb + 2>(w[yb]);                                     \
-        const pk16 n01 = __builtin_elementwise_min(a01, b01), x01 = __builtin_elementwise_max(a01, b01);          \
-        const pk16 n23 = __builtin_elementwise_min(a23, b23), x23 = __builtin_elementwise_max(a23, b23);          \
-        if (first) { A01 = n01; B01 = x01; A23 = n23; B23 = x23; }                                                \
-        else {                                                                                                    \
-            A01 = __builtin_elementwise_max(A01, n01); B01 = __builtin_elementwise_min(B01, x01);                 \
-            A23 = __builtin_elementwise_max(A23, n23); B23 = __builtin_elementwise_min(B23, x23);                 \
-        }                                                                                                         \
+        const pk16 a01 = row_pair<sa>(wa), a23 = row_pair<sa + 2>(wa);                                           \
+        const pk16 b01 = row_pair<sb>(wb), b23 = row_pair<sb + 2>(wb);                                           \
+        n01[i] = __builtin_elementwise_min(a01, b01); x01[i] = __builtin_elementwise_max(a01, b01);               \
+        n23[i] = __builtin_elementwise_min(a23, b23); x23[i] = __builtin_elementwise_max(a23, b23);               \
     }
             // ring pairs (k, k+8): (dx, dy) -> window start byte 3 + dx, tile row 3 + dy
-            FAST_PAIR(true, 6, 3, 0, 3)   // ( 0, 3) / ( 0,-3)
-            FAST_PAIR(false, 6, 4, 0, 2)  // ( 1, 3) / (-1,-3)
-            FAST_PAIR(false, 5, 5, 1, 1)  // ( 2, 2) / (-2,-2)
-            FAST_PAIR(false, 4, 6, 2, 0)  // ( 3, 1) / (-3,-1)
-            FAST_PAIR(false, 3, 6, 3, 0)  // ( 3, 0) / (-3, 0)
-            FAST_PAIR(false, 2, 6, 4, 0)  // ( 3,-1) / (-3, 1)
-            FAST_PAIR(false, 1, 5, 5, 1)  // ( 2,-2) / (-2, 2)
-            FAST_PAIR(false, 0, 4, 6, 2)  // ( 1,-3) / (-1, 3)
+            FAST_PAIR(0, w6, 3, w0, 3)  // ( 0, 3) / ( 0,-3)
+            FAST_PAIR(1, w5, 5, w1, 1)  // ( 2, 2) / (-2,-2)
+            FAST_PAIR(2, w3, 6, w3, 0)  // ( 3, 0) / (-3, 0)
+            FAST_PAIR(3, w1, 5, w5, 1)  // ( 2,-2) / (-2, 2)
 #undef FAST_PAIR
-            const pk16 v01 = row_pair<3>(w[3]), v23 = row_pair<5>(w[3]);
-            const pk16 lo01 = v01 - A01, hi01 = v01 - B01, lo23 = v23 - A23, hi23 = v23 - B23;
-            const int c0 = 4 * jg - ox;
-            const bool d0 = lo01.x > t, b0 = hi01.x < -t, d1 = lo01.y > t, b1 = hi01.y < -t;
-            const bool d2 = lo23.x > t, b2 = hi23.x < -t, d3 = lo23.y > t, b3 = hi23.y < -t;
-            const bool p0 = vg & (c0 >= 0) & (d0 != b0);
-            const bool p1 = vg & (c0 + 1 >= 0) & (c0 + 1 < iw) & (d1 != b1);
-            const bool p2 = vg & (c0 + 2 >= 0) & (c0 + 2 < iw) & (d2 != b2);
-            const bool p3 = vg & (c0 + 3 < iw) & (d3 != b3);
-            const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1), m2 = __ballot(p2), m3 = __ballot(p3);
-            int pos = n2 + (int)mbcnt64(m3, mbcnt64(m2, mbcnt64(m1, mbcnt64(m0, 0u))));
-            const int e = (rg << 8) + c0; // c0 < 0 only for pixels that are never stored
-            if (p0) s_q2[pos] = (uint16_t)(e | (b0 ? 0x8000 : 0));
-            pos += p0;
-            if (p1) s_q2[pos] = (uint16_t)((e + 1) | (b1 ? 0x8000 : 0));
-            pos += p1;
-            if (p2) s_q2[pos] = (uint16_t)((e + 2) | (b2 ? 0x8000 : 0));
-            pos += p2;
-            if (p3) s_q2[pos] = (uint16_t)((e + 3) | (b3 ? 0x8000 : 0));
+            auto u = [](pk16 v) { return __builtin_bit_cast(unsigned, v); };
+            auto k = [](unsigned v) { return __builtin_bit_cast(pk16, v); };
+            const pk16 A01 = __builtin_elementwise_max(k(h2max3(u(n01[0]), u(n01[1]), u(n01[2]))), n01[3]);
+            const pk16 A23 = __builtin_elementwise_max(k(h2max3(u(n23[0]), u(n23[1]), u(n23[2]))), n23[3]);
+            const pk16 B01 = __builtin_elementwise_min(k(h2min3(u(x01[0]), u(x01[1]), u(x01[2]))), x01[3]);
+            const pk16 B23 = __builtin_elementwise_min(k(h2min3(u(x23[0]), u(x23[1]), u(x23[2]))), x23[3]);
+            const pk16 v01 = row_pair<3>(w3), v23 = row_pair<5>(w3);
+            // sign bit of a half: dq = A + t - v < 0 <=> v - A > t (dark), bq = v + t - B < 0 <=> B - v > t (bright)
+            const unsigned dq01 = u((A01 + tp) - v01), bq01 = u((v01 + tp) - B01);
+            const unsigned dq23 = u((A23 + tp) - v23), bq23 = u((v23 + tp) - B23);
+            const unsigned o01 = (dq01 | bq01) & vm01, o23 = (dq23 | bq23) & vm23;
+            const unsigned long long m0 = neg_lo16(o01), m1 = neg_hi16(o01), m2 = neg_lo16(o23), m3 = neg_hi16(o23);
+            // bright flag straight from bq's sign bits
+            const unsigned q01 = (bq01 & 0x80008000u) | e01, q23 = (bq23 & 0x80008000u) | (e01 + 0x20002u);
+            const int pos0 = n2 + (int)mbcnt64(m3, mbcnt64(m2, mbcnt64(m1, mbcnt64(m0, 0u))));
+            const int pos1 = add_lane_bit(pos0, m0), pos2 = add_lane_bit(pos1, m1), pos3 = add_lane_bit(pos2, m2);
+            lds_store_lo16(m0, lds_addr(s_q2 + pos0), q01);
+            lds_store_hi16(m1, lds_addr(s_q2 + pos1), q01);
+            lds_store_lo16(m2, lds_addr(s_q2 + pos2), q23);
+            lds_store_hi16(m3, lds_addr(s_q2 + pos3), q23);
             n2 += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
-            jg += dj; rg += dr;
-            if (jg >= ng) { jg -= ng; rg++; }
+            // both polarities passed: once more, as dark, on the side list (rare: uniform branch)
+            const unsigned xb01 = dq01 & bq01 & vm01, xb23 = dq23 & bq23 & vm23;
+            if (__builtin_amdgcn_ballot_w64((xb01 | xb23) != 0u) != 0ull) {
+                const bool x0 = (xb01 & 0x8000u) != 0u, x1 = (int)xb01 < 0, x2 = (xb23 & 0x8000u) != 0u, x3 = (int)xb23 < 0;
+                const unsigned long long y0 = __builtin_amdgcn_ballot_w64(x0), y1 = __builtin_amdgcn_ballot_w64(x1), y2 = __builtin_amdgcn_ballot_w64(x2), y3 = __builtin_amdgcn_ballot_w64(x3);
+                const int add = __popcll(y0) + __popcll(y1) + __popcll(y2) + __popcll(y3);
+                if (nx + add > 256) { // side list full: score what it holds now
+                    FAST_WAVE_SYNC();
+                    score_entries(nx, [&](int q) { return (unsigned)s_xq[q]; });
+                    FAST_WAVE_SYNC();
+                    nx = 0;
+                }
+                int xp = nx + (int)mbcnt64(y3, mbcnt64(y2, mbcnt64(y1, mbcnt64(y0, 0u))));
+                if (x0) s_xq[xp] = (uint16_t)(q01 & 0x7fffu);
+                xp += x0;
+                if (x1) s_xq[xp] = (uint16_t)((q01 >> 16) & 0x7fffu);
+                xp += x1;
+                if (x2) s_xq[xp] = (uint16_t)(q23 & 0x7fffu);
+                xp += x2;
+                if (x3) s_xq[xp] = (uint16_t)((q23 >> 16) & 0x7fffu);
+                nx += add;
+            }
         }
     }
     FAST_WAVE_SYNC();
     if (ORBFE_CUT(3)) { if (lane == 0) *cnt_out = 0; return; }
-    // ---- C: exact score for the entry's polarity: max over the 16 arcs of the min of the arc's 9 differences v - r_k
-    //      = v' - min over arcs of (max of the arc's ring values); the maximum of a 9-arc is the maximum of three 3-arc maxima,
-    //      so the whole score is 16 + 16 three-way maxima and 8 three-way minima (v_pk_maximum3_f16 / v_pk_minimum3_f16, two
-    //      queue entries per lane, one in each half) instead of 80 two-way ones.  Bright entries are negated (centre and ring),
-    //      which maps their score onto the dark formula; both the negation and the byte -> f16 conversion are ONE xor. ----
-    const unsigned tt16 = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(float)t) * 0x10001u; // t in both halves
-    for (int q0 = 0; q0 < n2; q0 += 128) {
-        const int qa = q0 + lane, qb = q0 + 64 + lane;
-        const bool va = qa < n2, vb = qb < n2;
-        const unsigned ea = s_q2[va ? qa : 0], eb = s_q2[vb ? qb : 0];
-        const int ra = (ea >> 8) & 127, ca = ea & 255, rb = (eb >> 8) & 127, cb = eb & 255;
-        const uint8_t *pa = &s_tile[(ra + 3) * tile_pitch + ca + 3 + ox];
-        const uint8_t *pb = &s_tile[(rb + 3) * tile_pitch + cb + 3 + ox];
-        // 0x6400: p -> 1024 + p; 0x8000 more for a bright entry: -> -(1024 + p)
-        const unsigned fx = 0x64006400u ^ ((ea & 0x8000u) ? 0x8000u : 0u) ^ ((eb & 0x8000u) ? 0x80000000u : 0u);
-        // one v_perm_b32 packs the two bytes into the two halves, one full-rate v_xor_b32 converts / negates (spelled this way
-        // because the compiler otherwise picks a shift + a three-input or: two half-rate ops)
-        auto pack = [&](unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x0c040c00u) ^ fx; };
-        const unsigned vv = pack(pa[0], pb[0]);
-        unsigned e[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) e[k] = pack(pa[roff[k]], pb[roff[k]]);
-        unsigned m3[16], m9[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) m3[k] = h2max3(e[k], e[(k + 1) & 15], e[(k + 2) & 15]);
-#pragma unroll
-        for (int k = 0; k < 16; k++) m9[k] = h2max3(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
-        unsigned worst = h2min3(m9[0], m9[1], m9[2]);
-        worst = h2min3(worst, m9[3], m9[4]); worst = h2min3(worst, m9[5], m9[6]); worst = h2min3(worst, m9[7], m9[8]);
-        worst = h2min3(worst, m9[9], m9[10]); worst = h2min3(worst, m9[11], m9[12]); worst = h2min3(worst, m9[13], m9[14]);
-        worst = h2min(worst, m9[15]);
-        // best = max(v' - worst, t): an exact f16 integer in [t, 255]; + 1023 puts score = best - 1 into the low mantissa bits
-        const unsigned best = h2max(h2sub(vv, worst), tt16);
-        const unsigned sc2 = h2add(best, 0x63fe63feu);
-        const int sa = (int)(sc2 & 0xffu), sb = (int)((sc2 >> 16) & 0xffu);
-        if (va && sa >= t) s_sc[(ra + 1) * scp + ca + 1] = (uint8_t)sa;
-        if (vb && sb >= t) s_sc[(rb + 1) * scp + cb + 1] = (uint8_t)sb;
-    }
+    // the ordered queue, then the side list
+    score_entries(n2 + nx, [&](int q) { return (unsigned)(q < n2 ? s_q2[q] : s_xq[q - n2]); });
     FAST_WAVE_SYNC();
     if (ORBFE_CUT(4)) { if (lane == 0) *cnt_out = 0; return; }
     // ---- D: NMS + threshold choice.  The first 256 queue entries (all of them for ordinary cells) keep their flag and
     //      coordinates in registers for the compaction of phase E; later ones go through the LDS flag array. ----
     bool any = false;
     auto nms_flag = [&](unsigned rc) {
-        const uint8_t *p = &s_sc[((rc >> 8) + 1) * scp + (rc & 255) + 1];
+        const uint8_t *p = &s_sc[(rc >> 8) * scp + (rc & 255) + 1]; // rc >> 8 = row + 1
         const int s = p[0];
         // all nine reads issued together (a short-circuit chain would be nine dependent LDS round trips)
         const int n0 = p[-scp - 1], n1 = p[-scp], n2_ = p[-scp + 1], n3 = p[-1], n4 = p[1], n5 = p[scp - 1], n6 = p[scp], n7 = p[scp + 1];
@@ -401,7 +464,7 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
         const int pos = p0 + lane;
         const bool v = pos < n_out;
         const unsigned rc = v ? (s_q2[pos] & 0x7fffu) : 0u;
-        const int r = rc >> 8, c = rc & 255;
+        const int r = (int)(rc >> 8) - 1, c = rc & 255;
         unsigned tx = 0u, ty = 0u;
         if (BK) { tx = (unsigned)__shfl((int)tabx, c, 64); ty = (unsigned)__shfl((int)taby, r, 64); }
         if (v) {
