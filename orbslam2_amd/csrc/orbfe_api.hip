@@ -354,6 +354,12 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
     ctx->params = p;
     int rc = build_config(ctx);
     if (rc != ORBFE_OK) { snprintf(g_err, sizeof(g_err), "%s", ctx->err); delete ctx; return rc; }
+    // the XCD-aware block maps divide block indices through a float reciprocal that is exact below 2^21 (xcd_map)
+    if (((size_t)ctx->cfg.cells_total / 4 + 1) * (size_t)p.max_images >= ((size_t)1 << 23) ||
+        ((size_t)ctx->cfg.sel_total / 4 + 1) * (size_t)p.max_images >= ((size_t)1 << 23)) {
+        delete ctx;
+        return fail(nullptr, ORBFE_ERR_CAPACITY, "max_images %d: more than 2^24 workgroups per launch", p.max_images);
+    }
     // edge threshold must cover the descriptor reach (pattern radius 18.4 + rounding) and the patch
     if (hipSetDevice(p.device) != hipSuccess) { delete ctx; return fail(nullptr, ORBFE_ERR_NO_DEVICE, "hipSetDevice failed"); }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return fail(nullptr, ORBFE_ERR_NO_DEVICE, "hipStreamCreate failed"); }

@@ -54,11 +54,14 @@ __host__ __forceinline__ int xcd_grid(int blocks_per_unit, int n_units)
     const int lg = xcd_split_log2(n_units), per_xcd = (blocks_per_unit + (1 << lg) - 1) >> lg, side = 8 >> lg;
     return per_xcd * ((n_units + side - 1) / side) * 8;
 }
+// a / b for 0 <= a < 2^21, b >= 1: exact through the 1-ulp reciprocal (the quotient's distance to the next integer, 0.5 / b,
+// exceeds (a / b) * 2^-22); six VALU operations instead of the compiler's integer-division sequence
+__device__ __forceinline__ int small_div(int a, int b) { return (int)(((float)a + 0.5f) * __builtin_amdgcn_rcpf((float)b)); }
 __device__ __forceinline__ bool xcd_map(int blocks_per_unit, int n_units, int &unit, int &blk)
 {
     const int lg = xcd_split_log2(n_units), xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int per_xcd = (blocks_per_unit + (1 << lg) - 1) >> lg;
-    const int round = jb / per_xcd;
+    const int round = small_div(jb, per_xcd); // jb < 2^21: at most 2^24 blocks per launch
     unit = round * (8 >> lg) + (xcd >> lg);
     blk = ((jb - round * per_xcd) << lg) + (xcd & ((1 << lg) - 1));
     return unit < n_units && blk < blocks_per_unit;

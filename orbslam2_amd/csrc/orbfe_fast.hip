@@ -108,7 +108,7 @@ __device__ __forceinline__ unsigned h2sub(unsigned a, unsigned b) { unsigned d; 
 // the waves of a workgroup are independent; a wave's own LDS traffic only needs its outstanding LDS operations retired
 #define FAST_WAVE_SYNC() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); } while (0)
 template <int TP, bool BK>
-__global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int tile_pitch_rt, int tile_bytes, int sc_bytes, int q_bytes, int lds_per_wave ORBFE_CUT_PARAM)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void fast_cell_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int tile_pitch_rt, int tile_bytes, int sc_bytes, int q_bytes, int lds_per_wave ORBFE_CUT_PARAM)
 {
     const int tile_pitch = TP ? TP : tile_pitch_rt;
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem_all[];
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
         if (cell >= cfg.lv[l].cell_off) level = l;
     const LevelInfo &L = cfg.lv[level];
     const int ci = cell - L.cell_off;
-    const int ci_i = ci / L.n_cols, ci_j = ci - ci_i * L.n_cols;
+    const int ci_i = small_div(ci, L.n_cols), ci_j = ci - ci_i * L.n_cols;
     const int lane = threadIdx.x & 63;
     int *cnt_out = buf.cell_cnt + (size_t)img * cfg.cells_total + cell;
 
@@ -170,7 +170,9 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
     uint8_t *s_qf = s_tile;                            // per queue-2 entry: 0 / 1 (local max, >= minTh) / 2 (>= iniTh)
     const int scp = iw + 2;
 
-    const int xa = ini_x & ~3, ox = ini_x - xa;
+    // tile column 0 is pixel ini_x: the staging loads are UNALIGNED dwords (free on this memory system), so interior pixel c
+    // always sits at tile byte c + 3 and a cell of up to 32 columns is eight 4-pixel groups per row whatever ini_x & 3 is
+    const int xa = ini_x, ox = 0;
     const int wpr = (max_x - xa + 3) >> 2; // words per tile row
     const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (size_t)ini_y * L.pitch + xa;
     // The reference runs FAST at iniThFAST and, only when that yields no keypoint in the cell, again at minThFAST
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
     } else {
         // (row, word) of element i = lane, advanced by 64 per step; 32-bit offsets only (64-bit multiplies and a
         // per-element division cost more VALU issue than the copy itself)
-        int r = (int)(((float)lane + 0.5f) * (1.0f / (float)wpr)), c = lane - r * wpr;
+        int r = small_div(lane, wpr), c = lane - r * wpr;
         const int dr = 64 / wpr, dc = 64 - dr * wpr;
         const int nw = th * wpr;
         for (int i0 = lane; i0 < nw; i0 += 256) {
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
                 if (i0 + 64 * u < nw) *(uint32_t *)(s_tile + dst[u]) = v[u];
         }
     }
-    for (int i = lane; i < sc_bytes / 4; i += 64) ((uint32_t *)s_sc)[i] = 0;
+    for (int i = lane; i < sc_bytes / 16; i += 64) ((uint4 *)s_sc)[i] = make_uint4(0u, 0u, 0u, 0u); // sc_bytes is a multiple of 16
     FAST_WAVE_SYNC();
     if (ORBFE_CUT(1)) { if (lane == 0) *cnt_out = 0; return; }
     // Phases A and C work on TWO pixels per lane, one in each 16-bit half of a register, with packed
@@ -249,17 +251,19 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
             const bool va = qa < count, vb = qb < count;
             const unsigned ea = fetch(va ? qa : 0), eb = fetch(vb ? qb : 0);
             const int ra = (ea >> 8) & 63, ca = ea & 255, rb = (eb >> 8) & 63, cb = eb & 255; // ra, rb = row + 1
-            const uint8_t *pa = &s_tile[(ra + 2) * tile_pitch + ca + 3 + ox];
-            const uint8_t *pb = &s_tile[(rb + 2) * tile_pitch + cb + 3 + ox];
+            // base = the ring's lowest address (row - 3, column - 3), so every ring offset is a non-negative immediate
+            const uint8_t *pa = &s_tile[(ra - 1) * tile_pitch + ca + ox];
+            const uint8_t *pb = &s_tile[(rb - 1) * tile_pitch + cb + ox];
             // 0x6400: p -> 1024 + p; 0x8000 more for a bright entry: -> -(1024 + p)
             const unsigned fx = 0x64006400u ^ ((ea & 0x8000u) ? 0x8000u : 0u) ^ ((eb & 0x8000u) ? 0x80000000u : 0u);
             // one v_perm_b32 packs the two bytes into the two halves, one full-rate v_xor_b32 converts / negates (spelled this
             // way because the compiler otherwise picks a shift + a three-input or: two half-rate ops)
             auto pack = [&](unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x0c040c00u) ^ fx; };
-            const unsigned vv = pack(pa[0], pb[0]);
+            const int ctr = 3 * tile_pitch + 3;
+            const unsigned vv = pack(pa[ctr], pb[ctr]);
             unsigned e[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) e[k] = pack(pa[roff[k]], pb[roff[k]]);
+            for (int k = 0; k < 16; k++) e[k] = pack(pa[ctr + roff[k]], pb[ctr + roff[k]]);
             unsigned m3[16], m9[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) m3[k] = h2max3(e[k], e[(k + 1) & 15], e[(k + 2) & 15]);
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
         // invariants and leaves one add each for the address and the entries per iteration
         const int ng = (iw + ox + 3) >> 2;       // groups per interior row; group j covers c = 4j - ox .. 4j - ox + 3
         const int dr = 64 / ng;
-        const int rl = (int)(((float)lane + 0.5f) * (1.0f / (float)ng)), jg = lane - rl * ng;
+        const int rl = small_div(lane, ng), jg = lane - rl * ng;
         const int pw = tile_pitch >> 2;
         const pk16 tp = {(short)t, (short)t};
         const int c0 = 4 * jg - ox;
@@ -384,8 +388,19 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
     }
     FAST_WAVE_SYNC();
     if (ORBFE_CUT(3)) { if (lane == 0) *cnt_out = 0; return; }
-    // the ordered queue, then the side list
-    score_entries(n2 + nx, [&](int q) { return (unsigned)(q < n2 ? s_q2[q] : s_xq[q - n2]); });
+    // the side list goes behind the ordered queue when it fits (it always does on real images: the queue has room for every
+    // pixel of the cell), so one call scores both; phases D / E only walk the first n2 entries
+    int n_sc = n2;
+    if (nx) {
+        if (n2 + nx <= (q_bytes >> 1)) {
+            for (int i = lane; i < nx; i += 64) s_q2[n2 + i] = s_xq[i];
+            n_sc = n2 + nx;
+            FAST_WAVE_SYNC();
+        } else {
+            score_entries(nx, [&](int q) { return (unsigned)s_xq[q]; });
+        }
+    }
+    score_entries(n_sc, [&](int q) { return (unsigned)s_q2[q]; });
     FAST_WAVE_SYNC();
     if (ORBFE_CUT(4)) { if (lane == 0) *cnt_out = 0; return; }
     // ---- D: NMS + threshold choice.  The first 256 queue entries (all of them for ordinary cells) keep their flag and
@@ -493,7 +508,7 @@ __global__ __launch_bounds__(256) void fast_cell_kernel(DeviceConfig cfg, Device
         FAST_WAVE_SYNC();
         const unsigned cnt = lane < nb ? s_ac[lane] : 0u;
         if (cnt) {
-            const int ly = (int)(((float)lane + 0.5f) / (float)ncols), lx = lane - ly * ncols;
+            const int ly = small_div(lane, ncols), lx = lane - ly * ncols;
             const unsigned gx = (unsigned)(gx0 + lx), by = (unsigned)(by0 + ly);
             auto spread5 = [](unsigned v) { return (v & 1u) | ((v & 2u) << 1) | ((v & 4u) << 2) | ((v & 8u) << 3) | ((v & 16u) << 4); };
             const unsigned b = ((gx >> 5) << 10) | spread5(gx & 31u) | (spread5(by) << 1);
