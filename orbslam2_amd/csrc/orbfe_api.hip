@@ -467,6 +467,82 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
                 D.rs_src_rows[v] = worst;
             }
         }
+        {   // plan of the fused pyramid tail (pyr_tail_kernel): a workgroup owns a strip of ORBFE_TAIL_COLS extended columns of
+            // the LAST level over all its rows and computes, level by level in LDS, exactly the columns of the previous tail
+            // levels that strip needs (plus the margin columns at the image's left / right, which no later level reads);
+            // columns shared by neighbouring strips (one or two per level) are computed twice
+            DeviceConfig &c2 = ctx->cfg;
+            c2.tail_first = 0; c2.tail_n = 0; c2.tail_strips = 0; c2.tail_lds_bytes = 0;
+            const int nst = p.nlevels >= 4 ? 3 : (p.nlevels == 3 ? 2 : 0);
+            const char *env = getenv("ORBFE_NO_TAIL");
+            if (nst >= 2 && !(env && env[0] == '1')) {
+                const int F = p.nlevels - nst, Lz = p.nlevels - 1;
+                const int strips = (c2.lv[Lz].rs_xtab_n + ORBFE_TAIL_COLS - 1) / ORBFE_TAIL_COLS;
+                std::vector<int> plan((size_t)strips * ORBFE_TAIL_MAX * 4, 0);
+                int max_wd[ORBFE_TAIL_MAX] = {0, 0, 0}, max_src = 0;
+                bool ok = true;
+                auto src_hull = [&](int l, int x0, int n, int &lo, int &hi) { // source columns of extended columns [x0, x0 + n) of level l
+                    lo = INT_MAX; hi = -1;
+                    for (int i = x0; i < x0 + n; i++) {
+                        const uint32_t e = tab[c2.lv[l].rs_xtab_off + i];
+                        const int a = (int)(e & 0xffffu), b2 = (int)(e >> 16);
+                        lo = std::min(lo, std::min(a, b2)); hi = std::max(hi, std::max(a, b2));
+                    }
+                };
+                for (int sj = 0; sj < strips; sj++) {
+                    int x0 = sj * ORBFE_TAIL_COLS, n = std::min(ORBFE_TAIL_COLS, c2.lv[Lz].rs_xtab_n - x0);
+                    for (int st = nst - 1; st >= 0; st--) {
+                        const int l = F + st;
+                        int *e = &plan[((size_t)sj * ORBFE_TAIL_MAX + st) * 4];
+                        e[0] = x0; e[1] = n >> 2;
+                        max_wd[st] = std::max(max_wd[st], n >> 2);
+                        if (n >> 2 > 64) ok = false; // one lane per 4-pixel word of a strip row
+                        int lo, hi;
+                        src_hull(l, x0, n, lo, hi); // interior columns of level l - 1
+                        if (st == 0) {
+                            e[2] = lo & ~3; e[3] = (((hi | 3) + 1) - (lo & ~3)) >> 2; // staged words of level F - 1 (4-aligned interior start)
+                            max_src = std::max(max_src, e[3]);
+                            break;
+                        }
+                        // columns of level l - 1 this strip computes: the needed interior columns (+ PYR_MX as extended index)
+                        // rounded out to words, and the margin columns for the first / last strip
+                        x0 = sj == 0 ? 0 : ((lo + 4) & ~3);
+                        const int x1 = sj == strips - 1 ? c2.lv[l - 1].rs_xtab_n : std::min(c2.lv[l - 1].rs_xtab_n, ((hi + 4) | 3) + 1);
+                        n = x1 - x0;
+                    }
+                }
+                for (int st = 0; st < nst && ok; st++) { // every extended column of every tail level is computed by some strip
+                    int covered = 0;
+                    for (int sj = 0; sj < strips; sj++) {
+                        const int *e = &plan[((size_t)sj * ORBFE_TAIL_MAX + st) * 4];
+                        if (e[0] > covered) ok = false;
+                        covered = std::max(covered, e[0] + 4 * e[1]);
+                    }
+                    if (covered != c2.lv[F + st].rs_xtab_n) ok = false;
+                }
+                size_t off = 0;
+                for (int st = 0; st < nst; st++) { c2.tail_lds_y[st] = (int)off; off += (size_t)2 * c2.lv[F + st].rs_ytab_n * 4; }
+                off = (off + 15) & ~(size_t)15;
+                c2.tail_lds_src = (int)off;
+                off += (size_t)c2.lv[F - 1].h * max_src * 4;
+                for (int st = 0; st + 1 < nst; st++) {
+                    c2.tail_lds_buf[st] = (int)off;
+                    off += (size_t)(c2.lv[F + st].h + 6) * max_wd[st] * 4;
+                }
+                if (ok && F >= 1 && off <= 64 * 1024) {
+                    c2.tail_first = F; c2.tail_n = nst; c2.tail_strips = strips; c2.tail_src_words = max_src;
+                    for (int st = 0; st < nst; st++) c2.tail_words[st] = max_wd[st];
+                    c2.tail_lds_bytes = (int)off;
+                    int *d_plan = nullptr;
+                    A(d_plan, plan.size());
+                    if (hipMemcpy(d_plan, plan.data(), plan.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+                        orbfe_destroy(ctx);
+                        return fail(nullptr, ORBFE_ERR_HIP, "pyramid tail plan upload failed");
+                    }
+                    b.tail_plan = d_plan;
+                }
+            }
+        }
         while (tab.size() % 4) tab.push_back(0);
         if (tab.empty()) tab.resize(4, 0);
         uint32_t *d_tab = nullptr;

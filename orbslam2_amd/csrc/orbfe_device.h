@@ -7,6 +7,8 @@
 #include <stdlib.h>
 
 #define ORBFE_MAX_LEVELS 16
+#define ORBFE_TAIL_MAX 3   // levels fused by pyr_tail_kernel
+#define ORBFE_TAIL_COLS 64 // extended columns of the last level per workgroup
 #define ORBFE_WAVE 64
 
 // Profiling cut points (tools/*_phases.sh, tools/*_insts.sh): an extra kernel argument that makes a kernel return after a
@@ -61,6 +63,13 @@ struct DeviceConfig {
     int max_nodes;         // quadtree node capacity (LDS)
     int row_cap;           // entries per image row in DeviceBuffers::row_ent
     int patch_n;           // entries in DeviceBuffers::patch_uv (multiple of 64)
+    // fused pyramid tail (pyr_tail_kernel): the last tail_n levels (2 or 3) in one launch, 0 = not used
+    int tail_first, tail_n, tail_strips;
+    int tail_src_words;                // staged words per row of level tail_first - 1 (widest strip)
+    int tail_words[ORBFE_TAIL_MAX];    // words per row of stage s computed by the widest strip
+    int tail_lds_y[ORBFE_TAIL_MAX];    // LDS byte offsets: row tables of stage s, ...
+    int tail_lds_buf[ORBFE_TAIL_MAX];  // ... and the columns of stage s kept for stage s + 1
+    int tail_lds_src, tail_lds_bytes;
     int umax[64];
     int taps[7];           // Gaussian 8.8 fixed-point taps
     size_t pyr_bytes;      // per image
@@ -115,6 +124,7 @@ struct DeviceBuffers {
     uint2 *row_ent;      // [pair][height][row_cap] entries: (iR | octave << 16, x bits), appended by describe_kernel
     const uint32_t *bk_tab; // quadtree bucket tables: per level X[region_w] then Y[region_h] (see ORBFE_BK_*)
     const uint32_t *rs_tab; // cv::resize offset/weight tables of every level (see pyr_resize_kernel)
+    const int *tail_plan;   // [tail_strips][ORBFE_TAIL_MAX][4]: first extended column, words, first staged source column, staged words (pyr_tail_kernel)
     long long *dbg_ts;   // 4096 timestamps for kernel bring-up (ORBFE_OT2_STOP=99); never read by product code
     const uint8_t *slot_level; // [sel_total] level of every keypoint slot
     const int16_t *patch_uv; // IC_Angle patch offsets: (u & 0xff) | (v << 8), padded with (0,0)

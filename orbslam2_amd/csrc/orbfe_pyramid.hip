@@ -223,6 +223,151 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(DeviceConfig cfg, Devic
 }
 
 // ---------------------------------------------------------------------------
+// Fused pyramid tail: the last NST levels (NST = 2 or 3) in ONE launch.  On their own these levels are latency bound: each
+// launch is a chain of dependent table loads, staging, one barrier and a few microseconds of arithmetic (10 us per level for
+// 2 us of work at 346 x 105), and each re-reads from HBM what the previous one just wrote.  Here a workgroup owns a STRIP of
+// ORBFE_TAIL_COLS extended columns of the last level over all its rows and walks the chain in LDS: it stages the columns of
+// level F - 1 it needs (all rows), computes from them its columns of level F (written to HBM and kept in LDS), from those its
+// columns of level F + 1, and so on.  Which columns those are is a host-built plan (orbfe_api.hip, from the same column
+// tables), including the margin columns at the left / right of each level, which no later level reads; a strip's neighbours
+// share one or two columns per level with it (computed by both: same arithmetic, same bytes) -- cutting by rows instead costs
+// 40 % in halo rows (measured: no gain over the separate launches).
+// A lane owns one 4-pixel word of the strip (its column-table entries stay in registers for the whole level) and a run of
+// consecutive rows: 64 / words lanes share a word and split the wave's rows between them, so the horizontal pass of a source
+// row is still reused by the next output row.  Row tables sit in LDS.  The arithmetic is pyr_resize_kernel's.
+// ---------------------------------------------------------------------------
+#define TAIL_THREADS 512
+template <int NST>
+__global__ __launch_bounds__(TAIL_THREADS) void pyr_tail_kernel(DeviceConfig cfg, DeviceBuffers buf)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_tail[];
+    const int img = blockIdx.y, strip = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int F = cfg.tail_first;
+    const int *plan = buf.tail_plan + strip * (ORBFE_TAIL_MAX * 4);
+    uint8_t *pyr = buf.pyr + (size_t)img * cfg.pyr_bytes;
+    // this lane's word and row run of every stage, and the word's column-table entries (issued first: longest latency)
+    int xi_[NST], yb_[NST], ye_[NST];
+    uint4 X0_[NST], X1_[NST];
+#pragma unroll
+    for (int st = 0; st < NST; st++) {
+        const LevelInfo &D = cfg.lv[F + st];
+        const int x0 = plan[st * 4], nwd = plan[st * 4 + 1];
+        const int nq = 64 / nwd;                       // lanes per word
+        const int q = small_div(lane, nwd), w = lane - q * nwd;
+        const int R = D.h + 2 * PYR_MY, rpw = (R + TAIL_THREADS / 64 - 1) / (TAIL_THREADS / 64); // rows per wave, then per lane
+        const int wb = wave * rpw, we = wb + rpw < R ? wb + rpw : R;
+        const int rpl = (rpw + nq - 1) / nq;
+        yb_[st] = wb + q * rpl;
+        ye_[st] = q < nq ? (yb_[st] + rpl < we ? yb_[st] + rpl : we) : yb_[st];
+        xi_[st] = x0 + 4 * w;
+        const uint32_t *xt = buf.rs_tab + D.rs_xtab_off;
+        X0_[st] = *(const uint4 *)(xt + xi_[st]);
+        X1_[st] = *(const uint4 *)(xt + D.rs_xtab_n + xi_[st]);
+    }
+    // row tables of every stage -> LDS (two planes of rs_ytab_n words each, contiguous in rs_tab)
+#pragma unroll
+    for (int st = 0; st < NST; st++) {
+        const LevelInfo &D = cfg.lv[F + st];
+        const uint32_t *g = buf.rs_tab + D.rs_ytab_off;
+        uint32_t *d = (uint32_t *)(s_tail + cfg.tail_lds_y[st]);
+        for (int i = tid; i < 2 * D.rs_ytab_n; i += TAIL_THREADS) d[i] = g[i];
+    }
+    // the strip's columns of level F - 1, every row (interior pixels, 4-aligned start); this copy is the kernel's longest
+    // dependent chain, so eight loads per thread are in flight
+    const int src_x0 = plan[2], src_words = plan[3];
+    {
+        const LevelInfo &S = cfg.lv[F - 1];
+        const uint8_t *sp = pyr + S.pyr_off + src_x0;
+        uint32_t *d = (uint32_t *)(s_tail + cfg.tail_lds_src);
+        int r = small_div(tid, src_words), c = tid - r * src_words;
+        const int dr = TAIL_THREADS / src_words, dc = TAIL_THREADS - dr * src_words;
+        const int nw = S.h * src_words;
+        for (int i0 = tid; i0 < nw; i0 += 8 * TAIL_THREADS) {
+            uint32_t v[8];
+            int di[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                di[u] = __mul24(r, src_words) + c;
+                if (i0 + TAIL_THREADS * u < nw) v[u] = *(const uint32_t *)(sp + (unsigned)(__mul24(r, S.pitch) + 4 * c));
+                c += dc; r += dr;
+                if (c >= src_words) { c -= src_words; r++; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (i0 + TAIL_THREADS * u < nw) d[di[u]] = v[u];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < NST; st++) {
+        const LevelInfo &D = cfg.lv[F + st];
+        // source in LDS: interior pixel (sx, sy) of the source level at src[sy * src_pitch + sx]
+        const uint8_t *src;
+        int src_pitch;
+        if (st == 0) {
+            src_pitch = src_words * 4;
+            src = s_tail + cfg.tail_lds_src - src_x0;
+        } else {
+            src_pitch = plan[(st - 1) * 4 + 1] * 4;
+            src = s_tail + cfg.tail_lds_buf[st - 1] + PYR_MY * src_pitch + (PYR_MX - plan[(st - 1) * 4]);
+        }
+        const int keep_pitch = plan[st * 4 + 1] * 4;
+        uint8_t *keep = st + 1 < NST ? s_tail + cfg.tail_lds_buf[st] + (xi_[st] - plan[st * 4]) : nullptr; // extended rows, the strip's columns
+        uint8_t *dst = pyr + D.pyr_off + (xi_[st] - PYR_MX);
+        const uint32_t *yt = (const uint32_t *)(s_tail + cfg.tail_lds_y[st]);
+        const int ny = D.rs_ytab_n;
+        const uint32_t x0v[4] = {X0_[st].x, X0_[st].y, X0_[st].z, X0_[st].w}, x1v[4] = {X1_[st].x, X1_[st].y, X1_[st].z, X1_[st].w};
+        int tagA = -1, tagB = -1;          // source rows held in hA / hB (per lane: lanes of different runs are at different rows)
+        unsigned hA[4], hB[4];
+        auto hpass = [&](int sy, unsigned h[4]) {
+            const uint8_t *r = src + __mul24(sy, src_pitch);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned p0 = r[x0v[j] & 0xffffu], p1 = r[x0v[j] >> 16];
+                h[j] = (__umul24(p0, x1v[j] & 0xffffu) + __umul24(p1, x1v[j] >> 16)) & ~15u;
+            }
+        };
+        uint32_t y0n = 0u, y1n = 0u; // row-table entries one row ahead
+        if (yb_[st] < ye_[st]) { y0n = yt[yb_[st]]; y1n = yt[ny + yb_[st]]; }
+        for (int y = yb_[st]; y < ye_[st]; y++) {
+            const uint32_t y0e = y0n, y1e = y1n;
+            if (y + 1 < ye_[st]) { y0n = yt[y + 1]; y1n = yt[ny + y + 1]; }
+            const int sy0 = (int)(y0e & 0xffffu), sy1 = (int)(y0e >> 16);
+            if (tagA != sy0) {
+                if (tagB == sy0) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { const unsigned t = hA[j]; hA[j] = hB[j]; hB[j] = t; }
+                    tagB = tagA; tagA = sy0;
+                } else {
+                    hpass(sy0, hA); tagA = sy0;
+                }
+            }
+            if (tagB != sy1) {
+                if (sy1 == sy0) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) hB[j] = hA[j];
+                } else {
+                    hpass(sy1, hB);
+                }
+                tagB = sy1;
+            }
+            const unsigned b0 = (y1e & 0xffffu) << 12, b1 = (y1e >> 16) << 12;
+            uint32_t out = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned v0 = (unsigned)(((unsigned long long)(b0 & 0xffffffu) * (unsigned long long)(hA[j] & 0xffffffu)) >> 32);
+                const unsigned v1 = (unsigned)(((unsigned long long)(b1 & 0xffffffu) * (unsigned long long)(hB[j] & 0xffffffu)) >> 32);
+                out |= ((v0 + v1 + 2u) >> 2) << (8 * j);
+            }
+            *(uint32_t *)(dst + (ptrdiff_t)(y - PYR_MY) * D.pitch) = out;
+            if (keep) *(uint32_t *)(keep + __mul24(y, keep_pitch)) = out;
+        }
+        if (st + 1 < NST) __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Gaussian 7x7 (8.8 fixed point, separable), all levels in one launch.
 // Register sliding window: a lane owns 4 adjacent columns and walks down BL_ROWS rows; per input
 // row it loads three aligned words (12 px), forms the four 7-tap row sums with v_dot4_u32_u8, keeps
@@ -310,7 +455,8 @@ void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, cons
 
 void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
 {
-    for (int l = 1; l < cfg.nlevels; l++) {
+    const int last_single = cfg.tail_first ? cfg.tail_first - 1 : cfg.nlevels - 1;
+    for (int l = 1; l <= last_single; l++) {
         const int src_words = (cfg.lv[l - 1].w + 3) / 4; // interior pixels of the source row (4-aligned start)
         const int total_rows = cfg.lv[l].h + 2 * PYR_MY;
         // rows per wave: the largest of 4, 2, 1 whose staged source rows fit 60 KB of LDS (rs_src_rows[i] = source
@@ -326,6 +472,11 @@ void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int
             dim3 grid((total_rows + 3) / 4, n_images);
             hipLaunchKernelGGL(pyr_resize_kernel<1>, grid, dim3(256), (size_t)span[2] * src_words * 4, s, cfg, buf, l, src_words, span[2]);
         }
+    }
+    if (cfg.tail_first) {
+        dim3 grid(cfg.tail_strips, n_images);
+        if (cfg.tail_n == 3) hipLaunchKernelGGL(pyr_tail_kernel<3>, grid, dim3(TAIL_THREADS), (size_t)cfg.tail_lds_bytes, s, cfg, buf);
+        else hipLaunchKernelGGL(pyr_tail_kernel<2>, grid, dim3(TAIL_THREADS), (size_t)cfg.tail_lds_bytes, s, cfg, buf);
     }
 }
 
