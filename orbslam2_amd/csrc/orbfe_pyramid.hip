@@ -92,6 +92,50 @@ __global__ __launch_bounds__(256) void ingest_kernel(DeviceConfig cfg, DeviceBuf
     } // rows
 }
 
+// ingest of packed CV_8UC1 images without rectification (the stereo / mono path of the benchmark): a plain copy with margins, so
+// a thread moves 16 pixels of one extended row (one unaligned 128-bit load, one aligned 128-bit store) instead of 4; the
+// (row, chunk) pairs of an 8-row band are dealt to the threads flat, because an extended row is rarely a multiple of 64 chunks
+// (79 for KITTI's 1241 columns).  Only the chunks that touch the left / right margin gather reflected bytes.
+#define ING16_ROWS 8
+__global__ __launch_bounds__(256) void ingest16_kernel(DeviceConfig cfg, DeviceBuffers buf, const uint8_t *__restrict__ src)
+{
+    const int img = blockIdx.y;
+    const LevelInfo &L = cfg.lv[0];
+    if (blockIdx.x == 0) { // first kernel of every chain: clear the image's status word and, for a right image, its pair's stereo row counters
+        if (threadIdx.x == 0) buf.status[img] = 0;
+        if (img & 1)
+            for (int i = threadIdx.x; i < cfg.height; i += 256) buf.row_cnt[(size_t)(img >> 1) * cfg.height + i] = 0;
+    }
+    const int ext_w = (L.w + 12 + 3) & ~3;            // extended row in bytes: PYR_MX + w + >= 8, whole words
+    const int cpr = (ext_w + 15) >> 4;                // 16-byte chunks per row (the last one may be half used: the pitch covers it)
+    const int y_first = (int)blockIdx.x * ING16_ROWS - PYR_MY;
+    int rows = L.h + PYR_MY - y_first;
+    rows = rows < ING16_ROWS ? rows : ING16_ROWS;
+    const int n = rows * cpr;
+    const uint8_t *simg = src + (size_t)img * L.h * L.w;
+    uint8_t *dimg = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int r = small_div(i, cpr), c = i - r * cpr;
+        const int y = y_first + r, x0 = c * 16 - PYR_MX;
+        const uint8_t *s = simg + (size_t)reflect101(y, L.h) * L.w;
+        uint4 v;
+        if (x0 >= 0 && x0 + 15 < L.w) {
+            __builtin_memcpy(&v, s + x0, 16);
+        } else {
+            uint32_t w4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t t = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) t |= (uint32_t)s[reflect101(x0 + 4 * k + j, L.w)] << (8 * j);
+                w4[k] = t;
+            }
+            v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        }
+        *(uint4 *)(dimg + (ptrdiff_t)y * L.pitch + x0) = v;
+    }
+}
+
 // pyramid: level l from level l-1 (cv::resize INTER_LINEAR, 8UC1 fixed point) over the extended (margin-
 // included) domain of level l.  The per-column / per-row source offsets and 11-bit weights (cv::resize's
 // xofs/ialpha, yofs/ibeta tables) are built once per context on the host with exactly the arithmetic of
@@ -447,6 +491,11 @@ void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, cons
 {
     const int words = (cfg.lv[0].w + 12 + 3) / 4;
     dim3 grid((words + 63) / 64, (cfg.lv[0].h + 2 * PYR_MY + 4 * ING_ROWS - 1) / (4 * ING_ROWS), n_images);
+    if (!cfg.rm_on && cfg.in_cn == 1) {
+        dim3 grid16((cfg.lv[0].h + 2 * PYR_MY + ING16_ROWS - 1) / ING16_ROWS, n_images);
+        hipLaunchKernelGGL(ingest16_kernel, grid16, dim3(256), 0, s, cfg, buf, d_images);
+        return;
+    }
     if (cfg.rm_on) hipLaunchKernelGGL((ingest_kernel<1, true>), grid, dim3(256), 0, s, cfg, buf, d_images);
     else if (cfg.in_cn == 3) hipLaunchKernelGGL(ingest_kernel<3>, grid, dim3(256), 0, s, cfg, buf, d_images);
     else if (cfg.in_cn == 4) hipLaunchKernelGGL(ingest_kernel<4>, grid, dim3(256), 0, s, cfg, buf, d_images);
