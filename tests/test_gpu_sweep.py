@@ -52,6 +52,36 @@ def test_noise_image_many_candidates():
     ctx.close()
 
 
+@pytest.mark.parametrize("ini,mn", [(10, 7), (30, 7)])
+def test_ramp_image_every_pixel_passes_both_polarities(ini, mn):
+    """A sawtooth ramp v = (16 x + 5 y) mod 256 (+ a little noise): opposite ring pixels are v +- d with d = 15 .. 48 on all four
+    pairs the device's quick test uses, so away from the wrap lines EVERY pixel passes it as dark and as bright.  That fills the
+    both-polarity side list of fast_cell_kernel far beyond its 256 entries per cell (scored in batches while the quick test is
+    still running) and makes the ordered queue as long as the cell has pixels.  ini = 30: most cells go to the second attempt."""
+    from orbslam2_amd import api
+    w, h = 640, 360
+    yy, xx = np.mgrid[0:h, 0:w]
+    rng = np.random.default_rng(5)
+    img = ((16 * xx + 5 * yy + rng.integers(0, 3, (h, w))) % 256).astype(np.uint8)
+    # the fraction of pixels that pass the four-pair test in both polarities at the test's thresholds (numpy restatement)
+    v = img.astype(np.int32)[3:-3, 3:-3]
+    ring = lambda dx, dy: img.astype(np.int32)[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx]
+    pairs = [(ring(0, 3), ring(0, -3)), (ring(2, 2), ring(-2, -2)), (ring(3, 0), ring(-3, 0)), (ring(2, -2), ring(-2, 2))]
+    dark = np.ones_like(v, bool); bright = np.ones_like(v, bool)
+    for a, b in pairs:
+        dark &= np.minimum(a, b) < v - mn
+        bright &= np.maximum(a, b) > v + mn
+    assert (dark & bright).mean() > 0.5
+    kw = dict(nfeatures=800, ini_th_fast=ini, min_th_fast=mn)
+    ctx = api.Context(width=w, height=h, **kw)
+    k, d = ctx.extract(img)
+    ex = O.Extractor(**kw)
+    kr, dr = ex.extract(img)
+    assert len(kr) > 100
+    assert np.array_equal(k, kr.astype(api.KP_DTYPE)) and np.array_equal(d, dr)
+    ctx.close()
+
+
 def test_reuse_context_many_frames():
     from orbslam2_amd import api
     ctx = api.Context(width=480, height=320, nfeatures=700, fx=400.0, fy=400.0, cx=240.0, cy=160.0, bf=100.0)

@@ -22,6 +22,14 @@ for i in range(n):
         f = float(rng.uniform(0.05, 0.4))
         left = np.clip((left.astype(np.float32) - 128) * f + 128, 0, 255).astype(np.uint8)
         right = np.clip((right.astype(np.float32) - 128) * f + 128, 0, 255).astype(np.uint8)
+    if i % 7 == 3:  # pure noise: nearly every pixel passes FAST's quick test, many in both polarities (side list, its overflow)
+        left = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        right = np.roll(left, -5, axis=1)
+    if i % 7 == 5:  # period-6 / period-4 stripes + noise: ring pairs straddle the centre almost everywhere
+        yy, xx = np.mgrid[0:h, 0:w]
+        pat = (((xx // 3) + (yy // 2)) % 2) * 120 + 60 + rng.integers(-25, 26, (h, w))
+        left = np.clip(pat, 0, 255).astype(np.uint8)
+        right = np.roll(left, -4, axis=1)
     fx, bf = 0.7 * w, 0.2 * w
     kw = dict(nfeatures=nf, ini_th_fast=ini, min_th_fast=mn)
     ctx = api.Context(width=w, height=h, fx=fx, fy=fx, cx=w / 2, cy=h / 2, bf=bf, **kw)
