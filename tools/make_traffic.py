@@ -2,26 +2,31 @@
 """pmc_FETCH_SIZE.txt + pmc_WRITE_SIZE.txt (tools/pmc_summary.py output) -> traffic json read by bench.py.
 
 usage: make_traffic.py <dir with pmc_FETCH_SIZE.txt, pmc_WRITE_SIZE.txt> <pairs per launch> <out.json>
-Counter values are KB per launch (mean over launches); the pyramid's 7 launches per step are summed.
+Counter values are KB per launch (mean over launches); a stage's launches per step (the pyramid has several) are summed:
+launches per step = the kernel's dispatch count / fast_cell_kernel's (one per step).
 """
 import ast, json, sys
 
-STAGE_OF = {"ingest_kernel": "ingest", "pyr_resize_kernel": "pyramid", "blur_kernel": "blur", "fast_cell_kernel": "fast",
+STAGE_OF = {"ingest_kernel": "ingest", "ingest16_kernel": "ingest", "pyr_resize_kernel": "pyramid", "pyr_tail_kernel": "pyramid", "blur_kernel": "blur", "fast_cell_kernel": "fast",
             "octree": "octree", "describe_kernel": "describe", "stereo_match_kernel": "stereo_match",
             "stereo_rowtable_kernel": "stereo_match", "stereo_median_kernel": "stereo_median"}
-LAUNCHES = {"pyr_resize_kernel": 7}
 
 
 def read(path, counter):
-    out = {}
+    rows = []
     for line in open(path):
         if "{" not in line:
             continue
         name = line[:line.index("{")].strip()
         vals = ast.literal_eval(line[line.index("{"):line.rindex("}") + 1])
+        n = int(line[line.rindex("n=") + 2:]) if "n=" in line[line.rindex("}"):] else 1
+        rows.append((name, vals, n))
+    steps = max([n for name, _, n in rows if "fast_cell_kernel" in name] or [1])
+    out = {}
+    for name, vals, n in rows:
         for k, st in STAGE_OF.items():
             if k in name and "gather" not in name:
-                out[st] = out.get(st, 0.0) + vals[counter] * LAUNCHES.get(k, 1)
+                out[st] = out.get(st, 0.0) + vals[counter] * (n / steps)
     return out
 
 
