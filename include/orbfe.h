@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ORBFE_ABI_VERSION 2 /* 2: orbfe_frame_view.device_slot_plus1 */
+#define ORBFE_ABI_VERSION 3 /* 2: orbfe_frame_view.device_slot_plus1; 3: .keyframe */
 
 enum {
     ORBFE_OK = 0,
@@ -229,6 +229,12 @@ typedef struct orbfe_frame_view { /* what the matchers read from a Frame (includ
      * is always the current frame, so this is the Tracking-thread fast path; zero-initialise the struct to stay on the
      * upload path. */
     int32_t device_slot_plus1;
+    /* nonzero: the view describes a KeyFrame.  A KeyFrame keeps the frame's grid (cells assigned with the frame's FLOAT bounds and
+     * cell size, src/KeyFrame.cc:32-50) but its own bounds are ints initialised from those floats (include/KeyFrame.h:194-197), and
+     * KeyFrame::GetFeaturesInArea / IsInImage (src/KeyFrame.cc:563-607) use the ints.  Pass the frame's float bounds
+     * (Frame::mnMinX ... are static) in min_x .. max_y and set this flag: cells are assigned with the floats, windows and the
+     * in-image test use (float)(int) of them.  Without distortion the bounds are whole numbers and the flag changes nothing. */
+    int32_t keyframe;
 } orbfe_frame_view;
 
 /* what Frame::isInFrustum (src/Frame.cc:270-326) leaves in a MapPoint for SearchLocalPoints */

@@ -112,6 +112,7 @@ def _bind_match(L):
     vp = C.c_void_p
     L.orc_grid_create.restype = vp; L.orc_grid_create.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
     L.orc_grid_destroy.restype = None; L.orc_grid_destroy.argtypes = [vp]
+    L.orc_grid_as_keyframe.restype = None; L.orc_grid_as_keyframe.argtypes = [vp]
     L.orc_features_in_area.restype = C.c_int
     L.orc_features_in_area.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, vp, C.c_int]
     L.orc_three_maxima.restype = None
@@ -136,11 +137,13 @@ def _bind_match(L):
 class Grid:
     """Frame grid (AssignFeaturesToGrid) over mvKeysUn; keeps the arrays alive."""
 
-    def __init__(self, keys_un, min_x, max_x, min_y, max_y):
+    def __init__(self, keys_un, min_x, max_x, min_y, max_y, keyframe=False):
         self.L = lib()
         self.keys = np.ascontiguousarray(keys_un)
         self.bounds = (float(min_x), float(max_x), float(min_y), float(max_y))
         self.h = self.L.orc_grid_create(_ptr(self.keys), len(self.keys), *self.bounds)
+        if keyframe:  # a KeyFrame's copy of the frame's grid: integer bounds for windows / IsInImage (src/KeyFrame.cc:563-607)
+            self.L.orc_grid_as_keyframe(self.h)
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -139,6 +139,7 @@ typedef struct orc_track_point { int32_t in_view; float proj_x, proj_y, proj_xr;
 
 orc_grid *orc_grid_create(const orc_keypoint *keys_un, int n, float min_x, float max_x, float min_y, float max_y);
 void orc_grid_destroy(orc_grid *g);
+void orc_grid_as_keyframe(orc_grid *g); /* bounds -> the ints a KeyFrame keeps (queries and IsInImage only; cells stay) */
 int orc_features_in_area(const orc_grid *g, float x, float y, float r, int min_level, int max_level, int32_t *out, int cap);
 void orc_three_maxima(const int32_t *histo_sizes, int L, int *ind1, int *ind2, int *ind3);
 float orc_log_det(float x);

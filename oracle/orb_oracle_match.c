@@ -29,6 +29,15 @@ struct orc_grid {
     int *cell_idx;
 };
 
+/* KeyFrame::KeyFrame (src/KeyFrame.cc:32-50): the keyframe takes the frame's grid and cell size as they are and keeps the image
+ * bounds as INTS initialised from the frame's floats (include/KeyFrame.h:194-197); KeyFrame::GetFeaturesInArea / IsInImage
+ * (src/KeyFrame.cc:563-607) then compute with those ints.  Call after orc_grid_create with the frame's float bounds. */
+void orc_grid_as_keyframe(orc_grid *g)
+{
+    g->min_x = (float)(int)g->min_x; g->max_x = (float)(int)g->max_x;
+    g->min_y = (float)(int)g->min_y; g->max_y = (float)(int)g->max_y;
+}
+
 /* Frame::AssignFeaturesToGrid + PosInGrid, reference src/Frame.cc:231-246,383-393 (Q6: round()) */
 orc_grid *orc_grid_create(const orc_keypoint *keys_un, int n, float min_x, float max_x, float min_y, float max_y)
 {

@@ -50,7 +50,7 @@ class Params(C.Structure):
 class FrameView(C.Structure):
     _fields_ = [("n", C.c_int32), ("keys_un", C.c_void_p), ("u_right", C.c_void_p), ("descriptors", C.c_void_p),
                 ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
-                ("device_slot_plus1", C.c_int32)]
+                ("device_slot_plus1", C.c_int32), ("keyframe", C.c_int32)]
 
 
 TP_DTYPE = np.dtype([("in_view", "<i4"), ("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("level", "<i4"), ("view_cos", "<f4")])
@@ -372,13 +372,14 @@ class Context:
         return dict(zip(names, ms.tolist())), calls.value
 
     # ---- Tracking-thread matchers (flattened inputs; see include/orbfe.h) ----
-    def _view(self, keys_un, u_right, desc, bounds, device_slot=None):
+    def _view(self, keys_un, u_right, desc, bounds, device_slot=None, keyframe=False):
         """orbfe_frame_view over host arrays; device_slot = k makes the matchers read image slot k of the latest extraction call
-        in HBM instead of uploading the arrays (the host copies are still needed by the host-side accept rules)."""
+        in HBM instead of uploading the arrays (the host copies are still needed by the host-side accept rules); keyframe: the
+        view is a KeyFrame's (windows and the in-image test use the integer-truncated bounds, include/orbfe.h)."""
         k = np.ascontiguousarray(keys_un, KP_DTYPE); d = np.ascontiguousarray(desc, np.uint8)
         ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
         fv = FrameView(len(k), _p(k), None if ur is None else _p(ur), _p(d), *[float(b) for b in bounds],
-                       0 if device_slot is None else device_slot + 1)
+                       0 if device_slot is None else device_slot + 1, 1 if keyframe else 0)
         fv._keep = (k, d, ur)
         return fv
 

@@ -73,7 +73,9 @@ orbfe_frame_view device_view_of(const Frame &F)
     return v;
 }
 
-// ... and from a KeyFrame (include/KeyFrame.h:160-199; the bounds are ints there)
+// ... and from a KeyFrame (include/KeyFrame.h:160-199).  The keyframe's grid is the frame's (filled with the frame's FLOAT bounds and
+// cell size, src/KeyFrame.cc:32-50) while its own bounds are ints; Frame's bounds are static and identical for every frame of a
+// run, so the view carries those floats plus the keyframe flag, and the library truncates them where KeyFrame.cc uses the ints.
 orbfe_frame_view view_of(const KeyFrame *pKF)
 {
     orbfe_frame_view v = orbfe_frame_view();
@@ -81,7 +83,8 @@ orbfe_frame_view view_of(const KeyFrame *pKF)
     v.keys_un = keys_of(pKF->mvKeysUn);
     v.u_right = pKF->mvuRight.empty() ? nullptr : pKF->mvuRight.data();
     v.descriptors = pKF->mDescriptors.ptr<uchar>(0);
-    v.min_x = (float)pKF->mnMinX; v.max_x = (float)pKF->mnMaxX; v.min_y = (float)pKF->mnMinY; v.max_y = (float)pKF->mnMaxY;
+    v.min_x = Frame::mnMinX; v.max_x = Frame::mnMaxX; v.min_y = Frame::mnMinY; v.max_y = Frame::mnMaxY;
+    v.keyframe = 1;
     return v;
 }
 

@@ -23,6 +23,12 @@
 #include <new>
 #include <vector>
 
+// KeyFrame::IsInImage (src/KeyFrame.cc:604-607): the keyframe's bounds are ints initialised from the frame's floats
+static inline bool kf_is_in_image(const orbfe_frame_view *kf, float u, float v)
+{
+    if (kf->keyframe) return u >= (float)(int)kf->min_x && u < (float)(int)kf->max_x && v >= (float)(int)kf->min_y && v < (float)(int)kf->max_y;
+    return u >= kf->min_x && u < kf->max_x && v >= kf->min_y && v < kf->max_y;
+}
 #define GRID_COLS 64 // FRAME_GRID_COLS include/Frame.h:36
 #define GRID_ROWS 48 // FRAME_GRID_ROWS include/Frame.h:37
 using orbfe_resolve::HISTO_LENGTH;
@@ -38,7 +44,8 @@ struct MatchFrame {
     const uint8_t *desc;
     const float *u_right;    // may be null
     int n;
-    float min_x, min_y, inv_w, inv_h;
+    float min_x, min_y, inv_w, inv_h;    // Frame::mnMinX / mnMinY, mfGridElementWidthInv / HeightInv: the grid ASSIGNMENT
+    float q_min_x, q_min_y;              // bounds of the window QUERY: the same, or (float)(int) of them for a KeyFrame (src/KeyFrame.cc:568-580)
     int *cell_cnt, *cell_off, *cell_idx; // CSR over ix * GRID_ROWS + iy
 };
 
@@ -132,13 +139,13 @@ __global__ __launch_bounds__(256) void window_candidates_kernel(MatchFrame f, co
     const MatchQuery Q = q[iq];
     int total = 0, ncx = 0, ncy = 0, min_cx = 0, min_cy = 0;
     if (Q.flags & 1) {
-        int v = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.u, f.min_x), Q.r), f.inv_w));
+        int v = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.u, f.q_min_x), Q.r), f.inv_w));
         min_cx = v > 0 ? v : 0;
-        v = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.u, f.min_x), Q.r), f.inv_w));
+        v = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.u, f.q_min_x), Q.r), f.inv_w));
         const int max_cx = v < GRID_COLS - 1 ? v : GRID_COLS - 1;
-        v = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.v, f.min_y), Q.r), f.inv_h));
+        v = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.v, f.q_min_y), Q.r), f.inv_h));
         min_cy = v > 0 ? v : 0;
-        v = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.v, f.min_y), Q.r), f.inv_h));
+        v = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.v, f.q_min_y), Q.r), f.inv_h));
         const int max_cy = v < GRID_ROWS - 1 ? v : GRID_ROWS - 1;
         if (min_cx < GRID_COLS && max_cx >= 0 && min_cy < GRID_ROWS && max_cy >= 0) {
             ncx = max_cx - min_cx + 1;
@@ -329,6 +336,8 @@ static int run_window_queries(orbfe_context *ctx, const orbfe_frame_view *fv, co
     uint8_t *din = (uint8_t *)st->in_blk.p, *dout = (uint8_t *)st->out_blk.p;
     MatchFrame f;
     f.n = n; f.min_x = fv->min_x; f.min_y = fv->min_y;
+    f.q_min_x = fv->keyframe ? (float)(int)fv->min_x : fv->min_x; // KeyFrame::mnMinX is an int initialised from the frame's float
+    f.q_min_y = fv->keyframe ? (float)(int)fv->min_y : fv->min_y;
     f.inv_w = (float)GRID_COLS / (fv->max_x - fv->min_x); // mfGridElementWidthInv, src/Frame.cc:99
     f.inv_h = (float)GRID_ROWS / (fv->max_y - fv->min_y);
     f.cell_cnt = (int *)st->cells.p; f.cell_off = f.cell_cnt + ncell; f.cell_idx = f.cell_off + ncell + 1;
@@ -660,7 +669,7 @@ extern "C" int orbfe_fuse(orbfe_context *ctx, const orbfe_frame_view *kf, const 
         const float x = pc[0] * invz, y = pc[1] * invz;
         const float u = P->fx * x + P->cx;
         const float v = P->fy * y + P->cy;
-        if (!(u >= kf->min_x && u < kf->max_x && v >= kf->min_y && v < kf->max_y)) continue; // KeyFrame::IsInImage
+        if (!kf_is_in_image(kf, u, v)) continue; // KeyFrame::IsInImage
         float po[3];
         for (int k = 0; k < 3; k++) po[k] = pos[3 * i + k] - ow[k];
         const float dist3d = (float)sqrt((double)po[0] * po[0] + (double)po[1] * po[1] + (double)po[2] * po[2]);
@@ -741,7 +750,7 @@ static int sim3_projection_impl(orbfe_context *ctx, int mode, const orbfe_frame_
         const float x = pc[0] * invz, y = pc[1] * invz;
         const float u = P->fx * x + P->cx;
         const float v = P->fy * y + P->cy;
-        if (!(u >= kf->min_x && u < kf->max_x && v >= kf->min_y && v < kf->max_y)) continue;
+        if (!kf_is_in_image(kf, u, v)) continue;
         float po[3];
         for (int k = 0; k < 3; k++) po[k] = pos[3 * i + k] - ow[k];
         const float dist = (float)sqrt((double)po[0] * po[0] + (double)po[1] * po[1] + (double)po[2] * po[2]);
@@ -813,7 +822,7 @@ static int sim3_one_way(orbfe_context *ctx, const float *Taw, const float *sRt, 
         const float invz = (float)(1.0 / (double)pb[2]);
         const float x = pb[0] * invz, y = pb[1] * invz;
         const float u = P->fx * x + P->cx, v = P->fy * y + P->cy;
-        if (!(u >= kfb->min_x && u < kfb->max_x && v >= kfb->min_y && v < kfb->max_y)) continue;
+        if (!kf_is_in_image(kfb, u, v)) continue;
         const float dist = (float)sqrt((double)pb[0] * pb[0] + (double)pb[1] * pb[1] + (double)pb[2] * pb[2]);
         if (dist < 0.8f * min_distance[i] || dist > 1.2f * max_distance[i]) continue;
         const int lvl = predict_scale(max_distance[i], dist, log_sf, P->nlevels);

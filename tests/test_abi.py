@@ -24,12 +24,12 @@ def test_every_declared_symbol_is_exported():
     for n in names:
         assert hasattr(lib, n), "liborbfe.so does not export %s" % n
     assert sorted(api.EXPORTS) == names, "api.EXPORTS out of sync with include/orbfe.h"
-    assert lib.orbfe_abi_version() == 2  # 2: orbfe_frame_view.device_slot_plus1
+    assert lib.orbfe_abi_version() == 3  # 2: orbfe_frame_view.device_slot_plus1; 3: .keyframe
 
 
 def test_struct_layouts():
     assert C.sizeof(api.Params) == 17 * 4
-    assert C.sizeof(api.FrameView) == 4 + 4 + 3 * 8 + 4 * 4 + 4 + 4  # n, pad, 3 pointers, 4 floats, device_slot_plus1, tail pad
+    assert C.sizeof(api.FrameView) == 4 + 4 + 3 * 8 + 4 * 4 + 4 + 4  # n, pad, 3 pointers, 4 floats, device_slot_plus1, keyframe
     assert api.KP_DTYPE.itemsize == 28
 
 

@@ -342,8 +342,8 @@ def test_gpu_sim3_projection_matchers(gpu, mode, seed, th):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,th", [(60, 7.5), (61, 3.0)])
-def test_gpu_search_by_sim3(gpu, seed, th):
+@pytest.mark.parametrize("seed,th,kfb", [(60, 7.5, False), (61, 3.0, False), (62, 7.5, True)])
+def test_gpu_search_by_sim3(gpu, seed, th, kfb):
     """ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1098-1322) == oracle: two keyframes of the same 3-D points whose maps differ by a
     similarity; both projection directions and the mutual-consistency check."""
     api, ctx = gpu
@@ -355,7 +355,7 @@ def test_gpu_search_by_sim3(gpu, seed, th):
     T1 = _se3(0.0, [0, 0, 0]).astype(np.float64)
     T2 = _se3(4.0, [-0.5, 0.03, 0.1]).astype(np.float64)
     base_d = rng.integers(0, 256, (n, 32)).astype(np.uint8)
-    bounds = (0.0, float(W), 0.0, float(H))
+    bounds = KF_BOUNDS if kfb else (0.0, float(W), 0.0, float(H))  # kfb: a distorted camera's bounds, kept as ints by the keyframes
 
     def keyframe(T, seed2, extra):
         r = np.random.default_rng(seed2)
@@ -379,17 +379,66 @@ def test_gpu_search_by_sim3(gpu, seed, th):
     R12 = (T1[:, :3] @ T2[:, :3].T)
     t12 = T1[:, 3] - R12 @ T2[:, 3]
     s12 = np.float32(1.02)
-    g1, g2 = O.Grid(k1, *bounds), O.Grid(k2, *bounds)
+    g1, g2 = O.Grid(k1, *bounds, keyframe=kfb), O.Grid(k2, *bounds, keyframe=kfb)
     pts1 = (pos1, mx1, mn1, d1, v1); pts2 = (pos2, mx2, mn2, d2, v2)  # GetDescriptor() = the observing keypoint's descriptor here
     ref, nref = O.search_by_sim3(g1, d1, T1.astype(np.float32), pts1, g2, d2, T2.astype(np.float32), pts2, sf, CAM, LOG_SF, NL,
                                  s12, R12.astype(np.float32), t12.astype(np.float32), th)
-    view1 = ctx._view(k1, None, d1, bounds); view2 = ctx._view(k2, None, d2, bounds)
+    view1 = ctx._view(k1, None, d1, bounds, keyframe=kfb); view2 = ctx._view(k2, None, d2, bounds, keyframe=kfb)
     got, ngot = ctx.search_by_sim3(view1, T1.astype(np.float32), pts1, view2, T2.astype(np.float32), pts2, s12, R12.astype(np.float32),
                                    t12.astype(np.float32), th)
     assert ngot == nref and np.array_equal(got, ref)
     assert nref > 150
     ok = np.nonzero(ref >= 0)[0]
     assert (perm1[ok] == perm2[ref[ok]]).mean() > 0.9  # same 3-D point on both sides
+
+# Image bounds of a distorted camera (Frame::ComputeImageBounds undistorts the four corners): not whole numbers.  A KeyFrame keeps
+# them as ints (include/KeyFrame.h:194-197) while its grid was filled by the Frame with the floats.
+KF_BOUNDS = (-13.62, W + 10.71, -9.37, H + 7.48)
+
+
+@pytest.mark.gpu
+def test_gpu_keyframe_views_use_the_keyframes_integer_bounds(gpu):
+    """KeyFrame-side matchers with the bounds of a DISTORTED camera: cells assigned with the frame's float bounds, windows
+    (KeyFrame::GetFeaturesInArea, src/KeyFrame.cc:568-580) and IsInImage (:604-607) with their integer truncation -- Fuse, the
+    two Sim3 matchers and SearchBySim3 against the oracle's keyframe grid; and the flag is not a no-op on this data."""
+    api, ctx = gpu
+    s = _scene(71, n_last=1500, n_distract=400)
+    rng = np.random.default_rng(71)
+    n = len(s["pos"])
+    dist0 = np.linalg.norm(s["pos"], axis=1).astype(np.float32)
+    max_d = (dist0 * s["sf"][s["octave"]]).astype(np.float32)
+    min_d = (max_d / s["sf"][NL - 1]).astype(np.float32)
+    normal = (s["pos"] / dist0[:, None] + rng.normal(0, 0.45, (n, 3))).astype(np.float32)
+    normal = (normal / np.linalg.norm(normal, axis=1, keepdims=True)).astype(np.float32)
+    ex = s["ex"]
+    g = O.Grid(s["k"], *KF_BOUNDS, keyframe=True)
+    view = ctx._view(s["k"], s["ur"], s["d"], KF_BOUNDS, keyframe=True)
+    # the raw window query: integer bounds move cell borders by up to 0.62 px, so some windows gain or lose a cell column / row
+    g_frame = O.Grid(s["k"], *KF_BOUNDS)
+    qx = rng.uniform(0, W, 600).astype(np.float32); qy = rng.uniform(0, H, 600).astype(np.float32); qr = rng.uniform(2, 30, 600).astype(np.float32)
+    got_q = ctx.features_in_area_batch(view, qx, qy, qr)
+    for i in range(600):
+        assert np.array_equal(got_q[i], g.features_in_area(qx[i], qy[i], qr[i]))
+    # Fuse
+    ref, nref = O.fuse(g, s["ur"], s["d"], s["sf"], ex.inv_sigma2(), CAM, s["T_cur"], LOG_SF, NL, s["pos"], normal, max_d, min_d, s["desc_last"], s["valid"], 3.0)
+    got, ngot = ctx.fuse(view, s["T_cur"], s["pos"], normal, max_d, min_d, s["desc_last"], s["valid"], 3.0)
+    assert ngot == nref and np.array_equal(got, ref) and nref > 100
+    # Sim3 SearchByProjection / Fuse
+    Scw = s["T_cur"].copy(); Scw *= np.float32(1.07)
+    kf_matched = (rng.random(len(s["k"])) < 0.1).astype(np.uint8)
+    for mode in (0, 1):
+        ref, nref = O.sim3_projection(mode, g, s["d"], s["sf"], CAM, Scw, LOG_SF, NL, s["pos"], normal, max_d, min_d, s["desc_last"], s["valid"], kf_matched, 6.0)
+        got, ngot = ctx.sim3_projection(mode, view, Scw, s["pos"], normal, max_d, min_d, s["desc_last"], s["valid"], kf_matched, 6.0)
+        assert ngot == nref and np.array_equal(got, ref) and nref > 100
+    # the cell ranges of the keyframe grid differ from the frame grid's for some windows of this scene (the flag matters)
+    differ = 0
+    cells = lambda grid, x, y, r: (int(np.floor((x - grid[0] - r) * grid[2])), int(np.ceil((x - grid[0] + r) * grid[2])))
+    inv_w = np.float32(64.0) / (np.float32(KF_BOUNDS[1]) - np.float32(KF_BOUNDS[0]))
+    for i in range(600):
+        a = cells((np.float32(KF_BOUNDS[0]), 0, inv_w), qx[i], 0, qr[i])
+        b = cells((np.float32(int(KF_BOUNDS[0])), 0, inv_w), qx[i], 0, qr[i])
+        differ += a != b
+    assert differ > 10
 
 
 def _frame_scene(k, d, ur, seed, all_points=False):
