@@ -291,7 +291,7 @@ static int build_config(orbfe_context *ctx)
         if (L.sel_cap + 1 > max_nodes) max_nodes = L.sel_cap + 1;
         L.blur_tile_off = tile_off;
         L.blur_tiles_x = (L.w + 255) / 256;
-        L.blur_tiles_y = (L.h + 31) / 32; // BL_ROWS of blur_kernel
+        L.blur_tiles_y = (L.h + 15) / 16; // BL_ROWS of blur_kernel
         tile_off += L.blur_tiles_x * L.blur_tiles_y;
     }
     c.pyr_bytes = pyr_off;
