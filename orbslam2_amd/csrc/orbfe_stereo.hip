@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, Dev
 {
     // XCD-aware block -> (pair, block) map: all blocks of a pair on one XCD (its L2 then holds the pair's
     // descriptors, keypoints and the pyramid rows the SAD windows touch)
+    __shared__ uint2 s_cand[(256 / SM_G) * 4 * SM_G]; // per 16-lane group: the candidates of a 64-entry chunk that passed the filter
     const int kpb = 256 / SM_G;
     const int bpp = (cfg.sel_total + kpb - 1) / kpb;
     int pair, blk;
@@ -74,10 +75,45 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, Dev
     int cnt = 0;
     if (row >= 0 && row < cfg.height) cnt = buf.row_cnt[(size_t)pair * cfg.height + row];
     if (cnt <= cfg.row_cap) {
+        // Two rounds of loads instead of two per candidate: (1) every lane fetches up to four list entries at once and applies
+        // the octave / disparity filter (about a fifth pass); (2) the survivors are packed into a per-group LDS list through a
+        // ballot, so that each lane then fetches ONE survivor's descriptor -- all in flight together.  A row list of ~50
+        // entries used to cost four dependent entry -> descriptor round trips per lane.
         const uint2 *rent = buf.row_ent + ((size_t)pair * cfg.height + row) * cfg.row_cap;
-        for (int j = gl; j < cnt; j += SM_G) {
-            const uint2 e = rent[j];
-            consider((int)(e.x & 0xffffu), (int)(e.x >> 16), __uint_as_float(e.y));
+        uint2 *s_list = s_cand + (threadIdx.x / SM_G) * (4 * SM_G);
+        const int gshift = (threadIdx.x & 63) & ~(SM_G - 1); // first lane of this group inside its wave
+        for (int j0 = 0; j0 < cnt; j0 += 4 * SM_G) {
+            uint2 e[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + gl + SM_G * u;
+                e[u] = rent[j < cnt ? j : cnt - 1];
+            }
+            int n_pass = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + gl + SM_G * u;
+                const int oct = (int)(e[u].x >> 16);
+                const float xr = __uint_as_float(e[u].y);
+                ok[u] = j < cnt && oct >= level_l - 1 && oct <= level_l + 1 && xr >= min_u && xr <= max_u;
+                const unsigned slice = (unsigned)(__ballot(ok[u]) >> gshift) & ((1u << SM_G) - 1u);
+                if (ok[u]) s_list[n_pass + __popc(slice & ((1u << gl) - 1u))] = e[u];
+                n_pass += __popc(slice);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f); // this wave's LDS writes have landed (the groups of a wave run in lockstep)
+            __builtin_amdgcn_wave_barrier();
+            for (int k = gl; k < n_pass; k += SM_G) {
+                const uint2 c = s_list[k];
+                const int iR = (int)(c.x & 0xffffu);
+                const uint4 *p = (const uint4 *)(dR + (size_t)iR * 32);
+                const uint4 lo = p[0], hi = p[1];
+                const uint32_t dr[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                const unsigned key = ((unsigned)hamming256(dl, dr) << 16) | (unsigned)iR;
+                if (key < best) { best = key; best_x = __uint_as_float(c.y); }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier(); // the list is rewritten by the next chunk
         }
     } else { // the row's list overflowed its capacity: test every right keypoint's band
         for (int iR = gl; iR < nR; iR += SM_G) {
