@@ -596,6 +596,36 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
         }
         b.bk_tab = d_tab;
     }
+    {   // FAST cell table: what fast_cell_kernel's prologue would otherwise derive per wave from a chain of dependent scalar loads
+        // (level search over lv[].cell_off, a division by n_cols, the clipping of src/ORBextractor.cc:783-800)
+        std::vector<uint32_t> ci((size_t)c.cells_total * 4, 0u);
+        for (int l = 0; l < p.nlevels; l++) {
+            const LevelInfo &L = c.lv[l];
+            const int max_bx = L.w - c.edge_threshold + 3, max_by = L.h - c.edge_threshold + 3;
+            for (int k = 0; k < L.n_cells; k++) {
+                const int i = k / L.n_cols, j = k - i * L.n_cols;
+                const int ini_y = c.min_border + i * L.h_cell, ini_x = c.min_border + j * L.w_cell;
+                int max_y = ini_y + L.h_cell + 6, max_x = ini_x + L.w_cell + 6;
+                uint32_t *e = &ci[(size_t)(L.cell_off + k) * 4];
+                e[0] = (uint32_t)l; e[3] = (uint32_t)k;
+                if (ini_y >= max_by - 3 || ini_x >= max_bx - 6) continue; // src/ORBextractor.cc:788-798: no FAST call
+                if (max_y > max_by) max_y = max_by;
+                if (max_x > max_bx) max_x = max_bx;
+                const int tw = max_x - ini_x, th = max_y - ini_y;
+                if (tw - 6 <= 0 || th - 6 <= 0) continue;
+                e[0] |= 1u << 8;
+                e[1] = (uint32_t)ini_x | ((uint32_t)ini_y << 16);
+                e[2] = (uint32_t)tw | ((uint32_t)th << 8);
+            }
+        }
+        uint32_t *d_ci = nullptr;
+        A(d_ci, ci.size());
+        if (hipMemcpy(d_ci, ci.data(), ci.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            orbfe_destroy(ctx);
+            return fail(nullptr, ORBFE_ERR_HIP, "cell table upload failed");
+        }
+        b.cell_info = (const uint4 *)d_ci;
+    }
     {   // keypoint slot -> level
         std::vector<uint8_t> sl(c.sel_total);
         for (int l = 0; l < p.nlevels; l++)

@@ -124,39 +124,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     const int cell = blk * 4 + wave;
     if (cell >= cfg.cells_total) return;
     uint8_t *s_mem = s_mem_all + wave * lds_per_wave;
-    int level = 0;
-    for (int l = 1; l < cfg.nlevels; l++)
-        if (cell >= cfg.lv[l].cell_off) level = l;
+    // the cell's level, position and clipped tile size from the host-built table (one scalar load instead of the level search,
+    // a division and the clipping of src/ORBextractor.cc:783-800 behind a chain of dependent scalar loads)
+    const uint4 cinfo = buf.cell_info[cell];
+    const int level = (int)(cinfo.x & 0xffu);
     const LevelInfo &L = cfg.lv[level];
-    const int ci = cell - L.cell_off;
-    const int ci_i = small_div(ci, L.n_cols), ci_j = ci - ci_i * L.n_cols;
+    const int ci = (int)cinfo.w;
     const int lane = threadIdx.x & 63;
     int *cnt_out = buf.cell_cnt + (size_t)img * cfg.cells_total + cell;
-
-    const int min_b = cfg.min_border;
-    const int max_bx = L.w - cfg.edge_threshold + 3;
-    const int max_by = L.h - cfg.edge_threshold + 3;
-    const int ini_y = min_b + ci_i * L.h_cell;
-    const int ini_x = min_b + ci_j * L.w_cell;
-    int max_y = ini_y + L.h_cell + 6;
-    int max_x = ini_x + L.w_cell + 6;
-    if (ini_y >= max_by - 3 || ini_x >= max_bx - 6) { // src/ORBextractor.cc:788-798
+    if (!(cinfo.x & 0x100u)) { // no FAST call for this cell (src/ORBextractor.cc:788-798)
         if (lane == 0) *cnt_out = 0;
         return;
     }
-    if (max_y > max_by) max_y = max_by;
-    if (max_x > max_bx) max_x = max_bx;
-    const int tw = max_x - ini_x, th = max_y - ini_y;
+    const int ini_x = (int)(cinfo.y & 0xffffu), ini_y = (int)(cinfo.y >> 16);
+    const int max_x = ini_x + (int)(cinfo.z & 0xffu);
+    const int tw = (int)(cinfo.z & 0xffu), th = (int)((cinfo.z >> 8) & 0xffu);
     const int iw = tw - 6, ih = th - 6;
-    if (iw <= 0 || ih <= 0) {
-        if (lane == 0) *cnt_out = 0;
-        return;
-    }
+    const int cell_x0 = ini_x - cfg.min_border, cell_y0 = ini_y - cfg.min_border; // j * wCell, i * hCell
     // bucket tables of this cell's columns / rows (BK): issued now, consumed in phase E
     unsigned tabx = 0u, taby = 0u;
     if (BK) {
-        const uint32_t *bx_tab = buf.bk_tab + L.bk_xoff + 3 + ci_j * L.w_cell; // survivor x = c + 3 + j * wCell
-        const uint32_t *by_tab = buf.bk_tab + L.bk_yoff + 3 + ci_i * L.h_cell;
+        const uint32_t *bx_tab = buf.bk_tab + L.bk_xoff + 3 + cell_x0; // survivor x = c + 3 + j * wCell
+        const uint32_t *by_tab = buf.bk_tab + L.bk_yoff + 3 + cell_y0;
         tabx = bx_tab[lane < iw ? lane : iw - 1];
         taby = by_tab[lane < ih ? lane : ih - 1];
     }
@@ -484,8 +473,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         if (BK) { tx = (unsigned)__shfl((int)tabx, c, 64); ty = (unsigned)__shfl((int)taby, r, 64); }
         if (v) {
             // cell-local FAST coords (c+3, r+3) + (j*wCell, i*hCell): src/ORBextractor.cc:816-817
-            const unsigned x = (unsigned)(c + 3 + ci_j * L.w_cell);
-            const unsigned y = (unsigned)(r + 3 + ci_i * L.h_cell);
+            const unsigned x = (unsigned)(c + 3 + cell_x0);
+            const unsigned y = (unsigned)(r + 3 + cell_y0);
             const unsigned sc = s_sc[(r + 1) * scp + c + 1];
             oxy[pos] = x | (y << 16);
             osc[pos] = (uint8_t)sc;
