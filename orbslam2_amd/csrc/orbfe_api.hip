@@ -626,6 +626,21 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
         }
         b.cell_info = (const uint4 *)d_ci;
     }
+    {   // blur tile table (blur_kernel): level, 256-column strip and first row of every wave's tile
+        std::vector<uint32_t> ti((size_t)(c.blur_tiles_total > 0 ? c.blur_tiles_total : 1), 0u);
+        for (int l = 0; l < p.nlevels; l++) {
+            const LevelInfo &L = c.lv[l];
+            for (int t = 0; t < L.blur_tiles_x * L.blur_tiles_y; t++)
+                ti[L.blur_tile_off + t] = (uint32_t)l | ((uint32_t)(t % L.blur_tiles_x) << 8) | ((uint32_t)((t / L.blur_tiles_x) * 16) << 16); // 16 = BL_ROWS
+        }
+        uint32_t *d_ti = nullptr;
+        A(d_ti, ti.size());
+        if (hipMemcpy(d_ti, ti.data(), ti.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            orbfe_destroy(ctx);
+            return fail(nullptr, ORBFE_ERR_HIP, "blur tile table upload failed");
+        }
+        b.blur_tile_info = d_ti;
+    }
     {   // keypoint slot -> level
         std::vector<uint8_t> sl(c.sel_total);
         for (int l = 0; l < p.nlevels; l++)

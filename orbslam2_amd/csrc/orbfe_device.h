@@ -125,6 +125,7 @@ struct DeviceBuffers {
     const uint32_t *bk_tab; // quadtree bucket tables: per level X[region_w] then Y[region_h] (see ORBFE_BK_*)
     const uint32_t *rs_tab; // cv::resize offset/weight tables of every level (see pyr_resize_kernel)
     const uint4 *cell_info; // [cells_total] FAST cells: level | valid << 8, ini_x | ini_y << 16, tile w | h << 8, index inside the level (fast_cell_kernel)
+    const uint32_t *blur_tile_info; // [blur_tiles_total] level | column strip << 8 | first row << 16 (blur_kernel)
     const int *tail_plan;   // [tail_strips][ORBFE_TAIL_MAX][4]: first extended column, words, first staged source column, staged words (pyr_tail_kernel)
     long long *dbg_ts;   // 4096 timestamps for kernel bring-up (ORBFE_OT2_STOP=99); never read by product code
     const uint8_t *slot_level; // [sel_total] level of every keypoint slot

@@ -427,13 +427,10 @@ __global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffe
     const int lane = threadIdx.x & 63;
     const int u = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (u >= cfg.blur_tiles_total) return;
-    int level = 0;
-    for (int l = 1; l < cfg.nlevels; l++)
-        if (u >= cfg.lv[l].blur_tile_off) level = l;
-    const LevelInfo &L = cfg.lv[level];
-    const int t = u - L.blur_tile_off;
-    const int x0 = (t % L.blur_tiles_x) * BL_COLS + lane * 4;
-    const int r0 = (t / L.blur_tiles_x) * BL_ROWS;
+    const uint32_t ti = buf.blur_tile_info[u]; // host-built: saves the per-wave level search (a chain of dependent scalar loads)
+    const LevelInfo &L = cfg.lv[ti & 0xffu];
+    const int x0 = (int)((ti >> 8) & 0xffu) * BL_COLS + lane * 4;
+    const int r0 = (int)(ti >> 16);
     if (x0 >= L.w || r0 >= L.h) return;
     const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + x0;
     // output in 32 x 4 px tiles of 128 B: describe_kernel's 37-row patches then touch about half as many cache lines
