@@ -467,6 +467,33 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
                 D.rs_src_rows[v] = worst;
             }
         }
+        {   // per-block source-row range of the resize launches (pyr_resize_kernel stages it before it has read any row table)
+            std::vector<uint32_t> blk;
+            for (int l = 1; l < p.nlevels; l++) {
+                LevelInfo &D = ctx->cfg.lv[l];
+                const int src_words = (ctx->cfg.lv[l - 1].w + 3) / 4, ny = D.h + 6;
+                D.rs_rw = (size_t)D.rs_src_rows[0] * src_words * 4 <= 60 * 1024 ? 4 : ((size_t)D.rs_src_rows[1] * src_words * 4 <= 60 * 1024 ? 2 : 1);
+                D.rs_blk_off = (int)blk.size();
+                const int rows = 4 * D.rs_rw;
+                for (int y0 = 0; y0 < ny; y0 += rows) {
+                    int lo = INT_MAX, hi = -1;
+                    for (int i = y0; i < y0 + rows && i < ny; i++) {
+                        const uint32_t e = tab[D.rs_ytab_off + i];
+                        const int a = (int)(e & 0xffffu), b2 = (int)(e >> 16);
+                        lo = std::min(lo, std::min(a, b2)); hi = std::max(hi, std::max(a, b2));
+                    }
+                    blk.push_back((uint32_t)lo | ((uint32_t)(hi - lo + 1) << 16));
+                }
+            }
+            if (blk.empty()) blk.push_back(0);
+            uint32_t *d_blk = nullptr;
+            A(d_blk, blk.size());
+            if (hipMemcpy(d_blk, blk.data(), blk.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+                orbfe_destroy(ctx);
+                return fail(nullptr, ORBFE_ERR_HIP, "resize block table upload failed");
+            }
+            b.rs_blk = d_blk;
+        }
         {   // plan of the fused pyramid tail (pyr_tail_kernel): a workgroup owns a strip of ORBFE_TAIL_COLS extended columns of
             // the LAST level over all its rows and computes, level by level in LDS, exactly the columns of the previous tail
             // levels that strip needs (plus the margin columns at the image's left / right, which no later level reads);

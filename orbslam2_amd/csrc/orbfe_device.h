@@ -46,6 +46,7 @@ struct LevelInfo {
     int rs_xtab_off, rs_xtab_n;    // resize column table (two planes of rs_xtab_n words) in DeviceBuffers::rs_tab
     int rs_ytab_off, rs_ytab_n;    // resize row table
     int rs_src_rows[3];            // source rows spanned by the worst block of 16 / 8 / 4 output rows (pyr_resize_kernel)
+    int rs_rw, rs_blk_off;         // rows per wave the launch uses (4 / 2 / 1) and this level's entries in DeviceBuffers::rs_blk
     int bk_xoff, bk_yoff;          // quadtree bucket tables of this level in DeviceBuffers::bk_tab (orbfe_octree3.hip)
 };
 
@@ -126,6 +127,7 @@ struct DeviceBuffers {
     const uint32_t *rs_tab; // cv::resize offset/weight tables of every level (see pyr_resize_kernel)
     const uint4 *cell_info; // [cells_total] FAST cells: level | valid << 8, ini_x | ini_y << 16, tile w | h << 8, index inside the level (fast_cell_kernel)
     const uint32_t *blur_tile_info; // [blur_tiles_total] level | column strip << 8 | first row << 16 (blur_kernel)
+    const uint32_t *rs_blk; // per (level, block of 4 * rs_rw output rows): first source row | source rows << 16 (pyr_resize_kernel)
     const int *tail_plan;   // [tail_strips][ORBFE_TAIL_MAX][4]: first extended column, words, first staged source column, staged words (pyr_tail_kernel)
     long long *dbg_ts;   // 4096 timestamps for kernel bring-up (ORBFE_OT2_STOP=99); never read by product code
     const uint8_t *slot_level; // [sel_total] level of every keypoint slot

@@ -178,20 +178,13 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(DeviceConfig cfg, Devic
     const int xi_first = (lane < nwords ? lane : 0) * 4;
     uint4 X0 = *(const uint4 *)(xt + xi_first);
     uint4 X1 = *(const uint4 *)(xt + D.rs_xtab_n + xi_first);
-    // source row range of the block (every wave computes it: lanes < nrows hold one output row each)
-    const uint32_t Yl = yt[y0 + (lane < nrows ? lane : 0)];
-    int smin = (int)(Yl & 0xffffu), smax = (int)(Yl >> 16);
-    { const int t = smin < smax ? smin : smax; smax = smin < smax ? smax : smin; smin = t; }
-#pragma unroll
-    for (int o = 1; o < 4 * RW; o <<= 1) {
-        const int a = __shfl_xor(smin, o, 64), b = __shfl_xor(smax, o, 64);
-        smin = a < smin ? a : smin; smax = b > smax ? b : smax;
-    }
-    smin = __builtin_amdgcn_readfirstlane(smin); smax = __builtin_amdgcn_readfirstlane(smax);
+    // source row range of the block: host-built (one scalar load), so the staging below does not wait for a row-table read
+    const uint32_t be = buf.rs_blk[D.rs_blk_off + blockIdx.x];
+    const int smin = (int)(be & 0xffffu), smax = smin + (int)(be >> 16) - 1;
     int n_src = smax - smin + 1;
     if (n_src > max_src_rows) n_src = max_src_rows; // cannot happen: the host sized max_src_rows from the same table
     {
-        int r = (int)(((float)tid + 0.5f) * (1.0f / (float)src_words)), c = tid - r * src_words;
+        int r = small_div(tid, src_words), c = tid - r * src_words;
         const int dr = 256 / src_words, dc = 256 - dr * src_words;
         const uint8_t *sp = src + (size_t)smin * S.pitch;
         const int nw = n_src * src_words;
@@ -508,10 +501,10 @@ void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int
         // rows per wave: the largest of 4, 2, 1 whose staged source rows fit 60 KB of LDS (rs_src_rows[i] = source
         // row span of the worst block of 16 / 8 / 4 output rows, from the host's row table)
         const int *span = cfg.lv[l].rs_src_rows;
-        if ((size_t)span[0] * src_words * 4 <= 60 * 1024) {
+        if (cfg.lv[l].rs_rw == 4) {
             dim3 grid((total_rows + 15) / 16, n_images);
             hipLaunchKernelGGL(pyr_resize_kernel<4>, grid, dim3(256), (size_t)span[0] * src_words * 4, s, cfg, buf, l, src_words, span[0]);
-        } else if ((size_t)span[1] * src_words * 4 <= 60 * 1024) {
+        } else if (cfg.lv[l].rs_rw == 2) {
             dim3 grid((total_rows + 7) / 8, n_images);
             hipLaunchKernelGGL(pyr_resize_kernel<2>, grid, dim3(256), (size_t)span[1] * src_words * 4, s, cfg, buf, l, src_words, span[1]);
         } else {
