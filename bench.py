@@ -129,14 +129,17 @@ def host_fed(api, torch, dev, host, P, ctx0, steps=10):
                 self.ctx.fetch_batch_async(2 * P, *[h.data_ptr() for h in self.h_out], self.stream.cuda_stream)
 
     def run(lanes):
-        for l in lanes:
-            l.step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(steps):
-            lanes[k % len(lanes)].step()
-        torch.cuda.synchronize()
-        return P * steps / (time.perf_counter() - t0)
+        best = 0.0
+        for rep in range(3):  # best of three short passes: one page-fault or clock stall otherwise decides a 10-step figure
+            for l in lanes:
+                l.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                lanes[k % len(lanes)].step()
+            torch.cuda.synchronize()
+            best = max(best, P * steps / (time.perf_counter() - t0))
+        return best
 
     p = ctx0.params
     ctx1 = api.Context(width=p.width, height=p.height, nfeatures=p.nfeatures, scale_factor=p.scale_factor, nlevels=p.nlevels,
@@ -145,7 +148,7 @@ def host_fed(api, torch, dev, host, P, ctx0, steps=10):
     a, b = Lane(ctx0), Lane(ctx1)
     out = {"unit": "frames/s", "serial": run([a]), "overlapped": run([a, b]),
            "bytes_up_per_step": int(h_in.numel()), "bytes_down_per_step": int(sum(a.sizes)),
-           "note": "pinned host memory in and out; serial = one stream, overlapped = two contexts on two streams"}
+           "note": "pinned host memory in and out; serial = one stream, overlapped = two contexts on two streams; best of 3 passes of 10 steps"}
     ctx1.close()
     return out
 
