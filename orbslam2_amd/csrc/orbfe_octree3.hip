@@ -181,7 +181,10 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     __shared__ int s_w[4 * OT3_WAVES];
     __shared__ int s_scal[8];
-    const int level = blockIdx.x, img = blockIdx.y;
+    // longest first: the workgroups of level 0 (largest quota, most split passes) are dispatched before those of level 1, ...; with
+    // one or two LDS-filling workgroups per CU the launch then ends about (total work / CUs) after the last level-0 group, instead of
+    // every round of (image, all levels) groups waiting for its level-0 member
+    const int img = blockIdx.x, level = blockIdx.y;
     const LevelInfo &L = cfg.lv[level];
     const int tid = threadIdx.x;
     const int MAXN = cfg.max_nodes;
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(OT3_THREADS) void candidates_gather_kernel(DeviceCo
 
 void orbfe_launch_octree3(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, size_t lds, bool nodes_in_hbm, hipStream_t s)
 {
-    dim3 grid(cfg.nlevels, n_images);
+    dim3 grid(n_images, cfg.nlevels);
     const size_t node_bytes = orbfe_octree3_node_bytes(cfg.max_nodes, sort_cap);
     if (nodes_in_hbm) hipLaunchKernelGGL(octree3_kernel<true>, grid, dim3(OT3_THREADS), lds, s, cfg, buf, sort_cap, node_bytes);
     else hipLaunchKernelGGL(octree3_kernel<false>, grid, dim3(OT3_THREADS), lds, s, cfg, buf, sort_cap, node_bytes);
