@@ -82,6 +82,37 @@ def test_ramp_image_every_pixel_passes_both_polarities(ini, mn):
     ctx.close()
 
 
+@pytest.mark.parametrize("square,blur", [(24, False), (37, True)])
+def test_checkerboard_many_tied_scores(square, blur):
+    """A calibration checkerboard (the reference ships one for its camera calibration tool): flat squares, corners in a regular
+    lattice, and -- without blur -- thousands of candidates with IDENTICAL FAST scores, so the NMS strictness, the quadtree's
+    first-maximum rule and the order of equal responses decide which keypoints survive.  Stereo frame bit-exact."""
+    from orbslam2_amd import api
+    w, h = 752, 480
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.where(((xx // square) + (yy // square)) % 2 == 0, 225, 30).astype(np.float32)
+    if blur:  # soft edges and a brightness ramp: scores differ, many cells need the minTh attempt
+        k = np.array([1, 4, 6, 4, 1], np.float32) / 16
+        img = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 1, img)
+        img = np.apply_along_axis(lambda c: np.convolve(c, k, mode="same"), 0, img)
+        img = img * (0.55 + 0.45 * xx / w)
+    left = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    right = np.roll(left, -9, axis=1)
+    fx, bf = 460.0, 50.0
+    ctx = api.Context(width=w, height=h, nfeatures=1200, fx=fx, fy=fx, cx=w / 2, cy=h / 2, bf=bf)
+    out = ctx.stereo_frame(left, right)
+    exl, exr = O.Extractor(nfeatures=1200), O.Extractor(nfeatures=1200)
+    kl, dl = exl.extract(left); kr, dr = exr.extract(right)
+    ur, dp, _ = O.stereo_matches(exl, exr, kl, dl, kr, dr, bf, fx)
+    assert len(kl) > 300
+    if not blur:
+        assert len(np.unique(kl["response"])) < len(kl) // 8  # heavy ties
+    assert np.array_equal(out["kps_left"], kl.astype(api.KP_DTYPE)) and np.array_equal(out["kps_right"], kr.astype(api.KP_DTYPE))
+    assert np.array_equal(out["desc_left"], dl) and np.array_equal(out["desc_right"], dr)
+    assert np.array_equal(out["u_right"], ur) and np.array_equal(out["depth"], dp)
+    ctx.close()
+
+
 def test_reuse_context_many_frames():
     from orbslam2_amd import api
     ctx = api.Context(width=480, height=320, nfeatures=700, fx=400.0, fy=400.0, cx=240.0, cy=160.0, bf=100.0)
