@@ -21,7 +21,7 @@ __device__ __attribute__((aligned(16))) const int8_t g_pattern[1024] = {
 #define DS_BLR_REGS 6 // 37 rows * 10 words = 370 words
 
 
-__global__ __launch_bounds__(256, 6) void describe_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int stereo ORBFE_CUT_PARAM)
+__global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int stereo ORBFE_CUT_PARAM)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dm[];
     // XCD-aware block -> (image, block) map: workgroups are dealt round-robin over the 8 XCDs, so block
