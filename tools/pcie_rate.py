@@ -43,15 +43,19 @@ class Lane:
 
 
 def run(lanes, steps=20):
-    for l in lanes:
-        l.step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(steps):
-        lanes[k % len(lanes)].step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return P * steps / dt, dt / steps * 1e3
+    best = None
+    for rep in range(3):  # best of three passes: the first pass after a context is created sometimes runs at half speed
+        for l in lanes:
+            l.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            lanes[k % len(lanes)].step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best = dt
+    return P * steps / best, best / steps * 1e3
 
 
 a, b = Lane(), Lane()
