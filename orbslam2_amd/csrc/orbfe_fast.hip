@@ -79,12 +79,12 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(
 __device__ __forceinline__ void lds_store_lo16(unsigned long long m, unsigned addr, unsigned v)
 {
     unsigned long long save;
-    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16 %2, %3\n\ts_or_b64 exec, exec, %0" : "=&s"(save) : "s"(m), "v"(addr), "v"(v) : "memory");
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16 %2, %3\n\ts_or_b64 exec, exec, %0" : "=&s"(save) : "s"(m), "v"(addr), "v"(v) : "memory", "scc");
 }
 __device__ __forceinline__ void lds_store_hi16(unsigned long long m, unsigned addr, unsigned v)
 {
     unsigned long long save;
-    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16_d16_hi %2, %3\n\ts_or_b64 exec, exec, %0" : "=&s"(save) : "s"(m), "v"(addr), "v"(v) : "memory");
+    asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b16_d16_hi %2, %3\n\ts_or_b64 exec, exec, %0" : "=&s"(save) : "s"(m), "v"(addr), "v"(v) : "memory", "scc");
 }
 
 // ---- packed half-precision min / max for the exact score (phase C) ------------------------------------------------------
