@@ -291,7 +291,7 @@ static int build_config(orbfe_context *ctx)
         if (L.sel_cap + 1 > max_nodes) max_nodes = L.sel_cap + 1;
         L.blur_tile_off = tile_off;
         L.blur_tiles_x = (L.w + 255) / 256;
-        L.blur_tiles_y = (L.h + 15) / 16; // BL_ROWS of blur_kernel
+        L.blur_tiles_y = (L.h + ORBFE_BLUR_ROWS - 1) / ORBFE_BLUR_ROWS;
         tile_off += L.blur_tiles_x * L.blur_tiles_y;
     }
     c.pyr_bytes = pyr_off;
@@ -658,7 +658,7 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
         for (int l = 0; l < p.nlevels; l++) {
             const LevelInfo &L = c.lv[l];
             for (int t = 0; t < L.blur_tiles_x * L.blur_tiles_y; t++)
-                ti[L.blur_tile_off + t] = (uint32_t)l | ((uint32_t)(t % L.blur_tiles_x) << 8) | ((uint32_t)((t / L.blur_tiles_x) * 16) << 16); // 16 = BL_ROWS
+                ti[L.blur_tile_off + t] = (uint32_t)l | ((uint32_t)(t % L.blur_tiles_x) << 8) | ((uint32_t)((t / L.blur_tiles_x) * ORBFE_BLUR_ROWS) << 16);
         }
         uint32_t *d_ti = nullptr;
         A(d_ti, ti.size());

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void pyr_tail_kernel(DeviceConfig cfg
 // the last seven row-sum vectors in registers and emits one 4-px output word.  No LDS, no barriers;
 // HBM traffic = one read of the level (+6/BL_ROWS row halo, L2-served) and one write.
 // ---------------------------------------------------------------------------
-#define BL_ROWS 16  // rows per wave: 6 / BL_ROWS of the rows are loaded (and row-filtered) twice; 16 beats 32 (0.117 -> 0.114 ms: more waves) and 8 / 64
+#define BL_ROWS ORBFE_BLUR_ROWS // rows per wave: 6 / BL_ROWS of the rows are loaded (and row-filtered) twice; 16 beats 32 (0.117 -> 0.114 ms: more waves) and 8 / 64
 #define BL_COLS 256 // per wave: 64 lanes x 4 px
 __global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffers buf)
 {
