@@ -1,0 +1,178 @@
+"""oracle/literal_bow.py -- TEST INFRASTRUCTURE (never imported by the product, bench.py's timed region or smoke()).
+
+A second, independent statement of the bag-of-words row: the loops of the vendored fbow library and of the reference's
+BoW matcher transcribed LITERALLY into Python -- the vocabulary as the byte blob fbow reads (`Vocabulary::fromStream`), blocks
+addressed through the same offsets, `std::map` as a dict walked in key order, the two-pointer merges with `lower_bound` as
+written.  It shares no code with oracle/orb_oracle_bow.c (sorted arrays, binary searches) or orbslam2_amd/csrc/orbfe_bow.hip
+(thread per descriptor, pair kernels), so `C oracle == this file` checks their array formulations against the reference's own
+containers.  Pure-Python loops: small cases only.
+
+Transcribed (reference file:line):
+  fbow::Vocabulary::fromStream / params / Block          Thirdparty/fbow/src/fbow.cpp:181-191, fbow.h:117-178
+  fbow::Vocabulary::transform(features, level, r1, r2)   Thirdparty/fbow/src/fbow.cpp:50-86 -> _transform2<L1_32bytes>, fbow.h:400-444
+  fbow::fBow::score                                      Thirdparty/fbow/src/fbow.cpp:206-254
+  ORBmatcher::SearchByFboW(KeyFrame*, Frame&, matches)   src/ORBmatcher.cc:157-283
+  ORBmatcher::ComputeThreeMaxima / DescriptorDistance    src/ORBmatcher.cc:1597-1659 (from oracle/literal_matchers.py)
+"""
+from __future__ import annotations
+
+import math
+import struct
+
+import numpy as np
+
+from .literal_matchers import HISTO_LENGTH, TH_LOW, c_round, compute_three_maxima, descriptor_distance
+
+F32 = np.float32
+
+
+class Vocabulary:
+    """fbow::Vocabulary over the stream bytes: signature, `params` struct (with the compiler's padding), block data."""
+
+    def __init__(self, blob: bytes):
+        sig, = struct.unpack_from("<Q", blob, 0)
+        if sig != 55824124:
+            raise ValueError("Vocabulary::fromStream invalid signature")
+        # struct params { char _desc_name_[50]; uint32_t _aligment, _nblocks; uint64_t _desc_size_bytes_wp, _block_size_bytes_wp,
+        #                 _feature_off_start, _child_off_start, _total_size; int32_t _desc_type, _desc_size; uint32_t _m_k; }
+        (self.desc_name, self.aligment, self.nblocks, self.desc_size_bytes_wp, self.block_size_bytes_wp, self.feature_off_start,
+         self.child_off_start, self.total_size, self.desc_type, self.desc_size, self.m_k) = struct.unpack_from("<50s2xII4xQQQQQiiI", blob, 8)
+        # the compiler's layout on LP64: 2 bytes after the name (uint32_t alignment), 4 before the first uint64_t, 4 at the end
+        params_size = (struct.calcsize("<50s2xII4xQQQQQiiI") + 7) & ~7  # sizeof(params) = 120
+        self.data = blob[8 + params_size: 8 + params_size + self.total_size]
+        assert len(self.data) == self.total_size
+
+    # Block accessors, fbow.h:165-178
+    def block_n(self, b):
+        return struct.unpack_from("<H", self.data, b * self.block_size_bytes_wp)[0]
+
+    def block_feature(self, b, i):
+        o = b * self.block_size_bytes_wp + self.feature_off_start + i * self.desc_size_bytes_wp
+        return np.frombuffer(self.data, np.uint8, self.desc_size, o)
+
+    def block_node_info(self, b, i):
+        o = b * self.block_size_bytes_wp + self.child_off_start + i * 8
+        return struct.unpack_from("<If", self.data, o)  # id_or_childblock, weight
+
+
+def transform(voc: Vocabulary, features: np.ndarray, store_level: int):
+    """Vocabulary::transform(features, level, r1, r2) -> (r1: {word: float32 weight sum}, r2: {node: [feature indices]})."""
+    r1, r2 = {}, {}
+    nbits = int(math.ceil(math.log2(voc.m_k)))
+    for cur_feature in range(len(features)):
+        feat = features[cur_feature]
+        c_block = 0
+        level = 0
+        cur_node_id = 0
+        while True:
+            best_first, best_second = 0xFFFFFFFF, 0  # std::pair<DType, uint32_t>(numeric_limits<uint32_t>::max(), 0)
+            for cur_node in range(voc.block_n(c_block)):
+                d = descriptor_distance(voc.block_feature(c_block, cur_node), feat)  # L1_32bytes: popcount of the xor
+                if d < best_first:
+                    best_first, best_second = d, cur_node
+            if level == store_level:
+                r2.setdefault(cur_node_id, []).append(cur_feature)
+            id_or_child, weight = voc.block_node_info(c_block, best_second)
+            isleaf = bool(id_or_child & 0x80000000)
+            node_id = id_or_child & 0x7FFFFFFF
+            if isleaf:
+                r1[node_id] = F32(r1.get(node_id, F32(0))) + F32(weight)  # fBow is std::map<uint32_t, float>: float accumulation
+                if level < store_level:
+                    r2.setdefault(cur_node_id, []).append(cur_feature)
+                break
+            c_block = node_id
+            cur_node_id = ((cur_node_id << nbits) | best_second) & 0xFFFFFFFF
+            level += 1
+            if not (not isleaf and node_id != 0):  # while( !bn_info->isleaf() && bn_info->getId()!=0 )
+                break
+    return r1, r2
+
+
+def score(v1: dict, v2: dict) -> float:
+    """fBow::score: sum over the common words of vi * wi -- a FLOAT product (`const auto &vi = it->second`) added to a double --
+    walking both maps in key order."""
+    k1, k2 = sorted(v1), sorted(v2)
+    i = j = 0
+    s = 0.0
+    while i < len(k1) and j < len(k2):
+        if k1[i] == k2[j]:
+            s += float(F32(v1[k1[i]]) * F32(v2[k2[j]]))
+            i += 1
+            j += 1
+        elif k1[i] < k2[j]:
+            while i < len(k1) and k1[i] < k2[j]:
+                i += 1
+        else:
+            while j < len(k2) and k2[j] < k1[i]:
+                j += 1
+    # ||v - w||_L2 = sqrt(2 - 2 sum v_i w_i) for unit vectors (Nister 2006); the vectors of transform(features, level, ...) are
+    # NOT normalised (only the one-argument transform normalises), so with real vocabularies this saturates at 1
+    if s >= 1:
+        s = 1.0
+    else:
+        s = 1.0 - math.sqrt(1.0 - s)
+    return s
+
+
+def _lower_bound(keys, k):
+    lo = 0
+    while lo < len(keys) and keys[lo] < k:
+        lo += 1
+    return lo
+
+
+def search_by_fbow_kf_frame(kf_featvec: dict, kf_has_good_point, kf_desc, kf_angle, f_featvec: dict, f_desc, f_angle, n_f,
+                            nnratio, check_orientation):
+    """ORBmatcher::SearchByFboW(KeyFrame*, Frame&, vpMapPointMatches): returns (match[n_f] = KF keypoint index or -1, nmatches).
+    kf_has_good_point[i]: vpMapPointsKF[i] is non-null and not bad."""
+    matches = [-1] * n_f
+    nmatches = 0
+    rot_hist = [[] for _ in range(HISTO_LENGTH)]
+    factor = F32(1.0) / F32(HISTO_LENGTH)
+    kf_keys, f_keys = sorted(kf_featvec), sorted(f_featvec)
+    ki = fi = 0
+    while ki < len(kf_keys) and fi < len(f_keys):
+        if kf_keys[ki] == f_keys[fi]:
+            v_kf, v_f = kf_featvec[kf_keys[ki]], f_featvec[f_keys[fi]]
+            for real_kf in v_kf:
+                if not kf_has_good_point[real_kf]:
+                    continue
+                d_kf = kf_desc[real_kf]
+                best1, best_idx, best2 = 256, -1, 256
+                for real_f in v_f:
+                    if matches[real_f] >= 0:
+                        continue
+                    dist = descriptor_distance(d_kf, f_desc[real_f])
+                    if dist < best1:
+                        best2 = best1
+                        best1 = dist
+                        best_idx = real_f
+                    elif dist < best2:
+                        best2 = dist
+                if best1 <= TH_LOW:
+                    if F32(best1) < F32(nnratio) * F32(best2):
+                        matches[best_idx] = real_kf
+                        if check_orientation:
+                            rot = F32(kf_angle[real_kf]) - F32(f_angle[best_idx])
+                            if rot < 0.0:
+                                rot = rot + F32(360.0)
+                            b = c_round(rot * factor)
+                            if b == HISTO_LENGTH:
+                                b = 0
+                            rot_hist[b].append(best_idx)
+                        nmatches += 1
+            ki += 1
+            fi += 1
+        elif kf_keys[ki] < f_keys[fi]:
+            ki = _lower_bound(kf_keys, f_keys[fi])
+        else:
+            fi = _lower_bound(f_keys, kf_keys[ki])
+    if check_orientation:
+        ind1, ind2, ind3 = compute_three_maxima(rot_hist, HISTO_LENGTH)
+        for i in range(HISTO_LENGTH):
+            if i in (ind1, ind2, ind3):
+                continue
+            for j in rot_hist[i]:
+                matches[j] = -1
+                nmatches -= 1
+    return np.array(matches, np.int32), nmatches

@@ -1,0 +1,82 @@
+"""C oracle == literal Python transcription of fbow's transform / score and of SearchByFboW (oracle/literal_bow.py): the vocabulary
+is walked through fbow's own block offsets, fBow / fBow2 are dicts in key order, the matcher is the reference's two-pointer merge.
+CPU only, small cases."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import literal_bow as LB
+from tests.test_bow import _descs, _oracle_transform, _oracle_voc, _p
+from orbslam2_amd import bow as B
+
+
+@pytest.fixture(scope="module")
+def vocab():
+    return B.build_vocabulary(_descs(1, 3000), k=10, levels=5, seed=7)
+
+
+def _maps_of(words, ww, fv):
+    nodes, off, feat = fv
+    r1 = {int(w): np.float32(x) for w, x in zip(words, ww)}
+    r2 = {int(n): feat[off[i]:off[i + 1]].tolist() for i, n in enumerate(nodes)}
+    return r1, r2
+
+
+@pytest.mark.parametrize("level", [4, 2, 9])
+def test_transform_literal_vs_oracle(vocab, level):
+    L, v = _oracle_voc(vocab)
+    voc = LB.Vocabulary(vocab)
+    assert voc.m_k == L.orc_vocab_k(v) and voc.desc_size == 32
+    d = _descs(2, 500)
+    _, (words, ww), fv = _oracle_transform(L, v, d, level)
+    r1o, r2o = _maps_of(words, ww, fv)
+    r1, r2 = LB.transform(voc, d, level)
+    assert sorted(r1) == sorted(r1o) and sorted(r2) == sorted(r2o)
+    assert all(np.float32(r1[k]).view(np.uint32) == np.float32(r1o[k]).view(np.uint32) for k in r1)  # float accumulation order
+    assert all(r2[k] == r2o[k] for k in r2)
+    L.orc_vocab_destroy(v)
+
+
+def test_score_literal_vs_oracle(vocab):
+    L, v = _oracle_voc(vocab)
+    L.orc_bow_score.restype = C.c_double
+    L.orc_bow_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    voc = LB.Vocabulary(vocab)
+    a, _ = LB.transform(voc, _descs(3, 400), 4)
+    for seed in (4, 5, 6):
+        b, _ = LB.transform(voc, _descs(seed, 300), 4)
+        wa = np.array(sorted(a), np.uint32); va = np.array([a[k] for k in sorted(a)], np.float32)
+        wb = np.array(sorted(b), np.uint32); vb = np.array([b[k] for k in sorted(b)], np.float32)
+        ref = L.orc_bow_score(_p(wa), _p(va), len(wa), _p(wb), _p(vb), len(wb))
+        assert LB.score(a, b) == ref == 1.0  # un-normalised vectors of the four-argument transform saturate the score
+        # the same vectors scaled to unit-ish length: the 1 - sqrt(1 - s) branch
+        fa = np.float32(1.0 / np.sqrt(float((va.astype(np.float64) ** 2).sum()))); fb = np.float32(1.0 / np.sqrt(float((vb.astype(np.float64) ** 2).sum())))
+        va2, vb2 = (va * fa).astype(np.float32), (vb * fb).astype(np.float32)
+        a2 = {int(k): x for k, x in zip(wa, va2)}; b2 = {int(k): x for k, x in zip(wb, vb2)}
+        ref2 = L.orc_bow_score(_p(wa), _p(va2), len(wa), _p(wb), _p(vb2), len(wb))
+        assert LB.score(a2, b2) == ref2 and 0.0 < ref2 < 1.0
+    L.orc_vocab_destroy(v)
+
+
+@pytest.mark.parametrize("ratio,ori", [(0.7, True), (0.75, False), (0.95, True)])
+def test_search_by_fbow_literal_vs_oracle(vocab, ratio, ori):
+    L, v = _oracle_voc(vocab)
+    voc = LB.Vocabulary(vocab)
+    rng = np.random.default_rng(5)
+    kf_d = _descs(4, 600)
+    perm = rng.permutation(600)[:450]
+    f_d = np.concatenate([_descs(6, 0, base=kf_d[perm], flip=0.04), _descs(7, 200)])
+    _, _, kf_fv = _oracle_transform(L, v, kf_d)
+    _, _, f_fv = _oracle_transform(L, v, f_d)
+    kf_valid = (rng.random(len(kf_d)) < 0.8).astype(np.int32)
+    kf_ang = rng.uniform(0, 360, len(kf_d)).astype(np.float32)
+    f_ang = np.concatenate([(kf_ang[perm] + rng.normal(0, 5, 450)) % 360, rng.uniform(0, 360, 200)]).astype(np.float32)
+    ref = np.zeros(len(f_d), np.int32)
+    nref = L.orc_search_by_bow(_p(kf_fv[0]), _p(kf_fv[1]), _p(kf_fv[2]), len(kf_fv[0]), _p(kf_valid), _p(kf_d), _p(kf_ang),
+                               _p(f_fv[0]), _p(f_fv[1]), _p(f_fv[2]), len(f_fv[0]), _p(f_d), _p(f_ang), len(f_d), ratio, int(ori), _p(ref))
+    _, kf_r2 = LB.transform(voc, kf_d, 4)
+    _, f_r2 = LB.transform(voc, f_d, 4)
+    got, ngot = LB.search_by_fbow_kf_frame(kf_r2, kf_valid, kf_d, kf_ang, f_r2, f_d, f_ang, len(f_d), ratio, ori)
+    assert ngot == nref and np.array_equal(got, ref) and nref > 100
+    L.orc_vocab_destroy(v)
