@@ -176,3 +176,61 @@ def search_by_fbow_kf_frame(kf_featvec: dict, kf_has_good_point, kf_desc, kf_ang
                 matches[j] = -1
                 nmatches -= 1
     return np.array(matches, np.int32), nmatches
+
+
+def search_by_fbow_kf_kf(fv1: dict, good1, desc1, angle1, n1, fv2: dict, good2, desc2, angle2, nnratio, check_orientation):
+    """ORBmatcher::SearchByFboW(KeyFrame*, KeyFrame*, vpMatches12), src/ORBmatcher.cc:517-650: returns (match12[n1] = keypoint of
+    keyframe 2 or -1, nmatches).  good*[i]: the keypoint's map point is non-null and not bad.  (Here the threshold is `< TH_LOW`
+    and the histogram holds idx1; a matched keypoint of keyframe 2 stays matched even if the rotation filter drops the pair.)"""
+    match12 = [-1] * n1
+    matched2 = [False] * len(good2)
+    rot_hist = [[] for _ in range(HISTO_LENGTH)]
+    factor = F32(1.0) / F32(HISTO_LENGTH)
+    nmatches = 0
+    k1, k2 = sorted(fv1), sorted(fv2)
+    i = j = 0
+    while i < len(k1) and j < len(k2):
+        if k1[i] == k2[j]:
+            for idx1 in fv1[k1[i]]:
+                if not good1[idx1]:
+                    continue
+                d1 = desc1[idx1]
+                best1, best_idx2, best2 = 256, -1, 256
+                for idx2 in fv2[k2[j]]:
+                    if matched2[idx2] or not good2[idx2]:
+                        continue
+                    dist = descriptor_distance(d1, desc2[idx2])
+                    if dist < best1:
+                        best2 = best1
+                        best1 = dist
+                        best_idx2 = idx2
+                    elif dist < best2:
+                        best2 = dist
+                if best1 < TH_LOW:
+                    if F32(best1) < F32(nnratio) * F32(best2):
+                        match12[idx1] = best_idx2
+                        matched2[best_idx2] = True
+                        if check_orientation:
+                            rot = F32(angle1[idx1]) - F32(angle2[best_idx2])
+                            if rot < 0.0:
+                                rot = rot + F32(360.0)
+                            b = c_round(rot * factor)
+                            if b == HISTO_LENGTH:
+                                b = 0
+                            rot_hist[b].append(idx1)
+                        nmatches += 1
+            i += 1
+            j += 1
+        elif k1[i] < k2[j]:
+            i = _lower_bound(k1, k2[j])
+        else:
+            j = _lower_bound(k2, k1[i])
+    if check_orientation:
+        ind1, ind2, ind3 = compute_three_maxima(rot_hist, HISTO_LENGTH)
+        for b in range(HISTO_LENGTH):
+            if b in (ind1, ind2, ind3):
+                continue
+            for idx1 in rot_hist[b]:
+                match12[idx1] = -1
+                nmatches -= 1
+    return np.array(match12, np.int32), nmatches

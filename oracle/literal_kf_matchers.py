@@ -234,3 +234,76 @@ def fuse_sim3(pKF: KeyFrame, Scw, points, th):
             out[iMP] = bestIdx
             nFused += 1
     return out, nFused
+
+
+TH_HIGH = 100  # src/ORBmatcher.cc:35
+
+
+def search_by_sim3(pKF1: KeyFrame, T1w, pts1, pKF2: KeyFrame, T2w, pts2, s12, R12, t12, th):
+    """ORBmatcher::SearchBySim3, src/ORBmatcher.cc:1098-1322.  pts*: dict arrays with one entry per keypoint slot of the keyframe:
+    pos, max_distance (mfMaxDistance), min_distance, desc, valid (map point non-null, not bad, not already matched).
+    -> (match12[N1] = keypoint of keyframe 2 or -1, nFound).  Both keyframes share the camera of pKF1 (as the reference reads it)."""
+    T1w = np.asarray(T1w, np.float32); T2w = np.asarray(T2w, np.float32)
+    R12 = np.asarray(R12, np.float32).reshape(3, 3); t12 = np.asarray(t12, np.float32).reshape(3)
+    s12 = F32(s12)
+    # sR12 = s12 * R12;  sR21 = (1.0 / s12) * R12.t();  t21 = -sR21 * t12  (a scaled Mat is a multiplication by (float)alpha)
+    sR12 = (R12 * s12).astype(np.float32)
+    inv_s = F32(1.0 / float(s12))
+    sR21 = (R12.T * inv_s).astype(np.float32)
+    t21 = [-((sR21[i, 0] * t12[0] + sR21[i, 1] * t12[1]) + sR21[i, 2] * t12[2]) for i in range(3)]
+    A21 = np.concatenate([sR21, np.array(t21, np.float32).reshape(3, 1)], axis=1)
+    A12 = np.concatenate([sR12, t12.reshape(3, 1)], axis=1)
+    fx, fy, cx, cy = pKF1.fx, pKF1.fy, pKF1.cx, pKF1.cy
+
+    def one_way(Taw, A, pts, pKFb):
+        n = len(pts["valid"])
+        vnMatch = [-1] * n
+        for i in range(n):
+            if not pts["valid"][i]:
+                continue
+            p3Dw = [F32(c) for c in pts["pos"][i]]
+            p3Dca = _rx_plus_t(Taw, p3Dw)
+            p3Dcb = _rx_plus_t(A, p3Dca)
+            if p3Dcb[2] < 0.0:
+                continue
+            invz = F32(1.0 / float(p3Dcb[2]))
+            x = p3Dcb[0] * invz
+            y = p3Dcb[1] * invz
+            u = fx * x + cx
+            v = fy * y + cy
+            if not pKFb.IsInImage(u, v):
+                continue
+            maxDistance = F32(1.2) * F32(pts["max_distance"][i])
+            minDistance = F32(0.8) * F32(pts["min_distance"][i])
+            dist3D = _norm3(p3Dcb)
+            if dist3D < minDistance or dist3D > maxDistance:
+                continue
+            nPredictedLevel = _predict_scale_kf(pts["max_distance"][i], dist3D, pKFb)
+            radius = F32(th) * pKFb.mvScaleFactors[nPredictedLevel]
+            vIndices = pKFb.GetFeaturesInArea(u, v, radius)
+            if not vIndices:
+                continue
+            dMP = pts["desc"][i]
+            bestDist, bestIdx = INT_MAX, -1
+            for idx in vIndices:
+                octave = int(pKFb.mvKeysUn[idx]["octave"])
+                if octave < nPredictedLevel - 1 or octave > nPredictedLevel:
+                    continue
+                d = descriptor_distance(dMP, pKFb.mDescriptors[idx])
+                if d < bestDist:
+                    bestDist, bestIdx = d, idx
+            if bestDist <= TH_HIGH:
+                vnMatch[i] = bestIdx
+        return vnMatch
+
+    vnMatch1 = one_way(T1w, A21, pts1, pKF2)
+    vnMatch2 = one_way(T2w, A12, pts2, pKF1)
+    match12 = np.full(len(vnMatch1), -1, np.int32)
+    nFound = 0
+    for i1 in range(len(vnMatch1)):
+        idx2 = vnMatch1[i1]
+        if idx2 >= 0:
+            if vnMatch2[idx2] == i1:
+                match12[i1] = idx2
+                nFound += 1
+    return match12, nFound

@@ -80,3 +80,26 @@ def test_search_by_fbow_literal_vs_oracle(vocab, ratio, ori):
     got, ngot = LB.search_by_fbow_kf_frame(kf_r2, kf_valid, kf_d, kf_ang, f_r2, f_d, f_ang, len(f_d), ratio, ori)
     assert ngot == nref and np.array_equal(got, ref) and nref > 100
     L.orc_vocab_destroy(v)
+
+
+@pytest.mark.parametrize("ratio,ori", [(0.75, True), (0.8, False), (0.95, True)])
+def test_search_by_fbow_kf_kf_literal_vs_oracle(vocab, ratio, ori):
+    L, v = _oracle_voc(vocab)
+    voc = LB.Vocabulary(vocab)
+    rng = np.random.default_rng(9)
+    d1 = _descs(14, 600)
+    perm = rng.permutation(600)[:450]
+    d2 = np.concatenate([_descs(16, 0, base=d1[perm], flip=0.04), _descs(17, 200)])
+    _, _, fv1 = _oracle_transform(L, v, d1)
+    _, _, fv2 = _oracle_transform(L, v, d2)
+    good1 = (rng.random(len(d1)) < 0.8).astype(np.int32); good2 = (rng.random(len(d2)) < 0.85).astype(np.int32)
+    a1 = rng.uniform(0, 360, len(d1)).astype(np.float32)
+    a2 = np.concatenate([(a1[perm] + rng.normal(0, 5, 450)) % 360, rng.uniform(0, 360, 200)]).astype(np.float32)
+    ref = np.zeros(len(d1), np.int32)
+    nref = L.orc_search_by_bow_kf(_p(fv1[0]), _p(fv1[1]), _p(fv1[2]), len(fv1[0]), _p(good1), _p(d1), _p(a1), len(d1),
+                                  _p(fv2[0]), _p(fv2[1]), _p(fv2[2]), len(fv2[0]), _p(good2), _p(d2), _p(a2), len(d2), ratio, int(ori), _p(ref))
+    _, r2a = LB.transform(voc, d1, 4)
+    _, r2b = LB.transform(voc, d2, 4)
+    got, ngot = LB.search_by_fbow_kf_kf(r2a, good1, d1, a1, len(d1), r2b, good2, d2, a2, ratio, ori)
+    assert ngot == nref and np.array_equal(got, ref) and nref > 80
+    L.orc_vocab_destroy(v)
