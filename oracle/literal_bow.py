@@ -234,3 +234,95 @@ def search_by_fbow_kf_kf(fv1: dict, good1, desc1, angle1, n1, fv2: dict, good2, 
                 match12[idx1] = -1
                 nmatches -= 1
     return np.array(match12, np.int32), nmatches
+
+
+def check_dist_epipolar_line(kp1, kp2, F12, level_sigma2):
+    """ORBmatcher::CheckDistEpipolarLine, src/ORBmatcher.cc:138-155 (float arithmetic, left to right)."""
+    x1, y1 = F32(kp1["x"]), F32(kp1["y"])
+    a = (x1 * F32(F12[0, 0]) + y1 * F32(F12[1, 0])) + F32(F12[2, 0])
+    b = (x1 * F32(F12[0, 1]) + y1 * F32(F12[1, 1])) + F32(F12[2, 1])
+    c = (x1 * F32(F12[0, 2]) + y1 * F32(F12[1, 2])) + F32(F12[2, 2])
+    num = (a * F32(kp2["x"]) + b * F32(kp2["y"])) + c
+    den = a * a + b * b
+    if den == 0:
+        return False
+    dsqr = num * num / den
+    return float(dsqr) < 3.84 * float(F32(level_sigma2[int(kp2["octave"])]))
+
+
+def search_for_triangulation(fv1: dict, keys1, ur1, has_mp1, desc1, fv2: dict, keys2, ur2, has_mp2, desc2, F12, Cw1, T2w,
+                             fx2, fy2, cx2, cy2, scale_factors, level_sigma2, only_stereo, check_orientation):
+    """ORBmatcher::SearchForTriangulation, src/ORBmatcher.cc:652-819 -> (vMatches12, nmatches)."""
+    F12 = np.asarray(F12, np.float32).reshape(3, 3)
+    T2w = np.asarray(T2w, np.float32)
+    # epipole in the second image: C2 = R2w * Cw + t2w
+    C2 = [((F32(T2w[i, 0]) * F32(Cw1[0]) + F32(T2w[i, 1]) * F32(Cw1[1])) + F32(T2w[i, 2]) * F32(Cw1[2])) + F32(T2w[i, 3]) for i in range(3)]
+    invz = F32(1.0) / C2[2]
+    ex = F32(fx2) * C2[0] * invz + F32(cx2)
+    ey = F32(fy2) * C2[1] * invz + F32(cy2)
+    n1, n2 = len(keys1), len(keys2)
+    nmatches = 0
+    matched2 = [False] * n2
+    m12 = [-1] * n1
+    rot_hist = [[] for _ in range(HISTO_LENGTH)]
+    factor = F32(1.0) / F32(HISTO_LENGTH)
+    k1, k2 = sorted(fv1), sorted(fv2)
+    i = j = 0
+    while i < len(k1) and j < len(k2):
+        if k1[i] == k2[j]:
+            for idx1 in fv1[k1[i]]:
+                if has_mp1[idx1]:
+                    continue
+                stereo1 = ur1[idx1] >= 0
+                if only_stereo and not stereo1:
+                    continue
+                kp1 = keys1[idx1]
+                d1 = desc1[idx1]
+                best_dist, best_idx2 = TH_LOW, -1
+                for idx2 in fv2[k2[j]]:
+                    if matched2[idx2] or has_mp2[idx2]:
+                        continue
+                    stereo2 = ur2[idx2] >= 0
+                    if only_stereo and not stereo2:
+                        continue
+                    dist = descriptor_distance(d1, desc2[idx2])
+                    if dist > TH_LOW or dist > best_dist:
+                        continue
+                    kp2 = keys2[idx2]
+                    if not stereo1 and not stereo2:
+                        distex = ex - F32(kp2["x"])
+                        distey = ey - F32(kp2["y"])
+                        if distex * distex + distey * distey < F32(100) * F32(scale_factors[int(kp2["octave"])]):
+                            continue
+                    if check_dist_epipolar_line(kp1, kp2, F12, level_sigma2):
+                        best_idx2 = idx2
+                        best_dist = dist
+                if best_idx2 >= 0:
+                    kp2 = keys2[best_idx2]
+                    m12[idx1] = best_idx2
+                    matched2[best_idx2] = True
+                    nmatches += 1
+                    if check_orientation:
+                        rot = F32(kp1["angle"]) - F32(kp2["angle"])
+                        if rot < 0.0:
+                            rot = rot + F32(360.0)
+                        b = c_round(rot * factor)
+                        if b == HISTO_LENGTH:
+                            b = 0
+                        rot_hist[b].append(idx1)
+            i += 1
+            j += 1
+        elif k1[i] < k2[j]:
+            i = _lower_bound(k1, k2[j])
+        else:
+            j = _lower_bound(k2, k1[i])
+    if check_orientation:
+        ind1, ind2, ind3 = compute_three_maxima(rot_hist, HISTO_LENGTH)
+        for b in range(HISTO_LENGTH):
+            if b in (ind1, ind2, ind3):
+                continue
+            for idx1 in rot_hist[b]:
+                matched2[m12[idx1]] = False
+                m12[idx1] = -1
+                nmatches -= 1
+    return np.array(m12, np.int32), nmatches

@@ -103,3 +103,56 @@ def test_search_by_fbow_kf_kf_literal_vs_oracle(vocab, ratio, ori):
     got, ngot = LB.search_by_fbow_kf_kf(r2a, good1, d1, a1, len(d1), r2b, good2, d2, a2, ratio, ori)
     assert ngot == nref and np.array_equal(got, ref) and nref > 80
     L.orc_vocab_destroy(v)
+
+
+@pytest.mark.parametrize("only_stereo,ori", [(False, True), (True, True), (False, False)])
+def test_search_for_triangulation_literal_vs_oracle(vocab, only_stereo, ori):
+    from oracle import oracle as O
+    L, v = _oracle_voc(vocab)
+    L.orc_search_for_triangulation.restype = C.c_int
+    L.orc_search_for_triangulation.argtypes = ([C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int]) * 2 + [C.c_void_p] * 3 + \
+        [C.c_float] * 4 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    voc = LB.Vocabulary(vocab)
+    fx = fy = 500.0; cx, cy = 320.0, 240.0
+    ex = O.Extractor()
+    sf = np.ascontiguousarray(ex.scale_factors(), np.float32); s2 = np.ascontiguousarray(ex.sigma2(), np.float32)
+    rng = np.random.default_rng(21)
+    n = 500
+    P = np.stack([rng.uniform(-6, 6, n), rng.uniform(-4, 4, n), rng.uniform(4, 30, n)], axis=1)
+    T1 = np.concatenate([np.eye(3), np.zeros((3, 1))], axis=1)
+    a = np.deg2rad(3.0)
+    R2 = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    T2 = np.concatenate([R2, np.array([[-0.4], [0.02], [0.05]])], axis=1)
+
+    def view(T, seed, desc_base):
+        r = np.random.default_rng(seed)
+        pc = (T[:, :3] @ P.T).T + T[:, 3]
+        k = np.zeros(n, O.KP_DTYPE)
+        k["x"] = fx * pc[:, 0] / pc[:, 2] + cx + r.normal(0, 0.4, n); k["y"] = fy * pc[:, 1] / pc[:, 2] + cy + r.normal(0, 0.4, n)
+        k["octave"] = r.integers(0, 8, n); k["angle"] = (desc_base[1] + r.normal(0, 4, n)) % 360; k["size"] = 31; k["class_id"] = -1
+        d = desc_base[0] ^ np.packbits(r.random((n, 256)) < 0.03, axis=1, bitorder="little")
+        ur = np.where(r.random(n) < 0.5, k["x"] - 40.0 / pc[:, 2], -1.0).astype(np.float32)
+        has_mp = (r.random(n) < 0.3).astype(np.uint8)
+        return k, d, ur, has_mp
+
+    base = (_descs(9, n), rng.uniform(0, 360, n))
+    k1, d1, ur1, mp1 = view(T1, 1, base)
+    k2, d2, ur2, mp2 = view(T2, 2, base)
+    _, _, fv1 = _oracle_transform(L, v, d1)
+    _, _, fv2 = _oracle_transform(L, v, d2)
+    R12 = T1[:, :3] @ T2[:, :3].T
+    t12 = -R12 @ T2[:, 3] + T1[:, 3]
+    tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    F12 = (np.linalg.inv(K).T @ tx @ R12 @ np.linalg.inv(K)).astype(np.float32)
+    Cw1 = (-T1[:, :3].T @ T1[:, 3]).astype(np.float32)
+    T2f = T2.astype(np.float32)
+    ref = np.zeros(n, np.int32)
+    nref = L.orc_search_for_triangulation(_p(fv1[0]), _p(fv1[1]), _p(fv1[2]), len(fv1[0]), _p(k1), _p(ur1), _p(mp1), _p(d1), n,
+                                          _p(fv2[0]), _p(fv2[1]), _p(fv2[2]), len(fv2[0]), _p(k2), _p(ur2), _p(mp2), _p(d2), n,
+                                          _p(F12), _p(Cw1), _p(T2f), fx, fy, cx, cy, _p(sf), _p(s2), int(only_stereo), int(ori), _p(ref))
+    _, r2a = LB.transform(voc, d1, 4)
+    _, r2b = LB.transform(voc, d2, 4)
+    got, ngot = LB.search_for_triangulation(r2a, k1, ur1, mp1, d1, r2b, k2, ur2, mp2, d2, F12, Cw1, T2f, fx, fy, cx, cy, sf, s2, only_stereo, ori)
+    assert ngot == nref and np.array_equal(got, ref) and nref > (20 if only_stereo else 60)
+    L.orc_vocab_destroy(v)
