@@ -326,3 +326,136 @@ def search_for_triangulation(fv1: dict, keys1, ur1, has_mp1, desc1, fv2: dict, k
                 m12[idx1] = -1
                 nmatches -= 1
     return np.array(m12, np.int32), nmatches
+
+
+class LKeyFrame:
+    """The members of KeyFrame that KeyFrameDatabase touches."""
+
+    def __init__(self, mnId, bow: dict):
+        self.mnId = mnId
+        self.mFbowVec = bow                    # {word: float32 weight}
+        self.mnRelocQuery = -1; self.mnRelocWords = 0; self.mRelocScore = F32(0)
+        self.mnLoopQuery = -1; self.mnLoopWords = 0; self.mLoopScore = F32(0)
+        self.best_covisibles = []              # GetBestCovisibilityKeyFrames(10), in its order
+        self.connected = set()                 # GetConnectedKeyFrames()
+
+
+class KeyFrameDatabase:
+    """src/KeyFrameDatabase.cc:38-307 transcribed: mvInvertedFile as a dict of lists (push_back order), list / set / pair logic as
+    written.  Query ids must be fresh per call (mnId of the frame / keyframe), as in the reference."""
+
+    def __init__(self):
+        self.mvInvertedFile = {}
+
+    def add(self, pKF):
+        for w in sorted(pKF.mFbowVec):
+            self.mvInvertedFile.setdefault(w, []).append(pKF)
+
+    def erase(self, pKF):
+        for w in sorted(pKF.mFbowVec):
+            lKFs = self.mvInvertedFile.get(w, [])
+            for k, other in enumerate(lKFs):
+                if other is pKF:
+                    del lKFs[k]
+                    break
+
+    def DetectRelocalizationCandidates(self, F_id, F_bow):
+        lKFsSharingWords = []
+        for w in sorted(F_bow):
+            for pKFi in self.mvInvertedFile.get(w, []):
+                if pKFi.mnRelocQuery != F_id:
+                    pKFi.mnRelocWords = 0
+                    pKFi.mnRelocQuery = F_id
+                    lKFsSharingWords.append(pKFi)
+                pKFi.mnRelocWords += 1
+        if not lKFsSharingWords:
+            return []
+        maxCommonWords = 0
+        for kf in lKFsSharingWords:
+            if kf.mnRelocWords > maxCommonWords:
+                maxCommonWords = kf.mnRelocWords
+        minCommonWords = int(F32(maxCommonWords) * F32(0.8))
+        lScoreAndMatch = []
+        for pKFi in lKFsSharingWords:
+            if pKFi.mnRelocWords > minCommonWords:
+                si = F32(score(F_bow, pKFi.mFbowVec))
+                pKFi.mRelocScore = si
+                lScoreAndMatch.append((si, pKFi))
+        if not lScoreAndMatch:
+            return []
+        lAccScoreAndMatch = []
+        bestAccScore = F32(0)
+        for first, pKFi in lScoreAndMatch:
+            bestScore = first
+            accScore = bestScore
+            pBestKF = pKFi
+            for pKF2 in pKFi.best_covisibles:
+                if pKF2.mnRelocQuery != F_id:
+                    continue
+                accScore = accScore + pKF2.mRelocScore
+                if pKF2.mRelocScore > bestScore:
+                    pBestKF = pKF2
+                    bestScore = pKF2.mRelocScore
+            lAccScoreAndMatch.append((accScore, pBestKF))
+            if accScore > bestAccScore:
+                bestAccScore = accScore
+        minScoreToRetain = F32(0.75) * bestAccScore
+        added, out = set(), []
+        for si, pKFi in lAccScoreAndMatch:
+            if si > minScoreToRetain:
+                if id(pKFi) not in added:
+                    out.append(pKFi)
+                    added.add(id(pKFi))
+        return out
+
+    def DetectLoopCandidates(self, pKF, minScore):
+        minScore = F32(minScore)
+        spConnectedKeyFrames = pKF.connected
+        lKFsSharingWords = []
+        for w in sorted(pKF.mFbowVec):
+            for pKFi in self.mvInvertedFile.get(w, []):
+                if pKFi.mnLoopQuery != pKF.mnId:
+                    pKFi.mnLoopWords = 0
+                    if pKFi not in spConnectedKeyFrames:
+                        pKFi.mnLoopQuery = pKF.mnId
+                        lKFsSharingWords.append(pKFi)
+                pKFi.mnLoopWords += 1
+        if not lKFsSharingWords:
+            return []
+        lScoreAndMatch = []
+        maxCommonWords = 0
+        for kf in lKFsSharingWords:
+            if kf.mnLoopWords > maxCommonWords:
+                maxCommonWords = kf.mnLoopWords
+        minCommonWords = int(F32(maxCommonWords) * F32(0.8))
+        for pKFi in lKFsSharingWords:
+            if pKFi.mnLoopWords > minCommonWords:
+                si = F32(score(pKF.mFbowVec, pKFi.mFbowVec))
+                pKFi.mLoopScore = si
+                if si >= minScore:
+                    lScoreAndMatch.append((si, pKFi))
+        if not lScoreAndMatch:
+            return []
+        lAccScoreAndMatch = []
+        bestAccScore = minScore
+        for first, pKFi in lScoreAndMatch:
+            bestScore = first
+            accScore = first
+            pBestKF = pKFi
+            for pKF2 in pKFi.best_covisibles:
+                if pKF2.mnLoopQuery == pKF.mnId and pKF2.mnLoopWords > minCommonWords:
+                    accScore = accScore + pKF2.mLoopScore
+                    if pKF2.mLoopScore > bestScore:
+                        pBestKF = pKF2
+                        bestScore = pKF2.mLoopScore
+            lAccScoreAndMatch.append((accScore, pBestKF))
+            if accScore > bestAccScore:
+                bestAccScore = accScore
+        minScoreToRetain = F32(0.75) * bestAccScore
+        added, out = set(), []
+        for first, pKFi in lAccScoreAndMatch:
+            if first > minScoreToRetain:
+                if id(pKFi) not in added:
+                    out.append(pKFi)
+                    added.add(id(pKFi))
+        return out

@@ -156,3 +156,82 @@ def test_search_for_triangulation_literal_vs_oracle(vocab, only_stereo, ori):
     got, ngot = LB.search_for_triangulation(r2a, k1, ur1, mp1, d1, r2b, k2, ur2, mp2, d2, F12, Cw1, T2f, fx, fy, cx, cy, sf, s2, only_stereo, ori)
     assert ngot == nref and np.array_equal(got, ref) and nref > (20 if only_stereo else 60)
     L.orc_vocab_destroy(v)
+
+
+def _random_db(seed, n_kf=60, n_words=400):
+    """Keyframes with sparse unit-length BoW vectors over a small word set (so scores spread over (0, 1)), covisibility lists."""
+    rng = np.random.default_rng(seed)
+    protos = []
+    for _ in range(8):  # places: keyframes of one place share most of their words
+        nw = int(rng.integers(30, 60))
+        protos.append((np.sort(rng.choice(n_words, nw, replace=False)), rng.random(nw) + 0.05))
+    kfs = []
+    for k in range(n_kf):
+        pw, pv = protos[int(rng.integers(0, len(protos)))]
+        keep = rng.random(len(pw)) < 0.8
+        extra = np.setdiff1d(rng.choice(n_words, 8, replace=False), pw[keep])
+        words = np.concatenate([pw[keep], extra]); w = np.concatenate([pv[keep] * rng.uniform(0.7, 1.3, int(keep.sum())), rng.random(len(extra)) * 0.3 + 0.02])
+        order = np.argsort(words)
+        words = words[order].astype(np.uint32); w = w[order].astype(np.float32)
+        w = (w / np.float32(np.sqrt(float((w.astype(np.float64) ** 2).sum())))).astype(np.float32)
+        kfs.append((words, w))
+    covis = [rng.choice(n_kf, int(rng.integers(0, 11)), replace=False).astype(np.int32) for _ in range(n_kf)]
+    covis = [c[c != k] for k, c in enumerate(covis)]
+    return rng, kfs, covis
+
+
+def _csr(kfs, covis):
+    kf_off = np.zeros(len(kfs) + 1, np.int32); kf_off[1:] = np.cumsum([len(a) for a, _ in kfs])
+    dbw = np.concatenate([a for a, _ in kfs]).astype(np.uint32); dbv = np.concatenate([b for _, b in kfs]).astype(np.float32)
+    c_off = np.zeros(len(kfs) + 1, np.int32); c_off[1:] = np.cumsum([len(c) for c in covis])
+    c_idx = np.concatenate(covis + [np.zeros(0, np.int32)]).astype(np.int32)
+    if len(c_idx) == 0:
+        c_idx = np.zeros(1, np.int32)
+    return kf_off, dbw, dbv, c_off, c_idx
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_keyframe_database_literal_vs_oracle(seed):
+    from oracle import oracle as O
+    L = O.lib()
+    L.orc_detect_reloc_candidates.restype = C.c_int
+    L.orc_detect_reloc_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int]
+    L.orc_detect_loop_candidates.restype = C.c_int
+    L.orc_detect_loop_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 3 + [C.c_int]
+    rng, kfs, covis = _random_db(seed)
+    n = len(kfs)
+    kf_off, dbw, dbv, c_off, c_idx = _csr(kfs, covis)
+    db = LB.KeyFrameDatabase()
+    lk = [LB.LKeyFrame(k, {int(w): np.float32(x) for w, x in zip(*kfs[k])}) for k in range(n)]
+    for k in range(n):
+        lk[k].best_covisibles = [lk[int(j)] for j in covis[k]]
+        db.add(lk[k])
+    state = np.zeros(n, np.float32)  # mRelocScore of every keyframe: persists across queries in both statements
+    nonempty = 0
+    for q in range(6):  # relocalisation queries (frames): noisy copies of a keyframe's vector
+        src = int(rng.integers(0, n))
+        words, w = kfs[src]
+        keep = rng.random(len(words)) < 0.8
+        qw = words[keep]; qv = (w[keep] * np.float32(rng.uniform(0.8, 1.1))).astype(np.float32)
+        cand = np.zeros(n, np.int32)
+        m = L.orc_detect_reloc_candidates(_p(qw), _p(qv), len(qw), n, _p(kf_off), _p(dbw), _p(dbv), _p(c_off), _p(c_idx), _p(state), _p(cand), n)
+        got = db.DetectRelocalizationCandidates(1000 + q, {int(a): np.float32(b) for a, b in zip(qw, qv)})
+        assert [kf.mnId for kf in got] == cand[:m].tolist()
+        assert all(lk[k].mRelocScore == state[k] for k in range(n))
+        nonempty += m > 0
+    assert nonempty >= 4
+    nonempty = 0
+    for q in range(6):  # loop queries (keyframes of the database, with their connected sets)
+        src = int(rng.integers(0, n))
+        connected = (rng.random(n) < 0.15).astype(np.uint8); connected[src] = 1
+        lk[src].connected = {lk[k] for k in range(n) if connected[k]}
+        qw, qv = kfs[src]
+        min_score = float(rng.uniform(0.0, 0.15))
+        cand = np.zeros(n, np.int32)
+        m = L.orc_detect_loop_candidates(_p(qw), _p(qv), len(qw), n, _p(kf_off), _p(dbw), _p(dbv), _p(connected), min_score, _p(c_off), _p(c_idx), _p(cand), n)
+        lk[src].mnId = 5000 + q + seed * 10  # a fresh query id (mnLoopQuery compares ids)
+        got = db.DetectLoopCandidates(lk[src], min_score)
+        got_idx = [lk.index(kf) for kf in got]
+        assert got_idx == cand[:m].tolist()
+        nonempty += m > 0
+    assert nonempty >= 3
