@@ -534,3 +534,20 @@ def compute_stereo_matches(exL: LiteralExtractor, exR: LiteralExtractor, mvKeys,
         mvuRight[vDistIdx[i][1]] = -1
         mvDepth[vDistIdx[i][1]] = -1
     return mvuRight, mvDepth
+
+
+def compute_stereo_from_rgbd(mvKeys, mvKeysUn_x, imDepth: np.ndarray, mbf):
+    """Frame::ComputeStereoFromRGBD, src/Frame.cc:645-666 -> (mvuRight, mvDepth).  mvKeys: KeyPoint list (raw), mvKeysUn_x: the
+    undistorted x of each keypoint; imDepth: CV_32F.  `imDepth.at<float>(v, u)` truncates the float coordinates."""
+    N = len(mvKeys)
+    mvuRight = np.full(N, -1.0, np.float32)
+    mvDepth = np.full(N, -1.0, np.float32)
+    mbf = F32(mbf)
+    for i in range(N):
+        kp = mvKeys[i]
+        v, u = kp.y, kp.x
+        d = F32(imDepth[_trunc(v), _trunc(u)])
+        if d > 0:
+            mvDepth[i] = d
+            mvuRight[i] = F32(mvKeysUn_x[i]) - mbf / d
+    return mvuRight, mvDepth

@@ -94,3 +94,15 @@ def test_quadtree_literal_vs_oracle_on_adversarial_points():
         got = [(float(k.x), float(k.y), float(k.response)) for k in res]
         want = [(float(xs[i]), float(ys[i]), float(sc[i])) for i in sel]
         assert got == want, (trial, len(got), len(want))
+
+
+def test_stereo_from_rgbd_literal_vs_oracle():
+    left, _, depth = synth.stereo_pair(400, 240, seed=21, bf=60.0, with_depth=True)
+    lit = LX.LiteralExtractor(400)
+    keys, _ = lit(left)
+    orc = O.Extractor(400)
+    k, _ = orc.extract(left)
+    ur, dp = LX.compute_stereo_from_rgbd(keys, [kp.x for kp in keys], depth, 60.0)
+    ur2, dp2 = O.stereo_from_rgbd(k, k, depth, 60.0)
+    assert (dp > 0).sum() > 100 and (dp < 0).sum() > 0  # the synthetic depth map has holes
+    assert np.array_equal(ur.view(np.uint32), ur2.view(np.uint32)) and np.array_equal(dp.view(np.uint32), dp2.view(np.uint32))
