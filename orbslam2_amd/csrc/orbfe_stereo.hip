@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, Dev
 
 // Median of the accepted SADs, then cut at 1.5*1.4*median (src/Frame.cc:628-641; Q2: skip when empty).
 // The reference sorts (SAD, iL) pairs and reads element size/2; only its SAD matters, so the median is
-// found by a 3-level radix select (8 bits per level, LDS histograms) instead of a sort.
+// found by a 2-level radix select (8 bits per level, LDS histograms; a SAD fits 16 bits) instead of a sort.
 __global__ __launch_bounds__(256) void stereo_median_kernel(DeviceConfig cfg, DeviceBuffers buf)
 {
     extern __shared__ int s_vals[]; // [sel_total] the pair's SADs, read from HBM once
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void stereo_median_kernel(DeviceConfig cfg, De
     const int *sad = buf.sad + (size_t)imgL * cfg.sel_total;
     for (int i = tid; i < nL; i += 256) s_vals[i] = sad[i];
     unsigned prefix = 0, mask = 0;
-    for (int shift = 16; shift >= 0; shift -= 8) { // SAD < 2^24 (121 px * 510)
+    for (int shift = 8; shift >= 0; shift -= 8) { // SAD <= 121 px * 510 = 61 710 < 2^16: two 8-bit digits
         s_hist[tid] = 0;
         __syncthreads();
         for (int i = tid; i < nL; i += 256) {
@@ -256,9 +256,9 @@ __global__ __launch_bounds__(256) void stereo_median_kernel(DeviceConfig cfg, De
                 if (lane >= o) inc += t;
             }
             const int total = __shfl(inc, 63, 64);
-            if (shift == 16 && lane == 0) s_sel[2] = total;
+            if (shift == 8 && lane == 0) s_sel[2] = total;
             // vDistIdx[size/2] in ascending order; later digits continue with the rank left inside the chosen bucket
-            const int rank = shift == 16 ? total / 2 : s_sel[1];
+            const int rank = shift == 8 ? total / 2 : s_sel[1];
             const int before = inc - sum;
             if (total > 0 && rank >= before && rank < inc) {
                 int r = rank - before, d = 4 * lane;
