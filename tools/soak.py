@@ -13,11 +13,11 @@ from oracle import oracle as O  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 bad = 0
 for i in range(n):
-    rng = np.random.default_rng(7000 + i)
+    rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "7000")) + i)
     w, h = int(rng.integers(120, 700)), int(rng.integers(100, 420))
     nf = int(rng.integers(50, 2500))
     ini = int(rng.integers(8, 45)); mn = int(rng.integers(3, ini + 1))
-    left, right = synth.stereo_pair(w, h, seed=9000 + i)
+    left, right = synth.stereo_pair(w, h, seed=int(os.environ.get("SOAK_SEED", "7000")) + 2000 + i)
     if i % 3 == 1:  # low contrast: many cells fall back to minTh
         f = float(rng.uniform(0.05, 0.4))
         left = np.clip((left.astype(np.float32) - 128) * f + 128, 0, 255).astype(np.uint8)
