@@ -218,3 +218,45 @@ def build_vocabulary(desc: np.ndarray, k: int = 10, levels: int = 3, seed: int =
     params = struct.pack("<50s2xII4x5QiiI4x", b"orb", 8, len(blocks), desc_wp, block_size, feat_off, child_off, len(data), 0, 32, k)
     assert len(params) == 120
     return struct.pack("<Q", 55824124) + params + bytes(data)
+
+
+def build_full_vocabulary(k: int = 10, levels: int = 6, seed: int = 11) -> bytes:
+    """A COMPLETE k-ary tree of `levels` levels in the fbow file format -- (k^levels - 1) / (k - 1) blocks, k^levels words: 45 MB
+    for k = 10, levels = 6, the size of the ORB vocabulary ORB-SLAM2 ships (which is not in the reference checkout).  No
+    clustering: a child's descriptor is its parent's with a level-dependent share of random bit flips, so descents behave like
+    those of a trained tree (siblings are distinct, descendants stay near their ancestors).  Block b's children are blocks
+    k * b + 1 .. k * b + k (breadth-first numbering); leaf weights are drawn from [1, 10).  Vectorised: a few seconds."""
+    rng = np.random.default_rng(seed)
+    n_blocks = (k ** levels - 1) // (k - 1)
+    n_internal = (k ** (levels - 1) - 1) // (k - 1)   # blocks whose nodes have children
+    desc_wp, feat_off = 32, 8
+    child_off = feat_off + k * desc_wp
+    block_size = feat_off + k * (desc_wp + 8)
+    data = np.zeros((n_blocks, block_size), np.uint8)
+    feats = np.zeros((n_blocks, k, 32), np.uint8)
+    flip_p = [0.5, 0.22, 0.14, 0.09, 0.06, 0.04, 0.03, 0.02]
+    parent_feat = np.zeros((1, 32), np.uint8)          # the root block's "parent"
+    first = 0
+    for d in range(levels):
+        nb = k ** d
+        base = np.repeat(parent_feat, k, axis=0).reshape(nb, k, 32)
+        flips = np.packbits(rng.random((nb, k, 256)) < flip_p[min(d, len(flip_p) - 1)], axis=2, bitorder="little")
+        feats[first:first + nb] = base ^ flips
+        parent_feat = feats[first:first + nb].reshape(nb * k, 32)
+        first += nb
+    hdr = np.zeros((n_blocks, 2), np.uint32)
+    leaf_block = np.arange(n_blocks) >= n_internal
+    hdr[:, 0] = k | (leaf_block.astype(np.uint32) << 16)                    # u16 N, u16 isLeaf
+    hdr[1:, 1] = ((np.arange(1, n_blocks) - 1) // k).astype(np.uint32)      # parent block
+    data[:, 0:8] = hdr.view(np.uint8).reshape(n_blocks, 8)
+    data[:, feat_off:feat_off + k * desc_wp] = feats.reshape(n_blocks, k * 32)
+    info = np.zeros((n_blocks, k, 2), np.uint32)
+    child = (np.arange(n_blocks)[:, None] * k + 1 + np.arange(k)[None, :]).astype(np.uint32)
+    info[:n_internal, :, 0] = child[:n_internal]
+    word = (np.arange(n_blocks - n_internal)[:, None] * k + np.arange(k)[None, :]).astype(np.uint32)
+    info[n_internal:, :, 0] = word | np.uint32(0x80000000)
+    info[n_internal:, :, 1] = rng.uniform(1.0, 10.0, (n_blocks - n_internal, k)).astype(np.float32).view(np.uint32)
+    data[:, child_off:child_off + 8 * k] = info.view(np.uint8).reshape(n_blocks, 8 * k)
+    blob = data.tobytes()
+    params = struct.pack("<50s2xII4x5QiiI4x", b"orb", 8, n_blocks, desc_wp, block_size, feat_off, child_off, len(blob), 0, 32, k)
+    return struct.pack("<Q", 55824124) + params + blob

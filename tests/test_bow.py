@@ -141,6 +141,42 @@ def test_gpu_bow_transform_and_search(vocab):
 
 
 @pytest.mark.gpu
+def test_gpu_full_size_vocabulary():
+    """The size ORB-SLAM2 ships: k = 10, six levels, 10^6 words, 45 MB (orbslam2_amd.bow.build_full_vocabulary; the real file is not in
+    the reference checkout).  transform at the reference's level 4 and SearchByFboW on it == oracle."""
+    from orbslam2_amd import api
+    blob = B.build_full_vocabulary()
+    assert 44e6 < len(blob) < 47e6
+    ctx = api.Context(width=640, height=480)
+    B.vocab_load(ctx, blob)
+    L, v = _oracle_voc(blob)
+    assert L.orc_vocab_k(v) == 10
+    rng = np.random.default_rng(3)
+    # descriptors near random leaves of the tree (so that the descents go deep along real branches), plus pure noise
+    data = np.frombuffer(blob, np.uint8, offset=8 + 120).reshape(-1, 408)
+    leaves = data[rng.integers(11111, 111111, 1300), 8:8 + 320].reshape(1300, 10, 32)[np.arange(1300), rng.integers(0, 10, 1300)]
+    kf_d = np.concatenate([leaves ^ np.packbits(rng.random((1300, 256)) < 0.02, axis=1, bitorder="little"),
+                           rng.integers(0, 256, (200, 32)).astype(np.uint8)])
+    f_d = np.concatenate([kf_d[:1100] ^ np.packbits(rng.random((1100, 256)) < 0.03, axis=1, bitorder="little"),
+                          rng.integers(0, 256, (400, 32)).astype(np.uint8)])
+    (w, wt, nd), (words, ww), kf_fv = _oracle_transform(L, v, kf_d, 4)
+    gw, gwt, gnd = B.transform(ctx, kf_d, 4)
+    assert np.array_equal(gw, w) and np.array_equal(gwt, wt) and np.array_equal(gnd, nd)
+    assert len(np.unique(w)) > 1200 and w.max() < 10 ** 6 and (nd < 16 ** 4).all()
+    _, _, f_fv = _oracle_transform(L, v, f_d, 4)
+    kf_valid = (rng.random(len(kf_d)) < 0.85).astype(np.int32)
+    kf_ang = rng.uniform(0, 360, len(kf_d)).astype(np.float32)
+    f_ang = np.concatenate([(kf_ang[:1100] + rng.normal(0, 5, 1100)) % 360, rng.uniform(0, 360, 400)]).astype(np.float32)
+    ref = np.zeros(len(f_d), np.int32)
+    nref = L.orc_search_by_bow(_p(kf_fv[0]), _p(kf_fv[1]), _p(kf_fv[2]), len(kf_fv[0]), _p(kf_valid), _p(kf_d), _p(kf_ang),
+                               _p(f_fv[0]), _p(f_fv[1]), _p(f_fv[2]), len(f_fv[0]), _p(f_d), _p(f_ang), len(f_d), 0.75, 1, _p(ref))
+    got, ngot = B.search_by_bow(ctx, kf_fv, kf_valid, kf_d, kf_ang, f_fv, f_d, f_ang, 0.75, True)
+    assert ngot == nref and np.array_equal(got, ref) and nref > 300
+    L.orc_vocab_destroy(v)
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_gpu_keyframe_database_relocalisation(vocab):
     """BASELINE config 3's database side: 500 keyframes' BoW vectors in HBM, fBow::score + DetectRelocalizationCandidates
     (src/KeyFrameDatabase.cc:196-307) == oracle; also erase() and the persistent mRelocScore state (contract Q10)."""

@@ -124,6 +124,16 @@ def main():
         lambda: B.search_by_bow(ctx, kf_fv, kf_valid, kf_d, kf_ang, f_fv, f_d, f_ang, 0.75, True),
         lambda: L.orc_search_by_bow(P(kf_fv[0]), P(kf_fv[1]), P(kf_fv[2]), len(kf_fv[0]), P(kf_valid), P(kf_d), P(kf_ang),
                                     P(f_fv[0]), P(f_fv[1]), P(f_fv[2]), len(f_fv[0]), P(f_d), P(f_ang), len(f_d), 0.75, 1, P(ref)))
+    # the same transform against a vocabulary of the size ORB-SLAM2 ships (k = 10, six levels, 10^6 words, 45 MB; synthetic complete tree)
+    ctx3 = api.Context(width=TM.W, height=TM.H)
+    big = B.build_full_vocabulary()
+    B.vocab_load(ctx3, big)
+    L3, v3 = TB._oracle_voc(big)
+    data = np.frombuffer(big, np.uint8, offset=8 + 120).reshape(-1, 408)
+    leaves = data[rng.integers(11111, 111111, 1500), 8:8 + 320].reshape(1500, 10, 32)[np.arange(1500), rng.integers(0, 10, 1500)]
+    big_d = leaves ^ np.packbits(rng.random((1500, 256)) < 0.02, axis=1, bitorder="little")
+    row("fbow transform, 1500 descriptors, full-size vocabulary (10^6 words, 45 MB) [row 17]",
+        lambda: B.transform(ctx3, big_d, 4), lambda: TB._oracle_transform(L3, v3, big_d, 4))
     print(json.dumps(out, indent=1))
     ctx.close()
 
