@@ -41,68 +41,78 @@ ex = O.Extractor(nfeatures=NF)
 out["config 0 Mono-TUM1 640x480/1000: extract"] = {"gpu_ms": med(lambda: ctx.extract(img), 50), "cpu_ms": med(lambda: ex.extract(img), 10, 1)}
 ctx.close()
 
-# ---- config 2
+# ---- config 2 (twice: a small vocabulary trained on these images' descriptors, and a complete k = 10 / six-level tree of the size
+# ORB-SLAM2 ships: 10^6 words, 45 MB)
 W, H, NF, NKF = 752, 480, 1200, 500
 ctx = api.Context(width=W, height=H, nfeatures=NF, fx=458.654, fy=457.296, cx=367.215, cy=248.375, bf=47.9, max_images=1)
 ex = O.Extractor(nfeatures=NF)
 imgs = [synth.mono_image(W, H, seed=900 + i) for i in range(NKF)]
 kf_kd = [ctx.extract(im) for im in imgs]
-blob = B.build_vocabulary(np.concatenate([d for _, d in kf_kd[:8]]), k=10, levels=4, seed=3)
-B.vocab_load(ctx, blob)
-L, v = TB._oracle_voc(blob)
-L.orc_detect_reloc_candidates.restype = C.c_int
-L.orc_detect_reloc_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int]
-db = B.KeyFrameDB(ctx)
-kf_bow, kf_fv = [], []
-for _, d in kf_kd:
-    w, wt, nd = B.transform(ctx, d, 4)
-    words, ww, nodes, off, feat = B.maps(w, wt, nd)
-    db.add(words, ww)
-    kf_bow.append((words, ww)); kf_fv.append((nodes, off, feat))
-rng = np.random.default_rng(1)
-q_img = np.clip(imgs[5].astype(np.int16) + rng.normal(0, 2.0, imgs[5].shape).round().astype(np.int16), 0, 255).astype(np.uint8)
-covis_off = np.arange(NKF + 1, dtype=np.int32) * 2
-covis_idx = np.stack([(np.arange(NKF) + 1) % NKF, (np.arange(NKF) - 1) % NKF], axis=1).astype(np.int32).ravel()
-kf_off = np.zeros(NKF + 1, np.int32); kf_off[1:] = np.cumsum([len(a) for a, _ in kf_bow])
-dbw = np.concatenate([a for a, _ in kf_bow]); dbv = np.concatenate([b for _, b in kf_bow])
-res = {}
+L = O.lib()
 
 
-def gpu_chain():
-    qk, qd = ctx.extract(q_img)
-    gw, gwt, gnd = B.transform(ctx, qd, 4)
-    q_words, q_ww, qn, qo, qf = B.maps(gw, gwt, gnd)
-    st = np.zeros(NKF, np.float32)
-    cand = db.detect_reloc_candidates(q_words, q_ww, covis_off, covis_idx, st)
-    kfi = int(cand[0])
-    kfk, kfd = kf_kd[kfi]
-    m, nm = B.search_by_bow(ctx, kf_fv[kfi], np.ones(len(kfd), np.int32), kfd, kfk["angle"].copy(), (qn, qo, qf), qd, qk["angle"].copy(), 0.75, True)
-    res["gpu"] = (cand.tolist(), nm)
+def config2(blob, label):
+    B.vocab_load(ctx, blob)
+    L, v = TB._oracle_voc(blob)
+    L.orc_detect_reloc_candidates.restype = C.c_int
+    L.orc_detect_reloc_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int]
+    db = B.KeyFrameDB(ctx)
+    kf_bow, kf_fv = [], []
+    for _, d in kf_kd:
+        w, wt, nd = B.transform(ctx, d, 4)
+        words, ww, nodes, off, feat = B.maps(w, wt, nd)
+        db.add(words, ww)
+        kf_bow.append((words, ww)); kf_fv.append((nodes, off, feat))
+    rng = np.random.default_rng(1)
+    q_img = np.clip(imgs[5].astype(np.int16) + rng.normal(0, 2.0, imgs[5].shape).round().astype(np.int16), 0, 255).astype(np.uint8)
+    covis_off = np.arange(NKF + 1, dtype=np.int32) * 2
+    covis_idx = np.stack([(np.arange(NKF) + 1) % NKF, (np.arange(NKF) - 1) % NKF], axis=1).astype(np.int32).ravel()
+    kf_off = np.zeros(NKF + 1, np.int32); kf_off[1:] = np.cumsum([len(a) for a, _ in kf_bow])
+    dbw = np.concatenate([a for a, _ in kf_bow]); dbv = np.concatenate([b for _, b in kf_bow])
+    res = {}
 
 
-def cpu_chain():
-    qk, qd = ex.extract(q_img)
-    (w, wt, nd), (q_words, q_ww), q_fv = TB._oracle_transform(L, v, qd)
-    st = np.zeros(NKF, np.float32); cand = np.zeros(NKF, np.int32)
-    n = L.orc_detect_reloc_candidates(TB._p(q_words), TB._p(q_ww), len(q_words), NKF, TB._p(kf_off), TB._p(dbw), TB._p(dbv),
-                                      TB._p(covis_off), TB._p(covis_idx), TB._p(st), TB._p(cand), NKF)
-    kfi = int(cand[0])
-    kfk, kfd = kf_kd[kfi]
-    fv = kf_fv[kfi]
-    ref = np.zeros(len(qd), np.int32)
-    nref = L.orc_search_by_bow(TB._p(fv[0]), TB._p(fv[1]), TB._p(fv[2]), len(fv[0]), TB._p(np.ones(len(kfd), np.int32)), TB._p(kfd),
-                               TB._p(kfk["angle"].copy()), TB._p(q_fv[0]), TB._p(q_fv[1]), TB._p(q_fv[2]), len(q_fv[0]), TB._p(qd),
-                               TB._p(qk["angle"].copy()), len(qd), 0.75, 1, TB._p(ref))
-    res["cpu"] = (cand[:n].tolist(), nref)
+    def gpu_chain():
+        qk, qd = ctx.extract(q_img)
+        gw, gwt, gnd = B.transform(ctx, qd, 4)
+        q_words, q_ww, qn, qo, qf = B.maps(gw, gwt, gnd)
+        st = np.zeros(NKF, np.float32)
+        cand = db.detect_reloc_candidates(q_words, q_ww, covis_off, covis_idx, st)
+        kfi = int(cand[0])
+        kfk, kfd = kf_kd[kfi]
+        m, nm = B.search_by_bow(ctx, kf_fv[kfi], np.ones(len(kfd), np.int32), kfd, kfk["angle"].copy(), (qn, qo, qf), qd, qk["angle"].copy(), 0.75, True)
+        res["gpu"] = (cand.tolist(), nm)
 
 
-g, c = med(gpu_chain, 30), med(cpu_chain, 5, 1)
-out["config 2 Mono-EuRoC 752x480/1200: extract + BoW transform + 500-KF database query + SearchByBoW"] = {
-    "gpu_ms": g, "cpu_ms": c, "same_candidates_and_matches": res["gpu"] == res["cpu"], "matches": res["gpu"][1]}
-L.orc_vocab_destroy(v)
+    def cpu_chain():
+        qk, qd = ex.extract(q_img)
+        (w, wt, nd), (q_words, q_ww), q_fv = TB._oracle_transform(L, v, qd)
+        st = np.zeros(NKF, np.float32); cand = np.zeros(NKF, np.int32)
+        n = L.orc_detect_reloc_candidates(TB._p(q_words), TB._p(q_ww), len(q_words), NKF, TB._p(kf_off), TB._p(dbw), TB._p(dbv),
+                                          TB._p(covis_off), TB._p(covis_idx), TB._p(st), TB._p(cand), NKF)
+        kfi = int(cand[0])
+        kfk, kfd = kf_kd[kfi]
+        fv = kf_fv[kfi]
+        ref = np.zeros(len(qd), np.int32)
+        nref = L.orc_search_by_bow(TB._p(fv[0]), TB._p(fv[1]), TB._p(fv[2]), len(fv[0]), TB._p(np.ones(len(kfd), np.int32)), TB._p(kfd),
+                                   TB._p(kfk["angle"].copy()), TB._p(q_fv[0]), TB._p(q_fv[1]), TB._p(q_fv[2]), len(q_fv[0]), TB._p(qd),
+                                   TB._p(qk["angle"].copy()), len(qd), 0.75, 1, TB._p(ref))
+        res["cpu"] = (cand[:n].tolist(), nref)
+
+
+    g, c = med(gpu_chain, 30), med(cpu_chain, 5, 1)
+    out["config 2 Mono-EuRoC 752x480/1200: extract + BoW transform + 500-KF database query + SearchByBoW" + label] = {
+        "gpu_ms": g, "cpu_ms": c, "same_candidates_and_matches": res["gpu"] == res["cpu"], "matches": res["gpu"][1]}
+    L.orc_vocab_destroy(v)
+
+
+
+config2(B.build_vocabulary(np.concatenate([d for _, d in kf_kd[:8]]), k=10, levels=4, seed=3), "")
+config2(B.build_full_vocabulary(), " -- complete k=10 / six-level vocabulary (10^6 words, 45 MB)")
 ctx.close()
 
 # ---- config 4
+res = {}
 W, H, NF = 1280, 720, 2500
 fx = fy = 911.0; cx, cy, bf = 640.0, 360.0, 45.5
 ctx = api.Context(width=W, height=H, nfeatures=NF, fx=fx, fy=fy, cx=cx, cy=cy, bf=bf, max_images=1)
