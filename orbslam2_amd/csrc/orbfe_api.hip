@@ -320,7 +320,7 @@ static int build_config(orbfe_context *ctx)
         ctx->ot2_lds = orbfe_octree2_lds_bytes(c.max_nodes, sc, pts);
         ctx->use_octree2 = roots_ok && c.max_nodes <= 4096 && ctx->ot2_lds <= 150 * 1024;
         {
-            bool ok3 = roots_ok && c.cell_cap <= 4096; // key fields: 12-bit cell, 12-bit slot
+            bool ok3 = roots_ok && c.cell_cap <= 4095; // key fields: 12-bit cell, 12-bit slot; bucket partials: 12-bit count
             for (int l = 0; l < p.nlevels; l++) ok3 = ok3 && c.lv[l].n_cells <= 4096 && c.lv[l].w_cell <= 64 && c.lv[l].h_cell <= 64; // one lane per cell column / row
             ctx->ot3_nodes_in_hbm = orbfe_octree3_lds_bytes(c.max_nodes, sc, false) > 150 * 1024;
             ctx->ot3_lds = orbfe_octree3_lds_bytes(c.max_nodes, sc, ctx->ot3_nodes_in_hbm);
@@ -384,10 +384,6 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
     A(b.ot_sc3, B * c.cand_total);
     A(b.idx0, B * c.cand_total);
     A(b.idx1, B * c.cand_total);
-    A(b.bk_cnt, B * c.nlevels * 4096);
-    A(b.bk_best, B * c.nlevels * 4096);
-    Z(b.bk_cnt, B * c.nlevels * 4096 * sizeof(uint32_t));
-    Z(b.bk_best, B * c.nlevels * 4096 * sizeof(uint32_t));
     A(b.bk_end, B * c.nlevels * 4097);
     b.ot3_scratch = nullptr;
     if (ctx->use_octree3 && ctx->ot3_nodes_in_hbm) A(b.ot3_scratch, B * c.nlevels * orbfe_octree3_node_bytes(c.max_nodes, ctx->ot2_sort_cap));
@@ -580,9 +576,10 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
         }
         b.rs_tab = d_tab;
     }
+    std::vector<uint32_t> bk_tab_host;
     {   // quadtree bucket tables (orbfe_octree3.hip): root and depth-5 path bits of every x / y of each level's
         // candidate region, with the reference's arithmetic (src/ORBextractor.cc:537-564 roots, :145-209 splits)
-        std::vector<uint32_t> tab;
+        std::vector<uint32_t> &tab = bk_tab_host;
         auto spread5 = [](unsigned v) { unsigned r = 0; for (int i = 0; i < 5; i++) r |= ((v >> i) & 1u) << (2 * i); return r; };
         for (int l = 0; l < p.nlevels; l++) {
             LevelInfo &L = ctx->cfg.lv[l];
@@ -652,6 +649,50 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
             return fail(nullptr, ORBFE_ERR_HIP, "cell table upload failed");
         }
         b.cell_info = (const uint4 *)d_ci;
+        // bucket partials (fast_cell_kernel phase E -> octree3_kernel): the survivors of a cell fall into the bucket columns
+        // X[first col] >> 16 .. X[last col] >> 16 and the rows Y[..] >> 16 likewise (the tables are monotone).  A cell whose
+        // rectangle has at most 64 buckets accumulates them in LDS and stores the count and best key of each with plain
+        // stores into its own entries of bk_part (one word each); bk_emap names the bucket and the cell of every entry.  Cells with larger rectangles
+        // (the small levels, where a bucket is 3 px wide) have no entries: the quadtree kernel buckets their candidates.
+        std::vector<uint32_t> off((size_t)c.cells_total, 0u);
+        std::vector<uint32_t> emap;
+        auto spread5 = [](unsigned v) { unsigned r = 0; for (int i = 0; i < 5; i++) r |= ((v >> i) & 1u) << (2 * i); return r; };
+        for (int l = 0; l < p.nlevels; l++) {
+            LevelInfo &L = ctx->cfg.lv[l];
+            L.bk_part_off = (int)emap.size();
+            L.bk_points = 0;
+            for (int k = 0; k < L.n_cells; k++) {
+                const uint32_t *e = &ci[(size_t)(L.cell_off + k) * 4];
+                off[L.cell_off + k] = (uint32_t)emap.size();
+                if (!(e[0] & 0x100u)) continue; // no FAST call: no entries
+                const int cx0 = (int)(e[1] & 0xffffu) - c.min_border, cy0 = (int)(e[1] >> 16) - c.min_border;
+                const int iw = (int)(e[2] & 0xffu) - 6, ih = (int)((e[2] >> 8) & 0xffu) - 6;
+                const uint32_t *tx = &bk_tab_host[L.bk_xoff + 3 + cx0], *ty = &bk_tab_host[L.bk_yoff + 3 + cy0];
+                const int gx0 = (int)(tx[0] >> 16), gx1 = (int)(tx[iw - 1] >> 16), by0 = (int)(ty[0] >> 16), by1 = (int)(ty[ih - 1] >> 16);
+                const int ncols = gx1 - gx0 + 1, nb = ncols * (by1 - by0 + 1);
+                if (nb > 64) { off[L.cell_off + k] = ~0u; L.bk_points = 1; continue; }
+                for (int j = 0; j < nb; j++) {
+                    const unsigned gx = (unsigned)(gx0 + j % ncols), by = (unsigned)(by0 + j / ncols);
+                    emap.push_back(((gx >> 5) << 10) | spread5(gx & 31u) | (spread5(by) << 1) | ((uint32_t)k << 16));
+                }
+            }
+            L.bk_part_n = (int)emap.size() - L.bk_part_off;
+        }
+        ctx->cfg.bk_part_total = (int)emap.size();
+        while (emap.size() % 8 || emap.empty()) emap.push_back(0);
+        uint32_t *d_off = nullptr;
+        uint32_t *d_emap = nullptr;
+        A(d_off, off.size());
+        A(d_emap, emap.size());
+        A(b.bk_part, B * emap.size());
+        Z(b.bk_part, B * emap.size() * sizeof(uint32_t));
+        if (hipMemcpy(d_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_emap, emap.data(), emap.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            orbfe_destroy(ctx);
+            return fail(nullptr, ORBFE_ERR_HIP, "bucket partial table upload failed");
+        }
+        b.bk_off = d_off;
+        b.bk_emap = d_emap;
     }
     {   // blur tile table (blur_kernel): level, 256-column strip and first row of every wave's tile
         std::vector<uint32_t> ti((size_t)(c.blur_tiles_total > 0 ? c.blur_tiles_total : 1), 0u);
@@ -864,7 +905,7 @@ static DeviceBuffers shift_buffers(const DeviceBuffers &b, const DeviceConfig &c
     o.cand_xy += i * c.cand_total; o.cand_sc += i * c.cand_total; o.cand_sc2 += i * c.cand_total;
     o.idx0 += i * c.cand_total; o.idx1 += i * c.cand_total; o.ot_xy2 += i * c.cand_total; o.ot_sc3 += i * c.cand_total;
     o.lvl_ncand += i * c.nlevels; o.sel_cnt += i * c.nlevels;
-    o.bk_cnt += i * c.nlevels * 4096; o.bk_best += i * c.nlevels * 4096; o.bk_end += i * c.nlevels * 4097;
+    o.bk_part += i * c.bk_part_total; o.bk_end += i * c.nlevels * 4097;
     if (o.ot3_scratch) o.ot3_scratch += i * c.nlevels * orbfe_octree3_node_bytes(c.max_nodes, ot_sort_cap_of(c));
     o.sel_xy += i * c.sel_total; o.sel_sc += i * c.sel_total;
     o.kps = (KeyPointPOD *)o.kps + i * c.sel_total; o.desc += i * c.sel_total * 32;

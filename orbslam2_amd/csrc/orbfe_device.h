@@ -49,6 +49,8 @@ struct LevelInfo {
     int rs_src_rows[3];            // source rows spanned by the worst block of 16 / 8 / 4 output rows (pyr_resize_kernel)
     int rs_rw, rs_blk_off;         // rows per wave the launch uses (4 / 2 / 1) and this level's entries in DeviceBuffers::rs_blk
     int bk_xoff, bk_yoff;          // quadtree bucket tables of this level in DeviceBuffers::bk_tab (orbfe_octree3.hip)
+    int bk_part_off, bk_part_n;    // this level's per-cell bucket partials in DeviceBuffers::bk_part / bk_emap
+    int bk_points;                 // some cell of the level spans > 64 buckets: the quadtree kernel buckets its candidates itself
 };
 
 struct DeviceConfig {
@@ -63,6 +65,7 @@ struct DeviceConfig {
     int sel_total;         // per image == keypoint capacity
     int blur_tiles_total;
     int max_nodes;         // quadtree node capacity (LDS)
+    int bk_part_total;     // per image: entries of DeviceBuffers::bk_part
     int row_cap;           // entries per image row in DeviceBuffers::row_ent
     int patch_n;           // entries in DeviceBuffers::patch_uv (multiple of 64)
     // fused pyramid tail (pyr_tail_kernel): the last tail_n levels (2 or 3) in one launch, 0 = not used
@@ -107,8 +110,9 @@ struct DeviceBuffers {
     uint32_t *ot_xy2;    // [img][cand_total] quadtree ping-pong partner
     uint8_t *ot_sc3;     // [img][cand_total]
     uint32_t *idx0, *idx1; // [img][cand_total] ping-pong permutation
-    uint32_t *bk_cnt;    // [img][nlevels][4096] quadtree bucket counts (orbfe_octree3.hip); zero between frames
-    uint32_t *bk_best;   // [img][nlevels][4096] quadtree bucket best keys; zero between frames
+    uint32_t *bk_part;   // [img][bk_part_total] count | best slot << 12 | best score << 24 (ORBFE_BK_PART) of every bucket a FAST cell's
+                         // survivors can fall into, cell after cell; rewritten by fast_cell_kernel every frame, summed into the
+                         // bucket arrays (LDS) by octree3_kernel
     int *bk_end;         // [img][nlevels][4097] quadtree deep path: bucket ends of the counting sort
     uint8_t *ot3_scratch; // [img][nlevels][node_bytes] quadtree node tables when they do not fit LDS (else null)
     int *lvl_ncand;      // [img][nlevels]
@@ -125,6 +129,8 @@ struct DeviceBuffers {
     int *row_cnt;        // [pair][height] stereo row lists: right keypoints whose band covers the row (cleared by ingest)
     uint2 *row_ent;      // [pair][height][row_cap] entries: (iR | octave << 16, x bits), appended by describe_kernel
     const uint32_t *bk_tab; // quadtree bucket tables: per level X[region_w] then Y[region_h] (see ORBFE_BK_*)
+    const uint32_t *bk_emap; // [bk_part_total] bucket index | level-local cell << 16 of every bk_part entry
+    const uint32_t *bk_off;  // [cells_total] first bk_part entry of the cell; ~0u: the cell spans > 64 buckets (no partials)
     const uint32_t *rs_tab; // cv::resize offset/weight tables of every level (see pyr_resize_kernel)
     const uint4 *cell_info; // [cells_total] FAST cells: level | valid << 8, ini_x | ini_y << 16, tile w | h << 8, index inside the level (fast_cell_kernel)
     const uint32_t *blur_tile_info; // [blur_tiles_total] level | column strip << 8 | first row << 16 (blur_kernel)
@@ -146,6 +152,10 @@ struct DeviceBuffers {
 #define ORBFE_BK_BUCKETS 4096
 #define ORBFE_BK_REF_MASK 0xffffffu
 #define ORBFE_BK_KEY(sc, cell, slot) (((sc) << 24) | (ORBFE_BK_REF_MASK - (unsigned)(((cell) << 12) | (slot))))
+// A cell's partial entry: the cell is implied by the entry's position, so count (<= cell_cap <= 1024) and the key's score and
+// (inverted) slot fields fit one word; ORBFE_BK_PART_KEY rebuilds the key for level-local cell `cell`.
+#define ORBFE_BK_PART(cnt, key) ((cnt) | (((key) & 0xfffu) << 12) | ((key) & 0xff000000u))
+#define ORBFE_BK_PART_KEY(e, cell) (((e) & 0xff000000u) | ((4095u - (unsigned)(cell)) << 12) | (((e) >> 12) & 0xfffu))
 
 struct KeyPointPOD {
     float x, y, size, angle, response;

@@ -104,7 +104,7 @@ __device__ __forceinline__ unsigned h2sub(unsigned a, unsigned b) { unsigned d; 
 // TP = tile pitch in bytes as a compile-time constant (0: run-time value): with it every ring / row offset folds
 // into the immediate offset field of the LDS instructions instead of costing address VALU.
 // BK: also accumulate the quadtree bucket counts / best keys of the survivors (orbfe_octree3.hip) -- aggregated per
-// cell in LDS, then a few global atomics per cell.
+// cell in LDS, then stored to the cell's own entries of DeviceBuffers::bk_part.
 // the waves of a workgroup are independent; a wave's own LDS traffic only needs its outstanding LDS operations retired
 #define FAST_WAVE_SYNC() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); } while (0)
 template <int TP, bool BK>
@@ -142,8 +142,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     const int iw = tw - 6, ih = th - 6;
     const int cell_x0 = ini_x - cfg.min_border, cell_y0 = ini_y - cfg.min_border; // j * wCell, i * hCell
     // bucket tables of this cell's columns / rows (BK): issued now, consumed in phase E
-    unsigned tabx = 0u, taby = 0u;
+    unsigned tabx = 0u, taby = 0u, bk_off = ~0u;
     if (BK) {
+        bk_off = buf.bk_off[cell];
         const uint32_t *bx_tab = buf.bk_tab + L.bk_xoff + 3 + cell_x0; // survivor x = c + 3 + j * wCell
         const uint32_t *by_tab = buf.bk_tab + L.bk_yoff + 3 + cell_y0;
         tabx = bx_tab[lane < iw ? lane : iw - 1];
@@ -427,19 +428,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     // ---- E: ordered emission ----
     uint32_t *oxy = buf.cell_xy + ((size_t)img * cfg.cells_total + cell) * cfg.cell_cap;
     uint8_t *osc = buf.cell_sc + ((size_t)img * cfg.cells_total + cell) * cfg.cell_cap;
-    // BK: the cell's survivors fall into the bucket columns gx0..gx1 and rows by0..by1 (tables are monotone); when
-    // that rectangle has at most 64 buckets they are accumulated in LDS first
+    // BK: the cell's survivors fall into the bucket columns gx0..gx1 and rows by0..by1 (tables are monotone).  When that
+    // rectangle has at most 64 buckets (the host decides: bk_off) their counts and best keys are accumulated in LDS and stored
+    // to the cell's own entries of bk_part: plain stores, no global atomics (a device-scope atomic is a memory-side request
+    // of its own on this multi-die part); the quadtree kernel buckets the candidates of the other cells itself
     unsigned *s_ac = (unsigned *)(s_mem + tile_bytes + sc_bytes + q_bytes), *s_ab = s_ac + 64;
     int gx0 = 0, by0 = 0, ncols = 1, nb = 0;
-    uint32_t *g_cnt = nullptr, *g_best = nullptr;
-    if (BK) {
+    const bool part = BK && bk_off != ~0u;
+    if (part) {
         gx0 = (int)(__builtin_amdgcn_readfirstlane(tabx) >> 16);
         by0 = (int)(__builtin_amdgcn_readfirstlane(taby) >> 16);
         ncols = (int)(__builtin_amdgcn_readlane(tabx, 63) >> 16) - gx0 + 1; // lanes >= iw hold the last column / row
         nb = ncols * ((int)(__builtin_amdgcn_readlane(taby, 63) >> 16) - by0 + 1);
-        if (nb <= 64) { s_ac[lane] = 0u; s_ab[lane] = 0u; }
-        g_cnt = buf.bk_cnt + ((size_t)img * cfg.nlevels + level) * ORBFE_BK_BUCKETS;
-        g_best = buf.bk_best + ((size_t)img * cfg.nlevels + level) * ORBFE_BK_BUCKETS;
+        s_ac[lane] = 0u; s_ab[lane] = 0u;
         FAST_WAVE_SYNC();
     }
     // survivors are first compacted in place over the queue (a write never passes this iteration's reads), then
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         const unsigned rc = v ? (s_q2[pos] & 0x7fffu) : 0u;
         const int r = (int)(rc >> 8) - 1, c = rc & 255;
         unsigned tx = 0u, ty = 0u;
-        if (BK) { tx = (unsigned)__shfl((int)tabx, c, 64); ty = (unsigned)__shfl((int)taby, r, 64); }
+        if (part) { tx = (unsigned)__shfl((int)tabx, c, 64); ty = (unsigned)__shfl((int)taby, r, 64); }
         if (v) {
             // cell-local FAST coords (c+3, r+3) + (j*wCell, i*hCell): src/ORBextractor.cc:816-817
             const unsigned x = (unsigned)(c + 3 + cell_x0);
@@ -478,32 +479,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             const unsigned sc = s_sc[(r + 1) * scp + c + 1];
             oxy[pos] = x | (y << 16);
             osc[pos] = (uint8_t)sc;
-            if (BK) {
-                const unsigned key = ORBFE_BK_KEY(sc, (unsigned)ci, (unsigned)pos);
-                if (nb <= 64) {
-                    const int li = ((int)(ty >> 16) - by0) * ncols + ((int)(tx >> 16) - gx0);
-                    atomicAdd(&s_ac[li], 1u);
-                    atomicMax(&s_ab[li], key);
-                } else {
-                    const unsigned b = (tx | ty) & 0xfffu;
-                    atomicAdd(&g_cnt[b], 1u);
-                    atomicMax(&g_best[b], key);
-                }
+            if (part) {
+                const int li = ((int)(ty >> 16) - by0) * ncols + ((int)(tx >> 16) - gx0);
+                atomicAdd(&s_ac[li], 1u);
+                atomicMax(&s_ab[li], ORBFE_BK_KEY(sc, (unsigned)ci, (unsigned)pos));
             }
         }
     }
     if (lane == 0) *cnt_out = run < cfg.cell_cap ? run : cfg.cell_cap;
-    if (BK && nb <= 64 && !ORBFE_CUT(5)) {
+    if (part && !ORBFE_CUT(5)) { // every frame rewrites all nb entries (zeros included): nothing to clear between frames
         FAST_WAVE_SYNC();
-        const unsigned cnt = lane < nb ? s_ac[lane] : 0u;
-        if (cnt) {
-            const int ly = small_div(lane, ncols), lx = lane - ly * ncols;
-            const unsigned gx = (unsigned)(gx0 + lx), by = (unsigned)(by0 + ly);
-            auto spread5 = [](unsigned v) { return (v & 1u) | ((v & 2u) << 1) | ((v & 4u) << 2) | ((v & 8u) << 3) | ((v & 16u) << 4); };
-            const unsigned b = ((gx >> 5) << 10) | spread5(gx & 31u) | (spread5(by) << 1);
-            atomicAdd(&g_cnt[b], cnt);
-            atomicMax(&g_best[b], s_ab[lane]);
-        }
+        if (lane < nb) buf.bk_part[(size_t)img * cfg.bk_part_total + bk_off + lane] = ORBFE_BK_PART(s_ac[lane], s_ab[lane]);
     }
 }
 

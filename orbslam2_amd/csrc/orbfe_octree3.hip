@@ -8,8 +8,9 @@
 //   1. fast_cell_kernel (phase E) looks up every survivor's root and quadrant path down to depth 5
 //      ("bucket") in two host-built tables (the path is separable in x and y) and accumulates per-bucket
 //      counts and the per-bucket best key  score << 24 | ~(cell << 12 | slot)  (max score, first in
-//      cv::FAST emission order = the reference's "first maximum wins") -- per cell in LDS, then a few
-//      global atomics per cell; this kernel takes the 4096 + 4096 words over and clears them;
+//      cv::FAST emission order = the reference's "first maximum wins") -- per cell in LDS, then
+//      plain stores of the cell's partial (count, best key) entries (bucket partials, DeviceBuffers::bk_part: a cell's
+//      survivors fall into a small rectangle of buckets); this kernel adds them up per bucket in LDS;
 //   2. counts and best keys are summed / maximised up the quadrant pyramid (depths 4..0);
 //   3. the split passes work on the node list alone (<= max_nodes entries in LDS): a node is
 //      (box, depth, path), its child counts are pyramid look-ups, and the list-order bookkeeping, the
@@ -225,18 +226,62 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
     const int n_ini = L.n_ini, quota = L.quota;
     const float hx = L.hx;
 
-    // ---- 1. buckets: filled by fast_cell_kernel<.., true> (phase E); taken over and cleared for the next frame ----
+    // ---- 1. buckets: the per-cell partial (count, best key) entries of fast_cell_kernel<.., true> (phase E), summed / maximised
+    //      per bucket in LDS; bk_emap (host-built) names the bucket of every entry.  The candidates of cells without entries
+    //      (more than 64 buckets under one cell: levels whose buckets are ~3 px) are bucketed here from the cell slots. ----
     {
-        uint32_t *g_cnt = buf.bk_cnt + (ib * cfg.nlevels + level) * OT3_BUCKETS;
-        uint32_t *g_best = buf.bk_best + (ib * cfg.nlevels + level) * OT3_BUCKETS;
         int *cnt5 = s_cnt + ot3_off(OT3_DB);
         unsigned *best5 = s_best + ot3_off(OT3_DB);
+        // ten entries per thread in flight (one batch covers level 0 of a 752 x 480 frame); the first batch is issued before the LDS arrays are cleared
+        const uint32_t *part = buf.bk_part + ib * cfg.bk_part_total + L.bk_part_off;
+        const uint32_t *emap = buf.bk_emap + L.bk_part_off;
+        const int n_part = L.bk_part_n;
+        constexpr int U = 10;
+        uint32_t pe[U], be[U];
+        auto load = [&](int e0) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int e = e0 + u * OT3_THREADS + tid;
+                pe[u] = 0u; be[u] = 0u;
+                if (e < n_part) { pe[u] = part[e]; be[u] = emap[e]; }
+            }
+        };
+        auto apply = [&]() {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (pe[u] & 0xfffu) {
+                    atomicAdd(&cnt5[be[u] & 0xffffu], (int)(pe[u] & 0xfffu));
+                    atomicMax(&best5[be[u] & 0xffffu], ORBFE_BK_PART_KEY(pe[u], be[u] >> 16));
+                }
+        };
+        load(0);
         const uint4 zero = {0u, 0u, 0u, 0u};
-        for (int i = tid; i < OT3_BUCKETS / 4; i += OT3_THREADS) {
-            const uint4 c = ((const uint4 *)g_cnt)[i], b = ((const uint4 *)g_best)[i];
-            ((uint4 *)g_cnt)[i] = zero; ((uint4 *)g_best)[i] = zero;
-            cnt5[4 * i] = (int)c.x; cnt5[4 * i + 1] = (int)c.y; cnt5[4 * i + 2] = (int)c.z; cnt5[4 * i + 3] = (int)c.w;
-            best5[4 * i] = b.x; best5[4 * i + 1] = b.y; best5[4 * i + 2] = b.z; best5[4 * i + 3] = b.w;
+        for (int i = tid; i < OT3_BUCKETS / 4; i += OT3_THREADS) { ((uint4 *)cnt5)[i] = zero; ((uint4 *)best5)[i] = zero; }
+        __syncthreads();
+        apply();
+        for (int e0 = U * OT3_THREADS; e0 < n_part; e0 += U * OT3_THREADS) { load(e0); apply(); }
+        if (L.bk_points) {
+            // sixteen lanes per cell (these levels have a handful of candidates per cell), everything a lane needs first loaded
+            // without waiting for the cell's count: slots beyond it are allocated but unused
+            const uint32_t *bk_off = buf.bk_off + L.cell_off;
+            auto put = [&](uint32_t xy, unsigned sc, int c, int k) {
+                int root;
+                const unsigned path = ot3_path((int)(xy & 0xffffu), (int)(xy >> 16), OT3_DB, hx, n_ini, region_h, root);
+                const int b = (root << (2 * OT3_DB)) + (int)path;
+                atomicAdd(&cnt5[b], 1);
+                atomicMax(&best5[b], OT3_KEY(sc, c, k));
+            };
+            for (int idx = tid; idx < 16 * L.n_cells; idx += OT3_THREADS) {
+                const int c = idx >> 4, k0 = idx & 15;
+                const size_t base = (size_t)c * cfg.cell_cap;
+                const uint32_t off = bk_off[c];
+                const int cnt = cell_cnt[c];
+                const uint32_t xy0 = k0 < cfg.cell_cap ? cell_xy[base + k0] : 0u;
+                const unsigned sc0 = k0 < cfg.cell_cap ? cell_sc[base + k0] : 0u;
+                if (off != ~0u) continue;
+                if (k0 < cnt) put(xy0, sc0, c, k0);
+                for (int k = k0 + 16; k < cnt; k += 16) put(cell_xy[base + k], (unsigned)cell_sc[base + k], c, k);
+            }
         }
     }
     __syncthreads();
