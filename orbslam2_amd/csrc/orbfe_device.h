@@ -9,7 +9,7 @@
 #define ORBFE_MAX_LEVELS 16
 #define ORBFE_TAIL_MAX 3   // levels fused by pyr_tail_kernel
 #define ORBFE_TAIL_COLS 64 // extended columns of the last level per workgroup
-#define ORBFE_BLUR_ROWS 16 // rows per wave of blur_kernel (a multiple of the 4-row tiles of the blurred pyramid)
+#define ORBFE_BLUR_ROWS 16
 #define ORBFE_WAVE 64
 
 // Profiling cut points (tools/*_phases.sh, tools/*_insts.sh): an extra kernel argument that makes a kernel return after a

@@ -407,11 +407,14 @@ __global__ __launch_bounds__(TAIL_THREADS) void pyr_tail_kernel(DeviceConfig cfg
 // ---------------------------------------------------------------------------
 // Gaussian 7x7 (8.8 fixed point, separable), all levels in one launch.
 // Register sliding window: a lane owns 4 adjacent columns and walks down BL_ROWS rows; per input
-// row it loads three aligned words (12 px), forms the four 7-tap row sums with v_dot4_u32_u8, keeps
-// the last seven row-sum vectors in registers and emits one 4-px output word.  No LDS, no barriers;
-// HBM traffic = one read of the level (+6/BL_ROWS row halo, L2-served) and one write.
+// row it loads three aligned words (12 px), forms the four 7-tap row sums with v_dot4_u32_u8 against
+// shifted tap words, keeps the row sums of the last eight rows as four row pairs and emits two 4-px
+// output words per two input rows with v_dot2_u32_u16.  No LDS, no barriers; HBM traffic = one read
+// of the level (+6/BL_ROWS row halo, L2-served) and one write.  Round 2: 872 -> 630 VALU instructions
+// per wave (13.6 -> 9.8 per pixel), 0.109 -> 0.098 ms; the first 12 % of the cut bought all of that, the
+// kernel now runs at the ~4.8 TB/s of mixed read / write traffic the memory system gives it.
 // ---------------------------------------------------------------------------
-#define BL_ROWS ORBFE_BLUR_ROWS // rows per wave: 6 / BL_ROWS of the rows are loaded (and row-filtered) twice; 16 beats 32 (0.117 -> 0.114 ms: more waves) and 8 / 64
+#define BL_ROWS ORBFE_BLUR_ROWS // rows per wave (even): 6 / BL_ROWS of the rows are loaded (and row-filtered) twice; 16, 24 and 32 measure the same, 8 / 64 slower
 #define BL_COLS 256 // per wave: 64 lanes x 4 px
 __global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffers buf)
 {
@@ -429,50 +432,73 @@ __global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffe
     // output in 32 x 4 px tiles of 128 B: describe_kernel's 37-row patches then touch about half as many cache lines
     uint8_t *dst = buf.blur + (size_t)img * cfg.blur_bytes + L.blur_off + (((unsigned)(r0 >> 2) * L.blur_tx + (x0 >> 5)) << 7) + (x0 & 31);
     const unsigned tile_row_bytes = (unsigned)L.blur_tx << 7;
-    const unsigned k_lo = (unsigned)cfg.taps[0] | ((unsigned)cfg.taps[1] << 8) | ((unsigned)cfg.taps[2] << 16) | ((unsigned)cfg.taps[3] << 24);
-    const unsigned k_hi = (unsigned)cfg.taps[4] | ((unsigned)cfg.taps[5] << 8) | ((unsigned)cfg.taps[6] << 16);
-    const unsigned k6 = cfg.taps[6];
+    unsigned tw[4][3]; // tw[j][q]: taps against the bytes of word q for pixel j; byte 4 q + b meets tap 4 q + b - 1 - j
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            unsigned w = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int t = 4 * q + b - 1 - j;
+                if (t >= 0 && t <= 6) w |= (unsigned)cfg.taps[t] << (8 * b);
+            }
+            tw[j][q] = w;
+        }
     const int y_max = L.h + PYR_MY - 1; // last materialised row
-    // column pass on consecutive-row pairs: P[i % 6][j] = H_i | H_(i+1) << 16 (row sums fit 16 bits: <= 255 * 256), so the
-    // seven taps are three v_dot2_u32_u16 and one v_mad: k0 H_(i-6) + k1 H_(i-5) | k2 H_(i-4) + k3 H_(i-3) | k4 H_(i-2) + k5 H_(i-1) | k6 H_i
+    // column pass on row PAIRS starting at even window rows: Q[m % 4][j] = H_2m | H_(2m+1) << 16 (row sums fit 16 bits:
+    // <= 255 * 256).  Output row 2a is k0 k1 | k2 k3 | k4 k5 | k6 0 against Q[a .. a+3], output row 2a + 1 is
+    // 0 k0 | k1 k2 | k3 k4 | k5 k6 against the same four pairs: four v_dot2_u32_u16 per pixel either way, and only one pair is
+    // formed per two rows (pairs at every row start, which the three-dot2-plus-mad form needs, cost twice the packing ops).
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    const u16x2 t01 = {(unsigned short)cfg.taps[0], (unsigned short)cfg.taps[1]}, t23 = {(unsigned short)cfg.taps[2], (unsigned short)cfg.taps[3]};
-    const u16x2 t45 = {(unsigned short)cfg.taps[4], (unsigned short)cfg.taps[5]};
-    unsigned P[6][4], hp[4] = {0, 0, 0, 0};
+    const unsigned short k0 = (unsigned short)cfg.taps[0], k1 = (unsigned short)cfg.taps[1], k2 = (unsigned short)cfg.taps[2], k3 = (unsigned short)cfg.taps[3];
+    const unsigned short k4 = (unsigned short)cfg.taps[4], k5 = (unsigned short)cfg.taps[5], k6 = (unsigned short)cfg.taps[6];
+    const u16x2 te[4] = {{k0, k1}, {k2, k3}, {k4, k5}, {k6, 0}}, to[4] = {{0, k0}, {k1, k2}, {k3, k4}, {k5, k6}};
+    unsigned Q[4][4], he[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < BL_ROWS + 6; i++) {
         int y = r0 - 3 + i;
         y = y > y_max ? y_max : y; // rows past the margin only feed outputs that are never stored
-        const uint32_t *row = (const uint32_t *)(src + (ptrdiff_t)y * L.pitch);
+        const uint32_t *row = (const uint32_t *)(src + __mul24(y, L.pitch)); // y >= -3: the margin rows above the image
         const unsigned w0 = row[-1], w1 = row[0], w2 = row[1];
+        // row pass: pixel j of the lane's word is byte 4 + j of (w0, w1, w2) and its seven taps cover bytes 1 + j .. 7 + j, so
+        // H_j is a byte dot product of the three aligned words with tap words shifted by j (wave-uniform, in scalar registers):
+        // 2 + 3 + 3 + 2 v_dot4_u32_u8 per four pixels and no byte alignment ops (aligning the pixels instead costs 6 + 8)
         unsigned hn[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const unsigned lo = j == 3 ? w1 : __builtin_amdgcn_alignbyte(w1, w0, j + 1);
-            const unsigned hi = j == 3 ? w2 : __builtin_amdgcn_alignbyte(w2, w1, j + 1);
-            hn[j] = __builtin_amdgcn_udot4(lo, k_lo, __builtin_amdgcn_udot4(hi, k_hi, 0u, false), false);
+            unsigned acc = __builtin_amdgcn_udot4(w1, tw[j][1], 0u, false);
+            if (j < 3) acc = __builtin_amdgcn_udot4(w0, tw[j][0], acc, false);
+            if (j > 0) acc = __builtin_amdgcn_udot4(w2, tw[j][2], acc, false);
+            hn[j] = acc;
         }
-        if (i >= 6) {
-            const int yo = r0 + i - 6;
-            if (yo < L.h) {
-                unsigned o = 0;
+        if (!(i & 1)) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) he[j] = hn[j];
+            continue;
+        }
+        const int m = i >> 1;
+#pragma unroll
+        for (int j = 0; j < 4; j++) Q[m & 3][j] = he[j] | (hn[j] << 16);
+        if (m < 3) continue;
+        const int a = m - 3;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int orow = 2 * a + half;
+            if (r0 + orow < L.h) {
+                unsigned ob[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    unsigned acc = k6 * hn[j] + 32768u;
-                    acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, P[(i - 6) % 6][j]), t01, acc, false);
-                    acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, P[(i - 4) % 6][j]), t23, acc, false);
-                    acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, P[(i - 2) % 6][j]), t45, acc, false);
-                    o |= (acc >> 16) << (8 * j);
+                    unsigned acc = 32768u;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, Q[(a + q) & 3][j]), half ? to[q] : te[q], acc, false);
+                    ob[j] = acc;
                 }
-                *(uint32_t *)(dst + ((unsigned)((i - 6) >> 2) * tile_row_bytes + (unsigned)(((i - 6) & 3) << 5))) = o;
+                // byte 2 of the four sums -> one word: two v_perm_b32 and an or
+                const unsigned o = __builtin_amdgcn_perm(ob[1], ob[0], 0x0c0c0602u) | __builtin_amdgcn_perm(ob[3], ob[2], 0x06020c0cu);
+                *(uint32_t *)(dst + ((unsigned)(orow >> 2) * tile_row_bytes + (unsigned)((orow & 3) << 5))) = o;
             }
         }
-        if (i >= 1) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) P[(i - 1) % 6][j] = hp[j] | (hn[j] << 16); // pair (i-1, i); the slot's previous pair (i-7, i-6) is dead
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) hp[j] = hn[j];
     }
 }
 
