@@ -1422,14 +1422,14 @@ extern "C" int orbfe_fetch_pyramid(orbfe_context *ctx, int image, int level, int
     { const int rcw = wait_latest(ctx); if (rcw != ORBFE_OK) return rcw; }
     const LevelInfo &L = ctx->cfg.lv[level];
     if (dst_stride < (size_t)L.w) return fail(ctx, ORBFE_ERR_INVALID, "dst_stride smaller than level width");
-    if (blurred) { // tiled on the device (32 x 4 px tiles): download the level's tiles and lay the rows out
+    if (blurred) { // tiled on the device: download the level's tiles and lay the rows out
         const size_t bytes = (size_t)L.blur_tx * ((L.h + 3) / 4) * 128;
         std::vector<uint8_t> t(bytes);
         HIP_TRY(ctx, hipMemcpy(t.data(), ctx->buf.blur + (size_t)image * ctx->cfg.blur_bytes + L.blur_off, bytes, hipMemcpyDeviceToHost));
         for (int y = 0; y < L.h; y++)
-            for (int x = 0; x < L.w; x += 32) {
-                const size_t off = ((size_t)(y >> 2) * L.blur_tx + (x >> 5)) * 128 + (size_t)(y & 3) * 32;
-                memcpy(dst + (size_t)y * dst_stride + x, t.data() + off, (size_t)std::min(32, L.w - x));
+            for (int x = 0; x < L.w; x += 4) { // 32 x 4 px tiles of eight 4 x 4 px blocks
+                const size_t off = ((size_t)(y >> 2) * L.blur_tx + (x >> 5)) * 128 + (size_t)((x & 31) >> 2) * 16 + (size_t)(y & 3) * 4;
+                memcpy(dst + (size_t)y * dst_stride + x, t.data() + off, (size_t)std::min(4, L.w - x));
             }
         return ORBFE_OK;
     }

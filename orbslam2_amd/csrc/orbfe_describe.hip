@@ -93,14 +93,14 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
             pr[k] = *(const uint32_t *)(base + ((unsigned)__mul24(e & 0xffu, pitch) + (e >> 8))); // one 32-bit offset: saddr + voffset
         }
     };
-    // the blurred pyramid is stored in 32 x 4 px tiles of 128 B (blur_kernel): pixel (X, Y) of a level is at
-    // ((Y >> 2) * tiles_per_row + (X >> 5)) * 128 + (Y & 3) * 32 + (X & 31)
+    // the blurred pyramid is stored in 32 x 4 px tiles of 128 B, each eight 4 x 4 px blocks of 16 B (blur_kernel): the word
+    // of pixels X .. X + 3 (X a multiple of 4) of row Y is at ((Y >> 2) * tiles_per_row + (X >> 5)) * 128 + (X & 28) * 4 + (Y & 3) * 4
     auto fetch_blr = [&](const uint8_t *base /* uniform: level origin */, int tx, int x0, int y0) {
 #pragma unroll
         for (int k = 0; k < DS_BLR_REGS; k++) {
             const unsigned e = wtab[k] >> 16;
             const unsigned Y = (unsigned)y0 + (e & 0xffu), X = (unsigned)x0 + (e >> 8);
-            pb[k] = *(const uint32_t *)(base + ((((Y >> 2) * (unsigned)tx + (X >> 5)) << 7) + ((Y & 3u) << 5) + (X & 31u)));
+            pb[k] = *(const uint32_t *)(base + ((((Y >> 2) * (unsigned)tx + (X >> 5)) << 7) + ((X & 28u) << 2) + ((Y & 3u) << 2)));
         }
     };
     // slot i of this wave: uniform keypoint data; returns false if the slot holds no keypoint

@@ -9,7 +9,7 @@
 #define ORBFE_MAX_LEVELS 16
 #define ORBFE_TAIL_MAX 3   // levels fused by pyr_tail_kernel
 #define ORBFE_TAIL_COLS 64 // extended columns of the last level per workgroup
-#define ORBFE_BLUR_ROWS 16
+#define ORBFE_BLUR_ROWS 32
 #define ORBFE_WAVE 64
 
 // Profiling cut points (tools/*_phases.sh, tools/*_insts.sh): an extra kernel argument that makes a kernel return after a
@@ -78,7 +78,7 @@ struct DeviceConfig {
     int umax[64];
     int taps[7];           // Gaussian 8.8 fixed-point taps
     size_t pyr_bytes;      // per image
-    size_t blur_bytes;     // per image: blurred pyramid, 32 x 4 px tiles of 128 B (see orbfe_pyramid.hip)
+    size_t blur_bytes;     // per image: blurred pyramid, 32 x 4 px tiles of 128 B, each eight 4 x 4 px blocks (see orbfe_pyramid.hip)
     float bf, fx, mb;
     // input pixel format (orbfe_set_input_format): 1 = CV_8UC1; 3 / 4 = interleaved colour converted by ingest with
     // cv::cvtColor's fixed-point weights for channels 0, 1, 2 (in_coef) and in_shift fraction bits

@@ -411,10 +411,10 @@ __global__ __launch_bounds__(TAIL_THREADS) void pyr_tail_kernel(DeviceConfig cfg
 // shifted tap words, keeps the row sums of the last eight rows as four row pairs and emits two 4-px
 // output words per two input rows with v_dot2_u32_u16.  No LDS, no barriers; HBM traffic = one read
 // of the level (+6/BL_ROWS row halo, L2-served) and one write.  Round 2: 872 -> 630 VALU instructions
-// per wave (13.6 -> 9.8 per pixel), 0.109 -> 0.098 ms; the first 12 % of the cut bought all of that, the
-// kernel now runs at the ~4.8 TB/s of mixed read / write traffic the memory system gives it.
+// per wave (13.6 -> 9.8 per pixel), 0.109 -> 0.098 ms (the first 12 % of the cut bought all of that:
+// the kernel then waits for memory), and whole-line 16-byte stores (tiles of 4 x 4 px blocks): -> 0.083 ms.
 // ---------------------------------------------------------------------------
-#define BL_ROWS ORBFE_BLUR_ROWS // rows per wave (even): 6 / BL_ROWS of the rows are loaded (and row-filtered) twice; 16, 24 and 32 measure the same, 8 / 64 slower
+#define BL_ROWS ORBFE_BLUR_ROWS // rows per wave (a multiple of 4): 6 / BL_ROWS of the rows are loaded (and row-filtered) twice; 32 beats 16 by 4 us now that the kernel is memory-bound (no difference while it was issue-bound)
 #define BL_COLS 256 // per wave: 64 lanes x 4 px
 __global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffers buf)
 {
@@ -429,8 +429,11 @@ __global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffe
     const int r0 = (int)(ti >> 16);
     if (x0 >= L.w || r0 >= L.h) return;
     const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + x0;
-    // output in 32 x 4 px tiles of 128 B: describe_kernel's 37-row patches then touch about half as many cache lines
-    uint8_t *dst = buf.blur + (size_t)img * cfg.blur_bytes + L.blur_off + (((unsigned)(r0 >> 2) * L.blur_tx + (x0 >> 5)) << 7) + (x0 & 31);
+    // output in 32 x 4 px tiles of 128 B (describe_kernel's 37-row patches then touch about half as many cache lines), a tile
+    // being eight 4 x 4 px blocks of 16 B: the lane's four columns of four rows are ONE 16-byte store and a wave's store
+    // instruction fills eight whole lines (one dword per row in row-major tiles meant 32-B pieces of eight lines per store:
+    // 0.097 -> 0.084 ms)
+    uint8_t *dst = buf.blur + (size_t)img * cfg.blur_bytes + L.blur_off + (((unsigned)(r0 >> 2) * L.blur_tx + (x0 >> 5)) << 7) + ((x0 & 31) << 2);
     const unsigned tile_row_bytes = (unsigned)L.blur_tx << 7;
     unsigned tw[4][3]; // tw[j][q]: taps against the bytes of word q for pixel j; byte 4 q + b meets tap 4 q + b - 1 - j
 #pragma unroll
@@ -455,6 +458,7 @@ __global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffe
     const unsigned short k4 = (unsigned short)cfg.taps[4], k5 = (unsigned short)cfg.taps[5], k6 = (unsigned short)cfg.taps[6];
     const u16x2 te[4] = {{k0, k1}, {k2, k3}, {k4, k5}, {k6, 0}}, to[4] = {{0, k0}, {k1, k2}, {k3, k4}, {k5, k6}};
     unsigned Q[4][4], he[4] = {0, 0, 0, 0};
+    uint4 og = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < BL_ROWS + 6; i++) {
         int y = r0 - 3 + i;
@@ -482,23 +486,24 @@ __global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffe
         for (int j = 0; j < 4; j++) Q[m & 3][j] = he[j] | (hn[j] << 16);
         if (m < 3) continue;
         const int a = m - 3;
+        unsigned o2[2];
 #pragma unroll
         for (int half = 0; half < 2; half++) {
-            const int orow = 2 * a + half;
-            if (r0 + orow < L.h) {
-                unsigned ob[4];
+            unsigned ob[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    unsigned acc = 32768u;
+            for (int j = 0; j < 4; j++) {
+                unsigned acc = 32768u;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, Q[(a + q) & 3][j]), half ? to[q] : te[q], acc, false);
-                    ob[j] = acc;
-                }
-                // byte 2 of the four sums -> one word: two v_perm_b32 and an or
-                const unsigned o = __builtin_amdgcn_perm(ob[1], ob[0], 0x0c0c0602u) | __builtin_amdgcn_perm(ob[3], ob[2], 0x06020c0cu);
-                *(uint32_t *)(dst + ((unsigned)(orow >> 2) * tile_row_bytes + (unsigned)((orow & 3) << 5))) = o;
+                for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, Q[(a + q) & 3][j]), half ? to[q] : te[q], acc, false);
+                ob[j] = acc;
             }
+            // byte 2 of the four sums -> one word: two v_perm_b32 and an or
+            o2[half] = __builtin_amdgcn_perm(ob[1], ob[0], 0x0c0c0602u) | __builtin_amdgcn_perm(ob[3], ob[2], 0x06020c0cu);
         }
+        if (!(a & 1)) { og.x = o2[0]; og.y = o2[1]; continue; }
+        og.z = o2[0]; og.w = o2[1];
+        // rows 2a - 2 .. 2a + 1 = one row of tiles; rows past the level in the last one are allocated and never read
+        if (r0 + 2 * a - 2 < L.h) *(uint4 *)(dst + (unsigned)(a >> 1) * tile_row_bytes) = og;
     }
 }
 
