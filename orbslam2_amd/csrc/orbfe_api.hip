@@ -240,7 +240,7 @@ static int build_config(orbfe_context *ctx)
         // the 2 px its aligned 40-byte patch rows overshoot: one spare tile column)
         L.blur_off = (int)blur_off;
         L.blur_tx = (L.w + 31) / 32 + 1;
-        blur_off += (size_t)L.blur_tx * ((L.h + 3) / 4) * 128;
+        blur_off += (size_t)L.blur_tx * ((L.h + 3) / 4 + 1) * 128; // + one tile row: describe stages 40 rows from a multiple of 4 (up to row h + 1; loaded, never used)
         if (l > 0) {
             L.rs_scale_x = 1.0 / ((double)L.w / (double)c.lv[l - 1].w);
             L.rs_scale_y = 1.0 / ((double)L.h / (double)c.lv[l - 1].h);
@@ -739,8 +739,8 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
         ctx->cfg.patch_n = (int)uv.size();
     }
     {   // the same patch as byte-dot-product weights for describe_kernel's hp == 15 path: the 31 x 31 window as 31 rows x 8
-        // four-pixel words (u = -15 .. 16), grid word s = lane + 64 k; per (k, lane): [0..3] weights (u + 16) inside the
-        // circle else 0, [4..7] weights 1 / 0, [8..11] row offset r * 40 + 4 w | (v & 0xff) << 16
+        // four-pixel words (u = -15 .. 16), grid word s = lane + 64 k; per lane 12 words: [0..3] weights (u + 16) inside the
+        // circle else 0 for k = 0..3, [4..7] weights 1 / 0, [8] the four rows' v as signed bytes (three 128-bit loads per lane)
         std::vector<uint32_t> mt(12 * 64, 0u);
         if (p.half_patch_size == 15)
             for (int k = 0; k < 4; k++)
@@ -753,9 +753,9 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
                         const int u = 4 * w + j - 15;
                         if (u >= -um && u <= um) { wu |= (uint32_t)(u + 16) << (8 * j); w1 |= 1u << (8 * j); }
                     }
-                    mt[(size_t)k * 64 + lane] = wu;
-                    mt[(size_t)(4 + k) * 64 + lane] = w1;
-                    mt[(size_t)(8 + k) * 64 + lane] = (uint32_t)(r * 40 + 4 * w) | ((uint32_t)(v & 0xff) << 16);
+                    mt[(size_t)lane * 12 + k] = wu;
+                    mt[(size_t)lane * 12 + 4 + k] = w1;
+                    mt[(size_t)lane * 12 + 8] |= (uint32_t)(v & 0xff) << (8 * k);
                 }
         uint32_t *d_mt = nullptr;
         A(d_mt, mt.size());

@@ -8,17 +8,20 @@ __device__ __attribute__((aligned(16))) const int8_t g_pattern[1024] = {
 // ---------------------------------------------------------------------------
 // orientation + descriptor + final keypoint record: one wave per keypoint slot
 // ---------------------------------------------------------------------------
-// The kernel is bound by vector-memory INSTRUCTION issue (a wave64 byte gather costs the texture
-// addresser ~16 cycles whatever it fetches), so everything is fetched as aligned dwords into LDS:
-// the block stages the two tables once, each wave stages a keypoint's 31-row raw patch (5 loads) and
-// 37-row blurred patch (6 loads), and all per-pixel / per-sample accesses become LDS byte reads.
-// A wave handles DS_KPW consecutive keypoint slots: the table staging and the slot bookkeeping are paid
-// once per 4 * DS_KPW keypoints, and the patch words of keypoint i+1 are fetched into registers while
-// keypoint i is computed from LDS, so the global-load latency is off the critical path.
-#define DS_PATCH_W 40 // bytes per staged patch row (10 words: covers 31+3 / 37+3 px at any alignment)
+// The kernel is bound by vector-memory INSTRUCTION issue: the texture addresser spends >= 16 cycles on a wave64 load
+// whatever its width (TA busy 73 % with twelve dword loads per keypoint), so a keypoint's patches are fetched with THREE
+// 128-bit loads and all per-pixel / per-sample accesses are LDS reads:
+//   raw patch (IC_Angle, hp == 15): 31 rows x 32 bytes from column cx - 15 (unaligned 16-byte loads are fine on this memory
+//     system): lane = (row, half), one load for the whole patch, stored lane-linear (row pitch 32 B = the 31 x 8 word grid of
+//     the moment weights, no byte alignment step);
+//   blurred patch (descriptor): 40 rows from a row that is a multiple of 4 = ten tile rows, in each of which the patch's ten
+//     4 x 4 px blocks are 160 contiguous bytes (blur_kernel's layout): lane = (tile row, block), two loads.
+// A wave handles DS_KPW consecutive keypoint slots: the table staging and the slot bookkeeping are paid once per 4 * DS_KPW
+// keypoints, and the patch of keypoint i+1 is fetched into registers while keypoint i is computed from LDS.
+#define DS_PATCH_W 40 // bytes per staged row of the blurred patch (10 words: 37 + 3 px at any alignment) and of the generic raw patch
+#define DS_RAW_W 32   // bytes per staged row of the raw patch, hp == 15
 #define DS_KPW 4      // keypoint slots per wave
-#define DS_RAW_REGS 5 // prefetch registers for the raw patch (raw_rows * 10 words <= 320, i.e. half_patch <= 15)
-#define DS_BLR_REGS 6 // 37 rows * 10 words = 370 words
+#define DS_BLR_ROWS 40 // blurred patch rows staged: the 37 the descriptor can reach, from a row that is a multiple of 4
 
 
 __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int stereo ORBFE_CUT_PARAM)
@@ -36,7 +39,6 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
     const int slot0 = blk * (4 * DS_KPW) + wave * DS_KPW;
     const int hp = cfg.half_patch;
     const int raw_rows = 2 * hp + 1;
-    const int raw_words = raw_rows * (DS_PATCH_W / 4);
     const int *sel_cnt = buf.sel_cnt + (size_t)img * cfg.nlevels;
     if (blk == 0 && tid == 0) {
         int tot = 0;
@@ -46,9 +48,12 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
     // block-shared tables: patch offsets (patch_n shorts) | pattern (256 words)
     int16_t *s_uv = (int16_t *)s_dm;
     int *s_pat = (int *)(s_dm + ((cfg.patch_n * 2 + 15) & ~15));
-    uint8_t *s_raw = (uint8_t *)(s_pat + 256) + wave * ((raw_rows + 37) * DS_PATCH_W);
-    uint8_t *s_blr = s_raw + raw_rows * DS_PATCH_W;
-    for (int i = tid; i < cfg.patch_n / 2; i += 256) ((int *)s_uv)[i] = ((const int *)buf.patch_uv)[i];
+    const bool dot_moments = hp == 15; // the reference's HALF_PATCH_SIZE: raw patch by one 128-bit load, moments by byte dot products
+    const int raw_bytes = dot_moments ? 32 * DS_RAW_W : ((raw_rows * DS_PATCH_W + 15) & ~15);
+    uint8_t *s_raw = (uint8_t *)(s_pat + 256) + wave * (raw_bytes + DS_BLR_ROWS * DS_PATCH_W);
+    uint8_t *s_blr = s_raw + raw_bytes;
+    if (cfg.half_patch != 15) // the offset list is only read by the generic moment loop
+        for (int i = tid; i < cfg.patch_n / 2; i += 256) ((int *)s_uv)[i] = ((const int *)buf.patch_uv)[i];
     s_pat[tid] = ((const int *)g_pattern)[tid];
     // per-wave slot data, one slot per lane (lanes < DS_KPW), issued before the barrier
     const int my_slot = slot0 + (lane < DS_KPW ? lane : 0);
@@ -67,41 +72,28 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
     const int excl = inc - c_l; // keypoints of the lower levels
     if (ORBFE_CUT(1)) return;
 
-    const int r0 = lane / (DS_PATCH_W / 4), c0 = lane - r0 * (DS_PATCH_W / 4);
-    const bool raw_in_regs = raw_words <= 64 * DS_RAW_REGS;
-    uint32_t pr[DS_RAW_REGS], pb[DS_BLR_REGS];
-    // Word i = lane + 64*k of a staged patch is (row i / 10, word i % 10).  The (row, 4 * word) pairs of this lane's words are
-    // computed once per wave and packed two per register (raw | blurred << 16, each row | 4 * word << 8); a patch word is then
-    // one mad away from a wave-uniform base address (scalar registers), instead of 64-bit per-lane pointer stepping with
-    // per-load predication -- that bookkeeping used to be 40 % of the kernel's VALU instructions.  Words past the end of a
-    // patch repeat its last word (same value to the same LDS slot), so nothing is predicated.
-    const int blr_words = 37 * (DS_PATCH_W / 4);
-    uint32_t wtab[DS_BLR_REGS];
+    const int r0 = lane / (DS_PATCH_W / 4), c0 = lane - r0 * (DS_PATCH_W / 4); // generic raw path
+    uint4 pr = {0u, 0u, 0u, 0u}, pb[2];
+    // per-lane constants.  Raw: row (lanes 62, 63 repeat row 30: same bytes to LDS words the moment weights ignore) and 16 * half.
+    // Blurred, k = 0, 1: block i = lane + 64 k of the 10 x 10 grid (i >= 100 repeats block 99: same value to the same place)
+    // as tile row | 16 * block << 8 | LDS byte offset of the block's first row (tile row * 160 + 4 * block) << 16.
+    const int raw_row = (lane >> 1) < raw_rows ? (lane >> 1) : raw_rows - 1, raw_h16 = (lane & 1) << 4;
+    uint32_t wb[2];
 #pragma unroll
-    for (int k = 0; k < DS_BLR_REGS; k++) {
-        const int i = lane + 64 * k;
-        const int ir = i < raw_words ? i : raw_words - 1, ib = i < blr_words ? i : blr_words - 1;
-        const int rr = (ir * 6554) >> 16, rb = (ib * 6554) >> 16; // / 10 for i < 16384
-        wtab[k] = (uint32_t)(rr | ((4 * (ir - 10 * rr)) << 8)) | ((uint32_t)(rb | ((4 * (ib - 10 * rb)) << 8)) << 16);
+    for (int k = 0; k < 2; k++) {
+        const int i = lane + 64 * k < 100 ? lane + 64 * k : 99;
+        const int tr = (i * 6554) >> 16, bl = i - 10 * tr; // / 10
+        wb[k] = (uint32_t)tr | ((uint32_t)(16 * bl) << 8) | ((uint32_t)(tr * 4 * DS_PATCH_W + 4 * bl) << 16);
     }
-    const int lds_last_raw = 4 * (lane + 64 * (DS_RAW_REGS - 1) < raw_words ? lane + 64 * (DS_RAW_REGS - 1) : raw_words - 1);
-    const int lds_last_blr = 4 * (lane + 64 * (DS_BLR_REGS - 1) < blr_words ? lane + 64 * (DS_BLR_REGS - 1) : blr_words - 1);
-    auto fetch_raw = [&](const uint8_t *base /* uniform: patch origin */, int pitch) {
-#pragma unroll
-        for (int k = 0; k < DS_RAW_REGS; k++) {
-            const unsigned e = wtab[k] & 0xffffu;
-            pr[k] = *(const uint32_t *)(base + ((unsigned)__mul24(e & 0xffu, pitch) + (e >> 8))); // one 32-bit offset: saddr + voffset
-        }
+    auto fetch_raw = [&](const uint8_t *base /* uniform: pixel (cx - 15, cy - 15) */, int pitch) {
+        __builtin_memcpy(&pr, base + (unsigned)(__mul24(raw_row, pitch) + raw_h16), 16); // 16 bytes at any alignment: one global_load_dwordx4
     };
-    // the blurred pyramid is stored in 32 x 4 px tiles of 128 B, each eight 4 x 4 px blocks of 16 B (blur_kernel): the word
-    // of pixels X .. X + 3 (X a multiple of 4) of row Y is at ((Y >> 2) * tiles_per_row + (X >> 5)) * 128 + (X & 28) * 4 + (Y & 3) * 4
-    auto fetch_blr = [&](const uint8_t *base /* uniform: level origin */, int tx, int x0, int y0) {
+    // the blurred pyramid is stored in 32 x 4 px tiles of 128 B, each eight 4 x 4 px blocks of 16 B (blur_kernel): the block
+    // of pixels X .. X + 3 (X a multiple of 4) x rows 4 T .. 4 T + 3 is at T * tile_row_bytes + 4 * X, its rows 4 bytes apart
+    auto fetch_blr = [&](const uint8_t *base /* uniform: block (x0, y0 >> 2) of the level */, unsigned tile_row_bytes) {
 #pragma unroll
-        for (int k = 0; k < DS_BLR_REGS; k++) {
-            const unsigned e = wtab[k] >> 16;
-            const unsigned Y = (unsigned)y0 + (e & 0xffu), X = (unsigned)x0 + (e >> 8);
-            pb[k] = *(const uint32_t *)(base + ((((Y >> 2) * (unsigned)tx + (X >> 5)) << 7) + ((X & 28u) << 2) + ((Y & 3u) << 2)));
-        }
+        for (int k = 0; k < 2; k++)
+            pb[k] = *(const uint4 *)(base + (__umul24(wb[k] & 0xffu, tile_row_bytes) + ((wb[k] >> 8) & 0xffu)));
     };
     // slot i of this wave: uniform keypoint data; returns false if the slot holds no keypoint
     int level = 0, cx = 0, cy = 0, score = 0, out = 0;
@@ -120,14 +112,15 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
     auto prefetch_raw = [&](int i) -> bool {
         if (i >= DS_KPW || !slot_data(i)) return false;
         const LevelInfo &L = cfg.lv[level];
-        if (raw_in_regs)
-            fetch_raw(buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (ptrdiff_t)(cy - hp) * L.pitch + ((cx - hp) & ~3), L.pitch);
+        if (dot_moments)
+            fetch_raw(buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (ptrdiff_t)(cy - hp) * L.pitch + (cx - hp), L.pitch);
         return true;
     };
     auto prefetch_blur = [&](int i) -> bool {
         if (i >= DS_KPW || !slot_data(i)) return false;
         const LevelInfo &L = cfg.lv[level];
-        fetch_blr(buf.blur + (size_t)img * cfg.blur_bytes + L.blur_off, L.blur_tx, (cx - 18) & ~3, cy - 18);
+        const unsigned trb = (unsigned)L.blur_tx << 7;
+        fetch_blr(buf.blur + (size_t)img * cfg.blur_bytes + L.blur_off + (size_t)((cy - 18) >> 2) * trb + 4 * ((cx - 18) & ~3), trb);
         return true;
     };
 
@@ -136,22 +129,19 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
     // instructions, part of them double precision, would otherwise be repeated per keypoint by all 64 lanes);
     // pass 2: blurred patches -> descriptors and keypoint records.
     int m10_l = 0, m01_l = 0;
-    // hp == 15 (the reference's HALF_PATCH_SIZE): the 31 x 31 patch is read as 31 rows x 8 four-pixel words (u = -15 .. 16),
+    // hp == 15 (the reference's HALF_PATCH_SIZE): the 31 x 31 patch is 31 rows x 8 four-pixel words (u = -15 .. 16) in LDS,
     // word s = lane + 64 k of that grid per lane, and the moments come from byte dot products against per-lane constant
     // weight words: m10 = sum (u + 16) I - 16 sum I, m01 = sum_rows v * (row sum I), the circle mask folded into the weights
     // (0 outside |u| <= umax[|v|]).  Integer sums: the order does not matter, the result is IC_Angle's exactly.
-    const bool dot_moments = hp == 15;
     uint32_t mw_u[4] = {0, 0, 0, 0}, mw_1[4] = {0, 0, 0, 0};
-    int mw_v[4] = {0, 0, 0, 0}, mw_off[4] = {0, 0, 0, 0};
-    if (dot_moments) { // host-built per-lane constants (orbfe_api.hip): 12 coalesced loads per wave
+    int mw_v[4] = {0, 0, 0, 0};
+    if (dot_moments) { // host-built per-lane constants (orbfe_api.hip), 48 bytes per lane: three 128-bit loads per wave
+        const uint4 *mt = (const uint4 *)buf.mom_tab + 3 * lane;
+        const uint4 a = mt[0], b = mt[1], c = mt[2];
+        mw_u[0] = a.x; mw_u[1] = a.y; mw_u[2] = a.z; mw_u[3] = a.w;
+        mw_1[0] = b.x; mw_1[1] = b.y; mw_1[2] = b.z; mw_1[3] = b.w;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            mw_u[k] = buf.mom_tab[k * 64 + lane];
-            mw_1[k] = buf.mom_tab[(4 + k) * 64 + lane];
-            const uint32_t e = buf.mom_tab[(8 + k) * 64 + lane];
-            mw_off[k] = (int)(e & 0xffffu);
-            mw_v[k] = (int)(int8_t)(e >> 16);
-        }
+        for (int k = 0; k < 4; k++) mw_v[k] = (int)(int8_t)(c.x >> (8 * k));
     }
     bool have = prefetch_raw(0);
     for (int i = 0; i < DS_KPW; i++) {
@@ -160,17 +150,14 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
         if (cur) {
             slot_data(i);
             kx = cx; ky = cy; lv = level;
-            if (raw_in_regs) {
-#pragma unroll
-                for (int k = 0; k < DS_RAW_REGS - 1; k++) ((uint32_t *)s_raw)[lane + 64 * k] = pr[k];
-                *(uint32_t *)(s_raw + lds_last_raw) = pr[DS_RAW_REGS - 1];
-            }
-            if (!raw_in_regs) { // big patches: straight through (no prefetch)
+            if (dot_moments) {
+                ((uint4 *)s_raw)[lane] = pr;
+            } else { // other patch sizes: aligned words straight through (no prefetch), row pitch DS_PATCH_W
                 const LevelInfo &Lr = cfg.lv[lv];
                 const uint8_t *gp = buf.pyr + (size_t)img * cfg.pyr_bytes + Lr.pyr_off + (ptrdiff_t)__mul24(ky - hp + r0, Lr.pitch) + ((kx - hp) & ~3) + 4 * c0;
                 const int step = 6 * Lr.pitch + 16, wrap = Lr.pitch - DS_PATCH_W;
                 int c = c0;
-                for (int w = lane; w < raw_words; w += 64) {
+                for (int w = lane; w < raw_rows * (DS_PATCH_W / 4); w += 64) {
                     ((uint32_t *)s_raw)[w] = *(const uint32_t *)gp;
                     gp += step; c += 4;
                     if (c >= DS_PATCH_W / 4) { c -= DS_PATCH_W / 4; gp += wrap; }
@@ -186,13 +173,11 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
         const int xr = (kx - hp) & ~3;
         int m10 = 0, m01 = 0;
         if (dot_moments) {
-            const unsigned a = (unsigned)(kx - hp - xr); // byte of u = -15 inside its aligned word (wave-uniform)
             unsigned acc_u = 0;
             int acc_1 = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t lo = *(const uint32_t *)(s_raw + mw_off[k]), hi = *(const uint32_t *)(s_raw + mw_off[k] + 4);
-                const uint32_t px = __builtin_amdgcn_alignbyte(hi, lo, a);
+                const uint32_t px = ((const uint32_t *)s_raw)[lane + 64 * k];
                 acc_u = __builtin_amdgcn_udot4(px, mw_u[k], acc_u, false);
                 const int t = (int)__builtin_amdgcn_udot4(px, mw_1[k], 0u, false);
                 acc_1 += t;
@@ -228,8 +213,10 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
             slot_data(i);
             lv = level; kx = cx; ky = cy; ksc = score; kout = out;
 #pragma unroll
-            for (int k = 0; k < DS_BLR_REGS - 1; k++) ((uint32_t *)s_blr)[lane + 64 * k] = pb[k];
-            *(uint32_t *)(s_blr + lds_last_blr) = pb[DS_BLR_REGS - 1];
+            for (int k = 0; k < 2; k++) { // the block's four rows, one LDS row apart
+                uint32_t *d = (uint32_t *)(s_blr + (wb[k] >> 16));
+                d[0] = pb[k].x; d[DS_PATCH_W / 4] = pb[k].y; d[2 * (DS_PATCH_W / 4)] = pb[k].z; d[3 * (DS_PATCH_W / 4)] = pb[k].w;
+            }
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
@@ -243,7 +230,7 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
         if (ORBFE_CUT(3)) { if (lane == 0) buf.depth[(size_t)img * cfg.sel_total + kout] = angle; continue; }
 
         // computeOrbDescriptor (src/ORBextractor.cc:103-142)
-        const uint8_t *center = s_blr + 18 * DS_PATCH_W + (kx - xb);
+        const uint8_t *center = s_blr + (18 + ((ky - 18) & 3)) * DS_PATCH_W + (kx - xb);
         unsigned long long *dout = (unsigned long long *)(buf.desc + ((size_t)img * cfg.sel_total + kout) * 32);
         unsigned long long bits[4];
 #pragma unroll
@@ -311,6 +298,7 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
 void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool stereo, hipStream_t s)
 {
     dim3 grid(xcd_grid((cfg.sel_total + 4 * DS_KPW - 1) / (4 * DS_KPW), n_images));
-    const size_t lds = ((cfg.patch_n * 2 + 15) & ~15) + 256 * 4 + (size_t)4 * (2 * cfg.half_patch + 1 + 37) * DS_PATCH_W;
+    const size_t raw_bytes = cfg.half_patch == 15 ? 32 * DS_RAW_W : (((2 * cfg.half_patch + 1) * DS_PATCH_W + 15) & ~15);
+    const size_t lds = ((cfg.patch_n * 2 + 15) & ~15) + 256 * 4 + 4 * (raw_bytes + DS_BLR_ROWS * DS_PATCH_W);
     hipLaunchKernelGGL(describe_kernel, grid, dim3(256), lds, s, cfg, buf, n_images, stereo ? 1 : 0 ORBFE_CUT_ARG("ORBFE_DESC_DBG"));
 }

@@ -139,7 +139,7 @@ struct DeviceBuffers {
     long long *dbg_ts;   // 4096 timestamps for kernel bring-up (ORBFE_OT2_STOP=99); never read by product code
     const uint8_t *slot_level; // [sel_total] level of every keypoint slot
     const int16_t *patch_uv; // IC_Angle patch offsets: (u & 0xff) | (v << 8), padded with (0,0)
-    const uint32_t *mom_tab; // [12][64] byte-dot-product weights of the same patch (hp == 15), see orbfe_api.hip
+    const uint32_t *mom_tab; // [64 lanes][12] byte-dot-product weights of the same patch (hp == 15), see orbfe_api.hip
 };
 
 // Quadtree buckets (orbfe_octree3.hip).  A candidate's bucket = its root and quadrant path down to depth 5; the
