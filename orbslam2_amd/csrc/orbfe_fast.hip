@@ -177,44 +177,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     int fq[4];
     for (int attempt = 0; attempt < 2; attempt++) {
     n2 = 0;
-    if (wpr <= 16) {
-        // tile rows of at most 16 words (cells up to ~55 px): a wave-load covers 4 rows x 16 words; lanes beyond the row /
-        // the last row repeat the last valid element (same value to the same LDS word), so nothing is predicated
-        const int c4 = 4 * ((lane & 15) < wpr ? (lane & 15) : wpr - 1);
-        const int rr = lane >> 4;
-        const int nu = (th + 3) >> 2;
-        for (int u0 = 0; u0 < nu; u0 += 4) { // 4 loads in flight per lane
-            uint32_t v[4];
-            int dst[4];
+    {
+        // 16-byte chunks (unaligned 128-bit loads are fine on this memory system; the LDS side is aligned: the tile pitch is a
+        // multiple of 16): lane = (row of the pass, chunk), 64 / cpr rows per load instruction -- two loads for a 37-row tile
+        // of three chunks instead of twelve dword loads.  Lanes beyond the last whole row of a pass and rows beyond the tile
+        // repeat an element (same value to the same LDS bytes), so nothing is predicated.  The last chunk of a row may read up
+        // to 15 bytes past the tile (inside the pyramid row's margin) into LDS bytes no pixel test uses.
+        const int cpr = (wpr + 3) >> 2;
+        const int rpi = small_div(64, cpr);
+        int rl0 = small_div(lane, cpr);
+        rl0 = rl0 < rpi ? rl0 : rpi - 1;
+        const int ch16 = (lane - rl0 * cpr < cpr ? lane - rl0 * cpr : 0) << 4;
+        for (int rb = 0; rb < th; rb += 2 * rpi) { // two loads in flight per lane
+            uint4 v[2];
+            int dst[2];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                int r = rr + 4 * (u0 + u);
+            for (int u = 0; u < 2; u++) {
+                int r = rb + u * rpi + rl0;
                 r = r < th ? r : th - 1;
-                dst[u] = __mul24(r, tile_pitch) + c4;
-                v[u] = *(const uint32_t *)(src + (unsigned)(__mul24(r, L.pitch) + c4));
+                dst[u] = __mul24(r, tile_pitch) + ch16;
+                __builtin_memcpy(&v[u], src + (unsigned)(__mul24(r, L.pitch) + ch16), 16);
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) *(uint32_t *)(s_tile + dst[u]) = v[u];
-        }
-    } else {
-        // (row, word) of element i = lane, advanced by 64 per step; 32-bit offsets only (64-bit multiplies and a
-        // per-element division cost more VALU issue than the copy itself)
-        int r = small_div(lane, wpr), c = lane - r * wpr;
-        const int dr = 64 / wpr, dc = 64 - dr * wpr;
-        const int nw = th * wpr;
-        for (int i0 = lane; i0 < nw; i0 += 256) {
-            uint32_t v[4];
-            int dst[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                dst[u] = __mul24(r, tile_pitch) + 4 * c;
-                if (i0 + 64 * u < nw) v[u] = *(const uint32_t *)(src + (unsigned)(__mul24(r, L.pitch) + 4 * c));
-                c += dc; r += dr;
-                if (c >= wpr) { c -= wpr; r++; }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (i0 + 64 * u < nw) *(uint32_t *)(s_tile + dst[u]) = v[u];
+            for (int u = 0; u < 2; u++) *(uint4 *)(s_tile + dst[u]) = v[u];
         }
     }
     for (int i = lane; i < sc_bytes / 16; i += 64) ((uint4 *)s_sc)[i] = make_uint4(0u, 0u, 0u, 0u); // sc_bytes is a multiple of 16
@@ -500,7 +485,7 @@ static inline int max_cell_h(const DeviceConfig &cfg) { int m = 0; for (int l = 
 void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool buckets, hipStream_t s)
 {
     const int mw = max_cell_w(cfg), mh = max_cell_h(cfg);
-    const int tile_pitch = (mw + 6 + 3 + 3 + 3) & ~3; // + alignment slack on both sides
+    const int tile_pitch = (mw + 6 + 15) & ~15; // whole 16-byte chunks (the staging stores 128 bits at a time)
     const int tile_rows = mh + 6;
     const int tile_bytes = (tile_pitch * tile_rows + 15) & ~15;
     const int sc_bytes = ((mw + 2) * (mh + 2) + 15) & ~15;
@@ -517,11 +502,8 @@ void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_
         else hipLaunchKernelGGL((fast_cell_kernel<TP, false>), grid, dim3(256), lds, s, cfg, buf, n_images, tile_pitch, tile_region, sc_bytes, q_bytes, lds_per_wave ORBFE_CUT_ARG("ORBFE_FAST_DBG")); \
     } while (0)
     switch (tile_pitch) {
-    case 44: FAST_LAUNCH(44); break;
+    case 32: FAST_LAUNCH(32); break;
     case 48: FAST_LAUNCH(48); break;
-    case 52: FAST_LAUNCH(52); break;
-    case 56: FAST_LAUNCH(56); break;
-    case 60: FAST_LAUNCH(60); break;
     case 64: FAST_LAUNCH(64); break;
     default: FAST_LAUNCH(0); break;
     }
