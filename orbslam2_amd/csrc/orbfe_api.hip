@@ -468,7 +468,8 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
             for (int l = 1; l < p.nlevels; l++) {
                 LevelInfo &D = ctx->cfg.lv[l];
                 const int src_words = (ctx->cfg.lv[l - 1].w + 3) / 4, ny = D.h + 6;
-                D.rs_rw = (size_t)D.rs_src_rows[0] * src_words * 4 <= 60 * 1024 ? 4 : ((size_t)D.rs_src_rows[1] * src_words * 4 <= 60 * 1024 ? 2 : 1);
+                const size_t rowp = ((size_t)src_words * 4 + 15) & ~(size_t)15; // staged row pitch (pyr_resize_kernel)
+                D.rs_rw = D.rs_src_rows[0] * rowp <= 60 * 1024 ? 4 : (D.rs_src_rows[1] * rowp <= 60 * 1024 ? 2 : 1);
                 D.rs_blk_off = (int)blk.size();
                 const int rows = 4 * D.rs_rw;
                 for (int y0 = 0; y0 < ny; y0 += rows) {

@@ -173,3 +173,11 @@ __device__ __forceinline__ int hamming256(const uint32_t *a, const uint32_t *b)
     return d;
 }
 
+// 16 bytes from an address that is only 4-byte aligned: one global_load_dwordx4 (fine on this memory system).  A plain struct
+// load rather than __builtin_memcpy into an array element, which demotes the array to scratch memory.
+struct __attribute__((packed, aligned(4))) orbfe_u4_unaligned { uint32_t x, y, z, w; };
+__device__ __forceinline__ uint4 load16_unaligned(const uint8_t *p)
+{
+    const orbfe_u4_unaligned t = *(const orbfe_u4_unaligned *)p;
+    return make_uint4(t.x, t.y, t.z, t.w);
+}

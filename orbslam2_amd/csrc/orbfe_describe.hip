@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
         wb[k] = (uint32_t)tr | ((uint32_t)(16 * bl) << 8) | ((uint32_t)(tr * 4 * DS_PATCH_W + 4 * bl) << 16);
     }
     auto fetch_raw = [&](const uint8_t *base /* uniform: pixel (cx - 15, cy - 15) */, int pitch) {
-        __builtin_memcpy(&pr, base + (unsigned)(__mul24(raw_row, pitch) + raw_h16), 16); // 16 bytes at any alignment: one global_load_dwordx4
+        pr = load16_unaligned(base + (unsigned)(__mul24(raw_row, pitch) + raw_h16)); // 16 bytes at any alignment: one global_load_dwordx4
     };
     // the blurred pyramid is stored in 32 x 4 px tiles of 128 B, each eight 4 x 4 px blocks of 16 B (blur_kernel): the block
     // of pixels X .. X + 3 (X a multiple of 4) x rows 4 T .. 4 T + 3 is at T * tile_row_bytes + 4 * X, its rows 4 bytes apart

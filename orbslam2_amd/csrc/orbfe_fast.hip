@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                 int r = rb + u * rpi + rl0;
                 r = r < th ? r : th - 1;
                 dst[u] = __mul24(r, tile_pitch) + ch16;
-                __builtin_memcpy(&v[u], src + (unsigned)(__mul24(r, L.pitch) + ch16), 16);
+                v[u] = load16_unaligned(src + (unsigned)(__mul24(r, L.pitch) + ch16));
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) *(uint4 *)(s_tile + dst[u]) = v[u];

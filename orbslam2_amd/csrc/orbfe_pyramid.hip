@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(DeviceConfig cfg, Devic
     const uint32_t *yt = buf.rs_tab + D.rs_ytab_off;
     const int total_rows = D.h + 2 * PYR_MY;
     const int nrows = (total_rows - y0) < 4 * RW ? (total_rows - y0) : 4 * RW;
-    const int row_bytes = src_words * 4;
+    const int row_bytes = (src_words * 4 + 15) & ~15; // staged row pitch
     // table entries this wave needs after the barrier, requested now so that their latency overlaps the staging:
     // the vertical entries of its rows (uniform) and the column entries of its first pass
     const int nwords = (D.w + 12 + 3) >> 2; // extended row in 4-px words
@@ -184,23 +184,27 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(DeviceConfig cfg, Devic
     int n_src = smax - smin + 1;
     if (n_src > max_src_rows) n_src = max_src_rows; // cannot happen: the host sized max_src_rows from the same table
     {
-        int r = small_div(tid, src_words), c = tid - r * src_words;
-        const int dr = 256 / src_words, dc = 256 - dr * src_words;
+        // 16-byte chunks, four in flight per thread: unaligned 128-bit loads (a source row starts 4 bytes into its 64-byte aligned
+        // pitch), aligned 128-bit LDS stores (row pitch rounded up to 16; the last chunk of a row reads up to 12 bytes of the
+        // right margin that no table entry points at)
+        const int cpr = row_bytes >> 4;
+        int r = small_div(tid, cpr), c = tid - r * cpr;
+        const int dr = small_div(256, cpr), dc = 256 - dr * cpr;
         const uint8_t *sp = src + (size_t)smin * S.pitch;
-        const int nw = n_src * src_words;
-        for (int i0 = tid; i0 < nw; i0 += 1024) { // 4 loads in flight per thread
-            uint32_t v[4];
+        const int nc = n_src * cpr;
+        for (int i0 = tid; i0 < nc; i0 += 1024) {
+            uint4 v[4];
             int di[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                di[u] = __mul24(r, src_words) + c;
-                if (i0 + 256 * u < nw) v[u] = *(const uint32_t *)(sp + (unsigned)(__mul24(r, S.pitch) + 4 * c));
+                const int rr = r < n_src ? r : n_src - 1; // past the block: repeat a chunk of its last row (same bytes, same place)
+                di[u] = __mul24(rr, row_bytes) + 16 * c;
+                v[u] = load16_unaligned(sp + (unsigned)(__mul24(rr, S.pitch) + 16 * c));
                 c += dc; r += dr;
-                if (c >= src_words) { c -= src_words; r++; }
+                if (c >= cpr) { c -= cpr; r++; }
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (i0 + 256 * u < nw) ((uint32_t *)s_src)[di[u]] = v[u];
+            for (int u = 0; u < 4; u++) *(uint4 *)(s_src + di[u]) = v[u];
         }
     }
     __syncthreads();
@@ -311,28 +315,38 @@ __global__ __launch_bounds__(TAIL_THREADS) void pyr_tail_kernel(DeviceConfig cfg
         for (int i = tid; i < 2 * D.rs_ytab_n; i += TAIL_THREADS) d[i] = g[i];
     }
     // the strip's columns of level F - 1, every row (interior pixels, 4-aligned start); this copy is the kernel's longest
-    // dependent chain, so eight loads per thread are in flight
+    // dependent chain
     const int src_x0 = plan[2], src_words = plan[3];
     {
         const LevelInfo &S = cfg.lv[F - 1];
         const uint8_t *sp = pyr + S.pyr_off + src_x0;
         uint32_t *d = (uint32_t *)(s_tail + cfg.tail_lds_src);
-        int r = small_div(tid, src_words), c = tid - r * src_words;
-        const int dr = TAIL_THREADS / src_words, dc = TAIL_THREADS - dr * src_words;
-        const int nw = S.h * src_words;
-        for (int i0 = tid; i0 < nw; i0 += 8 * TAIL_THREADS) {
-            uint32_t v[8];
-            int di[8];
+        // 16-byte chunks of a row (unaligned 128-bit loads), four in flight per thread; the LDS rows keep their pitch of
+        // src_words words, so a chunk is stored as up to four words (the last chunk of a row may be partial)
+        const int cpr = (src_words + 3) >> 2;
+        int r = small_div(tid, cpr), c = tid - r * cpr;
+        const int dr = small_div(TAIL_THREADS, cpr), dc = TAIL_THREADS - dr * cpr;
+        const int nc = S.h * cpr;
+        for (int i0 = tid; i0 < nc; i0 += 4 * TAIL_THREADS) {
+            uint4 v[4];
+            int di[4], left[4]; // first word of the chunk in LDS, words up to the row's end
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                di[u] = __mul24(r, src_words) + c;
-                if (i0 + TAIL_THREADS * u < nw) v[u] = *(const uint32_t *)(sp + (unsigned)(__mul24(r, S.pitch) + 4 * c));
+            for (int u = 0; u < 4; u++) {
+                const int rr = r < S.h ? r : S.h - 1; // past the level: repeat a chunk of its last row (same words, same place)
+                left[u] = src_words - 4 * c;
+                di[u] = __mul24(rr, src_words) + 4 * c;
+                v[u] = load16_unaligned(sp + (unsigned)(__mul24(rr, S.pitch) + 16 * c));
                 c += dc; r += dr;
-                if (c >= src_words) { c -= src_words; r++; }
+                if (c >= cpr) { c -= cpr; r++; }
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (i0 + TAIL_THREADS * u < nw) d[di[u]] = v[u];
+            for (int u = 0; u < 4; u++)
+            {
+                d[di[u]] = v[u].x;
+                if (left[u] > 1) d[di[u] + 1] = v[u].y;
+                if (left[u] > 2) d[di[u] + 2] = v[u].z;
+                if (left[u] > 3) d[di[u] + 3] = v[u].w;
+            }
         }
     }
     __syncthreads();
@@ -529,18 +543,19 @@ void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int
     for (int l = 1; l <= last_single; l++) {
         const int src_words = (cfg.lv[l - 1].w + 3) / 4; // interior pixels of the source row (4-aligned start)
         const int total_rows = cfg.lv[l].h + 2 * PYR_MY;
+        const size_t rowp = ((size_t)src_words * 4 + 15) & ~(size_t)15; // staged row pitch
         // rows per wave: the largest of 4, 2, 1 whose staged source rows fit 60 KB of LDS (rs_src_rows[i] = source
         // row span of the worst block of 16 / 8 / 4 output rows, from the host's row table)
         const int *span = cfg.lv[l].rs_src_rows;
         if (cfg.lv[l].rs_rw == 4) {
             dim3 grid((total_rows + 15) / 16, n_images);
-            hipLaunchKernelGGL(pyr_resize_kernel<4>, grid, dim3(256), (size_t)span[0] * src_words * 4, s, cfg, buf, l, src_words, span[0]);
+            hipLaunchKernelGGL(pyr_resize_kernel<4>, grid, dim3(256), (size_t)span[0] * rowp, s, cfg, buf, l, src_words, span[0]);
         } else if (cfg.lv[l].rs_rw == 2) {
             dim3 grid((total_rows + 7) / 8, n_images);
-            hipLaunchKernelGGL(pyr_resize_kernel<2>, grid, dim3(256), (size_t)span[1] * src_words * 4, s, cfg, buf, l, src_words, span[1]);
+            hipLaunchKernelGGL(pyr_resize_kernel<2>, grid, dim3(256), (size_t)span[1] * rowp, s, cfg, buf, l, src_words, span[1]);
         } else {
             dim3 grid((total_rows + 3) / 4, n_images);
-            hipLaunchKernelGGL(pyr_resize_kernel<1>, grid, dim3(256), (size_t)span[2] * src_words * 4, s, cfg, buf, l, src_words, span[2]);
+            hipLaunchKernelGGL(pyr_resize_kernel<1>, grid, dim3(256), (size_t)span[2] * rowp, s, cfg, buf, l, src_words, span[2]);
         }
     }
     if (cfg.tail_first) {
