@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(DeviceConfig cfg, DeviceBuf
 // ingest of packed CV_8UC1 images without rectification (the stereo / mono path of the benchmark): a plain copy with margins, so
 // a thread moves 16 pixels of one extended row (one unaligned 128-bit load, one aligned 128-bit store) instead of 4; the
 // (row, chunk) pairs of an 8-row band are dealt to the threads flat, because an extended row is rarely a multiple of 64 chunks
-// (79 for KITTI's 1241 columns).  Only the chunks that touch the left / right margin gather reflected bytes.
+// (79 for KITTI's 1241 columns).  The chunks that touch the left / right margin gather reflected bytes, in a loop of their own.
 #define ING16_ROWS 8
 __global__ __launch_bounds__(256) void ingest16_kernel(DeviceConfig cfg, DeviceBuffers buf, const uint8_t *__restrict__ src)
 {
@@ -111,28 +111,38 @@ __global__ __launch_bounds__(256) void ingest16_kernel(DeviceConfig cfg, DeviceB
     const int y_first = (int)blockIdx.x * ING16_ROWS - PYR_MY;
     int rows = L.h + PYR_MY - y_first;
     rows = rows < ING16_ROWS ? rows : ING16_ROWS;
-    const int n = rows * cpr;
     const uint8_t *simg = src + (size_t)img * L.h * L.w;
     uint8_t *dimg = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int r = small_div(i, cpr), c = i - r * cpr;
+    // interior chunks (all 16 bytes inside the image row): plain copies.  Kept apart from the few chunks that touch a margin:
+    // dealt flat together, nearly every wave held one of those and ran their 16-byte-load gather path for all its lanes
+    // (38 load instructions per wave instead of 3).
+    const int c_hi_ = (L.w - 11 + 15) >> 4;           // first chunk that reaches past the row's last pixel (x0 + 15 >= w)
+    const int c_hi = c_hi_ < 1 ? 1 : (c_hi_ > cpr ? cpr : c_hi_);
+    const int ci = c_hi - 1;                          // interior chunks 1 .. c_hi - 1 per row
+    if (ci > 0) {
+        const int ni = rows * ci;
+        for (int i = threadIdx.x; i < ni; i += 256) {
+            const int r = small_div(i, ci), c = 1 + i - r * ci;
+            const int y = y_first + r, x0 = c * 16 - PYR_MX;
+            const uint4 v = load16_unaligned(simg + (size_t)reflect101(y, L.h) * L.w + x0);
+            *(uint4 *)(dimg + (ptrdiff_t)y * L.pitch + x0) = v;
+        }
+    }
+    const int ne = cpr - ci;                          // chunk 0 and chunks c_hi .. cpr - 1: reflected bytes gathered one by one
+    for (int i = threadIdx.x; i < rows * ne; i += 256) {
+        const int r = small_div(i, ne), e = i - r * ne;
+        const int c = e == 0 ? 0 : c_hi + e - 1;
         const int y = y_first + r, x0 = c * 16 - PYR_MX;
         const uint8_t *s = simg + (size_t)reflect101(y, L.h) * L.w;
-        uint4 v;
-        if (x0 >= 0 && x0 + 15 < L.w) {
-            __builtin_memcpy(&v, s + x0, 16);
-        } else {
-            uint32_t w4[4];
+        uint32_t w4[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                uint32_t t = 0;
+        for (int k = 0; k < 4; k++) {
+            uint32_t t = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) t |= (uint32_t)s[reflect101(x0 + 4 * k + j, L.w)] << (8 * j);
-                w4[k] = t;
-            }
-            v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            for (int j = 0; j < 4; j++) t |= (uint32_t)s[reflect101(x0 + 4 * k + j, L.w)] << (8 * j);
+            w4[k] = t;
         }
-        *(uint4 *)(dimg + (ptrdiff_t)y * L.pitch + x0) = v;
+        *(uint4 *)(dimg + (ptrdiff_t)y * L.pitch + x0) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
     }
 }
 
