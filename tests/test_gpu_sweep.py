@@ -257,6 +257,28 @@ def test_random_geometry_and_parameters(i):
     ctx.close()
 
 
+@pytest.mark.parametrize("hp,edge", [(15, 19), (12, 19), (17, 21), (9, 24)])
+def test_other_patch_sizes(hp, edge):
+    """HALF_PATCH_SIZE other than the reference's 15 (and a wider edge threshold): describe_kernel then stages the IC_Angle patch
+    by aligned words and runs the generic moment loop instead of the 128-bit / byte-dot-product path; the blurred patch and the
+    descriptor are the same code.  Stereo frame bit-exact against the oracle."""
+    from orbslam2_amd import api
+    w, h = 512, 300
+    kw = dict(nfeatures=900, half_patch_size=hp, patch_size=2 * hp + 1, edge_threshold=edge)
+    exl, exr = O.Extractor(**kw), O.Extractor(**kw)
+    left, right = synth.stereo_pair(w, h, seed=4100 + hp)
+    fx, bf = 0.7 * w, 0.2 * w
+    ctx = api.Context(width=w, height=h, fx=fx, fy=fx, cx=w / 2, cy=h / 2, bf=bf, **kw)
+    out = ctx.stereo_frame(left, right)
+    kl, dl = exl.extract(left); kr, dr = exr.extract(right)
+    ur, dp, _ = O.stereo_matches(exl, exr, kl, dl, kr, dr, bf, fx)
+    assert len(kl) > 300
+    assert np.array_equal(out["kps_left"], kl.astype(api.KP_DTYPE)) and np.array_equal(out["kps_right"], kr.astype(api.KP_DTYPE))
+    assert np.array_equal(out["desc_left"], dl) and np.array_equal(out["desc_right"], dr)
+    assert np.array_equal(out["u_right"], ur) and np.array_equal(out["depth"], dp)
+    ctx.close()
+
+
 @pytest.mark.parametrize("kind", ["low_contrast", "checker4", "checker3_mixed", "stripes"])
 def test_fast_threshold_fallback_cells(kind):
     """ComputeKeyPointsOctTree runs FAST at iniThFAST and, for a cell without keypoints, again at minThFAST
