@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
     sincos_det(__fmul_rn(angle_l, factor_pi), &b_l, &a_l);
 
     int rl_lv = -1;          // lane i < DS_KPW: level | index << 8 of the wave's i-th keypoint (-1: none), its x and y
-    float rl_x = 0.f, rl_y = 0.f;
+    float rl_x = 0.f, rl_y = 0.f, size_keep = 0.f;
+    unsigned long long dkeep = 0ull;
     for (int i = 0; i < DS_KPW; i++) {
         const bool cur = have;
         int lv = 0, kx = 0, ky = 0, ksc = 0, kout = 0;
@@ -231,7 +232,6 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
 
         // computeOrbDescriptor (src/ORBextractor.cc:103-142)
         const uint8_t *center = s_blr + (18 + ((ky - 18) & 3)) * DS_PATCH_W + (kx - xb);
-        unsigned long long *dout = (unsigned long long *)(buf.desc + ((size_t)img * cfg.sel_total + kout) * 32);
         unsigned long long bits[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -246,19 +246,27 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
             const int t1 = center[__mul24(rr1, DS_PATCH_W) + cc1];
             bits[r] = __ballot(t0 < t1);
         }
-        if (lane < 4) dout[lane] = lane == 0 ? bits[0] : (lane == 1 ? bits[1] : (lane == 2 ? bits[2] : bits[3]));
+        // results stay in registers until the wave's last keypoint is done (lane 4 i + w: descriptor word w of keypoint i; lane i:
+        // its record): a store issued here would be waited for by the next keypoint's s_waitcnt (gfx9 counts stores in vmcnt)
+        if ((lane >> 2) == i) dkeep = (lane & 3) == 0 ? bits[0] : ((lane & 3) == 1 ? bits[1] : ((lane & 3) == 2 ? bits[2] : bits[3]));
         float px = (float)kx, py = (float)ky;
         if (lv != 0) { px = __fmul_rn(px, L.scale); py = __fmul_rn(py, L.scale); }
-        if (lane == i) { rl_lv = lv | (kout << 8); rl_x = px; rl_y = py; } // for the stereo row lists below
-        if (lane == 0) {
+        if (lane == i) { rl_lv = lv | (kout << 8); rl_x = px; rl_y = py; size_keep = (float)L.scaled_patch; } // also for the stereo row lists below
+        (void)ksc; (void)angle;
+    }
+    {
+        const int lvk = __shfl(rl_lv, lane >> 2, 64); // level | index << 8 of the keypoint this lane holds a descriptor word of
+        if (lane < 4 * DS_KPW && lvk >= 0)
+            *(unsigned long long *)(buf.desc + ((size_t)img * cfg.sel_total + (lvk >> 8)) * 32 + (lane & 3) * 8) = dkeep;
+        if (lane < DS_KPW && rl_lv >= 0) {
             KeyPointPOD kp;
-            kp.x = px; kp.y = py;
-            kp.size = (float)L.scaled_patch;
-            kp.angle = angle;
-            kp.response = (float)ksc;
-            kp.octave = lv;
+            kp.x = rl_x; kp.y = rl_y;
+            kp.size = size_keep;
+            kp.angle = angle_l;            // lane i computed keypoint i's angle
+            kp.response = (float)score_l;  // and loaded its slot's score
+            kp.octave = rl_lv & 255;
             kp.class_id = -1;
-            ((KeyPointPOD *)buf.kps)[(size_t)img * cfg.sel_total + kout] = kp;
+            ((KeyPointPOD *)buf.kps)[(size_t)img * cfg.sel_total + (rl_lv >> 8)] = kp;
         }
     }
     if (stereo && (img & 1)) {
