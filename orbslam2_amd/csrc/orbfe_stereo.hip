@@ -8,9 +8,11 @@
 // dozen candidates of which ~10 pass the octave / disparity filter, so a whole wave per keypoint idles most lanes
 // and, with ~7 dependent global round trips per keypoint, needs 4x the waves to hide the same latency.
 //   coarse search: lanes stride the row list; arg-min key dist << 16 | iR (= the reference's first minimum);
-//   SAD: lane handles window pixels p = gl, gl + 16, .. < 121; the 11 shifted right-image bytes of a pixel are
-//        12 contiguous bytes = three unaligned dword loads; sums reduced over the group by xor shuffles.
+//   SAD: the 11 x 11 left window and the 11 x 21 right band go through LDS (three 128-bit loads by 11 lanes); lane handles window
+//        pixels p = gl, gl + 16, .. < 121; the 11 shifted right-image bytes of a pixel are 12 contiguous bytes of its band row;
+//        sums reduced over the group by xor shuffles.
 #define SM_G 16
+#define SM_WIN_BYTES (11 * 16 + 11 * 32 + 16) // left window rows (16 B each), right band rows (32 B each), + 16: a row's shifted read may touch the next word
 __device__ __forceinline__ unsigned group_min_u32(unsigned v)
 {
 #pragma unroll
@@ -27,6 +29,7 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, Dev
     // XCD-aware block -> (pair, block) map: all blocks of a pair on one XCD (its L2 then holds the pair's
     // descriptors, keypoints and the pyramid rows the SAD windows touch)
     __shared__ uint2 s_cand[(256 / SM_G) * 4 * SM_G]; // per 16-lane group: the candidates of a 64-entry chunk that passed the filter
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[(256 / SM_G) * SM_WIN_BYTES]; // per group: the SAD windows
     const int kpb = 256 / SM_G;
     const int bpp = (cfg.sel_total + kpb - 1) / kpb;
     int pair, blk;
@@ -152,10 +155,32 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, Dev
         if (in_ref && safe) {
             const uint8_t *imL = buf.pyr + (size_t)imgL * cfg.pyr_bytes + L.pyr_off;
             const uint8_t *imR = buf.pyr + (size_t)imgR * cfg.pyr_bytes + L.pyr_off;
-            const int lc = imL[__mul24(cv, L.pitch) + cu];
+            // the group's windows through LDS: lane r < 11 fetches row r of the left window (11 bytes from column cu - 5: one
+            // unaligned 128-bit load) and of the right band (21 bytes from column cr - 10: two), instead of every lane fetching a
+            // byte and a 12-byte piece for each of its 8 window pixels (18 load instructions per lane; the texture addresser was
+            // busy 62 % of this kernel).  The extra bytes (up to column cu + 10 / cr + 21) lie in the row's right margin.
+            uint8_t *wl = s_win + (threadIdx.x / SM_G) * SM_WIN_BYTES, *wr = wl + 11 * 16;
+            if (gl < 11) {
+                const unsigned ro = (unsigned)__mul24(cv - 5 + gl, L.pitch);
+                const uint4 a = load16_unaligned(imL + ro + cu - 5);
+                const uint4 b0 = load16_unaligned(imR + ro + cr - 10), b1 = load16_unaligned(imR + ro + cr + 6);
+                *(uint4 *)(wl + 16 * gl) = a;
+                *(uint4 *)(wr + 32 * gl) = b0;
+                *(uint4 *)(wr + 32 * gl + 16) = b1;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f); // this wave's LDS writes have landed (the lanes of a group run in lockstep)
+            __builtin_amdgcn_wave_barrier();
+            // 12 bytes from byte o of a right-band row: four aligned words, shifted
+            auto window = [&](int row, int o, uint32_t (&w)[3]) {
+                const uint32_t *q = (const uint32_t *)(wr + 32 * row + (o & ~3));
+                const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                const unsigned sh = (unsigned)(o & 3);
+                w[0] = __builtin_amdgcn_alignbyte(q1, q0, sh); w[1] = __builtin_amdgcn_alignbyte(q2, q1, sh); w[2] = __builtin_amdgcn_alignbyte(q3, q2, sh);
+            };
+            const int lc = wl[16 * 5 + 5];
             // centre row of the right image: bytes cr-5 .. cr+5 (+1 spare) = rc of the 11 shifts
             uint32_t rcw[3];
-            __builtin_memcpy(rcw, imR + __mul24(cv, L.pitch) + cr - 5, 12);
+            window(5, 5, rcw);
             // |(IL - lc) - (IR_i - rc_i)| for the 11 shifts i, two shifts per register in packed int16 (v_pk_sub / v_pk_max /
             // v_pk_add; byte pairs zero-extended by one constant-selector v_perm_b32): values are below 511, a lane's sum over
             // its 8 window pixels below 4088 and the group's over 121 pixels below 61 710, so 16 bits are exact throughout
@@ -170,11 +195,11 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, Dev
             for (int t = 0; t < 8; t++) {
                 const int p = gl + SM_G * t;
                 if (p < 121) {
-                    const int py = (p * 745) >> 13, dy = py - 5, dx = p - py * 11 - 5; // p / 11 for p < 128
-                    const short a = (short)((int)imL[__mul24(cv + dy, L.pitch) + cu + dx] - lc);
+                    const int py = (p * 745) >> 13, px = p - py * 11; // p / 11 for p < 128
+                    const short a = (short)((int)wl[16 * py + px] - lc);
                     const pk16 aa = {a, a};
                     uint32_t w[3];
-                    __builtin_memcpy(w, imR + __mul24(cv + dy, L.pitch) + cr + dx - 5, 12);
+                    window(py, px, w); // right bytes cr + dx - 5 .. cr + dx + 6, dx = px - 5
 #pragma unroll
                     for (int j = 0; j < 6; j++) {
                         const pk16 d = aa - (pair16(w, j) - kk[j]);
