@@ -23,6 +23,7 @@ __device__ __forceinline__ unsigned group_min_u32(unsigned v)
     return v;
 }
 __device__ __forceinline__ int group_sum_i32(int v) { return row_sum_i32(v); } // SM_G == 16 == one DPP row
+__device__ __forceinline__ uint32_t sad_u16(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_sad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 
 __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_pairs)
 {
@@ -181,35 +182,42 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, Dev
             // centre row of the right image: bytes cr-5 .. cr+5 (+1 spare) = rc of the 11 shifts
             uint32_t rcw[3];
             window(5, 5, rcw);
-            // |(IL - lc) - (IR_i - rc_i)| for the 11 shifts i, two shifts per register in packed int16 (v_pk_sub / v_pk_max /
-            // v_pk_add; byte pairs zero-extended by one constant-selector v_perm_b32): values are below 511, a lane's sum over
-            // its 8 window pixels below 4088 and the group's over 121 pixels below 61 710, so 16 bits are exact throughout
-            auto pair16 = [](const uint32_t (&w)[3], int j) { // bytes 2j, 2j+1 of the 12-byte window
-                const uint32_t word = w[j >> 1];
-                return __builtin_bit_cast(pk16, (j & 1) ? __builtin_amdgcn_perm(0u, word, 0x0c030c02u) : __builtin_amdgcn_perm(0u, word, 0x0c010c00u));
-            };
-            pk16 kk[6], acc[6];
+            // |(IL - lc) - (IR_i - rc_i)| = |(IL + rc_i) - (IR_i + lc)| for the 11 shifts i: both sides are in [0, 510], so TWO window
+            // pixels per register (16-bit halves, plain 32-bit adds: no carry crosses) and one v_sad_u16 per shift and pixel pair,
+            // which also accumulates: 4 ops per pair and shift (byte pair by v_perm_b32, two adds, the sad) instead of 12.  A
+            // lane's sum over its 8 window pixels is below 4088.
+            const uint32_t lc2 = (uint32_t)lc * 0x10001u;
+            uint32_t rc2[11], acc[11];
 #pragma unroll
-            for (int j = 0; j < 6; j++) { kk[j] = pair16(rcw, j); acc[j] = (pk16){0, 0}; }
+            for (int i = 0; i < 11; i++) {
+                const uint32_t word = rcw[i >> 2];
+                const uint32_t sel = (i & 3) == 0 ? 0x0c000c00u : ((i & 3) == 1 ? 0x0c010c01u : ((i & 3) == 2 ? 0x0c020c02u : 0x0c030c03u));
+                rc2[i] = __builtin_amdgcn_perm(0u, word, sel); // rc_i in both halves
+                acc[i] = 0u;
+            }
 #pragma unroll
-            for (int t = 0; t < 8; t++) {
-                const int p = gl + SM_G * t;
-                if (p < 121) {
-                    const int py = (p * 745) >> 13, px = p - py * 11; // p / 11 for p < 128
-                    const short a = (short)((int)wl[16 * py + px] - lc);
-                    const pk16 aa = {a, a};
-                    uint32_t w[3];
-                    window(py, px, w); // right bytes cr + dx - 5 .. cr + dx + 6, dx = px - 5
+            for (int t = 0; t < 8; t += 2) {
+                const int p0 = gl + SM_G * t, p1 = p0 + SM_G;
+                const int py0 = (p0 * 745) >> 13, px0 = p0 - py0 * 11; // p / 11 for p < 128
+                const int p1c = p1 < 121 ? p1 : p0;                    // only t = 6 of lanes 9 .. 15: masked out below
+                const int py1 = (p1c * 745) >> 13, px1 = p1c - py1 * 11;
+                const uint32_t il2 = (uint32_t)wl[16 * py0 + px0] | ((uint32_t)wl[16 * py1 + px1] << 16);
+                uint32_t w0[3], w1[3];
+                window(py0, px0, w0); // right bytes cr + dx - 5 .. cr + dx + 6, dx = px - 5
+                window(py1, px1, w1);
+                const uint32_t m = p1 < 121 ? 0xffffffffu : 0x0000ffffu;
 #pragma unroll
-                    for (int j = 0; j < 6; j++) {
-                        const pk16 d = aa - (pair16(w, j) - kk[j]);
-                        acc[j] += __builtin_elementwise_max(d, (pk16){0, 0} - d);
-                    }
+                for (int i = 0; i < 11; i++) {
+                    const uint32_t sel = (i & 3) == 0 ? 0x0c040c00u : ((i & 3) == 1 ? 0x0c050c01u : ((i & 3) == 2 ? 0x0c060c02u : 0x0c070c03u));
+                    const uint32_t ir2 = __builtin_amdgcn_perm(w1[i >> 2], w0[i >> 2], sel); // byte i of pixel t | byte i of pixel t + 1 << 16
+                    uint32_t x2 = il2 + rc2[i], y2 = ir2 + lc2;
+                    if (t == 6) { x2 &= m; y2 &= m; }
+                    acc[i] = sad_u16(x2, y2, acc[i]);
                 }
             }
             int dists[11];
 #pragma unroll
-            for (int i = 0; i < 11; i++) dists[i] = (i & 1) ? (int)(unsigned short)acc[i >> 1].y : (int)(unsigned short)acc[i >> 1].x;
+            for (int i = 0; i < 11; i++) dists[i] = (int)acc[i];
             int sad_best = 0x7fffffff, best_inc = 0;
 #pragma unroll
             for (int i = 0; i < 11; i++) {
