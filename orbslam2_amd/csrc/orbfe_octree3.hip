@@ -188,6 +188,20 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
     const int img = blockIdx.x, level = blockIdx.y;
     const LevelInfo &L = cfg.lv[level];
     const int tid = threadIdx.x;
+#ifdef ORBFE_PROFILE_CUTS // tools/octree3_timeline.py (`make cuts` build only): start / end of the first 2048 workgroups and the phase
+                          // boundaries of image 0's workgroups, 100 MHz clock
+    struct Stamp {
+        long long *p;
+        __device__ Stamp(long long *q) : p(q) { if (p) p[0] = (long long)__builtin_amdgcn_s_memrealtime(); }
+        __device__ ~Stamp() { if (p) p[1] = (long long)__builtin_amdgcn_s_memrealtime(); }
+    } stamp(tid == 0 && (img * cfg.nlevels + level) < 2048 ? buf.dbg_ts + 2 * (img * cfg.nlevels + level) : nullptr);
+    long long *ph = tid == 0 && img == 0 && level < 8 ? buf.dbg_ts + 2048 + 64 * level : nullptr;
+    int ph_n = 0;
+#define OT3_PHASE() do { if (ph && ph_n < 63) ph[ph_n++] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define OT3_PHASE() do { } while (0)
+#endif
+    OT3_PHASE();
     const int MAXN = cfg.max_nodes;
 
     uint8_t *p = s_raw;
@@ -285,6 +299,7 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
         }
     }
     __syncthreads();
+    OT3_PHASE();
     // ---- 2. pyramid ----
     for (int d = OT3_DB - 1; d >= 0; d--) {
         const int n_e = OT3_ROOTS << (2 * d);
@@ -298,6 +313,7 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
         }
         __syncthreads();
     }
+    OT3_PHASE();
     // ---- roots (src/ORBextractor.cc:537-581) ----
     if (tid == 0) {
         int n = 0, nc = 0;
@@ -347,6 +363,7 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
     int sorted_phase = 0;
     for (int iter = 0; iter < 100000; iter++) { // n grows every pass, so this ends at n >= quota at the latest
         const int n = *s_n;
+        OT3_PHASE();
         // child counts
         for (int i = tid; i < n; i += OT3_THREADS) {
             int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
@@ -451,6 +468,7 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
         } else {
             // processing order of the multi-point nodes
             const int m = ot3_scan_array(s_kk, n, s_w); // s_kk[i] = rank among multi nodes (list order)
+            if (sorted_phase) OT3_PHASE(); // scan kk
             if (!sorted_phase) {
                 for (int i = tid; i < n; i += OT3_THREADS)
                     if (cur.cnt[i] > 1) s_plist[s_kk[i]] = i;
@@ -459,30 +477,38 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
                 // (size, pointer) order of the reference under contract Q3: count descending, list position ascending
                 int P = 1;
                 while (P < m) P <<= 1;
+                if (m <= 2 * OT3_THREADS && nc < 65536) {
+                    // few keys (all distinct), counts and list positions below 2^16: 32-bit keys ranked by counting -- every thread
+                    // compares its key(s) with all m, sixteen per step (four 128-bit broadcast reads in flight; with one key per
+                    // step the loop is bound by LDS latency: 7-10 us of a workgroup's 30, tools/octree3_timeline.py); the rank is
+                    // the node's place in s_plist
+                    uint32_t *k32 = (uint32_t *)s_key;
+                    const int m16 = (m + 15) & ~15; // <= 2 * sort_cap words
+                    for (int i = tid; i < m16; i += OT3_THREADS) k32[i] = ~0u;
+                    __syncthreads();
+                    for (int i = tid; i < n; i += OT3_THREADS)
+                        if (cur.cnt[i] > 1) k32[s_kk[i]] = ((0xffffu - (unsigned)cur.cnt[i]) << 16) | (unsigned)i;
+                    __syncthreads();
+                    auto below = [](const uint4 &q, uint32_t v) { return (int)(q.x < v) + (int)(q.y < v) + (int)(q.z < v) + (int)(q.w < v); };
+                    for (int u = 0; u * OT3_THREADS < m; u++) { // one round per 512 keys
+                        const bool has = tid + u * OT3_THREADS < m;
+                        const uint32_t mine = has ? k32[tid + u * OT3_THREADS] : ~0u;
+                        int rk = 0;
+                        for (int j = 0; j < m16; j += 16) {
+                            const uint4 a = *(const uint4 *)(k32 + j), b = *(const uint4 *)(k32 + j + 4), c = *(const uint4 *)(k32 + j + 8), d = *(const uint4 *)(k32 + j + 12);
+                            rk += below(a, mine) + below(b, mine) + below(c, mine) + below(d, mine);
+                        }
+                        if (has) s_plist[rk] = (int)(mine & 0xffffu);
+                    }
+                    __syncthreads();
+                    goto ranked;
+                }
                 for (int i = tid; i < P; i += OT3_THREADS) s_key[i] = ~0ull;
                 __syncthreads();
                 for (int i = tid; i < n; i += OT3_THREADS)
                     if (cur.cnt[i] > 1)
                         s_key[s_kk[i]] = ((unsigned long long)(0xffffffffu - (unsigned)cur.cnt[i]) << 32) | (unsigned)i;
                 __syncthreads();
-                if (m <= 2 * OT3_THREADS) {
-                    // few keys (all distinct): rank by counting -- m broadcast LDS reads per thread and one barrier
-                    // instead of the log^2 barrier steps of the sorting network below
-                    unsigned long long mine[2];
-                    int rk[2] = {0, 0};
-#pragma unroll
-                    for (int u = 0; u < 2; u++) mine[u] = tid + u * OT3_THREADS < m ? s_key[tid + u * OT3_THREADS] : ~0ull;
-                    for (int j = 0; j < m; j++) {
-                        const unsigned long long kj = s_key[j];
-                        rk[0] += kj < mine[0]; rk[1] += kj < mine[1];
-                    }
-                    __syncthreads();
-#pragma unroll
-                    for (int u = 0; u < 2; u++)
-                        if (tid + u * OT3_THREADS < m) s_key[rk[u]] = mine[u];
-                    __syncthreads();
-                    P = 0; // skip the network
-                }
                 for (int k = 2; k <= P; k <<= 1) {
                     for (int j = k >> 1; j > 0; j >>= 1) {
                         for (int i = tid; i < P; i += OT3_THREADS) {
@@ -498,7 +524,9 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
                 }
                 for (int i = tid; i < m; i += OT3_THREADS) s_plist[i] = (int)(s_key[i] & 0xffffffffu);
                 __syncthreads();
+            ranked:;
             }
+            if (sorted_phase) OT3_PHASE(); // ranked
             // k = non-empty children per processing rank; exclusive prefix in s_un
             for (int r = tid; r < m; r += OT3_THREADS) {
                 const int i = s_plist[r];
@@ -508,6 +536,7 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
             }
             __syncthreads();
             ot3_scan_array(s_un, m, s_w);
+            if (sorted_phase) OT3_PHASE(); // scan un
             if (tid == 0) { *s_nproc = m; *s_nexpand = 0; }
             __syncthreads();
             if (sorted_phase) { // first r with n + sum_{r'<=r}(k-1) >= quota (src/ORBextractor.cc:724-725); monotone in r
@@ -521,11 +550,13 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
             }
             __syncthreads();
             const int nproc = *s_nproc, total_k = *s_total_k;
+            if (sorted_phase) OT3_PHASE(); // nproc
             for (int r = tid; r < nproc; r += OT3_THREADS) s_rank[s_plist[r]] = r;
             __syncthreads();
             for (int i = tid; i < n; i += OT3_THREADS) s_plist[i] = (s_rank[i] < 0) ? 1 : 0; // reuse: unprocessed flags
             __syncthreads();
             const int n_un = ot3_scan_array(s_plist, n, s_w);
+            if (sorted_phase) OT3_PHASE(); // scan flags
             n_new = total_k + n_un;
             if (n_new > MAXN) { // cannot happen for max_nodes >= max(quota+3, 4*n_ini); guard anyway
                 if (tid == 0) { *status = 2; *sel_cnt = 0; }
@@ -568,6 +599,7 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
         __syncthreads();
     }
 
+    OT3_PHASE();
     // ---- 4. keep the best response per node, first wins (src/ORBextractor.cc:735-754) ----
     const int n = *s_n;
     const int n_out = n < L.sel_cap ? n : L.sel_cap;
@@ -593,6 +625,7 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
         sel_sc[i] = (uint8_t)(key >> 24);
     }
     if (tid == 0) *sel_cnt = n_out;
+    OT3_PHASE();
 }
 
 // Parity tap (orbfe_fetch_candidates): the candidates of every level in cv::FAST emission order
