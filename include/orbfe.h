@@ -56,7 +56,7 @@ typedef struct orbfe_params {
     int32_t min_th_fast;
     int32_t patch_size;
     int32_t half_patch_size;
-    int32_t edge_threshold;
+    int32_t edge_threshold; /* >= 19 (the descriptor pattern's reach + 1) and >= half_patch_size + 4 */
     float fx, fy, cx, cy;
     float bf;             /* baseline * fx (Frame::mbf) */
     int32_t device;       /* HIP device ordinal */

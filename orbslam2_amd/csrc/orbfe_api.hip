@@ -340,10 +340,10 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
     *out = nullptr;
     const orbfe_params &p = *params;
     if (p.nlevels < 1 || p.nlevels > ORBFE_MAX_LEVELS || p.nfeatures < 1 || !(p.scale_factor > 1.0f) ||
-        p.half_patch_size < 1 || p.half_patch_size > 62 || p.edge_threshold < p.half_patch_size + 4 ||
+        p.half_patch_size < 1 || p.half_patch_size > 62 || p.edge_threshold < p.half_patch_size + 4 || p.edge_threshold < 19 ||
         p.width < 1 || p.height < 1 || p.max_images < 1 || p.min_th_fast < 1 || p.ini_th_fast < p.min_th_fast ||
         p.ini_th_fast > 254)
-        return fail(nullptr, ORBFE_ERR_INVALID, "invalid orbfe_params");
+        return fail(nullptr, ORBFE_ERR_INVALID, "invalid orbfe_params"); // edge_threshold >= 19: the rotated test pattern reaches 18 px from a keypoint (describe_kernel stages +-18)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, ORBFE_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
@@ -360,7 +360,6 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
         delete ctx;
         return fail(nullptr, ORBFE_ERR_CAPACITY, "max_images %d: more than 2^24 workgroups per launch", p.max_images);
     }
-    // edge threshold must cover the descriptor reach (pattern radius 18.4 + rounding) and the patch
     if (hipSetDevice(p.device) != hipSuccess) { delete ctx; return fail(nullptr, ORBFE_ERR_NO_DEVICE, "hipSetDevice failed"); }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return fail(nullptr, ORBFE_ERR_NO_DEVICE, "hipStreamCreate failed"); }
     if (ctx->use_octree2 && orbfe_octree2_prepare(ctx->ot2_lds) != 0) ctx->use_octree2 = false;

@@ -40,6 +40,10 @@ def test_invalid_params_rejected():
     assert lib.orbfe_create(C.byref(bad), C.byref(h)) == api.ERR_INVALID
     assert b"invalid" in lib.orbfe_last_error(None)
     assert lib.orbfe_create(None, C.byref(h)) == api.ERR_INVALID
+    # the rotated test pattern reaches 18 px from a keypoint: an edge threshold below the reference's 19 would let the descriptor
+    # stage read outside the level image
+    shallow = api.Params(2000, 1.2, 8, 20, 7, 19, 9, 15, 1, 1, 0, 0, 1, 0, 640, 480, 2)  # half_patch 9, edge 15
+    assert lib.orbfe_create(C.byref(shallow), C.byref(h)) == api.ERR_INVALID
 
 
 def test_no_gpu_means_loud_failure_not_cpu_fallback():
