@@ -438,7 +438,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void pyr_tail_kernel(DeviceConfig cfg
 // per wave (13.6 -> 9.8 per pixel), 0.109 -> 0.098 ms (the first 12 % of the cut bought all of that:
 // the kernel then waits for memory), and whole-line 16-byte stores (tiles of 4 x 4 px blocks): -> 0.083 ms.
 // ---------------------------------------------------------------------------
-#define BL_ROWS ORBFE_BLUR_ROWS // rows per wave (a multiple of 4): 6 / BL_ROWS of the rows are loaded (and row-filtered) twice; 32 beats 16 by 4 us now that the kernel is memory-bound (no difference while it was issue-bound)
+#define BL_ROWS ORBFE_BLUR_ROWS // rows per wave (a multiple of 4): 6 / BL_ROWS of the rows are loaded (and row-filtered) twice; 32 beats 16 by 4 us now that the kernel is memory-bound (no difference while it was issue-bound); 48 / 64: + 3 / + 9 us (too few waves)
 #define BL_COLS 256 // per wave: 64 lanes x 4 px
 __global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffers buf)
 {
