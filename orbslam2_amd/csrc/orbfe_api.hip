@@ -556,6 +556,7 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
                     c2.tail_first = F; c2.tail_n = nst; c2.tail_strips = strips; c2.tail_src_words = max_src;
                     for (int st = 0; st < nst; st++) c2.tail_words[st] = max_wd[st];
                     c2.tail_lds_bytes = (int)off;
+                    if (getenv("ORBFE_HOST_TRACE")) fprintf(stderr, "orbfe: pyramid tail: levels %d..%d, %d strips, %d bytes of LDS per workgroup\n", F, F + nst - 1, strips, (int)off);
                     int *d_plan = nullptr;
                     A(d_plan, plan.size());
                     if (hipMemcpy(d_plan, plan.data(), plan.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {

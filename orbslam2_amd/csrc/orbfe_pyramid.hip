@@ -296,6 +296,19 @@ __global__ __launch_bounds__(TAIL_THREADS) void pyr_tail_kernel(DeviceConfig cfg
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int F = cfg.tail_first;
     const int *plan = buf.tail_plan + strip * (ORBFE_TAIL_MAX * 4);
+#ifdef ORBFE_PROFILE_CUTS // tools/tail_timeline.py (`make cuts` build only): phase boundaries of image 0's workgroups, 100 MHz clock
+    long long *ph = tid == 0 && img == 0 && strip < 8 ? buf.dbg_ts + 3072 + 16 * strip : nullptr;
+    struct Stamp { // start / end of the first 1024 workgroups
+        long long *p;
+        __device__ Stamp(long long *q) : p(q) { if (p) p[0] = (long long)__builtin_amdgcn_s_memrealtime(); }
+        __device__ ~Stamp() { if (p) p[1] = (long long)__builtin_amdgcn_s_memrealtime(); }
+    } stamp(tid == 0 && (img * (int)gridDim.x + strip) < 1024 ? buf.dbg_ts + 2 * (img * (int)gridDim.x + strip) : nullptr);
+    int ph_n = 0;
+#define TAIL_PHASE() do { if (ph && ph_n < 15) ph[ph_n++] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TAIL_PHASE() do { } while (0)
+#endif
+    TAIL_PHASE();
     uint8_t *pyr = buf.pyr + (size_t)img * cfg.pyr_bytes;
     // this lane's word and row run of every stage, and the word's column-table entries (issued first: longest latency)
     int xi_[NST], yb_[NST], ye_[NST];
@@ -360,6 +373,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void pyr_tail_kernel(DeviceConfig cfg
         }
     }
     __syncthreads();
+    TAIL_PHASE();
 #pragma unroll
     for (int st = 0; st < NST; st++) {
         const LevelInfo &D = cfg.lv[F + st];
@@ -425,6 +439,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void pyr_tail_kernel(DeviceConfig cfg
             if (keep) *(uint32_t *)(keep + __mul24(y, keep_pitch)) = out;
         }
         if (st + 1 < NST) __syncthreads();
+        TAIL_PHASE();
     }
 }
 
