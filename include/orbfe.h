@@ -7,9 +7,23 @@
  * exceptions cross this boundary.  All functions return ORBFE_OK (0) or a
  * negative error code; orbfe_last_error() gives a message.
  *
- * Threading: a context is not re-entrant (the reference never re-enters one
- * ORBextractor, src/Frame.cc:78-81); different contexts may be used from
- * different threads concurrently.
+ * Threading: different contexts may be used from different threads concurrently
+ * (the reference runs its two extractor objects on two threads, src/Frame.cc:78-81).
+ * Calls on the SAME context are serialised by a mutex inside the context, so the
+ * reference's Tracking / LocalMapping / LoopClosing threads may share one (their
+ * ORBmatcher objects do, through the compat shim); "the latest extraction call" that
+ * the fetch functions and device_slot_plus1 refer to is then whichever call the
+ * context saw last -- callers that interleave enqueue and fetch from several threads
+ * on one context must order those pairs themselves.
+ *
+ * Environment (read once, by orbfe_create; meant for tests and A/B measurements):
+ *   ORBFE_OCTREE=2|1   force the point-parallel (2) or the generic node-parallel (1)
+ *                      DistributeOctTree kernel instead of the bucket-pyramid one
+ *                      (orbfe_quadtree_kernel() reports the choice);
+ *   ORBFE_NO_TAIL=1    keep the last pyramid levels on separate launches instead of
+ *                      the fused tail kernel;
+ *   ORBFE_HOST_TRACE=1 print the context's geometry, kernel choices and LDS sizes to
+ *                      stderr at create time.
  *
  * There is NO CPU fallback: if no HIP device is present orbfe_create fails
  * with ORBFE_ERR_NO_DEVICE.
@@ -24,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ORBFE_ABI_VERSION 3 /* 2: orbfe_frame_view.device_slot_plus1; 3: .keyframe */
+#define ORBFE_ABI_VERSION 4 /* 2: orbfe_frame_view.device_slot_plus1; 3: .keyframe; 4: orbfe_get_camera, orbfe_assign_features_to_grid */
 
 enum {
     ORBFE_OK = 0,
@@ -76,6 +90,10 @@ void orbfe_destroy(orbfe_context *ctx);
 /* Getters of include/ORBextractor.h:61-82 (GetLevels/GetScaleFactors/...), plus
  * mnFeaturesPerLevel and umax for tests.  Arrays hold nlevels entries (umax: half_patch+1). */
 int orbfe_levels(const orbfe_context *ctx);
+/* cam[5] = fx, fy, cx, cy, bf the context was created with: every matcher / optimiser entry point projects with these
+ * (the reference reads Frame::fx ... / pKF->fx ..., one camera model per process, src/Frame.cc:29-33); a shim that is handed
+ * a KeyFrame checks them against pKF->fx ... instead of trusting that the right context was picked. */
+int orbfe_get_camera(const orbfe_context *ctx, float *cam);
 int orbfe_keypoint_capacity(const orbfe_context *ctx); /* max keypoints one image can yield */
 int orbfe_get_tables(const orbfe_context *ctx, float *scale, float *inv_scale, float *sigma2,
                      float *inv_sigma2, int32_t *features_per_level, int32_t *umax);
@@ -223,7 +241,8 @@ typedef struct orbfe_frame_view { /* what the matchers read from a Frame (includ
      * k + 1: the frame IS image slot k of this context's latest extraction call (orbfe_extract / _stereo_frame / _rgbd_frame:
      * slot 0; batched calls: any slot): keypoints (undistorted on the device when orbfe_set_distortion is active) and
      * descriptors are read where the extraction left them in HBM, and the 64 x 48 grid is built once per frame and reused by
-     * every later matcher call on it.  n must be that slot's keypoint count; keys_un must still point to the host copy (the
+     * every later matcher call on it.  n must be that slot's keypoint count (checked: a view of another frame is refused
+     * with ORBFE_ERR_INVALID); keys_un must still point to the host copy (the
      * host-side accept rules read angles from it), u_right (n floats, or NULL) is uploaded with every call, descriptors may
      * be NULL.  What Tracking matches against
      * is always the current frame, so this is the Tracking-thread fast path; zero-initialise the struct to stay on the
@@ -249,6 +268,11 @@ typedef struct orbfe_track_point {
  * result in the reference's order. */
 int orbfe_features_in_area(orbfe_context *ctx, const orbfe_frame_view *frame, float x, float y, float r,
                            int min_level, int max_level, int32_t *out, int cap, int *n);
+/* Frame::AssignFeaturesToGrid (src/Frame.cc:231-246) = the 64 x 48 grid itself, as CSR: mGrid[ix][iy] is
+ * cell_idx[cell_off[ix * 48 + iy] .. cell_off[ix * 48 + iy + 1]) (ascending keypoint indices = push_back order);
+ * cell_off has 64 * 48 + 1 entries, cell_idx fv->n.  For a device-resident frame the grid stays cached for the matcher
+ * calls that follow. */
+int orbfe_assign_features_to_grid(orbfe_context *ctx, const orbfe_frame_view *fv, int32_t *cell_off, int32_t *cell_idx);
 /* nq queries against the same frame in one call (the frame is uploaded and bucketed once): query i's indices are
  * out[out_off[i] .. out_off[i + 1]), in GetFeaturesInArea's order; min_level / max_level may be NULL (-1 for all). */
 int orbfe_features_in_area_batch(orbfe_context *ctx, const orbfe_frame_view *fv, int nq, const float *x, const float *y,

@@ -16,61 +16,34 @@
 #include <string>
 
 #include "../../include/orbfe.h"
+#include "compat_util.h"
 
 namespace ORB_SLAM2
 {
+using namespace orbfe_compat;
 
 const int ORBmatcher::TH_HIGH = 100;     // src/ORBmatcher.cc:35-37
 const int ORBmatcher::TH_LOW = 50;
 const int ORBmatcher::HISTO_LENGTH = 30;
 
-static_assert(sizeof(cv::KeyPoint) == sizeof(orbfe_keypoint), "cv::KeyPoint must be layout-identical to orbfe_keypoint");
-static_assert(sizeof(cv::Point2f) == 2 * sizeof(float), "cv::Point2f must be two floats");
 
 namespace
 {
 
-void check(orbfe_context *ctx, int rc)
-{
-    if (rc != ORBFE_OK) throw std::runtime_error(std::string("ORBmatcher (orbfe): ") + orbfe_last_error(ctx));
-}
-
-orbfe_context *context_of(const Frame &F)
-{
-    orbfe_context *ctx = F.mpORBextractorLeft ? F.mpORBextractorLeft->Context() : ORBextractor::DefaultContext();
-    if (!ctx) throw std::runtime_error("ORBmatcher: the frame's ORBextractor has no device context yet (no image extracted)");
-    return ctx;
-}
-
-orbfe_context *default_context()
+// The keyframe-only overloads have no Frame to reach an extractor through: they use the process-wide default context
+// (ORBextractor::DefaultContext()).  orbfe_fuse / _sim3 / search_by_sim3 project with the CONTEXT's fx, fy, cx, cy, bf and scale
+// tables where the reference reads pKF->fx ... (src/ORBmatcher.cc:831-835), so a default context of another camera would give
+// wrong matches silently: refuse it.
+orbfe_context *kf_context(const KeyFrame *pKF)
 {
     orbfe_context *ctx = ORBextractor::DefaultContext();
     if (!ctx) throw std::runtime_error("ORBmatcher: no ORBextractor device context exists in this process");
+    float cam[5];
+    check(ctx, orbfe_get_camera(ctx, cam));
+    if (cam[0] != pKF->fx || cam[1] != pKF->fy || cam[2] != pKF->cx || cam[3] != pKF->cy || cam[4] != pKF->mbf)
+        throw std::runtime_error("ORBmatcher: the default device context was created for another camera than this KeyFrame's "
+                                 "(call SetCamera() on the left ORBextractor before its first frame, or SetAsDefault() on the right one)");
     return ctx;
-}
-
-const orbfe_keypoint *keys_of(const std::vector<cv::KeyPoint> &v) { return reinterpret_cast<const orbfe_keypoint *>(v.data()); }
-
-// what the matchers read from a Frame (include/Frame.h:131-185)
-orbfe_frame_view view_of(const Frame &F)
-{
-    orbfe_frame_view v = orbfe_frame_view(); // upload path; see device_view_of() for the resident one
-    v.n = F.N;
-    v.keys_un = keys_of(F.mvKeysUn);
-    v.u_right = F.mvuRight.empty() ? nullptr : F.mvuRight.data();
-    v.descriptors = F.mDescriptors.ptr<uchar>(0);
-    v.min_x = Frame::mnMinX; v.max_x = Frame::mnMaxX; v.min_y = Frame::mnMinY; v.max_y = Frame::mnMaxY;
-    return v;
-}
-
-// The frame every Tracking matcher searches IN is the current one, i.e. the latest extraction of its extractor: if F is that
-// frame (ORBextractor::IsResidentFrame: same count, same leading descriptors) the matchers read it where the extraction left
-// it in HBM and build its grid once; any other frame takes the upload path.
-orbfe_frame_view device_view_of(const Frame &F)
-{
-    orbfe_frame_view v = view_of(F);
-    if (F.mpORBextractorLeft && F.mpORBextractorLeft->IsResidentFrame(F.N, F.mDescriptors.ptr<uchar>(0))) v.device_slot_plus1 = 1;
-    return v;
 }
 
 // ... and from a KeyFrame (include/KeyFrame.h:160-199).  The keyframe's grid is the frame's (filled with the frame's FLOAT bounds and
@@ -86,42 +59,6 @@ orbfe_frame_view view_of(const KeyFrame *pKF)
     v.min_x = Frame::mnMinX; v.max_x = Frame::mnMaxX; v.min_y = Frame::mnMinY; v.max_y = Frame::mnMaxY;
     v.keyframe = 1;
     return v;
-}
-
-// top three rows of a 4 x 4 (or the whole of a 3 x 4) CV_32F pose, row major
-void pose_3x4(const cv::Mat &T, float *out)
-{
-    for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 4; c++) out[4 * r + c] = T.at<float>(r, c);
-}
-void pose_from_Rt(const cv::Mat &R, const cv::Mat &t, float *out)
-{
-    for (int r = 0; r < 3; r++) {
-        for (int c = 0; c < 3; c++) out[4 * r + c] = R.at<float>(r, c);
-        out[4 * r + 3] = t.at<float>(r);
-    }
-}
-
-// MapPoint exposes only the scaled distances (GetMaxDistanceInvariance() = 1.2f * mfMaxDistance, GetMinDistanceInvariance() =
-// 0.8f * mfMinDistance, src/MapPoint.cc:390-400); the C ABI takes the raw members (it forms the same products for the range
-// gate and needs mfMaxDistance itself for PredictScale, src/MapPoint.cc:402-417).  Recover a raw value whose product is
-// EXACTLY the scaled one, so the range gates are bit-identical; where two neighbouring floats share that product (the product
-// crosses a binade in about one case in six) the one nearest to scaled / k is taken, which can move PredictScale's ratio by one
-// ulp -- its ceil() changes only if log(ratio) / log(scaleFactor) is an integer to within 1e-7.
-float raw_from_scaled(float scaled, float k)
-{
-    const float r0 = scaled / k;
-    float best = r0;
-    bool found = false;
-    double best_err = 0.0;
-    const float cand[5] = {r0, std::nextafter(r0, 0.0f), std::nextafter(r0, 3.0e38f), std::nextafter(std::nextafter(r0, 0.0f), 0.0f),
-                           std::nextafter(std::nextafter(r0, 3.0e38f), 3.0e38f)};
-    for (int i = 0; i < 5; i++) {
-        if (k * cand[i] != scaled) continue;
-        const double err = std::fabs((double)cand[i] - (double)scaled / (double)k);
-        if (!found || err < best_err) { best = cand[i]; best_err = err; found = true; }
-    }
-    return best;
 }
 
 // rows of per-point arrays, one entry per element of a vector<MapPoint*>
@@ -285,7 +222,7 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std
 // src/ORBmatcher.cc:285-398 -> orbfe_search_by_projection_sim3
 int ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, std::vector<MapPoint *> &vpMatched, int th)
 {
-    orbfe_context *ctx = default_context();
+    orbfe_context *ctx = kf_context(pKF);
     std::set<MapPoint *> spAlreadyFound(vpMatched.begin(), vpMatched.end()); // :302-303
     spAlreadyFound.erase(static_cast<MapPoint *>(NULL));
     const size_t n = vpPoints.size();
@@ -333,7 +270,7 @@ int ORBmatcher::SearchByFboW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &v
 // src/ORBmatcher.cc:517-650 -> orbfe_search_by_bow_kf
 int ORBmatcher::SearchByFboW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12)
 {
-    orbfe_context *ctx = default_context();
+    orbfe_context *ctx = kf_context(pKF1);
     const std::vector<MapPoint *> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
     vpMatches12 = std::vector<MapPoint *>(vpMapPoints1.size(), static_cast<MapPoint *>(NULL));
     const FeatCSR fv1(pKF1->mFbowFeatVec), fv2(pKF2->mFbowFeatVec);
@@ -371,7 +308,7 @@ int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Po
 // src/ORBmatcher.cc:652-819 -> orbfe_search_for_triangulation
 int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo)
 {
-    orbfe_context *ctx = default_context();
+    orbfe_context *ctx = kf_context(pKF1);
     const FeatCSR fv1(pKF1->mFbowFeatVec), fv2(pKF2->mFbowFeatVec);
     const int n1 = pKF1->N, n2 = pKF2->N;
     std::vector<uint8_t> has1(n1 > 0 ? n1 : 1, 0), has2(n2 > 0 ? n2 : 1, 0);
@@ -402,7 +339,7 @@ int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F
 int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12, const float &s12, const cv::Mat &R12,
                              const cv::Mat &t12, const float th)
 {
-    orbfe_context *ctx = default_context();
+    orbfe_context *ctx = kf_context(pKF1);
     const std::vector<MapPoint *> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
     const int N1 = (int)vpMapPoints1.size(), N2 = (int)vpMapPoints2.size();
     std::vector<bool> vbAlreadyMatched1(N1, false), vbAlreadyMatched2(N2, false); // :1126-1139
@@ -444,7 +381,7 @@ int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoin
 // src/ORBmatcher.cc:821-971: the search is orbfe_fuse, the map mutation (:943-964) stays here, literally
 int ORBmatcher::Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, const float th)
 {
-    orbfe_context *ctx = default_context();
+    orbfe_context *ctx = kf_context(pKF);
     const size_t n = vpMapPoints.size();
     PointRows pts(n);
     for (size_t i = 0; i < n; i++) {
@@ -463,6 +400,11 @@ int ORBmatcher::Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, 
         const int bestIdx = best[i];
         if (bestIdx < 0) continue;
         MapPoint *pMP = vpMapPoints[i];
+        // The reference searches and mutates point by point (:843-964); here every search ran before the first mutation.  The
+        // search itself reads only the keyframe's keypoints, so the two orders differ exactly where an EARLIER mutation changes
+        // this point's :843-847 filter: a point replaced meanwhile (it appears in vpMapPoints and was the keyframe's own point
+        // at an earlier bestIdx) or already added to pKF (listed twice).  Re-applying the filter here restores the sequence.
+        if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
         MapPoint *pMPinKF = pKF->GetMapPoint(bestIdx);
         if (pMPinKF) {
             if (!pMPinKF->isBad()) {
@@ -481,7 +423,7 @@ int ORBmatcher::Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, 
 // src/ORBmatcher.cc:973-1096: search = orbfe_fuse_sim3, bookkeeping (:1073-1090) here
 int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, float th, std::vector<MapPoint *> &vpReplacePoint)
 {
-    orbfe_context *ctx = default_context();
+    orbfe_context *ctx = kf_context(pKF);
     const std::set<MapPoint *> spAlreadyFound = pKF->GetMapPoints(); // :989
     const size_t n = vpPoints.size();
     PointRows pts(n);

@@ -41,6 +41,8 @@ struct orbfe_context {
     size_t d_ham_bytes = 0;
     int last_images = 0;
     unsigned epoch = 0;       // extraction calls enqueued so far (device-resident frame caches key on it)
+    std::vector<int> slot_cnt;    // keypoint counts of the slots of call `slot_cnt_epoch` (host copy, filled by the first fetch)
+    unsigned slot_cnt_epoch = ~0u;
     bool use_octree2 = false; // point-parallel quadtree (all levels have <= 4 roots and the LDS budget fits)
     bool use_octree3 = false; // bucket-pyramid quadtree (orbfe_octree3.hip); preferred when its limits hold
     size_t ot3_lds = 0;
@@ -55,7 +57,12 @@ struct orbfe_context {
     int prof_calls = 0;      // calls recorded since the last reset
     int prof_stages[64];     // number of stages recorded by each call in the ring
     int prof_groups = 1;
-    hipStream_t prof_stream = nullptr;
+    // Recorded on the stream of every enqueue call when its work has been queued: what "the latest extraction" means to the
+    // blocking fetches and to the matchers on the resident frame.  The caller's stream handle itself is NOT kept -- a caller
+    // may enqueue, synchronise and destroy its stream before it fetches.
+    hipEvent_t ev_latest = nullptr;
+    bool latest_foreign = false; // the latest call ran on a caller's stream
+    std::recursive_mutex mu;
     // stream groups (orbfe_set_streams)
     int groups = 1;
     hipStream_t gstreams[ORBFE_MAX_GROUPS] = {};
@@ -107,7 +114,26 @@ const DeviceBuffers *orbfe_ctx_buffers(const orbfe_context *ctx) { return &ctx->
 unsigned orbfe_ctx_epoch(const orbfe_context *ctx) { return ctx->epoch; }
 int orbfe_ctx_wait_foreign_stream(orbfe_context *ctx)
 {
-    if (ctx->prof_stream && ctx->prof_stream != ctx->stream) (void)hipStreamSynchronize(ctx->prof_stream); // caller-owned: may be gone
+    if (ctx->latest_foreign && hipStreamWaitEvent(ctx->stream, ctx->ev_latest, 0) != hipSuccess)
+        return fail(ctx, ORBFE_ERR_HIP, "hipStreamWaitEvent on the latest extraction failed");
+    return ORBFE_OK;
+}
+std::recursive_mutex &orbfe_ctx_mutex(orbfe_context *ctx) { return ctx->mu; }
+// Keypoint count of image slot `slot` of the latest extraction call: from the host copy the frame entry points leave behind,
+// else one blocking read of the counters per call (batched calls whose results were not fetched yet).
+int orbfe_ctx_slot_count(orbfe_context *ctx, int slot, int *cnt)
+{
+    if (slot < 0 || slot >= ctx->last_images)
+        return fail(ctx, ORBFE_ERR_INVALID, "device slot %d: the latest extraction call filled %d image slots", slot, ctx->last_images);
+    if (ctx->slot_cnt_epoch != ctx->epoch || (int)ctx->slot_cnt.size() < ctx->last_images) {
+        if (ctx->latest_foreign && hipEventSynchronize(ctx->ev_latest) != hipSuccess) return fail(ctx, ORBFE_ERR_HIP, "hipEventSynchronize failed");
+        ctx->slot_cnt.resize(ctx->last_images);
+        if (hipMemcpyAsync(ctx->slot_cnt.data(), ctx->buf.kp_cnt, sizeof(int) * ctx->last_images, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            return fail(ctx, ORBFE_ERR_HIP, "reading the keypoint counters failed");
+        ctx->slot_cnt_epoch = ctx->epoch;
+    }
+    *cnt = ctx->slot_cnt[slot];
     return ORBFE_OK;
 }
 orbfe_pose_state *orbfe_ctx_pose_state(orbfe_context *ctx)
@@ -354,14 +380,17 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
     ctx->params = p;
     int rc = build_config(ctx);
     if (rc != ORBFE_OK) { snprintf(g_err, sizeof(g_err), "%s", ctx->err); delete ctx; return rc; }
-    // the XCD-aware block maps divide block indices through a float reciprocal that is exact below 2^21 (xcd_map)
+    // the XCD-aware block maps divide jb = blockIdx.x / 8 through a float reciprocal that is exact for jb < 2^21 (small_div,
+    // orbfe_common.hpp), i.e. below 2^24 workgroups per launch; xcd_grid may round a launch up to twice blocks x images, so
+    // the limit on blocks x images is 2^23
     if (((size_t)ctx->cfg.cells_total / 4 + 1) * (size_t)p.max_images >= ((size_t)1 << 23) ||
         ((size_t)ctx->cfg.sel_total / 4 + 1) * (size_t)p.max_images >= ((size_t)1 << 23)) {
         delete ctx;
-        return fail(nullptr, ORBFE_ERR_CAPACITY, "max_images %d: more than 2^24 workgroups per launch", p.max_images);
+        return fail(nullptr, ORBFE_ERR_CAPACITY, "max_images %d: more than 2^23 workgroups per launch", p.max_images);
     }
     if (hipSetDevice(p.device) != hipSuccess) { delete ctx; return fail(nullptr, ORBFE_ERR_NO_DEVICE, "hipSetDevice failed"); }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return fail(nullptr, ORBFE_ERR_NO_DEVICE, "hipStreamCreate failed"); }
+    if (hipEventCreateWithFlags(&ctx->ev_latest, hipEventDisableTiming) != hipSuccess) { orbfe_destroy(ctx); return fail(nullptr, ORBFE_ERR_NO_DEVICE, "hipEventCreate failed"); }
     if (ctx->use_octree2 && orbfe_octree2_prepare(ctx->ot2_lds) != 0) ctx->use_octree2 = false;
     if (ctx->use_octree3 && orbfe_octree3_prepare(ctx->ot3_lds, ctx->ot3_nodes_in_hbm) != 0) ctx->use_octree3 = false;
     const DeviceConfig &c = ctx->cfg;
@@ -786,6 +815,7 @@ extern "C" void orbfe_destroy(orbfe_context *ctx)
         if (ctx->ev_join[g]) hipEventDestroy(ctx->ev_join[g]);
     }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_latest) hipEventDestroy(ctx->ev_latest);
     if (ctx->match) orbfe_match_state_destroy(ctx->match);
     if (ctx->bow) orbfe_bow_state_destroy(ctx->bow);
     if (ctx->pose) orbfe_pose_state_destroy(ctx->pose);
@@ -798,6 +828,13 @@ extern "C" void orbfe_destroy(orbfe_context *ctx)
     if (ctx->d_und) hipFree(ctx->d_und);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+extern "C" int orbfe_get_camera(const orbfe_context *ctx, float *cam)
+{
+    if (!ctx || !cam) return ORBFE_ERR_INVALID;
+    cam[0] = ctx->params.fx; cam[1] = ctx->params.fy; cam[2] = ctx->params.cx; cam[3] = ctx->params.cy; cam[4] = ctx->params.bf;
+    return ORBFE_OK;
 }
 
 extern "C" int orbfe_levels(const orbfe_context *ctx) { return ctx ? ctx->cfg.nlevels : ORBFE_ERR_INVALID; }
@@ -831,7 +868,7 @@ static hipStream_t pick_stream(orbfe_context *ctx, void *stream) { return stream
 // enqueue calls run on: wait for the stream of the latest enqueue (and the context's own) first.
 static int wait_latest(orbfe_context *ctx)
 {
-    if (ctx->prof_stream && ctx->prof_stream != ctx->stream) (void)hipStreamSynchronize(ctx->prof_stream); // caller-owned: may be gone
+    if (ctx->latest_foreign) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_latest));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ORBFE_OK;
 }
@@ -843,6 +880,7 @@ extern "C" const char *orbfe_stage_name(int stage) { return stage >= 0 && stage 
 
 extern "C" int orbfe_set_profiling(orbfe_context *ctx, int enabled)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx) return ORBFE_ERR_INVALID;
     if (enabled && ctx->events.empty()) {
         ctx->events.resize((size_t)PROF_RING * ORBFE_MAX_GROUPS * (ORBFE_NUM_STAGES + 1));
@@ -872,12 +910,13 @@ static inline void prof_mark(orbfe_context *ctx, int group, int idx, hipStream_t
 // (with G groups a stage runs as G launches per call, or 7*G for the pyramid).
 extern "C" int orbfe_stage_times(orbfe_context *ctx, float *ms, int *calls, int reset)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || !ms) return ORBFE_ERR_INVALID;
     for (int i = 0; i < ORBFE_NUM_STAGES; i++) ms[i] = 0.f;
     int n = ctx->prof_calls < PROF_RING ? ctx->prof_calls : PROF_RING;
     if (calls) *calls = n;
     if (n > 0) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->prof_stream));
+        { const int rcw = wait_latest(ctx); if (rcw != ORBFE_OK) return rcw; }
         for (int c = 0; c < n; c++)
             for (int g = 0; g < ctx->prof_groups; g++) {
                 const hipEvent_t *ev = &ctx->events[((size_t)c * ORBFE_MAX_GROUPS + g) * (ORBFE_NUM_STAGES + 1)];
@@ -974,7 +1013,8 @@ static int enqueue_batch(orbfe_context *ctx, const uint8_t *d_images, int n_unit
     ctx->last_images = n_images;
     ctx->epoch++;
     ctx->prof_groups = G;
-    ctx->prof_stream = s;
+    ctx->latest_foreign = s != ctx->stream;
+    if (ctx->latest_foreign) HIP_TRY(ctx, hipEventRecord(ctx->ev_latest, s));
     if (ctx->profiling) ctx->prof_calls++;
     return ORBFE_OK;
 }
@@ -987,6 +1027,7 @@ extern "C" int orbfe_quadtree_kernel(const orbfe_context *ctx)
 
 extern "C" int orbfe_set_streams(orbfe_context *ctx, int groups)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || groups < 1 || groups > ORBFE_MAX_GROUPS) return fail(ctx, ORBFE_ERR_INVALID, "groups must be in [1, %d]", ORBFE_MAX_GROUPS);
     if (ctx->profiling) return fail(ctx, ORBFE_ERR_INVALID, "change the stream count before enabling profiling");
     HIP_TRY(ctx, hipSetDevice(ctx->params.device));
@@ -1001,6 +1042,7 @@ extern "C" int orbfe_set_streams(orbfe_context *ctx, int groups)
 
 extern "C" int orbfe_enqueue_extract(orbfe_context *ctx, const uint8_t *d_images, int n_images, void *stream)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || !d_images) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
     if (n_images < 1 || n_images > ctx->params.max_images)
         return fail(ctx, ORBFE_ERR_CAPACITY, "n_images %d outside [1, %d]", n_images, ctx->params.max_images);
@@ -1009,6 +1051,7 @@ extern "C" int orbfe_enqueue_extract(orbfe_context *ctx, const uint8_t *d_images
 
 extern "C" int orbfe_enqueue_stereo(orbfe_context *ctx, const uint8_t *d_images, int n_pairs, void *stream)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || !d_images) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
     if (n_pairs < 1 || 2 * n_pairs > ctx->params.max_images)
         return fail(ctx, ORBFE_ERR_CAPACITY, "n_pairs %d needs max_images >= %d", n_pairs, 2 * n_pairs);
@@ -1031,6 +1074,7 @@ static int resize_input_staging(orbfe_context *ctx, size_t image_bytes)
 
 extern "C" int orbfe_set_rectification(orbfe_context *ctx, int side, const float *map_x, const float *map_y, int src_w, int src_h)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || side < 0 || side > 1) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     DeviceConfig &c = ctx->cfg;
@@ -1076,6 +1120,7 @@ extern "C" int orbfe_set_rectification(orbfe_context *ctx, int side, const float
 
 extern "C" int orbfe_set_input_format(orbfe_context *ctx, int channels, int rgb_order, int legacy_weights)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx) return ORBFE_ERR_INVALID;
     if (channels != 1 && channels != 3 && channels != 4) return fail(ctx, ORBFE_ERR_INVALID, "channels must be 1, 3 or 4");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1096,6 +1141,7 @@ extern "C" int orbfe_set_input_format(orbfe_context *ctx, int channels, int rgb_
 
 extern "C" int orbfe_set_distortion(orbfe_context *ctx, const float *dist, int n)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || (n != 0 && n != 4 && n != 5) || (n > 0 && !dist)) return fail(ctx, ORBFE_ERR_INVALID, "distortion needs 0, 4 or 5 coefficients (k1 k2 p1 p2 [k3])");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cfg.n_dist = n;
@@ -1124,12 +1170,14 @@ static int undistort_on_device(orbfe_context *ctx, const orbfe_keypoint *kps, co
 
 extern "C" int orbfe_undistort_keypoints(orbfe_context *ctx, const orbfe_keypoint *kps, int n, orbfe_keypoint *kps_un)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || n < 0 || (n > 0 && (!kps || !kps_un))) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     return undistort_on_device(ctx, kps, nullptr, n, kps_un);
 }
 
 extern "C" int orbfe_fetch_keys_un(orbfe_context *ctx, int image, orbfe_keypoint *kps_un, int cap, int *n)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || image < 0 || image >= ctx->params.max_images || !n) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     { const int rcw = wait_latest(ctx); if (rcw != ORBFE_OK) return rcw; }
     int cnt = 0;
@@ -1142,6 +1190,7 @@ extern "C" int orbfe_fetch_keys_un(orbfe_context *ctx, int image, orbfe_keypoint
 
 extern "C" int orbfe_image_bounds(orbfe_context *ctx, float *bounds)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || !bounds) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     const float cols = (float)ctx->params.width, rows = (float)ctx->params.height;
     if (ctx->cfg.n_dist == 0 || ctx->cfg.dist[0] == 0.0f) { // src/Frame.cc:455-461
@@ -1161,6 +1210,7 @@ extern "C" int orbfe_image_bounds(orbfe_context *ctx, float *bounds)
 
 extern "C" int orbfe_synchronize(orbfe_context *ctx, void *stream)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx) return ORBFE_ERR_INVALID;
     HIP_TRY(ctx, hipStreamSynchronize(pick_stream(ctx, stream)));
     return ORBFE_OK;
@@ -1168,6 +1218,7 @@ extern "C" int orbfe_synchronize(orbfe_context *ctx, void *stream)
 
 extern "C" int orbfe_fetch_counts(orbfe_context *ctx, int32_t *counts, int n_images)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || !counts || n_images < 1 || n_images > ctx->params.max_images) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     { const int rcw = wait_latest(ctx); if (rcw != ORBFE_OK) return rcw; }
     HIP_TRY(ctx, hipMemcpy(counts, ctx->buf.kp_cnt, sizeof(int32_t) * n_images, hipMemcpyDeviceToHost));
@@ -1177,6 +1228,7 @@ extern "C" int orbfe_fetch_counts(orbfe_context *ctx, int32_t *counts, int n_ima
 extern "C" int orbfe_fetch_batch_async(orbfe_context *ctx, int n_images, orbfe_keypoint *kps, uint8_t *desc, int32_t *counts,
                                        float *u_right, float *depth, void *stream)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || n_images < 1 || n_images > ctx->params.max_images) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     hipStream_t s = pick_stream(ctx, stream);
     const size_t n = (size_t)n_images * ctx->cfg.sel_total;
@@ -1191,6 +1243,7 @@ extern "C" int orbfe_fetch_batch_async(orbfe_context *ctx, int n_images, orbfe_k
 extern "C" int orbfe_fetch_image(orbfe_context *ctx, int image, orbfe_keypoint *kps, uint8_t *desc,
                                  float *u_right, float *depth, int cap, int *n)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || image < 0 || image >= ctx->params.max_images || !n) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     { const int rcw = wait_latest(ctx); if (rcw != ORBFE_OK) return rcw; }
     int cnt = 0, status = 0;
@@ -1211,6 +1264,7 @@ extern "C" int orbfe_fetch_image(orbfe_context *ctx, int image, orbfe_keypoint *
 
 extern "C" int orbfe_debug_timestamps(orbfe_context *ctx, long long *dst, int n)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || !dst || n < 0 || n > 4096) return ORBFE_ERR_INVALID;
     HIP_TRY(ctx, hipMemcpy(dst, ctx->buf.dbg_ts, sizeof(long long) * n, hipMemcpyDeviceToHost));
     return ORBFE_OK;
@@ -1218,6 +1272,7 @@ extern "C" int orbfe_debug_timestamps(orbfe_context *ctx, long long *dst, int n)
 
 extern "C" int orbfe_device_buffers(orbfe_context *ctx, void **kps, void **desc, void **counts, void **u_right, void **depth)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx) return ORBFE_ERR_INVALID;
     if (kps) *kps = ctx->buf.kps;
     if (desc) *desc = ctx->buf.desc;
@@ -1296,6 +1351,8 @@ static int download_frame(orbfe_context *ctx, int nimg, bool with_depth)
         HIP_TRY(ctx, hipMemcpyAsync(ho + o.depth, ctx->buf.depth, sizeof(float) * st, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    ctx->slot_cnt.assign((const int *)(ho + o.cnt), (const int *)(ho + o.cnt) + nimg);
+    ctx->slot_cnt_epoch = ctx->epoch;
     return ORBFE_OK;
 }
 
@@ -1320,6 +1377,7 @@ static int hand_over(orbfe_context *ctx, int image, orbfe_keypoint *kps, uint8_t
 extern "C" int orbfe_extract(orbfe_context *ctx, const uint8_t *img, int w, int h, size_t stride,
                              orbfe_keypoint *kps, uint8_t *desc, int cap, int *n)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || !n) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
     if (!img || w <= 0 || h <= 0) { *n = 0; return ORBFE_OK; } // _image.empty(): src/ORBextractor.cc:861-862
     int rc = ensure_host_stage(ctx, false);
@@ -1339,6 +1397,7 @@ extern "C" int orbfe_stereo_frame(orbfe_context *ctx, const uint8_t *left, const
                                   orbfe_keypoint *kps_right, uint8_t *desc_right, int *n_right,
                                   float *u_right, float *depth, int cap)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || !n_left || !n_right) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
     if (!left || !right || w <= 0 || h <= 0) { *n_left = 0; *n_right = 0; return ORBFE_OK; }
     if (ctx->params.max_images < 2) return fail(ctx, ORBFE_ERR_CAPACITY, "stereo needs max_images >= 2");
@@ -1405,6 +1464,7 @@ extern "C" int orbfe_rgbd_frame(orbfe_context *ctx, const uint8_t *gray, const f
                                 orbfe_keypoint *kps, uint8_t *desc, int *n,
                                 float *u_right, float *depth, int cap)
 {
+    ORBFE_ENTRY(ctx);
     return rgbd_frame_impl(ctx, gray, depth_img, sizeof(float), 1.0f, w, h, gray_stride, depth_stride, kps, desc, n, u_right, depth, cap);
 }
 
@@ -1413,11 +1473,13 @@ extern "C" int orbfe_rgbd_frame_u16(orbfe_context *ctx, const uint8_t *gray, con
                                     orbfe_keypoint *kps, uint8_t *desc, int *n,
                                     float *u_right, float *depth, int cap)
 {
+    ORBFE_ENTRY(ctx);
     return rgbd_frame_impl(ctx, gray, depth_img, sizeof(uint16_t), depth_map_factor, w, h, gray_stride, depth_stride, kps, desc, n, u_right, depth, cap);
 }
 
 extern "C" int orbfe_fetch_pyramid(orbfe_context *ctx, int image, int level, int blurred, uint8_t *dst, size_t dst_stride)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || !dst || image < 0 || image >= ctx->params.max_images || level < 0 || level >= ctx->cfg.nlevels)
         return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     { const int rcw = wait_latest(ctx); if (rcw != ORBFE_OK) return rcw; }
@@ -1442,6 +1504,7 @@ extern "C" int orbfe_fetch_pyramid(orbfe_context *ctx, int image, int level, int
 extern "C" int orbfe_fetch_candidates(orbfe_context *ctx, int image, int level, int32_t *xs, int32_t *ys,
                                       int32_t *scores, int cap, int *n)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || !n || image < 0 || image >= ctx->params.max_images || level < 0 || level >= ctx->cfg.nlevels)
         return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     { const int rcw = wait_latest(ctx); if (rcw != ORBFE_OK) return rcw; }
@@ -1470,6 +1533,7 @@ extern "C" int orbfe_fetch_candidates(orbfe_context *ctx, int image, int level, 
 
 extern "C" int orbfe_hamming_matrix(orbfe_context *ctx, const uint8_t *desc_a, int na, const uint8_t *desc_b, int nb, int32_t *dist)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || !desc_a || !desc_b || !dist || na < 0 || nb < 0) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     if (na == 0 || nb == 0) return ORBFE_OK;
     const size_t need = (size_t)32 * na + (size_t)32 * nb + sizeof(int) * (size_t)na * nb;

@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void pair_hamming_kernel(const uint8_t *__rest
 // fbow::Vocabulary::fromStream (fbow.cpp:181-191) from a memory blob; the tree goes to HBM.
 extern "C" int orbfe_vocab_load(orbfe_context *ctx, const uint8_t *blob, size_t size)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || !blob) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
     orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
     if (!st) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "out of host memory");
@@ -192,6 +193,7 @@ extern "C" int orbfe_vocab_load(orbfe_context *ctx, const uint8_t *blob, size_t 
 extern "C" int orbfe_bow_transform(orbfe_context *ctx, const uint8_t *desc, int n, int level,
                                    uint32_t *word_id, float *weight, uint32_t *node_id)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || n < 0 || level < 0 || (n > 0 && (!desc || !word_id || !weight || !node_id))) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
     if (!st || !st->loaded) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "no vocabulary loaded (orbfe_vocab_load)");
@@ -359,6 +361,7 @@ extern "C" int orbfe_search_by_bow(orbfe_context *ctx,
                                    const uint8_t *f_desc, const float *f_angle, int n_f,
                                    float nnratio, int check_ori, int32_t *f_match, int *nmatches)
 {
+    ORBFE_ENTRY(ctx);
     return search_by_bow_impl(ctx, false, kf_nodes, kf_off, kf_feat, kf_nnodes, kf_valid, kf_desc, kf_angle, n_kf,
                               f_nodes, f_off, f_feat, f_nnodes, nullptr, f_desc, f_angle, n_f, nnratio, check_ori, f_match, nmatches);
 }
@@ -370,6 +373,7 @@ extern "C" int orbfe_search_by_bow_kf(orbfe_context *ctx,
                                       const int32_t *valid2, const uint8_t *desc2, const float *angle2, int n2,
                                       float nnratio, int check_ori, int32_t *match12, int *nmatches)
 {
+    ORBFE_ENTRY(ctx);
     return search_by_bow_impl(ctx, true, nodes1, off1, feat1, nnodes1, valid1, desc1, angle1, n1,
                               nodes2, off2, feat2, nnodes2, valid2, desc2, angle2, n2, nnratio, check_ori, match12, nmatches);
 }
@@ -443,6 +447,7 @@ __global__ __launch_bounds__(256) void kfdb_score_kernel(const uint32_t *__restr
 
 extern "C" int orbfe_kfdb_clear(orbfe_context *ctx)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx) return ORBFE_ERR_INVALID;
     orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
     if (!st) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "out of host memory");
@@ -452,6 +457,7 @@ extern "C" int orbfe_kfdb_clear(orbfe_context *ctx)
 
 extern "C" int orbfe_kfdb_add(orbfe_context *ctx, const uint32_t *words, const float *weights, int n, int *kf_index)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || n < 0 || (n > 0 && (!words || !weights))) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
     orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
     if (!st) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "out of host memory");
@@ -517,6 +523,7 @@ static int kfdb_compact(orbfe_context *ctx, orbfe_bow_state *st)
 
 extern "C" int orbfe_kfdb_erase(orbfe_context *ctx, int kf_index)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx) return ORBFE_ERR_INVALID;
     orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
     if (!st || kf_index < 0 || kf_index >= (int)st->db_len.size()) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "keyframe index out of range");
@@ -533,6 +540,7 @@ extern "C" int orbfe_kfdb_erase(orbfe_context *ctx, int kf_index)
 
 extern "C" int orbfe_kfdb_size(orbfe_context *ctx)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx) return 0;
     orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
     return st ? (int)st->db_off.size() : 0;
@@ -581,6 +589,7 @@ static int kfdb_scores(orbfe_context *ctx, orbfe_bow_state *st, const uint32_t *
 
 extern "C" int orbfe_kfdb_score(orbfe_context *ctx, const uint32_t *q_words, const float *q_w, int nq, int32_t *common, float *score)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || nq < 0 || (nq > 0 && (!q_words || !q_w))) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
     orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
     if (!st) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "out of host memory");
@@ -596,6 +605,7 @@ extern "C" int orbfe_detect_reloc_candidates(orbfe_context *ctx, const uint32_t 
                                              const int32_t *covis_off, const int32_t *covis_idx, float *reloc_score,
                                              int32_t *cand, int cap, int *n_cand)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || !n_cand || nq < 0 || (nq > 0 && (!q_words || !q_w)) || !covis_off || !reloc_score || cap < 0 || (cap > 0 && !cand))
         return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
     orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
@@ -659,6 +669,7 @@ extern "C" int orbfe_detect_loop_candidates(orbfe_context *ctx, const uint32_t *
                                             const int32_t *covis_off, const int32_t *covis_idx,
                                             int32_t *cand, int cap, int *n_cand)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || !n_cand || nq < 0 || (nq > 0 && (!q_words || !q_w)) || !covis_off || cap < 0 || (cap > 0 && !cand))
         return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
     orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
@@ -741,6 +752,7 @@ extern "C" int orbfe_search_for_triangulation(orbfe_context *ctx,
                                               const float *F12, const float *Cw1, const float *T2w, float fx2, float fy2, float cx2, float cy2,
                                               int only_stereo, int check_ori, int32_t *match12, int *nmatches)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || !nmatches || n1 < 0 || n2 < 0 || nnodes1 < 0 || nnodes2 < 0 || (n1 > 0 && !match12) || !F12 || !Cw1 || !T2w ||
         (nnodes1 > 0 && (!nodes1 || !off1 || !feat1 || !keys1 || !u_right1 || !has_mp1 || !desc1)) ||
         (nnodes2 > 0 && (!nodes2 || !off2 || !feat2 || !keys2 || !u_right2 || !has_mp2 || !desc2)))

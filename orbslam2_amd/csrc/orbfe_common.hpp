@@ -61,7 +61,7 @@ __device__ __forceinline__ bool xcd_map(int blocks_per_unit, int n_units, int &u
 {
     const int lg = xcd_split_log2(n_units), xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int per_xcd = (blocks_per_unit + (1 << lg) - 1) >> lg;
-    const int round = small_div(jb, per_xcd); // jb < 2^21: at most 2^24 blocks per launch
+    const int round = small_div(jb, per_xcd); // jb < 2^21: at most 2^24 blocks per launch (orbfe_create refuses blocks x images >= 2^23)
     unit = round * (8 >> lg) + (xcd >> lg);
     blk = ((jb - round * per_xcd) << lg) + (xcd & ((1 << lg) - 1));
     return unit < n_units && blk < blocks_per_unit;

@@ -1,6 +1,7 @@
 // orbfe_host.h -- internal host-side accessors shared by the translation units of liborbfe.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include "../../include/orbfe.h"
 
 // growable device scratch buffer shared by the host-side entry points (matchers, BoW, pose)
@@ -27,6 +28,14 @@ orbfe_match_state *orbfe_match_state_create();
 void orbfe_match_state_destroy(orbfe_match_state *s);
 
 int orbfe_fail(orbfe_context *ctx, int code, const char *fmt, ...);
+// Every entry point that takes a (non-const) context holds the context's mutex for its whole duration: the reference's
+// Tracking, LocalMapping and LoopClosing threads each construct ORBmatcher objects (src/LocalMapping.cc:215,482,
+// src/LoopClosing.cc:275,623) and the shim gives them all the left extractor's context, whose matcher / BoW / database state
+// (pinned staging, growable device buffers, grid cache, the stream) is single-user.  Recursive: entry points call each other.
+std::recursive_mutex &orbfe_ctx_mutex(orbfe_context *ctx);
+#define ORBFE_ENTRY(ctx)                                  \
+    std::unique_lock<std::recursive_mutex> orbfe_entry_lock_; \
+    if (ctx) orbfe_entry_lock_ = std::unique_lock<std::recursive_mutex>(orbfe_ctx_mutex(ctx))
 orbfe_match_state *orbfe_ctx_match_state(orbfe_context *ctx);
 hipStream_t orbfe_ctx_stream(orbfe_context *ctx);
 int orbfe_ctx_device(const orbfe_context *ctx);
@@ -37,8 +46,9 @@ struct DeviceConfig;
 struct DeviceBuffers;
 const DeviceConfig *orbfe_ctx_config(const orbfe_context *ctx);
 const DeviceBuffers *orbfe_ctx_buffers(const orbfe_context *ctx);
+int orbfe_ctx_slot_count(orbfe_context *ctx, int slot, int *cnt); // keypoints in image slot `slot` of the latest extraction call
 unsigned orbfe_ctx_epoch(const orbfe_context *ctx);          // counts the extraction calls enqueued on this context
-int orbfe_ctx_wait_foreign_stream(orbfe_context *ctx);      // waits for the latest extraction if it ran on a caller's stream
+int orbfe_ctx_wait_foreign_stream(orbfe_context *ctx);      // makes the context's stream wait for the latest extraction call (event, no host wait)
 
 struct orbfe_bow_state;
 orbfe_bow_state *orbfe_bow_state_create();

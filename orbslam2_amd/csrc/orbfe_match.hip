@@ -317,7 +317,11 @@ static int run_window_queries(orbfe_context *ctx, const orbfe_frame_view *fv, co
         if (slot >= orbfe_ctx_params(ctx)->max_images) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "device slot %d out of range", slot);
         int rc = orbfe_ctx_wait_foreign_stream(ctx); // the extraction may have been enqueued on a caller stream
         if (rc != ORBFE_OK) return rc;
-        if (n > cfg->sel_total) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "frame view holds %d keypoints, a device slot at most %d", n, cfg->sel_total);
+        // a stale or mismatched view would silently match against another frame's leftovers: the view's count must be the slot's
+        int slot_n = 0;
+        rc = orbfe_ctx_slot_count(ctx, slot, &slot_n);
+        if (rc != ORBFE_OK) return rc;
+        if (n != slot_n) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "frame view holds %d keypoints, device slot %d holds %d (not the latest extraction?)", n, slot, slot_n);
     }
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t fn = resident ? 0 : (size_t)n; // frame rows in the upload block
@@ -478,6 +482,7 @@ static int check_view(orbfe_context *ctx, const orbfe_frame_view *fv)
 extern "C" int orbfe_features_in_area(orbfe_context *ctx, const orbfe_frame_view *fv, float x, float y, float r,
                                       int min_level, int max_level, int32_t *out, int cap, int *n)
 {
+    ORBFE_ENTRY(ctx);
     int rc = check_view(ctx, fv);
     if (rc != ORBFE_OK) return rc;
     if (!n) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
@@ -496,11 +501,36 @@ extern "C" int orbfe_features_in_area(orbfe_context *ctx, const orbfe_frame_view
     return ORBFE_OK;
 }
 
+// Frame::AssignFeaturesToGrid (src/Frame.cc:231-246): mGrid as CSR.  The grid is the one every matcher call on this frame uses
+// (built by the same kernels; for a device-resident frame it stays cached for the calls that follow).
+extern "C" int orbfe_assign_features_to_grid(orbfe_context *ctx, const orbfe_frame_view *fv, int32_t *cell_off, int32_t *cell_idx)
+{
+    ORBFE_ENTRY(ctx);
+    int rc = check_view(ctx, fv);
+    if (rc != ORBFE_OK) return rc;
+    if (!cell_off || (fv->n > 0 && !cell_idx)) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    const int ncell = GRID_COLS * GRID_ROWS;
+    if (fv->n == 0) { memset(cell_off, 0, sizeof(int32_t) * (ncell + 1)); return ORBFE_OK; }
+    std::vector<MatchQuery> q(1);
+    q[0] = MatchQuery{0.f, 0.f, 0.f, -1, -1, 0.f, 0.f, 0}; // flags 0: no window is searched, the call only builds the grid
+    std::vector<uint8_t> qd(32, 0);
+    rc = run_window_queries(ctx, fv, q, qd);
+    if (rc != ORBFE_OK) return rc;
+    orbfe_match_state *st = match_state(ctx);
+    const int *d_off = (const int *)st->cells.p + ncell;
+    MTRY(ctx, hipMemcpy(cell_off, d_off, sizeof(int) * (ncell + 1), hipMemcpyDeviceToHost));
+    const int total = cell_off[ncell]; // keypoints that fell inside the grid (PosInGrid drops the others)
+    if (total < 0 || total > fv->n) return orbfe_fail(ctx, ORBFE_ERR_HIP, "grid holds %d entries for %d keypoints", total, fv->n);
+    if (total > 0) MTRY(ctx, hipMemcpy(cell_idx, d_off + ncell + 1, sizeof(int) * total, hipMemcpyDeviceToHost));
+    return ORBFE_OK;
+}
+
 // Many GetFeaturesInArea queries against one frame: the frame is uploaded and its grid built once.
 extern "C" int orbfe_features_in_area_batch(orbfe_context *ctx, const orbfe_frame_view *fv, int nq, const float *x, const float *y,
                                             const float *r, const int32_t *min_level, const int32_t *max_level,
                                             int32_t *out_off, int32_t *out, int cap)
 {
+    ORBFE_ENTRY(ctx);
     int rc = check_view(ctx, fv);
     if (rc != ORBFE_OK) return rc;
     if (nq < 0 || !out_off || (nq > 0 && (!x || !y || !r))) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
@@ -534,6 +564,7 @@ extern "C" int orbfe_search_by_projection_last(orbfe_context *ctx, const orbfe_f
                                                const uint8_t *cur_has_obs, float th, int mono, int check_ori,
                                                int32_t *cur_match, int *nmatches)
 {
+    ORBFE_ENTRY(ctx);
     int rc = check_view(ctx, cur);
     if (rc != ORBFE_OK) return rc;
     if (!Tcw_cur || !Tcw_last || !cur_match || !nmatches || n_last < 0 ||
@@ -575,6 +606,7 @@ extern "C" int orbfe_is_in_frustum(orbfe_context *ctx, const float *Tcw, float m
                                    int n, const float *pos, const float *normal, const float *max_distance,
                                    const float *min_distance, float viewing_cos_limit, orbfe_track_point *out)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || !Tcw || n < 0 || (n > 0 && (!pos || !normal || !max_distance || !min_distance || !out)))
         return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
     const orbfe_params *P = orbfe_ctx_params(ctx);
@@ -590,6 +622,7 @@ extern "C" int orbfe_search_by_projection_points(orbfe_context *ctx, const orbfe
                                                  const uint8_t *cur_has_obs, float th, float nnratio,
                                                  int32_t *cur_match, int *nmatches)
 {
+    ORBFE_ENTRY(ctx);
     int rc = check_view(ctx, cur);
     if (rc != ORBFE_OK) return rc;
     if (!cur_match || !nmatches || n_pts < 0 || (n_pts > 0 && (!pts || !pt_desc || !pt_obs))) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
@@ -622,6 +655,7 @@ extern "C" int orbfe_search_by_projection_kf(orbfe_context *ctx, const orbfe_fra
                                              const uint8_t *cur_has_point, float th, int orb_dist, int check_ori,
                                              int32_t *cur_match, int *nmatches)
 {
+    ORBFE_ENTRY(ctx);
     int rc = check_view(ctx, cur);
     if (rc != ORBFE_OK) return rc;
     if (!Tcw_cur || !cur_match || !nmatches || n_kf < 0 ||
@@ -656,6 +690,7 @@ extern "C" int orbfe_fuse(orbfe_context *ctx, const orbfe_frame_view *kf, const 
                           const float *pos, const float *normal, const float *max_distance, const float *min_distance,
                           const uint8_t *pt_desc, const int32_t *pt_valid, float th, int32_t *best_idx, int *n_fused)
 {
+    ORBFE_ENTRY(ctx);
     int rc = check_view(ctx, kf);
     if (rc != ORBFE_OK) return rc;
     if (!Tcw || !n_fused || n_pts < 0 || (n_pts > 0 && (!pos || !normal || !max_distance || !min_distance || !pt_desc || !pt_valid || !best_idx)))
@@ -801,6 +836,7 @@ extern "C" int orbfe_search_by_projection_sim3(orbfe_context *ctx, const orbfe_f
                                                const uint8_t *pt_desc, const int32_t *pt_valid, const uint8_t *kf_matched, float th,
                                                int32_t *pt_match, int *nmatches)
 {
+    ORBFE_ENTRY(ctx);
     return sim3_projection_impl(ctx, 0, kf, Scw, n_pts, pos, normal, max_distance, min_distance, pt_desc, pt_valid, kf_matched, th, pt_match, nmatches);
 }
 
@@ -808,6 +844,7 @@ extern "C" int orbfe_fuse_sim3(orbfe_context *ctx, const orbfe_frame_view *kf, c
                                const float *pos, const float *normal, const float *max_distance, const float *min_distance,
                                const uint8_t *pt_desc, const int32_t *pt_valid, float th, int32_t *best_idx, int *n_fused)
 {
+    ORBFE_ENTRY(ctx);
     return sim3_projection_impl(ctx, 1, kf, Scw, n_pts, pos, normal, max_distance, min_distance, pt_desc, pt_valid, nullptr, th, best_idx, n_fused);
 }
 
@@ -863,6 +900,7 @@ extern "C" int orbfe_search_by_sim3(orbfe_context *ctx,
                                     const float *min_distance2, const uint8_t *pt_desc2, const int32_t *valid2,
                                     float s12, const float *R12, const float *t12, float th, int32_t *match12, int *n_found)
 {
+    ORBFE_ENTRY(ctx);
     int rc = check_view(ctx, kf1);
     if (rc != ORBFE_OK) return rc;
     rc = check_view(ctx, kf2);
@@ -901,6 +939,7 @@ extern "C" int orbfe_search_for_initialization(orbfe_context *ctx, const orbfe_f
                                                float *prev_matched, int window_size, float nnratio, int check_ori,
                                                int32_t *matches12, int *nmatches)
 {
+    ORBFE_ENTRY(ctx);
     int rc = check_view(ctx, f2);
     if (rc != ORBFE_OK) return rc;
     if (!f1 || f1->n < 0 || (f1->n > 0 && (!f1->keys_un || !f1->descriptors || !prev_matched)) || !matches12 || !nmatches)

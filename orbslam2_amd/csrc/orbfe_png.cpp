@@ -20,6 +20,9 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <exception>
+#include <new>
+#include <system_error>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -97,7 +100,7 @@ int parse(const uint8_t *file, size_t size, Chunks &c, bool want_data)
             c.n_palette = (int)(len / 3);
             memcpy(c.palette, data, len);
         } else if (memcmp(type, "tRNS", 4) == 0) {
-            if (c.hd.color == 3) { c.n_trns = (int)(len > 256 ? 256 : len); memcpy(c.trns_alpha, data, (size_t)c.n_trns); c.hd.has_trns = true; }
+            if (c.hd.color == 3) { c.n_trns = (int)(len > 256 ? 256 : len); memcpy(c.trns_alpha, data, (size_t)c.n_trns); c.hd.has_trns = c.n_trns > 0; } // libpng: num_trans == 0 -> no alpha
             else if (c.hd.color == 2 && len == 6) { for (int k = 0; k < 3; k++) c.trns_key[k] = (uint16_t)((data[2 * k] << 8) | data[2 * k + 1]); c.hd.has_trns = true; }
             // grey + tRNS: cv::imread keeps one channel (readHeader only looks at tRNS for RGB / palette images)
         } else if (memcmp(type, "IDAT", 4) == 0) {
@@ -284,7 +287,7 @@ int decode(const uint8_t *file, size_t size, uint8_t *dst, size_t dst_stride, Pn
 extern "C" const char *orbfe_png_last_error(void) { return t_err; }
 
 extern "C" int orbfe_png_info(const uint8_t *file, size_t size, int *width, int *height, int *channels, int *bit_depth)
-{
+try {
     Chunks c;
     const int rc = parse(file, size, c, false);
     if (rc != ORBFE_OK) return rc;
@@ -293,11 +296,18 @@ extern "C" int orbfe_png_info(const uint8_t *file, size_t size, int *width, int 
     if (channels) *channels = c.hd.out_channels;
     if (bit_depth) *bit_depth = c.hd.out_depth;
     return ORBFE_OK;
+} catch (const std::bad_alloc &) {
+    return png_fail("out of host memory");
+} catch (const std::exception &e) {
+    snprintf(t_err, sizeof(t_err), "%s", e.what());
+    return ORBFE_ERR_INVALID;
+} catch (...) {
+    return png_fail("unexpected exception");
 }
 
 extern "C" int orbfe_png_decode(const uint8_t *file, size_t size, uint8_t *dst, size_t dst_bytes, size_t dst_stride,
                                 int *width, int *height, int *channels, int *bit_depth)
-{
+try {
     if (!dst) return png_fail("null destination");
     Chunks c;
     int rc = parse(file, size, c, false);
@@ -312,13 +322,20 @@ extern "C" int orbfe_png_decode(const uint8_t *file, size_t size, uint8_t *dst, 
     if (channels) *channels = hd.out_channels;
     if (bit_depth) *bit_depth = hd.out_depth;
     return ORBFE_OK;
+} catch (const std::bad_alloc &) {
+    return png_fail("out of host memory");
+} catch (const std::exception &e) {
+    snprintf(t_err, sizeof(t_err), "%s", e.what());
+    return ORBFE_ERR_INVALID;
+} catch (...) {
+    return png_fail("unexpected exception");
 }
 
 // n files of one common geometry (a camera stream), one image per worker thread, into dst[i * image_bytes ..]: what feeds a
 // batched orbfe_enqueue_* call.  Returns the first error (the other images are still decoded).
 extern "C" int orbfe_png_decode_batch(const uint8_t *const *files, const size_t *sizes, int n, uint8_t *dst, size_t image_bytes,
                                       int width, int height, int channels, int bit_depth, int threads)
-{
+try {
     if (!files || !sizes || !dst || n < 0 || width < 1 || height < 1) return png_fail("bad argument");
     const size_t need = (size_t)width * height * channels * (bit_depth / 8);
     if (image_bytes < need) { snprintf(t_err, sizeof(t_err), "image_bytes smaller than one decoded image"); return ORBFE_ERR_CAPACITY; }
@@ -329,12 +346,16 @@ extern "C" int orbfe_png_decode_batch(const uint8_t *const *files, const size_t 
             const int i = next.fetch_add(1);
             if (i >= n) return;
             int w = 0, h = 0, ch = 0, bd = 0;
-            int rc = orbfe_png_info(files[i], sizes[i], &w, &h, &ch, &bd);
+            int rc = orbfe_png_info(files[i], sizes[i], &w, &h, &ch, &bd); // catches its own exceptions
             if (rc == ORBFE_OK && (w != width || h != height || ch != channels || bd != bit_depth)) {
                 snprintf(t_err, sizeof(t_err), "image %d is %dx%d x%d channels x%d bit, the batch expects %dx%d x%d x%d", i, w, h, ch, bd, width, height, channels, bit_depth);
                 rc = ORBFE_ERR_UNSUPPORTED;
             }
-            if (rc == ORBFE_OK) rc = decode(files[i], sizes[i], dst + (size_t)i * image_bytes, 0, nullptr);
+            if (rc == ORBFE_OK) {
+                try { rc = decode(files[i], sizes[i], dst + (size_t)i * image_bytes, 0, nullptr); } // a worker must not throw: std::terminate
+                catch (const std::bad_alloc &) { rc = png_fail("out of host memory"); }
+                catch (...) { rc = png_fail("unexpected exception"); }
+            }
             int expected = ORBFE_OK;
             if (rc != ORBFE_OK && first_err.compare_exchange_strong(expected, rc)) snprintf(err_msg, sizeof(err_msg), "%s", t_err);
         }
@@ -342,12 +363,23 @@ extern "C" int orbfe_png_decode_batch(const uint8_t *const *files, const size_t 
     int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
     if (nt < 1) nt = 1;
     if (nt > n) nt = n > 0 ? n : 1;
+    if (nt > 64) nt = 64; // threads = 0 on a large host: one image per worker is all the parallelism there is
     if (nt == 1) work();
     else {
         std::vector<std::thread> pool;
-        for (int t = 0; t < nt; t++) pool.emplace_back(work);
+        pool.reserve(nt);
+        try { for (int t = 0; t < nt; t++) pool.emplace_back(work); }
+        catch (const std::system_error &) {} // fewer workers than asked for: the ones that started (or this thread) finish the queue
+        if (pool.empty()) work();
         for (auto &t : pool) t.join();
     }
     if (first_err.load() != ORBFE_OK) snprintf(t_err, sizeof(t_err), "%s", err_msg);
     return first_err.load();
+} catch (const std::bad_alloc &) {
+    return png_fail("out of host memory");
+} catch (const std::exception &e) {
+    snprintf(t_err, sizeof(t_err), "%s", e.what());
+    return ORBFE_ERR_INVALID;
+} catch (...) {
+    return png_fail("unexpected exception");
 }

@@ -705,6 +705,7 @@ extern "C" int orbfe_enqueue_pose_optimization(orbfe_context *ctx, int n_problem
                                                const float *d_Xw, float *d_Tcw, uint8_t *d_outlier, int32_t *d_n_inliers,
                                                int max_keypoints, void *stream)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || n_problems < 0) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     if (n_problems == 0) return ORBFE_OK;
     if (!d_offsets || !d_keys_un || !d_u_right || !d_has_point || !d_Xw || !d_Tcw || !d_outlier || !d_n_inliers)
@@ -750,6 +751,7 @@ extern "C" int orbfe_pose_optimization_batch(orbfe_context *ctx, int n_problems,
                                              const orbfe_keypoint *keys_un, const float *u_right, const uint8_t *has_point,
                                              const float *Xw, uint8_t *outlier, int32_t *n_inliers)
 {
+    ORBFE_ENTRY(ctx);
     if (!ctx || n_problems < 0) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     if (n_problems == 0) return ORBFE_OK;
     if (!offsets || !Tcw || !outlier || !n_inliers) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
@@ -809,6 +811,7 @@ extern "C" int orbfe_pose_optimization_batch(orbfe_context *ctx, int n_problems,
 extern "C" int orbfe_pose_optimization(orbfe_context *ctx, float *Tcw, int n, const orbfe_keypoint *keys_un, const float *u_right,
                                        const uint8_t *has_point, const float *Xw, uint8_t *outlier, int *n_inliers)
 {
+    ORBFE_ENTRY(ctx);
     if (!n_inliers || n < 0) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     const int32_t off[2] = {0, n};
     int32_t ninl = 0;

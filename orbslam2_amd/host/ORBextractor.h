@@ -16,6 +16,7 @@
 //    (the reference's own ComputeStereoMatches needs it; orbfe_stereo_frame does not).
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -81,8 +82,11 @@ public:
 
     ~ORBextractor()
     {
-        if (mCtx && DefaultContext() == mCtx) DefaultContext() = nullptr;
-        if (mCtx) orbfe_destroy(mCtx);
+        if (mCtx) {
+            orbfe_context *mine = mCtx;
+            DefaultSlot().compare_exchange_strong(mine, nullptr); // only if the default is still this extractor's
+            orbfe_destroy(mCtx);
+        }
     }
     ORBextractor(const ORBextractor &) = delete;
     ORBextractor &operator=(const ORBextractor &) = delete;
@@ -118,17 +122,22 @@ public:
     }
 
     // Identity of the frame that currently sits in image slot 0 of the device context (the latest extraction): keypoint count +
-    // a hash of its first descriptors.  The reference-signature ORBmatcher (compat/ORBmatcher.cc) compares a Frame against it to
-    // decide whether the matchers may read that frame in HBM (orbfe_frame_view.device_slot_plus1) instead of uploading it.
+    // a hash of ALL its descriptors (8 bytes per step: a few microseconds for 2000 keypoints).  The reference-signature shims
+    // (compat/ORBmatcher.cc, compat/Frame.cc) compare a Frame against it to decide whether the matchers may read that frame in
+    // HBM (orbfe_frame_view.device_slot_plus1) instead of uploading it; the library additionally refuses a view whose count is
+    // not the slot's.  `kind` says what else the slot holds: 1 = mvuRight / mvDepth of orbfe_stereo_frame, 2 = of orbfe_rgbd_frame.
     static uint64_t FrameFingerprint(int n, const uint8_t *descriptors)
     {
         uint64_t h = 1469598103934665603ull ^ (uint64_t)(uint32_t)n;
-        const int bytes = (n < 8 ? n : 8) * 32;
-        for (int i = 0; i < bytes; i++) { h ^= descriptors[i]; h *= 1099511628211ull; }
+        const size_t words = (size_t)n * 4;
+        for (size_t i = 0; i < words; i++) { uint64_t w; std::memcpy(&w, descriptors + 8 * i, 8); h = (h ^ w) * 1099511628211ull; h ^= h >> 29; }
         return h;
     }
     bool IsResidentFrame(int n, const uint8_t *descriptors) const { return mCtx && n > 0 && mResidentN == n && mResidentFp == FrameFingerprint(n, descriptors); }
-    void NoteResidentFrame(int n, const uint8_t *descriptors) { mResidentN = n; mResidentFp = n > 0 ? FrameFingerprint(n, descriptors) : 0; }
+    void NoteResidentFrame(int n, const uint8_t *descriptors, int kind = 0) { mResidentN = n; mResidentFp = n > 0 ? FrameFingerprint(n, descriptors) : 0; mResidentKind = kind; }
+    int ResidentKind() const { return mResidentKind; }
+    const orbfe_params &Params() const { return mParams; } // the eight constructor arguments (+ what the context was bound to)
+    const CameraParams &Camera() const { return mCam; }
 
     int inline GetLevels() { return mParams.nlevels; }
     float inline GetScaleFactor() { return (float)(double)mParams.scale_factor; }
@@ -198,15 +207,22 @@ public:
         const int rc = orbfe_create(&mParams, &mCtx);
         if (rc != ORBFE_OK) throw std::runtime_error(std::string("orbfe_create: ") + orbfe_last_error(nullptr));
         if (!mCam.distCoef.empty()) Check(orbfe_set_distortion(mCtx, mCam.distCoef.data(), (int)mCam.distCoef.size()));
-        DefaultContext() = mCtx;
+        orbfe_context *none = nullptr;
+        DefaultSlot().compare_exchange_strong(none, mCtx); // first context of the process, unless SetAsDefault() chose one
     }
 
-    // The context of the extractor created last in this process: what the keyframe-only ORBmatcher overloads (no Frame at
-    // hand to reach mpORBextractorLeft) and KeyFrameDatabase use.  A SLAM system has one left extractor (src/Tracking.cc:125).
-    static orbfe_context *&DefaultContext()
+    // The process-wide default context: what the keyframe-only ORBmatcher overloads (no Frame at hand to reach
+    // mpORBextractorLeft), KeyFrameDatabase and Optimizer use.  It is the FIRST device context created in the process (Tracking
+    // news the left extractor first, src/Tracking.cc:125, and Frame's stereo constructor touches the left one first) and never
+    // changes behind a caller's back; an integration that wants to be explicit calls mpORBextractorLeft->SetAsDefault() after
+    // BindImageSize().  The keyframe-side entry points project with the context's camera, so the shims check it against
+    // pKF->fx ... (compat/ORBmatcher.cc: kf_context) instead of trusting this choice.  Atomic: in mode A of INTEGRATION.md the
+    // two extractors create their contexts on two threads (src/Frame.cc:78-81).
+    static orbfe_context *DefaultContext() { return DefaultSlot().load(); }
+    void SetAsDefault()
     {
-        static orbfe_context *ctx = nullptr;
-        return ctx;
+        if (!mCtx) throw std::logic_error("ORBextractor::SetAsDefault before the device context exists (call BindImageSize first)");
+        DefaultSlot().store(mCtx);
     }
 
     // Frame::UndistortKeyPoints (src/Frame.cc:402-432) and ComputeImageBounds (:434-462) for this camera
@@ -225,6 +241,11 @@ public:
     void SetInputChannels(int channels) { Check(orbfe_set_input_format(mCtx, channels, mCam.rgb ? 1 : 0, 0)); }
 
 protected:
+    static std::atomic<orbfe_context *> &DefaultSlot()
+    {
+        static std::atomic<orbfe_context *> slot(nullptr);
+        return slot;
+    }
     void Check(int rc)
     {
         if (rc != ORBFE_OK) throw std::runtime_error(std::string("orbfe: ") + orbfe_last_error(mCtx));
@@ -247,6 +268,7 @@ protected:
     orbfe_context *mCtx = nullptr;
     bool mKeepPyramid = false;
     int mResidentN = -1;
+    int mResidentKind = 0;
     uint64_t mResidentFp = 0;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
 };
@@ -279,7 +301,7 @@ inline void ComputeStereoFrame(ORBextractor &extractorLeft, const ImageView &imL
                                       out.mvuRight.data(), out.mvDepth.data(), cap);
     if (rc != ORBFE_OK) throw std::runtime_error(std::string("orbfe_stereo_frame: ") + orbfe_last_error(ctx));
     out.N = nl;
-    extractorLeft.NoteResidentFrame(nl, out.mDescriptors.data());
+    extractorLeft.NoteResidentFrame(nl, out.mDescriptors.data(), 1);
     out.mvKeys.resize(nl); out.mDescriptors.resize((size_t)nl * 32);
     out.mvKeysRight.resize(nr); out.mDescriptorsRight.resize((size_t)nr * 32);
     out.mvuRight.resize(nl); out.mvDepth.resize(nl);
@@ -314,7 +336,7 @@ inline void ComputeRGBDFrame(ORBextractor &extractor, const ImageView &imGray, c
     if (orbfe_fetch_keys_un(ctx, 0, out.mvKeysUn.data(), cap, &n2) != ORBFE_OK || n2 != n)
         throw std::runtime_error(std::string("orbfe_fetch_keys_un: ") + orbfe_last_error(ctx));
     out.N = n;
-    extractor.NoteResidentFrame(n, out.mDescriptors.data());
+    extractor.NoteResidentFrame(n, out.mDescriptors.data(), 2);
     out.mvKeys.resize(n); out.mvKeysUn.resize(n); out.mDescriptors.resize((size_t)n * 32);
     out.mvuRight.resize(n); out.mvDepth.resize(n);
 }

@@ -12,7 +12,7 @@ class KeyFrame
 {
 public:
     explicit KeyFrame(Frame &F)
-        : fx(Frame::fx), fy(Frame::fy), cx(Frame::cx), cy(Frame::cy), N(F.N), mvKeys(F.mvKeys), mvKeysUn(F.mvKeysUn), mvuRight(F.mvuRight),
+        : fx(Frame::fx), fy(Frame::fy), cx(Frame::cx), cy(Frame::cy), invfx(Frame::invfx), invfy(Frame::invfy), mbf(F.mbf), mb(F.mb), mThDepth(F.mThDepth), N(F.N), mvKeys(F.mvKeys), mvKeysUn(F.mvKeysUn), mvuRight(F.mvuRight),
           mvDepth(F.mvDepth), mDescriptors(F.mDescriptors.clone()), mFbowFeatVec(F.mFbowFeatVec), mnMinX((int)Frame::mnMinX), mnMinY((int)Frame::mnMinY),
           mnMaxX((int)Frame::mnMaxX), mnMaxY((int)Frame::mnMaxY), mvpMapPoints(F.mvpMapPoints), Tcw(F.mTcw.clone())
     {
@@ -31,7 +31,7 @@ public:
     MapPoint *GetMapPoint(const size_t &idx) { return mvpMapPoints[idx]; }
     void AddMapPoint(MapPoint *pMP, const size_t &idx) { mvpMapPoints[idx] = pMP; }
 
-    const float fx, fy, cx, cy;
+    const float fx, fy, cx, cy, invfx, invfy, mbf, mb, mThDepth;
     const int N;
     const std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
     const std::vector<float> mvuRight, mvDepth;
