@@ -522,6 +522,10 @@ extern "C" int orbfe_assign_features_to_grid(orbfe_context *ctx, const orbfe_fra
     const int total = cell_off[ncell]; // keypoints that fell inside the grid (PosInGrid drops the others)
     if (total < 0 || total > fv->n) return orbfe_fail(ctx, ORBFE_ERR_HIP, "grid holds %d entries for %d keypoints", total, fv->n);
     if (total > 0) MTRY(ctx, hipMemcpy(cell_idx, d_off + ncell + 1, sizeof(int) * total, hipMemcpyDeviceToHost));
+    // the fill kernel claims a cell's slots through an atomic cursor (the matchers order candidates by their keys, not by list
+    // position); mGrid[ix][iy] is in push_back order = ascending keypoint index
+    for (int c = 0; c < ncell; c++)
+        if (cell_off[c + 1] - cell_off[c] > 1) std::sort(cell_idx + cell_off[c], cell_idx + cell_off[c + 1]);
     return ORBFE_OK;
 }
 

@@ -30,6 +30,15 @@ for i in range(n):
         pat = (((xx // 3) + (yy // 2)) % 2) * 120 + 60 + rng.integers(-25, 26, (h, w))
         left = np.clip(pat, 0, 255).astype(np.uint8)
         right = np.roll(left, -4, axis=1)
+    if i % 11 in (2, 6, 9):  # a photograph (tests/golden/natural) cut to this case's size, degraded the way real footage is
+        from tests import natural as N
+        ph = N.load(("china", "flower", "hopper")[i % 3])
+        deg = (N.saturate, N.block_quantise, N.flatten_contrast)[(i // 11) % 3](ph)
+        reps = (-(-h // deg.shape[0]), -(-(w + 16) // deg.shape[1]))
+        big = np.tile(deg, reps)
+        y0 = int(rng.integers(0, big.shape[0] - h + 1)); x0 = int(rng.integers(0, big.shape[1] - w - 15))
+        dsp = int(rng.integers(2, 16))
+        left = np.ascontiguousarray(big[y0:y0 + h, x0:x0 + w]); right = np.ascontiguousarray(big[y0:y0 + h, x0 + dsp:x0 + dsp + w])
     fx, bf = 0.7 * w, 0.2 * w
     kw = dict(nfeatures=nf, ini_th_fast=ini, min_th_fast=mn)
     ctx = api.Context(width=w, height=h, fx=fx, fy=fx, cx=w / 2, cy=h / 2, bf=bf, **kw)
