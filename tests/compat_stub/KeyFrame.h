@@ -32,6 +32,15 @@ public:
     void AddMapPoint(MapPoint *pMP, const size_t &idx) { mvpMapPoints[idx] = pMP; }
 
     const float fx, fy, cx, cy, invfx, invfy, mbf, mb, mThDepth;
+    // what KeyFrameDatabase reads and writes (include/KeyFrame.h:133,153-158; covisibility graph :62-72)
+    long unsigned int mnId = 0;
+    fbow::fBow mFbowVec;
+    long unsigned int mnLoopQuery = 0; int mnLoopWords = 0; float mLoopScore = 0.f;
+    long unsigned int mnRelocQuery = 0; int mnRelocWords = 0; float mRelocScore = 0.f;
+    std::vector<KeyFrame *> GetBestCovisibilityKeyFrames(const int &n) { return std::vector<KeyFrame *>(mvpOrderedConnectedKeyFrames.begin(), mvpOrderedConnectedKeyFrames.begin() + ((int)mvpOrderedConnectedKeyFrames.size() < n ? (int)mvpOrderedConnectedKeyFrames.size() : n)); }
+    std::set<KeyFrame *> GetConnectedKeyFrames() { return std::set<KeyFrame *>(mConnected.begin(), mConnected.end()); }
+    std::vector<KeyFrame *> mvpOrderedConnectedKeyFrames; // protected in the reference
+    std::vector<KeyFrame *> mConnected;                   // test fixture: the keys of mConnectedKeyFrameWeights
     const int N;
     const std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
     const std::vector<float> mvuRight, mvDepth;

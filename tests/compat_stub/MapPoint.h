@@ -2,6 +2,7 @@
 // orbslam2_amd/compat/ORBmatcher.cc uses, same names and types, trivial storage.  Never shipped.
 #pragma once
 #include <map>
+#include <mutex>
 #include "cvstub.h"
 
 namespace ORB_SLAM2
@@ -26,6 +27,7 @@ public:
     MapPoint *GetReplaced() { return mpReplaced; }
 
     int nObs = 0;
+    static std::mutex mGlobalMutex; // include/MapPoint.h:90 (defined by the drivers of this directory)
     // Variables used by the tracking
     float mTrackProjX, mTrackProjY, mTrackProjXR;
     bool mbTrackInView;

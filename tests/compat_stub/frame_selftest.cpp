@@ -2,21 +2,26 @@
 // exactly the way src/Tracking.cc does (:296 stereo, :326 RGB-D, :354-358 monocular: the reference's constructor signatures,
 // extractors new-ed as at :125-131) and dumps every member the constructors fill; tests/test_compat_frame.py compares the
 // dumps with the CPU oracle.  Frame / MapPoint / cv::Mat / fbow are the declaration stand-ins of this directory.
-//   usage: frame_selftest <dir> stereo|rgbd|mono|threads
+//   usage: frame_selftest <dir> stereo|rgbd|mono|threads|backend
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "Frame.h"
 #include "KeyFrame.h"
+#include "KeyFrameDatabase.h" // orbslam2_amd/compat
+#include "Optimizer.h"
 #include "ORBmatcher.h"
 
 using namespace ORB_SLAM2;
+std::mutex MapPoint::mGlobalMutex;
 
 static std::string g_dir;
 template <class T> static std::vector<T> rd(const std::string &name)
@@ -258,6 +263,89 @@ int main(int argc, char **argv)
             }
             wr("thr_bad.bin", std::vector<int32_t>{bad, 200});
             if (bad) { std::cerr << bad << " of 200 threaded frames differ from the serial result\n"; return 7; }
+        } else if (mode == "backend") {
+            // The two section-8(f) call sites that take the reference's objects: Optimizer::PoseOptimization(&mCurrentFrame)
+            // (src/Tracking.cc:875,998,1040) and mpKeyFrameDB->add / erase / DetectRelocalizationCandidates(&mCurrentFrame) /
+            // DetectLoopCandidates(mpCurrentKF, minScore) (src/Tracking.cc:1496, src/LoopClosing.cc:131).
+            mpORBextractorLeft->SetCamera(([&] { CameraParams c; c.fx = cam[0]; c.fy = cam[1]; c.cx = cam[2]; c.cy = cam[3]; c.bf = mbf; return c; })());
+            mpORBextractorLeft->BindImageSize(W, H);
+            Frame::fx = cam[0]; Frame::fy = cam[1]; Frame::cx = cam[2]; Frame::cy = cam[3]; Frame::invfx = 1.f / cam[0]; Frame::invfy = 1.f / cam[1];
+            { // ---- PoseOptimization
+                const std::vector<cv::KeyPoint> keys = rd<cv::KeyPoint>("pose_keys.bin");
+                const std::vector<float> ur = rd<float>("pose_ur.bin"), Xw = rd<float>("pose_xw.bin"), T0 = rd<float>("pose_T0.bin");
+                const std::vector<uchar> has = rd<uchar>("pose_has.bin");
+                const int n = (int)keys.size();
+                Frame F;
+                F.mpORBextractorLeft = mpORBextractorLeft; F.mpORBextractorRight = NULL;
+                F.N = n; F.mvKeysUn = keys; F.mvKeys = keys; F.mvuRight = ur; F.mbf = mbf; F.mb = mbf / cam[0];
+                std::vector<MapPoint> pts(n);
+                F.mvpMapPoints.assign(n, static_cast<MapPoint *>(NULL));
+                F.mvbOutlier.assign(n, false);
+                for (int i = 0; i < n; i++)
+                    if (has[i]) { pts[i].mWorldPos = cv::Mat(3, 1, CV_32F); for (int k = 0; k < 3; k++) pts[i].mWorldPos.at<float>(k) = Xw[3 * i + k]; F.mvpMapPoints[i] = &pts[i]; }
+                cv::Mat T(4, 4, CV_32F);
+                for (int i = 0; i < 16; i++) T.ptr<float>(0)[i] = T0[i];
+                F.SetPose(T);
+                const int nInl = Optimizer::PoseOptimization(&F); // src/Tracking.cc:875
+                std::vector<float> Tout(16);
+                for (int i = 0; i < 16; i++) Tout[i] = F.mTcw.at<float>(i / 4, i % 4);
+                std::vector<uchar> outl(n);
+                for (int i = 0; i < n; i++) outl[i] = F.mvbOutlier[i];
+                wr("pose_T.bin", Tout); wr("pose_outlier.bin", outl); wr("pose_ninl.bin", std::vector<int32_t>(1, nInl));
+                const cv::Mat Ow = F.GetCameraCenter(); // SetPose ran: the camera centre follows the new pose
+                wr("pose_Ow.bin", std::vector<float>{Ow.at<float>(0), Ow.at<float>(1), Ow.at<float>(2)});
+                // fewer than 3 correspondences: returns 0, pose and flags untouched (src/Optimizer.cc:404-405)
+                Frame G(F);
+                G.mvpMapPoints.assign(n, static_cast<MapPoint *>(NULL));
+                int kept = 0;
+                for (int i = 0; i < n && kept < 2; i++) if (has[i]) { G.mvpMapPoints[i] = &pts[i]; kept++; }
+                G.SetPose(T);
+                if (Optimizer::PoseOptimization(&G) != 0 || std::memcmp(G.mTcw.ptr<float>(0), T.ptr<float>(0), 64)) { std::cerr << "PoseOptimization with 2 points touched the pose\n"; return 8; }
+            }
+            { // ---- KeyFrameDatabase
+                const std::vector<int32_t> kf_off = rd<int32_t>("db_kf_off.bin"), cv_off = rd<int32_t>("db_covis_off.bin"), cv_idx = rd<int32_t>("db_covis_idx.bin");
+                const std::vector<uint32_t> kf_words = rd<uint32_t>("db_kf_words.bin");
+                const std::vector<float> kf_w = rd<float>("db_kf_w.bin");
+                const std::vector<int32_t> q_off = rd<int32_t>("db_q_off.bin"), erase_after = rd<int32_t>("db_erase_after.bin");
+                const std::vector<uint32_t> q_words = rd<uint32_t>("db_q_words.bin");
+                const std::vector<float> q_w = rd<float>("db_q_w.bin"), min_score = rd<float>("db_min_score.bin");
+                const std::vector<uchar> connected = rd<uchar>("db_connected.bin");
+                const int nkf = (int)kf_off.size() - 1, nq = (int)q_off.size() - 1;
+                Frame proto; // a keyframe is made from a frame (src/KeyFrame.cc:29); the database only reads its BoW vector and graph
+                proto.mpORBextractorLeft = mpORBextractorLeft; proto.N = 0; proto.mbf = mbf; proto.mb = mbf / cam[0]; proto.mThDepth = mThDepth;
+                std::vector<std::unique_ptr<KeyFrame> > kfs;
+                for (int k = 0; k < nkf; k++) {
+                    kfs.emplace_back(new KeyFrame(proto));
+                    kfs[k]->mnId = 100 + k;
+                    for (int j = kf_off[k]; j < kf_off[k + 1]; j++) { float w = kf_w[j]; kfs[k]->mFbowVec[kf_words[j]] = w; }
+                }
+                for (int k = 0; k < nkf; k++)
+                    for (int j = cv_off[k]; j < cv_off[k + 1]; j++) kfs[k]->mvpOrderedConnectedKeyFrames.push_back(kfs[cv_idx[j]].get());
+                KeyFrameDatabase *mpKeyFrameDB = new KeyFrameDatabase(mpFBOWVocabulary); // src/System.cc:88
+                for (int k = 0; k < nkf; k++) mpKeyFrameDB->add(kfs[k].get());
+                std::vector<int32_t> reloc_out, loop_out, counts;
+                std::vector<float> state;
+                for (int q = 0; q < nq; q++) {
+                    Frame F;
+                    F.mpORBextractorLeft = mpORBextractorLeft; F.N = 0; F.mnId = 1000 + q;
+                    for (int j = q_off[q]; j < q_off[q + 1]; j++) { float w = q_w[j]; F.mFbowVec[q_words[j]] = w; }
+                    const std::vector<KeyFrame *> vpCandidateKFs = mpKeyFrameDB->DetectRelocalizationCandidates(&F); // src/Tracking.cc:1496
+                    for (size_t i = 0; i < vpCandidateKFs.size(); i++) reloc_out.push_back((int32_t)vpCandidateKFs[i]->mnId - 100);
+                    for (int k = 0; k < nkf; k++) state.push_back(kfs[k]->mRelocScore);
+                    KeyFrame cur(proto); // the current keyframe is not in the database yet (src/LoopClosing.cc:131 runs before :143's add)
+                    cur.mnId = 5000 + q; cur.mFbowVec = F.mFbowVec;
+                    for (int k = 0; k < nkf; k++) if (connected[(size_t)q * nkf + k]) cur.mConnected.push_back(kfs[k].get());
+                    const std::vector<KeyFrame *> vpLoop = mpKeyFrameDB->DetectLoopCandidates(&cur, min_score[q]);
+                    for (size_t i = 0; i < vpLoop.size(); i++) loop_out.push_back((int32_t)vpLoop[i]->mnId - 100);
+                    counts.push_back((int32_t)vpCandidateKFs.size()); counts.push_back((int32_t)vpLoop.size());
+                    if (erase_after[q] >= 0) mpKeyFrameDB->erase(kfs[erase_after[q]].get()); // KeyFrame::SetBadFlag, src/KeyFrame.cc:520
+                }
+                wr("db_reloc.bin", reloc_out); wr("db_loop.bin", loop_out); wr("db_counts.bin", counts); wr("db_state.bin", state);
+                mpKeyFrameDB->clear(); // src/Tracking.cc:1607 (Reset)
+                Frame F; F.mpORBextractorLeft = mpORBextractorLeft; F.N = 0; F.mnId = 1;
+                { float w = 1.f; F.mFbowVec[q_words[0]] = w; }
+                if (!mpKeyFrameDB->DetectRelocalizationCandidates(&F).empty()) { std::cerr << "cleared database returned candidates\n"; return 9; }
+            }
         } else { std::cerr << "unknown mode " << mode << "\n"; return 2; }
         std::printf("frame selftest ok (%s)\n", mode.c_str());
     } catch (const std::exception &e) {

@@ -161,3 +161,17 @@ def test_reference_signature_calls_match_the_oracle(tmp_path):
     want = np.where(ref >= 0, idx[np.maximum(ref, 0)], -1)
     assert n1 == nref == n2 and nref > 200
     assert np.array_equal(out("out_resident.bin"), want) and np.array_equal(out("out_resident2.bin"), want)
+
+
+@pytest.mark.gpu
+def test_two_threads_share_one_context_like_tracking_and_local_mapping(tmp_path):
+    """The reference's Tracking, LocalMapping and LoopClosing threads each construct ORBmatcher objects (src/Tracking.cc:1283,
+    src/LocalMapping.cc:215,482, src/LoopClosing.cc:275,623) and the shim hands them all the left extractor's device context, whose
+    matcher state is single-user: the library serialises calls on one context with a mutex inside it (include/orbfe.h).  Driver
+    section 8: 60 x SearchByProjection(F, points) on one thread against 60 x Fuse(pKF, points) on another, every result equal to
+    the serial one."""
+    assert os.path.exists(EXE), "compat_selftest not built (make -C tests/compat_stub)"
+    write_scene(tmp_path)
+    r = subprocess.run([EXE, str(tmp_path), "stress"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "compat selftest ok" in r.stdout, r.stdout + r.stderr
+    assert np.fromfile(tmp_path / "stress.bin", np.int32).tolist() == [0, 0, 60]
