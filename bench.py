@@ -10,6 +10,15 @@ Frame pairs are independent, so ranks shard them with no data-path collective; t
 RCCL traffic is a one-time broadcast of the extractor parameters, pattern checksum and a
 (synthetic) fbow vocabulary from rank 0 at start-up.  Rank 0 prints ONE JSON line.
 
+The headline timed region runs one step chain at a time (--chains 1): that keeps every kernel alone on the chip, so the
+dominant kernel's HIP-event time, the rocprofv3 summary and `roofline` describe the kernel and not its neighbours.  Consecutive
+steps are independent, though, and a deployment keeps several in flight: step k on context k % C and that context's stream, so
+that one step's latency-bound stages (pyramid chain, quadtree, median) hide under another's issue-bound ones (FAST, describe).
+That regime is timed right after the headline region with the same protocol and reported as config.pipelined (--pipelined C,
+default 3; kernels of different chains share the chip there, so their individual durations stretch while throughput rises),
+and for BASELINE config 4's 8 pairs per GPU as config.small_batch.  The timed region is repeated --repeat times (same --steps
+each); `value` is the median, config.repeat holds min / max.
+
 Two sharding modes (BASELINE.json config 4 = "64 frame pairs in flight, sharded across 8x"):
   --mode weak   (default, the headline `value`): P pairs per step PER GPU, "scaling": "weak";
   --mode strong : P pairs per step IN TOTAL, dealt round-robin by dist.shard_pairs (8 per GPU at N = 8),
@@ -66,10 +75,9 @@ def traffic_bytes(stage: str, pairs: int, launches: int):
     """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (profiles/r02_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate passes of this same command, gfx950 correction 2 x FETCH_SIZE as
     MI355X_MICROARCH.md prescribes), scaled from the profiled batch to this run's batch; None if not profiled."""
+    # (profiles/r03_traffic.json when this round's passes are committed, else the latest earlier round)
     try:
-        path = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        if not os.path.exists(path):
-            path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        path = next(q for q in (os.path.join(ROOT, "profiles", n) for n in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")) if os.path.exists(q))
         t = json.load(open(path))["kernels"][stage]
         per_pair = (2.0 * t["fetch_kb_per_pair"] + t["write_kb_per_pair"]) * 1024.0
         return per_pair * pairs / launches
@@ -77,48 +85,85 @@ def traffic_bytes(stage: str, pairs: int, launches: int):
         return None
 
 
-def valu_issue(pairs: int, launches: int, launch_ms: float):
-    """Context for the roofline: the dominant kernel is bound by VALU issue, not by HBM.  SQ_INSTS_VALU of the kernel from the
-    committed rocprofv3 pass (per launch of 64 pairs), scaled to this run's batch, against the issue rate MEASURED on this chip
-    for the opcode class the kernel is made of (profiles/r02_valu_peak.json, tools/ubench/valu_peak.hip, outside rocprofv3):
-    gfx950 issues packed / integer min-max, v_perm, shifts, v_dot4, mbcnt ... once per ~4.1 cycles per SIMD (590 G wave-
-    instructions/s chip-wide at the clock it holds), and only add / sub / and / xor / mov / fp32 mul-add-fma once per ~2.3."""
-    try:
-        insts = None
-        for name in ("r02_pmc_sq.txt", "r01_pmc_sq.txt"):
-            path = os.path.join(ROOT, "profiles", name)
-            if not os.path.exists(path):
+def _sq_valu_per_pair():
+    """SQ_INSTS_VALU per stereo pair of every kernel of the step, from the committed rocprofv3 counter pass (launches of 64 pairs;
+    the pyramid's resize kernel runs once per level 1-4): {kernel name fragment: wave-instructions per pair}."""
+    for name in ("r03_pmc_sq.txt", "r02_pmc_sq.txt", "r01_pmc_sq.txt"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        out = {}
+        for line in open(path):
+            if "SQ_INSTS_VALU" not in line or "{" not in line:
                 continue
-            for line in open(path):
-                if "fast_cell_kernel" in line and "SQ_INSTS_VALU" in line:
-                    d = eval(line[line.index("{"):line.rindex("}") + 1], {"__builtins__": {}})
-                    insts = d["SQ_INSTS_VALU"] * (pairs / launches) / 64.0
-                    break
-            if insts is not None:
-                break
+            d = eval(line[line.index("{"):line.rindex("}") + 1], {"__builtins__": {}})
+            kern = line[:line.index("{")].strip()
+            if "rocclr" in kern or "candidates_gather" in kern:  # runtime copies; the parity tap of the post-run check
+                continue
+            calls_per_step = 4 if "pyr_resize_kernel" in kern else 1
+            out[kern] = out.get(kern, 0.0) + d["SQ_INSTS_VALU"] * calls_per_step / 64.0
+        if out:
+            return out, name
+    return None, None
+
+
+def valu_issue(pairs: int, launches: int, launch_ms: float, step_ms: float):
+    """Context for the roofline: the path is bound by VALU issue, not by HBM.  SQ_INSTS_VALU from the committed rocprofv3 pass,
+    scaled to this run's batch, against the issue rates MEASURED on this chip (profiles/r02_valu_peak.json, tools/ubench/valu_peak.hip,
+    outside rocprofv3): gfx950 issues packed / integer min-max, v_perm, shifts, v_dot4, mbcnt ... once per ~4.1 cycles per SIMD
+    (590 G wave-instructions/s chip-wide at the clock it holds) and add / sub / and / xor / mov / fp32 mul-add-fma once per ~2.3.
+      frac       the dominant kernel's instructions priced as if ALL were half-rate (round 2's figure, an upper bound of the truth);
+      frac_mix   priced by the kernel's opcode histogram (profiles/r03_isa_mix.json: tools/isa_mix.py disassembles liborbfe.so and
+                 weights the static mix of each phase by the phase's measured SQ_INSTS_VALU);
+      whole_step the same two figures for the sum of every kernel of a step against the measured ms_per_step."""
+    try:
+        per_pair, src = _sq_valu_per_pair()
         ops = json.load(open(os.path.join(ROOT, "profiles", "r02_valu_peak.json")))["ops"]
         half_rate = ops["v_pk_max_i16"]["8"]["chip_G_wave_inst_per_s"] * 1e9   # the class FAST is made of (pk min / max, perm)
         full_rate = ops["v_add_u32"]["8"]["chip_G_wave_inst_per_s"] * 1e9      # add / sub / and / xor / mov / fp32 fma
-        return {"wave_insts_per_launch": insts, "peak_wave_insts_per_s": half_rate, "frac": insts / (launch_ms * 1e-3) / half_rate,
-                "peak_source": "profiles/r02_valu_peak.json: v_pk_max_i16 at 8 waves per SIMD (measured, %.2f cycles per wave-instruction per SIMD); "
-                               "full-rate class (v_add_u32 ...) %.0f G/s" % (ops["v_pk_max_i16"]["8"]["cycles_per_wave_inst_per_simd"], full_rate / 1e9)}
+        fast = next(v for k, v in per_pair.items() if "fast_cell_kernel" in k)
+        insts = fast * pairs / launches
+        out = {"wave_insts_per_launch": insts, "peak_wave_insts_per_s": half_rate, "frac": insts / (launch_ms * 1e-3) / half_rate, "counter_source": "profiles/" + src,
+               "peak_source": "profiles/r02_valu_peak.json: v_pk_max_i16 at 8 waves per SIMD (measured, %.2f cycles per wave-instruction per SIMD); "
+                              "full-rate class (v_add_u32 ...) %.0f G/s" % (ops["v_pk_max_i16"]["8"]["cycles_per_wave_inst_per_simd"], full_rate / 1e9)}
+        total = sum(per_pair.values()) * pairs
+        whole = {"wave_insts_per_step": total, "frac": total / (step_ms * 1e-3) / half_rate}
+        mix_path = os.path.join(ROOT, "profiles", "r03_isa_mix.json")
+        if os.path.exists(mix_path):
+            mix = json.load(open(mix_path))
+            share = {k: v["full_rate_share"] for k, v in mix["kernels"].items()}  # fraction of the kernel's executed VALU instructions that are full-rate
+            def seconds(n, f):
+                return n * ((1.0 - f) / half_rate + f / full_rate)
+            f_fast = next(v for k, v in share.items() if "fast_cell_kernel" in k)
+            out["frac_mix"] = seconds(insts, f_fast) / (launch_ms * 1e-3)
+            out["full_rate_share"] = f_fast
+            t = 0.0
+            for k, n in per_pair.items():
+                f = next((v for kk, v in share.items() if kk in k or k in kk), 0.0)
+                t += seconds(n * pairs, f)
+            whole["frac_mix"] = t / (step_ms * 1e-3)
+        out["whole_step"] = whole
+        return out
     except Exception:
         pass
     return None
 
 
-def host_fed(api, torch, dev, host, P, ctx0, steps=10):
+def host_fed(api, torch, dev, host, P, make_ctx, steps=16, lanes_n=4):
     """PCIe-inclusive rate (never `value`): every step's P pairs start in PINNED host memory and the results (keypoints,
     descriptors, counts, uRight, depth at device capacity) end there.  serial = upload -> chain -> download on one stream;
-    overlapped = two contexts on two streams, so one step's copies run beside the other's kernels."""
+    overlapped = `lanes_n` lanes (fresh contexts, one stream each, step k on lane k % lanes_n), so one lane's copies run beside the
+    others' kernels.  Measured on this link (tools/pcie_rate.py, profiles/r03_pcie.json): 56 GB/s up alone, 55 GB/s down alone, but
+    the two directions at once take the SUM of their times (1.5 ms for a step's 59.7 MB up + 17.7 MB down): the copies bound the
+    rate at ~42.5 k pairs/s, and separate upload / download streams per lane (tried: 27-32 k) only add event hops."""
     h_in = torch.from_numpy(host).pin_memory()
 
     class Lane:
-        def __init__(self, ctx):
-            self.ctx = ctx
+        def __init__(self):
+            self.ctx = make_ctx()
             self.stream = torch.cuda.Stream()
             self.d_in = torch.empty(h_in.shape, dtype=torch.uint8, device=dev)
-            cap = ctx.capacity
+            cap = self.ctx.capacity
             self.sizes = [2 * P * cap * 28, 2 * P * cap * 32, 2 * P * 4, 2 * P * cap * 4, 2 * P * cap * 4]
             self.h_out = [torch.empty(n, dtype=torch.uint8).pin_memory() for n in self.sizes]
 
@@ -129,8 +174,8 @@ def host_fed(api, torch, dev, host, P, ctx0, steps=10):
                 self.ctx.fetch_batch_async(2 * P, *[h.data_ptr() for h in self.h_out], self.stream.cuda_stream)
 
     def run(lanes):
-        best = 0.0
-        for rep in range(3):  # best of three short passes: one page-fault or clock stall otherwise decides a 10-step figure
+        vals = []
+        for rep in range(3):  # three short passes: one page-fault or clock stall otherwise decides a 16-step figure
             for l in lanes:
                 l.step()
             torch.cuda.synchronize()
@@ -138,19 +183,49 @@ def host_fed(api, torch, dev, host, P, ctx0, steps=10):
             for k in range(steps):
                 lanes[k % len(lanes)].step()
             torch.cuda.synchronize()
-            best = max(best, P * steps / (time.perf_counter() - t0))
-        return best
+            vals.append(P * steps / (time.perf_counter() - t0))
+        return sorted(vals)[1], max(vals)
 
-    p = ctx0.params
-    ctx1 = api.Context(width=p.width, height=p.height, nfeatures=p.nfeatures, scale_factor=p.scale_factor, nlevels=p.nlevels,
-                       ini_th_fast=p.ini_th_fast, min_th_fast=p.min_th_fast, patch_size=p.patch_size, half_patch_size=p.half_patch_size,
-                       edge_threshold=p.edge_threshold, fx=p.fx, fy=p.fy, cx=p.cx, cy=p.cy, bf=p.bf, device=p.device, max_images=2 * P)
-    a, b = Lane(ctx0), Lane(ctx1)
-    out = {"unit": "frames/s", "serial": run([a]), "overlapped": run([a, b]),
-           "bytes_up_per_step": int(h_in.numel()), "bytes_down_per_step": int(sum(a.sizes)),
-           "note": "pinned host memory in and out; serial = one stream, overlapped = two contexts on two streams; best of 3 passes of 10 steps"}
-    ctx1.close()
-    return out
+    lanes = [Lane() for _ in range(lanes_n)]
+    serial, _ = run(lanes[:1])
+    over, over_best = run(lanes)
+    sizes = lanes[0].sizes
+    for l in lanes:
+        l.ctx.close()
+    return {"unit": "frames/s", "serial": serial, "overlapped": over, "overlapped_best_of_3": over_best, "lanes": lanes_n,
+            "bytes_up_per_step": int(h_in.numel()), "bytes_down_per_step": int(sum(sizes)),
+            "note": "pinned host memory in and out; serial = one stream; overlapped = %d lanes (fresh contexts, one stream each); median of 3 passes "
+                    "of %d steps; the link moves a step's up + down bytes in ~1.5 ms whether or not the directions overlap (profiles/r03_pcie.json): "
+                    "~42.5 k pairs/s bound" % (lanes_n, steps)}
+
+
+def small_batch(api, torch, d_images, P8, make_ctx, chains=4, steps=200, repeats=5):
+    """BASELINE.json config 4 as worded -- 64 pairs in flight over 8 GPUs = 8 pairs per GPU per step: one chain of 15 dependent
+    launches over 8 pairs is latency-bound, so `chains` step chains are kept in flight (step k on context k % chains)."""
+    ctxs = [make_ctx(P8) for _ in range(chains)]
+    streams = [torch.cuda.Stream() for _ in range(chains)]
+    ptr = d_images.data_ptr()
+
+    def run(n, c):
+        for k in range(n):
+            ctxs[k % c].enqueue_stereo(ptr, P8, streams[k % c].cuda_stream)
+
+    def rate(c):
+        run(4 * c, c)
+        torch.cuda.synchronize()
+        vals = []
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            run(steps, c)
+            torch.cuda.synchronize()
+            vals.append(P8 * steps / (time.perf_counter() - t0))
+        return sorted(vals)
+    v = rate(chains)
+    v1 = rate(1)
+    for c in ctxs:
+        c.close()
+    return {"pairs": P8, "chains_in_flight": chains, "value": v[len(v) // 2], "min": v[0], "max": v[-1], "ms_per_step": P8 / v[len(v) // 2] * 1e3,
+            "one_chain_at_a_time": v1[len(v1) // 2], "steps": steps, "repeat": repeats, "unit": "frames/s"}
 
 
 def cpu_baseline(n_pairs: int):
@@ -214,13 +289,17 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU (in flight in HBM; BASELINE.json config 4 batches 64 pairs)")
-    ap.add_argument("--streams", type=int, default=1, help="stream groups the batch is cut into inside the library (1 keeps per-kernel times clean; 2 overlaps stages, ~+5%)")
+    ap.add_argument("--chains", type=int, default=1, help="step chains in flight per GPU in the HEADLINE region: step k runs on context k %% chains and its stream (1 = one chain at a time)")
+    ap.add_argument("--pipelined", type=int, default=3, help="after the headline region, time the same steps with this many chains in flight -> config.pipelined (0 / 1 = skip)")
+    ap.add_argument("--repeat", type=int, default=5, help="the timed region (--steps steps) is repeated this often; value = median, config.repeat = min / max")
+    ap.add_argument("--streams", type=int, default=1, help="stream groups the batch is cut into inside the library (1 keeps per-kernel times clean)")
     ap.add_argument("--cpu-pairs", type=int, default=300, help="pairs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run oracle spot check")
     ap.add_argument("--mode", default="weak", choices=["weak", "strong"], help="weak: --pairs per GPU; strong: --pairs in total, sharded by dist.shard_pairs")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pairs the batch cycles through")
     ap.add_argument("--host-fed", type=int, default=1, help="1: after the timed region also measure the PCIe-inclusive rate (N = 1 only; never `value`)")
+    ap.add_argument("--small-batch", type=int, default=8, help="N = 1 only: also time steps of this many pairs (BASELINE config 4's 8 pairs per GPU) with 4 chains in flight -> config.small_batch; 0 = skip")
     args = ap.parse_args()
 
     import torch
@@ -261,11 +340,20 @@ def main():
     P = args.pairs if args.mode == "weak" else len(mine)
     if P < 1:
         raise SystemExit("bench: --mode strong needs --pairs >= number of GPUs")
-    ctx = api.Context(width=W, height=H, nfeatures=nf, scale_factor=sf, nlevels=nl, ini_th_fast=ini, min_th_fast=mn,
-                      patch_size=ps, half_patch_size=hps, edge_threshold=et, fx=fx, fy=fy, cx=cx, cy=cy, bf=bf,
-                      device=gpu_index, max_images=2 * P)
+    C = max(1, min(args.chains, 8))
+    CP = max(C, min(args.pipelined, 8)) if args.pipelined > 1 else C  # contexts needed in all
     G = max(1, min(args.streams, P, 8))
-    ctx.set_streams(G)
+
+    def make_ctx(pairs=P):
+        c = api.Context(width=W, height=H, nfeatures=nf, scale_factor=sf, nlevels=nl, ini_th_fast=ini, min_th_fast=mn,
+                        patch_size=ps, half_patch_size=hps, edge_threshold=et, fx=fx, fy=fy, cx=cx, cy=cy, bf=bf,
+                        device=gpu_index, max_images=2 * pairs)
+        return c
+
+    ctxs = [make_ctx() for _ in range(CP)]
+    for c in ctxs:
+        c.set_streams(G)
+    ctx = ctxs[0]
     if voc_blob is not None:
         BOW.vocab_load(ctx, voc_blob)
     host = np.empty((2 * P, H, W), np.uint8)
@@ -283,115 +371,177 @@ def main():
                 cache[k] = synth.stereo_pair(W, H, seed=1234 + k)
             host[2 * j], host[2 * j + 1] = cache[k]
     d_images = torch.from_numpy(host).to(dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    # every chain on a stream of its own (kernels are launched there, and the library's HIP events are recorded there)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(CP)]
     n_step = [P]
+    k_step = [0]
 
-    def step():
-        ctx.enqueue_stereo(d_images.data_ptr(), n_step[0], stream)
+    def step(chains=C):
+        i = k_step[0] % chains
+        k_step[0] += 1
+        ctxs[i].enqueue_stereo(d_images.data_ptr(), n_step[0], streams[i].cuda_stream)
 
     def barrier():
         D.barrier()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()  # the whole device: every chain's stream
 
-    for _ in range(args.warmup):
-        step()
+    def timed(steps, chains=C):
+        k_step[0] = 0
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(chains)
+        barrier()
+        return D.max_over_ranks(time.perf_counter() - t0, cdev)
+
+    for _ in range(max(args.warmup, CP)):  # every chain's context runs at least once before the clock starts
+        step(CP)
     barrier()
-    # Timed region: HIP events only around the dominant kernel (cell-wise FAST, stage 3) -- an event at every stage
-    # boundary costs ~6 us of idle GPU each, i.e. ~6 % of a step.  The full per-stage table comes from a separate,
-    # untimed pass after the timed region.
+    # Timed region: HIP events only around the dominant kernel (cell-wise FAST, stage 3) on the stream of its chain -- an event
+    # at every stage boundary costs ~6 us of idle GPU each, i.e. ~6 % of a step.  The full per-stage table comes from a separate,
+    # untimed single-chain pass after the timed region.
     DOM = "fast"
-    ctx.set_profiling(2 + api.STAGE_NAMES.index(DOM))
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    dom_ms_sum, dom_calls = ctx.stage_times(reset=True)
+    EVERY = 4  # events on every 4th step of a chain: the two events of a step cost ~4 % of it
+    for c in ctxs[:C]:
+        c.set_profiling(2 + api.STAGE_NAMES.index(DOM))
+        c.set_profiling_interval(EVERY)
+    R = max(1, args.repeat)
+    dts, dom_ms_sum, dom_calls = [], 0.0, 0
+    for _ in range(R):
+        dts.append(timed(args.steps))
+        for c in ctxs[:C]:
+            ms, calls = c.stage_times(reset=True)
+            dom_ms_sum += ms[DOM]; dom_calls += calls
+    dt = sorted(dts)[len(dts) // 2]
+    # the dominant kernel alone on the chip (one chain at a time): what the co-scheduled figure of the timed region stretches
+    for c in ctxs:
+        c.set_profiling_interval(1)
+    dom_alone = None
+    if C > 1:
+        k_step[0] = 0
+        for _ in range(min(args.steps, 10)):
+            step(1)
+        barrier()
+        ms, calls = ctx.stage_times(reset=True)
+        dom_alone = ms[DOM] / max(calls, 1) / G
+    for c in ctxs:
+        c.set_profiling(0)
+    single = None
+    if C > 1:  # one chain at a time beside it, no events
+        single = sorted(timed(args.steps, 1) for _ in range(3))[1]
+    piped = None
+    if CP > C:  # the deployment regime: CP step chains in flight, same steps, same barrier protocol, no events
+        for _ in range(CP):
+            step(CP)
+        piped = sorted(timed(args.steps, CP) for _ in range(R))
     ctx.set_profiling(1)
+    k_step[0] = 0
     for _ in range(min(args.steps, 10)):
-        step()
+        step(1)
     barrier()
     stage_ms, calls = ctx.stage_times(reset=True)
-    ctx.set_profiling(0)
-    dt = D.max_over_ranks(dt, cdev)
+    for c in ctxs:
+        c.set_profiling(0)
 
     # strong-scaling pass beside a weak run on several GPUs: P_total pairs in total, this rank's share per step
     strong = None
     if args.mode == "weak" and world > 1 and len(mine) >= 1:
         n_step[0] = len(mine)
-        for _ in range(args.warmup):
+        for _ in range(max(args.warmup, C)):
             step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        dts = D.max_over_ranks(time.perf_counter() - t0, cdev)
+        dts_s = sorted(timed(args.steps) for _ in range(3))[1]
         strong = {"pairs_per_step_total": P_total, "pairs_per_step_per_gpu": [len(D.shard_pairs(P_total, r, world)) for r in range(world)],
-                  "value": P_total * args.steps / dts, "ms_per_step": dts / args.steps * 1e3,
-                  "note": "same timing protocol; every rank runs the first len(shard) pairs of its resident batch"}
+                  "value": P_total * args.steps / dts_s, "ms_per_step": dts_s / args.steps * 1e3, "chains_in_flight": C,
+                  "note": "same timing protocol (median of 3); every rank runs the first len(shard) pairs of its resident batch"}
         n_step[0] = P
-        step()  # leave the full batch's results in the context for the checks below
-        barrier()
+    k_step[0] = 0
+    step(1)  # leave the full batch's results in context 0 for the checks below
+    barrier()
 
     counts = ctx.fetch_counts(2 * P)
     n_cand = 0
     if rank == 0:
         n_cand = sum(len(ctx.fetch_candidates(0, l)[0]) for l in range(nl))
-        if not args.no_check:  # the timed path must be the correct path: spot-check pair 0 against the oracle
+        if not args.no_check:  # the timed path must be the correct path: spot-check pair 0 of EVERY chain's context against the oracle
             from oracle import oracle as O
             exl, exr = O.Extractor(nfeatures=nf), O.Extractor(nfeatures=nf)
             kl, dl = exl.extract(host[0]); kr, dr = exr.extract(host[1])
             ur, dp, _ = O.stereo_matches(exl, exr, kl, dl, kr, dr, bf, fx)
-            got = ctx.fetch_image(0, stereo=True)
-            ok = (len(got["kps"]) == len(kl) and np.array_equal(got["desc"], dl) and np.array_equal(got["u_right"], ur)
-                  and np.array_equal(got["kps"]["x"], kl["x"]) and np.array_equal(got["kps"]["angle"], kl["angle"]))
-            if not ok:
-                raise SystemExit("bench: HIP output differs from the oracle -- result invalid")
+            for c in ctxs:
+                got = c.fetch_image(0, stereo=True)
+                ok = (len(got["kps"]) == len(kl) and np.array_equal(got["desc"], dl) and np.array_equal(got["u_right"], ur)
+                      and np.array_equal(got["kps"]["x"], kl["x"]) and np.array_equal(got["kps"]["angle"], kl["angle"]))
+                if not ok:
+                    raise SystemExit("bench: HIP output differs from the oracle -- result invalid")
 
     if rank == 0:
-        total_pairs = (P * world if args.mode == "weak" else P_total) * args.steps
-        value = total_pairs / dt
+        pairs_per_step = P * world if args.mode == "weak" else P_total
+        value = pairs_per_step * args.steps / dt
         alg = stage_alg_bytes_per_pair(n_cand)
         # stage time per step, summed over the G stream groups (they overlap in wall time)
         per_launch_ms = {k: v / max(calls, 1) for k, v in stage_ms.items()}
         dom = DOM
         if max(per_launch_ms, key=per_launch_ms.get) != DOM:
             print("bench: note: stage %s is now longer than %s" % (max(per_launch_ms, key=per_launch_ms.get), DOM), file=sys.stderr)
-        # per step a stage is G launches (one per stream group)
-        launches = G
-        dom_ms = dom_ms_sum[dom] / max(dom_calls, 1) / launches  # from the events of the timed region
+        launches = G  # per step a stage is G launches (one per stream group)
+        dom_ms = dom_ms_sum / max(dom_calls, 1) / launches  # from the events of the timed region, on the launching stream
         achieved = alg[dom] * P / launches / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         metric = "frames/sec ORB extract+match, KITTI 1241x376 stereo, 2000 feats"
         try:
             metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
         except Exception:
             pass
+        step_ms = dt / args.steps * 1e3
+        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bytes(dom, P, launches),
+                "launch_ms": dom_ms, "alg_bytes_per_launch": alg[dom] * P / launches,
+                "events_every_nth_step": EVERY,
+                "valu_issue": valu_issue(P, launches, dom_ms, step_ms),
+                "whole_pipeline": {"alg_bytes_per_pair": B_PAIR, "achieved": B_PAIR * value / world / 1e9,
+                                   "frac": B_PAIR * value / world / 1e9 / HBM_PEAK_GBS},
+                "stage_ms_per_step_summed_over_groups": per_launch_ms,
+                "stage_ms_note": "per-stage table from a separate untimed single-chain pass with events at every stage boundary; launch_ms from the timed region"}
+        if dom_alone is not None:
+            roof["launch_ms_one_chain"] = dom_alone
+            roof["frac_one_chain"] = alg[dom] * P / launches / (dom_alone * 1e-3) / 1e9 / HBM_PEAK_GBS
+            roof["launch_ms_note"] = ("launch_ms: the kernel co-scheduled with the other %d chains' kernels (timed region); launch_ms_one_chain: the same "
+                                      "launch with one chain at a time" % (C - 1))
         out = {
             "metric": metric, "value": value, "unit": "frames/s (1 frame = 1 stereo pair)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.mode,
+            "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, CP),
+            "ms_per_step": step_ms, "higher_is_better": True, "scaling": args.mode,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "Stereo-KITTI00-02 1241x376, 2000 features, 8 levels: extract L+R + ComputeStereoMatches"
                                    + (" (%d pairs per step per GPU, weak scaling)" % P if args.mode == "weak"
                                       else " (%d pairs per step in total, sharded round-robin over %d GPUs, strong scaling)" % (P_total, world)),
-                       "sharding": args.mode, "pairs_per_step_per_gpu": P, "distinct_pairs": n_distinct, "stream_groups": G, "quadtree_kernel": ctx.quadtree_kernel(), "parallelism": "frame-pair sharding, no data-path collective",
+                       "sharding": args.mode, "pairs_per_step_per_gpu": P, "distinct_pairs": n_distinct, "chains_in_flight": C, "stream_groups": G,
+                       "quadtree_kernel": ctx.quadtree_kernel(), "parallelism": "frame-pair sharding, no data-path collective",
+                       "repeat": {"n": R, "min": pairs_per_step * args.steps / max(dts), "max": pairs_per_step * args.steps / min(dts), "value_is": "median"},
                        "keypoints_left_right_pair0": [int(counts[0]), int(counts[1])]},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bytes(dom, P, launches),
-                         "launch_ms": dom_ms, "alg_bytes_per_launch": alg[dom] * P / launches,
-                         "valu_issue": valu_issue(P, launches, dom_ms),
-                         "whole_pipeline": {"alg_bytes_per_pair": B_PAIR, "achieved": B_PAIR * value / world / 1e9,
-                                            "frac": B_PAIR * value / world / 1e9 / HBM_PEAK_GBS},
-                         "stage_ms_per_step_summed_over_groups": per_launch_ms,
-                         "stage_ms_note": "per-stage table from a separate untimed pass with events at every stage boundary; launch_ms from the timed region"},
+            "roofline": roof,
         }
+        if piped is not None:
+            pv = pairs_per_step * args.steps / piped[len(piped) // 2]
+            out["config"]["pipelined"] = {"chains_in_flight": CP, "value": pv, "ms_per_step": piped[len(piped) // 2] / args.steps * 1e3,
+                                          "min": pairs_per_step * args.steps / piped[-1], "max": pairs_per_step * args.steps / piped[0],
+                                          "valu_issue_whole_step": (valu_issue(P, launches, dom_ms, piped[len(piped) // 2] / args.steps * 1e3) or {}).get("whole_step"),
+                                          "note": "the same %d steps with %d step chains in flight (step k on context k %% %d and its stream), same barrier protocol, "
+                                                  "median of %d; kernels of different chains share the chip, so per-kernel durations stretch (FAST ~2x) while the "
+                                                  "whole-step issue fraction rises" % (args.steps, CP, CP, R)}
+        if single is not None:
+            out["config"]["one_chain_at_a_time"] = {"value": pairs_per_step * args.steps / single, "ms_per_step": single / args.steps * 1e3,
+                                                    "note": "round 2's protocol (a step waits for the previous one's chain), median of 3"}
         if strong is not None:
             out["config"]["strong_scaling"] = strong
         if voc_blob is not None:
             out["config"]["vocabulary_broadcast_bytes"] = len(voc_blob)
+    for c in ctxs[1:]:
+        c.close()
+    if rank == 0:
+        if world == 1 and args.small_batch > 0 and args.mode == "weak":
+            out["config"]["small_batch"] = small_batch(api, torch, d_images, min(args.small_batch, P), make_ctx)
         if world == 1 and args.host_fed:
-            out["config"]["host_fed"] = host_fed(api, torch, dev, host, P, ctx)
+            out["config"]["host_fed"] = host_fed(api, torch, dev, host, P, make_ctx)
         if world == 1 and args.cpu_pairs > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
         else:

@@ -33,7 +33,7 @@ EXPORTS = [
     "orbfe_search_for_triangulation", "orbfe_fuse", "orbfe_search_by_projection_sim3", "orbfe_fuse_sim3", "orbfe_search_by_sim3", "orbfe_kfdb_clear", "orbfe_kfdb_add", "orbfe_kfdb_erase", "orbfe_kfdb_size", "orbfe_kfdb_score", "orbfe_detect_reloc_candidates", "orbfe_detect_loop_candidates",
     "orbfe_pose_optimization", "orbfe_pose_optimization_batch", "orbfe_enqueue_pose_optimization", "orbfe_set_input_format", "orbfe_fetch_batch_async", "orbfe_set_rectification", "orbfe_set_distortion", "orbfe_undistort_keypoints", "orbfe_fetch_keys_un", "orbfe_image_bounds",
     "orbfe_png_last_error", "orbfe_png_info", "orbfe_png_decode", "orbfe_png_decode_batch",
-    "orbfe_get_camera", "orbfe_assign_features_to_grid",
+    "orbfe_get_camera", "orbfe_assign_features_to_grid", "orbfe_set_profiling_interval",
 ]
 NUM_STAGES = 8
 STAGE_NAMES = ["ingest", "pyramid", "blur", "fast", "octree", "describe", "stereo_match", "stereo_median"]  # orbfe_stage_name()
@@ -363,6 +363,11 @@ class Context:
     def set_profiling(self, mode):
         """0/False = off, 1/True = events at every stage boundary, 2 + k = only around stage k."""
         self._check(self.L.orbfe_set_profiling(self.h, int(mode)))
+
+    def set_profiling_interval(self, every: int):
+        self.L.orbfe_set_profiling_interval.restype = C.c_int
+        self.L.orbfe_set_profiling_interval.argtypes = [C.c_void_p, C.c_int]
+        self._check(self.L.orbfe_set_profiling_interval(self.h, int(every)))
 
     def stage_times(self, reset=True):
         """{stage: total ms} over the recorded enqueue calls, and the number of calls."""

@@ -52,6 +52,9 @@ struct orbfe_context {
     size_t ot2_lds = 0;
     // stage timing: ring of PROF_RING calls x (ORBFE_NUM_STAGES + 1) events
     bool profiling = false;
+    int prof_every = 1;      // record events on every prof_every-th enqueue call only (orbfe_set_profiling_interval)
+    unsigned prof_seq = 0;   // enqueue calls seen while profiling
+    bool prof_now = false;   // the current call records
     int prof_only = -1; // >= 0: record only the two events around that stage
     std::vector<hipEvent_t> events;
     int prof_calls = 0;      // calls recorded since the last reset
@@ -888,15 +891,25 @@ extern "C" int orbfe_set_profiling(orbfe_context *ctx, int enabled)
     }
     if (enabled >= 2 + ORBFE_NUM_STAGES || enabled < 0) return fail(ctx, ORBFE_ERR_INVALID, "profiling mode must be 0, 1 or 2 + stage");
     ctx->profiling = enabled != 0;
+    ctx->prof_seq = 0;
     ctx->prof_only = enabled >= 2 ? enabled - 2 : -1;
     ctx->prof_calls = 0;
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_set_profiling_interval(orbfe_context *ctx, int every)
+{
+    ORBFE_ENTRY(ctx);
+    if (!ctx || every < 1) return fail(ctx, ORBFE_ERR_INVALID, "interval must be >= 1");
+    ctx->prof_every = every;
+    ctx->prof_seq = 0;
     return ORBFE_OK;
 }
 
 // record event #idx of the current call for stream group `group` (idx 0 = before the first stage)
 static inline void prof_mark(orbfe_context *ctx, int group, int idx, hipStream_t s)
 {
-    if (!ctx->profiling) return;
+    if (!ctx->prof_now) return;
     if (ctx->prof_only >= 0 && idx != ctx->prof_only && idx != ctx->prof_only + 1) {
         ctx->prof_stages[ctx->prof_calls % PROF_RING] = idx;
         return;
@@ -928,7 +941,7 @@ extern "C" int orbfe_stage_times(orbfe_context *ctx, float *ms, int *calls, int 
                 }
             }
     }
-    if (reset) ctx->prof_calls = 0;
+    if (reset) { ctx->prof_calls = 0; ctx->prof_seq = 0; }
     return ORBFE_OK;
 }
 
@@ -991,6 +1004,7 @@ static int enqueue_batch(orbfe_context *ctx, const uint8_t *d_images, int n_unit
 {
     hipStream_t s = pick_stream(ctx, stream);
     HIP_TRY(ctx, hipSetDevice(ctx->params.device));
+    ctx->prof_now = ctx->profiling && (ctx->prof_seq++ % (unsigned)ctx->prof_every) == 0;
     const int n_images = n_units * imgs_per_unit;
     int G = ctx->groups < n_units ? ctx->groups : n_units;
     if (G < 1) G = 1;
@@ -1015,7 +1029,7 @@ static int enqueue_batch(orbfe_context *ctx, const uint8_t *d_images, int n_unit
     ctx->prof_groups = G;
     ctx->latest_foreign = s != ctx->stream;
     if (ctx->latest_foreign) HIP_TRY(ctx, hipEventRecord(ctx->ev_latest, s));
-    if (ctx->profiling) ctx->prof_calls++;
+    if (ctx->prof_now) ctx->prof_calls++;
     return ORBFE_OK;
 }
 

@@ -28,18 +28,20 @@ def measure(api, torch, d_images, P, chains, groups, steps, warmup=20, repeats=5
             ctxs[k % chains].enqueue_stereo(ptr, P, streams[k % chains].cuda_stream)
     run(warmup)
     torch.cuda.synchronize()
-    vals = []
+    vals, host_us = [], []
     for _ in range(repeats):
         t0 = time.perf_counter()
         run(steps)
+        t1 = time.perf_counter()
         torch.cuda.synchronize()
         vals.append(P * steps / (time.perf_counter() - t0))
+        host_us.append((t1 - t0) / steps * 1e6)
     counts = ctxs[0].fetch_counts(2 * P)
     for c in ctxs:
         c.close()
     vals.sort()
     return {"pairs": P, "chains_in_flight": chains, "stream_groups": groups, "value": vals[len(vals) // 2], "min": vals[0], "max": vals[-1],
-            "ms_per_step": P / vals[len(vals) // 2] * 1e3, "keypoints_pair0": [int(counts[0]), int(counts[1])]}
+            "ms_per_step": P / vals[len(vals) // 2] * 1e3, "host_enqueue_us_per_step": sorted(host_us)[len(host_us) // 2], "keypoints_pair0": [int(counts[0]), int(counts[1])]}
 
 
 def main():
@@ -64,6 +66,7 @@ def main():
             rows.append(r)
             print(json.dumps(r), flush=True)
     if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         json.dump(rows, open(a.out, "w"), indent=1)
 
 
