@@ -771,25 +771,25 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
         b.patch_uv = d_uv;
         ctx->cfg.patch_n = (int)uv.size();
     }
-    {   // the same patch as byte-dot-product weights for describe_kernel's hp == 15 path: the 31 x 31 window as 31 rows x 8
-        // four-pixel words (u = -15 .. 16), grid word s = lane + 64 k; per lane 12 words: [0..3] weights (u + 16) inside the
-        // circle else 0 for k = 0..3, [4..7] weights 1 / 0, [8] the four rows' v as signed bytes (three 128-bit loads per lane)
+    {   // the same patch as byte-dot-product weights for describe_kernel (hp == 15): lane = 2 * row + half holds the 16 pixels
+        // u = -15 + 16 * half .. of row v = row - 15 as four words (its one 128-bit load of the raw patch); per lane 12 words:
+        // [0..3] weights (u + 16) inside the circle else 0, [4..7] weights 1 / 0, [8] v (three 128-bit loads per lane).
+        // Lanes 62 / 63 (no row 31) and u = 16 get zero weights.
         std::vector<uint32_t> mt(12 * 64, 0u);
         if (p.half_patch_size == 15)
-            for (int k = 0; k < 4; k++)
-                for (int lane = 0; lane < 64; lane++) {
-                    const int sidx = lane + 64 * k, r = sidx >> 3, w = sidx & 7;
-                    if (r >= 31) continue;
-                    const int v = r - 15, um = c.umax[v < 0 ? -v : v];
+            for (int lane = 0; lane < 62; lane++) {
+                const int r = lane >> 1, half = lane & 1, v = r - 15, um = c.umax[v < 0 ? -v : v];
+                for (int k = 0; k < 4; k++) {
                     uint32_t wu = 0, w1 = 0;
                     for (int j = 0; j < 4; j++) {
-                        const int u = 4 * w + j - 15;
+                        const int u = 16 * half + 4 * k + j - 15;
                         if (u >= -um && u <= um) { wu |= (uint32_t)(u + 16) << (8 * j); w1 |= 1u << (8 * j); }
                     }
                     mt[(size_t)lane * 12 + k] = wu;
                     mt[(size_t)lane * 12 + 4 + k] = w1;
-                    mt[(size_t)lane * 12 + 8] |= (uint32_t)(v & 0xff) << (8 * k);
                 }
+                mt[(size_t)lane * 12 + 8] = (uint32_t)v;
+            }
         uint32_t *d_mt = nullptr;
         A(d_mt, mt.size());
         if (hipMemcpy(d_mt, mt.data(), mt.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {

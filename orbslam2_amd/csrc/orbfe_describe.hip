@@ -24,7 +24,43 @@ __device__ __attribute__((aligned(16))) const int8_t g_pattern[1024] = {
 #define DS_BLR_ROWS 40 // blurred patch rows staged: the 37 the descriptor can reach, from a row that is a multiple of 4
 
 
-__global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int stereo ORBFE_CUT_PARAM)
+// Right image of a stereo pair: list each of the wave's keypoints in the rows its band covers (vRowIndices, src/Frame.cc:474-491:
+// rows floor(y - r) .. ceil(y + r), r = 2 * scale[octave]); the order inside a row list is irrelevant to stereo_match_kernel's
+// arg-min.  rl_lv / rl_x / rl_y: lane i < DS_KPW holds level | index << 8 (-1: none), x and y of the wave's i-th keypoint.
+__device__ __forceinline__ void describe_row_lists(const DeviceConfig &cfg, const DeviceBuffers &buf, int img, int lane, int rl_lv, float rl_x, float rl_y)
+{
+    // right image of a pair: list each keypoint in the rows its band covers (vRowIndices, src/Frame.cc:474-491: rows
+    // floor(y - r) .. ceil(y + r), r = 2 * scale[octave]); the order inside a row list is irrelevant to
+    // stereo_match_kernel's arg-min.  All of the wave's atomics are issued before the first dependent store.
+    int *rcnt = buf.row_cnt + (size_t)(img >> 1) * cfg.height;
+    uint2 *rent = buf.row_ent + (size_t)(img >> 1) * cfg.height * cfg.row_cap;
+    int pos[DS_KPW], yy[DS_KPW];
+    uint2 e[DS_KPW];
+#pragma unroll
+    for (int i = 0; i < DS_KPW; i++) {
+        const int lvk = __builtin_amdgcn_readlane(rl_lv, i);
+        const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rl_x), i));
+        const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rl_y), i));
+        pos[i] = -1; yy[i] = 0;
+        e[i].x = (uint32_t)(lvk >> 8) | ((uint32_t)(lvk & 255) << 16); e[i].y = __float_as_uint(x);
+        if (lvk >= 0) {
+            const float r = __fmul_rn(2.0f, cfg.lv[lvk & 255].scale);
+            int maxr = (int)ceilf(__fadd_rn(y, r)), minr = (int)floorf(__fsub_rn(y, r));
+            minr = minr < 0 ? 0 : minr; maxr = maxr > cfg.height - 1 ? cfg.height - 1 : maxr;
+            yy[i] = minr + lane;
+            if (yy[i] <= maxr) pos[i] = atomicAdd(&rcnt[yy[i]], 1);
+            for (int y2 = yy[i] + 64; y2 <= maxr; y2 += 64) { // bands taller than a wave (large scale factors only)
+                const int p2 = atomicAdd(&rcnt[y2], 1);
+                if (p2 < cfg.row_cap) rent[(size_t)y2 * cfg.row_cap + p2] = e[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < DS_KPW; i++)
+        if (pos[i] >= 0 && pos[i] < cfg.row_cap) rent[(size_t)yy[i] * cfg.row_cap + pos[i]] = e[i];
+}
+
+__global__ __launch_bounds__(256, 8) void describe_generic_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int stereo ORBFE_CUT_PARAM)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dm[];
     // XCD-aware block -> (image, block) map: workgroups are dealt round-robin over the 8 XCDs, so block
@@ -269,44 +305,218 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
             ((KeyPointPOD *)buf.kps)[(size_t)img * cfg.sel_total + (rl_lv >> 8)] = kp;
         }
     }
-    if (stereo && (img & 1)) {
-        // right image of a pair: list each keypoint in the rows its band covers (vRowIndices, src/Frame.cc:474-491: rows
-        // floor(y - r) .. ceil(y + r), r = 2 * scale[octave]); the order inside a row list is irrelevant to
-        // stereo_match_kernel's arg-min.  All of the wave's atomics are issued before the first dependent store.
-        int *rcnt = buf.row_cnt + (size_t)(img >> 1) * cfg.height;
-        uint2 *rent = buf.row_ent + (size_t)(img >> 1) * cfg.height * cfg.row_cap;
-        int pos[DS_KPW], yy[DS_KPW];
-        uint2 e[DS_KPW];
-#pragma unroll
-        for (int i = 0; i < DS_KPW; i++) {
-            const int lvk = __builtin_amdgcn_readlane(rl_lv, i);
-            const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rl_x), i));
-            const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rl_y), i));
-            pos[i] = -1; yy[i] = 0;
-            e[i].x = (uint32_t)(lvk >> 8) | ((uint32_t)(lvk & 255) << 16); e[i].y = __float_as_uint(x);
-            if (lvk >= 0) {
-                const float r = __fmul_rn(2.0f, cfg.lv[lvk & 255].scale);
-                int maxr = (int)ceilf(__fadd_rn(y, r)), minr = (int)floorf(__fsub_rn(y, r));
-                minr = minr < 0 ? 0 : minr; maxr = maxr > cfg.height - 1 ? cfg.height - 1 : maxr;
-                yy[i] = minr + lane;
-                if (yy[i] <= maxr) pos[i] = atomicAdd(&rcnt[yy[i]], 1);
-                for (int y2 = yy[i] + 64; y2 <= maxr; y2 += 64) { // bands taller than a wave (large scale factors only)
-                    const int p2 = atomicAdd(&rcnt[y2], 1);
-                    if (p2 < cfg.row_cap) rent[(size_t)y2 * cfg.row_cap + p2] = e[i];
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < DS_KPW; i++)
-            if (pos[i] >= 0 && pos[i] < cfg.row_cap) rent[(size_t)yy[i] * cfg.row_cap + pos[i]] = e[i];
-    }
+    if (stereo && (img & 1)) describe_row_lists(cfg, buf, img, lane, rl_lv, rl_x, rl_y);
 }
 
+
+// ---------------------------------------------------------------------------
+// describe_kernel: the reference's geometry (HALF_PATCH_SIZE 15), round 3.  Same outputs as describe_generic_kernel, bit for bit;
+// what changed is where the time went:
+//  * IC_Angle needs no LDS: a lane's one 128-bit load IS its share of the 31 x 31 patch (lane = 2 * row + half: 16 pixels of
+//    one row), so the moments are eight v_dot4_u32_u8 of the loaded registers against per-lane weight words (host-built for
+//    that layout; u-weights and mask, one v per lane) -- no LDS store, wait, barrier and four LDS reads per keypoint;
+//  * all four raw patches of the wave are requested before the first is used, and the blurred patches are prefetched TWO
+//    keypoints ahead (the per-keypoint arithmetic is ~500 cycles, a miss ~2 us: one patch ahead left the waves waiting 41 %
+//    of their time, round-2 counters);
+//  * the rBRIEF pattern sits in LDS as four floats per test (one ds_read_b128 instead of a word and eight unpack / convert
+//    instructions per round), and cvRound is one fp32 add of 1.5 * 2^23 (round-half-even in the add's own rounding; exact for
+//    |x| < 2^22): the sum's low bits are the integer, its bias goes into the LDS base address through a 24-bit multiply.
+// ---------------------------------------------------------------------------
+typedef const __attribute__((address_space(3))) uint8_t *ds_lds_cptr; // LDS pointers are 32 bits wide
+#define DS_LGKM0 0xc07f // s_waitcnt lgkmcnt(0) only: vmcnt / expcnt fields at their maxima (prefetches stay in flight)
+__global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int stereo ORBFE_CUT_PARAM)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dm[];
+    const int bpi = (cfg.sel_total + 4 * DS_KPW - 1) / (4 * DS_KPW); // blocks per image (XCD-aware map: see describe_generic_kernel)
+    int img, blk;
+    if (!xcd_map(bpi, n_images, img, blk)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot0 = blk * (4 * DS_KPW) + wave * DS_KPW;
+    const int *sel_cnt = buf.sel_cnt + (size_t)img * cfg.nlevels;
+    if (blk == 0 && tid == 0) {
+        int tot = 0;
+        for (int l = 0; l < cfg.nlevels; l++) tot += sel_cnt[l];
+        buf.kp_cnt[img] = tot;
+    }
+    // block-shared: the 256 tests as (x0, y0, x1, y1) floats; per wave: the blurred patch (40 rows x 40 bytes)
+    float4 *s_patf = (float4 *)s_dm;
+    uint8_t *s_blr = s_dm + 256 * sizeof(float4) + wave * (DS_BLR_ROWS * DS_PATCH_W);
+    {
+        const int pw = ((const int *)g_pattern)[tid];
+        s_patf[tid] = make_float4((float)(int)(int8_t)(pw & 0xff), (float)(int)(int8_t)((pw >> 8) & 0xff), (float)(int)(int8_t)((pw >> 16) & 0xff), (float)(pw >> 24));
+    }
+    const int my_slot = slot0 + (lane < DS_KPW ? lane : 0);
+    const bool my_in = lane < DS_KPW && my_slot < cfg.sel_total;
+    const int level_l = my_in ? buf.slot_level[my_slot] : 0;
+    const uint32_t xy_l = my_in ? buf.sel_xy[(size_t)img * cfg.sel_total + my_slot] : 0u;
+    const int score_l = my_in ? buf.sel_sc[(size_t)img * cfg.sel_total + my_slot] : 0;
+    const int c_l = lane < cfg.nlevels ? sel_cnt[lane] : 0;
+    // per-lane moment weights (host-built, orbfe_api.hip): 4 words (u + 16 inside the circle, else 0), 4 words (1 / 0), v
+    const uint4 *mt = (const uint4 *)buf.mom_tab + 3 * lane;
+    const uint4 mwu = mt[0], mw1 = mt[1];
+    const int mv = (int)mt[2].x;
+    __syncthreads();
+    int inc = c_l;
+#pragma unroll
+    for (int o = 1; o < ORBFE_MAX_LEVELS; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    const int excl = inc - c_l; // keypoints of the lower levels
+    if (ORBFE_CUT(1)) return;
+
+    // the wave's keypoints: uniform data of slot i (hv false: the slot holds no keypoint)
+    bool hv[DS_KPW];
+    int lvv[DS_KPW], cxv[DS_KPW], cyv[DS_KPW], outv[DS_KPW];
+#pragma unroll
+    for (int i = 0; i < DS_KPW; i++) {
+        hv[i] = false; lvv[i] = 0; cxv[i] = 0; cyv[i] = 0; outv[i] = 0;
+        if (slot0 + i < cfg.sel_total) {
+            const int level = __builtin_amdgcn_readlane(level_l, i);
+            const uint32_t xy = (uint32_t)__builtin_amdgcn_readlane((int)xy_l, i);
+            const int k = slot0 + i - cfg.lv[level].sel_off;
+            if (k < __builtin_amdgcn_readlane(c_l, level)) { // readlane (not a shuffle): the result is a scalar
+                hv[i] = true; lvv[i] = level;
+                outv[i] = k + __builtin_amdgcn_readlane(excl, level);
+                cxv[i] = (int)(xy & 0xffffu) + cfg.min_border;
+                cyv[i] = (int)(xy >> 16) + cfg.min_border;
+            }
+        }
+    }
+    // Pass 1: every raw patch of the wave in flight at once; lane = 2 * row + half holds pixels u = -15 + 16 * half .. + 15 of
+    // row v = row - 15 (lanes 62 / 63 repeat row 30 with zero weights)
+    const int raw_row = (lane >> 1) < 31 ? (lane >> 1) : 30, raw_h16 = (lane & 1) << 4;
+    uint4 pr[DS_KPW];
+#pragma unroll
+    for (int i = 0; i < DS_KPW; i++) {
+        pr[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (hv[i]) {
+            const LevelInfo &L = cfg.lv[lvv[i]];
+            const uint8_t *base = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (ptrdiff_t)(cyv[i] - 15) * L.pitch + (cxv[i] - 15);
+            pr[i] = load16_unaligned(base + (unsigned)(__mul24(raw_row, L.pitch) + raw_h16)); // 16 bytes at any alignment: one global_load_dwordx4
+        }
+    }
+    // blurred patches: block i = lane + 64 k of the 10 x 10 grid of 4 x 4 px blocks (layout: describe_generic_kernel)
+    uint32_t wb[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int i = lane + 64 * k < 100 ? lane + 64 * k : 99;
+        const int tr = (i * 6554) >> 16, bl = i - 10 * tr; // / 10
+        wb[k] = (uint32_t)tr | ((uint32_t)(16 * bl) << 8) | ((uint32_t)(tr * 4 * DS_PATCH_W + 4 * bl) << 16);
+    }
+    uint4 pb[2][2];
+    auto fetch_blr = [&](int i, uint4 *dst) {
+        const LevelInfo &L = cfg.lv[lvv[i]];
+        const unsigned trb = (unsigned)L.blur_tx << 7;
+        const uint8_t *base = buf.blur + (size_t)img * cfg.blur_bytes + L.blur_off + (size_t)((cyv[i] - 18) >> 2) * trb + 4 * ((cxv[i] - 18) & ~3);
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            dst[k] = *(const uint4 *)(base + (__umul24(wb[k] & 0xffu, trb) + ((wb[k] >> 8) & 0xffu)));
+    };
+    if (ORBFE_CUT(2)) return;
+    int m10_l = 0, m01_l = 0;
+#pragma unroll
+    for (int i = 0; i < DS_KPW; i++) {
+        if (!hv[i]) continue;
+        // IC_Angle (src/ORBextractor.cc:72-99): m10 = sum u I = sum (u + 16) I - 16 sum I, m01 = sum v I; integer sums, any order
+        unsigned acc_u = __builtin_amdgcn_udot4(pr[i].x, mwu.x, 0u, false);
+        acc_u = __builtin_amdgcn_udot4(pr[i].y, mwu.y, acc_u, false);
+        acc_u = __builtin_amdgcn_udot4(pr[i].z, mwu.z, acc_u, false);
+        acc_u = __builtin_amdgcn_udot4(pr[i].w, mwu.w, acc_u, false);
+        unsigned acc_1 = __builtin_amdgcn_udot4(pr[i].x, mw1.x, 0u, false);
+        acc_1 = __builtin_amdgcn_udot4(pr[i].y, mw1.y, acc_1, false);
+        acc_1 = __builtin_amdgcn_udot4(pr[i].z, mw1.z, acc_1, false);
+        acc_1 = __builtin_amdgcn_udot4(pr[i].w, mw1.w, acc_1, false);
+        const int m10 = wave_sum_i32((int)acc_u - 16 * (int)acc_1);
+        const int m01 = wave_sum_i32(mv * (int)acc_1);
+        if (lane == i) { m10_l = m10; m01_l = m01; }
+    }
+    if (hv[0]) fetch_blr(0, pb[0]); // in flight during the angle arithmetic
+    if (hv[1]) fetch_blr(1, pb[1]);
+    const float angle_l = fast_atan2_deg((float)m01_l, (float)m10_l);
+    const float factor_pi = __uint_as_float(0x3c8efa35u); // (float)(CV_PI/180.f)
+    float a_l, b_l;
+    sincos_det(__fmul_rn(angle_l, factor_pi), &b_l, &a_l);
+
+    int rl_lv = -1;          // lane i < DS_KPW: level | index << 8 of the wave's i-th keypoint (-1: none), its x and y
+    float rl_x = 0.f, rl_y = 0.f, size_keep = 0.f;
+    unsigned long long dkeep = 0ull;
+    const float magic = 12582912.0f; // 1.5 * 2^23: (x + magic) holds x rounded half-to-even in its low mantissa bits
+#pragma unroll
+    for (int i = 0; i < DS_KPW; i++) {
+        if (hv[i]) {
+            const uint4 *q = pb[i & 1];
+#pragma unroll
+            for (int k = 0; k < 2; k++) { // the block's four rows, one LDS row apart
+                uint32_t *d = (uint32_t *)(s_blr + (wb[k] >> 16));
+                d[0] = q[k].x; d[DS_PATCH_W / 4] = q[k].y; d[2 * (DS_PATCH_W / 4)] = q[k].z; d[3 * (DS_PATCH_W / 4)] = q[k].w;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(DS_LGKM0); // this wave's LDS writes are done (its later reads follow in order); the prefetches keep flying
+        __builtin_amdgcn_wave_barrier();
+        if (i + 2 < DS_KPW) { if (hv[i + 2 < DS_KPW ? i + 2 : 0]) fetch_blr(i + 2 < DS_KPW ? i + 2 : 0, pb[i & 1]); } // two keypoints ahead, into the registers just stored
+        if (!hv[i]) continue;
+        const int lv = lvv[i], kx = cxv[i], ky = cyv[i];
+        const LevelInfo &L = cfg.lv[lv];
+        const int xb = (kx - 18) & ~3;
+        const float angle = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(angle_l), i));
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_l), i));
+        const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b_l), i));
+        if (ORBFE_CUT(3)) { if (lane == 0) buf.depth[(size_t)img * cfg.sel_total + outv[i]] = angle; continue; }
+
+        // computeOrbDescriptor (src/ORBextractor.cc:103-142): center[cvRound(x b + y a) * step + cvRound(x a - y b)].
+        // With the biased integers ir = 0x4b400000 + r and ic = 0x4b400000 + c (bit patterns of the two sums):
+        // (ir & 0xffffff) * 40 + ic = (0x400000 + r) * 40 + 0x4b400000 + c = r * 40 + c + 0x55400000 (mod 2^32)
+        const unsigned center_biased = (unsigned)(uintptr_t)(ds_lds_cptr)(s_blr + (18 + ((ky - 18) & 3)) * DS_PATCH_W + (kx - xb)) - 0x55400000u;
+        unsigned long long bits[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float4 pt = s_patf[r * 64 + lane];
+            const unsigned ir0 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)), magic));
+            const unsigned ic0 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)), magic));
+            const unsigned ir1 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)), magic));
+            const unsigned ic1 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)), magic));
+            const unsigned a0 = __umul24(ir0, DS_PATCH_W) + ic0 + center_biased;
+            const unsigned a1 = __umul24(ir1, DS_PATCH_W) + ic1 + center_biased;
+            const int t0 = *(ds_lds_cptr)(uintptr_t)a0, t1 = *(ds_lds_cptr)(uintptr_t)a1; // ds_read_u8 at a 32-bit LDS address
+            bits[r] = __ballot(t0 < t1);
+        }
+        // results stay in registers until the wave's last keypoint is done (lane 4 i + w: descriptor word w of keypoint i; lane i:
+        // its record): a store issued here would be waited for by a later keypoint's vmcnt wait (gfx9 counts stores in vmcnt)
+        if ((lane >> 2) == i) dkeep = (lane & 3) == 0 ? bits[0] : ((lane & 3) == 1 ? bits[1] : ((lane & 3) == 2 ? bits[2] : bits[3]));
+        float px = (float)kx, py = (float)ky;
+        if (lv != 0) { px = __fmul_rn(px, L.scale); py = __fmul_rn(py, L.scale); }
+        if (lane == i) { rl_lv = lv | (outv[i] << 8); rl_x = px; rl_y = py; size_keep = (float)L.scaled_patch; } // also for the stereo row lists
+        (void)angle;
+    }
+    {
+        const int lvk = __shfl(rl_lv, lane >> 2, 64); // level | index << 8 of the keypoint this lane holds a descriptor word of
+        if (lane < 4 * DS_KPW && lvk >= 0)
+            *(unsigned long long *)(buf.desc + ((size_t)img * cfg.sel_total + (lvk >> 8)) * 32 + (lane & 3) * 8) = dkeep;
+        if (lane < DS_KPW && rl_lv >= 0) {
+            KeyPointPOD kp;
+            kp.x = rl_x; kp.y = rl_y;
+            kp.size = size_keep;
+            kp.angle = angle_l;            // lane i computed keypoint i's angle
+            kp.response = (float)score_l;  // and loaded its slot's score
+            kp.octave = rl_lv & 255;
+            kp.class_id = -1;
+            ((KeyPointPOD *)buf.kps)[(size_t)img * cfg.sel_total + (rl_lv >> 8)] = kp;
+        }
+    }
+    if (stereo && (img & 1)) describe_row_lists(cfg, buf, img, lane, rl_lv, rl_x, rl_y);
+}
 
 void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool stereo, hipStream_t s)
 {
     dim3 grid(xcd_grid((cfg.sel_total + 4 * DS_KPW - 1) / (4 * DS_KPW), n_images));
-    const size_t raw_bytes = cfg.half_patch == 15 ? 32 * DS_RAW_W : (((2 * cfg.half_patch + 1) * DS_PATCH_W + 15) & ~15);
+    if (cfg.half_patch == 15) { // the reference's HALF_PATCH_SIZE
+        const size_t lds = 256 * sizeof(float4) + 4 * (DS_BLR_ROWS * DS_PATCH_W);
+        hipLaunchKernelGGL(describe_kernel, grid, dim3(256), lds, s, cfg, buf, n_images, stereo ? 1 : 0 ORBFE_CUT_ARG("ORBFE_DESC_DBG"));
+        return;
+    }
+    const size_t raw_bytes = (((2 * cfg.half_patch + 1) * DS_PATCH_W + 15) & ~15);
     const size_t lds = ((cfg.patch_n * 2 + 15) & ~15) + 256 * 4 + 4 * (raw_bytes + DS_BLR_ROWS * DS_PATCH_W);
-    hipLaunchKernelGGL(describe_kernel, grid, dim3(256), lds, s, cfg, buf, n_images, stereo ? 1 : 0 ORBFE_CUT_ARG("ORBFE_DESC_DBG"));
+    hipLaunchKernelGGL(describe_generic_kernel, grid, dim3(256), lds, s, cfg, buf, n_images, stereo ? 1 : 0 ORBFE_CUT_ARG("ORBFE_DESC_DBG"));
 }
