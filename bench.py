@@ -113,8 +113,8 @@ def valu_issue(pairs: int, launches: int, launch_ms: float, step_ms: float):
     outside rocprofv3): gfx950 issues packed / integer min-max, v_perm, shifts, v_dot4, mbcnt ... once per ~4.1 cycles per SIMD
     (590 G wave-instructions/s chip-wide at the clock it holds) and add / sub / and / xor / mov / fp32 mul-add-fma once per ~2.3.
       frac       the dominant kernel's instructions priced as if ALL were half-rate (round 2's figure, an upper bound of the truth);
-      frac_mix   priced by the kernel's opcode histogram (profiles/r03_isa_mix.json: tools/isa_mix.py disassembles liborbfe.so and
-                 weights the static mix of each phase by the phase's measured SQ_INSTS_VALU);
+      frac_mix   priced by the kernel's opcode histogram (profiles/r03_isa_mix.json: tools/isa_mix.py disassembles the kernels, prices
+                 every opcode with its measured cycles and weights each phase by its measured SQ_INSTS_VALU);
       whole_step the same two figures for the sum of every kernel of a step against the measured ms_per_step."""
     try:
         per_pair, src = _sq_valu_per_pair()
@@ -130,18 +130,17 @@ def valu_issue(pairs: int, launches: int, launch_ms: float, step_ms: float):
         whole = {"wave_insts_per_step": total, "frac": total / (step_ms * 1e-3) / half_rate}
         mix_path = os.path.join(ROOT, "profiles", "r03_isa_mix.json")
         if os.path.exists(mix_path):
-            mix = json.load(open(mix_path))
-            share = {k: v["full_rate_share"] for k, v in mix["kernels"].items()}  # fraction of the kernel's executed VALU instructions that are full-rate
-            def seconds(n, f):
-                return n * ((1.0 - f) / half_rate + f / full_rate)
-            f_fast = next(v for k, v in share.items() if "fast_cell_kernel" in k)
-            out["frac_mix"] = seconds(insts, f_fast) / (launch_ms * 1e-3)
-            out["full_rate_share"] = f_fast
-            t = 0.0
-            for k, n in per_pair.items():
-                f = next((v for kk, v in share.items() if kk in k or k in kk), 0.0)
-                t += seconds(n * pairs, f)
-            whole["frac_mix"] = t / (step_ms * 1e-3)
+            mix = json.load(open(mix_path))["kernels"]
+            simd_cycles_per_s = half_rate * ops["v_pk_max_i16"]["8"]["cycles_per_wave_inst_per_simd"]  # 1024 SIMDs x the clock the chip held
+            def seconds(n, kern):  # n wave-instructions of kernel `kern` priced with its measured opcode mix
+                m = next((v for kk, v in mix.items() if kk.split("<")[0] in kern), None)
+                return n * (m["mean_cycles_per_valu"] if m else ops["v_pk_max_i16"]["8"]["cycles_per_wave_inst_per_simd"]) / simd_cycles_per_s
+            mf = next(v for k, v in mix.items() if "fast_cell_kernel" in k)
+            out["frac_mix"] = seconds(insts, "fast_cell_kernel") / (launch_ms * 1e-3)
+            out["mean_cycles_per_valu"] = mf["mean_cycles_per_valu"]
+            out["full_rate_share"] = mf["full_rate_share"]
+            out["mix_source"] = "profiles/r03_isa_mix.json (tools/isa_mix.py: opcode histogram of the disassembly per phase x measured cycles per opcode, phases weighted by SQ_INSTS_VALU)"
+            whole["frac_mix"] = sum(seconds(n * pairs, k) for k, n in per_pair.items()) / (step_ms * 1e-3)
         out["whole_step"] = whole
         return out
     except Exception:

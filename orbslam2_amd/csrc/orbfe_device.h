@@ -17,7 +17,9 @@
 // tools/ab/cuts.so); the shipped liborbfe.so has neither the argument nor the branches nor the getenv.
 #ifdef ORBFE_PROFILE_CUTS
 #define ORBFE_CUT_PARAM , int dbg
-#define ORBFE_CUT(n) (dbg == (n))
+// the marker leaves "; ORBFE_PHASE_END n" in the kernel's assembly at the cut: tools/isa_mix.py splits the disassembly into phases there
+template <int N> __device__ __forceinline__ bool orbfe_phase_end() { asm volatile("; ORBFE_PHASE_END %0" ::"n"(N)); return true; }
+#define ORBFE_CUT(n) (orbfe_phase_end<n>() && dbg == (n))
 #define ORBFE_CUT_ARG(env) , orbfe_cut_value(env)
 static inline int orbfe_cut_value(const char *env) { const char *v = getenv(env); return v ? atoi(v) : 0; }
 #else

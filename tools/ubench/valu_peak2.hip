@@ -15,6 +15,8 @@
 #define OPS(X)                                                                                   \
     X(v_add_u32, "v_add_u32 %0, %0, %1", 0)                     /* calibration: full rate in r02 */ \
     X(v_pk_max_i16, "v_pk_max_i16 %0, %0, %1", 0)               /* calibration: half rate in r02 */ \
+    X(v_cndmask_b32, "v_cndmask_b32_e64 %0, %0, %1, s[20:21]", 0) /* r02 selected on an unwritten VCC: 23 cycles */ \
+    X(v_lshlrev_b32, "v_lshlrev_b32 %0, 1, %0", 0)                                                \
     X(v_or_b32, "v_or_b32 %0, %0, %1", 0)                                                         \
     X(v_not_b32, "v_not_b32 %0, %0", 0)                                                           \
     X(v_lshrrev_b32, "v_lshrrev_b32 %0, 1, %0", 0)                                                \
@@ -63,6 +65,7 @@
     X(v_lshlrev_b64, "v_lshlrev_b64 %0, 1, %0", 2)                                                \
     X(v_mad_u64_u32, "v_mad_u64_u32 %0, vcc, %1, %2, %0", 4)                                      \
     X(v_pk_mul_f32, "v_pk_mul_f32 %0, %0, %1", 2)                                                 \
+    X(v_pk_add_f32, "v_pk_add_f32 %0, %0, %1", 2)                                                 \
     X(v_add_f64, "v_add_f64 %0, %0, %1", 2)                                                       \
     X(v_mul_f64, "v_mul_f64 %0, %0, %1", 2)                                                       \
     X(v_fma_f64, "v_fma_f64 %0, %0, %1, %2", 2)
