@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ORBFE_ABI_VERSION 4 /* 2: orbfe_frame_view.device_slot_plus1; 3: .keyframe; 4: orbfe_get_camera, orbfe_assign_features_to_grid */
+#define ORBFE_ABI_VERSION 4 /* 2: orbfe_frame_view.device_slot_plus1; 3: .keyframe; 4: orbfe_get_camera, orbfe_assign_features_to_grid, orbfe_stereo_batch, orbfe_device_count, orbfe_set_profiling_interval */
 
 enum {
     ORBFE_OK = 0,
@@ -114,6 +114,16 @@ int orbfe_stereo_frame(orbfe_context *ctx, const uint8_t *left, const uint8_t *r
                        orbfe_keypoint *kps_left, uint8_t *desc_left, int *n_left,
                        orbfe_keypoint *kps_right, uint8_t *desc_right, int *n_right,
                        float *u_right, float *depth, int cap);
+
+/* The same for n_pairs stereo pairs in one call (host memory in and out; pinned memory makes the copies asynchronous to other
+ * contexts' work): images = [2 * n_pairs][h][w * channels] packed (L0, R0, L1, R1, ...), one upload, one stage chain, one
+ * download.  Outputs are laid out like the device arrays, [image][orbfe_keypoint_capacity()] records (kps 28 B, desc 32 B,
+ * u_right / depth float: left-image slots) and counts[2 * n_pairs]; kps / desc / u_right / depth may be NULL.  This is the
+ * per-context call of a single-process multi-device host (orbslam2_amd/host/multi_device.h: N contexts, one feeder thread each). */
+int orbfe_stereo_batch(orbfe_context *ctx, const uint8_t *images, int n_pairs, orbfe_keypoint *kps, uint8_t *desc, int32_t *counts,
+                       float *u_right, float *depth);
+/* HIP devices visible to the process (orbfe_params.device ranges over them); 0 without a device. */
+int orbfe_device_count(void);
 
 /* Input pixel format of every image entry point of this context (host and device-resident), default CV_8UC1.
  * channels = 3 / 4 makes ingest perform the grey conversion Tracking::GrabImageMonocular / Stereo / RGBD do before they

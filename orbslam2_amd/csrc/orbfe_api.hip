@@ -1405,6 +1405,35 @@ extern "C" int orbfe_extract(orbfe_context *ctx, const uint8_t *img, int w, int 
     return hand_over(ctx, 0, kps, desc, nullptr, nullptr, cap, n);
 }
 
+extern "C" int orbfe_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+// Host-fed batch in one call: what a single-process multi-device host (orbslam2_amd/host/multi_device.h) runs per context.
+extern "C" int orbfe_stereo_batch(orbfe_context *ctx, const uint8_t *images, int n_pairs, orbfe_keypoint *kps, uint8_t *desc, int32_t *counts,
+                                  float *u_right, float *depth)
+{
+    ORBFE_ENTRY(ctx);
+    if (!ctx || !images || !counts) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    if (n_pairs < 1 || 2 * n_pairs > ctx->params.max_images) return fail(ctx, ORBFE_ERR_CAPACITY, "n_pairs %d needs max_images >= %d", n_pairs, 2 * n_pairs);
+    HIP_TRY(ctx, hipSetDevice(ctx->params.device));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_in, images, (size_t)2 * n_pairs * ctx->cfg.in_image_bytes, hipMemcpyHostToDevice, ctx->stream));
+    int rc = orbfe_enqueue_stereo(ctx, ctx->d_in, n_pairs, nullptr);
+    if (rc != ORBFE_OK) return rc;
+    rc = orbfe_fetch_batch_async(ctx, 2 * n_pairs, kps, desc, counts, u_right, depth, nullptr);
+    if (rc != ORBFE_OK) return rc;
+    std::vector<int> status(2 * n_pairs);
+    HIP_TRY(ctx, hipMemcpyAsync(status.data(), ctx->buf.status, sizeof(int) * 2 * n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 2 * n_pairs; i++)
+        if (status[i] != 0) return fail(ctx, ORBFE_ERR_CAPACITY, "device-side capacity overflow (status %d) on image %d", status[i], i);
+    ctx->slot_cnt.assign(counts, counts + 2 * n_pairs);
+    ctx->slot_cnt_epoch = ctx->epoch;
+    return ORBFE_OK;
+}
+
 extern "C" int orbfe_stereo_frame(orbfe_context *ctx, const uint8_t *left, const uint8_t *right,
                                   int w, int h, size_t stride,
                                   orbfe_keypoint *kps_left, uint8_t *desc_left, int *n_left,

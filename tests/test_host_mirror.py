@@ -61,3 +61,40 @@ def test_cpp_selftest_matches_oracle(tmp_path):
     urd, _ = O.stereo_from_rgbd(kl, kun, np.full((h, w), 2.0, np.float32), bf)
     assert np.array_equal(np.fromfile(pre + ".kun", O.KP_DTYPE), kun) and np.array_equal(np.fromfile(pre + ".urd", np.float32), urd)
     assert np.array_equal(np.fromfile(pre + ".bounds", np.float32), O.image_bounds(w, h, fx, fx, w * 0.5, h * 0.5, dist))
+
+
+def test_multi_device_host_shards_like_dist():
+    """ShardPairs (orbslam2_amd/host/multi_device.h) deals pairs exactly as orbslam2_amd/dist.py: shard_pairs does (one rule for the C++
+    host and for bench.py's one-process-per-GPU path)."""
+    from orbslam2_amd import dist as D
+    text = open(os.path.join(ROOT, "orbslam2_amd", "host", "multi_device.h")).read()
+    assert "for (int g = rank; g < n_pairs; g += world) mine.push_back(g);" in text
+    for n, world in ((64, 8), (7, 3), (2, 4)):
+        for r in range(world):
+            assert D.shard_pairs(n, r, world) == list(range(r, n, world))
+    assert "orbfe_stereo_batch(" in text and "#include <hip" not in text  # the C ABI only: compiles with plain g++
+
+
+@pytest.mark.gpu
+def test_single_process_multi_context_host_matches_single_context(tmp_path):
+    """One C++ process, three device contexts with a feeder thread each (on this one-GPU box all on device 0; context i on device
+    i % device_count in general), 10 pairs per step dealt round-robin: twenty steps, every pair equal to the single-context batch, in
+    frame order; pairs 0 and 9 against the oracle."""
+    exe = os.path.join(ROOT, "orbslam2_amd", "host", "multi_device_selftest")
+    assert os.path.exists(exe), "multi_device_selftest not built (make -C orbslam2_amd/host)"
+    w, h, nf, fx, bf, P = 480, 300, 500, 420.0, 150.0, 10
+    pairs = [synth.stereo_pair(w, h, seed=700 + i) for i in range(P)]
+    buf = np.stack([np.stack(p) for p in pairs])  # [P][2][h][w]
+    path, pre = tmp_path / "pairs.raw", str(tmp_path / "md")
+    buf.tofile(path)
+    r = subprocess.run([exe, str(path), str(P), str(w), str(h), str(nf), str(fx), str(bf), "3", pre], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "multi-device selftest ok" in r.stdout, r.stdout + r.stderr
+    assert "contexts 3" in r.stdout and "mismatches 0" in r.stdout
+    for g in (0, P - 1):
+        exl, exr = O.Extractor(nfeatures=nf), O.Extractor(nfeatures=nf)
+        kl, dl = exl.extract(pairs[g][0]); kr, dr = exr.extract(pairs[g][1])
+        ur, dp, _ = O.stereo_matches(exl, exr, kl, dl, kr, dr, bf, fx)
+        t = "%s_p%d" % (pre, g)
+        assert np.array_equal(np.fromfile(t + ".kl", O.KP_DTYPE), kl) and np.array_equal(np.fromfile(t + ".kr", O.KP_DTYPE), kr)
+        assert np.array_equal(np.fromfile(t + ".dl", np.uint8).reshape(-1, 32), dl) and np.array_equal(np.fromfile(t + ".dr", np.uint8).reshape(-1, 32), dr)
+        assert np.array_equal(np.fromfile(t + ".ur", np.float32), ur) and np.array_equal(np.fromfile(t + ".dp", np.float32), dp)
