@@ -10,7 +10,9 @@
 // simply the smallest key, independent of the order in which the GPU emitted the list.
 // Projection / frustum arithmetic is host code in the reference's evaluation order (contract Q4: no FMA
 // contraction; cv::Mat 3x3*3x1+t as OpenCV's small-matrix gemm path; PredictScale's log through one
-// deterministic routine) -- the same statements as oracle/orb_oracle_match.c, written independently.
+// deterministic routine).  The candidate machinery (64-bit keys, top-4 prefixes, replays) has no counterpart in the oracle, which
+// walks vectors as the reference does; the float statements of the projections and rot_bin are the reference's own and therefore
+// read the same on both sides (oracle/literal_matchers.py is the independent second reading of the control flow).
 #include "../../include/orbfe.h"
 #include "orbfe_device.h"
 #include "orbfe_host.h"

@@ -228,22 +228,29 @@ static inline int key_dist(ckey_t k) { return (int)(k >> 36); }
 static inline int key_idx(ckey_t k) { return (int)((k >> 8) & 0xffffu); }
 static inline int key_level(ckey_t k) { return (int)(k & 0xffu); }
 
-// ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1597-1638, on the bin sizes
+// ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1597-1638, on the bin sizes.  The reference keeps a running top three with
+// strict comparisons, i.e. the three largest NON-EMPTY bins in the order (size descending, index ascending); written here as
+// three selections of the largest remaining (size, -index) key instead of the reference's shifting if-chain (the oracle and
+// oracle/literal_matchers.py keep that form, so the two formulations check each other).
 static inline void three_maxima(const int32_t *sizes, int L, int *ind1, int *ind2, int *ind3)
 {
-    int max1 = 0, max2 = 0, max3 = 0;
-    *ind1 = *ind2 = *ind3 = -1;
-    for (int i = 0; i < L; i++) {
-        const int s = sizes[i];
-        if (s > max1) { max3 = max2; max2 = max1; max1 = s; *ind3 = *ind2; *ind2 = *ind1; *ind1 = i; }
-        else if (s > max2) { max3 = max2; max2 = s; *ind3 = *ind2; *ind2 = i; }
-        else if (s > max3) { max3 = s; *ind3 = i; }
+    int ind[3] = {-1, -1, -1};
+    int32_t val[3] = {0, 0, 0};
+    for (int r = 0; r < 3; r++) {
+        long long best = -1;
+        for (int i = 0; i < L; i++) {
+            if (sizes[i] <= 0 || i == ind[0] || i == ind[1]) continue;
+            const long long key = ((long long)sizes[i] << 32) | (long long)(0x7fffffff - i);
+            if (key > best) { best = key; ind[r] = i; val[r] = sizes[i]; }
+        }
+        if (best < 0) break;
     }
-    if ((float)max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
-    else if ((float)max3 < 0.1f * (float)max1) { *ind3 = -1; }
+    if ((float)val[1] < 0.1f * (float)val[0]) { ind[1] = -1; ind[2] = -1; } // :1628-1637
+    else if ((float)val[2] < 0.1f * (float)val[0]) ind[2] = -1;
+    *ind1 = ind[0]; *ind2 = ind[1]; *ind3 = ind[2];
 }
 
-static inline int rot_bin(float a1, float a2) // Q8: 30 slots, bin = round(rot / 30)
+static inline int rot_bin(float a1, float a2) // Q8: 30 slots, bin = round(rot / 30): the reference's three float statements (:1438-1443), the same in any restatement
 {
     const float factor = 1.0f / HISTO_LENGTH;
     float rot = a1 - a2;

@@ -65,3 +65,28 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liborb_oracle" not in text and "from oracle" not in text and "import oracle" not in text \
                     and "orb_oracle.h" not in text, os.path.join(dirpath, f)
+
+
+def test_product_three_maxima_selection_equals_the_oracles_running_top_three():
+    """orbfe_three_maxima needs no device: the product selects the three largest (size, -index) keys, the oracle keeps the reference's
+    shifting if-chain (src/ORBmatcher.cc:1597-1638) -- two formulations, checked against each other on random, tied and empty bins."""
+    import ctypes as C
+    import numpy as np
+    from oracle import oracle as O
+    from orbslam2_amd import api
+    lib = api.load()
+    lib.orbfe_three_maxima.restype = C.c_int
+    lib.orbfe_three_maxima.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_int)] * 3
+    rng = np.random.default_rng(3)
+    cases = [np.zeros(30, np.int32), np.full(30, 5, np.int32), np.array([0] * 12 + [9] + [0] * 17, np.int32)]
+    for _ in range(400):
+        h = rng.integers(0, rng.integers(1, 40), 30).astype(np.int32)
+        if rng.random() < 0.5:
+            h[rng.integers(0, 30, 6)] = h.max()      # ties for the lead
+        if rng.random() < 0.3:
+            h[rng.random(30) < 0.8] = 0              # mostly empty (only bins 0..12 are ever filled by the matchers)
+        cases.append(h)
+    for h in cases:
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        assert lib.orbfe_three_maxima(h.ctypes.data_as(C.c_void_p), len(h), C.byref(a), C.byref(b), C.byref(c)) == 0
+        assert (a.value, b.value, c.value) == tuple(O.three_maxima(h.tolist())), h.tolist()
