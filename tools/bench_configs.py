@@ -151,4 +151,51 @@ g, c = med(gpu4, 30), med(cpu4, 5, 1)
 out["config 4 D435i RGB-D 1280x720/2500: extract + ComputeStereoFromRGBD + SearchByProjection(last frame)"] = {
     "gpu_ms": g, "cpu_ms": c, "same_matches": bool(res["g4"][0] == res["c4"][0] and np.array_equal(res["g4"][1], res["c4"][1])), "matches": int(res["g4"][0])}
 ctx.close()
+
+# ---- natural pair vs the synthetic benchmark pair, KITTI geometry, per stage (round-2 verdict item 2): the generator makes 16 % of
+# all pixels FAST-9 corners; a photograph has flat and saturated regions and 1-2 % candidates.  64 pairs resident in HBM per step,
+# events at every stage boundary (so the sum is a little above an event-free step).
+import torch  # noqa: E402
+from tests import natural as N  # noqa: E402
+
+
+def stage_table(left, right, label):
+    h, w = left.shape
+    fx, fy, cx, cy, bf = N.camera(w, h)
+    P = 64
+    c2 = api.Context(width=w, height=h, nfeatures=2000, fx=fx, fy=fy, cx=cx, cy=cy, bf=bf, max_images=2 * P)
+    host = np.empty((2 * P, h, w), np.uint8)
+    host[0::2], host[1::2] = left, right
+    d = torch.from_numpy(host).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        c2.enqueue_stereo(d.data_ptr(), P, st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        c2.enqueue_stereo(d.data_ptr(), P, st)
+    torch.cuda.synchronize()
+    step_ms = (time.perf_counter() - t0) / 20 * 1e3
+    c2.set_profiling(1)
+    for _ in range(10):
+        c2.enqueue_stereo(d.data_ptr(), P, st)
+    torch.cuda.synchronize()
+    ms, calls = c2.stage_times(reset=True)
+    c2.set_profiling(0)
+    cand = sum(len(c2.fetch_candidates(0, l)[0]) for l in range(8))
+    got = c2.fetch_image(0, stereo=True)
+    exl, exr = O.Extractor(nfeatures=2000), O.Extractor(nfeatures=2000)
+    kl, dl = exl.extract(left); kr, dr = exr.extract(right)
+    ur, dp, m = O.stereo_matches(exl, exr, kl, dl, kr, dr, bf, fx)
+    ok = bool(len(got["kps"]) == len(kl) and np.array_equal(got["desc"], dl) and np.array_equal(got["u_right"], ur))
+    c2.close()
+    return {"image": label, "size": [w, h], "ms_per_64_pairs_event_free": round(step_ms, 4), "pairs_per_s": round(P / step_ms * 1e3),
+            "stage_ms_per_64_pairs": {k: round(v / max(calls, 1), 4) for k, v in ms.items()},
+            "fast_nms_candidates_per_image": cand, "keypoints": int(len(kl)), "stereo_matches": int(m), "equals_oracle": ok}
+
+
+nl, nr, _, _ = N.pair("china_kitti")
+sl, sr = synth.stereo_pair(1241, 376, seed=1234)
+out["natural vs synthetic, 1241x376 / 2000 features, 64 pairs per step"] = [stage_table(nl, nr, "china_kitti (photograph, tests/natural.py)"),
+                                                                           stage_table(sl, sr, "synthetic pair of bench.py (seed 1234)")]
 print(json.dumps(out, indent=1))
