@@ -328,6 +328,8 @@ int orbfe_search_for_initialization(orbfe_context *ctx, const orbfe_frame_view *
  * orbfe_vocab_load: fbow::Vocabulary::readFromFile / fromStream (Thirdparty/fbow/src/fbow.cpp:172-191) from a
  * memory blob in the fbow file format (u64 55824124, 120-byte params, block data); the tree stays in HBM. */
 int orbfe_vocab_load(orbfe_context *ctx, const uint8_t *blob, size_t size);
+/* Bytes of the vocabulary image the context holds, 0 when none is loaded. */
+long long orbfe_vocab_bytes(orbfe_context *ctx);
 /* Frame::ComputeFboW (src/Frame.cc:395-400) = Vocabulary::transform(desc, level, fBow, fBow2)
  * (Thirdparty/fbow/src/fbow.h:400-444): per descriptor the leaf word id, its weight and the id of the
  * node reached at `level` (4 in ORB-SLAM2).  n == 0 is an error, as in fbow (fbow.cpp:52). */

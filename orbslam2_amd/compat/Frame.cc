@@ -86,7 +86,7 @@ void ensure_vocabulary(orbfe_context *ctx, const fbow::Vocabulary *voc)
     static std::map<orbfe_context *, const fbow::Vocabulary *> loaded;
     std::lock_guard<std::mutex> lk(mu);
     std::map<orbfe_context *, const fbow::Vocabulary *>::iterator it = loaded.find(ctx);
-    if (it != loaded.end() && it->second == voc) return;
+    if (it != loaded.end() && it->second == voc && orbfe_vocab_bytes(ctx) > 0) return; // (a NEW context at a recycled address holds none)
     std::ostringstream os(std::ios::binary);
     voc->toStream(os);
     const std::string blob = os.str();

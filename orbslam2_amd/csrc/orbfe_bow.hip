@@ -190,6 +190,16 @@ extern "C" int orbfe_vocab_load(orbfe_context *ctx, const uint8_t *blob, size_t 
 }
 
 // Vocabulary::transform(features, level, fBow, fBow2): per-feature results (word, weight, node at `level`).
+// size in bytes of the vocabulary image this context holds (0: none): lets a shim that caches "already loaded" per context pointer
+// notice a NEW context at a recycled address
+extern "C" long long orbfe_vocab_bytes(orbfe_context *ctx)
+{
+    ORBFE_ENTRY(ctx);
+    if (!ctx) return 0;
+    orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
+    return st && st->loaded ? (long long)st->p.total_size : 0;
+}
+
 extern "C" int orbfe_bow_transform(orbfe_context *ctx, const uint8_t *desc, int n, int level,
                                    uint32_t *word_id, float *weight, uint32_t *node_id)
 {
