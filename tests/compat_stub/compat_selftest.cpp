@@ -262,7 +262,7 @@ int main(int argc, char **argv)
         //         SearchByProjection(F, vpMapPoints, th) on it: the shim must recognise the frame as the extractor's latest one
         //         (keypoints / descriptors read in HBM, grid built once) and a second call must reuse the grid
         {
-            const std::vector<uchar> img = rd<uchar>("real_image.bin");
+            const std::vector<uchar> img = rd<uchar>("rendered_image.bin");
             std::vector<orbfe_keypoint> rk;
             std::vector<uint8_t> rd_;
             extractor(ImageView{img.data(), W, H, (size_t)W}, rk, rd_);

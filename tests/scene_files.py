@@ -54,7 +54,7 @@ def write_scene(d, seed=77):
              "bow_kf_valid.bin": bow_valid, "bow_kf_nodes.bin": kf_fv[0], "bow_kf_off.bin": kf_fv[1], "bow_kf_feat.bin": kf_fv[2],
              "bow_f_nodes.bin": f_fv[0], "bow_f_off.bin": f_fv[1], "bow_f_feat.bin": f_fv[2], "fuse_kf_obs.bin": fuse_kf_obs}
     from orbslam2_amd import synth
-    files["real_image.bin"] = synth.stereo_pair(W, H, seed=seed + 5)[0]  # a real image for the driver's resident-frame section
+    files["rendered_image.bin"] = synth.stereo_pair(W, H, seed=seed + 5)[0]  # a full rendered image (not a keypoint-level scene) for the driver's resident-frame section
     for name, a in files.items():
         np.ascontiguousarray(a).tofile(d / name)
     return dict(s=s, m=m, n=n, valid3=valid3, usable=usable, max_d=max_d, min_d=min_d, normal=normal, tp=tp, found=found, k1=k1, k2=k2, d2=d2,

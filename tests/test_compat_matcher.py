@@ -149,7 +149,7 @@ def test_reference_signature_calls_match_the_oracle(tmp_path):
     n1, n2, nF = out("n_resident.bin")
     assert nF == len(rk) > 500
     ex = O.Extractor()
-    kref, dref = ex.extract(np.fromfile(d / "real_image.bin", np.uint8).reshape(int(s["bounds"][3]), int(s["bounds"][1])))
+    kref, dref = ex.extract(np.fromfile(d / "rendered_image.bin", np.uint8).reshape(int(s["bounds"][3]), int(s["bounds"][1])))
     assert np.array_equal(rk, kref) and np.array_equal(rdesc, dref)  # the mirror's operator() == oracle
     idx = np.arange(0, nF, 2)
     tpr = np.zeros(len(idx), O.TP_DTYPE)
