@@ -14,7 +14,12 @@
 #include <set>
 #include <vector>
 
-#include "Frame.h"
+#if defined(__has_include)
+#if __has_include("Thirdparty/fbow/include/fbow/fbow.h")
+#include "Thirdparty/fbow/include/fbow/fbow.h" // as the reference's header does (include/KeyFrameDatabase.h:33)
+#endif
+#endif
+#include "Frame.h"    // (the reference's KeyFrame.h includes KeyFrameDatabase.h itself: the forward declarations below cover that cycle)
 #include "KeyFrame.h"
 
 struct orbfe_context;
