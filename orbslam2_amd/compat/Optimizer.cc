@@ -1,4 +1,5 @@
-// compat/Optimizer.cc -- int Optimizer::PoseOptimization(Frame *pFrame) with the reference's signature (include/Optimizer.h:46,
+// compat/Optimizer.cc -- int Optimizer::PoseOptimization(Frame *pFrame) with the reference's signature (include/Optimizer.h:48: a
+// member of the Optimizer OBJECT Tracking holds as mpOptimizer in this fork; it reads none of the object's parameters,
 // src/Optimizer.cc:283-495) over the C ABI, so that src/Tracking.cc:875,998,1040,1475,1555,1580 compile and link unchanged.
 // Build: remove that one function from src/Optimizer.cc (the bundle adjustments, the essential graph and the Sim3 optimiser stay
 // where they are, on g2o) and add this file; "Optimizer.h" is the reference's own header.

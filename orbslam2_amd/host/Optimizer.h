@@ -1,4 +1,4 @@
-// Optimizer.h -- host-side mirror of ORB_SLAM2::Optimizer::PoseOptimization (reference include/Optimizer.h:46,
+// Optimizer.h -- host-side mirror of ORB_SLAM2::Optimizer::PoseOptimization (reference include/Optimizer.h:48,
 // src/Optimizer.cc:283-495) over the C ABI (include/orbfe.h).  The reference takes a Frame*; this mirror takes the
 // fields of the Frame it reads and writes, flattened:
 //   reads   mTcw, N, mvKeysUn, mvuRight, mvpMapPoints[i] != NULL and GetWorldPos() of those, mvInvLevelSigma2 / fx, fy,

@@ -37,7 +37,7 @@ public:
     fbow::fBow mFbowVec;
     long unsigned int mnLoopQuery = 0; int mnLoopWords = 0; float mLoopScore = 0.f;
     long unsigned int mnRelocQuery = 0; int mnRelocWords = 0; float mRelocScore = 0.f;
-    std::vector<KeyFrame *> GetBestCovisibilityKeyFrames(const int &n) { return std::vector<KeyFrame *>(mvpOrderedConnectedKeyFrames.begin(), mvpOrderedConnectedKeyFrames.begin() + ((int)mvpOrderedConnectedKeyFrames.size() < n ? (int)mvpOrderedConnectedKeyFrames.size() : n)); }
+    std::vector<KeyFrame *> GetBestCovisibilityKeyFrames(const int &N) { return std::vector<KeyFrame *>(mvpOrderedConnectedKeyFrames.begin(), mvpOrderedConnectedKeyFrames.begin() + ((int)mvpOrderedConnectedKeyFrames.size() < N ? (int)mvpOrderedConnectedKeyFrames.size() : N)); }
     std::set<KeyFrame *> GetConnectedKeyFrames() { return std::set<KeyFrame *>(mConnected.begin(), mConnected.end()); }
     std::vector<KeyFrame *> mvpOrderedConnectedKeyFrames; // protected in the reference
     std::vector<KeyFrame *> mConnected;                   // test fixture: the keys of mConnectedKeyFrameWeights

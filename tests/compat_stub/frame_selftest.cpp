@@ -22,6 +22,7 @@
 
 using namespace ORB_SLAM2;
 std::mutex MapPoint::mGlobalMutex;
+Optimizer::Optimizer(const string &) {} // src/Optimizer.cc:40-86 reads the settings file; PoseOptimization uses none of it
 
 static std::string g_dir;
 template <class T> static std::vector<T> rd(const std::string &name)
@@ -286,7 +287,8 @@ int main(int argc, char **argv)
                 cv::Mat T(4, 4, CV_32F);
                 for (int i = 0; i < 16; i++) T.ptr<float>(0)[i] = T0[i];
                 F.SetPose(T);
-                const int nInl = Optimizer::PoseOptimization(&F); // src/Tracking.cc:875
+                Optimizer *mpOptimizer = new Optimizer(std::string()); // src/Tracking.cc holds one, built from the settings file
+                const int nInl = mpOptimizer->PoseOptimization(&F); // src/Tracking.cc:875
                 std::vector<float> Tout(16);
                 for (int i = 0; i < 16; i++) Tout[i] = F.mTcw.at<float>(i / 4, i % 4);
                 std::vector<uchar> outl(n);
@@ -300,7 +302,7 @@ int main(int argc, char **argv)
                 int kept = 0;
                 for (int i = 0; i < n && kept < 2; i++) if (has[i]) { G.mvpMapPoints[i] = &pts[i]; kept++; }
                 G.SetPose(T);
-                if (Optimizer::PoseOptimization(&G) != 0 || std::memcmp(G.mTcw.ptr<float>(0), T.ptr<float>(0), 64)) { std::cerr << "PoseOptimization with 2 points touched the pose\n"; return 8; }
+                if (mpOptimizer->PoseOptimization(&G) != 0 || std::memcmp(G.mTcw.ptr<float>(0), T.ptr<float>(0), 64)) { std::cerr << "PoseOptimization with 2 points touched the pose\n"; return 8; }
             }
             { // ---- KeyFrameDatabase
                 const std::vector<int32_t> kf_off = rd<int32_t>("db_kf_off.bin"), cv_off = rd<int32_t>("db_covis_off.bin"), cv_idx = rd<int32_t>("db_covis_idx.bin");

@@ -33,7 +33,7 @@ def test_backend_shims_declare_the_reference_signatures_and_compile():
     body = _norm(re.sub(r"//[^\n]*", "", open(os.path.join(COMPAT, "KeyFrameDatabase.h")).read()))
     for d in REF_DB_DECLS:
         assert _norm(d) in body, d
-    assert _norm("int static PoseOptimization(Frame* pFrame);") in _norm(open(os.path.join(STUB, "Optimizer.h")).read())  # include/Optimizer.h:46
+    assert _norm("int PoseOptimization(Frame* pFrame);") in _norm(open(os.path.join(STUB, "Optimizer.h")).read())  # include/Optimizer.h:48 (a member, not static, in this fork)
     assert "int Optimizer::PoseOptimization(Frame *pFrame)" in open(os.path.join(COMPAT, "Optimizer.cc")).read()
     for f, calls in (("Optimizer.cc", ["orbfe_pose_optimization(", "MapPoint::mGlobalMutex", "pFrame->SetPose("]),
                      ("KeyFrameDatabase.cc", ["orbfe_kfdb_add(", "orbfe_kfdb_erase(", "orbfe_kfdb_clear(", "orbfe_detect_reloc_candidates(", "orbfe_detect_loop_candidates(",
