@@ -153,21 +153,22 @@ public:
 
 #ifdef ORBFE_WITH_OPENCV
     // include/ORBextractor.h:58-60
-    void operator()(cv::InputArray _image, cv::InputArray /*mask*/, std::vector<cv::KeyPoint> &_keypoints, cv::OutputArray _descriptors)
+    void operator()(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint> &keypoints, cv::OutputArray descriptors)
     {
-        if (_image.empty()) return;
-        cv::Mat image = _image.getMat();
-        if (image.type() != CV_8UC1) throw std::invalid_argument("ORBextractor: image must be CV_8UC1"); // assert at :865
+        (void)mask; // ignored, as in the reference (src/ORBextractor.cc:858-866 never reads it)
+        if (image.empty()) return;
+        const cv::Mat img = image.getMat();
+        if (img.type() != CV_8UC1) throw std::invalid_argument("ORBextractor: image must be CV_8UC1"); // assert at :865
         static_assert(sizeof(cv::KeyPoint) == sizeof(orbfe_keypoint), "cv::KeyPoint layout");
         std::vector<orbfe_keypoint> kps;
         std::vector<uint8_t> desc;
-        (*this)(ImageView{image.data, image.cols, image.rows, image.step}, kps, desc);
-        _keypoints.resize(kps.size());
-        if (!kps.empty()) std::memcpy((void *)_keypoints.data(), kps.data(), kps.size() * sizeof(orbfe_keypoint));
-        if (kps.empty()) { _descriptors.release(); }
+        (*this)(ImageView{img.data, img.cols, img.rows, (size_t)img.step}, kps, desc);
+        keypoints.resize(kps.size());
+        if (!kps.empty()) std::memcpy((void *)keypoints.data(), kps.data(), kps.size() * sizeof(orbfe_keypoint));
+        if (kps.empty()) { descriptors.release(); }
         else {
-            _descriptors.create((int)kps.size(), 32, CV_8U);
-            std::memcpy(_descriptors.getMat().data, desc.data(), desc.size());
+            descriptors.create((int)kps.size(), 32, CV_8U);
+            std::memcpy(descriptors.getMat().data, desc.data(), desc.size());
         }
         if (mKeepPyramid) {
             mvImagePyramid.resize(mParams.nlevels);

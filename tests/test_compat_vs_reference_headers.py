@@ -139,3 +139,17 @@ def test_stub_members_the_shims_call_exist_in_the_reference_with_the_same_signat
     assert stub_f - ref_f - fixture_funcs == set(), sorted(stub_f - ref_f - fixture_funcs)
     bad = {k: (v, ref_d.get(k)) for k, v in stub_d.items() if k not in fixture_data and ref_d.get(k) != re.sub(r"=.*$", "", v)}
     assert not bad, bad
+
+
+def test_extractor_mirror_keeps_the_references_public_interface():
+    """orbslam2_amd/host/ORBextractor.h shadows include/ORBextractor.h in an integration: everything public there (constructor, the
+    cv::InputArray call operator, the six getters, mvImagePyramid) must be declared identically; the protected pipeline stages
+    (ComputePyramid, ComputeKeyPointsOctTree, DistributeOctTree, the tables) are what the device replaces."""
+    ref_body = _class_body(_strip(open(os.path.join(REF, "ORBextractor.h")).read()), "ORBextractor")
+    pub_f, pub_d = _members(ref_body.split("protected:")[0])
+    text = _strip(open(os.path.join(ROOT, "orbslam2_amd", "host", "ORBextractor.h")).read()).replace("#ifdef ORBFE_WITH_OPENCV", "").replace("#endif", "")
+    got_f, got_d = _members(_class_body(text, "ORBextractor"))
+    assert len(pub_f) >= 9 and "mvImagePyramid" in pub_d
+    missing = {f for f in pub_f - got_f if not f.startswith("~")}  # the reference's empty destructor vs the mirror's that frees the context
+    assert missing == set(), sorted(missing)
+    assert {k: v for k, v in pub_d.items() if got_d.get(k) != v} == {}
