@@ -227,6 +227,44 @@ def small_batch(api, torch, d_images, P8, make_ctx, chains=4, steps=200, repeats
             "one_chain_at_a_time": v1[len(v1) // 2], "steps": steps, "repeat": repeats, "unit": "frames/s"}
 
 
+def natural_scene(api, torch, dev, P, make_ctx, steps=20):
+    """The same step on a PHOTOGRAPH at the benchmark geometry (tests/natural.py: china.png enlarged to 1241 x 376 with the oracle's
+    resize, right image = a crop 21 px apart with its own gain, offset and noise), one chain at a time: the generator's images have
+    FAST corners on 16 % of all pixels, a real frame has large flat regions.  Checked against the oracle like the headline."""
+    try:
+        from tests import natural as N
+        from oracle import oracle as O
+        left, right, d, nf = N.pair("china_kitti")
+    except Exception as e:  # the fixtures travel with the repository; a missing PIL is the only way here
+        return {"error": str(e)}
+    host = np.empty((2 * P, H, W), np.uint8)
+    host[0::2], host[1::2] = left, right
+    dimg = torch.from_numpy(host).to(dev)
+    fx, fy, cx, cy, bf = N.camera(W, H)
+    ctx = api.Context(width=W, height=H, nfeatures=nf, fx=fx, fy=fy, cx=cx, cy=cy, bf=bf, max_images=2 * P)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        ctx.enqueue_stereo(dimg.data_ptr(), P, st)
+    torch.cuda.synchronize()
+    vals = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.enqueue_stereo(dimg.data_ptr(), P, st)
+        torch.cuda.synchronize()
+        vals.append(P * steps / (time.perf_counter() - t0))
+    ncand = sum(len(ctx.fetch_candidates(0, l)[0]) for l in range(NLEVELS))
+    got = ctx.fetch_image(0, stereo=True)
+    exl, exr = O.Extractor(nfeatures=nf), O.Extractor(nfeatures=nf)
+    kl, dl = exl.extract(left); kr, dr = exr.extract(right)
+    ur, dp, m = O.stereo_matches(exl, exr, kl, dl, kr, dr, bf, fx)
+    ok = bool(len(got["kps"]) == len(kl) and np.array_equal(got["desc"], dl) and np.array_equal(got["u_right"], ur) and np.array_equal(got["kps"]["angle"], kl["angle"]))
+    ctx.close()
+    v = sorted(vals)[len(vals) // 2]
+    return {"image": "china_kitti (photograph at 1241x376, tests/natural.py), %d copies per step" % P, "value": v, "ms_per_step": P / v * 1e3, "unit": "frames/s, one chain at a time",
+            "fast_nms_candidates_per_image": ncand, "keypoints": int(len(kl)), "stereo_matches": int(m), "equals_oracle": ok}
+
+
 def cpu_baseline(n_pairs: int):
     """Oracle (kind=port) timed with the reference's threading: 2 threads per pair (src/Frame.cc:78-81)."""
     from oracle import oracle as O
@@ -298,6 +336,7 @@ def main():
     ap.add_argument("--mode", default="weak", choices=["weak", "strong"], help="weak: --pairs per GPU; strong: --pairs in total, sharded by dist.shard_pairs")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pairs the batch cycles through")
     ap.add_argument("--host-fed", type=int, default=1, help="1: after the timed region also measure the PCIe-inclusive rate (N = 1 only; never `value`)")
+    ap.add_argument("--natural", type=int, default=1, help="1: N = 1 only, also time the step on a photograph at the benchmark geometry -> config.natural_image")
     ap.add_argument("--small-batch", type=int, default=8, help="N = 1 only: also time steps of this many pairs (BASELINE config 4's 8 pairs per GPU) with 4 chains in flight -> config.small_batch; 0 = skip")
     args = ap.parse_args()
 
@@ -539,6 +578,8 @@ def main():
     if rank == 0:
         if world == 1 and args.small_batch > 0 and args.mode == "weak":
             out["config"]["small_batch"] = small_batch(api, torch, d_images, min(args.small_batch, P), make_ctx)
+        if world == 1 and args.natural and args.mode == "weak":
+            out["config"]["natural_image"] = natural_scene(api, torch, dev, P, make_ctx)
         if world == 1 and args.host_fed:
             out["config"]["host_fed"] = host_fed(api, torch, dev, host, P, make_ctx)
         if world == 1 and args.cpu_pairs > 0:
