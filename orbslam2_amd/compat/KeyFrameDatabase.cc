@@ -24,11 +24,33 @@ template <class Bow> void flatten(const Bow &bow, std::vector<uint32_t> &words, 
 
 KeyFrameDatabase::KeyFrameDatabase(fbow::Vocabulary *voc) : mpFBOWVoc(voc), mCtx(NULL) {}
 
+namespace
+{
+// A device context holds ONE keyframe database (the reference has one per System, src/System.cc:88): a second KeyFrameDatabase
+// object on the same context would clear and interleave the first one's entries, so ownership is explicit.
+std::mutex g_owner_mu;
+std::map<orbfe_context *, const KeyFrameDatabase *> g_owner;
+} // namespace
+
+KeyFrameDatabase::~KeyFrameDatabase()
+{
+    std::lock_guard<std::mutex> lk(g_owner_mu);
+    std::map<orbfe_context *, const KeyFrameDatabase *>::iterator it = g_owner.find(mCtx);
+    if (mCtx && it != g_owner.end() && it->second == this) g_owner.erase(it);
+}
+
 orbfe_context *KeyFrameDatabase::Context()
 {
     if (!mCtx) {
-        mCtx = ORBextractor::DefaultContext();
-        if (!mCtx) throw std::runtime_error("KeyFrameDatabase: no ORBextractor device context exists in this process yet");
+        orbfe_context *ctx = ORBextractor::DefaultContext();
+        if (!ctx) throw std::runtime_error("KeyFrameDatabase: no ORBextractor device context exists in this process yet");
+        {
+            std::lock_guard<std::mutex> lk(g_owner_mu);
+            if (g_owner.count(ctx) && g_owner[ctx] != this)
+                throw std::runtime_error("KeyFrameDatabase: this device context already serves another KeyFrameDatabase object (one database per context)");
+            g_owner[ctx] = this;
+        }
+        mCtx = ctx;
         check(mCtx, orbfe_kfdb_clear(mCtx));
     }
     return mCtx;

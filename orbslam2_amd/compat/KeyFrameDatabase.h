@@ -45,6 +45,7 @@ public:
     std::vector<KeyFrame *> DetectRelocalizationCandidates(Frame *F);
 
     KeyFrameDatabase() : mpFBOWVoc(NULL), mCtx(NULL) {}
+    ~KeyFrameDatabase(); // gives the device database back (the reference never destroys its one database; tests do)
     void SetFBOWvocabulary(fbow::Vocabulary *pfbowv) { mpFBOWVoc = pfbowv; }
 
 protected:

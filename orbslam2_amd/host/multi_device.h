@@ -79,6 +79,7 @@ public:
 
     // One step: n_pairs pairs ([pair][left | right][h][w] packed 8UC1 in host memory) -> results in frame order.  Every context
     // extracts its shard (upload, one stage chain, download) on its own feeder thread; the call returns when all are done.
+    // One Process() at a time per object (the caller is the application's frame loop); `pairs` and `out` must outlive the call.
     void Process(const uint8_t *pairs, int n_pairs, std::vector<StereoPairResult> &out)
     {
         if (n_pairs < 1 || n_pairs > mMaxPairs) throw std::invalid_argument("MultiDeviceFrontEnd::Process: batch larger than the capacity fixed at construction");
