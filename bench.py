@@ -336,6 +336,7 @@ def main():
     ap.add_argument("--mode", default="weak", choices=["weak", "strong"], help="weak: --pairs per GPU; strong: --pairs in total, sharded by dist.shard_pairs")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pairs the batch cycles through")
     ap.add_argument("--host-fed", type=int, default=1, help="1: after the timed region also measure the PCIe-inclusive rate (N = 1 only; never `value`)")
+    ap.add_argument("--rehearse-rccl", action="store_true", help="N = 1: run over a ONE-RANK process group of --backend, so a one-GPU box exercises the very RCCL calls of the multi-GPU path (parameter / vocabulary broadcast, barrier, MAX all-reduce)")
     ap.add_argument("--natural", type=int, default=1, help="1: N = 1 only, also time the step on a photograph at the benchmark geometry -> config.natural_image")
     ap.add_argument("--small-batch", type=int, default=8, help="N = 1 only: also time steps of this many pairs (BASELINE config 4's 8 pairs per GPU) with 4 chains in flight -> config.small_batch; 0 = skip")
     args = ap.parse_args()
@@ -357,7 +358,7 @@ def main():
     torch.cuda.set_device(gpu_index)
     dev = torch.device("cuda", gpu_index)
     cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
-    D.init(args.backend, dev)
+    D.init(args.backend, dev, force=args.rehearse_rccl)
 
     # one-time RCCL broadcast of the extractor parameters + rBRIEF pattern checksum
     blob = D.broadcast_params(D.pack_params(NFEAT, 1.2, NLEVELS, 20, 7, 31, 15, 19, FX, FY, CX, CY, BF), cdev)
@@ -366,7 +367,7 @@ def main():
     # one-time RCCL broadcast of the vocabulary (fbow file format) from rank 0 into every rank's HBM: the only other
     # xGMI traffic north_star allows.  Synthetic k = 10 / L = 3 tree here (no vocabulary file ships with the repo).
     voc_blob = None
-    if world > 1:
+    if world > 1 or args.rehearse_rccl:
         from orbslam2_amd import bow as BOW
         if rank == 0:
             rng = np.random.default_rng(99)
@@ -588,7 +589,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if world > 1 or args.rehearse_rccl:
         D.barrier()
         dist.destroy_process_group()
 

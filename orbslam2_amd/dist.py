@@ -22,9 +22,11 @@ def world_info():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init(backend: str, device=None):
+def init(backend: str, device=None, force: bool = False):
+    """Process group over `backend` when more than one rank runs (or `force`: a one-rank group, which lets a one-GPU box exercise the
+    very RCCL calls of the multi-GPU path -- every helper below runs its collective whenever a group exists)."""
     rank, _, world = world_info()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
@@ -44,7 +46,7 @@ def unpack_params(blob: bytes):
 def broadcast_params(blob: bytes, device) -> bytes:
     """Rank 0's parameter blob on every rank; raises if this rank's pattern table differs from rank 0's."""
     t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         mine = t.clone()
         dist.broadcast(t, src=0)
         n = struct.calcsize(PARAM_FMT)
@@ -58,7 +60,7 @@ def broadcast_blob(blob, device) -> bytes:
     ignored on the other ranks and may be None) on every rank: one 8-byte length broadcast, then the payload in one
     collective (backend "nccl" = RCCL over xGMI, device tensors; gloo: CPU tensors).  Every rank then hands the bytes to
     orbfe_vocab_load, which keeps the tree in its GPU's HBM.  A sha256 travels with the payload and is checked."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not dist.is_initialized():
         if blob is None:
             raise ValueError("broadcast_blob: rank 0 must supply the blob")
         return bytes(blob)
@@ -87,7 +89,7 @@ def shard_pairs(total_pairs: int, rank: int, world: int):
 
 
 def max_over_ranks(value: float, device) -> float:
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         t = torch.tensor([value], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
@@ -95,5 +97,5 @@ def max_over_ranks(value: float, device) -> float:
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.barrier()

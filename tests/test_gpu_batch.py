@@ -1,5 +1,7 @@
 """Device-resident batched path (orbfe_enqueue_stereo / orbfe_fetch_image) and stream groups:
 every pair of a batch must equal the single-frame result (and hence the oracle), whatever the grouping."""
+import os
+
 import numpy as np
 import pytest
 
@@ -155,3 +157,36 @@ def test_sharded_batch_on_two_ranks_covers_every_pair_once(batch):
         left, right = seen[i]
         assert np.array_equal(left["kps"], ref["kps_left"]) and np.array_equal(left["desc"], ref["desc_left"])
         assert np.array_equal(right["kps"], ref["kps_right"]) and np.array_equal(left["u_right"], ref["u_right"])
+
+
+def test_rccl_collectives_of_the_sharded_bench_on_one_rank(tmp_path):
+    """The multi-GPU path's collectives -- parameter + pattern-checksum broadcast, vocabulary broadcast, MAX all-reduce of the elapsed
+    time, barrier -- through the REAL backend (torch.distributed "nccl" = RCCL, device tensors) as a one-rank group: the same calls
+    bench.py makes on 8 GPUs, runnable on a one-GPU box.  (Two gloo ranks cover the N > 1 logic: tests/test_sharding_gloo.py.)"""
+    import subprocess
+    import sys
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text('''
+import os, sys, hashlib
+sys.path.insert(0, %r)
+os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+import numpy as np, torch
+from orbslam2_amd import dist as D
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+D.init("nccl", dev, force=True)
+import torch.distributed as dist
+assert dist.is_initialized() and dist.get_backend() == "nccl"
+blob = D.pack_params(2000, 1.2, 8, 20, 7, 31, 15, 19, 718.856, 718.856, 607.19, 185.22, 386.14)
+assert D.broadcast_params(blob, dev) == blob
+voc = np.random.default_rng(1).integers(0, 256, 3_000_000, dtype=np.uint8).tobytes()
+got = D.broadcast_blob(voc, dev)
+assert hashlib.sha256(got).digest() == hashlib.sha256(voc).digest()
+assert D.max_over_ranks(1.25, dev) == 1.25
+D.barrier()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("rccl one-rank ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, r.stdout + r.stderr[-2000:]
