@@ -341,6 +341,13 @@ def main():
     ap.add_argument("--small-batch", type=int, default=8, help="N = 1 only: also time steps of this many pairs (BASELINE config 4's 8 pairs per GPU) with 4 chains in flight -> config.small_batch; 0 = skip")
     args = ap.parse_args()
 
+    # Rank 0 prints ONE JSON line on stdout and nothing else: RCCL writes its version banner ("RCCL version : ... Librccl path : ...")
+    # to STDOUT when the first communicator is created, and other libraries may chat there too, so file descriptor 1 points at stderr
+    # until the line is ready.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from orbslam2_amd import api, synth
@@ -587,7 +594,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     ctx.close()
     if world > 1 or args.rehearse_rccl:
         D.barrier()
