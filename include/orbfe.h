@@ -22,6 +22,8 @@
  *                      (orbfe_quadtree_kernel() reports the choice);
  *   ORBFE_NO_TAIL=1    keep the last pyramid levels on separate launches instead of
  *                      the fused tail kernel;
+ *   ORBFE_PYR_LDS=1    keep cv::resize on the LDS-staged kernel (the path of scale factors
+ *                      above ~2) instead of the direct one;
  *   ORBFE_HOST_TRACE=1 print the context's geometry, kernel choices and LDS sizes to
  *                      stderr at create time.
  *

@@ -466,6 +466,30 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
                 tab[D.rs_xtab_off + i] = (uint32_t)sx | ((uint32_t)sx1 << 16);
                 tab[D.rs_xtab_off + nx + i] = (uint32_t)a0 | ((uint32_t)a1 << 16);
             }
+            {   // pyr_resize_direct_kernel: the two source bytes of every column as a v_perm_b32 selector into the 8 bytes that
+                // start at the leftmost source byte of the column's 4-column word, and that byte's offset per word
+                D.rs_dtab_off = (int)tab.size();
+                tab.resize(tab.size() + (size_t)nx + nx / 4, 0);
+                bool direct = true;
+                for (int wd = 0; wd < nx / 4; wd++) {
+                    int lo = INT_MAX;
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t e = tab[D.rs_xtab_off + 4 * wd + j];
+                        lo = std::min(lo, std::min((int)(e & 0xffffu), (int)(e >> 16)));
+                    }
+                    tab[D.rs_dtab_off + nx + wd] = (uint32_t)lo;
+                    if (orbfe_resize_word_base_host(wd, D.w, D.rs_scale_x, S.w) != lo) direct = false; // the kernel computes this offset
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t e = tab[D.rs_xtab_off + 4 * wd + j];
+                        const int o0 = (int)(e & 0xffffu) - lo, o1 = (int)(e >> 16) - lo;
+                        if (o0 > 7 || o1 > 7) direct = false;
+                        tab[D.rs_dtab_off + 4 * wd + j] = 0x0c000c00u | (uint32_t)(o0 & 7) | ((uint32_t)(o1 & 7) << 16);
+                    }
+                }
+                const char *env = getenv("ORBFE_PYR_LDS");
+                D.rs_direct = direct && ORBFE_PYR_RB > 0 && !(env && env[0] == '1');
+                if (getenv("ORBFE_HOST_TRACE")) fprintf(stderr, "orbfe: level %d cv::resize: %s kernel\n", l, D.rs_direct ? "direct (aligned 96-bit row loads)" : "LDS-staged");
+            }
             D.rs_ytab_off = (int)tab.size(); D.rs_ytab_n = ny;
             tab.resize(tab.size() + 2 * (size_t)ny, 0);
             for (int i = 0; i < ny; i++) {

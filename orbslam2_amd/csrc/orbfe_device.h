@@ -28,6 +28,9 @@ static inline int orbfe_cut_value(const char *env) { const char *v = getenv(env)
 #define ORBFE_CUT_ARG(env)
 #endif
 
+#ifndef ORBFE_PYR_RB
+#define ORBFE_PYR_RB 4 // extended rows per wave of pyr_resize_direct_kernel (0: never use it; A/B builds only)
+#endif
 // Per-level geometry (reference: src/ORBextractor.cc:759-781,925-926,533-557).
 struct LevelInfo {
     int w, h, pitch;       // level image size and row pitch (bytes)
@@ -50,6 +53,7 @@ struct LevelInfo {
     int rs_ytab_off, rs_ytab_n;    // resize row table
     int rs_src_rows[3];            // source rows spanned by the worst block of 16 / 8 / 4 output rows (pyr_resize_kernel)
     int rs_rw, rs_blk_off;         // rows per wave the launch uses (4 / 2 / 1) and this level's entries in DeviceBuffers::rs_blk
+    int rs_direct, rs_dtab_off;    // pyr_resize_direct_kernel usable (every 4-column word's sources lie within 8 bytes) and its table: rs_xtab_n byte selectors, then rs_xtab_n / 4 first-source-byte offsets
     int bk_xoff, bk_yoff;          // quadtree bucket tables of this level in DeviceBuffers::bk_tab (orbfe_octree3.hip)
     int bk_part_off, bk_part_n;    // this level's per-cell bucket partials in DeviceBuffers::bk_part / bk_emap
     int bk_points;                 // some cell of the level spans > 64 buckets: the quadtree kernel buckets its candidates itself
@@ -169,6 +173,7 @@ static_assert(sizeof(KeyPointPOD) == 28, "keypoint must match cv::KeyPoint");
 void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, const uint8_t *d_images,
                          int n_images, hipStream_t s);
 void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
+int orbfe_resize_word_base_host(int xw, int dst_w, double scale, int src_w); // pyr_resize_direct_kernel's first-source-byte formula, for orbfe_create's check
 void orbfe_launch_blur(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
 void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool buckets, hipStream_t s);
 void orbfe_launch_octree_generic(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);

@@ -273,6 +273,114 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(DeviceConfig cfg, Devic
     }
 }
 
+// The same resize without LDS (round 3).  With the 1.2 : 1 ratio of the pyramid the two source bytes of each of a lane's four
+// output columns lie within 8 bytes of the leftmost one (b), so a lane reads a source row as ONE aligned 96-bit global load at
+// b & ~3, shifts it to b with two v_alignbyte_b32 and picks its bytes with v_perm_b32 (host-built selectors,
+// LevelInfo::rs_dtab_off); the horizontal pass is then a v_dot2_u32_u16 against the packed weights.  A wave owns 64 words x
+// RB consecutive extended rows: the row-table entries are wave-uniform scalar loads, b is computed rather than looked up (the
+// first loads then wait for nothing but those), every load of the band is issued before the first store, and there is no
+// staging, no barrier and no byte gather through the LDS pipe, which is what bounded pyr_resize_kernel.  A source row shared
+// by consecutive output rows is loaded and filtered once (a uniform branch).  Measured, KITTI levels 1-4, 128 images:
+// 36.4 / 26.7 / 19.6 / 17.0 us (pyr_resize_kernel) -> 28.0 / 19.9 / 15.2 / 13.2 us; what is left is ~6 us per launch of
+// dependent latency (kernel arguments -> row table -> source rows) plus ~4.6 TB/s of traffic.  Variants (A/B on one box,
+// pyramid stage in ms, LDS kernel 0.131): byte-aligned 64-bit loads with the duplicates 0.118-0.120 (unaligned loads cost the
+// texture addresser about twice an aligned one), the same without duplicates 0.107, aligned 0.107, RB 2 / 4 / 8: 0.124 / 0.108 /
+// 0.110; a wave walking 16 / 32 / 64 rows with the next group's loads in flight: 0.124 / 0.130 / 0.154 (fewer, longer waves
+// lose: these launches live on the number of independent waves).  Levels whose words reach further than 8 bytes (scale
+// factors above ~2) keep pyr_resize_kernel, and ORBFE_PYR_LDS=1 forces it.
+// first source column of extended column i (cv::resize's xofs, as orbfe_create builds the table; it checks this formula against it)
+__host__ __device__ __forceinline__ int resize_first_source(int dx, double scale, int src_w)
+{
+    const float fx = (float)(((double)dx + 0.5) * scale - 0.5);
+    int sx = (int)floorf(fx);
+    sx = sx < 0 ? 0 : sx;
+    return sx >= src_w - 1 ? src_w - 1 : sx;
+}
+__host__ __device__ __forceinline__ int resize_word_base(int xw, int dst_w, double scale, int src_w)
+{
+    int lo = 0x7fffffff;
+    for (int j = 0; j < 4; j++) {
+        int q = 4 * xw + j - PYR_MX;
+        if (dst_w == 1) q = 0;
+        else while (q < 0 || q >= dst_w) q = q < 0 ? -q : 2 * dst_w - 2 - q;
+        lo = q < lo ? q : lo;
+    }
+    return resize_first_source(lo, scale, src_w);
+}
+int orbfe_resize_word_base_host(int xw, int dst_w, double scale, int src_w) { return resize_word_base(xw, dst_w, scale, src_w); }
+
+template <int RB>
+__global__ __launch_bounds__(256) void pyr_resize_direct_kernel(DeviceConfig cfg, DeviceBuffers buf, int level)
+{
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const int img = blockIdx.z;
+    const LevelInfo &D = cfg.lv[level];
+    const LevelInfo &S = cfg.lv[level - 1];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ny = D.rs_ytab_n, nx = D.rs_xtab_n, nwords = nx >> 2;
+    const int y0 = ((int)blockIdx.y * 4 + wave) * RB; // first extended row of this wave's band
+    if (y0 >= ny) return;
+    const int xw = (int)blockIdx.x * 64 + lane;
+    if (xw >= nwords) return; // no barriers: the spare lanes of the last strip just leave
+    const uint32_t *__restrict__ xt = buf.rs_tab + D.rs_xtab_off;
+    const uint32_t *__restrict__ dt = buf.rs_tab + D.rs_dtab_off;
+    // the row table through the constant address space: never written by a kernel, and only so does the compiler keep its
+    // (wave-uniform) reads scalar loads whatever stores to the pyramid are around
+    typedef const __attribute__((address_space(4))) uint32_t *rs_const_ptr;
+    const rs_const_ptr yt = (rs_const_ptr)(uintptr_t)(buf.rs_tab + D.rs_ytab_off);
+    const int base = resize_word_base(xw, D.w, D.rs_scale_x, S.w);
+    const uint8_t *sp = buf.pyr + (size_t)img * cfg.pyr_bytes + S.pyr_off + (base & ~3); // pixel (0,0) and the pitch are 4-byte aligned
+    const unsigned sh = (unsigned)base & 3u;
+    struct __attribute__((packed, aligned(4))) win_t { uint32_t x, y, z; };
+    uint8_t *dst = buf.pyr + (size_t)img * cfg.pyr_bytes + D.pyr_off + (xw * 4 - PYR_MX);
+    const unsigned spitch = (unsigned)S.pitch;
+    uint32_t ye[RB], yb[RB];
+#pragma unroll
+    for (int k = 0; k < RB; k++) {
+        const int yy = y0 + k < ny ? y0 + k : ny - 1;
+        ye[k] = yt[yy]; yb[k] = yt[ny + yy];
+    }
+    win_t wa[RB], wb[RB];
+#pragma unroll
+    for (int k = 0; k < RB; k++) {
+        if (k == 0 || (ye[k] & 0xffffu) != (ye[k - 1] >> 16)) // uniform: else the previous row's lower source row
+            wa[k] = *(const win_t *)(sp + __umul24(ye[k] & 0xffffu, spitch));
+        wb[k] = *(const win_t *)(sp + __umul24(ye[k] >> 16, spitch));
+    }
+    const uint4 SEL = *(const uint4 *)(dt + 4 * xw);
+    const uint4 WT = *(const uint4 *)(xt + nx + 4 * xw);
+    const uint32_t sel[4] = {SEL.x, SEL.y, SEL.z, SEL.w}, wt[4] = {WT.x, WT.y, WT.z, WT.w};
+    auto hpass = [&](const win_t w, unsigned h[4]) {
+        const unsigned lo = __builtin_amdgcn_alignbyte(w.y, w.x, sh), hi = __builtin_amdgcn_alignbyte(w.z, w.y, sh);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned pp = __builtin_amdgcn_perm(hi, lo, sel[j]); // S[sx] | S[sx1] << 16
+            h[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pp), __builtin_bit_cast(u16x2, wt[j]), 0u, false) & ~15u;
+        }
+    };
+    unsigned hA[4], hB[4];
+#pragma unroll
+    for (int k = 0; k < RB; k++) {
+        if (y0 + k >= ny) break; // uniform
+        if (k > 0 && (ye[k] & 0xffffu) == (ye[k - 1] >> 16)) { // uniform: this row's upper source row is the previous row's lower one
+#pragma unroll
+            for (int j = 0; j < 4; j++) hA[j] = hB[j];
+        } else {
+            hpass(wa[k], hA);
+        }
+        hpass(wb[k], hB);
+        const unsigned b0 = (yb[k] & 0xffffu) << 12, b1 = (yb[k] >> 16) << 12; // <= 2^23
+        uint32_t out = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned v0 = (unsigned)(((unsigned long long)(b0 & 0xffffffu) * (unsigned long long)(hA[j] & 0xffffffu)) >> 32);
+            const unsigned v1 = (unsigned)(((unsigned long long)(b1 & 0xffffffu) * (unsigned long long)(hB[j] & 0xffffffu)) >> 32);
+            out |= ((v0 + v1 + 2u) >> 2) << (8 * j);
+        }
+        *(uint32_t *)(dst + (ptrdiff_t)(y0 + k - PYR_MY) * D.pitch) = out;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Fused pyramid tail: the last NST levels (NST = 2 or 3) in ONE launch.  On their own these levels are latency bound: each
 // launch is a chain of dependent table loads, staging, one barrier and a few microseconds of arithmetic (10 us per level for
@@ -572,7 +680,12 @@ void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int
         // rows per wave: the largest of 4, 2, 1 whose staged source rows fit 60 KB of LDS (rs_src_rows[i] = source
         // row span of the worst block of 16 / 8 / 4 output rows, from the host's row table)
         const int *span = cfg.lv[l].rs_src_rows;
-        if (cfg.lv[l].rs_rw == 4) {
+        if (cfg.lv[l].rs_direct) {
+            const int nwords = cfg.lv[l].rs_xtab_n >> 2;
+            const int rb = ORBFE_PYR_RB > 0 ? ORBFE_PYR_RB : 8;
+            dim3 grid((nwords + 63) / 64, (total_rows + 4 * rb - 1) / (4 * rb), n_images);
+            hipLaunchKernelGGL(pyr_resize_direct_kernel<(ORBFE_PYR_RB > 0 ? ORBFE_PYR_RB : 8)>, grid, dim3(256), 0, s, cfg, buf, l);
+        } else if (cfg.lv[l].rs_rw == 4) {
             dim3 grid((total_rows + 15) / 16, n_images);
             hipLaunchKernelGGL(pyr_resize_kernel<4>, grid, dim3(256), (size_t)span[0] * rowp, s, cfg, buf, l, src_words, span[0]);
         } else if (cfg.lv[l].rs_rw == 2) {

@@ -166,6 +166,39 @@ def test_point_parallel_quadtree_kernel_still_matches(monkeypatch):
     assert np.array_equal(k1, kr.astype(api.KP_DTYPE)) and np.array_equal(d1, dr)
 
 
+def test_lds_resize_kernel_still_matches(monkeypatch):
+    """ORBFE_PYR_LDS=1 keeps the pyramid on pyr_resize_kernel (LDS-staged; the path for levels whose 4-column words reach
+    further than 8 source bytes) instead of pyr_resize_direct_kernel: same pyramid, same keypoints."""
+    from orbslam2_amd import api
+    left = synth.mono_image(1241, 376, seed=11)
+    ex = O.Extractor(nfeatures=2000)
+    kr, dr = ex.extract(left)
+    for lds in ("1", "0"):
+        monkeypatch.setenv("ORBFE_PYR_LDS", lds)
+        ctx = api.Context(width=1241, height=376, nfeatures=2000)
+        k, d = ctx.extract(left)
+        for l in range(8):
+            assert np.array_equal(ctx.fetch_pyramid(0, l), ex.pyramid_level(l)), (lds, l)
+        assert np.array_equal(k, kr.astype(api.KP_DTYPE)) and np.array_equal(d, dr), lds
+        ctx.close()
+
+
+@pytest.mark.parametrize("sf,nlevels", [(2.6, 3), (2.0, 4), (1.95, 4), (1.05, 6)])
+def test_resize_scale_factors_around_the_direct_kernel_limit(sf, nlevels):
+    """Scale factors whose words need more than 8 source bytes (2.6; some levels of 2.0, where level sizes round to a ratio
+    just above 2) take the LDS kernel, the others the direct one: orbfe_create decides per level from the column table."""
+    from orbslam2_amd import api
+    left = synth.mono_image(1000, 700, seed=int(sf * 100))
+    ex = O.Extractor(nfeatures=1000, scale_factor=sf, nlevels=nlevels)
+    kr, dr = ex.extract(left)
+    ctx = api.Context(width=1000, height=700, nfeatures=1000, scale_factor=sf, nlevels=nlevels)
+    k, d = ctx.extract(left)
+    for l in range(nlevels):
+        assert np.array_equal(ctx.fetch_pyramid(0, l), ex.pyramid_level(l)), l
+    assert np.array_equal(k, kr.astype(api.KP_DTYPE)) and np.array_equal(d, dr)
+    ctx.close()
+
+
 def test_stereo_row_list_overflow():
     """All keypoints inside a thin horizontal band: the per-row candidate lists exceed their fixed capacity and the
     stereo search must fall back to scanning every right keypoint -- same matches as the oracle."""
