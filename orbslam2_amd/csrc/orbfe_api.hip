@@ -44,6 +44,7 @@ struct orbfe_context {
     std::vector<int> slot_cnt;    // keypoint counts of the slots of call `slot_cnt_epoch` (host copy, filled by the first fetch)
     unsigned slot_cnt_epoch = ~0u;
     bool use_octree2 = false; // point-parallel quadtree (all levels have <= 4 roots and the LDS budget fits)
+    bool fuse_blur = true;    // blur level l - 1 in the launch that resizes it into level l (ORBFE_NO_FUSE=1: separate launches)
     bool use_octree3 = false; // bucket-pyramid quadtree (orbfe_octree3.hip); preferred when its limits hold
     size_t ot3_lds = 0;
     bool ot3_nodes_in_hbm = false; // node tables of the bucket-pyramid quadtree in HBM scratch (large per-level quotas)
@@ -553,6 +554,7 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
             DeviceConfig &c2 = ctx->cfg;
             c2.tail_first = 0; c2.tail_n = 0; c2.tail_strips = 0; c2.tail_lds_bytes = 0;
             const int nst = p.nlevels >= 4 ? 3 : (p.nlevels == 3 ? 2 : 0);
+            { const char *nf = getenv("ORBFE_NO_FUSE"); ctx->fuse_blur = !(nf && nf[0] == '1'); }
             const char *env = getenv("ORBFE_NO_TAIL");
             if (nst >= 2 && !(env && env[0] == '1')) {
                 const int F = p.nlevels - nst, Lz = p.nlevels - 1;
@@ -1001,9 +1003,9 @@ static void run_chain(orbfe_context *ctx, const uint8_t *d_images, int img0, int
     prof_mark(ctx, group, 0, s);
     orbfe_launch_ingest(cfg, buf, src, n_images, s);
     prof_mark(ctx, group, 1, s);
-    orbfe_launch_pyramid(cfg, buf, n_images, s);
+    const int blurred = orbfe_launch_pyramid(cfg, buf, n_images, ctx->fuse_blur, s);
     prof_mark(ctx, group, 2, s);
-    orbfe_launch_blur(cfg, buf, n_images, s);
+    orbfe_launch_blur(cfg, buf, n_images, blurred, s);
     prof_mark(ctx, group, 3, s);
     orbfe_launch_fast(cfg, buf, n_images, ctx->use_octree3, s);
     prof_mark(ctx, group, 4, s);

@@ -9,7 +9,9 @@
 #define ORBFE_MAX_LEVELS 16
 #define ORBFE_TAIL_MAX 3   // levels fused by pyr_tail_kernel
 #define ORBFE_TAIL_COLS 64 // extended columns of the last level per workgroup
+#ifndef ORBFE_BLUR_ROWS
 #define ORBFE_BLUR_ROWS 32
+#endif
 #define ORBFE_WAVE 64
 
 // Profiling cut points (tools/*_phases.sh, tools/*_insts.sh): an extra kernel argument that makes a kernel return after a
@@ -172,9 +174,9 @@ static_assert(sizeof(KeyPointPOD) == 28, "keypoint must match cv::KeyPoint");
 // launchers (orbfe_pyramid.hip, orbfe_fast.hip, orbfe_octree*.hip, orbfe_describe.hip, orbfe_stereo.hip)
 void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, const uint8_t *d_images,
                          int n_images, hipStream_t s);
-void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
+int orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool fuse_blur, hipStream_t s); // returns the number of levels (from 0) whose blur it launched too
 int orbfe_resize_word_base_host(int xw, int dst_w, double scale, int src_w); // pyr_resize_direct_kernel's first-source-byte formula, for orbfe_create's check
-void orbfe_launch_blur(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
+void orbfe_launch_blur(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int first_level, hipStream_t s);
 void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool buckets, hipStream_t s);
 void orbfe_launch_octree_generic(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
 void orbfe_launch_octree2(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, int lds_pts, size_t lds, hipStream_t s);

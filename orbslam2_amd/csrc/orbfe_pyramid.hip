@@ -310,17 +310,16 @@ __host__ __device__ __forceinline__ int resize_word_base(int xw, int dst_w, doub
 int orbfe_resize_word_base_host(int xw, int dst_w, double scale, int src_w) { return resize_word_base(xw, dst_w, scale, src_w); }
 
 template <int RB>
-__global__ __launch_bounds__(256) void pyr_resize_direct_kernel(DeviceConfig cfg, DeviceBuffers buf, int level)
+__device__ __forceinline__ void resize_direct_wave(const DeviceConfig &cfg, const DeviceBuffers &buf, int level, int img, int strip, int band)
 {
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    const int img = blockIdx.z;
     const LevelInfo &D = cfg.lv[level];
     const LevelInfo &S = cfg.lv[level - 1];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
     const int ny = D.rs_ytab_n, nx = D.rs_xtab_n, nwords = nx >> 2;
-    const int y0 = ((int)blockIdx.y * 4 + wave) * RB; // first extended row of this wave's band
+    const int y0 = band * RB; // first extended row of this wave's band
     if (y0 >= ny) return;
-    const int xw = (int)blockIdx.x * 64 + lane;
+    const int xw = strip * 64 + lane;
     if (xw >= nwords) return; // no barriers: the spare lanes of the last strip just leave
     const uint32_t *__restrict__ xt = buf.rs_tab + D.rs_xtab_off;
     const uint32_t *__restrict__ dt = buf.rs_tab + D.rs_dtab_off;
@@ -379,6 +378,13 @@ __global__ __launch_bounds__(256) void pyr_resize_direct_kernel(DeviceConfig cfg
         }
         *(uint32_t *)(dst + (ptrdiff_t)(y0 + k - PYR_MY) * D.pitch) = out;
     }
+}
+
+template <int RB>
+__global__ __launch_bounds__(256) void pyr_resize_direct_kernel(DeviceConfig cfg, DeviceBuffers buf, int level)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    resize_direct_wave<RB>(cfg, buf, level, blockIdx.z, blockIdx.x, (int)blockIdx.y * 4 + wave);
 }
 
 // ---------------------------------------------------------------------------
@@ -563,13 +569,10 @@ __global__ __launch_bounds__(TAIL_THREADS) void pyr_tail_kernel(DeviceConfig cfg
 // ---------------------------------------------------------------------------
 #define BL_ROWS ORBFE_BLUR_ROWS // rows per wave (a multiple of 4): 6 / BL_ROWS of the rows are loaded (and row-filtered) twice; 32 beats 16 by 4 us now that the kernel is memory-bound (no difference while it was issue-bound); 48 / 64: + 3 / + 9 us (too few waves)
 #define BL_COLS 256 // per wave: 64 lanes x 4 px
-__global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffers buf)
+// tile u of the flattened (level, row band, 256-column strip) list, by one wave
+__device__ __forceinline__ void blur_wave(const DeviceConfig &cfg, const DeviceBuffers &buf, int img, int u)
 {
-    // the waves of a workgroup are independent: wave u of the flattened (level, row band, 256-column strip) list
-    const int img = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    const int u = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (u >= cfg.blur_tiles_total) return;
     const uint32_t ti = buf.blur_tile_info[u]; // host-built: saves the per-wave level search (a chain of dependent scalar loads)
     const LevelInfo &L = cfg.lv[ti & 0xffu];
     const int x0 = (int)((ti >> 8) & 0xffu) * BL_COLS + lane * 4;
@@ -655,6 +658,38 @@ __global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffe
 }
 
 
+// the waves of a workgroup are independent; tiles [tile_begin, tile_end) of the list (level-major: a range is a set of levels)
+__global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffers buf, int tile_begin, int tile_end)
+{
+    const int u = tile_begin + (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (u >= tile_end) return;
+    blur_wave(cfg, buf, blockIdx.y, u);
+}
+
+// Level l from level l - 1 AND the blur of level l - 1 in one launch (both only read level l - 1), as independent waves of one
+// grid: no second stream, no event (those cost more than they return: tools/experiments).  The blur workgroups of ALL images are
+// dispatched first, the resize workgroups after them.  Measured (pyramid + blur stages, A/B on one box, separate launches
+// 0.186 ms): this order 0.181; blur and resize workgroups interleaved image by image, either one first, 0.198-0.200 (mixed,
+// the two kinds of waves slow each other down by more than the overlap returns: the blur streams whole rows at ~5 TB/s, the
+// resize lives on many short waves); 16- / 8-row blur bands in the interleaved order 0.189 / 0.192; s_setprio 3 for the
+// resize waves: no change.  So what the fusion buys is the launch boundary and the drain of the blur's last waves, 4 x ~1 us.
+// ORBFE_NO_FUSE=1 (orbfe_create) keeps the launches apart.
+template <int RB>
+__global__ __launch_bounds__(256) void pyr_resize_blur_kernel(DeviceConfig cfg, DeviceBuffers buf, int level, int strips, int n_resize, int tile_begin, int tile_end)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // grid = (image, item): every image's blur items come before any resize item (dispatch order is x fastest)
+    const int n_blur = (tile_end - tile_begin + 3) >> 2;
+    const int img = blockIdx.x, x = (int)blockIdx.y < n_blur ? n_resize + (int)blockIdx.y : (int)blockIdx.y - n_blur;
+    if (x < n_resize) {
+        const int bg = __builtin_amdgcn_readfirstlane(small_div(x, strips));
+        resize_direct_wave<RB>(cfg, buf, level, img, x - bg * strips, bg * 4 + wave);
+    } else {
+        const int u = tile_begin + (x - n_resize) * 4 + wave;
+        if (u < tile_end) blur_wave(cfg, buf, img, u);
+    }
+}
+
 void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, const uint8_t *d_images, int n_images, hipStream_t s)
 {
     const int words = (cfg.lv[0].w + 12 + 3) / 4;
@@ -670,9 +705,10 @@ void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, cons
     else hipLaunchKernelGGL(ingest_kernel<1>, grid, dim3(256), 0, s, cfg, buf, d_images);
 }
 
-void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
+int orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool fuse_blur, hipStream_t s)
 {
     const int last_single = cfg.tail_first ? cfg.tail_first - 1 : cfg.nlevels - 1;
+    int blurred = 0; // levels 0 .. blurred - 1 have had their blur launched (beside the resize that reads them)
     for (int l = 1; l <= last_single; l++) {
         const int src_words = (cfg.lv[l - 1].w + 3) / 4; // interior pixels of the source row (4-aligned start)
         const int total_rows = cfg.lv[l].h + 2 * PYR_MY;
@@ -682,9 +718,18 @@ void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int
         const int *span = cfg.lv[l].rs_src_rows;
         if (cfg.lv[l].rs_direct) {
             const int nwords = cfg.lv[l].rs_xtab_n >> 2;
-            const int rb = ORBFE_PYR_RB > 0 ? ORBFE_PYR_RB : 8;
-            dim3 grid((nwords + 63) / 64, (total_rows + 4 * rb - 1) / (4 * rb), n_images);
-            hipLaunchKernelGGL(pyr_resize_direct_kernel<(ORBFE_PYR_RB > 0 ? ORBFE_PYR_RB : 8)>, grid, dim3(256), 0, s, cfg, buf, l);
+            constexpr int rb = ORBFE_PYR_RB > 0 ? ORBFE_PYR_RB : 8;
+            const int strips = (nwords + 63) / 64, groups = (total_rows + 4 * rb - 1) / (4 * rb);
+            if (fuse_blur && blurred == l - 1) {
+                const LevelInfo &P = cfg.lv[l - 1];
+                const int t0 = P.blur_tile_off, t1 = t0 + P.blur_tiles_x * P.blur_tiles_y;
+                dim3 grid(n_images, strips * groups + (t1 - t0 + 3) / 4);
+                hipLaunchKernelGGL(pyr_resize_blur_kernel<rb>, grid, dim3(256), 0, s, cfg, buf, l, strips, strips * groups, t0, t1);
+                blurred = l;
+            } else {
+                dim3 grid(strips, groups, n_images);
+                hipLaunchKernelGGL(pyr_resize_direct_kernel<rb>, grid, dim3(256), 0, s, cfg, buf, l);
+            }
         } else if (cfg.lv[l].rs_rw == 4) {
             dim3 grid((total_rows + 15) / 16, n_images);
             hipLaunchKernelGGL(pyr_resize_kernel<4>, grid, dim3(256), (size_t)span[0] * rowp, s, cfg, buf, l, src_words, span[0]);
@@ -701,10 +746,15 @@ void orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int
         if (cfg.tail_n == 3) hipLaunchKernelGGL(pyr_tail_kernel<3>, grid, dim3(TAIL_THREADS), (size_t)cfg.tail_lds_bytes, s, cfg, buf);
         else hipLaunchKernelGGL(pyr_tail_kernel<2>, grid, dim3(TAIL_THREADS), (size_t)cfg.tail_lds_bytes, s, cfg, buf);
     }
+    return blurred;
 }
 
-void orbfe_launch_blur(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
+// levels first_level .. nlevels - 1 (the lower ones were blurred beside the pyramid launches)
+void orbfe_launch_blur(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int first_level, hipStream_t s)
 {
-    dim3 grid((cfg.blur_tiles_total + 3) / 4, n_images);
-    hipLaunchKernelGGL(blur_kernel, grid, dim3(256), 0, s, cfg, buf);
+    if (first_level >= cfg.nlevels) return;
+    const int t0 = cfg.lv[first_level].blur_tile_off, t1 = cfg.blur_tiles_total;
+    if (t1 <= t0) return;
+    dim3 grid((t1 - t0 + 3) / 4, n_images);
+    hipLaunchKernelGGL(blur_kernel, grid, dim3(256), 0, s, cfg, buf, t0, t1);
 }

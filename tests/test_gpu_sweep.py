@@ -183,6 +183,26 @@ def test_lds_resize_kernel_still_matches(monkeypatch):
         ctx.close()
 
 
+def test_blur_fused_and_separate_launches_match(monkeypatch):
+    """By default level l - 1 is blurred inside the launch that resizes it into level l; ORBFE_NO_FUSE=1 blurs every level in one
+    launch after the pyramid.  Both must give the oracle's blurred pyramid (and ORBFE_PYR_LDS=1, which leaves nothing to fuse)."""
+    from orbslam2_amd import api
+    left = synth.mono_image(752, 480, seed=3)
+    ex = O.Extractor(nfeatures=1200)
+    kr, dr = ex.extract(left)
+    for env in ({"ORBFE_NO_FUSE": "1"}, {"ORBFE_NO_FUSE": "0"}, {"ORBFE_PYR_LDS": "1"}):
+        for k in ("ORBFE_NO_FUSE", "ORBFE_PYR_LDS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = api.Context(width=752, height=480, nfeatures=1200)
+        k, d = ctx.extract(left)
+        for l in range(8):
+            assert np.array_equal(ctx.fetch_pyramid(0, l, blurred=True), O.gaussian7(ex.pyramid_level(l))), (env, l)
+        assert np.array_equal(k, kr.astype(api.KP_DTYPE)) and np.array_equal(d, dr), env
+        ctx.close()
+
+
 @pytest.mark.parametrize("sf,nlevels", [(2.6, 3), (2.0, 4), (1.95, 4), (1.05, 6)])
 def test_resize_scale_factors_around_the_direct_kernel_limit(sf, nlevels):
     """Scale factors whose words need more than 8 source bytes (2.6; some levels of 2.0, where level sizes round to a ratio
