@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""One-off soak: many random scenes / sizes / thresholds, stereo frame HIP vs oracle, bit for bit.  python3 tools/soak.py [n]"""
+"""One-off soak: many random scenes / sizes / thresholds, stereo frame HIP vs oracle, bit for bit.  python3 tools/soak.py [n]
+SOAK_SEED=<int> shifts the case list; SOAK_GEOM=1 also draws the scale factor (1.04-2.3) and the number of levels (1-10)."""
 import os
 import sys
 
@@ -41,7 +42,14 @@ for i in range(n):
         left = np.ascontiguousarray(big[y0:y0 + h, x0:x0 + w]); right = np.ascontiguousarray(big[y0:y0 + h, x0 + dsp:x0 + dsp + w])
     fx, bf = 0.7 * w, 0.2 * w
     kw = dict(nfeatures=nf, ini_th_fast=ini, min_th_fast=mn)
-    ctx = api.Context(width=w, height=h, fx=fx, fy=fx, cx=w / 2, cy=h / 2, bf=bf, **kw)
+    if os.environ.get("SOAK_GEOM"):  # any scale factor / pyramid depth (the resize kernel choice is per level, from the column table)
+        kw.update(scale_factor=float(np.float32(rng.uniform(1.04, 2.3))), nlevels=int(rng.integers(1, 11)))
+    try:
+        O.Extractor(**kw)
+        ctx = api.Context(width=w, height=h, fx=fx, fy=fx, cx=w / 2, cy=h / 2, bf=bf, **kw)
+    except (ValueError, api.OrbfeError):
+        skipped = globals().get("skipped", 0) + 1
+        continue
     out = ctx.stereo_frame(left, right)
     exl, exr = O.Extractor(**kw), O.Extractor(**kw)
     kl, dl = exl.extract(left); kr, dr = exr.extract(right)
@@ -53,5 +61,5 @@ for i in range(n):
         bad += 1
         print("MISMATCH case", i, w, h, kw)
     ctx.close()
-print("soak: %d cases, %d mismatches" % (n, bad))
+print("soak: %d cases (%d refused by the oracle or orbfe_create), %d mismatches" % (n, globals().get("skipped", 0), bad))
 sys.exit(1 if bad else 0)
