@@ -87,7 +87,7 @@ def traffic_bytes(stage: str, pairs: int, launches: int):
 
 def _sq_valu_per_pair():
     """SQ_INSTS_VALU per stereo pair of every kernel of the step, from the committed rocprofv3 counter pass (launches of 64 pairs;
-    the pyramid's resize kernel runs once per level 1-4): {kernel name fragment: wave-instructions per pair}."""
+    the pyramid's resize kernel -- with the blur of the level it reads fused in -- runs once per level 1-4): {kernel name fragment: wave-instructions per pair}."""
     for name in ("r03_pmc_sq.txt", "r02_pmc_sq.txt", "r01_pmc_sq.txt"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
@@ -100,7 +100,7 @@ def _sq_valu_per_pair():
             kern = line[:line.index("{")].strip()
             if "rocclr" in kern or "candidates_gather" in kern:  # runtime copies; the parity tap of the post-run check
                 continue
-            calls_per_step = 4 if "pyr_resize_kernel" in kern else 1
+            calls_per_step = 4 if any(k in kern for k in ("pyr_resize_kernel", "pyr_resize_direct_kernel", "pyr_resize_blur_kernel")) else 1  # levels 1-4
             out[kern] = out.get(kern, 0.0) + d["SQ_INSTS_VALU"] * calls_per_step / 64.0
         if out:
             return out, name
@@ -133,7 +133,8 @@ def valu_issue(pairs: int, launches: int, launch_ms: float, step_ms: float):
             mix = json.load(open(mix_path))["kernels"]
             simd_cycles_per_s = half_rate * ops["v_pk_max_i16"]["8"]["cycles_per_wave_inst_per_simd"]  # 1024 SIMDs x the clock the chip held
             def seconds(n, kern):  # n wave-instructions of kernel `kern` priced with its measured opcode mix
-                m = next((v for kk, v in mix.items() if kk.split("<")[0] in kern), None)
+                base = kern.replace("void ", "").split("<")[0].split("(")[0].strip()  # exact name: blur_kernel is a suffix of pyr_resize_blur_kernel
+                m = next((v for kk, v in mix.items() if kk.split("<")[0] == base), None)
                 return n * (m["mean_cycles_per_valu"] if m else ops["v_pk_max_i16"]["8"]["cycles_per_wave_inst_per_simd"]) / simd_cycles_per_s
             mf = next(v for k, v in mix.items() if "fast_cell_kernel" in k)
             out["frac_mix"] = seconds(insts, "fast_cell_kernel") / (launch_ms * 1e-3)
@@ -546,7 +547,7 @@ def main():
                 "whole_pipeline": {"alg_bytes_per_pair": B_PAIR, "achieved": B_PAIR * value / world / 1e9,
                                    "frac": B_PAIR * value / world / 1e9 / HBM_PEAK_GBS},
                 "stage_ms_per_step_summed_over_groups": per_launch_ms,
-                "stage_ms_note": "per-stage table from a separate untimed single-chain pass with events at every stage boundary; launch_ms from the timed region"}
+                "stage_ms_note": "per-stage table from a separate untimed single-chain pass with events at every stage boundary; launch_ms from the timed region; 'pyramid' includes the blur of the levels that are blurred inside the resize launches (0..3 at KITTI geometry), 'blur' is the launch for the remaining levels (ORBFE_NO_FUSE=1 separates them)"}
         if dom_alone is not None:
             roof["launch_ms_one_chain"] = dom_alone
             roof["frac_one_chain"] = alg[dom] * P / launches / (dom_alone * 1e-3) / 1e9 / HBM_PEAK_GBS

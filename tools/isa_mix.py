@@ -30,7 +30,8 @@ FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-
 UNITS = {  # translation unit -> [(kernel name fragment, report name)]
     "orbfe_fast.hip": [("fast_cell_kernelILi48ELb1E", "fast_cell_kernel<48, true>")],
     "orbfe_describe.hip": [("15describe_kernel", "describe_kernel")],
-    "orbfe_pyramid.hip": [("pyr_resize_kernelILi4E", "pyr_resize_kernel<4>"), ("pyr_tail_kernelILi3E", "pyr_tail_kernel<3>"), ("blur_kernel", "blur_kernel"),
+    "orbfe_pyramid.hip": [("pyr_resize_blur_kernelILi4E", "pyr_resize_blur_kernel<4>"), ("pyr_resize_direct_kernelILi4E", "pyr_resize_direct_kernel<4>"),
+                          ("pyr_resize_kernelILi4E", "pyr_resize_kernel<4>"), ("pyr_tail_kernelILi3E", "pyr_tail_kernel<3>"), ("11blur_kernel", "blur_kernel"),
                           ("ingest16_kernel", "ingest16_kernel")],
     "orbfe_stereo.hip": [("stereo_match_kernel", "stereo_match_kernel"), ("stereo_median_kernel", "stereo_median_kernel")],
     "orbfe_octree3.hip": [("octree3_kernelILb0E", "octree3_kernel<false>")],

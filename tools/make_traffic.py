@@ -7,7 +7,9 @@ launches per step = the kernel's dispatch count / fast_cell_kernel's (one per st
 """
 import ast, json, sys
 
-STAGE_OF = {"ingest_kernel": "ingest", "ingest16_kernel": "ingest", "pyr_resize_kernel": "pyramid", "pyr_tail_kernel": "pyramid", "blur_kernel": "blur", "fast_cell_kernel": "fast",
+# first match wins (pyr_resize_blur_kernel also contains "blur_kernel"): the fused resize + blur launches count as "pyramid", so "blur" is the
+# launch for the levels that are not blurred beside a resize (4-7 at KITTI geometry)
+STAGE_OF = {"ingest_kernel": "ingest", "ingest16_kernel": "ingest", "pyr_resize": "pyramid", "pyr_tail_kernel": "pyramid", "blur_kernel": "blur", "fast_cell_kernel": "fast",
             "octree": "octree", "describe_kernel": "describe", "stereo_match_kernel": "stereo_match",
             "stereo_rowtable_kernel": "stereo_match", "stereo_median_kernel": "stereo_median"}
 
@@ -27,6 +29,7 @@ def read(path, counter):
         for k, st in STAGE_OF.items():
             if k in name and "gather" not in name:
                 out[st] = out.get(st, 0.0) + vals[counter] * (n / steps)
+                break
     return out
 
 
