@@ -29,6 +29,9 @@
  *   ORBFE_HOST_TRACE=1 print the context's geometry, kernel choices and LDS sizes to
  *                      stderr at create time.
  *
+ * No C++ exception leaves the library: a host-side failure (out of memory, ...) is
+ * returned as ORBFE_ERR_HIP with its message in orbfe_last_error().
+ *
  * There is NO CPU fallback: if no HIP device is present orbfe_create fails
  * with ORBFE_ERR_NO_DEVICE.
  */

@@ -365,7 +365,7 @@ static int build_config(orbfe_context *ctx)
 }
 
 extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
-{
+try {
     if (!params || !out) return fail(nullptr, ORBFE_ERR_INVALID, "null argument");
     *out = nullptr;
     const orbfe_params &p = *params;
@@ -831,7 +831,7 @@ extern "C" int orbfe_create(const orbfe_params *params, orbfe_context **out)
 #undef Z
     *out = ctx;
     return ORBFE_OK;
-}
+} ORBFE_CATCH(nullptr)
 
 extern "C" void orbfe_destroy(orbfe_context *ctx)
 {
@@ -860,18 +860,18 @@ extern "C" void orbfe_destroy(orbfe_context *ctx)
 }
 
 extern "C" int orbfe_get_camera(const orbfe_context *ctx, float *cam)
-{
+try {
     if (!ctx || !cam) return ORBFE_ERR_INVALID;
     cam[0] = ctx->params.fx; cam[1] = ctx->params.fy; cam[2] = ctx->params.cx; cam[3] = ctx->params.cy; cam[4] = ctx->params.bf;
     return ORBFE_OK;
-}
+} ORBFE_CATCH(nullptr)
 
 extern "C" int orbfe_levels(const orbfe_context *ctx) { return ctx ? ctx->cfg.nlevels : ORBFE_ERR_INVALID; }
 extern "C" int orbfe_keypoint_capacity(const orbfe_context *ctx) { return ctx ? ctx->cfg.sel_total : ORBFE_ERR_INVALID; }
 
 extern "C" int orbfe_get_tables(const orbfe_context *ctx, float *scale, float *inv_scale, float *sigma2,
                                 float *inv_sigma2, int32_t *features_per_level, int32_t *umax)
-{
+try {
     if (!ctx) return ORBFE_ERR_INVALID;
     const int n = ctx->cfg.nlevels;
     if (scale) memcpy(scale, ctx->scale, sizeof(float) * n);
@@ -881,15 +881,15 @@ extern "C" int orbfe_get_tables(const orbfe_context *ctx, float *scale, float *i
     if (features_per_level) memcpy(features_per_level, ctx->feats, sizeof(int32_t) * n);
     if (umax) memcpy(umax, ctx->cfg.umax, sizeof(int32_t) * (ctx->cfg.half_patch + 1));
     return ORBFE_OK;
-}
+} ORBFE_CATCH(nullptr)
 
 extern "C" int orbfe_level_size(const orbfe_context *ctx, int level, int *w, int *h)
-{
+try {
     if (!ctx || level < 0 || level >= ctx->cfg.nlevels) return ORBFE_ERR_INVALID;
     if (w) *w = ctx->cfg.lv[level].w;
     if (h) *h = ctx->cfg.lv[level].h;
     return ORBFE_OK;
-}
+} ORBFE_CATCH(nullptr)
 
 static hipStream_t pick_stream(orbfe_context *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
 
@@ -908,7 +908,7 @@ static const char *k_stage_names[ORBFE_NUM_STAGES] = {"ingest", "pyramid", "blur
 extern "C" const char *orbfe_stage_name(int stage) { return stage >= 0 && stage < ORBFE_NUM_STAGES ? k_stage_names[stage] : ""; }
 
 extern "C" int orbfe_set_profiling(orbfe_context *ctx, int enabled)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx) return ORBFE_ERR_INVALID;
     if (enabled && ctx->events.empty()) {
@@ -921,16 +921,16 @@ extern "C" int orbfe_set_profiling(orbfe_context *ctx, int enabled)
     ctx->prof_only = enabled >= 2 ? enabled - 2 : -1;
     ctx->prof_calls = 0;
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_set_profiling_interval(orbfe_context *ctx, int every)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || every < 1) return fail(ctx, ORBFE_ERR_INVALID, "interval must be >= 1");
     ctx->prof_every = every;
     ctx->prof_seq = 0;
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 // record event #idx of the current call for stream group `group` (idx 0 = before the first stage)
 static inline void prof_mark(orbfe_context *ctx, int group, int idx, hipStream_t s)
@@ -948,7 +948,7 @@ static inline void prof_mark(orbfe_context *ctx, int group, int idx, hipStream_t
 // Per-stage elapsed ms summed over the recorded calls AND over the stream groups of each call
 // (with G groups a stage runs as G launches per call, or 7*G for the pyramid).
 extern "C" int orbfe_stage_times(orbfe_context *ctx, float *ms, int *calls, int reset)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || !ms) return ORBFE_ERR_INVALID;
     for (int i = 0; i < ORBFE_NUM_STAGES; i++) ms[i] = 0.f;
@@ -969,7 +969,7 @@ extern "C" int orbfe_stage_times(orbfe_context *ctx, float *ms, int *calls, int 
     }
     if (reset) { ctx->prof_calls = 0; ctx->prof_seq = 0; }
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 static inline int ot_sort_cap_of(const DeviceConfig &c) { int p = 1; while (p < c.max_nodes) p <<= 1; return p; }
 
@@ -1060,13 +1060,13 @@ static int enqueue_batch(orbfe_context *ctx, const uint8_t *d_images, int n_unit
 }
 
 extern "C" int orbfe_quadtree_kernel(const orbfe_context *ctx)
-{
+try {
     if (!ctx) return 0;
     return ctx->use_octree3 ? 3 : (ctx->use_octree2 ? 2 : 1);
-}
+} ORBFE_CATCH(nullptr)
 
 extern "C" int orbfe_set_streams(orbfe_context *ctx, int groups)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || groups < 1 || groups > ORBFE_MAX_GROUPS) return fail(ctx, ORBFE_ERR_INVALID, "groups must be in [1, %d]", ORBFE_MAX_GROUPS);
     if (ctx->profiling) return fail(ctx, ORBFE_ERR_INVALID, "change the stream count before enabling profiling");
@@ -1078,25 +1078,25 @@ extern "C" int orbfe_set_streams(orbfe_context *ctx, int groups)
     }
     ctx->groups = groups;
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_enqueue_extract(orbfe_context *ctx, const uint8_t *d_images, int n_images, void *stream)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || !d_images) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
     if (n_images < 1 || n_images > ctx->params.max_images)
         return fail(ctx, ORBFE_ERR_CAPACITY, "n_images %d outside [1, %d]", n_images, ctx->params.max_images);
     return enqueue_batch(ctx, d_images, n_images, 1, stream);
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_enqueue_stereo(orbfe_context *ctx, const uint8_t *d_images, int n_pairs, void *stream)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || !d_images) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
     if (n_pairs < 1 || 2 * n_pairs > ctx->params.max_images)
         return fail(ctx, ORBFE_ERR_CAPACITY, "n_pairs %d needs max_images >= %d", n_pairs, 2 * n_pairs);
     return enqueue_batch(ctx, d_images, n_pairs, 2, stream);
-}
+} ORBFE_CATCH(ctx)
 
 // the staging of the host entry points is sized by the input format: one packed image = image_bytes
 static int resize_input_staging(orbfe_context *ctx, size_t image_bytes)
@@ -1113,7 +1113,7 @@ static int resize_input_staging(orbfe_context *ctx, size_t image_bytes)
 }
 
 extern "C" int orbfe_set_rectification(orbfe_context *ctx, int side, const float *map_x, const float *map_y, int src_w, int src_h)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || side < 0 || side > 1) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1156,10 +1156,10 @@ extern "C" int orbfe_set_rectification(orbfe_context *ctx, int side, const float
         return resize_input_staging(ctx, (size_t)src_w * src_h);
     }
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_set_input_format(orbfe_context *ctx, int channels, int rgb_order, int legacy_weights)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx) return ORBFE_ERR_INVALID;
     if (channels != 1 && channels != 3 && channels != 4) return fail(ctx, ORBFE_ERR_INVALID, "channels must be 1, 3 or 4");
@@ -1177,17 +1177,17 @@ extern "C" int orbfe_set_input_format(orbfe_context *ctx, int channels, int rgb_
     ctx->cfg.in_coef[2] = rgb_order ? cb : cr;
     ctx->cfg.in_shift = legacy_weights ? 14 : 15;
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_set_distortion(orbfe_context *ctx, const float *dist, int n)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || (n != 0 && n != 4 && n != 5) || (n > 0 && !dist)) return fail(ctx, ORBFE_ERR_INVALID, "distortion needs 0, 4 or 5 coefficients (k1 k2 p1 p2 [k3])");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cfg.n_dist = n;
     for (int i = 0; i < 5; i++) ctx->cfg.dist[i] = i < n ? dist[i] : 0.f;
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 // scratch for the undistortion entry points: [0, n) input keypoints, [n, 2n) output
 static int undistort_on_device(orbfe_context *ctx, const orbfe_keypoint *kps, const KeyPointPOD *d_src, int n, orbfe_keypoint *kps_un)
@@ -1209,14 +1209,14 @@ static int undistort_on_device(orbfe_context *ctx, const orbfe_keypoint *kps, co
 }
 
 extern "C" int orbfe_undistort_keypoints(orbfe_context *ctx, const orbfe_keypoint *kps, int n, orbfe_keypoint *kps_un)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || n < 0 || (n > 0 && (!kps || !kps_un))) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     return undistort_on_device(ctx, kps, nullptr, n, kps_un);
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_fetch_keys_un(orbfe_context *ctx, int image, orbfe_keypoint *kps_un, int cap, int *n)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || image < 0 || image >= ctx->params.max_images || !n) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     { const int rcw = wait_latest(ctx); if (rcw != ORBFE_OK) return rcw; }
@@ -1226,10 +1226,10 @@ extern "C" int orbfe_fetch_keys_un(orbfe_context *ctx, int image, orbfe_keypoint
     if (cnt > cap) return fail(ctx, ORBFE_ERR_CAPACITY, "caller buffer holds %d keypoints, image has %d", cap, cnt);
     if (cnt > 0 && !kps_un) return fail(ctx, ORBFE_ERR_INVALID, "null output");
     return undistort_on_device(ctx, nullptr, (const KeyPointPOD *)ctx->buf.kps + (size_t)image * ctx->cfg.sel_total, cnt, kps_un);
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_image_bounds(orbfe_context *ctx, float *bounds)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || !bounds) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     const float cols = (float)ctx->params.width, rows = (float)ctx->params.height;
@@ -1246,28 +1246,28 @@ extern "C" int orbfe_image_bounds(orbfe_context *ctx, float *bounds)
     bounds[2] = std::min(o[0].y, o[1].y);
     bounds[3] = std::max(o[2].y, o[3].y);
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_synchronize(orbfe_context *ctx, void *stream)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx) return ORBFE_ERR_INVALID;
     HIP_TRY(ctx, hipStreamSynchronize(pick_stream(ctx, stream)));
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_fetch_counts(orbfe_context *ctx, int32_t *counts, int n_images)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || !counts || n_images < 1 || n_images > ctx->params.max_images) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     { const int rcw = wait_latest(ctx); if (rcw != ORBFE_OK) return rcw; }
     HIP_TRY(ctx, hipMemcpy(counts, ctx->buf.kp_cnt, sizeof(int32_t) * n_images, hipMemcpyDeviceToHost));
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_fetch_batch_async(orbfe_context *ctx, int n_images, orbfe_keypoint *kps, uint8_t *desc, int32_t *counts,
                                        float *u_right, float *depth, void *stream)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || n_images < 1 || n_images > ctx->params.max_images) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     hipStream_t s = pick_stream(ctx, stream);
@@ -1278,11 +1278,11 @@ extern "C" int orbfe_fetch_batch_async(orbfe_context *ctx, int n_images, orbfe_k
     if (u_right) HIP_TRY(ctx, hipMemcpyAsync(u_right, ctx->buf.u_right, sizeof(float) * n, hipMemcpyDeviceToHost, s));
     if (depth) HIP_TRY(ctx, hipMemcpyAsync(depth, ctx->buf.depth, sizeof(float) * n, hipMemcpyDeviceToHost, s));
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_fetch_image(orbfe_context *ctx, int image, orbfe_keypoint *kps, uint8_t *desc,
                                  float *u_right, float *depth, int cap, int *n)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || image < 0 || image >= ctx->params.max_images || !n) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     { const int rcw = wait_latest(ctx); if (rcw != ORBFE_OK) return rcw; }
@@ -1300,18 +1300,18 @@ extern "C" int orbfe_fetch_image(orbfe_context *ctx, int image, orbfe_keypoint *
         if (depth) HIP_TRY(ctx, hipMemcpy(depth, ctx->buf.depth + image * st, sizeof(float) * cnt, hipMemcpyDeviceToHost));
     }
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_debug_timestamps(orbfe_context *ctx, long long *dst, int n)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || !dst || n < 0 || n > 4096) return ORBFE_ERR_INVALID;
     HIP_TRY(ctx, hipMemcpy(dst, ctx->buf.dbg_ts, sizeof(long long) * n, hipMemcpyDeviceToHost));
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_device_buffers(orbfe_context *ctx, void **kps, void **desc, void **counts, void **u_right, void **depth)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx) return ORBFE_ERR_INVALID;
     if (kps) *kps = ctx->buf.kps;
@@ -1320,7 +1320,7 @@ extern "C" int orbfe_device_buffers(orbfe_context *ctx, void **kps, void **desc,
     if (u_right) *u_right = ctx->buf.u_right;
     if (depth) *depth = ctx->buf.depth;
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 // Layout of the pinned output block of the single-frame entry points: counts and status words of the (up to two)
 // images, then the keypoint / descriptor / uRight / depth arrays at their device capacity (sel_total per image).
@@ -1416,7 +1416,7 @@ static int hand_over(orbfe_context *ctx, int image, orbfe_keypoint *kps, uint8_t
 
 extern "C" int orbfe_extract(orbfe_context *ctx, const uint8_t *img, int w, int h, size_t stride,
                              orbfe_keypoint *kps, uint8_t *desc, int cap, int *n)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || !n) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
     if (!img || w <= 0 || h <= 0) { *n = 0; return ORBFE_OK; } // _image.empty(): src/ORBextractor.cc:861-862
@@ -1429,18 +1429,18 @@ extern "C" int orbfe_extract(orbfe_context *ctx, const uint8_t *img, int w, int 
     rc = download_frame(ctx, 1, false);
     if (rc != ORBFE_OK) return rc;
     return hand_over(ctx, 0, kps, desc, nullptr, nullptr, cap, n);
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_device_count(void)
-{
+try {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
-}
+} ORBFE_CATCH(nullptr)
 
 // Host-fed batch in one call: what a single-process multi-device host (orbslam2_amd/host/multi_device.h) runs per context.
 extern "C" int orbfe_stereo_batch(orbfe_context *ctx, const uint8_t *images, int n_pairs, orbfe_keypoint *kps, uint8_t *desc, int32_t *counts,
                                   float *u_right, float *depth)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || !images || !counts) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
     if (n_pairs < 1 || 2 * n_pairs > ctx->params.max_images) return fail(ctx, ORBFE_ERR_CAPACITY, "n_pairs %d needs max_images >= %d", n_pairs, 2 * n_pairs);
@@ -1450,22 +1450,24 @@ extern "C" int orbfe_stereo_batch(orbfe_context *ctx, const uint8_t *images, int
     if (rc != ORBFE_OK) return rc;
     rc = orbfe_fetch_batch_async(ctx, 2 * n_pairs, kps, desc, counts, u_right, depth, nullptr);
     if (rc != ORBFE_OK) return rc;
-    std::vector<int> status(2 * n_pairs);
-    HIP_TRY(ctx, hipMemcpyAsync(status.data(), ctx->buf.status, sizeof(int) * 2 * n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+    // the results are in the caller's buffers once the stream is idle; the status words are read after that, synchronously (an
+    // asynchronous copy into a local buffer would outlive it on an early return)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int> status((size_t)2 * n_pairs);
+    HIP_TRY(ctx, hipMemcpy(status.data(), ctx->buf.status, sizeof(int) * 2 * n_pairs, hipMemcpyDeviceToHost));
     for (int i = 0; i < 2 * n_pairs; i++)
         if (status[i] != 0) return fail(ctx, ORBFE_ERR_CAPACITY, "device-side capacity overflow (status %d) on image %d", status[i], i);
     ctx->slot_cnt.assign(counts, counts + 2 * n_pairs);
     ctx->slot_cnt_epoch = ctx->epoch;
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_stereo_frame(orbfe_context *ctx, const uint8_t *left, const uint8_t *right,
                                   int w, int h, size_t stride,
                                   orbfe_keypoint *kps_left, uint8_t *desc_left, int *n_left,
                                   orbfe_keypoint *kps_right, uint8_t *desc_right, int *n_right,
                                   float *u_right, float *depth, int cap)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || !n_left || !n_right) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
     if (!left || !right || w <= 0 || h <= 0) { *n_left = 0; *n_right = 0; return ORBFE_OK; }
@@ -1483,7 +1485,7 @@ extern "C" int orbfe_stereo_frame(orbfe_context *ctx, const uint8_t *left, const
     rc = hand_over(ctx, 0, kps_left, desc_left, u_right, depth, cap, n_left);
     if (rc != ORBFE_OK) return rc;
     return hand_over(ctx, 1, kps_right, desc_right, nullptr, nullptr, cap, n_right);
-}
+} ORBFE_CATCH(ctx)
 
 // Common body of the two RGB-D entry points.  The depth rows are packed while the extraction kernels already run:
 // the map is only sampled at the keypoints, at the very end of the chain.
@@ -1532,22 +1534,22 @@ extern "C" int orbfe_rgbd_frame(orbfe_context *ctx, const uint8_t *gray, const f
                                 int w, int h, size_t gray_stride, size_t depth_stride,
                                 orbfe_keypoint *kps, uint8_t *desc, int *n,
                                 float *u_right, float *depth, int cap)
-{
+try {
     ORBFE_ENTRY(ctx);
     return rgbd_frame_impl(ctx, gray, depth_img, sizeof(float), 1.0f, w, h, gray_stride, depth_stride, kps, desc, n, u_right, depth, cap);
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_rgbd_frame_u16(orbfe_context *ctx, const uint8_t *gray, const uint16_t *depth_img, float depth_map_factor,
                                     int w, int h, size_t gray_stride, size_t depth_stride,
                                     orbfe_keypoint *kps, uint8_t *desc, int *n,
                                     float *u_right, float *depth, int cap)
-{
+try {
     ORBFE_ENTRY(ctx);
     return rgbd_frame_impl(ctx, gray, depth_img, sizeof(uint16_t), depth_map_factor, w, h, gray_stride, depth_stride, kps, desc, n, u_right, depth, cap);
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_fetch_pyramid(orbfe_context *ctx, int image, int level, int blurred, uint8_t *dst, size_t dst_stride)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || !dst || image < 0 || image >= ctx->params.max_images || level < 0 || level >= ctx->cfg.nlevels)
         return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
@@ -1568,11 +1570,11 @@ extern "C" int orbfe_fetch_pyramid(orbfe_context *ctx, int image, int level, int
     const uint8_t *src = ctx->buf.pyr + (size_t)image * ctx->cfg.pyr_bytes + L.pyr_off;
     HIP_TRY(ctx, hipMemcpy2D(dst, dst_stride, src, (size_t)L.pitch, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost));
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_fetch_candidates(orbfe_context *ctx, int image, int level, int32_t *xs, int32_t *ys,
                                       int32_t *scores, int cap, int *n)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || !n || image < 0 || image >= ctx->params.max_images || level < 0 || level >= ctx->cfg.nlevels)
         return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
@@ -1598,10 +1600,10 @@ extern "C" int orbfe_fetch_candidates(orbfe_context *ctx, int image, int level, 
         if (scores) scores[i] = sc[i];
     }
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_hamming_matrix(orbfe_context *ctx, const uint8_t *desc_a, int na, const uint8_t *desc_b, int nb, int32_t *dist)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || !desc_a || !desc_b || !dist || na < 0 || nb < 0) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     if (na == 0 || nb == 0) return ORBFE_OK;
@@ -1620,4 +1622,4 @@ extern "C" int orbfe_hamming_matrix(orbfe_context *ctx, const uint8_t *desc_a, i
     HIP_TRY(ctx, hipMemcpyAsync(dist, dd, sizeof(int) * (size_t)na * nb, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)

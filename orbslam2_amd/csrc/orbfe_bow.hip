@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void pair_hamming_kernel(const uint8_t *__rest
 
 // fbow::Vocabulary::fromStream (fbow.cpp:181-191) from a memory blob; the tree goes to HBM.
 extern "C" int orbfe_vocab_load(orbfe_context *ctx, const uint8_t *blob, size_t size)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || !blob) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
     orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
@@ -187,7 +187,7 @@ extern "C" int orbfe_vocab_load(orbfe_context *ctx, const uint8_t *blob, size_t 
     st->p = p;
     st->loaded = true;
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 // Vocabulary::transform(features, level, fBow, fBow2): per-feature results (word, weight, node at `level`).
 // size in bytes of the vocabulary image this context holds (0: none): lets a shim that caches "already loaded" per context pointer
@@ -202,7 +202,7 @@ extern "C" long long orbfe_vocab_bytes(orbfe_context *ctx)
 
 extern "C" int orbfe_bow_transform(orbfe_context *ctx, const uint8_t *desc, int n, int level,
                                    uint32_t *word_id, float *weight, uint32_t *node_id)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || n < 0 || level < 0 || (n > 0 && (!desc || !word_id || !weight || !node_id))) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
@@ -227,13 +227,13 @@ extern "C" int orbfe_bow_transform(orbfe_context *ctx, const uint8_t *desc, int 
     BTRY(ctx, hipStreamSynchronize(s));
     BTRY(ctx, hipGetLastError());
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 // fBow / fBow2 as sorted arrays from the per-feature results (host; weights summed in feature order).
 extern "C" int orbfe_bow_maps(const uint32_t *word_id, const float *weight, const uint32_t *node_id, int n,
                               uint32_t *words, float *word_w, int *n_words,
                               uint32_t *nodes, int32_t *node_off, int32_t *node_feat, int *n_nodes)
-{
+try {
     if (n < 0 || !n_words || !n_nodes || (n > 0 && (!word_id || !weight || !node_id || !words || !word_w || !nodes || !node_off || !node_feat)))
         return ORBFE_ERR_INVALID;
     std::map<uint32_t, float> r1;
@@ -254,7 +254,7 @@ extern "C" int orbfe_bow_maps(const uint32_t *word_id, const float *weight, cons
     if (n > 0) node_off[k] = o;
     *n_nodes = k;
     return ORBFE_OK;
-}
+} ORBFE_CATCH(nullptr)
 
 static int rot_bin(float a1, float a2)
 {
@@ -370,11 +370,11 @@ extern "C" int orbfe_search_by_bow(orbfe_context *ctx,
                                    const uint32_t *f_nodes, const int32_t *f_off, const int32_t *f_feat, int f_nnodes,
                                    const uint8_t *f_desc, const float *f_angle, int n_f,
                                    float nnratio, int check_ori, int32_t *f_match, int *nmatches)
-{
+try {
     ORBFE_ENTRY(ctx);
     return search_by_bow_impl(ctx, false, kf_nodes, kf_off, kf_feat, kf_nnodes, kf_valid, kf_desc, kf_angle, n_kf,
                               f_nodes, f_off, f_feat, f_nnodes, nullptr, f_desc, f_angle, n_f, nnratio, check_ori, f_match, nmatches);
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_search_by_bow_kf(orbfe_context *ctx,
                                       const uint32_t *nodes1, const int32_t *off1, const int32_t *feat1, int nnodes1,
@@ -382,11 +382,11 @@ extern "C" int orbfe_search_by_bow_kf(orbfe_context *ctx,
                                       const uint32_t *nodes2, const int32_t *off2, const int32_t *feat2, int nnodes2,
                                       const int32_t *valid2, const uint8_t *desc2, const float *angle2, int n2,
                                       float nnratio, int check_ori, int32_t *match12, int *nmatches)
-{
+try {
     ORBFE_ENTRY(ctx);
     return search_by_bow_impl(ctx, true, nodes1, off1, feat1, nnodes1, valid1, desc1, angle1, n1,
                               nodes2, off2, feat2, nnodes2, valid2, desc2, angle2, n2, nnratio, check_ori, match12, nmatches);
-}
+} ORBFE_CATCH(ctx)
 
 // ---------------------------------------------------------------------------------------------
 // Keyframe database: KeyFrameDatabase::add / erase / clear / DetectRelocalizationCandidates
@@ -456,17 +456,17 @@ __global__ __launch_bounds__(256) void kfdb_score_kernel(const uint32_t *__restr
 }
 
 extern "C" int orbfe_kfdb_clear(orbfe_context *ctx)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx) return ORBFE_ERR_INVALID;
     orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
     if (!st) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "out of host memory");
     st->db_off.clear(); st->db_len.clear(); st->db_dead.clear(); st->db_used = 0; st->db_dead_words = 0;
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_kfdb_add(orbfe_context *ctx, const uint32_t *words, const float *weights, int n, int *kf_index)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || n < 0 || (n > 0 && (!words || !weights))) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
     orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
@@ -498,7 +498,7 @@ extern "C" int orbfe_kfdb_add(orbfe_context *ctx, const uint32_t *words, const f
     st->db_off.push_back((int)st->db_used); st->db_len.push_back(n); st->db_dead.push_back(0);
     st->db_used += (size_t)n;
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 // Reclaims the words of erased keyframes: the live segments are moved to the front of the CSR (keyframe indices stay).
 // Rare (once the dead words outnumber the live ones), so it goes through the host.
@@ -532,7 +532,7 @@ static int kfdb_compact(orbfe_context *ctx, orbfe_bow_state *st)
 }
 
 extern "C" int orbfe_kfdb_erase(orbfe_context *ctx, int kf_index)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx) return ORBFE_ERR_INVALID;
     orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
@@ -546,15 +546,15 @@ extern "C" int orbfe_kfdb_erase(orbfe_context *ctx, int kf_index)
     st->db_len[kf_index] = 0;
     if (st->db_dead_words > 1024 && 2 * st->db_dead_words > st->db_used) return kfdb_compact(ctx, st);
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_kfdb_size(orbfe_context *ctx)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx) return 0;
     orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
     return st ? (int)st->db_off.size() : 0;
-}
+} ORBFE_CATCH(ctx)
 
 // scores of every keyframe against the query; host vectors out
 static int kfdb_scores(orbfe_context *ctx, orbfe_bow_state *st, const uint32_t *q_words, const float *q_w, int nq,
@@ -598,7 +598,7 @@ static int kfdb_scores(orbfe_context *ctx, orbfe_bow_state *st, const uint32_t *
 }
 
 extern "C" int orbfe_kfdb_score(orbfe_context *ctx, const uint32_t *q_words, const float *q_w, int nq, int32_t *common, float *score)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || nq < 0 || (nq > 0 && (!q_words || !q_w))) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
     orbfe_bow_state *st = orbfe_ctx_bow_state(ctx);
@@ -609,12 +609,12 @@ extern "C" int orbfe_kfdb_score(orbfe_context *ctx, const uint32_t *q_words, con
     const int n_kf = (int)st->db_off.size();
     for (int k = 0; k < n_kf; k++) { if (common) common[k] = c[k]; if (score) score[k] = sc[k]; }
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_detect_reloc_candidates(orbfe_context *ctx, const uint32_t *q_words, const float *q_w, int nq,
                                              const int32_t *covis_off, const int32_t *covis_idx, float *reloc_score,
                                              int32_t *cand, int cap, int *n_cand)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || !n_cand || nq < 0 || (nq > 0 && (!q_words || !q_w)) || !covis_off || !reloc_score || cap < 0 || (cap > 0 && !cand))
         return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
@@ -669,7 +669,7 @@ extern "C" int orbfe_detect_reloc_candidates(orbfe_context *ctx, const uint32_t 
     *n_cand = n;
     if (n > cap) return orbfe_fail(ctx, ORBFE_ERR_CAPACITY, "caller buffer holds %d candidates, %d found", cap, n);
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 // KeyFrameDatabase::DetectLoopCandidates(KeyFrame *pKF, float minScore) (src/KeyFrameDatabase.cc:73-194): same device scoring
 // pass as the relocalisation query; the selection differs (connected keyframes excluded, minScore filter, accumulated score
@@ -678,7 +678,7 @@ extern "C" int orbfe_detect_loop_candidates(orbfe_context *ctx, const uint32_t *
                                             const uint8_t *connected, float min_score,
                                             const int32_t *covis_off, const int32_t *covis_idx,
                                             int32_t *cand, int cap, int *n_cand)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || !n_cand || nq < 0 || (nq > 0 && (!q_words || !q_w)) || !covis_off || cap < 0 || (cap > 0 && !cand))
         return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
@@ -736,7 +736,7 @@ extern "C" int orbfe_detect_loop_candidates(orbfe_context *ctx, const uint32_t *
     *n_cand = n;
     if (n > cap) return orbfe_fail(ctx, ORBFE_ERR_CAPACITY, "caller buffer holds %d candidates, %d found", cap, n);
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 // ---------------------------------------------------------------------------------------------
 // ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:652-819; LocalMapping::CreateNewMapPoints)
@@ -761,7 +761,7 @@ extern "C" int orbfe_search_for_triangulation(orbfe_context *ctx,
                                               const orbfe_keypoint *keys2, const float *u_right2, const uint8_t *has_mp2, const uint8_t *desc2, int n2,
                                               const float *F12, const float *Cw1, const float *T2w, float fx2, float fy2, float cx2, float cy2,
                                               int only_stereo, int check_ori, int32_t *match12, int *nmatches)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || !nmatches || n1 < 0 || n2 < 0 || nnodes1 < 0 || nnodes2 < 0 || (n1 > 0 && !match12) || !F12 || !Cw1 || !T2w ||
         (nnodes1 > 0 && (!nodes1 || !off1 || !feat1 || !keys1 || !u_right1 || !has_mp1 || !desc1)) ||
@@ -874,4 +874,4 @@ extern "C" int orbfe_search_for_triangulation(orbfe_context *ctx,
     }
     *nmatches = nm;
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)

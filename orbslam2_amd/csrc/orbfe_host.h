@@ -60,3 +60,12 @@ orbfe_pose_state *orbfe_pose_state_create();
 void orbfe_pose_state_destroy(orbfe_pose_state *s);
 orbfe_pose_state *orbfe_ctx_pose_state(orbfe_context *ctx);
 const float *orbfe_ctx_inv_sigma2(const orbfe_context *ctx);
+
+// No C++ exception may cross the C ABI (a ctypes / cgo / C caller would abort): every extern "C" function that returns a status is a
+// function-try-block closed by this handler.  The per-context lock of ORBFE_ENTRY is a local of the try block, so it is released first.
+#include <exception>
+#include <new>
+#define ORBFE_CATCH(ctxexpr)                                                                                              \
+    catch (const std::bad_alloc &) { return orbfe_fail(ctxexpr, ORBFE_ERR_HIP, "out of host memory"); }                   \
+    catch (const std::exception &e_) { return orbfe_fail(ctxexpr, ORBFE_ERR_HIP, "host exception: %s", e_.what()); }      \
+    catch (...) { return orbfe_fail(ctxexpr, ORBFE_ERR_HIP, "unknown host exception"); }

@@ -466,11 +466,11 @@ using orbfe_resolve::RotHist;
 using orbfe_resolve::rot_bin;
 
 extern "C" int orbfe_three_maxima(const int32_t *histo_sizes, int L, int *ind1, int *ind2, int *ind3)
-{
+try {
     if (!histo_sizes || !ind1 || !ind2 || !ind3 || L < 0) return ORBFE_ERR_INVALID;
     orbfe_resolve::three_maxima(histo_sizes, L, ind1, ind2, ind3); // ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1597-1638
     return ORBFE_OK;
-}
+} ORBFE_CATCH(nullptr)
 
 static int check_view(orbfe_context *ctx, const orbfe_frame_view *fv)
 {
@@ -483,7 +483,7 @@ static int check_view(orbfe_context *ctx, const orbfe_frame_view *fv)
 // Frame::GetFeaturesInArea (src/Frame.cc:328-381) for one window, in the reference's result order.
 extern "C" int orbfe_features_in_area(orbfe_context *ctx, const orbfe_frame_view *fv, float x, float y, float r,
                                       int min_level, int max_level, int32_t *out, int cap, int *n)
-{
+try {
     ORBFE_ENTRY(ctx);
     int rc = check_view(ctx, fv);
     if (rc != ORBFE_OK) return rc;
@@ -501,12 +501,12 @@ extern "C" int orbfe_features_in_area(orbfe_context *ctx, const orbfe_frame_view
     if ((int)keys.size() > cap) return orbfe_fail(ctx, ORBFE_ERR_CAPACITY, "window holds %d keypoints, caller buffer %d", (int)keys.size(), cap);
     for (size_t i = 0; i < keys.size(); i++) out[i] = key_idx(keys[i]);
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 // Frame::AssignFeaturesToGrid (src/Frame.cc:231-246): mGrid as CSR.  The grid is the one every matcher call on this frame uses
 // (built by the same kernels; for a device-resident frame it stays cached for the calls that follow).
 extern "C" int orbfe_assign_features_to_grid(orbfe_context *ctx, const orbfe_frame_view *fv, int32_t *cell_off, int32_t *cell_idx)
-{
+try {
     ORBFE_ENTRY(ctx);
     int rc = check_view(ctx, fv);
     if (rc != ORBFE_OK) return rc;
@@ -529,13 +529,13 @@ extern "C" int orbfe_assign_features_to_grid(orbfe_context *ctx, const orbfe_fra
     for (int c = 0; c < ncell; c++)
         if (cell_off[c + 1] - cell_off[c] > 1) std::sort(cell_idx + cell_off[c], cell_idx + cell_off[c + 1]);
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 // Many GetFeaturesInArea queries against one frame: the frame is uploaded and its grid built once.
 extern "C" int orbfe_features_in_area_batch(orbfe_context *ctx, const orbfe_frame_view *fv, int nq, const float *x, const float *y,
                                             const float *r, const int32_t *min_level, const int32_t *max_level,
                                             int32_t *out_off, int32_t *out, int cap)
-{
+try {
     ORBFE_ENTRY(ctx);
     int rc = check_view(ctx, fv);
     if (rc != ORBFE_OK) return rc;
@@ -560,7 +560,7 @@ extern "C" int orbfe_features_in_area_batch(orbfe_context *ctx, const orbfe_fram
     }
     if (total > cap) return orbfe_fail(ctx, ORBFE_ERR_CAPACITY, "the windows hold %d keypoints, caller buffer %d", total, cap);
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 // ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono), src/ORBmatcher.cc:1324-1466
 extern "C" int orbfe_search_by_projection_last(orbfe_context *ctx, const orbfe_frame_view *cur,
@@ -569,7 +569,7 @@ extern "C" int orbfe_search_by_projection_last(orbfe_context *ctx, const orbfe_f
                                                const int32_t *last_obs, const int32_t *last_octave, const float *last_angle,
                                                const uint8_t *cur_has_obs, float th, int mono, int check_ori,
                                                int32_t *cur_match, int *nmatches)
-{
+try {
     ORBFE_ENTRY(ctx);
     int rc = check_view(ctx, cur);
     if (rc != ORBFE_OK) return rc;
@@ -605,13 +605,13 @@ extern "C" int orbfe_search_by_projection_last(orbfe_context *ctx, const orbfe_f
         fprintf(stderr, "[orbfe] SearchByProjection(last): queries %.3f  device round trip %.3f  replay %.3f ms (%d points, %d keypoints)\n",
                 t1 - t0, t2 - t1, now_ms() - t2, n_last, N);
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 // Frame::isInFrustum, src/Frame.cc:270-326, for n map points
 extern "C" int orbfe_is_in_frustum(orbfe_context *ctx, const float *Tcw, float min_x, float max_x, float min_y, float max_y,
                                    int n, const float *pos, const float *normal, const float *max_distance,
                                    const float *min_distance, float viewing_cos_limit, orbfe_track_point *out)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || !Tcw || n < 0 || (n > 0 && (!pos || !normal || !max_distance || !min_distance || !out)))
         return orbfe_fail(ctx, ORBFE_ERR_INVALID, "null argument");
@@ -620,14 +620,14 @@ extern "C" int orbfe_is_in_frustum(orbfe_context *ctx, const float *Tcw, float m
     orbfe_resolve::is_in_frustum(orbfe_resolve::camera_of(P), P->nlevels, log_sf, Tcw, min_x, max_x, min_y, max_y, n, pos, normal, max_distance, min_distance,
                                  viewing_cos_limit, out);
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 // ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th), src/ORBmatcher.cc:43-135
 extern "C" int orbfe_search_by_projection_points(orbfe_context *ctx, const orbfe_frame_view *cur, int n_pts,
                                                  const orbfe_track_point *pts, const uint8_t *pt_desc, const int32_t *pt_obs,
                                                  const uint8_t *cur_has_obs, float th, float nnratio,
                                                  int32_t *cur_match, int *nmatches)
-{
+try {
     ORBFE_ENTRY(ctx);
     int rc = check_view(ctx, cur);
     if (rc != ORBFE_OK) return rc;
@@ -652,7 +652,7 @@ extern "C" int orbfe_search_by_projection_points(orbfe_context *ctx, const orbfe
     *nmatches = orbfe_resolve::resolve_points(src, n_pts, pt_obs, N, has_obs, nnratio, cur_match);
     if (src.error) return orbfe_fail(ctx, ORBFE_ERR_HIP, "candidate list download failed");
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 // ORBmatcher::SearchByProjection(Frame&, KeyFrame*, set, th, ORBdist), src/ORBmatcher.cc:1468-1595
 extern "C" int orbfe_search_by_projection_kf(orbfe_context *ctx, const orbfe_frame_view *cur, const float *Tcw_cur, int n_kf,
@@ -660,7 +660,7 @@ extern "C" int orbfe_search_by_projection_kf(orbfe_context *ctx, const orbfe_fra
                                              const float *kf_angle, const float *kf_max_distance, const float *kf_min_distance,
                                              const uint8_t *cur_has_point, float th, int orb_dist, int check_ori,
                                              int32_t *cur_match, int *nmatches)
-{
+try {
     ORBFE_ENTRY(ctx);
     int rc = check_view(ctx, cur);
     if (rc != ORBFE_OK) return rc;
@@ -687,7 +687,7 @@ extern "C" int orbfe_search_by_projection_kf(orbfe_context *ctx, const orbfe_fra
     *nmatches = orbfe_resolve::resolve_kf(src, n_kf, kf_angle, N, &cur->keys_un[0].angle, sizeof(orbfe_keypoint), has_pt, orb_dist, check_ori, cur_match);
     if (src.error) return orbfe_fail(ctx, ORBFE_ERR_HIP, "candidate list download failed");
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 // Search part of ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th), src/ORBmatcher.cc:821-971: per candidate map
 // point the keyframe keypoint to fuse with.  The points do not interact (the map mutation that follows stays with the
@@ -695,7 +695,7 @@ extern "C" int orbfe_search_by_projection_kf(orbfe_context *ctx, const orbfe_fra
 extern "C" int orbfe_fuse(orbfe_context *ctx, const orbfe_frame_view *kf, const float *Tcw, int n_pts,
                           const float *pos, const float *normal, const float *max_distance, const float *min_distance,
                           const uint8_t *pt_desc, const int32_t *pt_valid, float th, int32_t *best_idx, int *n_fused)
-{
+try {
     ORBFE_ENTRY(ctx);
     int rc = check_view(ctx, kf);
     if (rc != ORBFE_OK) return rc;
@@ -759,7 +759,7 @@ extern "C" int orbfe_fuse(orbfe_context *ctx, const orbfe_frame_view *kf, const 
     }
     *n_fused = nf;
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 // Sim3 decomposition of the LoopClosing matchers (src/ORBmatcher.cc:293-298, 981-986); see oracle/orb_oracle_match.c
 static void sim3_to_rt(const float *Scw, float *T)
@@ -841,18 +841,18 @@ extern "C" int orbfe_search_by_projection_sim3(orbfe_context *ctx, const orbfe_f
                                                const float *pos, const float *normal, const float *max_distance, const float *min_distance,
                                                const uint8_t *pt_desc, const int32_t *pt_valid, const uint8_t *kf_matched, float th,
                                                int32_t *pt_match, int *nmatches)
-{
+try {
     ORBFE_ENTRY(ctx);
     return sim3_projection_impl(ctx, 0, kf, Scw, n_pts, pos, normal, max_distance, min_distance, pt_desc, pt_valid, kf_matched, th, pt_match, nmatches);
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_fuse_sim3(orbfe_context *ctx, const orbfe_frame_view *kf, const float *Scw, int n_pts,
                                const float *pos, const float *normal, const float *max_distance, const float *min_distance,
                                const uint8_t *pt_desc, const int32_t *pt_valid, float th, int32_t *best_idx, int *n_fused)
-{
+try {
     ORBFE_ENTRY(ctx);
     return sim3_projection_impl(ctx, 1, kf, Scw, n_pts, pos, normal, max_distance, min_distance, pt_desc, pt_valid, nullptr, th, best_idx, n_fused);
-}
+} ORBFE_CATCH(ctx)
 
 // One direction of ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1143-1216 / 1218-1291): keyframe A's map points moved into
 // camera B by [sR|t], one window query each against B; match[i] = keypoint of B or -1 (the points do not interact).
@@ -905,7 +905,7 @@ extern "C" int orbfe_search_by_sim3(orbfe_context *ctx,
                                     const orbfe_frame_view *kf2, const float *T2w, const float *pos2, const float *max_distance2,
                                     const float *min_distance2, const uint8_t *pt_desc2, const int32_t *valid2,
                                     float s12, const float *R12, const float *t12, float th, int32_t *match12, int *n_found)
-{
+try {
     ORBFE_ENTRY(ctx);
     int rc = check_view(ctx, kf1);
     if (rc != ORBFE_OK) return rc;
@@ -938,13 +938,13 @@ extern "C" int orbfe_search_by_sim3(orbfe_context *ctx,
     }
     *n_found = nf;
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 // ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:400-515
 extern "C" int orbfe_search_for_initialization(orbfe_context *ctx, const orbfe_frame_view *f1, const orbfe_frame_view *f2,
                                                float *prev_matched, int window_size, float nnratio, int check_ori,
                                                int32_t *matches12, int *nmatches)
-{
+try {
     ORBFE_ENTRY(ctx);
     int rc = check_view(ctx, f2);
     if (rc != ORBFE_OK) return rc;
@@ -966,7 +966,7 @@ extern "C" int orbfe_search_for_initialization(orbfe_context *ctx, const orbfe_f
                                                       n2 > 0 ? &f2->keys_un[0].x : &none.x, nnratio, check_ori, prev_matched, matches12);
     if (src.error) return orbfe_fail(ctx, ORBFE_ERR_HIP, "candidate list download failed");
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 orbfe_match_state *orbfe_match_state_create() { return new (std::nothrow) orbfe_match_state(); }
 void orbfe_match_state_destroy(orbfe_match_state *s) { delete s; }

@@ -704,7 +704,7 @@ extern "C" int orbfe_enqueue_pose_optimization(orbfe_context *ctx, int n_problem
                                                const orbfe_keypoint *d_keys_un, const float *d_u_right, const uint8_t *d_has_point,
                                                const float *d_Xw, float *d_Tcw, uint8_t *d_outlier, int32_t *d_n_inliers,
                                                int max_keypoints, void *stream)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || n_problems < 0) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     if (n_problems == 0) return ORBFE_OK;
@@ -736,21 +736,21 @@ extern "C" int orbfe_enqueue_pose_optimization(orbfe_context *ctx, int n_problem
     }
     PTRY(ctx, hipGetLastError());
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 #ifdef ORBFE_POSE_TIMING
 extern "C" int orbfe_pose_debug_cycles(long long *dst, int reset)
-{
+try {
     if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pose_cycles), sizeof(long long) * 8) != hipSuccess) return -1;
     if (reset) { long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pose_cycles), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
-}
+} ORBFE_CATCH(nullptr)
 #endif
 
 extern "C" int orbfe_pose_optimization_batch(orbfe_context *ctx, int n_problems, const int32_t *offsets, float *Tcw,
                                              const orbfe_keypoint *keys_un, const float *u_right, const uint8_t *has_point,
                                              const float *Xw, uint8_t *outlier, int32_t *n_inliers)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!ctx || n_problems < 0) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     if (n_problems == 0) return ORBFE_OK;
@@ -806,11 +806,11 @@ extern "C" int orbfe_pose_optimization_batch(orbfe_context *ctx, int n_problems,
     memcpy(n_inliers, hb + o_n, sizeof(int32_t) * n_problems);
     if (total > 0) memcpy(outlier, hb + o_out, tn);
     return ORBFE_OK;
-}
+} ORBFE_CATCH(ctx)
 
 extern "C" int orbfe_pose_optimization(orbfe_context *ctx, float *Tcw, int n, const orbfe_keypoint *keys_un, const float *u_right,
                                        const uint8_t *has_point, const float *Xw, uint8_t *outlier, int *n_inliers)
-{
+try {
     ORBFE_ENTRY(ctx);
     if (!n_inliers || n < 0) return orbfe_fail(ctx, ORBFE_ERR_INVALID, "bad argument");
     const int32_t off[2] = {0, n};
@@ -818,4 +818,4 @@ extern "C" int orbfe_pose_optimization(orbfe_context *ctx, float *Tcw, int n, co
     const int rc = orbfe_pose_optimization_batch(ctx, 1, off, Tcw, keys_un, u_right, has_point, Xw, outlier, &ninl);
     *n_inliers = ninl;
     return rc;
-}
+} ORBFE_CATCH(ctx)

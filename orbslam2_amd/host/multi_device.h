@@ -52,6 +52,7 @@ public:
         mImageBytes = (size_t)proto.width * proto.height;
         const int share = (max_pairs + n_contexts - 1) / n_contexts;
         mLanes.resize(n_contexts);
+        try {
         for (int i = 0; i < n_contexts; i++) {
             Lane &L = mLanes[i];
             orbfe_params p = proto;
@@ -59,7 +60,6 @@ public:
             p.max_images = 2 * share;
             if (orbfe_create(&p, &L.ctx) != ORBFE_OK) {
                 const std::string msg = orbfe_last_error(nullptr);
-                Shutdown();
                 throw std::runtime_error("orbfe_create (context " + std::to_string(i) + ", device " + std::to_string(p.device) + "): " + msg);
             }
             L.device = p.device;
@@ -68,6 +68,10 @@ public:
             L.kps.resize((size_t)2 * share * L.cap); L.desc.resize((size_t)2 * share * L.cap * 32);
             L.ur.resize((size_t)2 * share * L.cap); L.dp.resize((size_t)2 * share * L.cap); L.counts.resize((size_t)2 * share);
             L.thread = std::thread(&MultiDeviceFrontEnd::Feed, this, i);
+        }
+        } catch (...) { // a failed allocation or thread start after some feeders run: stop and join them (a joinable std::thread must not be destroyed)
+            Shutdown();
+            throw;
         }
     }
     ~MultiDeviceFrontEnd() { Shutdown(); }

@@ -67,6 +67,31 @@ def test_product_never_imports_the_oracle():
                     and "orb_oracle.h" not in text, os.path.join(dirpath, f)
 
 
+def test_status_returning_entry_points_are_function_try_blocks():
+    """No C++ exception may cross the C ABI: every multi-line `extern "C" int` definition of the library is a function-try-block
+    closed by ORBFE_CATCH (orbfe_host.h), the PNG ones by their own handlers."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "orbslam2_amd", "csrc")
+    checked = 0
+    for path in glob.glob(os.path.join(csrc, "*.hip")):
+        lines = open(path).read().split("\n")
+        for i, line in enumerate(lines):
+            if not line.startswith('extern "C" int ') or line.rstrip().endswith(("}", ";")):
+                continue
+            j = i
+            while not re.match(r"^(try )?\{$", lines[j]):
+                j += 1
+                assert j < i + 12, (path, i + 1)
+            assert lines[j] == "try {", "%s:%d: entry point without a function-try-block" % (os.path.basename(path), i + 1)
+            k = j + 1
+            while not lines[k].startswith("}"):
+                k += 1
+            assert lines[k].startswith("} ORBFE_CATCH("), "%s:%d" % (os.path.basename(path), k + 1)
+            checked += 1
+    assert checked >= 60
+
+
 def test_product_three_maxima_selection_equals_the_oracles_running_top_three():
     """orbfe_three_maxima needs no device: the product selects the three largest (size, -index) keys, the oracle keeps the reference's
     shifting if-chain (src/ORBmatcher.cc:1597-1638) -- two formulations, checked against each other on random, tied and empty bins."""
