@@ -20,8 +20,9 @@
  *   ORBFE_OCTREE=2|1   force the point-parallel (2) or the generic node-parallel (1)
  *                      DistributeOctTree kernel instead of the bucket-pyramid one
  *                      (orbfe_quadtree_kernel() reports the choice);
- *   ORBFE_NO_TAIL=1    keep the last pyramid levels on separate launches instead of
- *                      the fused tail kernel;
+ *   ORBFE_NO_TAIL=1|0  never / always run the last three pyramid levels in the fused tail
+ *                      kernel (default: for batches of fewer than 64 images; larger
+ *                      batches run them as single launches);
  *   ORBFE_PYR_LDS=1    keep cv::resize on the LDS-staged kernel (the path of scale factors
  *                      above ~2) instead of the direct one;
  *   ORBFE_NO_FUSE=1    blur every level in one launch after the pyramid instead of blurring

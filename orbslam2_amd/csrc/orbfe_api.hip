@@ -556,6 +556,7 @@ try {
             const int nst = p.nlevels >= 4 ? 3 : (p.nlevels == 3 ? 2 : 0);
             { const char *nf = getenv("ORBFE_NO_FUSE"); ctx->fuse_blur = !(nf && nf[0] == '1'); }
             const char *env = getenv("ORBFE_NO_TAIL");
+            c2.tail_max_images = env && env[0] == '0' ? INT_MAX : 63; // ORBFE_NO_TAIL=0: the tail at every batch size (A/B)
             if (nst >= 2 && !(env && env[0] == '1')) {
                 const int F = p.nlevels - nst, Lz = p.nlevels - 1;
                 const int strips = (c2.lv[Lz].rs_xtab_n + ORBFE_TAIL_COLS - 1) / ORBFE_TAIL_COLS;

@@ -78,6 +78,7 @@ struct DeviceConfig {
     int patch_n;           // entries in DeviceBuffers::patch_uv (multiple of 64)
     // fused pyramid tail (pyr_tail_kernel): the last tail_n levels (2 or 3) in one launch, 0 = not used
     int tail_first, tail_n, tail_strips;
+    int tail_max_images;               // the fused tail serves batches of up to this many images; larger ones run levels tail_first.. as single launches
     int tail_src_words;                // staged words per row of level tail_first - 1 (widest strip)
     int tail_words[ORBFE_TAIL_MAX];    // words per row of stage s computed by the widest strip
     int tail_lds_y[ORBFE_TAIL_MAX];    // LDS byte offsets: row tables of stage s, ...

@@ -185,13 +185,14 @@ def test_lds_resize_kernel_still_matches(monkeypatch):
 
 def test_blur_fused_and_separate_launches_match(monkeypatch):
     """By default level l - 1 is blurred inside the launch that resizes it into level l; ORBFE_NO_FUSE=1 blurs every level in one
-    launch after the pyramid.  Both must give the oracle's blurred pyramid (and ORBFE_PYR_LDS=1, which leaves nothing to fuse)."""
+    launch after the pyramid.  Both must give the oracle's blurred pyramid (and ORBFE_PYR_LDS=1, which leaves nothing to fuse;
+    ORBFE_NO_TAIL=1: the last three levels as single launches, which batches of 64 images and more do by themselves)."""
     from orbslam2_amd import api
     left = synth.mono_image(752, 480, seed=3)
     ex = O.Extractor(nfeatures=1200)
     kr, dr = ex.extract(left)
-    for env in ({"ORBFE_NO_FUSE": "1"}, {"ORBFE_NO_FUSE": "0"}, {"ORBFE_PYR_LDS": "1"}):
-        for k in ("ORBFE_NO_FUSE", "ORBFE_PYR_LDS"):
+    for env in ({"ORBFE_NO_FUSE": "1"}, {"ORBFE_NO_FUSE": "0"}, {"ORBFE_PYR_LDS": "1"}, {"ORBFE_NO_TAIL": "1"}, {"ORBFE_NO_TAIL": "1", "ORBFE_NO_FUSE": "1"}):
+        for k in ("ORBFE_NO_FUSE", "ORBFE_PYR_LDS", "ORBFE_NO_TAIL"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
