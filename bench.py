@@ -87,21 +87,28 @@ def traffic_bytes(stage: str, pairs: int, launches: int):
 
 def _sq_valu_per_pair():
     """SQ_INSTS_VALU per stereo pair of every kernel of the step, from the committed rocprofv3 counter pass (launches of 64 pairs;
-    the pyramid's resize kernel -- with the blur of the level it reads fused in -- runs once per level 1-4): {kernel name fragment: wave-instructions per pair}."""
+    the pyramid's resize kernel -- with the blur of the level it reads fused in -- runs once per level; the counts file says how often): {kernel name fragment: wave-instructions per pair}."""
     for name in ("r03_pmc_sq.txt", "r02_pmc_sq.txt", "r01_pmc_sq.txt"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
-        out = {}
+        rows = []
         for line in open(path):
             if "SQ_INSTS_VALU" not in line or "{" not in line:
                 continue
             d = eval(line[line.index("{"):line.rindex("}") + 1], {"__builtins__": {}})
             kern = line[:line.index("{")].strip()
+            tail = line[line.rindex("}"):]
+            n = int(tail[tail.index("n=") + 2:]) if "n=" in tail else 1
             if "rocclr" in kern or "candidates_gather" in kern:  # runtime copies; the parity tap of the post-run check
                 continue
-            calls_per_step = 4 if any(k in kern for k in ("pyr_resize_kernel", "pyr_resize_direct_kernel", "pyr_resize_blur_kernel")) else 1  # levels 1-4
-            out[kern] = out.get(kern, 0.0) + d["SQ_INSTS_VALU"] * calls_per_step / 64.0
+            rows.append((kern, d["SQ_INSTS_VALU"], n))
+        # launches per step of a kernel = its dispatch count / fast_cell_kernel's (one per step): the resize kernel runs once per
+        # level (4 with the fused tail, 7 without)
+        steps = max([n for k, _, n in rows if "fast_cell_kernel" in k] or [1])
+        out = {}
+        for kern, v, n in rows:
+            out[kern] = out.get(kern, 0.0) + v * (n / steps) / 64.0
         if out:
             return out, name
     return None, None
