@@ -183,6 +183,32 @@ def test_lds_resize_kernel_still_matches(monkeypatch):
         ctx.close()
 
 
+@pytest.mark.parametrize("w,h,nlevels", [(48, 45, 2), (65, 49, 3), (257, 52, 4), (60, 300, 5), (1029, 70, 6)])
+def test_pyramid_of_narrow_and_short_images(w, h, nlevels):
+    """Level sizes around the resize kernel's granules: fewer than 64 four-column words per row (one partly filled strip), 64 n + 1
+    words, fewer extended rows than one workgroup's band -- raw and blurred pyramid, keypoints and descriptors against the oracle."""
+    from orbslam2_amd import api
+    kw = dict(nfeatures=300, nlevels=nlevels)
+    try:
+        ex = O.Extractor(**kw)
+    except ValueError:
+        pytest.skip("parameter set rejected by the oracle")
+    img = synth.mono_image(w, h, seed=w + h)
+    try:
+        ctx = api.Context(width=w, height=h, **kw)
+    except api.OrbfeError as e:
+        if e.code == api.ERR_UNSUPPORTED:
+            pytest.skip("geometry refused by orbfe_create: %s" % e)
+        raise
+    k, d = ctx.extract(img)
+    kr, dr = ex.extract(img)
+    for l in range(nlevels):
+        assert np.array_equal(ctx.fetch_pyramid(0, l), ex.pyramid_level(l)), l
+        assert np.array_equal(ctx.fetch_pyramid(0, l, blurred=True), O.gaussian7(ex.pyramid_level(l))), l
+    assert np.array_equal(k, kr.astype(api.KP_DTYPE)) and np.array_equal(d, dr)
+    ctx.close()
+
+
 def test_blur_fused_and_separate_launches_match(monkeypatch):
     """By default level l - 1 is blurred inside the launch that resizes it into level l; ORBFE_NO_FUSE=1 blurs every level in one
     launch after the pyramid.  Both must give the oracle's blurred pyramid (and ORBFE_PYR_LDS=1, which leaves nothing to fuse;
