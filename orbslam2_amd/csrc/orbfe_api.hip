@@ -421,7 +421,7 @@ try {
     if (ctx->use_octree3 && ctx->ot3_nodes_in_hbm) A(b.ot3_scratch, B * c.nlevels * orbfe_octree3_node_bytes(c.max_nodes, ctx->ot2_sort_cap));
     A(b.lvl_ncand, B * c.nlevels);
     A(b.sel_cnt, B * c.nlevels);
-    A(b.sel_xy, B * c.sel_total);
+    A(b.sel_xy, B * c.sel_total + 4); // + 4: stereo_rowlist_kernel reads whole quads of slots
     A(b.sel_sc, B * c.sel_total);
     A(kps, B * c.sel_total);
     b.kps = kps;
@@ -770,7 +770,7 @@ try {
         b.blur_tile_info = d_ti;
     }
     {   // keypoint slot -> level
-        std::vector<uint8_t> sl(c.sel_total);
+        std::vector<uint8_t> sl((size_t)c.sel_total + 4, 0); // + 4: read as whole 32-bit words of four slots (stereo_rowlist_kernel)
         for (int l = 0; l < p.nlevels; l++)
             for (int k = 0; k < c.lv[l].sel_cap; k++) sl[c.lv[l].sel_off + k] = (uint8_t)l;
         uint8_t *d_sl = nullptr;
@@ -1017,6 +1017,7 @@ static void run_chain(orbfe_context *ctx, const uint8_t *d_images, int img0, int
     orbfe_launch_describe(cfg, buf, n_images, n_pairs > 0, s);
     prof_mark(ctx, group, 6, s);
     if (n_pairs > 0) {
+        if (cfg.half_patch != 15) orbfe_launch_stereo_rowlists(cfg, buf, n_pairs, s); // describe_kernel (the reference's patch size) builds them in its own launch
         orbfe_launch_stereo_match(cfg, buf, n_pairs, s);
         prof_mark(ctx, group, 7, s);
         orbfe_launch_stereo_median(cfg, buf, n_pairs, s);

@@ -57,9 +57,11 @@ __host__ __forceinline__ int xcd_grid(int blocks_per_unit, int n_units)
 // a / b for 0 <= a < 2^21, b >= 1: exact through the 1-ulp reciprocal (the quotient's distance to the next integer, 0.5 / b,
 // exceeds (a / b) * 2^-22); six VALU operations instead of the compiler's integer-division sequence
 __device__ __forceinline__ int small_div(int a, int b) { return (int)(((float)a + 0.5f) * __builtin_amdgcn_rcpf((float)b)); }
-__device__ __forceinline__ bool xcd_map(int blocks_per_unit, int n_units, int &unit, int &blk)
+__device__ __forceinline__ bool xcd_map_of(int bid, int blocks_per_unit, int n_units, int &unit, int &blk); // the same for workgroup `bid` of a grid whose first (multiple of 8) workgroups do something else
+__device__ __forceinline__ bool xcd_map(int blocks_per_unit, int n_units, int &unit, int &blk) { return xcd_map_of((int)blockIdx.x, blocks_per_unit, n_units, unit, blk); }
+__device__ __forceinline__ bool xcd_map_of(int bid, int blocks_per_unit, int n_units, int &unit, int &blk)
 {
-    const int lg = xcd_split_log2(n_units), xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int lg = xcd_split_log2(n_units), xcd = bid & 7, jb = bid >> 3;
     const int per_xcd = (blocks_per_unit + (1 << lg) - 1) >> lg;
     const int round = small_div(jb, per_xcd); // jb < 2^21: at most 2^24 blocks per launch (orbfe_create refuses blocks x images >= 2^23)
     unit = round * (8 >> lg) + (xcd >> lg);

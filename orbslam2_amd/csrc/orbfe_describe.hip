@@ -1,5 +1,6 @@
 // orbfe_describe.hip -- IC_Angle + computeOrbDescriptor + keypoint records (src/ORBextractor.cc:72-142,831-846,909-915) and the stereo row lists.
 #include "orbfe_common.hpp"
+#include "orbfe_rowlist.hpp"
 
 __device__ __attribute__((aligned(16))) const int8_t g_pattern[1024] = {
 #include "orb_pattern_31.inc"
@@ -23,42 +24,6 @@ __device__ __attribute__((aligned(16))) const int8_t g_pattern[1024] = {
 #define DS_KPW 4      // keypoint slots per wave
 #define DS_BLR_ROWS 40 // blurred patch rows staged: the 37 the descriptor can reach, from a row that is a multiple of 4
 
-
-// Right image of a stereo pair: list each of the wave's keypoints in the rows its band covers (vRowIndices, src/Frame.cc:474-491:
-// rows floor(y - r) .. ceil(y + r), r = 2 * scale[octave]); the order inside a row list is irrelevant to stereo_match_kernel's
-// arg-min.  rl_lv / rl_x / rl_y: lane i < DS_KPW holds level | index << 8 (-1: none), x and y of the wave's i-th keypoint.
-__device__ __forceinline__ void describe_row_lists(const DeviceConfig &cfg, const DeviceBuffers &buf, int img, int lane, int rl_lv, float rl_x, float rl_y)
-{
-    // right image of a pair: list each keypoint in the rows its band covers (vRowIndices, src/Frame.cc:474-491: rows
-    // floor(y - r) .. ceil(y + r), r = 2 * scale[octave]); the order inside a row list is irrelevant to
-    // stereo_match_kernel's arg-min.  All of the wave's atomics are issued before the first dependent store.
-    int *rcnt = buf.row_cnt + (size_t)(img >> 1) * cfg.height;
-    uint2 *rent = buf.row_ent + (size_t)(img >> 1) * cfg.height * cfg.row_cap;
-    int pos[DS_KPW], yy[DS_KPW];
-    uint2 e[DS_KPW];
-#pragma unroll
-    for (int i = 0; i < DS_KPW; i++) {
-        const int lvk = __builtin_amdgcn_readlane(rl_lv, i);
-        const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rl_x), i));
-        const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rl_y), i));
-        pos[i] = -1; yy[i] = 0;
-        e[i].x = (uint32_t)(lvk >> 8) | ((uint32_t)(lvk & 255) << 16); e[i].y = __float_as_uint(x);
-        if (lvk >= 0) {
-            const float r = __fmul_rn(2.0f, cfg.lv[lvk & 255].scale);
-            int maxr = (int)ceilf(__fadd_rn(y, r)), minr = (int)floorf(__fsub_rn(y, r));
-            minr = minr < 0 ? 0 : minr; maxr = maxr > cfg.height - 1 ? cfg.height - 1 : maxr;
-            yy[i] = minr + lane;
-            if (yy[i] <= maxr) pos[i] = atomicAdd(&rcnt[yy[i]], 1);
-            for (int y2 = yy[i] + 64; y2 <= maxr; y2 += 64) { // bands taller than a wave (large scale factors only)
-                const int p2 = atomicAdd(&rcnt[y2], 1);
-                if (p2 < cfg.row_cap) rent[(size_t)y2 * cfg.row_cap + p2] = e[i];
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < DS_KPW; i++)
-        if (pos[i] >= 0 && pos[i] < cfg.row_cap) rent[(size_t)yy[i] * cfg.row_cap + pos[i]] = e[i];
-}
 
 __global__ __launch_bounds__(256, 8) void describe_generic_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int stereo ORBFE_CUT_PARAM)
 {
@@ -305,7 +270,7 @@ __global__ __launch_bounds__(256, 8) void describe_generic_kernel(DeviceConfig c
             ((KeyPointPOD *)buf.kps)[(size_t)img * cfg.sel_total + (rl_lv >> 8)] = kp;
         }
     }
-    if (stereo && (img & 1)) describe_row_lists(cfg, buf, img, lane, rl_lv, rl_x, rl_y);
+    (void)stereo; // the stereo row lists come from stereo_rowlist_kernel (orbfe_stereo.hip) for this kernel's geometries
 }
 
 
@@ -324,14 +289,28 @@ __global__ __launch_bounds__(256, 8) void describe_generic_kernel(DeviceConfig c
 // ---------------------------------------------------------------------------
 typedef const __attribute__((address_space(3))) uint8_t *ds_lds_cptr; // LDS pointers are 32 bits wide
 #define DS_LGKM0 0xc07f // s_waitcnt lgkmcnt(0) only: vmcnt / expcnt fields at their maxima (prefetches stay in flight)
-__global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int stereo ORBFE_CUT_PARAM)
+__global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_images, int stereo /* row-list workgroups ahead of the descriptor ones; 0: no stereo stage */ ORBFE_CUT_PARAM)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dm[];
-    const int bpi = (cfg.sel_total + 4 * DS_KPW - 1) / (4 * DS_KPW); // blocks per image (XCD-aware map: see describe_generic_kernel)
-    int img, blk;
-    if (!xcd_map(bpi, n_images, img, blk)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Stereo: the first `stereo` workgroups (a multiple of 8: the XCD map of the rest) build the pairs' row lists, four independent
+    // waves each (orbfe_rowlist.hpp: they need the quadtree's output only).  As a launch of its own that work takes 19.5 us, 8 of
+    // them launch and first-load latency; here it rides beside the descriptor waves.
+    int bid = blockIdx.x;
+    if (stereo) {
+        if (bid < stereo) {
+            const int bpp = rowlist_blocks(cfg.height);
+            const int e = bid * 4 + wave;
+            const int pair = __builtin_amdgcn_readfirstlane(small_div(e, bpp));
+            if (pair < (n_images >> 1)) rowlist_wave(cfg, buf, pair, e - pair * bpp, s_dm + wave * RL_LDS_BYTES);
+            return;
+        }
+        bid -= stereo;
+    }
+    const int bpi = (cfg.sel_total + 4 * DS_KPW - 1) / (4 * DS_KPW); // blocks per image (XCD-aware map: see describe_generic_kernel)
+    int img, blk;
+    if (!xcd_map_of(bid, bpi, n_images, img, blk)) return;
     const int slot0 = blk * (4 * DS_KPW) + wave * DS_KPW;
     const int *sel_cnt = buf.sel_cnt + (size_t)img * cfg.nlevels;
     if (blk == 0 && tid == 0) {
@@ -505,15 +484,20 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
             ((KeyPointPOD *)buf.kps)[(size_t)img * cfg.sel_total + (rl_lv >> 8)] = kp;
         }
     }
-    if (stereo && (img & 1)) describe_row_lists(cfg, buf, img, lane, rl_lv, rl_x, rl_y);
 }
 
 void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool stereo, hipStream_t s)
 {
     dim3 grid(xcd_grid((cfg.sel_total + 4 * DS_KPW - 1) / (4 * DS_KPW), n_images));
     if (cfg.half_patch == 15) { // the reference's HALF_PATCH_SIZE
-        const size_t lds = 256 * sizeof(float4) + 4 * (DS_BLR_ROWS * DS_PATCH_W);
-        hipLaunchKernelGGL(describe_kernel, grid, dim3(256), lds, s, cfg, buf, n_images, stereo ? 1 : 0 ORBFE_CUT_ARG("ORBFE_DESC_DBG"));
+        size_t lds = 256 * sizeof(float4) + 4 * (DS_BLR_ROWS * DS_PATCH_W);
+        int rl_blocks = 0; // workgroups that build the stereo row lists, ahead of the descriptor ones
+        if (stereo) {
+            rl_blocks = (((n_images / 2) * rowlist_blocks(cfg.height) + 3) / 4 + 7) & ~7;
+            if (lds < 4 * (size_t)RL_LDS_BYTES) lds = 4 * (size_t)RL_LDS_BYTES;
+        }
+        dim3 grid_s(rl_blocks + grid.x);
+        hipLaunchKernelGGL(describe_kernel, grid_s, dim3(256), lds, s, cfg, buf, n_images, rl_blocks ORBFE_CUT_ARG("ORBFE_DESC_DBG"));
         return;
     }
     const size_t raw_bytes = (((2 * cfg.half_patch + 1) * DS_PATCH_W + 15) & ~15);

@@ -135,8 +135,8 @@ struct DeviceBuffers {
     float *depth;        // [img][sel_total]
     int *sad;            // [img][sel_total] best SAD (or -1)
     int *status;         // [img] non-zero = device-side capacity problem
-    int *row_cnt;        // [pair][height] stereo row lists: right keypoints whose band covers the row (cleared by ingest)
-    uint2 *row_ent;      // [pair][height][row_cap] entries: (iR | octave << 16, x bits), appended by describe_kernel
+    int *row_cnt;        // [pair][height] stereo row lists: right keypoints whose band covers the row (every row written by the row-list waves, orbfe_rowlist.hpp)
+    uint2 *row_ent;      // [pair][height][row_cap] entries: (iR | octave << 16, x bits), written by stereo_rowlist_kernel
     const uint32_t *bk_tab; // quadtree bucket tables: per level X[region_w] then Y[region_h] (see ORBFE_BK_*)
     const uint32_t *bk_emap; // [bk_part_total] bucket index | level-local cell << 16 of every bk_part entry
     const uint32_t *bk_off;  // [cells_total] first bk_part entry of the cell; ~0u: the cell spans > 64 buckets (no partials)
@@ -190,6 +190,7 @@ size_t orbfe_octree3_node_bytes(int max_nodes, int sort_cap);
 size_t orbfe_octree3_lds_bytes(int max_nodes, int sort_cap, bool nodes_in_hbm);
 int orbfe_octree3_prepare(size_t lds, bool nodes_in_hbm);
 void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool stereo, hipStream_t s);
+void orbfe_launch_stereo_rowlists(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s);
 void orbfe_launch_stereo_match(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s);
 void orbfe_launch_stereo_median(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s);
 void orbfe_launch_rgbd(const DeviceConfig &cfg, const DeviceBuffers &buf, const float *d_depth,

@@ -36,11 +36,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(DeviceConfig cfg, DeviceBuf
 {
     const int img = blockIdx.z;
     const LevelInfo &L = cfg.lv[0];
-    if (blockIdx.x == 0 && blockIdx.y == 0) { // first kernel of every chain: clear the image's status word and, for a right image, its pair's stereo row counters
-        if (threadIdx.x == 0) buf.status[img] = 0;
-        if (img & 1)
-            for (int i = threadIdx.x; i < cfg.height; i += 256) buf.row_cnt[(size_t)(img >> 1) * cfg.height + i] = 0;
-    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) buf.status[img] = 0; // first kernel of every chain: clear the image's status word
     const int x0 = (int)(blockIdx.x * 64 + (threadIdx.x & 63)) * 4 - PYR_MX;
     if (x0 >= L.w + 8) return;
     // a wave copies ING_ROWS consecutive rows of its 64-word strip (one word per lane and row): four times fewer, longer
@@ -101,11 +97,7 @@ __global__ __launch_bounds__(256) void ingest16_kernel(DeviceConfig cfg, DeviceB
 {
     const int img = blockIdx.y;
     const LevelInfo &L = cfg.lv[0];
-    if (blockIdx.x == 0) { // first kernel of every chain: clear the image's status word and, for a right image, its pair's stereo row counters
-        if (threadIdx.x == 0) buf.status[img] = 0;
-        if (img & 1)
-            for (int i = threadIdx.x; i < cfg.height; i += 256) buf.row_cnt[(size_t)(img >> 1) * cfg.height + i] = 0;
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) buf.status[img] = 0; // first kernel of every chain: clear the image's status word
     const int ext_w = (L.w + 12 + 3) & ~3;            // extended row in bytes: PYR_MX + w + >= 8, whole words
     const int cpr = (ext_w + 15) >> 4;                // 16-byte chunks per row (the last one may be half used: the pitch covers it)
     const int y_first = (int)blockIdx.x * ING16_ROWS - PYR_MY;

@@ -1,6 +1,7 @@
 // orbfe_stereo.hip -- Frame::ComputeStereoMatches (src/Frame.cc:464-642), ComputeStereoFromRGBD (:645-666), batched DescriptorDistance.
 #include "orbfe_common.hpp"
 
+
 // ---------------------------------------------------------------------------
 // stereo: one wave per left keypoint (coarse Hamming band search + SAD + parabola)
 // ---------------------------------------------------------------------------
@@ -24,6 +25,16 @@ __device__ __forceinline__ unsigned group_min_u32(unsigned v)
 }
 __device__ __forceinline__ int group_sum_i32(int v) { return row_sum_i32(v); } // SM_G == 16 == one DPP row
 __device__ __forceinline__ uint32_t sad_u16(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_sad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+
+#include "orbfe_rowlist.hpp"
+
+// four independent waves per workgroup: wave w of workgroup b builds block 4 b + w of pair blockIdx.y
+__global__ __launch_bounds__(256) void stereo_rowlist_kernel(DeviceConfig cfg, DeviceBuffers buf)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_rl_all[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    rowlist_wave(cfg, buf, blockIdx.y, (int)blockIdx.x * 4 + wave, s_rl_all + wave * RL_LDS_BYTES);
+}
 
 __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_pairs)
 {
@@ -74,8 +85,8 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, Dev
             if (key < best) { best = key; best_x = xr; }
         }
     };
-    // candidates = right keypoints whose row band covers int(vL) (vRowIndices[vL], src/Frame.cc:513), listed per row by
-    // describe_kernel; the arg-min key (dist << 16 | iR) makes the result independent of the order inside a row list
+    // candidates = right keypoints whose row band covers int(vL) (vRowIndices[vL], src/Frame.cc:513), listed per row by the
+    // row-list waves (orbfe_rowlist.hpp); the arg-min key (dist << 16 | iR) makes the result independent of the order inside a row list
     int cnt = 0;
     if (row >= 0 && row < cfg.height) cnt = buf.row_cnt[(size_t)pair * cfg.height + row];
     if (cnt <= cfg.row_cap) {
@@ -402,6 +413,12 @@ __global__ __launch_bounds__(256) void hamming_matrix_kernel(const uint8_t *__re
     }
 }
 
+
+void orbfe_launch_stereo_rowlists(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s)
+{
+    dim3 grid((rowlist_blocks(cfg.height) + 3) / 4, n_pairs);
+    hipLaunchKernelGGL(stereo_rowlist_kernel, grid, dim3(256), 4 * RL_LDS_BYTES, s, cfg, buf);
+}
 
 void orbfe_launch_stereo_match(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s)
 {

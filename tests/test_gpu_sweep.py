@@ -273,6 +273,34 @@ def test_stereo_row_list_overflow():
     ctx.close()
 
 
+def test_stereo_row_lists_longer_than_their_lds_staging():
+    """Keypoints inside a 150-row band: the rows' candidate lists hold 100-200 entries -- more than the 64 the row-list waves stage
+    in LDS (the rest go straight to the global list), fewer than the lists' capacity -- same matches as the oracle."""
+    from orbslam2_amd import api
+    w, h, nf = 1241, 376, 2000
+    rng = np.random.default_rng(11)
+    tex = rng.integers(0, 256, (150, w + 40)).astype(np.uint8)
+    left = np.full((h, w), 120, np.uint8); right = left.copy()
+    left[110:260, :] = tex[:, 40:40 + w]
+    right[110:260, :] = tex[:, 31:31 + w]  # 9 px disparity
+    fx, bf = 718.856, 386.1448
+    ctx = api.Context(width=w, height=h, nfeatures=nf, fx=fx, fy=fx, cx=607.0, cy=185.0, bf=bf)
+    out = ctx.stereo_frame(left, right)
+    exl, exr = O.Extractor(nfeatures=nf), O.Extractor(nfeatures=nf)
+    kl, dl = exl.extract(left); kr, dr = exr.extract(right)
+    ur, dp, m = O.stereo_matches(exl, exr, kl, dl, kr, dr, bf, fx)
+    rows = np.zeros(h, int)
+    for k in kr:
+        r = 2.0 * 1.2 ** int(k["octave"])
+        rows[max(0, int(np.floor(k["y"] - r))):min(h - 1, int(np.ceil(k["y"] + r))) + 1] += 1
+    cap = 4 * len(kr) * 10 // h  # the capacity formula of orbfe_create
+    assert 64 < rows.max() <= cap and (rows > 64).sum() > 50
+    assert m > 50
+    assert np.array_equal(out["kps_right"], kr.astype(api.KP_DTYPE))
+    assert np.array_equal(out["u_right"], ur) and np.array_equal(out["depth"], dp)
+    ctx.close()
+
+
 @pytest.mark.parametrize("kw", [
     dict(nlevels=5, scale_factor=1.5, nfeatures=1500),
     dict(nlevels=12, scale_factor=1.1, nfeatures=3000),
