@@ -11,7 +11,7 @@ import ast, json, sys
 # launch for the levels that are not blurred beside a resize (4-7 at KITTI geometry)
 STAGE_OF = {"ingest_kernel": "ingest", "ingest16_kernel": "ingest", "pyr_resize": "pyramid", "pyr_tail_kernel": "pyramid", "blur_kernel": "blur", "fast_cell_kernel": "fast",
             "octree": "octree", "describe_kernel": "describe", "stereo_match_kernel": "stereo_match",
-            "stereo_rowtable_kernel": "stereo_match", "stereo_median_kernel": "stereo_median"}
+            "stereo_rowtable_kernel": "stereo_match", "stereo_rowlist_kernel": "stereo_match", "stereo_median_kernel": "stereo_median"}
 
 
 def read(path, counter):
