@@ -300,10 +300,10 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
     int bid = blockIdx.x;
     if (stereo) {
         if (bid < stereo) {
-            const int bpp = rowlist_blocks(cfg.height);
+            const int bpp = rowlist_blocks(cfg.height, RL_ROWS_FUSED);
             const int e = bid * 4 + wave;
             const int pair = __builtin_amdgcn_readfirstlane(small_div(e, bpp));
-            if (pair < (n_images >> 1)) rowlist_wave(cfg, buf, pair, e - pair * bpp, s_dm + wave * RL_LDS_BYTES);
+            if (pair < (n_images >> 1)) rowlist_wave<RL_ROWS_FUSED>(cfg, buf, pair, e - pair * bpp, s_dm + wave * RL_LDS_BYTES);
             return;
         }
         bid -= stereo;
@@ -493,7 +493,7 @@ void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, in
         size_t lds = 256 * sizeof(float4) + 4 * (DS_BLR_ROWS * DS_PATCH_W);
         int rl_blocks = 0; // workgroups that build the stereo row lists, ahead of the descriptor ones
         if (stereo) {
-            rl_blocks = (((n_images / 2) * rowlist_blocks(cfg.height) + 3) / 4 + 7) & ~7;
+            rl_blocks = (((n_images / 2) * rowlist_blocks(cfg.height, RL_ROWS_FUSED) + 3) / 4 + 7) & ~7;
             if (lds < 4 * (size_t)RL_LDS_BYTES) lds = 4 * (size_t)RL_LDS_BYTES;
         }
         dim3 grid_s(rl_blocks + grid.x);

@@ -5,7 +5,7 @@
 #include "orbfe_common.hpp"
 
 // Right keypoint iR is listed in rows floor(y - r) .. ceil(y + r), r = 2 * scale[octave].  One WAVE builds the lists of RL_ROWS
-// consecutive image rows of a pair in LDS and writes them out with plain, coalesced stores.  It reads the keypoints as the
+// consecutive image rows of a pair: the lists go to their place in runs of consecutive entries, the counts at the end.  It reads the keypoints as the
 // quadtree kernel left them (one coalesced word per slot: level-local integer coordinates; final index, x and y follow exactly as
 // describe_kernel derives them), all of an image's slots in flight at once; the per-level constants come from a 16-entry LDS table.
 //   (1) every keypoint's band against the block's rows -- y + r > r0 - 1 and y - r < r1, the same rounded sums the reference takes
@@ -13,30 +13,30 @@
 //       image, so this pass is kept to ~16 instructions per slot);
 //   (2) per queue chunk of 64 and block row: a ballot of the lanes whose band covers the row gives their list positions -- no
 //       atomics, no divergent per-lane row loop.
-// The LDS lists hold RL_LDS_CAP entries per row; a longer row (up to row_cap) writes its further entries straight to the global
-// list; a row's count may exceed row_cap (entries beyond it are dropped): stereo_match_kernel then scans every right keypoint.
+// A row's count may exceed row_cap (entries beyond it are dropped): stereo_match_kernel then scans every right keypoint.
 // History: rounds 1-2 appended from describe_kernel with one returning GLOBAL atomic and one scattered 8-byte store per (keypoint,
 // row): ~1.1 M of each per 64-pair step, 24 us of describe_kernel (0.163 -> 0.139 ms without them) and most of its write
 // amplification; issuing them at the start of the wave instead of its end changed nothing (their number, not their latency).  A
-// first LDS kernel (one workgroup per 8-16 rows, LDS atomics, every slot's full arithmetic under a divergent test) took 20-29 us.
-#ifndef ORBFE_RL_ROWS
-#define ORBFE_RL_ROWS 4 // image rows per wave (at most 16): 4 / 8 / 16 rows measured 19.5 / 24.4 / 34.5 us as a launch of its own
-#endif
-#define RL_LDS_CAP 64 // 4 waves x (level table + queue + 4 rows x 64 entries) = 17 KB per workgroup: describe_kernel keeps its 8 workgroups per CU
+// first LDS kernel (one workgroup per 8-16 rows, LDS atomics, every slot's full arithmetic under a divergent test) took 20-29 us;
+// these waves in a launch of their own 19.5 / 24.4 / 34.5 us at 4 / 8 / 16 rows per wave (7.8 of them launch + first-load
+// latency), riding in describe_kernel's launch 8 / 5 / 4 us (describe 0.1466 / 0.1439 / 0.1425 ms against 0.1385 without lists;
+// with the lists staged in LDS before a coalesced copy-out 0.1477: the runs a ballot writes are contiguous enough).
+#define RL_ROWS_FUSED 16 // image rows per wave inside describe_kernel's launch (long waves are free there: only their issue slots count)
+#define RL_ROWS_ALONE 4  // ... and in a launch of its own, which lives on the number of short waves
 #define RL_QUEUE 128
-#define RL_BATCH 4     // per lane and pass: 4 x 4 consecutive slots (one 128-bit load of coordinates, one 32-bit load of levels) in flight; 8 spills 13 VGPRs inside describe_kernel (64 allowed)
-#define RL_LDS_BYTES (16 * 16 + RL_QUEUE * 16 + ORBFE_RL_ROWS * RL_LDS_CAP * 8) // per wave: level constants, queue (entry.x, entry.y, y + r, y - r as bits), [rows][RL_LDS_CAP] entries
-__host__ __device__ __forceinline__ int rowlist_blocks(int height) { return (height + ORBFE_RL_ROWS - 1) / ORBFE_RL_ROWS; }
+#define RL_BATCH 4       // per lane and pass: 4 x 4 consecutive slots (one 128-bit load of coordinates, one 32-bit load of levels) in flight; 8 spills 13 VGPRs inside describe_kernel (64 allowed)
+#define RL_LDS_BYTES (16 * 16 + RL_QUEUE * 16) // per wave: level constants, queue (entry.x, entry.y, y + r, y - r as bits)
+__host__ __device__ __forceinline__ int rowlist_blocks(int height, int rows) { return (height + rows - 1) / rows; }
 
+template <int ROWS>
 __device__ __forceinline__ void rowlist_wave(const DeviceConfig &cfg, const DeviceBuffers &buf, int pair, int block, uint8_t *s_mem)
 {
     int4 *s_lev = (int4 *)s_mem;                      // per level: first final index, keypoint count, first slot, scale bits
     uint4 *s_q = (uint4 *)(s_mem + 16 * 16);
-    uint2 *s_ent = (uint2 *)(s_mem + 16 * 16 + RL_QUEUE * 16);
     const int lane = threadIdx.x & 63;
-    const int r0 = block * ORBFE_RL_ROWS;
+    const int r0 = block * ROWS;
     if (r0 >= cfg.height) return;
-    const int r1 = r0 + ORBFE_RL_ROWS < cfg.height ? r0 + ORBFE_RL_ROWS : cfg.height; // rows [r0, r1)
+    const int r1 = r0 + ROWS < cfg.height ? r0 + ROWS : cfg.height; // rows [r0, r1)
     const int imgR = 2 * pair + 1;
     const uint32_t *sxy = buf.sel_xy + (size_t)imgR * cfg.sel_total;
     const int *sel_cnt = buf.sel_cnt + (size_t)imgR * cfg.nlevels;
@@ -60,9 +60,9 @@ __device__ __forceinline__ void rowlist_wave(const DeviceConfig &cfg, const Devi
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    int cnt[ORBFE_RL_ROWS]; // list lengths (uniform)
+    int cnt[ROWS]; // list lengths (uniform)
 #pragma unroll
-    for (int k = 0; k < ORBFE_RL_ROWS; k++) cnt[k] = 0;
+    for (int k = 0; k < ROWS; k++) cnt[k] = 0;
     int nqd = 0; // queue fill (uniform)
     auto drain = [&]() {
         __builtin_amdgcn_s_waitcnt(0xc07f); // this wave's queue writes have landed
@@ -73,16 +73,13 @@ __device__ __forceinline__ void rowlist_wave(const DeviceConfig &cfg, const Devi
             const uint2 e = make_uint2(qe.x, qe.y);
             const int maxr = (int)ceilf(__uint_as_float(qe.z)), minr = (int)floorf(__uint_as_float(qe.w));
 #pragma unroll
-            for (int k = 0; k < ORBFE_RL_ROWS; k++) {
+            for (int k = 0; k < ROWS; k++) {
                 const int row = r0 + k;
                 const bool in = have && row < r1 && row >= minr && row <= maxr; // rows of the block only: that is the clamp of the band to the image
                 const unsigned long long m = __ballot(in);
                 if (m == 0ull) continue; // uniform
                 const int p = cnt[k] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (in) {
-                    if (p < RL_LDS_CAP) s_ent[k * RL_LDS_CAP + p] = e;
-                    else if (p < cap) rent[(size_t)k * cap + p] = e; // a crowded row: past the LDS list, straight to its place
-                }
+                if (in && p < cap) rent[(size_t)k * cap + p] = e; // the lanes of the ballot write consecutive entries of the row's list
                 cnt[k] += __popcll(m);
             }
         }
@@ -130,11 +127,6 @@ __device__ __forceinline__ void rowlist_wave(const DeviceConfig &cfg, const Devi
     }
     drain();
 #pragma unroll
-    for (int k = 0; k < ORBFE_RL_ROWS; k++) {
-        if (r0 + k >= r1) break;
-        if (lane == 0) rcnt[r0 + k] = cnt[k];
-        const int n = cnt[k] < RL_LDS_CAP ? cnt[k] : RL_LDS_CAP;
-        for (int i = lane; i < n; i += 64) rent[(size_t)k * cap + i] = s_ent[k * RL_LDS_CAP + i];
-    }
+    for (int k = 0; k < ROWS; k++)
+        if (lane == 0 && r0 + k < r1) rcnt[r0 + k] = cnt[k];
 }
-

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void stereo_rowlist_kernel(DeviceConfig cfg, D
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_rl_all[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    rowlist_wave(cfg, buf, blockIdx.y, (int)blockIdx.x * 4 + wave, s_rl_all + wave * RL_LDS_BYTES);
+    rowlist_wave<RL_ROWS_ALONE>(cfg, buf, blockIdx.y, (int)blockIdx.x * 4 + wave, s_rl_all + wave * RL_LDS_BYTES);
 }
 
 __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, DeviceBuffers buf, int n_pairs)
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void hamming_matrix_kernel(const uint8_t *__re
 
 void orbfe_launch_stereo_rowlists(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s)
 {
-    dim3 grid((rowlist_blocks(cfg.height) + 3) / 4, n_pairs);
+    dim3 grid((rowlist_blocks(cfg.height, RL_ROWS_ALONE) + 3) / 4, n_pairs);
     hipLaunchKernelGGL(stereo_rowlist_kernel, grid, dim3(256), 4 * RL_LDS_BYTES, s, cfg, buf);
 }
 
