@@ -1,0 +1,13 @@
+# like ktime.sh with a correctness check first (bench with the oracle spot check): usage ktime_env.sh <name> <pattern> VAR=val
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cp tools/ab/$1.so orbslam2_amd/liborbfe.so
+export $3
+timeout -k 10 120 python3 bench.py --steps 3 --warmup 1 --cpu-pairs 0 --pipelined 0 --small-batch 0 --natural 0 --host-fed 0 > gpurun_out/kte.json 2> gpurun_out/kte.err || { echo "$3: bench with check failed"; tail -2 gpurun_out/kte.err; exit 0; }
+rm -rf gpurun_out/kt_$1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_$1 -- python3 bench.py --steps 6 --warmup 2 --cpu-pairs 0 --pipelined 0 --small-batch 0 --natural 0 --host-fed 0 --no-check > /dev/null 2>&1 || exit 0
+f=$(find gpurun_out/kt_$1 -name "*kernel_stats.csv" | head -1)
+python3 -c "
+import csv,re,sys
+for r in csv.DictReader(open('$f')):
+    if re.search('$2', r['Name']): print('$1 $3', r['Name'].split('(')[0][-32:], r['Calls'], round(float(r['AverageNs'])/1000,1), 'us')"
+rm -rf gpurun_out/kt_$1
