@@ -495,6 +495,11 @@ def compute_stereo_matches(exL: LiteralExtractor, exR: LiteralExtractor, mvKeys,
                 endu = scaleduR0 + F32(L) + F32(w) + F32(1)
                 if iniu < 0 or endu >= pyrR.shape[1]:
                     continue
+                # Q12: where the reference's colRange / rowRange would throw (a window outside the level image; only with
+                # scaleFactor > 1.9) the keypoint stays unmatched
+                cu_, cv_, cr_ = _trunc(scaleduL), _trunc(scaledvL), _trunc(scaleduR0)
+                if cu_ - 5 < 0 or cu_ + 5 >= pyrL.shape[1] or cv_ - 5 < 0 or cv_ + 5 >= pyrL.shape[0] or cr_ - 10 < 0 or cr_ + 10 >= pyrR.shape[1]:
+                    continue
                 for incR in range(-L, L + 1):
                     cr = _trunc(scaleduR0 + F32(incR) - F32(w))
                     IR = [[F32(pyrR[r0 + y, cr + x]) for x in range(2 * w + 1)] for y in range(2 * w + 1)]

@@ -1011,6 +1011,12 @@ int orc_stereo_matches(const orc_extractor *exL, const orc_extractor *exR,
                 const float iniu = scaled_uR0 + (float)L - (float)w;
                 const float endu = scaled_uR0 + (float)L + (float)w + 1;
                 if (iniu < 0 || endu >= (float)exR->lw[lvl]) continue;
+                /* Q12: the reference's guard is short by 2 w on the left (iniu = scaleduR0 + L - w = scaleduR0 is never negative): a right
+                 * band that starts left of the level image (cr - 10 < 0) makes Mat::colRange throw cv::Exception (src/Frame.cc:582,
+                 * CV_Assert(0 <= _colRange.start) in the cv::Mat ROI constructor) and the process ends.  Only reachable when
+                 * 19 / scaleFactor < 10 (a right keypoint one octave finer than the left one, scaleFactor > 1.9); with the reference's
+                 * 1.2 every window is inside.  Contract: such a keypoint stays unmatched (the product's memory-safety guard). */
+                if (cu - 5 < 0 || cu + 5 >= lwL || cv - 5 < 0 || cv + 5 >= exL->lh[lvl] || cr - 10 < 0 || cr + 10 >= lwR) continue;
                 int sad_best = INT_MAX, best_inc = 0;
                 float vdists[11];
                 const int lc = imL[(size_t)cv * lwL + cu];

@@ -273,6 +273,27 @@ def test_stereo_row_list_overflow():
     ctx.close()
 
 
+def test_sad_window_left_of_the_level_image_q12():
+    """Scale factor 2.22: a right keypoint one octave finer than its left partner can lie 19 / 2.22 < 10 px from the left border of
+    the left keypoint's level, so the SAD band (columns cr - 10 ..) starts outside the image.  The reference's guard misses that
+    (iniu = scaleduR0 + L - w is never negative) and cv::Mat::colRange throws; contract Q12: the keypoint stays unmatched, in the
+    oracle and in the product alike (found by tools/soak.py, SOAK_GEOM=1 SOAK_SEED=131000, case 329)."""
+    from orbslam2_amd import api
+    w, h = 451, 278
+    kw = dict(nfeatures=729, ini_th_fast=33, min_th_fast=19, scale_factor=float(np.float32(2.218409776687622)), nlevels=6)
+    left, right = synth.stereo_pair(w, h, seed=131000 + 2000 + 329)
+    fx, bf = 0.7 * w, 0.2 * w
+    ctx = api.Context(width=w, height=h, fx=fx, fy=fx, cx=w / 2, cy=h / 2, bf=bf, **kw)
+    out = ctx.stereo_frame(left, right)
+    exl, exr = O.Extractor(**kw), O.Extractor(**kw)
+    kl, dl = exl.extract(left); kr, dr = exr.extract(right)
+    ur, dp, m = O.stereo_matches(exl, exr, kl, dl, kr, dr, bf, fx)
+    assert m > 100
+    assert np.array_equal(out["kps_left"], kl.astype(api.KP_DTYPE)) and np.array_equal(out["kps_right"], kr.astype(api.KP_DTYPE))
+    assert np.array_equal(out["u_right"], ur) and np.array_equal(out["depth"], dp)
+    ctx.close()
+
+
 def test_stereo_row_lists_longer_than_their_lds_staging():
     """Keypoints inside a 150-row band: the rows' candidate lists hold 100-200 entries -- more than the 64 the row-list waves stage
     in LDS (the rest go straight to the global list), fewer than the lists' capacity -- same matches as the oracle."""
