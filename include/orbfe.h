@@ -26,7 +26,8 @@
  *   ORBFE_PYR_LDS=1    keep cv::resize on the LDS-staged kernel (the path of scale factors
  *                      above ~2) instead of the direct one;
  *   ORBFE_NO_FUSE=1    blur every level in one launch after the pyramid instead of blurring
- *                      level l - 1 inside the launch that resizes it into level l;
+ *                      level l - 1 inside the launch that resizes it into level l and the
+ *                      remaining levels inside the quadtree launch;
  *   ORBFE_HOST_TRACE=1 print the context's geometry, kernel choices and LDS sizes to
  *                      stderr at create time.
  *

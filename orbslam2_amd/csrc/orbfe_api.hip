@@ -1006,11 +1006,12 @@ static void run_chain(orbfe_context *ctx, const uint8_t *d_images, int img0, int
     prof_mark(ctx, group, 1, s);
     const int blurred = orbfe_launch_pyramid(cfg, buf, n_images, ctx->fuse_blur, s);
     prof_mark(ctx, group, 2, s);
-    orbfe_launch_blur(cfg, buf, n_images, blurred, s);
+    const bool blur_in_quadtree = ctx->use_octree3 && ctx->fuse_blur; // the levels still unblurred ride in the quadtree launch
+    if (!blur_in_quadtree) orbfe_launch_blur(cfg, buf, n_images, blurred, s);
     prof_mark(ctx, group, 3, s);
     orbfe_launch_fast(cfg, buf, n_images, ctx->use_octree3, s);
     prof_mark(ctx, group, 4, s);
-    if (ctx->use_octree3) orbfe_launch_octree3(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot3_lds, ctx->ot3_nodes_in_hbm, s);
+    if (ctx->use_octree3) orbfe_launch_octree3(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot3_lds, ctx->ot3_nodes_in_hbm, s, blur_in_quadtree ? blurred : cfg.nlevels);
     else if (ctx->use_octree2) orbfe_launch_octree2(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot2_lds_pts, ctx->ot2_lds, s);
     else orbfe_launch_octree_generic(cfg, buf, n_images, s);
     prof_mark(ctx, group, 5, s);

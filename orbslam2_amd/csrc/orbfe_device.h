@@ -184,7 +184,7 @@ void orbfe_launch_octree2(const DeviceConfig &cfg, const DeviceBuffers &buf, int
 size_t orbfe_octree2_lds_bytes(int max_nodes, int sort_cap, int lds_pts);
 int orbfe_octree2_prepare(size_t lds);
 // orbfe_octree3.hip
-void orbfe_launch_octree3(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, size_t lds, bool nodes_in_hbm, hipStream_t s);
+void orbfe_launch_octree3(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, size_t lds, bool nodes_in_hbm, hipStream_t s, int blur_first_level); // also blurs levels blur_first_level .. nlevels - 1 (pass nlevels for none)
 void orbfe_launch_candidates_gather(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
 size_t orbfe_octree3_node_bytes(int max_nodes, int sort_cap);
 size_t orbfe_octree3_lds_bytes(int max_nodes, int sort_cap, bool nodes_in_hbm);

@@ -23,7 +23,8 @@
 // points of its bucket by replaying their paths.
 // Candidates are never gathered into emission order on this path; orbfe_fetch_candidates runs
 // candidates_gather_kernel on demand (parity tap).
-#include "orbfe_device.h"
+#include "orbfe_common.hpp"
+#include "orbfe_blur_wave.hpp"
 #include <cstdlib>
 
 #define OT3_THREADS 512
@@ -177,15 +178,24 @@ __device__ __forceinline__ void ot3_for_each_point(const int *cell_cnt, const ui
 }
 
 template <bool NODES_IN_HBM>
-__global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, DeviceBuffers buf, int sort_cap, size_t node_bytes)
+__global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, DeviceBuffers buf, int sort_cap, size_t node_bytes, int blur_rows, int blur_t0, int blur_t1)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     __shared__ int s_w[4 * OT3_WAVES];
     __shared__ int s_scal[8];
+    // The first blur_rows rows of the grid are not quadtree workgroups: their eight waves blur tiles [blur_t0, blur_t1) of the image
+    // (the levels no pyramid launch has blurred; describe_kernel is the first reader).  The quadtree workgroups are latency-bound and
+    // leave the chip mostly idle, so those memory-bound waves cost next to nothing here -- their own launch cost 9 us (level 7 of a
+    // 64-pair batch) to 21 us.
+    if ((int)blockIdx.y < blur_rows) {
+        const int u = blur_t0 + (int)blockIdx.y * OT3_WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        if (u < blur_t1) blur_wave(cfg, buf, blockIdx.x, u);
+        return;
+    }
     // longest first: the workgroups of level 0 (largest quota, most split passes) are dispatched before those of level 1, ...; with
     // one or two LDS-filling workgroups per CU the launch then ends about (total work / CUs) after the last level-0 group, instead of
     // every round of (image, all levels) groups waiting for its level-0 member
-    const int img = blockIdx.x, level = blockIdx.y;
+    const int img = blockIdx.x, level = (int)blockIdx.y - blur_rows;
     const LevelInfo &L = cfg.lv[level];
     const int tid = threadIdx.x;
 #ifdef ORBFE_PROFILE_CUTS // tools/octree3_timeline.py (`make cuts` build only): start / end of the first 2048 workgroups and the phase
@@ -676,12 +686,15 @@ __global__ __launch_bounds__(OT3_THREADS) void candidates_gather_kernel(DeviceCo
     }
 }
 
-void orbfe_launch_octree3(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, size_t lds, bool nodes_in_hbm, hipStream_t s)
+void orbfe_launch_octree3(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, size_t lds, bool nodes_in_hbm, hipStream_t s, int blur_first_level)
 {
-    dim3 grid(n_images, cfg.nlevels);
+    // blur of levels blur_first_level .. nlevels - 1 beside the quadtree (nlevels: none)
+    const int t0 = blur_first_level < cfg.nlevels ? cfg.lv[blur_first_level].blur_tile_off : cfg.blur_tiles_total, t1 = cfg.blur_tiles_total;
+    const int blur_rows = (t1 - t0 + OT3_WAVES - 1) / OT3_WAVES;
+    dim3 grid(n_images, blur_rows + cfg.nlevels);
     const size_t node_bytes = orbfe_octree3_node_bytes(cfg.max_nodes, sort_cap);
-    if (nodes_in_hbm) hipLaunchKernelGGL(octree3_kernel<true>, grid, dim3(OT3_THREADS), lds, s, cfg, buf, sort_cap, node_bytes);
-    else hipLaunchKernelGGL(octree3_kernel<false>, grid, dim3(OT3_THREADS), lds, s, cfg, buf, sort_cap, node_bytes);
+    if (nodes_in_hbm) hipLaunchKernelGGL(octree3_kernel<true>, grid, dim3(OT3_THREADS), lds, s, cfg, buf, sort_cap, node_bytes, blur_rows, t0, t1);
+    else hipLaunchKernelGGL(octree3_kernel<false>, grid, dim3(OT3_THREADS), lds, s, cfg, buf, sort_cap, node_bytes, blur_rows, t0, t1);
 }
 
 void orbfe_launch_candidates_gather(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)
