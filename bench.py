@@ -554,7 +554,7 @@ def main():
                 "whole_pipeline": {"alg_bytes_per_pair": B_PAIR, "achieved": B_PAIR * value / world / 1e9,
                                    "frac": B_PAIR * value / world / 1e9 / HBM_PEAK_GBS},
                 "stage_ms_per_step_summed_over_groups": per_launch_ms,
-                "stage_ms_note": "per-stage table from a separate untimed single-chain pass with events at every stage boundary; launch_ms from the timed region; 'pyramid' includes the blur of the levels that are blurred inside the resize launches (0..3 at KITTI geometry), 'blur' is the launch for the remaining levels (ORBFE_NO_FUSE=1 separates them)"}
+                "stage_ms_note": "per-stage table from a separate untimed single-chain pass with events at every stage boundary; launch_ms from the timed region; 'pyramid' includes the blur of the levels that are blurred inside the resize launches (0..6 for a 64-pair batch), 'blur' holds no launch any more: the remaining levels are blurred inside the quadtree launch ('octree'); ORBFE_NO_FUSE=1 separates them all"}
         if dom_alone is not None:
             roof["launch_ms_one_chain"] = dom_alone
             roof["frac_one_chain"] = alg[dom] * P / launches / (dom_alone * 1e-3) / 1e9 / HBM_PEAK_GBS
