@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One-off soak: many random scenes / sizes / thresholds, stereo frame HIP vs oracle, bit for bit.  python3 tools/soak.py [n]
-SOAK_SEED=<int> shifts the case list; SOAK_GEOM=1 also draws the scale factor (1.04-2.3) and the number of levels (1-10)."""
+SOAK_SEED=<int> shifts the case list; SOAK_GEOM=1 also draws the scale factor (1.04-2.3) and the number of levels (1-10); SOAK_PATCH=1 draws half_patch_size 8-18 and the edge
+threshold for every second case."""
 import os
 import sys
 
@@ -44,6 +45,9 @@ for i in range(n):
     kw = dict(nfeatures=nf, ini_th_fast=ini, min_th_fast=mn)
     if os.environ.get("SOAK_GEOM"):  # any scale factor / pyramid depth (the resize kernel choice is per level, from the column table)
         kw.update(scale_factor=float(np.float32(rng.uniform(1.04, 2.3))), nlevels=int(rng.integers(1, 11)))
+    if os.environ.get("SOAK_PATCH") and i % 2:  # other patch geometries: describe_generic_kernel + the row-list launch of its own
+        hp = int(rng.integers(8, 19)); edge = max(19, hp + 4) + int(rng.integers(0, 4))
+        kw.update(half_patch_size=hp, patch_size=2 * hp + 1, edge_threshold=edge)
     try:
         O.Extractor(**kw)
         ctx = api.Context(width=w, height=h, fx=fx, fy=fx, cx=w / 2, cy=h / 2, bf=bf, **kw)
