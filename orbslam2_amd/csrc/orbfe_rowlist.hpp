@@ -19,7 +19,7 @@
 // amplification; issuing them at the start of the wave instead of its end changed nothing (their number, not their latency).  A
 // first LDS kernel (one workgroup per 8-16 rows, LDS atomics, every slot's full arithmetic under a divergent test) took 20-29 us;
 // these waves in a launch of their own 19.5 / 24.4 / 34.5 us at 4 / 8 / 16 rows per wave (7.8 of them launch + first-load
-// latency), riding in describe_kernel's launch 8 / 5 / 4 us (describe 0.1466 / 0.1439 / 0.1425 ms against 0.1385 without lists;
+// latency), riding in describe_kernel's launch 8 / 5 / 4 us (describe 0.1466 / 0.1439 / 0.1425 ms against 0.1385 without lists; 32 rows: 0.146, its 32 counters spill;
 // with the lists staged in LDS before a coalesced copy-out 0.1477: the runs a ballot writes are contiguous enough).
 #define RL_ROWS_FUSED 16 // image rows per wave inside describe_kernel's launch (long waves are free there: only their issue slots count)
 #define RL_ROWS_ALONE 4  // ... and in a launch of its own, which lives on the number of short waves
