@@ -3,7 +3,9 @@
 
     python bench.py --gpus N --steps K --warmup W [--pairs P]
 
-One process per GPU (the driver launches N>1 through torch.distributed.run).  A "step"
+One process per GPU.  The driver launches N>1 through torch.distributed.run; started WITHOUT a launcher (`python bench.py --gpus N`, no
+RANK / WORLD_SIZE in the environment) this process spawns the N ranks itself before anything touches the GPU and relays rank 0's line
+(launch_ranks); a rank count that differs from --gpus is an error on every path, never a silent one-rank result.  A "step"
 is one pass of the hot path (extract left + extract right + ComputeStereoMatches) over
 one batch of P synthetic KITTI-geometry stereo pairs that are already resident in HBM.
 Frame pairs are independent, so ranks shard them with no data-path collective; the only
@@ -328,6 +330,99 @@ def cpu_baseline(n_pairs: int):
     return out
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher environment (the way the driver starts the N = 1 run): this process starts
+    the N ranks itself -- one child per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, exactly what torch.distributed.run
+    would export -- BEFORE anything here touches the GPU (it never does: no torch import, no HIP call), relays rank 0's one JSON
+    line and returns non-zero unless every rank exits 0 and the line says n_gpus == N.  A rank that dies takes the others with it
+    (they would otherwise wait in the rendezvous)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   ORBFE_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    line = {}
+
+    def read0():
+        line["out"] = procs[0].stdout.read()
+    t = threading.Thread(target=read0, daemon=True)
+    t.start()
+    rcs = [None] * n
+    failed = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+                if rcs[r] not in (None, 0) and failed is None:
+                    failed = r
+        if failed is not None:
+            break
+        time.sleep(0.05)
+    if failed is not None:
+        for r, p in enumerate(procs):
+            if p.poll() is None:
+                p.terminate()  # our own children, by handle
+        for p in procs:
+            try:
+                p.wait(15)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        print("bench: rank %d exited with code %d; %d-rank run aborted" % (failed, rcs[failed], n), file=sys.stderr)
+        return rcs[failed] if 0 < rcs[failed] < 256 else 1
+    t.join(30)
+    text = (line.get("out") or b"").decode("utf-8", "replace")
+    rows = [ln for ln in text.splitlines() if ln.strip().startswith("{")]
+    if len(rows) != 1:
+        print("bench: expected ONE JSON line from rank 0, got %d" % len(rows), file=sys.stderr)
+        return 1
+    try:
+        got = json.loads(rows[0]).get("n_gpus")
+    except Exception as e:
+        print("bench: rank 0's line is not JSON (%s)" % e, file=sys.stderr)
+        return 1
+    if got != n:
+        print("bench: rank 0 reports n_gpus %r, --gpus %d" % (got, n), file=sys.stderr)
+        return 1
+    print(rows[0], flush=True)
+    return 0
+
+
+def launcher_selftest(args, D, rank, world, real_stdout):
+    """--launcher-selftest: the distributed plumbing of the N > 1 run and nothing else, over gloo on CPU tensors (tests/test_bench_launcher.py):
+    rendezvous, rank count, parameter + pattern-checksum broadcast, vocabulary broadcast, MAX all-reduce, one line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    cdev = torch.device("cpu")
+    D.init("gloo", None, force=True)
+    joined = D.count_ranks(cdev)
+    if joined != world:
+        raise SystemExit("bench: %d ranks joined the process group, --gpus %d" % (joined, args.gpus))
+    params_blob = D.pack_params(NFEAT, 1.2, NLEVELS, 20, 7, 31, 15, 19, FX, FY, CX, CY, BF)
+    blob = D.broadcast_params(params_blob if rank == 0 else D.pack_params(1, 2.0, 3, 40, 30, 31, 15, 19, 1.0, 1.0, 0.0, 0.0, 1.0), cdev)
+    assert D.unpack_params(blob)[0] == NFEAT
+    voc = D.broadcast_blob(bytes(range(256)) * 16 if rank == 0 else None, cdev)
+    t = D.max_over_ranks(1.0 + rank, cdev)
+    assert t == float(world), t
+    D.barrier()
+    if rank == 0:
+        out = {"selftest": "launcher", "n_gpus": joined, "value": None,
+               "config": {"rccl": {"ranks": joined, "backend": "gloo", "broadcast_bytes": len(params_blob) + len(voc) + 8 + 32,
+                                   "self_launched": os.environ.get("ORBFE_BENCH_SELF_LAUNCHED") == "1"}}}
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
+    D.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -347,7 +442,14 @@ def main():
     ap.add_argument("--rehearse-rccl", action="store_true", help="N = 1: run over a ONE-RANK process group of --backend, so a one-GPU box exercises the very RCCL calls of the multi-GPU path (parameter / vocabulary broadcast, barrier, MAX all-reduce)")
     ap.add_argument("--natural", type=int, default=1, help="1: N = 1 only, also time the step on a photograph at the benchmark geometry -> config.natural_image")
     ap.add_argument("--small-batch", type=int, default=8, help="N = 1 only: also time steps of this many pairs (BASELINE config 4's 8 pairs per GPU) with 4 chains in flight -> config.small_batch; 0 = skip")
+    ap.add_argument("--launcher-selftest", action="store_true", help="CPU-only check of the N > 1 plumbing (self-launch, rendezvous, the one-time broadcasts, rank count, exit codes); prints the line's distributed fields and runs NO compute")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench: --gpus must be >= 1")
+
+    # --gpus N > 1 without a launcher's environment: this process becomes the launcher.  It never touches the GPU.
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
 
     # Rank 0 prints ONE JSON line on stdout and nothing else: RCCL writes its version banner ("RCCL version : ... Librccl path : ...")
     # to STDOUT when the first communicator is created, and other libraries may chat there too, so file descriptor 1 points at stderr
@@ -356,27 +458,42 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    from orbslam2_amd import dist as D
+    rank, local_rank, world = D.world_info()
+    # Never a silent fallback: a launcher that started a different number of ranks than --gpus asks for is an error on every rank
+    # (round-3 verdict: `python3 bench.py --gpus 8` used to report a one-GPU result with n_gpus 1).
+    if world != args.gpus:
+        raise SystemExit("bench: --gpus %d but the launcher environment says WORLD_SIZE=%d (rank %d): refusing to report a %d-rank run as %d GPUs"
+                         % (args.gpus, world, rank, world, args.gpus))
+    if os.environ.get("ORBFE_BENCH_FAIL_RANK") == str(rank):  # test hook: a rank that dies before the rendezvous
+        raise SystemExit(3)
+    if args.launcher_selftest:
+        return launcher_selftest(args, D, rank, world, real_stdout)
+
     import torch
     import torch.distributed as dist
     from orbslam2_amd import api, synth
 
-    from orbslam2_amd import dist as D
-    rank, local_rank, world = D.world_info()
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     # --backend gloo with ORBFE_BENCH_ONE_GPU=1 rehearses the multi-rank path on a one-GPU box (all ranks on device 0,
     # collectives on CPU tensors); the real run is one rank per GPU over RCCL.
     one_gpu = args.backend == "gloo" and os.environ.get("ORBFE_BENCH_ONE_GPU") == "1"
+    if not one_gpu and torch.cuda.device_count() < world:
+        raise SystemExit("bench: %d ranks but only %d GPU(s) visible (one rank per GPU; ORBFE_BENCH_ONE_GPU=1 --backend gloo rehearses on one)"
+                         % (world, torch.cuda.device_count()))
     gpu_index = 0 if one_gpu else local_rank
     torch.cuda.set_device(gpu_index)
     dev = torch.device("cuda", gpu_index)
     cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
     D.init(args.backend, dev, force=args.rehearse_rccl)
+    ranks_joined = D.count_ranks(cdev)  # SUM all-reduce of 1 over the group: what RCCL itself saw
+    if ranks_joined != world:
+        raise SystemExit("bench: %d ranks joined the process group, --gpus %d" % (ranks_joined, args.gpus))
 
     # one-time RCCL broadcast of the extractor parameters + rBRIEF pattern checksum
-    blob = D.broadcast_params(D.pack_params(NFEAT, 1.2, NLEVELS, 20, 7, 31, 15, 19, FX, FY, CX, CY, BF), cdev)
+    params_blob = D.pack_params(NFEAT, 1.2, NLEVELS, 20, 7, 31, 15, 19, FX, FY, CX, CY, BF)
+    blob = D.broadcast_params(params_blob, cdev)
     nf, sf, nl, ini, mn, ps, hps, et, fx, fy, cx, cy, bf = D.unpack_params(blob)
 
     # one-time RCCL broadcast of the vocabulary (fbow file format) from rank 0 into every rank's HBM: the only other
@@ -562,7 +679,7 @@ def main():
                                       "launch with one chain at a time" % (C - 1))
         out = {
             "metric": metric, "value": value, "unit": "frames/s (1 frame = 1 stereo pair)",
-            "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, CP),
+            "n_gpus": ranks_joined, "steps": args.steps, "warmup": max(args.warmup, CP),
             "ms_per_step": step_ms, "higher_is_better": True, "scaling": args.mode,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "Stereo-KITTI00-02 1241x376, 2000 features, 8 levels: extract L+R + ComputeStereoMatches"
@@ -589,6 +706,10 @@ def main():
             out["config"]["strong_scaling"] = strong
         if voc_blob is not None:
             out["config"]["vocabulary_broadcast_bytes"] = len(voc_blob)
+        # what the collectives themselves saw: ranks = SUM all-reduce of 1 over the group (1 and "none" when no group exists)
+        out["config"]["rccl"] = {"ranks": ranks_joined, "backend": args.backend if dist.is_initialized() else "none (single rank, no process group)",
+                                 "broadcast_bytes": (len(params_blob) + (len(voc_blob) + 8 + 32 if voc_blob is not None else 0)) if dist.is_initialized() else 0,
+                                 "self_launched": os.environ.get("ORBFE_BENCH_SELF_LAUNCHED") == "1"}
     for c in ctxs[1:]:
         c.close()
     if rank == 0:

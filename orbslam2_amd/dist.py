@@ -30,6 +30,9 @@ def init(backend: str, device=None, force: bool = False):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        import datetime
+        # a rank that never arrives fails the rendezvous of the others after this long instead of the default half hour
+        kw["timeout"] = datetime.timedelta(seconds=int(os.environ.get("ORBFE_DIST_TIMEOUT_S", "300")))
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world
 
@@ -94,6 +97,15 @@ def max_over_ranks(value: float, device) -> float:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
     return value
+
+
+def count_ranks(device) -> int:
+    """Ranks that actually joined the group: a SUM all-reduce of 1 (1 without a group)."""
+    if dist.is_initialized():
+        t = torch.ones(1, dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t.item())
+    return 1
 
 
 def barrier():
