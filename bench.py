@@ -79,7 +79,7 @@ def traffic_bytes(stage: str, pairs: int, launches: int):
     MI355X_MICROARCH.md prescribes), scaled from the profiled batch to this run's batch; None if not profiled."""
     # (profiles/r03_traffic.json when this round's passes are committed, else the latest earlier round)
     try:
-        path = next(q for q in (os.path.join(ROOT, "profiles", n) for n in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")) if os.path.exists(q))
+        path = next(q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")) if os.path.exists(q))
         t = json.load(open(path))["kernels"][stage]
         per_pair = (2.0 * t["fetch_kb_per_pair"] + t["write_kb_per_pair"]) * 1024.0
         return per_pair * pairs / launches
@@ -87,10 +87,22 @@ def traffic_bytes(stage: str, pairs: int, launches: int):
         return None
 
 
+def whole_step_traffic_per_pair():
+    """Counter bytes (2 * FETCH_SIZE + WRITE_SIZE) * 1024 of every kernel of a step, per pair, from the same committed passes (decimal
+    bytes, to be set against SURVEY's 19 567 078 algorithmic bytes); None if not profiled.  The stereo matcher's descriptor gathers are
+    counted by FETCH_SIZE as whole 64-byte sectors (tools/ubench/fetch_calib.hip), so its share is an upper bound."""
+    try:
+        path = next(q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json")) if os.path.exists(q))
+        ks = json.load(open(path))["kernels"]
+        return sum((2.0 * t["fetch_kb_per_pair"] + t["write_kb_per_pair"]) * 1024.0 for t in ks.values()), os.path.basename(path)
+    except Exception:
+        return None, None
+
+
 def _sq_valu_per_pair():
     """SQ_INSTS_VALU per stereo pair of every kernel of the step, from the committed rocprofv3 counter pass (launches of 64 pairs;
     the pyramid's resize kernel -- with the blur of the level it reads fused in -- runs once per level; the counts file says how often): {kernel name fragment: wave-instructions per pair}."""
-    for name in ("r03_pmc_sq.txt", "r02_pmc_sq.txt", "r01_pmc_sq.txt"):
+    for name in ("r04_pmc_sq.txt", "r03_pmc_sq.txt", "r02_pmc_sq.txt", "r01_pmc_sq.txt"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -158,29 +170,45 @@ def valu_issue(pairs: int, launches: int, launch_ms: float, step_ms: float):
     return None
 
 
-def host_fed(api, torch, dev, host, P, make_ctx, steps=16, lanes_n=4):
-    """PCIe-inclusive rate (never `value`): every step's P pairs start in PINNED host memory and the results (keypoints,
-    descriptors, counts, uRight, depth at device capacity) end there.  serial = upload -> chain -> download on one stream;
-    overlapped = `lanes_n` lanes (fresh contexts, one stream each, step k on lane k % lanes_n), so one lane's copies run beside the
-    others' kernels.  Measured on this link (tools/pcie_rate.py, profiles/r03_pcie.json): 56 GB/s up alone, 55 GB/s down alone, but
-    the two directions at once take the SUM of their times (1.5 ms for a step's 59.7 MB up + 17.7 MB down): the copies bound the
-    rate at ~42.5 k pairs/s, and separate upload / download streams per lane (tried: 27-32 k) only add event hops."""
+def host_fed(api, torch, dev, host, P, make_ctx, steps=48, lanes_n=4):
+    """PCIe-inclusive rate (never `value`): every step's P pairs start in PINNED host memory and the results end there.
+    serial = upload -> chain -> download on one stream; overlapped = `lanes_n` lanes (fresh contexts, one stream each, step k on lane
+    k % lanes_n), so one lane's copies run beside the others' kernels.  On this link the two directions at once take the SUM of their
+    times (tools/pcie_rate.py, profiles/r03_pcie.json: 56 GB/s up alone, 55 GB/s down alone), so the bytes bound the rate.  Round 4:
+    the results come down as ONE packed block (orbfe_fetch_batch_packed: 9 instead of 28 bytes per keypoint, uRight / depth of the
+    left images only; expanded on the host by orbfe_expand_packed, bit-identical) and level 0 is read in place from the upload
+    buffer (no ingest launch).  The block is written by the gather kernel straight into the pinned host block (ORBFE_PACK_DIRECT: posted
+    writes across the link, no copy engine), which runs beside the uploads; the uploads of the lanes then keep the link busy
+    (tools/r04_pcie_trace.sh: ~54 GB/s in steady state), so the rate approaches the upload-only bound of ~60 k pairs/s.  A pass is 48 steps
+    (round 3: 16): pipeline fill and drain (one upload before the first kernel, one chain + download after the last upload, ~2 ms) are
+    inside the timed region and cost a 16-step pass 12 %.  `unpacked` keeps round 3's five copies for comparison; `left_only` drops the
+    right images' keypoints and descriptors as well (nothing outside ComputeStereoMatches reads them)."""
     h_in = torch.from_numpy(host).pin_memory()
 
     class Lane:
-        def __init__(self):
+        def __init__(self, mode):
             self.ctx = make_ctx()
             self.stream = torch.cuda.Stream()
             self.d_in = torch.empty(h_in.shape, dtype=torch.uint8, device=dev)
             cap = self.ctx.capacity
-            self.sizes = [2 * P * cap * 28, 2 * P * cap * 32, 2 * P * 4, 2 * P * cap * 4, 2 * P * cap * 4]
-            self.h_out = [torch.empty(n, dtype=torch.uint8).pin_memory() for n in self.sizes]
+            self.mode = mode
+            if mode == "unpacked":
+                self.sizes = [2 * P * cap * 28, 2 * P * cap * 32, 2 * P * 4, 2 * P * cap * 4, 2 * P * cap * 4]
+                self.h_out = [torch.empty(n, dtype=torch.uint8).pin_memory() for n in self.sizes]
+            else:
+                self.flags = api.PACK_STEREO | api.PACK_DIRECT | (api.PACK_LEFT_ONLY if mode == "left_only" else 0)
+                self.lay = self.ctx.packed_layout(2 * P, self.flags)
+                self.sizes = [int(self.lay.bytes)]
+                self.h_out = [torch.empty(self.lay.bytes, dtype=torch.uint8).pin_memory()]
 
         def step(self):
             with torch.cuda.stream(self.stream):
                 self.d_in.copy_(h_in, non_blocking=True)
                 self.ctx.enqueue_stereo(self.d_in.data_ptr(), P, self.stream.cuda_stream)
-                self.ctx.fetch_batch_async(2 * P, *[h.data_ptr() for h in self.h_out], self.stream.cuda_stream)
+                if self.mode == "unpacked":
+                    self.ctx.fetch_batch_async(2 * P, *[h.data_ptr() for h in self.h_out], self.stream.cuda_stream)
+                else:
+                    self.ctx.fetch_batch_packed(2 * P, self.flags, self.h_out[0].data_ptr(), self.sizes[0], self.stream.cuda_stream)
 
     def run(lanes):
         vals = []
@@ -195,17 +223,30 @@ def host_fed(api, torch, dev, host, P, make_ctx, steps=16, lanes_n=4):
             vals.append(P * steps / (time.perf_counter() - t0))
         return sorted(vals)[1], max(vals)
 
-    lanes = [Lane() for _ in range(lanes_n)]
-    serial, _ = run(lanes[:1])
-    over, over_best = run(lanes)
-    sizes = lanes[0].sizes
-    for l in lanes:
-        l.ctx.close()
-    return {"unit": "frames/s", "serial": serial, "overlapped": over, "overlapped_best_of_3": over_best, "lanes": lanes_n,
-            "bytes_up_per_step": int(h_in.numel()), "bytes_down_per_step": int(sum(sizes)),
-            "note": "pinned host memory in and out; serial = one stream; overlapped = %d lanes (fresh contexts, one stream each); median of 3 passes "
-                    "of %d steps; the link moves a step's up + down bytes in ~1.5 ms whether or not the directions overlap (profiles/r03_pcie.json): "
-                    "~42.5 k pairs/s bound" % (lanes_n, steps)}
+    out = {"unit": "frames/s", "lanes": lanes_n, "bytes_up_per_step": int(h_in.numel())}
+    for mode in ("packed", "unpacked", "left_only"):
+        lanes = [Lane(mode) for _ in range(lanes_n)]
+        serial, _ = run(lanes[:1]) if mode == "packed" else (None, None)
+        over, over_best = run(lanes)
+        down = int(sum(lanes[0].sizes))
+        if mode == "packed":  # the packed block of pair 0 expands to what the unpacked fetch of the same context delivers
+            l0 = lanes[0]
+            blk = l0.h_out[0].numpy()
+            a, b = l0.ctx.expand_packed(blk, l0.lay, 0), l0.ctx.fetch_image(0, stereo=True)
+            same = bool(a["kps"].tobytes() == b["kps"].tobytes() and np.array_equal(a["desc"], b["desc"]) and a["u_right"].tobytes() == b["u_right"].tobytes()
+                        and a["depth"].tobytes() == b["depth"].tobytes())
+            out.update({"serial": serial, "overlapped": over, "overlapped_best_of_3": over_best, "bytes_down_per_step": down, "packed_equals_unpacked": same})
+        else:
+            out[mode] = {"overlapped": over, "bytes_down_per_step": down}
+        for l in lanes:
+            l.ctx.close()
+    up, dn = out["bytes_up_per_step"], out["bytes_down_per_step"]
+    out["copy_bound"] = {"upload_only": P / (up / 56.1e9), "sum_of_both_directions": P / (up / 56.1e9 + dn / 54.8e9),
+                         "note": "pairs/s at the rates measured alone (56.1 GB/s up, 54.8 GB/s down, profiles/r03_pcie.json): the upload alone, and a step's upload + download taking the sum of their times (what two copy-engine transfers in opposite directions do on this link)"}
+    out["note"] = ("pinned host memory in and out; serial = one stream; overlapped = %d lanes (fresh contexts, one stream each); median of 3 passes of %d steps; "
+                   "overlapped / bytes_down_per_step are the PACKED block written by the gather kernel into pinned host memory (round 4), `unpacked` = round 3's five "
+                   "copies, `left_only` = without the right images' keypoints and descriptors" % (lanes_n, steps))
+    return out
 
 
 def small_batch(api, torch, d_images, P8, make_ctx, chains=4, steps=200, repeats=5):
@@ -273,6 +314,178 @@ def natural_scene(api, torch, dev, P, make_ctx, steps=20):
     v = sorted(vals)[len(vals) // 2]
     return {"image": "china_kitti (photograph at 1241x376, tests/natural.py), %d copies per step" % P, "value": v, "ms_per_step": P / v * 1e3, "unit": "frames/s, one chain at a time",
             "fast_nms_candidates_per_image": ncand, "keypoints": int(len(kl)), "stereo_matches": int(m), "equals_oracle": ok}
+
+
+def _median_ms(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts))
+
+
+def secondary_configs(api, torch, dev):
+    """BASELINE.json configs 1, 3, 5 and the reference's own calling pattern (one Frame per call), untimed extras of the N = 1 line
+    (round-3 verdict item 6): per-frame time through the HOST entry points (host buffers in and out, copies included), each checked
+    against the oracle once.  tools/bench_configs.py is the long version (full-size vocabulary, CPU times)."""
+    import ctypes as C
+    from oracle import oracle as O
+    from orbslam2_amd import bow as B, synth
+    from tests import test_bow as TB
+    out = {"unit": "ms per frame, median, host buffers in and out"}
+    # config 1: Mono-TUM1 640x480 / 1000 features: ORBextractor::operator()
+    W1, H1, N1 = 640, 480, 1000
+    ctx = api.Context(width=W1, height=H1, nfeatures=N1, fx=517.3, fy=516.5, cx=318.6, cy=255.3, bf=40.0, max_images=1)
+    img = synth.mono_image(W1, H1, seed=5)
+    k, d = ctx.extract(img)
+    ko, do = O.Extractor(nfeatures=N1).extract(img)
+    out["tum1_extract_ms"] = {"value": _median_ms(lambda: ctx.extract(img), 40), "equals_oracle": bool(np.array_equal(k, ko.astype(api.KP_DTYPE)) and np.array_equal(d, do)),
+                              "config": "Mono-TUM1 640x480, 1000 features: orbfe_extract"}
+    ctx.close()
+    # config 3: Mono-EuRoC 752x480 / 1200 features: extract + fbow transform + 500-keyframe database query + SearchByFboW
+    W3, H3, N3, NKF = 752, 480, 1200, 500
+    ctx = api.Context(width=W3, height=H3, nfeatures=N3, fx=458.654, fy=457.296, cx=367.215, cy=248.375, bf=47.9, max_images=1)
+    ex = O.Extractor(nfeatures=N3)
+    base = [synth.mono_image(W3, H3, seed=900 + i) for i in range(20)]
+    rng = np.random.default_rng(11)
+    kf_kd = []
+    for i in range(NKF):  # 500 keyframes: 20 scenes x 25 noise realisations (each its own keypoints / descriptors / BoW vector)
+        im = base[i % 20]
+        if i >= 20:
+            im = np.clip(im.astype(np.int16) + rng.integers(-3, 4, im.shape, dtype=np.int16), 0, 255).astype(np.uint8)
+        kf_kd.append(ctx.extract(im))
+    blob = B.build_vocabulary(np.concatenate([dd for _, dd in kf_kd[:8]]), k=10, levels=4, seed=3)
+    B.vocab_load(ctx, blob)
+    L, v = TB._oracle_voc(blob)
+    L.orc_detect_reloc_candidates.restype = C.c_int
+    L.orc_detect_reloc_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int]
+    db = B.KeyFrameDB(ctx)
+    kf_bow, kf_fv = [], []
+    for _, dd in kf_kd:
+        w, wt, nd = B.transform(ctx, dd, 4)
+        words, ww, nodes, off, feat = B.maps(w, wt, nd)
+        db.add(words, ww)
+        kf_bow.append((words, ww)); kf_fv.append((nodes, off, feat))
+    q_img = np.clip(base[5].astype(np.int16) + rng.normal(0, 2.0, base[5].shape).round().astype(np.int16), 0, 255).astype(np.uint8)
+    covis_off = np.arange(NKF + 1, dtype=np.int32) * 2
+    covis_idx = np.stack([(np.arange(NKF) + 1) % NKF, (np.arange(NKF) - 1) % NKF], axis=1).astype(np.int32).ravel()
+    kf_off = np.zeros(NKF + 1, np.int32); kf_off[1:] = np.cumsum([len(a) for a, _ in kf_bow])
+    dbw = np.concatenate([a for a, _ in kf_bow]); dbv = np.concatenate([b for _, b in kf_bow])
+    res = {}
+
+    def gpu_chain():
+        qk, qd = ctx.extract(q_img)
+        gw, gwt, gnd = B.transform(ctx, qd, 4)
+        q_words, q_ww, qn, qo, qf = B.maps(gw, gwt, gnd)
+        st = np.zeros(NKF, np.float32)
+        cand = db.detect_reloc_candidates(q_words, q_ww, covis_off, covis_idx, st)
+        kfi = int(cand[0])
+        kfk, kfd = kf_kd[kfi]
+        m, nm = B.search_by_bow(ctx, kf_fv[kfi], np.ones(len(kfd), np.int32), kfd, kfk["angle"].copy(), (qn, qo, qf), qd, qk["angle"].copy(), 0.75, True)
+        res["gpu"] = (cand.tolist(), nm)
+
+    def cpu_chain():
+        qk, qd = ex.extract(q_img)
+        (w, wt, nd), (q_words, q_ww), q_fv = TB._oracle_transform(L, v, qd)
+        st = np.zeros(NKF, np.float32); cand = np.zeros(NKF, np.int32)
+        n = L.orc_detect_reloc_candidates(TB._p(q_words), TB._p(q_ww), len(q_words), NKF, TB._p(kf_off), TB._p(dbw), TB._p(dbv),
+                                          TB._p(covis_off), TB._p(covis_idx), TB._p(st), TB._p(cand), NKF)
+        kfi = int(cand[0])
+        kfk, kfd = kf_kd[kfi]
+        fv = kf_fv[kfi]
+        ref = np.zeros(len(qd), np.int32)
+        nref = L.orc_search_by_bow(TB._p(fv[0]), TB._p(fv[1]), TB._p(fv[2]), len(fv[0]), TB._p(np.ones(len(kfd), np.int32)), TB._p(kfd),
+                                   TB._p(kfk["angle"].copy()), TB._p(q_fv[0]), TB._p(q_fv[1]), TB._p(q_fv[2]), len(q_fv[0]), TB._p(qd),
+                                   TB._p(qk["angle"].copy()), len(qd), 0.75, 1, TB._p(ref))
+        res["cpu"] = (cand[:n].tolist(), nref)
+
+    g3 = _median_ms(gpu_chain, 25)
+    cpu_chain()
+    out["euroc_bow_reloc_ms"] = {"value": g3, "equals_oracle": bool(res["gpu"] == res["cpu"]), "matches": int(res["gpu"][1]), "keyframes": NKF,
+                                 "config": "Mono-EuRoC 752x480, 1200 features: extract + fbow transform + 500-keyframe database query + SearchByFboW (k=10 / L=4 vocabulary trained on these images)"}
+    L.orc_vocab_destroy(v)
+    ctx.close()
+    # config 5: D435i RGB-D 1280x720 / 2500 features: extract + ComputeStereoFromRGBD + SearchByProjection(last frame), per frame and batched
+    W5, H5, N5 = 1280, 720, 2500
+    fx = fy = 911.0; cx, cy, bf = 640.0, 360.0, 45.5
+    ctx = api.Context(width=W5, height=H5, nfeatures=N5, fx=fx, fy=fy, cx=cx, cy=cy, bf=bf, max_images=1)
+    ex = O.Extractor(nfeatures=N5)
+    img1, img2, depth = synth.stereo_pair(W5, H5, seed=321, with_depth=True, bf=bf)
+    f1 = ctx.rgbd_frame(img1, depth)
+    z = f1["depth"]
+    valid = (z > 0).astype(np.int32)
+    pos = np.stack([(f1["kps"]["x"] - cx) * z / fx, (f1["kps"]["y"] - cy) * z / fy, z], axis=1).astype(np.float32)
+    obs = np.ones(len(z), np.int32)
+    T_last = np.concatenate([np.eye(3), np.zeros((3, 1))], axis=1).astype(np.float32)
+    T_cur = T_last.copy(); T_cur[0, 3] = -bf / fx
+    bounds = (0.0, float(W5), 0.0, float(H5))
+    cam = O.Camera(fx, fy, cx, cy, bf, bf / fx)
+    k1o, d1o = ex.extract(img1)
+    r5 = {}
+
+    def gpu5():
+        f2 = ctx.rgbd_frame(img2, depth)
+        view = ctx._view(f2["kps"], f2["u_right"], f2["desc"], bounds, device_slot=0)  # the frame just extracted, matched where it lies in HBM
+        got, n = ctx.search_by_projection_last(view, T_cur, T_last, pos, f1["desc"], valid, obs, f1["kps"]["octave"].copy(),
+                                               f1["kps"]["angle"].copy(), None, 7.0, False, True)
+        r5["g"] = (n, got)
+
+    g5 = _median_ms(gpu5, 25)
+    k2, d2 = ex.extract(img2)
+    ur2, dp2 = O.stereo_from_rgbd(k2, k2, depth, bf)
+    ref, nref = O.search_by_projection_last(O.Grid(k2, *bounds), ur2, d2, ex.scale_factors(), cam, T_cur, T_last, pos, d1o, valid, obs,
+                                            k1o["octave"].copy(), k1o["angle"].copy(), None, 7.0, False, True)
+    out["d435i_rgbd_track_ms"] = {"value": g5, "equals_oracle": bool(r5["g"][0] == nref and np.array_equal(r5["g"][1], ref)), "matches": int(nref),
+                                  "config": "RealSense-D435i RGB-D 1280x720, 2500 features: orbfe_rgbd_frame + SearchByProjection(last frame) on the resident frame"}
+    ctx.close()
+    # the same configuration batched: 32 frames per step through orbfe_enqueue_rgbd (grey + float depth resident in HBM), one chain at a time
+    NB = 32
+    ctx = api.Context(width=W5, height=H5, nfeatures=N5, fx=fx, fy=fy, cx=cx, cy=cy, bf=bf, max_images=NB)
+    gray = np.empty((NB, H5, W5), np.uint8); dep = np.empty((NB, H5, W5), np.float32)
+    gray[0::2], gray[1::2] = img1, img2
+    dep[:] = depth
+    d_gray, d_dep = torch.from_numpy(gray).to(dev), torch.from_numpy(dep).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        ctx.enqueue_rgbd(d_gray.data_ptr(), d_dep.data_ptr(), NB, stream=st)
+    torch.cuda.synchronize()
+    vals = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(10):
+            ctx.enqueue_rgbd(d_gray.data_ptr(), d_dep.data_ptr(), NB, stream=st)
+        torch.cuda.synchronize()
+        vals.append(NB * 10 / (time.perf_counter() - t0))
+    got = ctx.fetch_image(1, stereo=True)
+    okb = bool(got["kps"].tobytes() == k2.astype(api.KP_DTYPE).tobytes() and np.array_equal(got["desc"], d2) and np.array_equal(got["u_right"], ur2) and np.array_equal(got["depth"], dp2))
+    v5 = sorted(vals)[len(vals) // 2]
+    out["d435i_rgbd_batched"] = {"value": v5, "unit": "frames/s", "frames_per_step": NB, "ms_per_step": NB / v5 * 1e3, "equals_oracle": okb,
+                                 "config": "the same camera, 32 frames per step resident in HBM: orbfe_enqueue_rgbd (extract + ComputeStereoFromRGBD in one chain), one chain at a time"}
+    ctx.close()
+    return out
+
+
+def single_frame(api, torch, dev):
+    """The reference's own calling pattern -- ONE Frame per call (src/Tracking.cc:296: Frame(left, right, ...)): the stereo frame of
+    the headline configuration through orbfe_stereo_frame (host images in, host keypoints / descriptors / uRight / depth out), and
+    with the pair already in HBM and the results left there."""
+    from orbslam2_amd import synth
+    left, right = synth.stereo_pair(W, H, seed=1234)
+    ctx = api.Context(width=W, height=H, nfeatures=NFEAT, fx=FX, fy=FY, cx=CX, cy=CY, bf=BF, max_images=2)
+    h2h = _median_ms(lambda: ctx.stereo_frame(left, right), 50, 5)
+    d = torch.from_numpy(np.stack([left, right])).to(dev)
+    torch.cuda.synchronize()
+
+    def resident():
+        ctx.enqueue_stereo(d.data_ptr(), 1)
+        ctx.synchronize()
+    res = _median_ms(resident, 50, 5)
+    ctx.close()
+    return {"stereo_host_to_host_ms": h2h, "stereo_resident_ms": res, "unit": "ms per frame pair, median of 50",
+            "note": "orbfe_stereo_frame (pageable host images in, host results out) / orbfe_enqueue_stereo + synchronise on a pair resident in HBM"}
 
 
 def cpu_baseline(n_pairs: int):
@@ -442,6 +655,7 @@ def main():
     ap.add_argument("--rehearse-rccl", action="store_true", help="N = 1: run over a ONE-RANK process group of --backend, so a one-GPU box exercises the very RCCL calls of the multi-GPU path (parameter / vocabulary broadcast, barrier, MAX all-reduce)")
     ap.add_argument("--natural", type=int, default=1, help="1: N = 1 only, also time the step on a photograph at the benchmark geometry -> config.natural_image")
     ap.add_argument("--small-batch", type=int, default=8, help="N = 1 only: also time steps of this many pairs (BASELINE config 4's 8 pairs per GPU) with 4 chains in flight -> config.small_batch; 0 = skip")
+    ap.add_argument("--secondary", type=int, default=1, help="1: N = 1 only, also time BASELINE configs 1, 3, 5 and the one-Frame-per-call pattern through the host entry points -> config.secondary, config.single_frame")
     ap.add_argument("--launcher-selftest", action="store_true", help="CPU-only check of the N > 1 plumbing (self-launch, rendezvous, the one-time broadcasts, rank count, exit codes); prints the line's distributed fields and runs NO compute")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -672,6 +886,11 @@ def main():
                                    "frac": B_PAIR * value / world / 1e9 / HBM_PEAK_GBS},
                 "stage_ms_per_step_summed_over_groups": per_launch_ms,
                 "stage_ms_note": "per-stage table from a separate untimed single-chain pass with events at every stage boundary; launch_ms from the timed region; 'pyramid' includes the blur of the levels that are blurred inside the resize launches (0..6 for a 64-pair batch), 'blur' holds no launch any more: the remaining levels are blurred inside the quadtree launch ('octree'); ORBFE_NO_FUSE=1 separates them all"}
+        if roof["traffic"]:
+            roof["traffic_ratio"] = roof["traffic"] / roof["alg_bytes_per_launch"]  # counter bytes / algorithmic bytes of the dominant kernel
+        wt, wsrc = whole_step_traffic_per_pair()
+        if wt:
+            roof["whole_pipeline"].update({"traffic_bytes_per_pair": wt, "traffic_ratio": wt / B_PAIR, "traffic_source": "profiles/" + wsrc})
         if dom_alone is not None:
             roof["launch_ms_one_chain"] = dom_alone
             roof["frac_one_chain"] = alg[dom] * P / launches / (dom_alone * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -717,6 +936,12 @@ def main():
             out["config"]["small_batch"] = small_batch(api, torch, d_images, min(args.small_batch, P), make_ctx)
         if world == 1 and args.natural and args.mode == "weak":
             out["config"]["natural_image"] = natural_scene(api, torch, dev, P, make_ctx)
+        if world == 1 and args.secondary and args.mode == "weak":
+            try:
+                out["config"]["secondary"] = secondary_configs(api, torch, dev)
+                out["config"]["single_frame"] = single_frame(api, torch, dev)
+            except Exception as e:  # an extra must not cost the headline its line
+                out["config"]["secondary"] = {"error": repr(e)}
         if world == 1 and args.host_fed:
             out["config"]["host_fed"] = host_fed(api, torch, dev, host, P, make_ctx)
         if world == 1 and args.cpu_pairs > 0:

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ORBFE_ABI_VERSION 4 /* 2: orbfe_frame_view.device_slot_plus1; 3: .keyframe; 4: orbfe_get_camera, orbfe_assign_features_to_grid, orbfe_stereo_batch, orbfe_device_count, orbfe_set_profiling_interval */
+#define ORBFE_ABI_VERSION 5 /* 2: orbfe_frame_view.device_slot_plus1; 3: .keyframe; 4: orbfe_get_camera, orbfe_assign_features_to_grid, orbfe_stereo_batch, orbfe_device_count, orbfe_set_profiling_interval; 5: orbfe_get_packed_layout, orbfe_fetch_batch_packed, orbfe_expand_packed, orbfe_enqueue_rgbd */
 
 enum {
     ORBFE_OK = 0,
@@ -191,7 +191,10 @@ int orbfe_fetch_pyramid(orbfe_context *ctx, int image, int level, int blurred,
  * d_images: device pointer to n_images contiguous 8UC1 images (w*h bytes each, row
  * stride w; stereo pairs as L0,R0,L1,R1,...).  Work is enqueued on `stream`
  * (a hipStream_t; NULL = the context's own stream) and NOT synchronised.  Results
- * stay in context-owned device buffers until fetched. */
+ * stay in context-owned device buffers until fetched.  Round 4: packed 8UC1 input is read IN PLACE as pyramid level 0 by every
+ * stage of the call (no copy into the library's pyramid), so the images must stay valid and unchanged until the call's work on
+ * `stream` has finished (stream order is enough: a copy into the same buffer queued on the same stream is fine).  ORBFE_NO_INPLACE=1
+ * at orbfe_create keeps the round-3 copy (ingest16_kernel); colour / rectified input always goes through ingest. */
 int orbfe_enqueue_extract(orbfe_context *ctx, const uint8_t *d_images, int n_images, void *stream);
 int orbfe_enqueue_stereo(orbfe_context *ctx, const uint8_t *d_images, int n_pairs, void *stream);
 int orbfe_synchronize(orbfe_context *ctx, void *stream);
@@ -214,6 +217,49 @@ int orbfe_fetch_counts(orbfe_context *ctx, int32_t *counts, int n_images);
  * copies overlap other streams' work; any pointer may be NULL.  Synchronise the stream before reading. */
 int orbfe_fetch_batch_async(orbfe_context *ctx, int n_images, orbfe_keypoint *kps, uint8_t *desc, int32_t *counts,
                             float *u_right, float *depth, void *stream);
+
+/* ---- packed results (round 4): the same batch in ONE device-to-host copy of about two thirds the bytes ----
+ * A cv::KeyPoint's pt, size, octave and class_id are functions of (x, y on its level, octave): size = scaledPatchSize
+ * (src/ORBextractor.cc:838), pt *= mvScaleFactor[level] (:909-915), and the octave follows from the per-level counts because a
+ * frame's keypoints are stored octave by octave (:866-917).  The block carries per keypoint x | y << 16 on its level (4 B), the
+ * angle (4 B) and the FAST score (1 B) -- 9 bytes instead of 28 -- plus per image the count and the per-level counts, the 32-byte
+ * descriptors, and with ORBFE_PACK_STEREO uRight / depth of the LEFT images only (orbfe_fetch_batch_async also moves the unused
+ * right-image slots).  ORBFE_PACK_LEFT_ONLY drops the right images' keypoints and descriptors too (nothing outside
+ * ComputeStereoMatches, src/Frame.cc:464-642, reads mvKeysRight / mDescriptorsRight).  Arrays are [out image][capacity] at the byte
+ * offsets of orbfe_packed_layout (64-byte aligned); out image o is image slot o, or slot 2 o with LEFT_ONLY. */
+enum { ORBFE_PACK_STEREO = 1, ORBFE_PACK_LEFT_ONLY = 2,
+       /* host_block is pinned host memory that the device addresses at the same pointer (hipHostMalloc / hipHostRegister; checked):
+        * the gather kernel stores the block across the link itself and NO copy is queued -- a kernel's stores run beside an upload,
+        * which two copy-engine transfers in opposite directions do not on the measured link (profiles/r04_pcie.json) */
+       ORBFE_PACK_DIRECT = 4 };
+typedef struct orbfe_packed_layout {
+    int32_t n_images_out, capacity, nlevels, n_pairs, flags, reserved;
+    size_t counts_off;       /* int32 [n_images_out] */
+    size_t level_counts_off; /* int32 [n_images_out][nlevels]: keypoints per octave */
+    size_t xy_off;           /* uint32 [n_images_out][capacity]: x | y << 16, level-image pixels */
+    size_t angle_off;        /* float [n_images_out][capacity] */
+    size_t response_off;     /* uint8 [n_images_out][capacity]: FAST score (cv::KeyPoint::response as an integer) */
+    size_t desc_off;         /* uint8 [n_images_out][capacity][32] */
+    size_t u_right_off;      /* float [n_pairs][capacity] (ORBFE_PACK_STEREO), pair p = image slots 2 p, 2 p + 1 */
+    size_t depth_off;        /* float [n_pairs][capacity] */
+    size_t bytes;            /* size of the block */
+} orbfe_packed_layout;
+int orbfe_get_packed_layout(const orbfe_context *ctx, int n_images, int flags, orbfe_packed_layout *out);
+/* Gathers the latest batched call's results for image slots 0 .. n_images - 1 into the block (one small kernel on `stream`) and
+ * copies it to host_block (>= layout.bytes; pinned memory for an asynchronous copy).  Does not wait; synchronise the stream. */
+int orbfe_fetch_batch_packed(orbfe_context *ctx, int n_images, int flags, void *host_block, size_t host_bytes, void *stream);
+/* Host-only: the cv::KeyPoint records of out image `out_image` of a fetched block, bit-identical to what orbfe_fetch_batch_async
+ * delivers (the reference's own float operations: one product per coordinate).  Descriptors / uRight / depth are read in place
+ * at the layout's offsets.  *n = keypoint count. */
+int orbfe_expand_packed(const orbfe_context *ctx, const void *host_block, const orbfe_packed_layout *layout, int out_image,
+                        orbfe_keypoint *kps, int cap, int *n);
+/* N RGB-D frames in one chain (BASELINE.json config 5 batched; multi-camera RGB-D, CMakeLists.txt:145-146): extraction of the
+ * n_images grey device images + Frame::ComputeStereoFromRGBD (src/Frame.cc:645-666) for every slot.  d_depth: n_images depth maps
+ * packed one after the other (w*h elements each), float metres or, depth_is_u16 != 0, raw uint16 scaled by depth_map_factor
+ * (Tracking's inverted mDepthMapFactor, src/Tracking.cc:151-155,323-324).  Results as after orbfe_enqueue_extract, plus uRight /
+ * depth for every image slot. */
+int orbfe_enqueue_rgbd(orbfe_context *ctx, const uint8_t *d_gray, const void *d_depth, int depth_is_u16, float depth_map_factor,
+                       int n_images, void *stream);
 /* Device pointers to the result buffers (for consumers that stay on the GPU):
  * keypoints [max_images][capacity], descriptors [max_images][capacity][32],
  * counts [max_images], u_right/depth [max_images][capacity]. */

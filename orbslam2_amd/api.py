@@ -34,6 +34,7 @@ EXPORTS = [
     "orbfe_pose_optimization", "orbfe_pose_optimization_batch", "orbfe_enqueue_pose_optimization", "orbfe_set_input_format", "orbfe_fetch_batch_async", "orbfe_set_rectification", "orbfe_set_distortion", "orbfe_undistort_keypoints", "orbfe_fetch_keys_un", "orbfe_image_bounds",
     "orbfe_png_last_error", "orbfe_png_info", "orbfe_png_decode", "orbfe_png_decode_batch",
     "orbfe_get_camera", "orbfe_assign_features_to_grid", "orbfe_set_profiling_interval", "orbfe_stereo_batch", "orbfe_device_count", "orbfe_vocab_bytes",
+    "orbfe_get_packed_layout", "orbfe_fetch_batch_packed", "orbfe_expand_packed", "orbfe_enqueue_rgbd",
 ]
 NUM_STAGES = 8
 STAGE_NAMES = ["ingest", "pyramid", "blur", "fast", "octree", "describe", "stereo_match", "stereo_median"]  # orbfe_stage_name()
@@ -53,6 +54,15 @@ class FrameView(C.Structure):
                 ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
                 ("device_slot_plus1", C.c_int32), ("keyframe", C.c_int32)]
 
+
+class PackedLayout(C.Structure):
+    """orbfe_packed_layout (include/orbfe.h): byte offsets of the arrays inside a packed result block."""
+    _fields_ = [("n_images_out", C.c_int32), ("capacity", C.c_int32), ("nlevels", C.c_int32), ("n_pairs", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32),
+                ("counts_off", C.c_size_t), ("level_counts_off", C.c_size_t), ("xy_off", C.c_size_t), ("angle_off", C.c_size_t),
+                ("response_off", C.c_size_t), ("desc_off", C.c_size_t), ("u_right_off", C.c_size_t), ("depth_off", C.c_size_t), ("bytes", C.c_size_t)]
+
+
+PACK_STEREO, PACK_LEFT_ONLY, PACK_DIRECT = 1, 2, 4
 
 TP_DTYPE = np.dtype([("in_view", "<i4"), ("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("level", "<i4"), ("view_cos", "<f4")])
 
@@ -149,6 +159,14 @@ def load():
     L.orbfe_image_bounds.argtypes = [vp, vp]
     L.orbfe_fetch_batch_async.restype = C.c_int
     L.orbfe_fetch_batch_async.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.orbfe_get_packed_layout.restype = C.c_int
+    L.orbfe_get_packed_layout.argtypes = [vp, C.c_int, C.c_int, C.POINTER(PackedLayout)]
+    L.orbfe_fetch_batch_packed.restype = C.c_int
+    L.orbfe_fetch_batch_packed.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t, vp]
+    L.orbfe_expand_packed.restype = C.c_int
+    L.orbfe_expand_packed.argtypes = [vp, vp, C.POINTER(PackedLayout), C.c_int, vp, C.c_int, ip]
+    L.orbfe_enqueue_rgbd.restype = C.c_int
+    L.orbfe_enqueue_rgbd.argtypes = [vp, vp, vp, C.c_int, C.c_float, C.c_int, vp]
     L.orbfe_set_rectification.restype = C.c_int
     L.orbfe_set_rectification.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int]
     L.orbfe_set_input_format.restype = C.c_int
@@ -335,6 +353,40 @@ class Context:
         """Raw-pointer form (pinned host buffers owned by the caller); see include/orbfe.h."""
         self._check(self.L.orbfe_fetch_batch_async(self.h, n_images, C.c_void_p(kps_ptr), C.c_void_p(desc_ptr), C.c_void_p(counts_ptr),
                                                    C.c_void_p(u_right_ptr), C.c_void_p(depth_ptr), C.c_void_p(stream)))
+
+    def packed_layout(self, n_images, flags=0):
+        lay = PackedLayout()
+        self._check(self.L.orbfe_get_packed_layout(self.h, n_images, flags, C.byref(lay)))
+        return lay
+
+    def fetch_batch_packed(self, n_images, flags, host_ptr, host_bytes, stream=0):
+        """Raw-pointer form: one small gather kernel + ONE device-to-host copy of the packed block (include/orbfe.h)."""
+        self._check(self.L.orbfe_fetch_batch_packed(self.h, n_images, flags, C.c_void_p(host_ptr), host_bytes, C.c_void_p(stream)))
+
+    def expand_packed(self, block, lay, out_image):
+        """cv::KeyPoint records (+ views of descriptors / uRight / depth) of one out image of a fetched block (numpy uint8 array)."""
+        k = np.zeros(lay.capacity, KP_DTYPE)
+        n = C.c_int()
+        self._check(self.L.orbfe_expand_packed(self.h, _p(block), C.byref(lay), out_image, _p(k), lay.capacity, C.byref(n)))
+        m, cap = n.value, lay.capacity
+        out = dict(kps=k[:m].copy(), desc=block[lay.desc_off + out_image * cap * 32: lay.desc_off + (out_image * cap + m) * 32].reshape(m, 32).copy())
+        slot = out_image * (2 if lay.flags & PACK_LEFT_ONLY else 1)
+        if (lay.flags & PACK_STEREO) and slot % 2 == 0:
+            pr = slot // 2
+            out["u_right"] = block[lay.u_right_off + pr * cap * 4: lay.u_right_off + (pr * cap + m) * 4].view(np.float32).copy()
+            out["depth"] = block[lay.depth_off + pr * cap * 4: lay.depth_off + (pr * cap + m) * 4].view(np.float32).copy()
+        return out
+
+    def fetch_packed(self, n_images, flags=0, stream=0):
+        """Blocking convenience for tests: (block, layout) of the latest batched call's results."""
+        lay = self.packed_layout(n_images, flags)
+        block = np.zeros(lay.bytes, np.uint8)
+        self.fetch_batch_packed(n_images, flags, block.ctypes.data, lay.bytes, stream)
+        self.synchronize(stream)
+        return block, lay
+
+    def enqueue_rgbd(self, gray_ptr, depth_ptr, n_images, depth_is_u16=False, depth_map_factor=1.0, stream=0):
+        self._check(self.L.orbfe_enqueue_rgbd(self.h, C.c_void_p(gray_ptr), C.c_void_p(depth_ptr), 1 if depth_is_u16 else 0, depth_map_factor, n_images, C.c_void_p(stream)))
 
     def fetch_counts(self, n_images):
         c = np.zeros(n_images, np.int32)

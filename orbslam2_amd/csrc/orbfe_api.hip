@@ -35,6 +35,9 @@ struct orbfe_context {
     uint8_t *h_in = nullptr;      // [min(max_images,2)][w*h]
     float *h_depth_in = nullptr;  // [w*h]
     uint8_t *h_out = nullptr;     // see HostOut
+    const void *pack_direct_ok = nullptr; // last host block verified for ORBFE_PACK_DIRECT
+    uint8_t *d_pack = nullptr;    // device staging of orbfe_fetch_batch_packed (lazily allocated for max_images)
+    size_t d_pack_bytes = 0;
     uint8_t *d_ham = nullptr;     // scratch for orbfe_hamming_matrix
     void *d_und = nullptr;        // scratch for the undistortion entry points
     size_t d_und_bytes = 0;
@@ -45,6 +48,11 @@ struct orbfe_context {
     unsigned slot_cnt_epoch = ~0u;
     bool use_octree2 = false; // point-parallel quadtree (all levels have <= 4 roots and the LDS budget fits)
     bool fuse_blur = true;    // blur level l - 1 in the launch that resizes it into level l (ORBFE_NO_FUSE=1: separate launches)
+    // Level 0 read in place from the caller's packed CV_8UC1 images (no ingest launch, no copy): possible when level 1 is resized
+    // by the LDS-free kernel and nothing stages level 0 through pyr_tail_kernel; ORBFE_NO_INPLACE=1 keeps the copy (A/B, tests).
+    // Colour / rectified input always goes through ingest (it computes level 0).
+    bool inplace_ok = false;
+    const uint8_t *last_src = nullptr; // images of the latest enqueue when it ran in place (orbfe_fetch_pyramid's level 0), else null
     bool use_octree3 = false; // bucket-pyramid quadtree (orbfe_octree3.hip); preferred when its limits hold
     size_t ot3_lds = 0;
     bool ot3_nodes_in_hbm = false; // node tables of the bucket-pyramid quadtree in HBM scratch (large per-level quotas)
@@ -825,6 +833,13 @@ try {
         }
         b.mom_tab = d_mt;
     }
+    {
+        const char *ni = getenv("ORBFE_NO_INPLACE");
+        const DeviceConfig &cc = ctx->cfg;
+        ctx->inplace_ok = !(ni && ni[0] == '1') && cc.nlevels >= 2 && cc.lv[1].rs_direct && cc.tail_first != 1 && p.width >= 16 && p.height >= 8;
+        if (getenv("ORBFE_HOST_TRACE")) fprintf(stderr, "orbfe: level 0 of packed grey input: %s\n", ctx->inplace_ok ? "read in place (no ingest launch)" : "copied by ingest16_kernel");
+        b.lv0 = b.pyr + cc.lv[0].pyr_off; b.lv0_stride = cc.pyr_bytes; b.lv0_pitch = cc.lv[0].pitch; b.lv0_packed = 0;
+    }
     Z(b.kp_cnt, sizeof(int) * B);
     Z(b.sel_cnt, sizeof(int) * B * c.nlevels);
     Z(b.status, sizeof(int) * B);
@@ -854,6 +869,7 @@ extern "C" void orbfe_destroy(orbfe_context *ctx)
     if (ctx->h_depth_in) hipHostFree(ctx->h_depth_in);
     if (ctx->h_out) hipHostFree(ctx->h_out);
     if (ctx->d_ham) hipFree(ctx->d_ham);
+    if (ctx->d_pack) hipFree(ctx->d_pack);
     for (int sd = 0; sd < 2; sd++) { if (ctx->cfg.rm_xy[sd]) hipFree((void *)ctx->cfg.rm_xy[sd]); if (ctx->cfg.rm_a[sd]) hipFree((void *)ctx->cfg.rm_a[sd]); }
     if (ctx->d_und) hipFree(ctx->d_und);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -980,6 +996,7 @@ static DeviceBuffers shift_buffers(const DeviceBuffers &b, const DeviceConfig &c
     DeviceBuffers o = b;
     const size_t i = (size_t)img0;
     o.pyr += i * c.pyr_bytes; o.blur += i * c.blur_bytes;
+    o.lv0 = o.pyr + c.lv[0].pyr_off; o.lv0_stride = c.pyr_bytes; o.lv0_pitch = c.lv[0].pitch; o.lv0_packed = 0;
     o.cell_cnt += i * c.cells_total; o.cell_base += i * c.cells_total;
     o.cell_xy += i * c.cells_total * c.cell_cap; o.cell_sc += i * c.cells_total * c.cell_cap;
     o.cand_xy += i * c.cand_total; o.cand_sc += i * c.cand_total; o.cand_sc2 += i * c.cand_total;
@@ -999,10 +1016,14 @@ static DeviceBuffers shift_buffers(const DeviceBuffers &b, const DeviceConfig &c
 static void run_chain(orbfe_context *ctx, const uint8_t *d_images, int img0, int n_images, int n_pairs, hipStream_t s, int group)
 {
     const DeviceConfig &cfg = ctx->cfg;
-    const DeviceBuffers buf = shift_buffers(ctx->buf, cfg, img0);
+    DeviceBuffers buf = shift_buffers(ctx->buf, cfg, img0);
     const uint8_t *src = d_images + (size_t)img0 * cfg.in_image_bytes;
     prof_mark(ctx, group, 0, s);
-    orbfe_launch_ingest(cfg, buf, src, n_images, s);
+    if (ctx->inplace_ok && cfg.in_cn == 1 && !cfg.rm_on) { // level 0 = the caller's images (the first pyramid launch clears the status words)
+        buf.lv0 = src; buf.lv0_stride = cfg.in_image_bytes; buf.lv0_pitch = cfg.width; buf.lv0_packed = 1;
+    } else {
+        orbfe_launch_ingest(cfg, buf, src, n_images, s);
+    }
     prof_mark(ctx, group, 1, s);
     const int blurred = orbfe_launch_pyramid(cfg, buf, n_images, ctx->fuse_blur, s);
     prof_mark(ctx, group, 2, s);
@@ -1053,6 +1074,7 @@ static int enqueue_batch(orbfe_context *ctx, const uint8_t *d_images, int n_unit
         }
     }
     HIP_TRY(ctx, hipGetLastError());
+    ctx->last_src = (ctx->inplace_ok && ctx->cfg.in_cn == 1 && !ctx->cfg.rm_on) ? d_images : nullptr;
     ctx->last_images = n_images;
     ctx->epoch++;
     ctx->prof_groups = G;
@@ -1282,6 +1304,113 @@ try {
     if (depth) HIP_TRY(ctx, hipMemcpyAsync(depth, ctx->buf.depth, sizeof(float) * n, hipMemcpyDeviceToHost, s));
     return ORBFE_OK;
 } ORBFE_CATCH(ctx)
+
+// ---- packed result block (include/orbfe.h: orbfe_packed_layout) ----
+static int packed_layout(const orbfe_context *ctx, int n_images, int flags, orbfe_packed_layout *o)
+{
+    if (!ctx || !o || n_images < 1 || n_images > ctx->params.max_images || (flags & ~(ORBFE_PACK_STEREO | ORBFE_PACK_LEFT_ONLY | ORBFE_PACK_DIRECT)))
+        return ORBFE_ERR_INVALID;
+    if ((flags & (ORBFE_PACK_STEREO | ORBFE_PACK_LEFT_ONLY)) && (n_images & 1)) return ORBFE_ERR_INVALID; // pairs L0 R0 L1 R1 ...
+    const size_t cap = (size_t)ctx->cfg.sel_total, nl = (size_t)ctx->cfg.nlevels;
+    const size_t n_out = (flags & ORBFE_PACK_LEFT_ONLY) ? (size_t)n_images / 2 : (size_t)n_images;
+    const size_t n_pairs = (flags & ORBFE_PACK_STEREO) ? (size_t)n_images / 2 : 0;
+    auto up = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    memset(o, 0, sizeof(*o));
+    o->n_images_out = (int32_t)n_out; o->capacity = (int32_t)cap; o->nlevels = (int32_t)nl; o->n_pairs = (int32_t)n_pairs; o->flags = flags;
+    size_t off = 0;
+    o->counts_off = off; off = up(off + 4 * n_out);
+    o->level_counts_off = off; off = up(off + 4 * n_out * nl);
+    o->xy_off = off; off = up(off + 4 * n_out * cap);
+    o->angle_off = off; off = up(off + 4 * n_out * cap);
+    o->response_off = off; off = up(off + n_out * cap);
+    o->desc_off = off; off = up(off + 32 * n_out * cap);
+    o->u_right_off = off; off = up(off + 4 * n_pairs * cap);
+    o->depth_off = off; off = up(off + 4 * n_pairs * cap);
+    o->bytes = off;
+    return ORBFE_OK;
+}
+
+extern "C" int orbfe_get_packed_layout(const orbfe_context *ctx, int n_images, int flags, orbfe_packed_layout *out)
+try {
+    return packed_layout(ctx, n_images, flags, out);
+} ORBFE_CATCH(nullptr)
+
+extern "C" int orbfe_fetch_batch_packed(orbfe_context *ctx, int n_images, int flags, void *host_block, size_t host_bytes, void *stream)
+try {
+    ORBFE_ENTRY(ctx);
+    orbfe_packed_layout lay;
+    if (packed_layout(ctx, n_images, flags, &lay) != ORBFE_OK || !host_block) return fail(ctx, ORBFE_ERR_INVALID, "bad argument");
+    if (n_images > ctx->last_images) return fail(ctx, ORBFE_ERR_INVALID, "the latest extraction call filled %d image slots, %d asked for", ctx->last_images, n_images);
+    if (host_bytes < lay.bytes) return fail(ctx, ORBFE_ERR_CAPACITY, "packed block needs %zu bytes, caller offers %zu", lay.bytes, host_bytes);
+    HIP_TRY(ctx, hipSetDevice(ctx->params.device));
+    PackedOffsets po = {lay.counts_off, lay.level_counts_off, lay.xy_off, lay.angle_off, lay.response_off, lay.desc_off, lay.u_right_off, lay.depth_off};
+    if (flags & ORBFE_PACK_DIRECT) {
+        // the caller's block is pinned host memory mapped into this device's address space: the gather kernel stores into it
+        // across the link itself (posted writes), so no copy engine is involved -- on the measured link an upload and a download
+        // queued on the copy engines take the SUM of their times, while a kernel's stores run beside an upload
+        if (host_block != ctx->pack_direct_ok) {
+            hipPointerAttribute_t at;
+            void *dp = nullptr;
+            if (hipPointerGetAttributes(&at, host_block) != hipSuccess || at.type != hipMemoryTypeHost || hipHostGetDevicePointer(&dp, host_block, 0) != hipSuccess || dp != host_block) {
+                (void)hipGetLastError();
+                return fail(ctx, ORBFE_ERR_INVALID, "ORBFE_PACK_DIRECT needs pinned host memory that the device addresses at the same pointer (hipHostMalloc / hipHostRegister)");
+            }
+            ctx->pack_direct_ok = host_block;
+        }
+        orbfe_launch_pack_results(ctx->cfg, ctx->buf, (uint8_t *)host_block, po, lay.n_images_out, (flags & ORBFE_PACK_LEFT_ONLY) ? 2 : 1, (flags & ORBFE_PACK_STEREO) != 0, pick_stream(ctx, stream));
+        HIP_TRY(ctx, hipGetLastError());
+        return ORBFE_OK;
+    }
+    if (ctx->d_pack_bytes < lay.bytes) { // sized once for the largest block this context can be asked for
+        orbfe_packed_layout mx;
+        packed_layout(ctx, ctx->params.max_images, 0, &mx); // every image slot, plus uRight / depth of half of them
+        const size_t want = mx.bytes + 2 * (((size_t)4 * ((size_t)ctx->params.max_images / 2 + 1) * (size_t)ctx->cfg.sel_total + 63) & ~(size_t)63);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_pack) (void)hipFree(ctx->d_pack);
+        ctx->d_pack = nullptr; ctx->d_pack_bytes = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_pack, want));
+        ctx->d_pack_bytes = want;
+    }
+    hipStream_t s = pick_stream(ctx, stream);
+    orbfe_launch_pack_results(ctx->cfg, ctx->buf, ctx->d_pack, po, lay.n_images_out, (flags & ORBFE_PACK_LEFT_ONLY) ? 2 : 1, (flags & ORBFE_PACK_STEREO) != 0, s);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(host_block, ctx->d_pack, lay.bytes, hipMemcpyDeviceToHost, s));
+    return ORBFE_OK;
+} ORBFE_CATCH(ctx)
+
+// Host side of the packed record: cv::KeyPoint from (level x, level y, octave, score, angle) with the operations of
+// src/ORBextractor.cc:838 (size = scaledPatchSize, an int stored as float), :909-915 (pt *= mvScaleFactor[level] for level != 0;
+// one IEEE float product each, as describe_kernel's __fmul_rn), cv::KeyPoint's response = (float)score (cv::FAST, :803-808),
+// class_id = -1.  Pure host code: no device call, no lock.
+extern "C" int orbfe_expand_packed(const orbfe_context *ctx, const void *host_block, const orbfe_packed_layout *lay, int out_image,
+                                   orbfe_keypoint *kps, int cap, int *n)
+try {
+    if (!ctx || !host_block || !lay || !n || out_image < 0 || out_image >= lay->n_images_out || lay->capacity != ctx->cfg.sel_total || lay->nlevels != ctx->cfg.nlevels)
+        return ORBFE_ERR_INVALID;
+    const uint8_t *b = (const uint8_t *)host_block;
+    const int cnt = ((const int32_t *)(b + lay->counts_off))[out_image];
+    *n = cnt;
+    if (cnt < 0 || cnt > lay->capacity) return ORBFE_ERR_INVALID;
+    if (cnt > cap) return ORBFE_ERR_CAPACITY;
+    if (cnt > 0 && !kps) return ORBFE_ERR_INVALID;
+    const int32_t *lc = (const int32_t *)(b + lay->level_counts_off) + (size_t)out_image * lay->nlevels;
+    const uint32_t *xy = (const uint32_t *)(b + lay->xy_off) + (size_t)out_image * lay->capacity;
+    const float *ang = (const float *)(b + lay->angle_off) + (size_t)out_image * lay->capacity;
+    const uint8_t *rs = b + lay->response_off + (size_t)out_image * lay->capacity;
+    int j = 0;
+    for (int l = 0; l < lay->nlevels && j < cnt; l++) {
+        const float scale = ctx->scale[l], size = (float)ctx->cfg.lv[l].scaled_patch;
+        int c = lc[l];
+        if (c < 0 || j + c > cnt) return ORBFE_ERR_INVALID;
+        for (; c > 0; c--, j++) {
+            float px = (float)(xy[j] & 0xffffu), py = (float)(xy[j] >> 16);
+            if (l != 0) { px = px * scale; py = py * scale; }
+            orbfe_keypoint &k = kps[j];
+            k.x = px; k.y = py; k.size = size; k.angle = ang[j]; k.response = (float)rs[j]; k.octave = l; k.class_id = -1;
+        }
+    }
+    return j == cnt ? ORBFE_OK : ORBFE_ERR_INVALID;
+} ORBFE_CATCH(nullptr)
 
 extern "C" int orbfe_fetch_image(orbfe_context *ctx, int image, orbfe_keypoint *kps, uint8_t *desc,
                                  float *u_right, float *depth, int cap, int *n)
@@ -1551,6 +1680,23 @@ try {
     return rgbd_frame_impl(ctx, gray, depth_img, sizeof(uint16_t), depth_map_factor, w, h, gray_stride, depth_stride, kps, desc, n, u_right, depth, cap);
 } ORBFE_CATCH(ctx)
 
+// N RGB-D frames in one chain (BASELINE config 5 batched; the reference builds a multi-camera RGB-D runner, CMakeLists.txt:145-146):
+// extraction of the N grey images, then Frame::ComputeStereoFromRGBD (src/Frame.cc:645-666) for every image slot in one launch.
+extern "C" int orbfe_enqueue_rgbd(orbfe_context *ctx, const uint8_t *d_gray, const void *d_depth, int depth_is_u16, float depth_map_factor,
+                                  int n_images, void *stream)
+try {
+    ORBFE_ENTRY(ctx);
+    if (!ctx || !d_gray || !d_depth) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    if (n_images < 1 || n_images > ctx->params.max_images) return fail(ctx, ORBFE_ERR_CAPACITY, "n_images %d outside [1, %d]", n_images, ctx->params.max_images);
+    if (ctx->cfg.rm_on) return fail(ctx, ORBFE_ERR_UNSUPPORTED, "RGB-D frames with rectification maps are not supported (the depth map would need the same warp)");
+    const int rc = enqueue_batch(ctx, d_gray, n_images, 1, stream);
+    if (rc != ORBFE_OK) return rc;
+    orbfe_launch_rgbd_batch(ctx->cfg, ctx->buf, d_depth, depth_is_u16 != 0, depth_is_u16 ? depth_map_factor : 1.0f, n_images, pick_stream(ctx, stream));
+    HIP_TRY(ctx, hipGetLastError());
+    if (ctx->latest_foreign) HIP_TRY(ctx, hipEventRecord(ctx->ev_latest, pick_stream(ctx, stream))); // "the latest call" now ends after the depth kernel
+    return ORBFE_OK;
+} ORBFE_CATCH(ctx)
+
 extern "C" int orbfe_fetch_pyramid(orbfe_context *ctx, int image, int level, int blurred, uint8_t *dst, size_t dst_stride)
 try {
     ORBFE_ENTRY(ctx);
@@ -1568,6 +1714,10 @@ try {
                 const size_t off = ((size_t)(y >> 2) * L.blur_tx + (x >> 5)) * 128 + (size_t)((x & 31) >> 2) * 16 + (size_t)(y & 3) * 4;
                 memcpy(dst + (size_t)y * dst_stride + x, t.data() + off, (size_t)std::min(4, L.w - x));
             }
+        return ORBFE_OK;
+    }
+    if (level == 0 && !blurred && ctx->last_src) { // read in place by the latest call: level 0 IS the caller's image (which must still be there)
+        HIP_TRY(ctx, hipMemcpy2D(dst, dst_stride, ctx->last_src + (size_t)image * ctx->cfg.in_image_bytes, (size_t)L.w, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost));
         return ORBFE_OK;
     }
     const uint8_t *src = ctx->buf.pyr + (size_t)image * ctx->cfg.pyr_bytes + L.pyr_off;

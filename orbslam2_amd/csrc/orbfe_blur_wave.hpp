@@ -15,21 +15,11 @@
 // ---------------------------------------------------------------------------
 #define BL_ROWS ORBFE_BLUR_ROWS // rows per wave (a multiple of 4): 6 / BL_ROWS of the rows are loaded (and row-filtered) twice; 32 beats 16 by 4 us now that the kernel is memory-bound (no difference while it was issue-bound); 48 / 64: + 3 / + 9 us (too few waves)
 #define BL_COLS 256 // per wave: 64 lanes x 4 px
-// tile u of the flattened (level, row band, 256-column strip) list, by one wave
-__device__ __forceinline__ void blur_wave(const DeviceConfig &cfg, const DeviceBuffers &buf, int img, int u)
+// tile u of the flattened (level, row band, 256-column strip) list, by one wave.  `fetch(y, w0, w1, w2)` delivers the three
+// words of input row y around the lane's four columns (bytes x0 - 4 .. x0 + 7, reflect-101 outside the image).
+template <class Fetch>
+__device__ __forceinline__ void blur_wave_rows(const DeviceConfig &cfg, const LevelInfo &L, int r0, uint8_t *dst, Fetch fetch)
 {
-    const int lane = threadIdx.x & 63;
-    const uint32_t ti = buf.blur_tile_info[u]; // host-built: saves the per-wave level search (a chain of dependent scalar loads)
-    const LevelInfo &L = cfg.lv[ti & 0xffu];
-    const int x0 = (int)((ti >> 8) & 0xffu) * BL_COLS + lane * 4;
-    const int r0 = (int)(ti >> 16);
-    if (x0 >= L.w || r0 >= L.h) return;
-    const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + x0;
-    // output in 32 x 4 px tiles of 128 B (describe_kernel's 37-row patches then touch about half as many cache lines), a tile
-    // being eight 4 x 4 px blocks of 16 B: the lane's four columns of four rows are ONE 16-byte store and a wave's store
-    // instruction fills eight whole lines (one dword per row in row-major tiles meant 32-B pieces of eight lines per store:
-    // 0.097 -> 0.084 ms)
-    uint8_t *dst = buf.blur + (size_t)img * cfg.blur_bytes + L.blur_off + (((unsigned)(r0 >> 2) * L.blur_tx + (x0 >> 5)) << 7) + ((x0 & 31) << 2);
     const unsigned tile_row_bytes = (unsigned)L.blur_tx << 7;
     unsigned tw[4][3]; // tw[j][q]: taps against the bytes of word q for pixel j; byte 4 q + b meets tap 4 q + b - 1 - j
 #pragma unroll
@@ -59,8 +49,8 @@ __device__ __forceinline__ void blur_wave(const DeviceConfig &cfg, const DeviceB
     for (int i = 0; i < BL_ROWS + 6; i++) {
         int y = r0 - 3 + i;
         y = y > y_max ? y_max : y; // rows past the margin only feed outputs that are never stored
-        const uint32_t *row = (const uint32_t *)(src + __mul24(y, L.pitch)); // y >= -3: the margin rows above the image
-        const unsigned w0 = row[-1], w1 = row[0], w2 = row[1];
+        unsigned w0, w1, w2;
+        fetch(y, w0, w1, w2); // y >= -3: the margin rows above the image
         // row pass: pixel j of the lane's word is byte 4 + j of (w0, w1, w2) and its seven taps cover bytes 1 + j .. 7 + j, so
         // H_j is a byte dot product of the three aligned words with tap words shifted by j (wave-uniform, in scalar registers):
         // 2 + 3 + 3 + 2 v_dot4_u32_u8 per four pixels and no byte alignment ops (aligning the pixels instead costs 6 + 8)
@@ -101,4 +91,86 @@ __device__ __forceinline__ void blur_wave(const DeviceConfig &cfg, const DeviceB
         // rows 2a - 2 .. 2a + 1 = one row of tiles; rows past the level in the last one are allocated and never read
         if (r0 + 2 * a - 2 < L.h) *(uint4 *)(dst + (unsigned)(a >> 1) * tile_row_bytes) = og;
     }
+}
+
+__device__ __forceinline__ void blur_wave(const DeviceConfig &cfg, const DeviceBuffers &buf, int img, int u)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t ti = buf.blur_tile_info[u]; // host-built: saves the per-wave level search (a chain of dependent scalar loads)
+    const int level = (int)(ti & 0xffu);
+    const LevelInfo &L = cfg.lv[level];
+    const int strip = (int)((ti >> 8) & 0xffu);
+    const int x0 = strip * BL_COLS + lane * 4;
+    const int r0 = (int)(ti >> 16);
+    if (x0 >= L.w || r0 >= L.h) return;
+    // output in 32 x 4 px tiles of 128 B (describe_kernel's 37-row patches then touch about half as many cache lines), a tile
+    // being eight 4 x 4 px blocks of 16 B: the lane's four columns of four rows are ONE 16-byte store and a wave's store
+    // instruction fills eight whole lines (one dword per row in row-major tiles meant 32-B pieces of eight lines per store:
+    // 0.097 -> 0.084 ms)
+    uint8_t *dst = buf.blur + (size_t)img * cfg.blur_bytes + L.blur_off + (((unsigned)(r0 >> 2) * L.blur_tx + (x0 >> 5)) << 7) + ((x0 & 31) << 2);
+    if (level == 0 && buf.lv0_packed) {
+        // Level 0 read in place from the caller's packed image (round 4): rows at any alignment and no margin.  A lane's 12 bytes
+        // come from ONE 128-bit load at the 4-byte boundary below them (byte-aligned loads cost the texture addresser about twice
+        // an aligned one: the first version, an unaligned 96-bit load per lane, made this level's blur 50 % slower) and three
+        // v_alignbyte_b32 by the ROW's misalignment, which is wave-uniform (the lane's columns start at a multiple of 4).  Rows
+        // above / below the image are the reflected rows (a scalar index).  Columns: only lane 0 of the first strip (its left
+        // neighbours are the reflection of its own pixels: one v_perm_b32 and three selects per row) and the last strip (a window
+        // clamped into the row, bytes picked by per-lane selectors computed once per wave) differ from the interior.
+        const uint8_t *simg = buf.lv0 + (size_t)img * buf.lv0_stride;
+        const unsigned a0 = (unsigned)((uintptr_t)simg & 3u);
+        const uint8_t *sbase = simg - a0; // 4-byte aligned; a window may start up to 3 bytes before the image, inside the word that holds its first pixel
+        const int pitch = buf.lv0_pitch, w = L.w, h = L.h;
+        auto row_off = [&](int y) { return (unsigned)__mul24(y < 0 ? -y : (y >= h ? 2 * h - 2 - y : y), pitch) + a0; }; // wave-uniform
+        const bool last = (strip + 1) * BL_COLS + 8 > w; // wave-uniform: some lane's 12 bytes reach past the row's last pixel
+        if (!last) {
+            const bool lane0 = strip == 0 && lane == 0; // columns -4 .. -1 are columns 4 .. 1
+            const unsigned xo = lane0 ? 0u : (unsigned)(x0 - 4);
+            blur_wave_rows(cfg, L, r0, dst, [&](int y, unsigned &w0, unsigned &w1, unsigned &w2) {
+                const unsigned ro = row_off(y), sh = ro & 3u;
+                const uint4 q = *(const uint4 *)(sbase + (ro & ~3u) + xo);
+                w0 = __builtin_amdgcn_alignbyte(q.y, q.x, sh); w1 = __builtin_amdgcn_alignbyte(q.z, q.y, sh); w2 = __builtin_amdgcn_alignbyte(q.w, q.z, sh);
+                if (strip == 0) { // uniform
+                    const unsigned t = __builtin_amdgcn_perm(w1, w0, 0x01020304u);
+                    w2 = lane0 ? w1 : w2; w1 = lane0 ? w0 : w1; w0 = lane0 ? t : w0;
+                }
+            });
+            return;
+        }
+        int xs = x0 - 4;
+        xs = xs > w - 12 ? w - 12 : xs;
+        xs = xs < 0 ? 0 : xs;
+        unsigned selA[3], selB[3]; // word q = perm(A1, A0, selA[q]) | perm(0, A2, selB[q]) of the window's words A0 A1 A2
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            unsigned sa = 0u, sb = 0u;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                int c = reflect101(x0 - 4 + 4 * q + b, w) - xs; // byte of the window; columns no kept output needs may fall outside it
+                c = c < 0 ? 0 : (c > 11 ? 11 : c);
+                sa |= (c < 8 ? (unsigned)c : 0x0cu) << (8 * b);
+                sb |= (c < 8 ? 0x0cu : (unsigned)(c - 8)) << (8 * b);
+            }
+            selA[q] = sa; selB[q] = sb;
+        }
+        const unsigned end16 = (unsigned)__mul24(h, pitch) + a0 - 16u; // last 16-byte load that stays inside the image
+        blur_wave_rows(cfg, L, r0, dst, [&](int y, unsigned &w0, unsigned &w1, unsigned &w2) {
+            const unsigned want = row_off(y) + (unsigned)xs; // first byte of the window
+            unsigned ld = want & ~3u;
+            ld = ld > end16 ? end16 : ld;
+            unsigned sh = want - ld; // 0 .. 4
+            uint4 q = *(const uint4 *)(sbase + ld);
+            if (sh >= 4u) { q.x = q.y; q.y = q.z; q.z = q.w; sh -= 4u; }
+            const unsigned A0 = __builtin_amdgcn_alignbyte(q.y, q.x, sh), A1 = __builtin_amdgcn_alignbyte(q.z, q.y, sh), A2 = __builtin_amdgcn_alignbyte(q.w, q.z, sh);
+            w0 = __builtin_amdgcn_perm(A1, A0, selA[0]) | __builtin_amdgcn_perm(0u, A2, selB[0]);
+            w1 = __builtin_amdgcn_perm(A1, A0, selA[1]) | __builtin_amdgcn_perm(0u, A2, selB[1]);
+            w2 = __builtin_amdgcn_perm(A1, A0, selA[2]) | __builtin_amdgcn_perm(0u, A2, selB[2]);
+        });
+        return;
+    }
+    const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + x0;
+    const int pitch = L.pitch;
+    blur_wave_rows(cfg, L, r0, dst, [&](int y, unsigned &w0, unsigned &w1, unsigned &w2) {
+        const uint32_t *row = (const uint32_t *)(src + __mul24(y, pitch));
+        w0 = row[-1]; w1 = row[0]; w2 = row[1];
+    });
 }

@@ -175,6 +175,17 @@ __device__ __forceinline__ int hamming256(const uint32_t *a, const uint32_t *b)
     return d;
 }
 
+// Raw pyramid level `level` of image `img`: first pixel and row pitch.  Level 0 goes through DeviceBuffers::lv0 (the library's
+// pitched copy, or the caller's packed images read in place); `level` is wave-uniform at every call site but the stereo
+// refinement's, where it is a select per lane.
+__device__ __forceinline__ const uint8_t *level_image(const DeviceConfig &cfg, const DeviceBuffers &buf, int img, int level, int &pitch)
+{
+    if (level == 0) { pitch = buf.lv0_pitch; return buf.lv0 + (size_t)img * buf.lv0_stride; }
+    const LevelInfo &L = cfg.lv[level];
+    pitch = L.pitch;
+    return buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off;
+}
+
 // 16 bytes from an address that is only 4-byte aligned: one global_load_dwordx4 (fine on this memory system).  A plain struct
 // load rather than __builtin_memcpy into an array element, which demotes the array to scratch memory.
 struct __attribute__((packed, aligned(4))) orbfe_u4_unaligned { uint32_t x, y, z, w; };
@@ -183,3 +194,6 @@ __device__ __forceinline__ uint4 load16_unaligned(const uint8_t *p)
     const orbfe_u4_unaligned t = *(const orbfe_u4_unaligned *)p;
     return make_uint4(t.x, t.y, t.z, t.w);
 }
+
+// 12 bytes from any address: one global_load_dwordx3
+struct __attribute__((packed, aligned(4))) orbfe_u3_unaligned { uint32_t x, y, z; };

@@ -112,9 +112,12 @@ __global__ __launch_bounds__(256, 8) void describe_generic_kernel(DeviceConfig c
     };
     auto prefetch_raw = [&](int i) -> bool {
         if (i >= DS_KPW || !slot_data(i)) return false;
-        const LevelInfo &L = cfg.lv[level];
         if (dot_moments)
-            fetch_raw(buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (ptrdiff_t)(cy - hp) * L.pitch + (cx - hp), L.pitch);
+        {
+            int lp;
+            const uint8_t *li = level_image(cfg, buf, img, level, lp);
+            fetch_raw(li + (ptrdiff_t)(cy - hp) * lp + (cx - hp), lp);
+        }
         return true;
     };
     auto prefetch_blur = [&](int i) -> bool {
@@ -154,9 +157,9 @@ __global__ __launch_bounds__(256, 8) void describe_generic_kernel(DeviceConfig c
             if (dot_moments) {
                 ((uint4 *)s_raw)[lane] = pr;
             } else { // other patch sizes: aligned words straight through (no prefetch), row pitch DS_PATCH_W
-                const LevelInfo &Lr = cfg.lv[lv];
-                const uint8_t *gp = buf.pyr + (size_t)img * cfg.pyr_bytes + Lr.pyr_off + (ptrdiff_t)__mul24(ky - hp + r0, Lr.pitch) + ((kx - hp) & ~3) + 4 * c0;
-                const int step = 6 * Lr.pitch + 16, wrap = Lr.pitch - DS_PATCH_W;
+                int lp;
+                const uint8_t *gp = level_image(cfg, buf, img, lv, lp) + (ptrdiff_t)__mul24(ky - hp + r0, lp) + ((kx - hp) & ~3) + 4 * c0; // level 0 in place: the words may be unaligned (fine on this memory system)
+                const int step = 6 * lp + 16, wrap = lp - DS_PATCH_W;
                 int c = c0;
                 for (int w = lane; w < raw_rows * (DS_PATCH_W / 4); w += 64) {
                     ((uint32_t *)s_raw)[w] = *(const uint32_t *)gp;
@@ -371,9 +374,9 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
     for (int i = 0; i < DS_KPW; i++) {
         pr[i] = make_uint4(0u, 0u, 0u, 0u);
         if (hv[i]) {
-            const LevelInfo &L = cfg.lv[lvv[i]];
-            const uint8_t *base = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (ptrdiff_t)(cyv[i] - 15) * L.pitch + (cxv[i] - 15);
-            pr[i] = load16_unaligned(base + (unsigned)(__mul24(raw_row, L.pitch) + raw_h16)); // 16 bytes at any alignment: one global_load_dwordx4
+            int lp;
+            const uint8_t *base = level_image(cfg, buf, img, lvv[i], lp) + (ptrdiff_t)(cyv[i] - 15) * lp + (cxv[i] - 15);
+            pr[i] = load16_unaligned(base + (unsigned)(__mul24(raw_row, lp) + raw_h16)); // 16 bytes at any alignment: one global_load_dwordx4
         }
     }
     // blurred patches: block i = lane + 64 k of the 10 x 10 grid of 4 x 4 px blocks (layout: describe_generic_kernel)

@@ -108,6 +108,13 @@ struct DeviceConfig {
 // Per-batch device buffers (all [image][...] with the per-image strides of DeviceConfig).
 struct DeviceBuffers {
     uint8_t *pyr;        // raw pyramid
+    // Level 0 as the kernels read it (level_image(), orbfe_common.hpp).  Copy mode: pyr + lv[0].pyr_off, per-image stride pyr_bytes,
+    // pitch lv[0].pitch, reflect-101 margin materialised by ingest.  In-place mode (lv0_packed = 1, round 4): the caller's packed
+    // CV_8UC1 images themselves -- no ingest launch, no copy; rows at any alignment, no margin (the blur of level 0 reflects by
+    // itself, every other reader stays inside the image)
+    const uint8_t *lv0;
+    size_t lv0_stride;
+    int lv0_pitch, lv0_packed;
     uint8_t *blur;       // blurred pyramid
     int *cell_cnt;       // [img][cells_total]
     uint32_t *cell_xy;   // [img][cells_total*cell_cap]  x | y<<16 (region relative)
@@ -198,4 +205,8 @@ void orbfe_launch_rgbd(const DeviceConfig &cfg, const DeviceBuffers &buf, const 
 void orbfe_launch_undistort(const DeviceConfig &cfg, const void *d_keys_in, void *d_keys_out, int n, hipStream_t s);
 void orbfe_launch_rgbd_u16(const DeviceConfig &cfg, const DeviceBuffers &buf, const uint16_t *d_depth, size_t depth_pitch_px,
                            float factor, int image, hipStream_t s);
+void orbfe_launch_rgbd_batch(const DeviceConfig &cfg, const DeviceBuffers &buf, const void *d_depth, bool is_u16, float factor, int n_images, hipStream_t s);
+// byte offsets of the arrays inside a packed result block (orbfe_packed_layout of include/orbfe.h mirrors it)
+struct PackedOffsets { size_t counts, level_counts, xy, angle, response, desc, u_right, depth; };
+void orbfe_launch_pack_results(const DeviceConfig &cfg, const DeviceBuffers &buf, uint8_t *d_out, const PackedOffsets &lay, int n_out, int img_step, bool stereo, hipStream_t s);
 void orbfe_launch_hamming_matrix(const uint8_t *da, int na, const uint8_t *db, int nb, int *dist, hipStream_t s);

@@ -164,7 +164,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     // always sits at tile byte c + 3 and a cell of up to 32 columns is eight 4-pixel groups per row whatever ini_x & 3 is
     const int xa = ini_x, ox = 0;
     const int wpr = (max_x - xa + 3) >> 2; // words per tile row
-    const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + (size_t)ini_y * L.pitch + xa;
+    int src_pitch;
+    const uint8_t *src = level_image(cfg, buf, img, level, src_pitch) + (size_t)ini_y * src_pitch + xa; // level 0 may be the caller's packed image (any row alignment: the staging loads are unaligned anyway)
     // The reference runs FAST at iniThFAST and, only when that yields no keypoint in the cell, again at minThFAST
     // (src/ORBextractor.cc:803-810).  Same here: the first attempt queues and scores only what passes the quick test at
     // iniTh (about 0.6 of what passes at minTh on the benchmark images, so phases C-E shrink accordingly); a cell without a
@@ -182,7 +183,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         // multiple of 16): lane = (row of the pass, chunk), 64 / cpr rows per load instruction -- two loads for a 37-row tile
         // of three chunks instead of twelve dword loads.  Lanes beyond the last whole row of a pass and rows beyond the tile
         // repeat an element (same value to the same LDS bytes), so nothing is predicated.  The last chunk of a row may read up
-        // to 15 bytes past the tile (inside the pyramid row's margin) into LDS bytes no pixel test uses.
+        // to 15 bytes past the tile (inside the pyramid row's margin, or -- level 0 read in place -- the first bytes of the next row: a
+        // tile ends >= 10 rows above the image's last row) into LDS bytes no pixel test uses.
         const int cpr = (wpr + 3) >> 2;
         const int rpi = small_div(64, cpr);
         int rl0 = small_div(lane, cpr);
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                 int r = rb + u * rpi + rl0;
                 r = r < th ? r : th - 1;
                 dst[u] = __mul24(r, tile_pitch) + ch16;
-                v[u] = load16_unaligned(src + (unsigned)(__mul24(r, L.pitch) + ch16));
+                v[u] = load16_unaligned(src + (unsigned)(__mul24(r, src_pitch) + ch16));
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) *(uint4 *)(s_tile + dst[u]) = v[u];

@@ -301,13 +301,18 @@ __host__ __device__ __forceinline__ int resize_word_base(int xw, int dst_w, doub
 }
 int orbfe_resize_word_base_host(int xw, int dst_w, double scale, int src_w) { return resize_word_base(xw, dst_w, scale, src_w); }
 
-template <int RB>
+// PACKED0 (round 4): the source is level 0 read IN PLACE from the caller's packed image (DeviceBuffers::lv0_packed) -- rows at any
+// alignment, so the 96-bit window is loaded at the row's own 4-byte boundary and the byte shift is per row; the one window that
+// could reach past the image's last byte (last source row, last words) is loaded 12 bytes before the image's end instead and
+// shifted into place.  The first workgroup of every image also clears the image's status word (ingest's job in copy mode).
+template <int RB, bool PACKED0 = false>
 __device__ __forceinline__ void resize_direct_wave(const DeviceConfig &cfg, const DeviceBuffers &buf, int level, int img, int strip, int band)
 {
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     const LevelInfo &D = cfg.lv[level];
     const LevelInfo &S = cfg.lv[level - 1];
     const int lane = threadIdx.x & 63;
+    if (PACKED0 && strip == 0 && band == 0 && lane == 0) buf.status[img] = 0;
     const int ny = D.rs_ytab_n, nx = D.rs_xtab_n, nwords = nx >> 2;
     const int y0 = band * RB; // first extended row of this wave's band
     if (y0 >= ny) return;
@@ -320,28 +325,54 @@ __device__ __forceinline__ void resize_direct_wave(const DeviceConfig &cfg, cons
     typedef const __attribute__((address_space(4))) uint32_t *rs_const_ptr;
     const rs_const_ptr yt = (rs_const_ptr)(uintptr_t)(buf.rs_tab + D.rs_ytab_off);
     const int base = resize_word_base(xw, D.w, D.rs_scale_x, S.w);
-    const uint8_t *sp = buf.pyr + (size_t)img * cfg.pyr_bytes + S.pyr_off + (base & ~3); // pixel (0,0) and the pitch are 4-byte aligned
-    const unsigned sh = (unsigned)base & 3u;
-    struct __attribute__((packed, aligned(4))) win_t { uint32_t x, y, z; };
+    // three words in ONE global_load_dwordx3 (a struct of three fields is split into two overlapping 64-bit loads as soon as its
+    // fields are selected between, as the clamped-window fix-up below does)
+    typedef uint32_t win_v __attribute__((ext_vector_type(3)));
+    typedef win_v win_ld __attribute__((aligned(4)));
+    struct win_t { uint32_t x, y, z; };
+    auto ld_win = [](const uint8_t *p) { const win_v v = *(const win_ld *)p; win_t w; w.x = v.x; w.y = v.y; w.z = v.z; return w; };
     uint8_t *dst = buf.pyr + (size_t)img * cfg.pyr_bytes + D.pyr_off + (xw * 4 - PYR_MX);
-    const unsigned spitch = (unsigned)S.pitch;
+    const unsigned spitch = PACKED0 ? (unsigned)buf.lv0_pitch : (unsigned)S.pitch;
+    const uint8_t *simg = PACKED0 ? buf.lv0 + (size_t)img * buf.lv0_stride : buf.pyr + (size_t)img * cfg.pyr_bytes + S.pyr_off;
+    // copy mode: pixel (0,0) and the pitch are 4-byte aligned, the window's shift is the lane's own constant.  In place: offsets from
+    // the 4-byte boundary at or below the image's first byte; a window's shift depends on its row
+    const unsigned a0 = PACKED0 ? (unsigned)((uintptr_t)simg & 3u) : 0u;
+    const uint8_t *sp = PACKED0 ? simg - a0 : simg + (base & ~3);
+    const unsigned sh_fixed = (unsigned)base & 3u;
+    const unsigned lim = (unsigned)S.h * spitch + a0 - 12u; // PACKED0: the last window that ends inside the image
     uint32_t ye[RB], yb[RB];
 #pragma unroll
     for (int k = 0; k < RB; k++) {
         const int yy = y0 + k < ny ? y0 + k : ny - 1;
         ye[k] = yt[yy]; yb[k] = yt[ny + yy];
     }
-    win_t wa[RB], wb[RB];
-#pragma unroll
-    for (int k = 0; k < RB; k++) {
-        if (k == 0 || (ye[k] & 0xffffu) != (ye[k - 1] >> 16)) // uniform: else the previous row's lower source row
-            wa[k] = *(const win_t *)(sp + __umul24(ye[k] & 0xffffu, spitch));
-        wb[k] = *(const win_t *)(sp + __umul24(ye[k] >> 16, spitch));
-    }
+    // window of source row `row`: 12 bytes from the 4-byte boundary at or below the lane's first source byte, and that byte's
+    // offset in them.  No branch here: every load of the band is issued before anything waits (a uniform "last row" branch
+    // around the load made the compiler serialise them: level 1 took 44 us instead of 28).
+    auto load_win = [&](unsigned row, win_t &w, unsigned &sh) {
+        if (!PACKED0) { w = ld_win(sp + __umul24(row, spitch)); sh = sh_fixed; return; }
+        const unsigned off = __umul24(row, spitch) + ((unsigned)base + a0);
+        unsigned ld = off & ~3u;
+        ld = ld > lim ? lim : ld; // only in the image's last row, last words: never read past the image (the caller's buffer may end there)
+        sh = off - ld;            // 0 .. 3, or up to 11 for a clamped window (whose bytes end at the row's last pixel)
+        w = ld_win(sp + ld);
+    };
     const uint4 SEL = *(const uint4 *)(dt + 4 * xw);
     const uint4 WT = *(const uint4 *)(xt + nx + 4 * xw);
+    win_t wa[RB], wb[RB];
+    unsigned sa[RB], sb[RB];
+#pragma unroll
+    for (int k = 0; k < RB; k++) {
+        sa[k] = 0u;
+        if (k == 0 || (ye[k] & 0xffffu) != (ye[k - 1] >> 16)) // uniform: else the previous row's lower source row
+            load_win(ye[k] & 0xffffu, wa[k], sa[k]);
+        load_win(ye[k] >> 16, wb[k], sb[k]);
+    }
     const uint32_t sel[4] = {SEL.x, SEL.y, SEL.z, SEL.w}, wt[4] = {WT.x, WT.y, WT.z, WT.w};
-    auto hpass = [&](const win_t w, unsigned h[4]) {
+    auto hpass = [&](win_t w, unsigned sh, bool last_row, unsigned h[4]) {
+        if (PACKED0 && last_row) { // uniform: a clamped window (load_win) brings the wanted bytes to the front
+            if (sh >= 8u) { w.x = w.z; sh -= 8u; } else if (sh >= 4u) { w.x = w.y; w.y = w.z; sh -= 4u; }
+        }
         const unsigned lo = __builtin_amdgcn_alignbyte(w.y, w.x, sh), hi = __builtin_amdgcn_alignbyte(w.z, w.y, sh);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -357,9 +388,9 @@ __device__ __forceinline__ void resize_direct_wave(const DeviceConfig &cfg, cons
 #pragma unroll
             for (int j = 0; j < 4; j++) hA[j] = hB[j];
         } else {
-            hpass(wa[k], hA);
+            hpass(wa[k], sa[k], (ye[k] & 0xffffu) + 1u == (unsigned)S.h, hA);
         }
-        hpass(wb[k], hB);
+        hpass(wb[k], sb[k], (ye[k] >> 16) + 1u == (unsigned)S.h, hB);
         const unsigned b0 = (yb[k] & 0xffffu) << 12, b1 = (yb[k] >> 16) << 12; // <= 2^23
         uint32_t out = 0;
 #pragma unroll
@@ -372,11 +403,11 @@ __device__ __forceinline__ void resize_direct_wave(const DeviceConfig &cfg, cons
     }
 }
 
-template <int RB>
+template <int RB, bool PACKED0 = false>
 __global__ __launch_bounds__(256) void pyr_resize_direct_kernel(DeviceConfig cfg, DeviceBuffers buf, int level)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    resize_direct_wave<RB>(cfg, buf, level, blockIdx.z, blockIdx.x, (int)blockIdx.y * 4 + wave);
+    resize_direct_wave<RB, PACKED0>(cfg, buf, level, blockIdx.z, blockIdx.x, (int)blockIdx.y * 4 + wave);
 }
 
 // ---------------------------------------------------------------------------
@@ -567,7 +598,7 @@ __global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffe
 // resize lives on many short waves); 16- / 8-row blur bands in the interleaved order 0.189 / 0.192; s_setprio 3 for the
 // resize waves: no change.  So what the fusion buys is the launch boundary and the drain of the blur's last waves, 4 x ~1 us.
 // ORBFE_NO_FUSE=1 (orbfe_create) keeps the launches apart.
-template <int RB>
+template <int RB, bool PACKED0 = false>
 __global__ __launch_bounds__(256) void pyr_resize_blur_kernel(DeviceConfig cfg, DeviceBuffers buf, int level, int strips, int n_resize, int tile_begin, int tile_end)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -576,7 +607,7 @@ __global__ __launch_bounds__(256) void pyr_resize_blur_kernel(DeviceConfig cfg, 
     const int img = blockIdx.x, x = (int)blockIdx.y < n_blur ? n_resize + (int)blockIdx.y : (int)blockIdx.y - n_blur;
     if (x < n_resize) {
         const int bg = __builtin_amdgcn_readfirstlane(small_div(x, strips));
-        resize_direct_wave<RB>(cfg, buf, level, img, x - bg * strips, bg * 4 + wave);
+        resize_direct_wave<RB, PACKED0>(cfg, buf, level, img, x - bg * strips, bg * 4 + wave);
     } else {
         const int u = tile_begin + (x - n_resize) * 4 + wave;
         if (u < tile_end) blur_wave(cfg, buf, img, u);
@@ -621,11 +652,13 @@ int orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int 
                 const LevelInfo &P = cfg.lv[l - 1];
                 const int t0 = P.blur_tile_off, t1 = t0 + P.blur_tiles_x * P.blur_tiles_y;
                 dim3 grid(n_images, strips * groups + (t1 - t0 + 3) / 4);
-                hipLaunchKernelGGL(pyr_resize_blur_kernel<rb>, grid, dim3(256), 0, s, cfg, buf, l, strips, strips * groups, t0, t1);
+                if (l == 1 && buf.lv0_packed) hipLaunchKernelGGL((pyr_resize_blur_kernel<rb, true>), grid, dim3(256), 0, s, cfg, buf, l, strips, strips * groups, t0, t1);
+                else hipLaunchKernelGGL(pyr_resize_blur_kernel<rb>, grid, dim3(256), 0, s, cfg, buf, l, strips, strips * groups, t0, t1);
                 blurred = l;
             } else {
                 dim3 grid(strips, groups, n_images);
-                hipLaunchKernelGGL(pyr_resize_direct_kernel<rb>, grid, dim3(256), 0, s, cfg, buf, l);
+                if (l == 1 && buf.lv0_packed) hipLaunchKernelGGL((pyr_resize_direct_kernel<rb, true>), grid, dim3(256), 0, s, cfg, buf, l);
+                else hipLaunchKernelGGL(pyr_resize_direct_kernel<rb>, grid, dim3(256), 0, s, cfg, buf, l);
             }
         } else if (cfg.lv[l].rs_rw == 4) {
             dim3 grid((total_rows + 15) / 16, n_images);

@@ -165,15 +165,17 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, Dev
         // keypoints >= 19 px from the border, kept as a memory-safety guard
         const bool safe = cu - 5 >= 0 && cu + 5 < L.w && cv - 5 >= 0 && cv + 5 < L.h && cr - 10 >= 0 && cr + 10 < L.w;
         if (in_ref && safe) {
-            const uint8_t *imL = buf.pyr + (size_t)imgL * cfg.pyr_bytes + L.pyr_off;
-            const uint8_t *imR = buf.pyr + (size_t)imgR * cfg.pyr_bytes + L.pyr_off;
+            int lpitch;
+            const uint8_t *imL = level_image(cfg, buf, imgL, level_l, lpitch);
+            const uint8_t *imR = level_image(cfg, buf, imgR, level_l, lpitch);
             // the group's windows through LDS: lane r < 11 fetches row r of the left window (11 bytes from column cu - 5: one
             // unaligned 128-bit load) and of the right band (21 bytes from column cr - 10: two), instead of every lane fetching a
             // byte and a 12-byte piece for each of its 8 window pixels (18 load instructions per lane; the texture addresser was
-            // busy 62 % of this kernel).  The extra bytes (up to column cu + 10 / cr + 21) lie in the row's right margin.
+            // busy 62 % of this kernel).  The extra bytes (up to column cu + 10 / cr + 21) lie in the row's right margin
+            // (level 0 read in place: in the first bytes of the next row; the window's last row is >= 14 rows above the image's).
             uint8_t *wl = s_win + (threadIdx.x / SM_G) * SM_WIN_BYTES, *wr = wl + 11 * 16;
             if (gl < 11) {
-                const unsigned ro = (unsigned)__mul24(cv - 5 + gl, L.pitch);
+                const unsigned ro = (unsigned)__mul24(cv - 5 + gl, lpitch);
                 const uint4 a = load16_unaligned(imL + ro + cu - 5);
                 const uint4 b0 = load16_unaligned(imR + ro + cr - 10), b1 = load16_unaligned(imR + ro + cr + 6);
                 *(uint4 *)(wl + 16 * gl) = a;
@@ -373,6 +375,8 @@ __global__ __launch_bounds__(256) void rgbd_kernel(DeviceConfig cfg, DeviceBuffe
                                                    size_t pitch_floats, int img, float factor)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    img += (int)blockIdx.y;                                              // batched call (orbfe_enqueue_rgbd): one grid row per image,
+    depth_img += (size_t)blockIdx.y * pitch_floats * (size_t)cfg.height; // the depth maps packed one after the other
     const int n = buf.kp_cnt[img];
     if (i >= n) return;
     const KeyPointPOD kp = ((const KeyPointPOD *)buf.kps)[(size_t)img * cfg.sel_total + i];
@@ -442,6 +446,66 @@ void orbfe_launch_rgbd_u16(const DeviceConfig &cfg, const DeviceBuffers &buf, co
                            float factor, int image, hipStream_t s)
 {
     hipLaunchKernelGGL(rgbd_kernel<uint16_t>, dim3((cfg.sel_total + 255) / 256), dim3(256), 0, s, cfg, buf, d_depth, depth_pitch_px, image, factor);
+}
+
+// n_images frames in one launch: depth map k (w x h elements, rows packed) belongs to image slot k
+void orbfe_launch_rgbd_batch(const DeviceConfig &cfg, const DeviceBuffers &buf, const void *d_depth, bool is_u16, float factor, int n_images, hipStream_t s)
+{
+    dim3 grid((cfg.sel_total + 255) / 256, n_images);
+    if (is_u16) hipLaunchKernelGGL(rgbd_kernel<uint16_t>, grid, dim3(256), 0, s, cfg, buf, (const uint16_t *)d_depth, (size_t)cfg.width, 0, factor);
+    else hipLaunchKernelGGL(rgbd_kernel<float>, grid, dim3(256), 0, s, cfg, buf, (const float *)d_depth, (size_t)cfg.width, 0, 1.0f);
+}
+
+// ---------------------------------------------------------------------------
+// Packed result block (orbfe_fetch_batch_packed, round 4).  A cv::KeyPoint is 28 bytes of which pt, size, octave and class_id are
+// functions of (level x, level y, octave) -- src/ORBextractor.cc:838 (size = scaledPatchSize), :909-915 (pt *= scale) -- and the
+// octave follows from the per-level counts, because a frame's keypoints are stored octave by octave (:866-917).  What has to cross
+// the link per keypoint is x | y << 16 on its level (4 B), the angle (4 B) and the FAST score (1 B): 9 bytes instead of 28; the
+// host expands with the reference's own float operations (orbfe_expand_packed).  One kernel gathers everything a step's results
+// need -- these records, counts, descriptors, uRight / depth of the left images -- into one contiguous block: ONE device-to-host
+// copy per step.  Out image o is device image slot o * img_step (img_step 2: left images only).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_results_kernel(DeviceConfig cfg, DeviceBuffers buf, uint8_t *__restrict__ out, PackedOffsets lay, int img_step, int stereo)
+{
+    const int oi = blockIdx.y, di = oi * img_step;
+    const int cap = cfg.sel_total, j0 = (int)blockIdx.x * 256, j = j0 + (int)threadIdx.x;
+    const int n = buf.kp_cnt[di];
+    const int *lc = buf.sel_cnt + (size_t)di * cfg.nlevels;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ((int *)(out + lay.counts))[oi] = n;
+        for (int l = 0; l < cfg.nlevels; l++) ((int *)(out + lay.level_counts))[oi * cfg.nlevels + l] = lc[l];
+    }
+    if (j < n) {
+        int l = 0, first = 0; // the keypoint's octave: octave by octave, in the quadtree's list order (describe_kernel's `excl`)
+        for (; l < cfg.nlevels - 1; l++) {
+            const int c = lc[l];
+            if (j < first + c) break;
+            first += c;
+        }
+        const int slot = cfg.lv[l].sel_off + (j - first);
+        const unsigned mb = (unsigned)cfg.min_border * 0x10001u;
+        ((uint32_t *)(out + lay.xy))[(size_t)oi * cap + j] = buf.sel_xy[(size_t)di * cap + slot] + mb; // level-image coordinates (both halves < 32768: no carry)
+        ((float *)(out + lay.angle))[(size_t)oi * cap + j] = ((const KeyPointPOD *)buf.kps)[(size_t)di * cap + j].angle;
+        (out + lay.response)[(size_t)oi * cap + j] = buf.sel_sc[(size_t)di * cap + slot];
+    }
+    // descriptors: this block's 256 slots = 512 coalesced 16-byte chunks (slots past the count travel too: fixed layout)
+    {
+        const uint4 *src = (const uint4 *)(buf.desc + ((size_t)di * cap + j0) * 32);
+        uint4 *dst = (uint4 *)(out + lay.desc + ((size_t)oi * cap + j0) * 32);
+        const int chunks = 2 * (cap - j0 < 256 ? cap - j0 : 256);
+        for (int c = threadIdx.x; c < chunks; c += 256) dst[c] = src[c];
+    }
+    if (stereo && (di & 1) == 0 && j < cap) { // uRight / depth of the left image of pair di / 2
+        const int pr = di >> 1;
+        ((float *)(out + lay.u_right))[(size_t)pr * cap + j] = buf.u_right[(size_t)di * cap + j];
+        ((float *)(out + lay.depth))[(size_t)pr * cap + j] = buf.depth[(size_t)di * cap + j];
+    }
+}
+
+void orbfe_launch_pack_results(const DeviceConfig &cfg, const DeviceBuffers &buf, uint8_t *d_out, const PackedOffsets &lay, int n_out, int img_step, bool stereo, hipStream_t s)
+{
+    dim3 grid((cfg.sel_total + 255) / 256, n_out);
+    hipLaunchKernelGGL(pack_results_kernel, grid, dim3(256), 0, s, cfg, buf, d_out, lay, img_step, stereo ? 1 : 0);
 }
 
 void orbfe_launch_hamming_matrix(const uint8_t *da, int na, const uint8_t *db, int nb, int *dist, hipStream_t s)
