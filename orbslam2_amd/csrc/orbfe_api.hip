@@ -360,6 +360,12 @@ static int build_config(orbfe_context *ctx)
         {
             bool ok3 = roots_ok && c.cell_cap <= 4095; // key fields: 12-bit cell, 12-bit slot; bucket partials: 12-bit count
             for (int l = 0; l < p.nlevels; l++) ok3 = ok3 && c.lv[l].n_cells <= 4096 && c.lv[l].w_cell <= 64 && c.lv[l].h_cell <= 64; // one lane per cell column / row
+            // the counts of the two deepest pyramid depths are 16 bit: a depth-4 node (1 / 256 of a root) holds at most one strict-NMS
+            // survivor per 2 x 2 px (always true within the cell-count limit above: <= 4096 cells of <= 64 x 64 px per level)
+            for (int l = 0; l < p.nlevels; l++) {
+                const long rw = (long)(c.lv[l].w - p.edge_threshold + 3) - c.min_border, rh = (long)(c.lv[l].h - p.edge_threshold + 3) - c.min_border;
+                if (rw > 0 && rh > 0) ok3 = ok3 && ((rw / c.lv[l].n_ini / 16 + 2) / 2 + 1) * ((rh / 16 + 2) / 2 + 1) <= 65535;
+            }
             ctx->ot3_nodes_in_hbm = orbfe_octree3_lds_bytes(c.max_nodes, sc, false) > 150 * 1024;
             ctx->ot3_lds = orbfe_octree3_lds_bytes(c.max_nodes, sc, ctx->ot3_nodes_in_hbm);
             const char *force = getenv("ORBFE_OCTREE"); // test knob: 2 = point-parallel kernel, 1 = generic kernel
@@ -425,6 +431,8 @@ try {
     A(b.idx0, B * c.cand_total);
     A(b.idx1, B * c.cand_total);
     A(b.bk_end, B * c.nlevels * 4097);
+    b.bk_best = nullptr;
+    if (ctx->use_octree3) A(b.bk_best, B * c.nlevels * ORBFE_BK_PYR);
     b.ot3_scratch = nullptr;
     if (ctx->use_octree3 && ctx->ot3_nodes_in_hbm) A(b.ot3_scratch, B * c.nlevels * orbfe_octree3_node_bytes(c.max_nodes, ctx->ot2_sort_cap));
     A(b.lvl_ncand, B * c.nlevels);
@@ -1004,6 +1012,7 @@ static DeviceBuffers shift_buffers(const DeviceBuffers &b, const DeviceConfig &c
     o.lvl_ncand += i * c.nlevels; o.sel_cnt += i * c.nlevels;
     o.bk_part += i * c.bk_part_total; o.bk_end += i * c.nlevels * 4097;
     if (o.ot3_scratch) o.ot3_scratch += i * c.nlevels * orbfe_octree3_node_bytes(c.max_nodes, ot_sort_cap_of(c));
+    if (o.bk_best) o.bk_best += i * c.nlevels * ORBFE_BK_PYR;
     o.sel_xy += i * c.sel_total; o.sel_sc += i * c.sel_total;
     o.kps = (KeyPointPOD *)o.kps + i * c.sel_total; o.desc += i * c.sel_total * 32;
     o.kp_cnt += i; o.status += i;

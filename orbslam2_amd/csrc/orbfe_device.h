@@ -131,6 +131,7 @@ struct DeviceBuffers {
                          // bucket arrays (LDS) by octree3_kernel
     int *bk_end;         // [img][nlevels][4097] quadtree deep path: bucket ends of the counting sort
     uint8_t *ot3_scratch; // [img][nlevels][node_bytes] quadtree node tables when they do not fit LDS (else null)
+    uint32_t *bk_best;   // [img][nlevels][ORBFE_BK_PYR] best-key pyramid of every (image, level): written after the pyramid step, read by the final selection
     int *lvl_ncand;      // [img][nlevels]
     int *sel_cnt;        // [img][nlevels]
     uint32_t *sel_xy;    // [img][sel_total]
@@ -166,6 +167,7 @@ struct DeviceBuffers {
 // = best score, first in cv::FAST emission order.
 #define ORBFE_BK_DEPTH 5
 #define ORBFE_BK_BUCKETS 4096
+#define ORBFE_BK_PYR 5460 // entries of one bucket pyramid: 4 roots x (1 + 4 + ... + 4^5)
 #define ORBFE_BK_REF_MASK 0xffffffu
 #define ORBFE_BK_KEY(sc, cell, slot) (((sc) << 24) | (ORBFE_BK_REF_MASK - (unsigned)(((cell) << 12) | (slot))))
 // A cell's partial entry: the cell is implied by the entry's position, so count (<= cell_cap <= 1024) and the key's score and

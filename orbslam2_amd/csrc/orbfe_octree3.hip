@@ -27,11 +27,22 @@
 #include "orbfe_blur_wave.hpp"
 #include <cstdlib>
 
-#define OT3_THREADS 512
+// Round 4: 256 threads and <= 40 KB of LDS per workgroup, so that all 1024 workgroups of a 64-pair step are resident at once
+// (four per CU: the kernel needs 118 VGPRs = 4 waves per SIMD = 16 per CU; with 512 threads and 80 KB that was two workgroups
+// per CU and two rounds of 25 us each).  What left the LDS: the node boxes (never read: a node's children come from the count
+// pyramid, its box is implied by root + path), the best-key pyramid after the pyramid step (copied to an HBM scratch slice, read
+// back by the final selection: one more dependent load per kept node), half of the count pyramid (depths 4 and 5 are 16 bit:
+// a bucket holds at most a few thousand strict-NMS survivors, orbfe_create checks), the sort keys (they alias the node array
+// that is being built).
+#ifndef OT3_THREADS
+#define OT3_THREADS 256
+#endif
 #define OT3_WAVES (OT3_THREADS / 64)
 #define OT3_DB 5                       // bucket depth
 #define OT3_ROOTS 4                    // root slots per level (n_ini <= 4)
 #define OT3_PYR (OT3_ROOTS * 1365)     // sum_{d=0..5} 4^d = 1365 entries per root
+#define OT3_HI (OT3_ROOTS * 85)        // entries of depths 0..3 (32-bit counts); depths 4 and 5 follow as 16-bit counts
+static_assert(OT3_PYR == ORBFE_BK_PYR, "the best-key scratch of orbfe_api.hip holds one pyramid per (image, level)");
 #define OT3_BUCKETS (OT3_ROOTS * 1024)
 // best key: score (8 bits) << 24 | ~(cell (12 bits) << 12 | slot (12 bits)); the host checks the field widths
 #define OT3_REF_MASK ORBFE_BK_REF_MASK
@@ -109,33 +120,39 @@ struct Ot3Nodes {
     int *cnt;
     unsigned *path;          // quadrant path, 2 bits per depth (depth <= 15)
     int *dr;                 // depth | root << 4
-    short *x0, *y0, *x1, *y1;
 };
 
-__device__ __forceinline__ void ot3_bind(Ot3Nodes &n, uint8_t *&p, int cap)
+// bytes of one node array: three words per node, and room for the sort keys of the "largest node first" phase, which are built
+// in the array that is not in use (the next pass's nodes are written after the ranking)
+__host__ __device__ __forceinline__ size_t ot3_slot_bytes(int cap, int sort_cap)
 {
-    n.cnt = (int *)p; p += sizeof(int) * cap;
-    n.path = (unsigned *)p; p += sizeof(unsigned) * cap;
-    n.dr = (int *)p; p += sizeof(int) * cap;
-    n.x0 = (short *)p; p += sizeof(short) * cap;
-    n.y0 = (short *)p; p += sizeof(short) * cap;
-    n.x1 = (short *)p; p += sizeof(short) * cap;
-    n.y1 = (short *)p; p += sizeof(short) * cap;
-    p = (uint8_t *)(((uintptr_t)p + 7) & ~(uintptr_t)7);
+    const size_t a = 3 * sizeof(int) * (size_t)cap, k = sizeof(unsigned long long) * (size_t)sort_cap;
+    return ((a > k ? a : k) + 15) & ~(size_t)15;
 }
 
-// bytes of the node tables (sort keys, two node arrays, per-node bookkeeping) of one workgroup
+__device__ __forceinline__ void ot3_bind(Ot3Nodes &n, uint8_t *&p, int cap, int sort_cap)
+{
+    uint8_t *q = p;
+    n.cnt = (int *)q; q += sizeof(int) * cap;
+    n.path = (unsigned *)q; q += sizeof(unsigned) * cap;
+    n.dr = (int *)q;
+    p += ot3_slot_bytes(cap, sort_cap);
+}
+
+// bytes of the node tables (two node arrays, per-node bookkeeping) of one workgroup
 size_t orbfe_octree3_node_bytes(int max_nodes, int sort_cap)
 {
     const size_t cap = (size_t)max_nodes;
-    const size_t node = 3 * sizeof(int) * cap + 4 * sizeof(short) * cap + 8;
-    return ((sizeof(unsigned long long) * sort_cap + 2 * node + sizeof(int) * cap * (4 + 1 + 1 + 1 + 1) + 64) + 255) & ~(size_t)255;
+    return ((2 * ot3_slot_bytes(max_nodes, sort_cap) + sizeof(int) * cap * (4 + 1 + 1 + 1 + 1) + 64) + 255) & ~(size_t)255;
 }
 
-// dynamic LDS of octree3_kernel: the two pyramids, plus the node tables unless they live in HBM
+// dynamic LDS of octree3_kernel: the count pyramid (32-bit entries for depths 0..3, 16-bit for depths 4 and 5), then one region
+// that holds the best-key pyramid while the buckets are summed up and the node tables afterwards (unless those live in HBM)
 size_t orbfe_octree3_lds_bytes(int max_nodes, int sort_cap, bool nodes_in_hbm)
 {
-    return 2 * sizeof(int) * OT3_PYR + (nodes_in_hbm ? 0 : orbfe_octree3_node_bytes(max_nodes, sort_cap)) + 64;
+    const size_t cnt = sizeof(int) * OT3_HI + sizeof(uint16_t) * (OT3_PYR - OT3_HI), best = sizeof(int) * OT3_PYR;
+    const size_t nodes = nodes_in_hbm ? 0 : orbfe_octree3_node_bytes(max_nodes, sort_cap);
+    return ((cnt + 15) & ~(size_t)15) + (best > nodes ? best : nodes) + 64;
 }
 
 // root and quadrant path of a point down to `depth` (src/ORBextractor.cc:537-564 for the root, :145-209 for a split)
@@ -178,7 +195,7 @@ __device__ __forceinline__ void ot3_for_each_point(const int *cell_cnt, const ui
 }
 
 template <bool NODES_IN_HBM>
-__global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, DeviceBuffers buf, int sort_cap, size_t node_bytes, int blur_rows, int blur_t0, int blur_t1)
+__global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void octree3_kernel(DeviceConfig cfg, DeviceBuffers buf, int sort_cap, size_t node_bytes, int blur_rows, int blur_t0, int blur_t1)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     __shared__ int s_w[4 * OT3_WAVES];
@@ -214,19 +231,24 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
     OT3_PHASE();
     const int MAXN = cfg.max_nodes;
 
+    // LDS: counts of depths 0..3 (int), of depths 4 and 5 (uint16: entry e >= OT3_HI at s_c16[e - OT3_HI]), then the shared region:
+    // best-key pyramid until the pyramid step is done, node tables afterwards
     uint8_t *p = s_raw;
-    int *s_cnt = (int *)p; p += sizeof(int) * OT3_PYR;            // point counts, all depths 0..5
-    unsigned *s_best = (unsigned *)p; p += sizeof(int) * OT3_PYR; // best key, all depths
+    int *s_chi = (int *)p; p += sizeof(int) * OT3_HI;
+    uint16_t *s_c16 = (uint16_t *)p; p += sizeof(uint16_t) * (OT3_PYR - OT3_HI);
+    p = (uint8_t *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+    unsigned *s_best = (unsigned *)p; // best key, all depths (steps 1 and 2 only)
+    unsigned *g_best = buf.bk_best + ((size_t)img * cfg.nlevels + level) * OT3_PYR; // ... and where it lives afterwards
+    auto cnt_at = [&](int e) -> int { return e < OT3_HI ? s_chi[e] : (int)s_c16[e - OT3_HI]; };
     // deep path only: s_bend[1 + b] = end of bucket b in the sorted arrays.  Kept in HBM scratch so that the LDS
-    // footprint lets two workgroups share a CU.
+    // footprint lets several workgroups share a CU.
     int *s_bend = buf.bk_end + ((size_t)img * cfg.nlevels + level) * (OT3_BUCKETS + 1);
     // Node tables: LDS when they fit beside the pyramids (NODES_IN_HBM = false); otherwise the workgroup's slice of an HBM
     // scratch buffer -- many features on few levels (a level's node capacity ~ its quota) must not be a create-time error.
     if (NODES_IN_HBM) p = buf.ot3_scratch + ((size_t)img * cfg.nlevels + level) * node_bytes;
-    unsigned long long *s_key = (unsigned long long *)p; p += sizeof(unsigned long long) * sort_cap;
     Ot3Nodes A, B;
-    ot3_bind(A, p, MAXN);
-    ot3_bind(B, p, MAXN);
+    ot3_bind(A, p, MAXN, sort_cap);
+    ot3_bind(B, p, MAXN, sort_cap);
     int *s_ccnt = (int *)p; p += sizeof(int) * 4 * MAXN; // child counts per node
     int *s_rank = (int *)p; p += sizeof(int) * MAXN;     // processing rank (-1: not processed this pass)
     int *s_plist = (int *)p; p += sizeof(int) * MAXN;    // processing order -> node
@@ -254,8 +276,11 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
     //      per bucket in LDS; bk_emap (host-built) names the bucket of every entry.  The candidates of cells without entries
     //      (more than 64 buckets under one cell: levels whose buckets are ~3 px) are bucketed here from the cell slots. ----
     {
-        int *cnt5 = s_cnt + ot3_off(OT3_DB);
+        // depth-5 counts: 16 bit each, summed with 32-bit LDS atomics on the word that holds the pair (a bucket's total stays below
+        // 2^16, so nothing carries into the neighbour)
+        unsigned *cnt5w = (unsigned *)(s_c16 + (ot3_off(OT3_DB) - OT3_HI));
         unsigned *best5 = s_best + ot3_off(OT3_DB);
+        auto cnt5_add = [&](int b, int v) { atomicAdd(&cnt5w[b >> 1], (unsigned)v << (16 * (b & 1))); };
         // ten entries per thread in flight (one batch covers level 0 of a 752 x 480 frame); the first batch is issued before the LDS arrays are cleared
         const uint32_t *part = buf.bk_part + ib * cfg.bk_part_total + L.bk_part_off;
         const uint32_t *emap = buf.bk_emap + L.bk_part_off;
@@ -274,13 +299,14 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
 #pragma unroll
             for (int u = 0; u < U; u++)
                 if (pe[u] & 0xfffu) {
-                    atomicAdd(&cnt5[be[u] & 0xffffu], (int)(pe[u] & 0xfffu));
+                    cnt5_add((int)(be[u] & 0xffffu), (int)(pe[u] & 0xfffu));
                     atomicMax(&best5[be[u] & 0xffffu], ORBFE_BK_PART_KEY(pe[u], be[u] >> 16));
                 }
         };
         load(0);
         const uint4 zero = {0u, 0u, 0u, 0u};
-        for (int i = tid; i < OT3_BUCKETS / 4; i += OT3_THREADS) { ((uint4 *)cnt5)[i] = zero; ((uint4 *)best5)[i] = zero; }
+        for (int i = tid; i < OT3_BUCKETS / 4; i += OT3_THREADS) ((uint4 *)best5)[i] = zero;
+        for (int i = tid; i < OT3_BUCKETS / 8; i += OT3_THREADS) ((uint4 *)cnt5w)[i] = zero;
         __syncthreads();
         apply();
         for (int e0 = U * OT3_THREADS; e0 < n_part; e0 += U * OT3_THREADS) { load(e0); apply(); }
@@ -292,7 +318,7 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
                 int root;
                 const unsigned path = ot3_path((int)(xy & 0xffffu), (int)(xy >> 16), OT3_DB, hx, n_ini, region_h, root);
                 const int b = (root << (2 * OT3_DB)) + (int)path;
-                atomicAdd(&cnt5[b], 1);
+                cnt5_add(b, 1);
                 atomicMax(&best5[b], OT3_KEY(sc, c, k));
             };
             for (int idx = tid; idx < 16 * L.n_cells; idx += OT3_THREADS) {
@@ -316,26 +342,27 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
         const int o = ot3_off(d), oc = ot3_off(d + 1);
         for (int e = tid; e < n_e; e += OT3_THREADS) {
             const int c = oc + 4 * e;
-            s_cnt[o + e] = s_cnt[c] + s_cnt[c + 1] + s_cnt[c + 2] + s_cnt[c + 3];
+            const int sum = cnt_at(c) + cnt_at(c + 1) + cnt_at(c + 2) + cnt_at(c + 3);
+            if (o + e < OT3_HI) s_chi[o + e] = sum; else s_c16[o + e - OT3_HI] = (uint16_t)sum;
             const unsigned b0 = s_best[c], b1 = s_best[c + 1], b2 = s_best[c + 2], b3 = s_best[c + 3];
             const unsigned m01 = b0 > b1 ? b0 : b1, m23 = b2 > b3 ? b2 : b3;
             s_best[o + e] = m01 > m23 ? m01 : m23;
         }
         __syncthreads();
     }
+    // the best keys leave the LDS: the final selection reads them back from this workgroup's slice (its own stores: same L2),
+    // and their LDS region becomes the node tables
+    for (int i = tid; i < OT3_PYR / 4; i += OT3_THREADS) ((uint4 *)g_best)[i] = ((const uint4 *)s_best)[i];
+    __syncthreads();
     OT3_PHASE();
     // ---- roots (src/ORBextractor.cc:537-581) ----
     if (tid == 0) {
         int n = 0, nc = 0;
         for (int b = 0; b < n_ini; b++) {
-            const int c = s_cnt[b];
+            const int c = s_chi[b];
             nc += c;
             if (c > 0) {
-                A.x0[n] = (short)(int)__fmul_rn(hx, (float)b);
-                A.x1[n] = (short)(int)__fmul_rn(hx, (float)(b + 1));
-                A.y0[n] = 0;
-                A.y1[n] = (short)region_h;
-                A.cnt[n] = c; A.path[n] = 0u; A.dr[n] = b << 4;
+                A.cnt[n] = c; A.path[n] = 0u; A.dr[n] = b << 4; // the root's box (:541-557) is implied by b: see ot3_path
                 n++;
             }
         }
@@ -382,7 +409,7 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
                 const int dr = cur.dr[i], d = dr & 15, root = dr >> 4;
                 if (d < OT3_DB) {
                     const int c = ot3_off(d + 1) + 4 * ((root << (2 * d)) + (int)cur.path[i]);
-                    c0 = s_cnt[c]; c1 = s_cnt[c + 1]; c2 = s_cnt[c + 2]; c3 = s_cnt[c + 3];
+                    c0 = cnt_at(c); c1 = cnt_at(c + 1); c2 = cnt_at(c + 2); c3 = cnt_at(c + 3);
                 } else {
                     *s_deep = 1;
                 }
@@ -395,8 +422,8 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
         if (*s_deep) {
             if (!deep_ready && deep_ok) {
                 // counting sort of the candidates by bucket: s_bend[1 + b] runs from the bucket's start to its end
-                const int *cnt5 = s_cnt + ot3_off(OT3_DB);
-                for (int b = tid; b < OT3_BUCKETS; b += OT3_THREADS) s_bend[1 + b] = cnt5[b];
+                const uint16_t *cnt5 = s_c16 + (ot3_off(OT3_DB) - OT3_HI);
+                for (int b = tid; b < OT3_BUCKETS; b += OT3_THREADS) s_bend[1 + b] = (int)cnt5[b];
                 if (tid == 0) s_bend[0] = 0;
                 __syncthreads();
                 ot3_scan_array(s_bend + 1, OT3_BUCKETS, s_w);
@@ -424,17 +451,12 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
         }
 
         // child k of node i as new node q
-        auto emit = [&](int q, int i, int k, int cnt, int x0, int y0, int x1, int y1, int mx, int my) {
-            nxt.x0[q] = (short)((k & 1) ? mx : x0); nxt.x1[q] = (short)((k & 1) ? x1 : mx);
-            nxt.y0[q] = (short)((k & 2) ? my : y0); nxt.y1[q] = (short)((k & 2) ? y1 : my);
+        auto emit = [&](int q, int i, int k, int cnt) {
             nxt.cnt[q] = cnt;
             nxt.path[q] = (cur.path[i] << 2) | (unsigned)k;
             nxt.dr[q] = (cur.dr[i] & 15) < 15 ? cur.dr[i] + 1 : cur.dr[i]; // depth 15 = 1-px boxes: never multi-point
         };
-        auto copy_node = [&](int q, int i) {
-            nxt.x0[q] = cur.x0[i]; nxt.y0[q] = cur.y0[i]; nxt.x1[q] = cur.x1[i]; nxt.y1[q] = cur.y1[i];
-            nxt.cnt[q] = cur.cnt[i]; nxt.path[q] = cur.path[i]; nxt.dr[q] = cur.dr[i];
-        };
+        auto copy_node = [&](int q, int i) { nxt.cnt[q] = cur.cnt[i]; nxt.path[q] = cur.path[i]; nxt.dr[q] = cur.dr[i]; };
 
         int n_new, nexpand_fast = -1;
         if (!sorted_phase && n <= OT3_THREADS) {
@@ -466,13 +488,11 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
                 if (!multi) {
                     copy_node(total_k + v4[2], i);
                 } else {
-                    const int x0 = cur.x0[i], y0 = cur.y0[i], x1 = cur.x1[i], y1 = cur.y1[i];
-                    const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
                     int q = total_k - (v4[1] + k); // blocks of later-processed parents sit nearer the front; children n4..n1
-                    if (c3 > 0) emit(q++, i, 3, c3, x0, y0, x1, y1, mx, my);
-                    if (c2 > 0) emit(q++, i, 2, c2, x0, y0, x1, y1, mx, my);
-                    if (c1 > 0) emit(q++, i, 1, c1, x0, y0, x1, y1, mx, my);
-                    if (c0 > 0) emit(q++, i, 0, c0, x0, y0, x1, y1, mx, my);
+                    if (c3 > 0) emit(q++, i, 3, c3);
+                    if (c2 > 0) emit(q++, i, 2, c2);
+                    if (c1 > 0) emit(q++, i, 1, c1);
+                    if (c0 > 0) emit(q++, i, 0, c0);
                 }
             }
         } else {
@@ -484,10 +504,12 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
                     if (cur.cnt[i] > 1) s_plist[s_kk[i]] = i;
                 __syncthreads();
             } else {
-                // (size, pointer) order of the reference under contract Q3: count descending, list position ascending
+                // (size, pointer) order of the reference under contract Q3: count descending, list position ascending.  The keys are
+                // built in the node array of the NEXT pass (written only after the ranking; ot3_slot_bytes makes room)
+                unsigned long long *s_key = (unsigned long long *)nxt.cnt;
                 int P = 1;
                 while (P < m) P <<= 1;
-                if (m <= 2 * OT3_THREADS && nc < 65536) {
+                if (m <= 4 * OT3_THREADS && nc < 65536) {
                     // few keys (all distinct), counts and list positions below 2^16: 32-bit keys ranked by counting -- every thread
                     // compares its key(s) with all m, sixteen per step (four 128-bit broadcast reads in flight; with one key per
                     // step the loop is bound by LDS latency: 7-10 us of a workgroup's 30, tools/octree3_timeline.py); the rank is
@@ -579,15 +601,13 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
                     copy_node(total_k + s_plist[i], i);
                     continue;
                 }
-                const int x0 = cur.x0[i], y0 = cur.y0[i], x1 = cur.x1[i], y1 = cur.y1[i];
-                const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
                 const int c0 = s_ccnt[4 * i], c1 = s_ccnt[4 * i + 1], c2 = s_ccnt[4 * i + 2], c3 = s_ccnt[4 * i + 3];
                 const int k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
                 int q = total_k - (s_un[r] + k);
-                if (c3 > 0) emit(q++, i, 3, c3, x0, y0, x1, y1, mx, my);
-                if (c2 > 0) emit(q++, i, 2, c2, x0, y0, x1, y1, mx, my);
-                if (c1 > 0) emit(q++, i, 1, c1, x0, y0, x1, y1, mx, my);
-                if (c0 > 0) emit(q++, i, 0, c0, x0, y0, x1, y1, mx, my);
+                if (c3 > 0) emit(q++, i, 3, c3);
+                if (c2 > 0) emit(q++, i, 2, c2);
+                if (c1 > 0) emit(q++, i, 1, c1);
+                if (c0 > 0) emit(q++, i, 0, c0);
                 const int nexp = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
                 if (nexp) atomicAdd(s_nexpand, nexp);
             }
@@ -619,7 +639,7 @@ __global__ __launch_bounds__(OT3_THREADS) void octree3_kernel(DeviceConfig cfg, 
         const unsigned path = cur.path[i];
         unsigned key = 0u;
         if (d <= OT3_DB) {
-            key = s_best[ot3_off(d) + (root << (2 * d)) + (int)path];
+            key = g_best[ot3_off(d) + (root << (2 * d)) + (int)path];
         } else { // only reachable through deep_children, i.e. with the sorted arrays built
             const int b = (root << (2 * OT3_DB)) + (int)(path >> (2 * (d - OT3_DB)));
             for (int j = s_bend[b]; j < s_bend[b + 1]; j++) {
