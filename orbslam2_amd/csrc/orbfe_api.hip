@@ -642,6 +642,76 @@ try {
                 }
             }
         }
+        {   // plan of pyr_pair_kernel (levels l and l + 1 in one launch): tiles of TW words x TR extended rows of level l + 1; per tile
+            // column the words of level l (extended) its sources lie in and the words it stores, per tile row the same for rows.
+            // The stored ranges partition level l's extended domain; a tile computes the hull of both.
+            std::vector<int> plan;
+            const char *np = getenv("ORBFE_NO_PAIR");
+            const bool want = !(np && np[0] == '1');
+            ctx->cfg.pp_max_images = np && np[0] == '0' ? INT_MAX : 63; // ORBFE_NO_PAIR=0: pairs at every batch size (A/B)
+            for (int l = 1; l + 1 < p.nlevels; l++) {
+                LevelInfo &D1 = ctx->cfg.lv[l];
+                const LevelInfo &D2 = ctx->cfg.lv[l + 1];
+                D1.pp_ok = 0;
+                if (!want || !D1.rs_direct || !D2.rs_direct) continue;
+                const int nw1 = D1.rs_xtab_n >> 2, ny1 = D1.rs_ytab_n, nw2 = D2.rs_xtab_n >> 2, ny2 = D2.rs_ytab_n;
+                static const int k_tr[4] = {12, 11, 10, 8}, k_tw[6] = {48, 44, 40, 32, 24, 16};
+                for (int ci = 0; ci < 24 && !D1.pp_ok; ci++) { // the largest tile whose level-l rectangle fits 64 words x 16 rows
+                    const int TR = k_tr[ci / 6], TW = k_tw[ci % 6];
+                    const int ntx = (nw2 + TW - 1) / TW, nty = (ny2 + TR - 1) / TR;
+                    std::vector<int> px((size_t)ntx * 4), py((size_t)nty * 4);
+                    bool ok = true;
+                    int prev = 0;
+                    for (int t = 0; t < ntx && ok; t++) { // columns: sources of extended columns [4 TW t, ...) of level l + 1
+                        int lo = INT_MAX, hi = -1;
+                        for (int i = 4 * TW * t; i < std::min(4 * TW * (t + 1), D2.rs_xtab_n); i++) {
+                            const uint32_t e = tab[D2.rs_xtab_off + i];
+                            lo = std::min(lo, (int)std::min(e & 0xffffu, e >> 16)); hi = std::max(hi, (int)std::max(e & 0xffffu, e >> 16));
+                        }
+                        // the kernel's windows start at the word's computed first source byte and read 12 bytes from the 4-byte boundary below
+                        const int need0 = (lo + 4) >> 2, need1 = ((hi + 4) >> 2) + 1; // extended words [need0, need1) of level l (interior column c = extended byte c + 4)
+                        const int s0 = t == 0 ? 0 : std::max(prev, std::min(need0, prev)); // stores continue where the previous tile's ended
+                        const int s1 = t == ntx - 1 ? nw1 : need1;
+                        const int c0 = std::min(need0, s0), c1 = std::max(need1, s1);
+                        if (t > 0 && need0 > prev) ok = false; // a gap nobody would store
+                        px[4 * t] = c0; px[4 * t + 1] = c1 - c0; px[4 * t + 2] = s0; px[4 * t + 3] = std::max(s1, s0);
+                        if (c1 - c0 > 64 || c0 < 0 || c1 > nw1) ok = false;
+                        prev = std::max(s1, s0);
+                    }
+                    if (prev != nw1) ok = false;
+                    prev = 0;
+                    for (int t = 0; t < nty && ok; t++) {
+                        int lo = INT_MAX, hi = -1;
+                        for (int i = TR * t; i < std::min(TR * (t + 1), ny2); i++) {
+                            const uint32_t e = tab[D2.rs_ytab_off + i];
+                            lo = std::min(lo, (int)std::min(e & 0xffffu, e >> 16)); hi = std::max(hi, (int)std::max(e & 0xffffu, e >> 16));
+                        }
+                        const int need0 = lo + 3, need1 = hi + 3 + 1; // extended rows of level l (interior row r = extended row r + 3)
+                        const int s0 = t == 0 ? 0 : prev;
+                        const int s1 = t == nty - 1 ? ny1 : need1;
+                        if (t > 0 && need0 > prev) ok = false;
+                        const int c0 = std::min(need0, s0), c1 = std::max(need1, s1);
+                        py[4 * t] = c0; py[4 * t + 1] = c1 - c0; py[4 * t + 2] = s0; py[4 * t + 3] = std::max(s1, s0);
+                        if (c1 - c0 > 16 || c0 < 0 || c1 > ny1) ok = false;
+                        prev = std::max(s1, s0);
+                    }
+                    if (prev != ny1) ok = false;
+                    if (!ok) continue;
+                    D1.pp_ok = 1; D1.pp_ntx = ntx; D1.pp_nty = nty; D1.pp_tw = TW; D1.pp_tr = TR;
+                    D1.pp_xoff = (int)plan.size() / 4; plan.insert(plan.end(), px.begin(), px.end());
+                    D1.pp_yoff = (int)plan.size() / 4; plan.insert(plan.end(), py.begin(), py.end());
+                }
+                if (getenv("ORBFE_HOST_TRACE")) fprintf(stderr, "orbfe: levels %d + %d in one launch: %s (%d x %d tiles of %d words x %d rows)\n", l, l + 1, D1.pp_ok ? "yes" : "no", D1.pp_ntx, D1.pp_nty, D1.pp_tw, D1.pp_tr);
+            }
+            if (plan.empty()) plan.resize(4, 0);
+            int *d_pp = nullptr;
+            A(d_pp, plan.size());
+            if (hipMemcpy(d_pp, plan.data(), plan.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+                orbfe_destroy(ctx);
+                return fail(nullptr, ORBFE_ERR_HIP, "pyramid pair plan upload failed");
+            }
+            b.pair_plan = d_pp;
+        }
         while (tab.size() % 4) tab.push_back(0);
         if (tab.empty()) tab.resize(4, 0);
         uint32_t *d_tab = nullptr;

@@ -56,6 +56,9 @@ struct LevelInfo {
     int rs_src_rows[3];            // source rows spanned by the worst block of 16 / 8 / 4 output rows (pyr_resize_kernel)
     int rs_rw, rs_blk_off;         // rows per wave the launch uses (4 / 2 / 1) and this level's entries in DeviceBuffers::rs_blk
     int rs_direct, rs_dtab_off;    // pyr_resize_direct_kernel usable (every 4-column word's sources lie within 8 bytes) and its table: rs_xtab_n byte selectors, then rs_xtab_n / 4 first-source-byte offsets
+    // pyr_pair_kernel (this level and the next in one launch): usable, tile grid over the NEXT level's extended domain (tiles of
+    // pp_tw words x pp_tr rows), and this level's entries in DeviceBuffers::pair_plan (int4 units)
+    int pp_ok, pp_ntx, pp_nty, pp_tw, pp_tr, pp_xoff, pp_yoff;
     int bk_xoff, bk_yoff;          // quadtree bucket tables of this level in DeviceBuffers::bk_tab (orbfe_octree3.hip)
     int bk_part_off, bk_part_n;    // this level's per-cell bucket partials in DeviceBuffers::bk_part / bk_emap
     int bk_points;                 // some cell of the level spans > 64 buckets: the quadtree kernel buckets its candidates itself
@@ -78,6 +81,7 @@ struct DeviceConfig {
     int patch_n;           // entries in DeviceBuffers::patch_uv (multiple of 64)
     // fused pyramid tail (pyr_tail_kernel): the last tail_n levels (2 or 3) in one launch, 0 = not used
     int tail_first, tail_n, tail_strips;
+    int pp_max_images;                 // pyr_pair_kernel (two levels per launch) serves batches of up to this many images
     int tail_max_images;               // the fused tail serves batches of up to this many images; larger ones run levels tail_first.. as single launches
     int tail_src_words;                // staged words per row of level tail_first - 1 (widest strip)
     int tail_words[ORBFE_TAIL_MAX];    // words per row of stage s computed by the widest strip
@@ -152,6 +156,7 @@ struct DeviceBuffers {
     const uint4 *cell_info; // [cells_total] FAST cells: level | valid << 8, ini_x | ini_y << 16, tile w | h << 8, index inside the level (fast_cell_kernel)
     const uint32_t *blur_tile_info; // [blur_tiles_total] level | column strip << 8 | first row << 16 (blur_kernel)
     const uint32_t *rs_blk; // per (level, block of 4 * rs_rw output rows): first source row | source rows << 16 (pyr_resize_kernel)
+    const int *pair_plan;   // pyr_pair_kernel: per tile column / row of a level pair {first word (row) of the LDS tile, words (rows), first, end word (row) this workgroup stores}
     const int *tail_plan;   // [tail_strips][ORBFE_TAIL_MAX][4]: first extended column, words, first staged source column, staged words (pyr_tail_kernel)
     long long *dbg_ts;   // 4096 timestamps for kernel bring-up (ORBFE_OT2_STOP=99); never read by product code
     const uint8_t *slot_level; // [sel_total] level of every keypoint slot

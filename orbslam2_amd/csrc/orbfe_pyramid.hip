@@ -305,19 +305,34 @@ int orbfe_resize_word_base_host(int xw, int dst_w, double scale, int src_w) { re
 // alignment, so the 96-bit window is loaded at the row's own 4-byte boundary and the byte shift is per row; the one window that
 // could reach past the image's last byte (last source row, last words) is loaded 12 bytes before the image's end instead and
 // shifted into place.  The first workgroup of every image also clears the image's status word (ingest's job in copy mode).
+struct ResizeStoreGlobal { // the word of extended row y goes to the level's row in HBM
+    uint8_t *dst; int pitch;
+    __device__ __forceinline__ void operator()(int y, uint32_t out) const { *(uint32_t *)(dst + (ptrdiff_t)(y - PYR_MY) * pitch) = out; }
+};
+// word xw of the extended rows y0 .. min(y0 + RB, y_end) - 1 of `level`; store(y, word) receives the results
+template <int RB, bool PACKED0, class Store>
+__device__ __forceinline__ void resize_direct_rows(const DeviceConfig &cfg, const DeviceBuffers &buf, int level, int img, int xw, int y0, int y_end, Store store);
+
 template <int RB, bool PACKED0 = false>
 __device__ __forceinline__ void resize_direct_wave(const DeviceConfig &cfg, const DeviceBuffers &buf, int level, int img, int strip, int band)
+{
+    const LevelInfo &D = cfg.lv[level];
+    const int lane = threadIdx.x & 63;
+    if (PACKED0 && strip == 0 && band == 0 && lane == 0) buf.status[img] = 0;
+    const int xw = strip * 64 + lane;
+    const ResizeStoreGlobal st = {buf.pyr + (size_t)img * cfg.pyr_bytes + D.pyr_off + (xw * 4 - PYR_MX), D.pitch};
+    resize_direct_rows<RB, PACKED0>(cfg, buf, level, img, xw, band * RB, D.rs_ytab_n, st);
+}
+
+template <int RB, bool PACKED0, class Store>
+__device__ __forceinline__ void resize_direct_rows(const DeviceConfig &cfg, const DeviceBuffers &buf, int level, int img, int xw, int y0, int y_end, Store store)
 {
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     const LevelInfo &D = cfg.lv[level];
     const LevelInfo &S = cfg.lv[level - 1];
-    const int lane = threadIdx.x & 63;
-    if (PACKED0 && strip == 0 && band == 0 && lane == 0) buf.status[img] = 0;
     const int ny = D.rs_ytab_n, nx = D.rs_xtab_n, nwords = nx >> 2;
-    const int y0 = band * RB; // first extended row of this wave's band
-    if (y0 >= ny) return;
-    const int xw = strip * 64 + lane;
-    if (xw >= nwords) return; // no barriers: the spare lanes of the last strip just leave
+    if (y0 >= y_end) return;
+    if (xw >= nwords) return; // no barriers in here: the spare lanes of the last strip just leave
     const uint32_t *__restrict__ xt = buf.rs_tab + D.rs_xtab_off;
     const uint32_t *__restrict__ dt = buf.rs_tab + D.rs_dtab_off;
     // the row table through the constant address space: never written by a kernel, and only so does the compiler keep its
@@ -331,7 +346,6 @@ __device__ __forceinline__ void resize_direct_wave(const DeviceConfig &cfg, cons
     typedef win_v win_ld __attribute__((aligned(4)));
     struct win_t { uint32_t x, y, z; };
     auto ld_win = [](const uint8_t *p) { const win_v v = *(const win_ld *)p; win_t w; w.x = v.x; w.y = v.y; w.z = v.z; return w; };
-    uint8_t *dst = buf.pyr + (size_t)img * cfg.pyr_bytes + D.pyr_off + (xw * 4 - PYR_MX);
     const unsigned spitch = PACKED0 ? (unsigned)buf.lv0_pitch : (unsigned)S.pitch;
     const uint8_t *simg = PACKED0 ? buf.lv0 + (size_t)img * buf.lv0_stride : buf.pyr + (size_t)img * cfg.pyr_bytes + S.pyr_off;
     // copy mode: pixel (0,0) and the pitch are 4-byte aligned, the window's shift is the lane's own constant.  In place: offsets from
@@ -343,7 +357,7 @@ __device__ __forceinline__ void resize_direct_wave(const DeviceConfig &cfg, cons
     uint32_t ye[RB], yb[RB];
 #pragma unroll
     for (int k = 0; k < RB; k++) {
-        const int yy = y0 + k < ny ? y0 + k : ny - 1;
+        const int yy = y0 + k < y_end ? y0 + k : y_end - 1;
         ye[k] = yt[yy]; yb[k] = yt[ny + yy];
     }
     // window of source row `row`: 12 bytes from the 4-byte boundary at or below the lane's first source byte, and that byte's
@@ -383,7 +397,7 @@ __device__ __forceinline__ void resize_direct_wave(const DeviceConfig &cfg, cons
     unsigned hA[4], hB[4];
 #pragma unroll
     for (int k = 0; k < RB; k++) {
-        if (y0 + k >= ny) break; // uniform
+        if (y0 + k >= y_end) break; // uniform
         if (k > 0 && (ye[k] & 0xffffu) == (ye[k - 1] >> 16)) { // uniform: this row's upper source row is the previous row's lower one
 #pragma unroll
             for (int j = 0; j < 4; j++) hA[j] = hB[j];
@@ -399,7 +413,7 @@ __device__ __forceinline__ void resize_direct_wave(const DeviceConfig &cfg, cons
             const unsigned v1 = (unsigned)(((unsigned long long)(b1 & 0xffffffu) * (unsigned long long)(hB[j] & 0xffffffu)) >> 32);
             out |= ((v0 + v1 + 2u) >> 2) << (8 * j);
         }
-        *(uint32_t *)(dst + (ptrdiff_t)(y0 + k - PYR_MY) * D.pitch) = out;
+        store(y0 + k, out);
     }
 }
 
@@ -614,6 +628,111 @@ __global__ __launch_bounds__(256) void pyr_resize_blur_kernel(DeviceConfig cfg, 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Two pyramid levels per launch (round 4): level l from level l - 1 in HBM, and level l + 1 from the rows of level l the workgroup
+// has just computed, kept in LDS -- the dependent chain of the pyramid has one launch per PAIR of levels, and level l is not read
+// back from HBM for its own resize.  A workgroup owns a tile of PP_TW words x PP_TR extended rows of level l + 1.  Phase 1: its four
+// waves compute the rectangle of level l (extended coordinates) that the tile's sources lie in -- with pyr_resize_direct's waves,
+// results to an LDS tile (<= 64 words x 16 rows) and, for the part of the rectangle this workgroup is RESPONSIBLE for, to HBM: the
+// responsibility rectangles of all workgroups partition level l's extended domain (margins go to the border tiles), so every
+// pixel of level l is stored exactly once although neighbouring tiles' rectangles overlap by a column / row or two (computed by both:
+// same arithmetic, same bytes; ~12 % more level-l work).  Phase 2 (after one barrier): the same resize from the LDS tile (three
+// aligned LDS words per row and lane instead of a 96-bit global load, then the identical v_alignbyte / v_perm / v_dot2 passes).
+// Both levels must be resizable by the LDS-free kernel (LevelInfo::rs_direct); the host plans the rectangles from the same tables
+// (orbfe_api.hip: pair plan) and falls back to single-level launches when a rectangle would not fit.  ORBFE_NO_PAIR=1 disables it.
+// ---------------------------------------------------------------------------
+#define PP_LDS_ROWS 17 // 16 tile rows + one spare: a lane's 12-byte window may run past its row's last word
+template <bool PACKED0>
+__global__ __launch_bounds__(256) void pyr_pair_kernel(DeviceConfig cfg, DeviceBuffers buf, int l1, int n_pair, int tile_begin, int tile_end)
+{
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) uint32_t s_tile[PP_LDS_ROWS * 64];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int n_blur = (tile_end - tile_begin + 3) >> 2;
+    const int img = blockIdx.x;
+    if ((int)blockIdx.y < n_blur) { // the blur of the levels below rides in front (as in pyr_resize_blur_kernel)
+        const int u = tile_begin + (int)blockIdx.y * 4 + wave;
+        if (u < tile_end) blur_wave(cfg, buf, img, u);
+        return;
+    }
+    const int x = (int)blockIdx.y - n_blur;
+    if (x >= n_pair) return;
+    const LevelInfo &D1 = cfg.lv[l1];
+    const LevelInfo &D2 = cfg.lv[l1 + 1];
+    const int ntx = D1.pp_ntx;
+    const int ty = __builtin_amdgcn_readfirstlane(small_div(x, ntx)), tx = x - ty * ntx;
+    if (PACKED0 && x == 0 && threadIdx.x == 0) buf.status[img] = 0; // first launch of the chain when level 0 is read in place
+    const int4 px = ((const int4 *)buf.pair_plan)[D1.pp_xoff + tx]; // first word, words of the LDS tile; first, end word this group stores to HBM
+    const int4 py = ((const int4 *)buf.pair_plan)[D1.pp_yoff + ty]; // the same for rows
+    // ---- phase 1: level l1, rows py.x + 4 * wave ..., word px.x + lane ----
+    {
+        const int xw = px.x + lane, y0 = py.x + 4 * wave, y_end = py.x + py.y;
+        uint8_t *g = buf.pyr + (size_t)img * cfg.pyr_bytes + D1.pyr_off + (xw * 4 - PYR_MX);
+        const int pitch = D1.pitch;
+        const bool mine_x = xw >= px.z && xw < px.w;
+        uint32_t *t = s_tile + lane;
+        auto st = [&](int y, uint32_t out) {
+            t[(y - py.x) * 64] = out;
+            if (mine_x && y >= py.z && y < py.w) *(uint32_t *)(g + (ptrdiff_t)(y - PYR_MY) * pitch) = out;
+        };
+        if (lane < px.y) resize_direct_rows<4, PACKED0>(cfg, buf, l1, img, xw, y0, y_end, st);
+    }
+    __syncthreads();
+    // ---- phase 2: level l1 + 1 from the tile ----
+    const int nw2 = D2.rs_xtab_n >> 2, ny2 = D2.rs_ytab_n, nx2 = D2.rs_xtab_n;
+    const int xw2 = tx * D1.pp_tw + lane;
+    if (lane >= D1.pp_tw || xw2 >= nw2) return;
+    const int rb2 = (D1.pp_tr + 3) >> 2; // rows per wave
+    const int y2_0 = ty * D1.pp_tr + wave * rb2;
+    int y2_end = ty * D1.pp_tr + D1.pp_tr;
+    y2_end = y2_end < y2_0 + rb2 ? y2_end : y2_0 + rb2;
+    y2_end = y2_end < ny2 ? y2_end : ny2;
+    if (y2_0 >= y2_end) return;
+    typedef const __attribute__((address_space(4))) uint32_t *rs_const_ptr;
+    const rs_const_ptr yt = (rs_const_ptr)(uintptr_t)(buf.rs_tab + D2.rs_ytab_off);
+    const uint4 SEL = *(const uint4 *)(buf.rs_tab + D2.rs_dtab_off + 4 * xw2);
+    const uint4 WT = *(const uint4 *)(buf.rs_tab + D2.rs_xtab_off + nx2 + 4 * xw2);
+    const uint32_t sel[4] = {SEL.x, SEL.y, SEL.z, SEL.w}, wt[4] = {WT.x, WT.y, WT.z, WT.w};
+    const int base = resize_word_base(xw2, D2.w, D2.rs_scale_x, D1.w); // first source column (interior of level l1)
+    const int bo = base + PYR_MX - 4 * px.x;                            // ... as a byte of the tile row
+    const uint32_t *tw = s_tile + (bo >> 2);
+    const unsigned sh = (unsigned)bo & 3u;
+    auto hpass = [&](int srow, unsigned h[4]) { // source row as an interior row of level l1
+        const uint32_t *r = tw + (srow + PYR_MY - py.x) * 64;
+        const uint32_t w0 = r[0], w1 = r[1], w2 = r[2];
+        const unsigned lo = __builtin_amdgcn_alignbyte(w1, w0, sh), hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned pp = __builtin_amdgcn_perm(hi, lo, sel[j]);
+            h[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pp), __builtin_bit_cast(u16x2, wt[j]), 0u, false) & ~15u;
+        }
+    };
+    uint8_t *dst = buf.pyr + (size_t)img * cfg.pyr_bytes + D2.pyr_off + (xw2 * 4 - PYR_MX);
+    unsigned hA[4], hB[4];
+    int have = -1; // source row whose horizontal pass sits in hB
+    for (int y = y2_0; y < y2_end; y++) { // uniform
+        const uint32_t ye = yt[y], yb = yt[ny2 + y];
+        const int s0 = (int)(ye & 0xffffu), s1 = (int)(ye >> 16);
+        if (s0 == have) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) hA[j] = hB[j];
+        } else {
+            hpass(s0, hA);
+        }
+        hpass(s1, hB);
+        have = s1;
+        const unsigned b0 = (yb & 0xffffu) << 12, b1 = (yb >> 16) << 12;
+        uint32_t out = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned v0 = (unsigned)(((unsigned long long)(b0 & 0xffffffu) * (unsigned long long)(hA[j] & 0xffffffu)) >> 32);
+            const unsigned v1 = (unsigned)(((unsigned long long)(b1 & 0xffffffu) * (unsigned long long)(hB[j] & 0xffffffu)) >> 32);
+            out |= ((v0 + v1 + 2u) >> 2) << (8 * j);
+        }
+        *(uint32_t *)(dst + (ptrdiff_t)(y - PYR_MY) * D2.pitch) = out;
+    }
+}
+
 void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, const uint8_t *d_images, int n_images, hipStream_t s)
 {
     const int words = (cfg.lv[0].w + 12 + 3) / 4;
@@ -644,13 +763,27 @@ int orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int 
         // rows per wave: the largest of 4, 2, 1 whose staged source rows fit 60 KB of LDS (rs_src_rows[i] = source
         // row span of the worst block of 16 / 8 / 4 output rows, from the host's row table)
         const int *span = cfg.lv[l].rs_src_rows;
+        // Pairs serve the same batches as the fused tail (fewer than 64 images, where the chain of dependent launches is what a step
+        // waits for: a single stereo pair's five pyramid launches 48 us -> three 34 us, 8 pairs per step +6 %); at 128 images every
+        // per-level launch is throughput-bound and the pair kernel's ~15 % recomputed pixels and its barrier make the pyramid 15 us
+        // SLOWER (170 -> 185 us), so large batches keep one launch per level.  ORBFE_NO_PAIR=0 forces pairs, =1 forbids them.
+        if (cfg.lv[l].pp_ok && l + 1 <= last_single && n_images <= cfg.pp_max_images) { // this level and the next in one launch; the blur of every finished level rides along
+            const int t0 = fuse_blur ? cfg.lv[blurred].blur_tile_off : 0, t1 = fuse_blur ? cfg.lv[l - 1].blur_tile_off + cfg.lv[l - 1].blur_tiles_x * cfg.lv[l - 1].blur_tiles_y : 0;
+            const int n_pair = cfg.lv[l].pp_ntx * cfg.lv[l].pp_nty;
+            dim3 grid(n_images, n_pair + (t1 - t0 + 3) / 4);
+            if (l == 1 && buf.lv0_packed) hipLaunchKernelGGL(pyr_pair_kernel<true>, grid, dim3(256), 0, s, cfg, buf, l, n_pair, t0, t1);
+            else hipLaunchKernelGGL(pyr_pair_kernel<false>, grid, dim3(256), 0, s, cfg, buf, l, n_pair, t0, t1);
+            if (fuse_blur) blurred = l;
+            l++; // level l + 1 is done too
+            continue;
+        }
         if (cfg.lv[l].rs_direct) {
             const int nwords = cfg.lv[l].rs_xtab_n >> 2;
             constexpr int rb = ORBFE_PYR_RB > 0 ? ORBFE_PYR_RB : 8;
             const int strips = (nwords + 63) / 64, groups = (total_rows + 4 * rb - 1) / (4 * rb);
-            if (fuse_blur && blurred == l - 1) {
+            if (fuse_blur && blurred <= l - 1) { // every level finished by the earlier launches and not blurred yet
                 const LevelInfo &P = cfg.lv[l - 1];
-                const int t0 = P.blur_tile_off, t1 = t0 + P.blur_tiles_x * P.blur_tiles_y;
+                const int t0 = cfg.lv[blurred].blur_tile_off, t1 = P.blur_tile_off + P.blur_tiles_x * P.blur_tiles_y;
                 dim3 grid(n_images, strips * groups + (t1 - t0 + 3) / 4);
                 if (l == 1 && buf.lv0_packed) hipLaunchKernelGGL((pyr_resize_blur_kernel<rb, true>), grid, dim3(256), 0, s, cfg, buf, l, strips, strips * groups, t0, t1);
                 else hipLaunchKernelGGL(pyr_resize_blur_kernel<rb>, grid, dim3(256), 0, s, cfg, buf, l, strips, strips * groups, t0, t1);

@@ -1,7 +1,7 @@
 # same build, one environment variable off / on, 3 alternations.  usage: env_ab.sh VAR
 for r in 1 2 3; do
   for v in 1 0; do
-    env $1=$v timeout -k 10 200 python bench.py --cpu-pairs 0 --pipelined 0 --small-batch 0 --natural 0 --host-fed 0 --no-check  > gpurun_out/ab_env$v$r.json 2>/dev/null
+    env $1=$v timeout -k 10 200 python bench.py --cpu-pairs 0 --pipelined 0 --small-batch 0 --natural 0 --host-fed 0 --secondary 0 --no-check  > gpurun_out/ab_env$v$r.json 2>/dev/null
     python -c "
 import json;d=json.loads(open('gpurun_out/ab_env$v$r.json').read().strip().splitlines()[-1]);s=d['roofline']['stage_ms_per_step_summed_over_groups'];print('$1=$v', round(d['value']), ' '.join('%s=%.4f' % (k[:4], x) for k, x in s.items()))"
   done

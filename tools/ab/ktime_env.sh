@@ -4,7 +4,7 @@ cp tools/ab/$1.so orbslam2_amd/liborbfe.so
 export $3
 timeout -k 10 120 python3 bench.py --steps 3 --warmup 1 --cpu-pairs 0 --pipelined 0 --small-batch 0 --natural 0 --host-fed 0 > gpurun_out/kte.json 2> gpurun_out/kte.err || { echo "$3: bench with check failed"; tail -2 gpurun_out/kte.err; exit 0; }
 rm -rf gpurun_out/kt_$1
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_$1 -- python3 bench.py --steps 6 --warmup 2 --cpu-pairs 0 --pipelined 0 --small-batch 0 --natural 0 --host-fed 0 --no-check > /dev/null 2>&1 || exit 0
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_$1 -- python3 bench.py --steps 6 --warmup 2 --cpu-pairs 0 --pipelined 0 --small-batch 0 --natural 0 --host-fed 0 --secondary 0 --no-check > /dev/null 2>&1 || exit 0
 f=$(find gpurun_out/kt_$1 -name "*kernel_stats.csv" | head -1)
 python3 -c "
 import csv,re,sys

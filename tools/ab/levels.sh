@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 cp tools/ab/$1.so orbslam2_amd/liborbfe.so
 [ -n "$2" ] && export $2
 rm -rf gpurun_out/lv_$1
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/lv_$1 -- python3 bench.py --steps 6 --warmup 2 --cpu-pairs 0 --pipelined 0 --small-batch 0 --natural 0 --host-fed 0 --no-check > /dev/null 2>&1 || exit 1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/lv_$1 -- python3 bench.py --steps 6 --warmup 2 --cpu-pairs 0 --pipelined 0 --small-batch 0 --natural 0 --host-fed 0 --secondary 0 --no-check > /dev/null 2>&1 || exit 1
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("gpurun_out/lv_$1/**/*kernel_trace.csv", recursive=True)[0]

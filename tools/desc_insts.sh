@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for d in 1 2 3 0; do
   rm -rf gpurun_out/di$d
-  ORBFE_DESC_DBG=$d rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES --kernel-trace --output-format csv -d gpurun_out/di$d -- python3 bench.py --steps 2 --warmup 1 --cpu-pairs 0 --pipelined 0 --small-batch 0 --natural 0 --host-fed 0 --no-check > /dev/null 2>&1 || exit 1
+  ORBFE_DESC_DBG=$d rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES --kernel-trace --output-format csv -d gpurun_out/di$d -- python3 bench.py --steps 2 --warmup 1 --cpu-pairs 0 --pipelined 0 --small-batch 0 --natural 0 --host-fed 0 --secondary 0 --no-check > /dev/null 2>&1 || exit 1
   python3 tools/pmc_summary.py gpurun_out/di$d | grep describe | python3 -c "
 import sys,ast
 l=sys.stdin.read(); d=ast.literal_eval(l[l.index('{'):l.rindex('}')+1]); w=d['SQ_WAVES']

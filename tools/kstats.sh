@@ -2,7 +2,7 @@
 # quick per-kernel timing on the GPU box: rocprofv3 kernel trace + stats of a short bench run -> gpurun_out/kstats.csv,
 # and the pyramid launches split by level (launch order)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rm -rf gpurun_out/kst; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kst -- python3 bench.py --cpu-pairs 0 --pipelined 0 --small-batch 0 --natural 0 --host-fed 0 --no-check --steps 10 > gpurun_out/kst.json 2>/dev/null || exit 1
+rm -rf gpurun_out/kst; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kst -- python3 bench.py --cpu-pairs 0 --pipelined 0 --small-batch 0 --natural 0 --host-fed 0 --secondary 0 --no-check --steps 10 > gpurun_out/kst.json 2>/dev/null || exit 1
 cp gpurun_out/kst/*/*kernel_stats.csv gpurun_out/kstats.csv
 python3 - <<'PY'
 import csv, glob, collections, json

@@ -10,7 +10,7 @@ for set in "TA_TA_BUSY_sum TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ
            ; do  # a third set (TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum ...) aborted rocprofv3 and hung its shutdown: check names against avail.txt first
   tag=$(echo $set | cut -d' ' -f1)
   rm -rf $out/raw_$tag
-  timeout -k 10 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/raw_$tag -- python3 bench.py --steps 3 --warmup 1 --cpu-pairs 0 --pipelined 0 --small-batch 0 --natural 0 --host-fed 0 --no-check > /dev/null 2> $out/err_$tag.txt || { echo "pass $tag failed"; tail -3 $out/err_$tag.txt; continue; }
+  timeout -k 10 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/raw_$tag -- python3 bench.py --steps 3 --warmup 1 --cpu-pairs 0 --pipelined 0 --small-batch 0 --natural 0 --host-fed 0 --secondary 0 --no-check > /dev/null 2> $out/err_$tag.txt || { echo "pass $tag failed"; tail -3 $out/err_$tag.txt; continue; }
   python3 tools/pmc_summary.py $out/raw_$tag > $out/$tag.txt
   rm -rf $out/raw_$tag
 done

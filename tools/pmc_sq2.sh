@@ -7,7 +7,7 @@ for set in "SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr"; do
   tag=$(echo $set | cut -d' ' -f1)
   rm -rf gpurun_out/pmc2_$tag
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc2_$tag -- python3 bench.py --steps 3 --warmup 1 --cpu-pairs 0 --pipelined 0 --small-batch 0 --natural 0 --host-fed 0 --no-check  > /dev/null 2>&1 || { echo "pass $tag failed"; continue; }
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc2_$tag -- python3 bench.py --steps 3 --warmup 1 --cpu-pairs 0 --pipelined 0 --small-batch 0 --natural 0 --host-fed 0 --secondary 0 --no-check  > /dev/null 2>&1 || { echo "pass $tag failed"; continue; }
   python3 tools/pmc_summary.py gpurun_out/pmc2_$tag > gpurun_out/pmc2_$tag.txt
   rm -rf gpurun_out/pmc2_$tag
 done

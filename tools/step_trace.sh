@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=$1; shift
 for a in "$@"; do export "$a"; done
 rm -rf gpurun_out/st_$tag
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/st_$tag -- python3 bench.py --cpu-pairs 0 --pipelined 0 --small-batch 0 --natural 0 --host-fed 0 --no-check --steps 10 --repeat 2 > gpurun_out/st_$tag.json 2>/dev/null || exit 1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/st_$tag -- python3 bench.py --cpu-pairs 0 --pipelined 0 --small-batch 0 --natural 0 --host-fed 0 --secondary 0 --no-check --steps 10 --repeat 2 > gpurun_out/st_$tag.json 2>/dev/null || exit 1
 python3 - "$tag" <<'PY'
 import csv, glob, sys, collections
 tag = sys.argv[1]
