@@ -1106,7 +1106,10 @@ static void run_chain(orbfe_context *ctx, const uint8_t *d_images, int img0, int
     prof_mark(ctx, group, 1, s);
     const int blurred = orbfe_launch_pyramid(cfg, buf, n_images, ctx->fuse_blur, s);
     prof_mark(ctx, group, 2, s);
-    const bool blur_in_quadtree = ctx->use_octree3 && ctx->fuse_blur; // the levels still unblurred ride in the quadtree launch
+    // the levels still unblurred after the pyramid ride in the quadtree launch, whose workgroups mostly wait (at the head of FAST's
+    // launch instead they cost FAST 10 us for 3 us saved there, and the three extra kernel arguments alone cost FAST 8 us: it sits at
+    // its scalar-register limit; tools/experiments); ORBFE_NO_FUSE=1: a launch of their own
+    const bool blur_in_quadtree = ctx->use_octree3 && ctx->fuse_blur;
     if (!blur_in_quadtree) orbfe_launch_blur(cfg, buf, n_images, blurred, s);
     prof_mark(ctx, group, 3, s);
     orbfe_launch_fast(cfg, buf, n_images, ctx->use_octree3, s);

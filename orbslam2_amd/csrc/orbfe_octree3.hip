@@ -310,9 +310,14 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
         __syncthreads();
         apply();
         for (int e0 = U * OT3_THREADS; e0 < n_part; e0 += U * OT3_THREADS) { load(e0); apply(); }
+        OT3_PHASE();
         if (L.bk_points) {
             // sixteen lanes per cell (these levels have a handful of candidates per cell), everything a lane needs first loaded
-            // without waiting for the cell's count: slots beyond it are allocated but unused
+            // without waiting for the cell's count: slots beyond it are allocated but unused.  On the benchmark's dense images this
+            // phase is 14-18 us of the workgroups of levels 4-7, which end the launch (tools/octree3_timeline.py).  Round 4 measured
+            // three rewrites that all stayed at 14-19 us: the bucket from the host tables instead of ot3_path, four / six items per
+            // thread with every load issued first, 32 lanes x 2 preloaded slots per cell -- each trades dependent round trips (~2 us
+            // under this launch's load) against VALU issue (the four workgroups of a CU are of one level and in this phase together)
             const uint32_t *bk_off = buf.bk_off + L.cell_off;
             auto put = [&](uint32_t xy, unsigned sc, int c, int k) {
                 int root;
@@ -353,7 +358,10 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
     // the best keys leave the LDS: the final selection reads them back from this workgroup's slice (its own stores: same L2),
     // and their LDS region becomes the node tables
     for (int i = tid; i < OT3_PYR / 4; i += OT3_THREADS) ((uint4 *)g_best)[i] = ((const uint4 *)s_best)[i];
-    __syncthreads();
+    // the region may be overwritten once every wave has READ its part (the stores carry the data in registers): wait for the LDS
+    // reads only, not for the stores' round trip (__syncthreads waits for vmcnt(0): 4 us here); the stores have long landed when
+    // the final selection reads the slice, many barriers later
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     OT3_PHASE();
     // ---- roots (src/ORBextractor.cc:537-581) ----
     if (tid == 0) {

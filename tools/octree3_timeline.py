@@ -31,4 +31,4 @@ for l in range(8):
     if len(v) > 1:
         d = np.diff(v)
         # after the roots: one entry per full pass, then the largest-first pass as child counts + scan | ranking | k scan | nproc | flag scan | build
-        print("level %d phases (us): buckets %.1f  pyramid %.1f  roots, passes: %s  final %.1f" % (l, d[0], d[1], " ".join("%.1f" % x for x in d[2:-1]), d[-1]))
+        print("level %d phases (us): partials %.1f  points %.1f  pyramid %.1f  roots, passes: %s  final %.1f" % (l, d[0], d[1], d[2], " ".join("%.1f" % x for x in d[3:-1]), d[-1]))

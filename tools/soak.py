@@ -61,6 +61,12 @@ for i in range(n):
     ok = (np.array_equal(out["kps_left"], kl.astype(api.KP_DTYPE)) and np.array_equal(out["kps_right"], kr.astype(api.KP_DTYPE)) and
           np.array_equal(out["desc_left"], dl) and np.array_equal(out["desc_right"], dr) and np.array_equal(out["u_right"], ur) and
           np.array_equal(out["depth"], dp))
+    # round 4: the packed result block of the same (still resident) frame must expand to the very same records
+    blk, lay = ctx.fetch_packed(2, api.PACK_STEREO)
+    pl, pr = ctx.expand_packed(blk, lay, 0), ctx.expand_packed(blk, lay, 1)
+    ok = ok and (pl["kps"].tobytes() == out["kps_left"].tobytes() and pr["kps"].tobytes() == out["kps_right"].tobytes() and
+                 np.array_equal(pl["desc"], out["desc_left"]) and np.array_equal(pr["desc"], out["desc_right"]) and
+                 pl["u_right"].tobytes() == out["u_right"].tobytes() and pl["depth"].tobytes() == out["depth"].tobytes())
     if not ok:
         bad += 1
         print("MISMATCH case", i, w, h, kw)
