@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ORBFE_ABI_VERSION 5 /* 2: orbfe_frame_view.device_slot_plus1; 3: .keyframe; 4: orbfe_get_camera, orbfe_assign_features_to_grid, orbfe_stereo_batch, orbfe_device_count, orbfe_set_profiling_interval; 5: orbfe_get_packed_layout, orbfe_fetch_batch_packed, orbfe_expand_packed, orbfe_enqueue_rgbd */
+#define ORBFE_ABI_VERSION 5 /* 2: orbfe_frame_view.device_slot_plus1; 3: .keyframe; 4: orbfe_get_camera, orbfe_assign_features_to_grid, orbfe_stereo_batch, orbfe_device_count, orbfe_set_profiling_interval; 5: orbfe_get_packed_layout, orbfe_fetch_batch_packed, orbfe_expand_packed, orbfe_stereo_batch_packed, orbfe_enqueue_rgbd */
 
 enum {
     ORBFE_OK = 0,
@@ -253,6 +253,10 @@ int orbfe_fetch_batch_packed(orbfe_context *ctx, int n_images, int flags, void *
  * at the layout's offsets.  *n = keypoint count. */
 int orbfe_expand_packed(const orbfe_context *ctx, const void *host_block, const orbfe_packed_layout *layout, int out_image,
                         orbfe_keypoint *kps, int cap, int *n);
+/* orbfe_stereo_batch with the packed block as its result (ORBFE_PACK_STEREO is implied): upload, one stage chain, one gather
+ * kernel, one copy into host_block (any host memory; ORBFE_PACK_DIRECT needs pinned memory), synchronised on return.
+ * What orbslam2_amd/host/multi_device.h runs per context. */
+int orbfe_stereo_batch_packed(orbfe_context *ctx, const uint8_t *images, int n_pairs, int flags, void *host_block, size_t host_bytes);
 /* N RGB-D frames in one chain (BASELINE.json config 5 batched; multi-camera RGB-D, CMakeLists.txt:145-146): extraction of the
  * n_images grey device images + Frame::ComputeStereoFromRGBD (src/Frame.cc:645-666) for every slot.  d_depth: n_images depth maps
  * packed one after the other (w*h elements each), float metres or, depth_is_u16 != 0, raw uint16 scaled by depth_map_factor

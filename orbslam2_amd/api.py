@@ -34,7 +34,7 @@ EXPORTS = [
     "orbfe_pose_optimization", "orbfe_pose_optimization_batch", "orbfe_enqueue_pose_optimization", "orbfe_set_input_format", "orbfe_fetch_batch_async", "orbfe_set_rectification", "orbfe_set_distortion", "orbfe_undistort_keypoints", "orbfe_fetch_keys_un", "orbfe_image_bounds",
     "orbfe_png_last_error", "orbfe_png_info", "orbfe_png_decode", "orbfe_png_decode_batch",
     "orbfe_get_camera", "orbfe_assign_features_to_grid", "orbfe_set_profiling_interval", "orbfe_stereo_batch", "orbfe_device_count", "orbfe_vocab_bytes",
-    "orbfe_get_packed_layout", "orbfe_fetch_batch_packed", "orbfe_expand_packed", "orbfe_enqueue_rgbd",
+    "orbfe_get_packed_layout", "orbfe_fetch_batch_packed", "orbfe_expand_packed", "orbfe_enqueue_rgbd", "orbfe_stereo_batch_packed",
 ]
 NUM_STAGES = 8
 STAGE_NAMES = ["ingest", "pyramid", "blur", "fast", "octree", "describe", "stereo_match", "stereo_median"]  # orbfe_stage_name()

@@ -1676,6 +1676,26 @@ try {
     return ORBFE_OK;
 } ORBFE_CATCH(ctx)
 
+// The same batch with the packed result block (one gather kernel + one copy, about two thirds the bytes; orbfe_expand_packed on the host).
+extern "C" int orbfe_stereo_batch_packed(orbfe_context *ctx, const uint8_t *images, int n_pairs, int flags, void *host_block, size_t host_bytes)
+try {
+    ORBFE_ENTRY(ctx);
+    if (!ctx || !images || !host_block) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    if (n_pairs < 1 || 2 * n_pairs > ctx->params.max_images) return fail(ctx, ORBFE_ERR_CAPACITY, "n_pairs %d needs max_images >= %d", n_pairs, 2 * n_pairs);
+    HIP_TRY(ctx, hipSetDevice(ctx->params.device));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_in, images, (size_t)2 * n_pairs * ctx->cfg.in_image_bytes, hipMemcpyHostToDevice, ctx->stream));
+    int rc = orbfe_enqueue_stereo(ctx, ctx->d_in, n_pairs, nullptr);
+    if (rc != ORBFE_OK) return rc;
+    rc = orbfe_fetch_batch_packed(ctx, 2 * n_pairs, flags | ORBFE_PACK_STEREO, host_block, host_bytes, nullptr);
+    if (rc != ORBFE_OK) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int> status((size_t)2 * n_pairs);
+    HIP_TRY(ctx, hipMemcpy(status.data(), ctx->buf.status, sizeof(int) * 2 * n_pairs, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 2 * n_pairs; i++)
+        if (status[i] != 0) return fail(ctx, ORBFE_ERR_CAPACITY, "device-side capacity overflow (status %d) on image %d", status[i], i);
+    return ORBFE_OK;
+} ORBFE_CATCH(ctx)
+
 extern "C" int orbfe_stereo_frame(orbfe_context *ctx, const uint8_t *left, const uint8_t *right,
                                   int w, int h, size_t stride,
                                   orbfe_keypoint *kps_left, uint8_t *desc_left, int *n_left,

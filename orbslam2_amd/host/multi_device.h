@@ -65,8 +65,9 @@ public:
             L.device = p.device;
             L.cap = orbfe_keypoint_capacity(L.ctx);
             L.images.resize((size_t)2 * share * mImageBytes);
-            L.kps.resize((size_t)2 * share * L.cap); L.desc.resize((size_t)2 * share * L.cap * 32);
-            L.ur.resize((size_t)2 * share * L.cap); L.dp.resize((size_t)2 * share * L.cap); L.counts.resize((size_t)2 * share);
+            orbfe_packed_layout lay; // the largest block this context returns (round 4: results come down packed, one copy per step)
+            if (orbfe_get_packed_layout(L.ctx, 2 * share, ORBFE_PACK_STEREO, &lay) != ORBFE_OK) throw std::runtime_error("orbfe_get_packed_layout failed");
+            L.block.resize(lay.bytes);
             L.thread = std::thread(&MultiDeviceFrontEnd::Feed, this, i);
         }
         } catch (...) { // a failed allocation or thread start after some feeders run: stop and join them (a joinable std::thread must not be destroyed)
@@ -109,10 +110,7 @@ private:
         std::thread thread;
         bool go = false;
         std::string error;
-        std::vector<uint8_t> images, desc;
-        std::vector<orbfe_keypoint> kps;
-        std::vector<float> ur, dp;
-        std::vector<int32_t> counts;
+        std::vector<uint8_t> images, block; // this context's pairs, packed L0 R0 L1 R1 ...; its packed result block (include/orbfe.h)
     };
 
     void Feed(int i)
@@ -131,18 +129,32 @@ private:
             try {
                 for (size_t j = 0; j < mine.size(); j++) // this context's pairs, packed L0 R0 L1 R1 ...
                     std::memcpy(&L.images[2 * j * mImageBytes], pairs + (size_t)2 * mine[j] * mImageBytes, 2 * mImageBytes);
-                if (orbfe_stereo_batch(L.ctx, L.images.data(), (int)mine.size(), L.kps.data(), L.desc.data(), L.counts.data(), L.ur.data(), L.dp.data()) != ORBFE_OK)
+                const int n_mine = (int)mine.size();
+                orbfe_packed_layout lay;
+                if (orbfe_get_packed_layout(L.ctx, 2 * n_mine, ORBFE_PACK_STEREO, &lay) != ORBFE_OK ||
+                    orbfe_stereo_batch_packed(L.ctx, L.images.data(), n_mine, 0, L.block.data(), L.block.size()) != ORBFE_OK)
                     throw std::runtime_error(orbfe_last_error(L.ctx));
-                for (size_t j = 0; j < mine.size(); j++) { // gather in frame order
+                const uint8_t *blk = L.block.data();
+                const size_t cap = (size_t)lay.capacity;
+                // expand on the host with the reference's own operations (pt = level coordinates * mvScaleFactor[octave],
+                // src/ORBextractor.cc:909-915; size = scaledPatchSize, :838), gather in frame order
+                auto keys = [&](int o, std::vector<orbfe_keypoint> &dst) {
+                    const int n = ((const int32_t *)(blk + lay.counts_off))[o];
+                    dst.resize((size_t)n);
+                    int got = 0;
+                    if (orbfe_expand_packed(L.ctx, blk, &lay, o, dst.data(), n, &got) != ORBFE_OK || got != n) throw std::runtime_error("orbfe_expand_packed failed");
+                    return n;
+                };
+                for (int j = 0; j < n_mine; j++) {
                     StereoPairResult &r = (*out)[mine[j]];
-                    const size_t l = 2 * j, rr = 2 * j + 1;
-                    const int nl = L.counts[l], nr = L.counts[rr];
-                    r.mvKeys.assign(&L.kps[l * L.cap], &L.kps[l * L.cap] + nl);
-                    r.mvKeysRight.assign(&L.kps[rr * L.cap], &L.kps[rr * L.cap] + nr);
-                    r.mDescriptors.assign(&L.desc[l * L.cap * 32], &L.desc[l * L.cap * 32] + (size_t)nl * 32);
-                    r.mDescriptorsRight.assign(&L.desc[rr * L.cap * 32], &L.desc[rr * L.cap * 32] + (size_t)nr * 32);
-                    r.mvuRight.assign(&L.ur[l * L.cap], &L.ur[l * L.cap] + nl);
-                    r.mvDepth.assign(&L.dp[l * L.cap], &L.dp[l * L.cap] + nl);
+                    const int l = 2 * j, rr = 2 * j + 1;
+                    const int nl = keys(l, r.mvKeys), nr = keys(rr, r.mvKeysRight);
+                    const uint8_t *dl = blk + lay.desc_off + (size_t)l * cap * 32, *dr = blk + lay.desc_off + (size_t)rr * cap * 32;
+                    r.mDescriptors.assign(dl, dl + (size_t)nl * 32);
+                    r.mDescriptorsRight.assign(dr, dr + (size_t)nr * 32);
+                    const float *ur = (const float *)(blk + lay.u_right_off) + (size_t)j * cap, *dp = (const float *)(blk + lay.depth_off) + (size_t)j * cap;
+                    r.mvuRight.assign(ur, ur + nl);
+                    r.mvDepth.assign(dp, dp + nl);
                 }
             } catch (const std::exception &e) {
                 L.error = e.what();

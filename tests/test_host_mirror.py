@@ -72,7 +72,7 @@ def test_multi_device_host_shards_like_dist():
     for n, world in ((64, 8), (7, 3), (2, 4)):
         for r in range(world):
             assert D.shard_pairs(n, r, world) == list(range(r, n, world))
-    assert "orbfe_stereo_batch(" in text and "#include <hip" not in text  # the C ABI only: compiles with plain g++
+    assert "orbfe_stereo_batch_packed(" in text and "orbfe_expand_packed(" in text and "#include <hip" not in text  # the C ABI only (packed result block, expanded on the host): compiles with plain g++
 
 
 @pytest.mark.gpu
