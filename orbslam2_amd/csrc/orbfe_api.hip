@@ -649,6 +649,7 @@ try {
             const char *np = getenv("ORBFE_NO_PAIR");
             const bool want = !(np && np[0] == '1');
             ctx->cfg.pp_max_images = np && np[0] == '0' ? INT_MAX : 63; // ORBFE_NO_PAIR=0: pairs at every batch size (A/B)
+            { const char *rl = getenv("ORBFE_RS_LOOKUP"); ctx->cfg.rs_lookup = rl && (rl[0] == '0' || rl[0] == '1') ? rl[0] - '0' : -1; }
             for (int l = 1; l + 1 < p.nlevels; l++) {
                 LevelInfo &D1 = ctx->cfg.lv[l];
                 const LevelInfo &D2 = ctx->cfg.lv[l + 1];

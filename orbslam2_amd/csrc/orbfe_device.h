@@ -81,6 +81,7 @@ struct DeviceConfig {
     int patch_n;           // entries in DeviceBuffers::patch_uv (multiple of 64)
     // fused pyramid tail (pyr_tail_kernel): the last tail_n levels (2 or 3) in one launch, 0 = not used
     int tail_first, tail_n, tail_strips;
+    int rs_lookup;                     // pyr_resize_direct: first source byte of a word from the table (1), from the formula (0), by batch size (-1)
     int pp_max_images;                 // pyr_pair_kernel (two levels per launch) serves batches of up to this many images
     int tail_max_images;               // the fused tail serves batches of up to this many images; larger ones run levels tail_first.. as single launches
     int tail_src_words;                // staged words per row of level tail_first - 1 (widest strip)

@@ -310,10 +310,13 @@ struct ResizeStoreGlobal { // the word of extended row y goes to the level's row
     __device__ __forceinline__ void operator()(int y, uint32_t out) const { *(uint32_t *)(dst + (ptrdiff_t)(y - PYR_MY) * pitch) = out; }
 };
 // word xw of the extended rows y0 .. min(y0 + RB, y_end) - 1 of `level`; store(y, word) receives the results
-template <int RB, bool PACKED0, class Store>
+// LOOKUP: the word's first source byte from the host table instead of the double-precision formula: 45 fewer VALU instructions per
+// wave (a fifth of the kernel) for one more dependent load -- used for batches of 64 images and more, whose launches are bound by
+// instruction issue (0.3 VALU per output pixel), not by the latency of a wave's load chain (round 4: pyramid + blur 174 -> 168 us in the stage table, value + 0.9 %)
+template <int RB, bool PACKED0, class Store, bool LOOKUP = false>
 __device__ __forceinline__ void resize_direct_rows(const DeviceConfig &cfg, const DeviceBuffers &buf, int level, int img, int xw, int y0, int y_end, Store store);
 
-template <int RB, bool PACKED0 = false>
+template <int RB, bool PACKED0 = false, bool LOOKUP = false>
 __device__ __forceinline__ void resize_direct_wave(const DeviceConfig &cfg, const DeviceBuffers &buf, int level, int img, int strip, int band)
 {
     const LevelInfo &D = cfg.lv[level];
@@ -321,10 +324,10 @@ __device__ __forceinline__ void resize_direct_wave(const DeviceConfig &cfg, cons
     if (PACKED0 && strip == 0 && band == 0 && lane == 0) buf.status[img] = 0;
     const int xw = strip * 64 + lane;
     const ResizeStoreGlobal st = {buf.pyr + (size_t)img * cfg.pyr_bytes + D.pyr_off + (xw * 4 - PYR_MX), D.pitch};
-    resize_direct_rows<RB, PACKED0>(cfg, buf, level, img, xw, band * RB, D.rs_ytab_n, st);
+    resize_direct_rows<RB, PACKED0, ResizeStoreGlobal, LOOKUP>(cfg, buf, level, img, xw, band * RB, D.rs_ytab_n, st);
 }
 
-template <int RB, bool PACKED0, class Store>
+template <int RB, bool PACKED0, class Store, bool LOOKUP>
 __device__ __forceinline__ void resize_direct_rows(const DeviceConfig &cfg, const DeviceBuffers &buf, int level, int img, int xw, int y0, int y_end, Store store)
 {
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -339,7 +342,7 @@ __device__ __forceinline__ void resize_direct_rows(const DeviceConfig &cfg, cons
     // (wave-uniform) reads scalar loads whatever stores to the pyramid are around
     typedef const __attribute__((address_space(4))) uint32_t *rs_const_ptr;
     const rs_const_ptr yt = (rs_const_ptr)(uintptr_t)(buf.rs_tab + D.rs_ytab_off);
-    const int base = resize_word_base(xw, D.w, D.rs_scale_x, S.w);
+    const int base = LOOKUP ? (int)dt[nx + xw] : resize_word_base(xw, D.w, D.rs_scale_x, S.w); // orbfe_create checks the formula against the table
     // three words in ONE global_load_dwordx3 (a struct of three fields is split into two overlapping 64-bit loads as soon as its
     // fields are selected between, as the clamped-window fix-up below does)
     typedef uint32_t win_v __attribute__((ext_vector_type(3)));
@@ -417,11 +420,11 @@ __device__ __forceinline__ void resize_direct_rows(const DeviceConfig &cfg, cons
     }
 }
 
-template <int RB, bool PACKED0 = false>
+template <int RB, bool PACKED0 = false, bool LOOKUP = false>
 __global__ __launch_bounds__(256) void pyr_resize_direct_kernel(DeviceConfig cfg, DeviceBuffers buf, int level)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    resize_direct_wave<RB, PACKED0>(cfg, buf, level, blockIdx.z, blockIdx.x, (int)blockIdx.y * 4 + wave);
+    resize_direct_wave<RB, PACKED0, LOOKUP>(cfg, buf, level, blockIdx.z, blockIdx.x, (int)blockIdx.y * 4 + wave);
 }
 
 // ---------------------------------------------------------------------------
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(256) void blur_kernel(DeviceConfig cfg, DeviceBuffe
 // resize lives on many short waves); 16- / 8-row blur bands in the interleaved order 0.189 / 0.192; s_setprio 3 for the
 // resize waves: no change.  So what the fusion buys is the launch boundary and the drain of the blur's last waves, 4 x ~1 us.
 // ORBFE_NO_FUSE=1 (orbfe_create) keeps the launches apart.
-template <int RB, bool PACKED0 = false>
+template <int RB, bool PACKED0 = false, bool LOOKUP = false>
 __global__ __launch_bounds__(256) void pyr_resize_blur_kernel(DeviceConfig cfg, DeviceBuffers buf, int level, int strips, int n_resize, int tile_begin, int tile_end)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -621,7 +624,7 @@ __global__ __launch_bounds__(256) void pyr_resize_blur_kernel(DeviceConfig cfg, 
     const int img = blockIdx.x, x = (int)blockIdx.y < n_blur ? n_resize + (int)blockIdx.y : (int)blockIdx.y - n_blur;
     if (x < n_resize) {
         const int bg = __builtin_amdgcn_readfirstlane(small_div(x, strips));
-        resize_direct_wave<RB, PACKED0>(cfg, buf, level, img, x - bg * strips, bg * 4 + wave);
+        resize_direct_wave<RB, PACKED0, LOOKUP>(cfg, buf, level, img, x - bg * strips, bg * 4 + wave);
     } else {
         const int u = tile_begin + (x - n_resize) * 4 + wave;
         if (u < tile_end) blur_wave(cfg, buf, img, u);
@@ -754,6 +757,7 @@ int orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int 
     // the chain's latency: 8 pairs per step 46.9 k pairs/s against 45.4 k), three direct launches carry the blur of the level below
     // and leave the last blur launch one level instead of four (64 pairs: 86.4 k -> 87.0 k, three chains in flight 96.2 -> 96.9 k)
     const bool tail = cfg.tail_first && n_images <= cfg.tail_max_images;
+    const bool lookup = cfg.rs_lookup == 1 || (cfg.rs_lookup < 0 && n_images >= 64); // ORBFE_RS_LOOKUP=1 | 0 forces; default: large batches
     const int last_single = tail ? cfg.tail_first - 1 : cfg.nlevels - 1;
     int blurred = 0; // levels 0 .. blurred - 1 have had their blur launched (beside the resize that reads them)
     for (int l = 1; l <= last_single; l++) {
@@ -785,13 +789,19 @@ int orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int 
                 const LevelInfo &P = cfg.lv[l - 1];
                 const int t0 = cfg.lv[blurred].blur_tile_off, t1 = P.blur_tile_off + P.blur_tiles_x * P.blur_tiles_y;
                 dim3 grid(n_images, strips * groups + (t1 - t0 + 3) / 4);
-                if (l == 1 && buf.lv0_packed) hipLaunchKernelGGL((pyr_resize_blur_kernel<rb, true>), grid, dim3(256), 0, s, cfg, buf, l, strips, strips * groups, t0, t1);
-                else hipLaunchKernelGGL(pyr_resize_blur_kernel<rb>, grid, dim3(256), 0, s, cfg, buf, l, strips, strips * groups, t0, t1);
+                const bool packed = l == 1 && buf.lv0_packed;
+                if (packed && lookup) hipLaunchKernelGGL((pyr_resize_blur_kernel<rb, true, true>), grid, dim3(256), 0, s, cfg, buf, l, strips, strips * groups, t0, t1);
+                else if (packed) hipLaunchKernelGGL((pyr_resize_blur_kernel<rb, true, false>), grid, dim3(256), 0, s, cfg, buf, l, strips, strips * groups, t0, t1);
+                else if (lookup) hipLaunchKernelGGL((pyr_resize_blur_kernel<rb, false, true>), grid, dim3(256), 0, s, cfg, buf, l, strips, strips * groups, t0, t1);
+                else hipLaunchKernelGGL((pyr_resize_blur_kernel<rb, false, false>), grid, dim3(256), 0, s, cfg, buf, l, strips, strips * groups, t0, t1);
                 blurred = l;
             } else {
                 dim3 grid(strips, groups, n_images);
-                if (l == 1 && buf.lv0_packed) hipLaunchKernelGGL((pyr_resize_direct_kernel<rb, true>), grid, dim3(256), 0, s, cfg, buf, l);
-                else hipLaunchKernelGGL(pyr_resize_direct_kernel<rb>, grid, dim3(256), 0, s, cfg, buf, l);
+                const bool packed = l == 1 && buf.lv0_packed;
+                if (packed && lookup) hipLaunchKernelGGL((pyr_resize_direct_kernel<rb, true, true>), grid, dim3(256), 0, s, cfg, buf, l);
+                else if (packed) hipLaunchKernelGGL((pyr_resize_direct_kernel<rb, true, false>), grid, dim3(256), 0, s, cfg, buf, l);
+                else if (lookup) hipLaunchKernelGGL((pyr_resize_direct_kernel<rb, false, true>), grid, dim3(256), 0, s, cfg, buf, l);
+                else hipLaunchKernelGGL((pyr_resize_direct_kernel<rb, false, false>), grid, dim3(256), 0, s, cfg, buf, l);
             }
         } else if (cfg.lv[l].rs_rw == 4) {
             dim3 grid((total_rows + 15) / 16, n_images);
