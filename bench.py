@@ -693,10 +693,13 @@ def main():
     # --backend gloo with ORBFE_BENCH_ONE_GPU=1 rehearses the multi-rank path on a one-GPU box (all ranks on device 0,
     # collectives on CPU tensors); the real run is one rank per GPU over RCCL.
     one_gpu = args.backend == "gloo" and os.environ.get("ORBFE_BENCH_ONE_GPU") == "1"
-    if not one_gpu and torch.cuda.device_count() < world:
+    ndev = torch.cuda.device_count()
+    # a launcher may give every rank its own single visible device (HIP_VISIBLE_DEVICES per rank): then the rank's GPU is index 0
+    masked = not one_gpu and world > 1 and ndev == 1 and os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))) is not None
+    if not one_gpu and not masked and ndev < world:
         raise SystemExit("bench: %d ranks but only %d GPU(s) visible (one rank per GPU; ORBFE_BENCH_ONE_GPU=1 --backend gloo rehearses on one)"
-                         % (world, torch.cuda.device_count()))
-    gpu_index = 0 if one_gpu else local_rank
+                         % (world, ndev))
+    gpu_index = 0 if (one_gpu or masked) else local_rank
     torch.cuda.set_device(gpu_index)
     dev = torch.device("cuda", gpu_index)
     cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
