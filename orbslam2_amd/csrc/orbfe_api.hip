@@ -724,49 +724,6 @@ try {
         b.rs_tab = d_tab;
     }
     std::vector<uint32_t> bk_tab_host;
-    {   // quadtree bucket tables (orbfe_octree3.hip): root and depth-5 path bits of every x / y of each level's
-        // candidate region, with the reference's arithmetic (src/ORBextractor.cc:537-564 roots, :145-209 splits)
-        std::vector<uint32_t> &tab = bk_tab_host;
-        auto spread5 = [](unsigned v) { unsigned r = 0; for (int i = 0; i < 5; i++) r |= ((v >> i) & 1u) << (2 * i); return r; };
-        for (int l = 0; l < p.nlevels; l++) {
-            LevelInfo &L = ctx->cfg.lv[l];
-            const int region_w = (L.w - p.edge_threshold + 3) - c.min_border, region_h = (L.h - p.edge_threshold + 3) - c.min_border;
-            L.bk_xoff = (int)tab.size();
-            for (int x = 0; x < region_w; x++) {
-                int b = (int)((float)x / L.hx);
-                b = b < 0 ? 0 : (b >= L.n_ini ? L.n_ini - 1 : b);
-                int x0 = (int)(L.hx * (float)b), x1 = (int)(L.hx * (float)(b + 1));
-                unsigned col = 0;
-                for (int d = 0; d < ORBFE_BK_DEPTH; d++) {
-                    const int mx = x0 + ((x1 - x0 + 1) >> 1);
-                    const int cx = x < mx ? 0 : 1;
-                    col = (col << 1) | (unsigned)cx;
-                    if (cx) x0 = mx; else x1 = mx;
-                }
-                tab.push_back(((unsigned)b << 10) | spread5(col) | (((unsigned)b * 32u + col) << 16));
-            }
-            L.bk_yoff = (int)tab.size();
-            for (int y = 0; y < region_h; y++) {
-                int y0 = 0, y1 = region_h;
-                unsigned row = 0;
-                for (int d = 0; d < ORBFE_BK_DEPTH; d++) {
-                    const int my = y0 + ((y1 - y0 + 1) >> 1);
-                    const int cy = y < my ? 0 : 1;
-                    row = (row << 1) | (unsigned)cy;
-                    if (cy) y0 = my; else y1 = my;
-                }
-                tab.push_back((spread5(row) << 1) | (row << 16));
-            }
-        }
-        if (tab.empty()) tab.resize(4, 0);
-        uint32_t *d_tab = nullptr;
-        A(d_tab, tab.size());
-        if (hipMemcpy(d_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
-            orbfe_destroy(ctx);
-            return fail(nullptr, ORBFE_ERR_HIP, "bucket table upload failed");
-        }
-        b.bk_tab = d_tab;
-    }
     {   // FAST cell table: what fast_cell_kernel's prologue would otherwise derive per wave from a chain of dependent scalar loads
         // (level search over lv[].cell_off, a division by n_cols, the clipping of src/ORBextractor.cc:783-800)
         std::vector<uint32_t> ci((size_t)c.cells_total * 4, 0u);
@@ -804,6 +761,79 @@ try {
         std::vector<uint32_t> off((size_t)c.cells_total, 0u);
         std::vector<uint32_t> emap;
         auto spread5 = [](unsigned v) { unsigned r = 0; for (int i = 0; i < 5; i++) r |= ((v >> i) & 1u) << (2 * i); return r; };
+        // Quadtree bucket tables (orbfe_octree3.hip): root and path bits down to the level's bucket depth of every x / y of the
+        // level's candidate region, with the reference's arithmetic (src/ORBextractor.cc:537-564 roots, :145-209 splits):
+        //   X[x] = root << 2 depth | x path bits spread to the even positions | (root * 2^depth + column) << 16
+        //   Y[y] = y path bits spread to the odd positions | row << 16
+        // Bucket depth per level (round 4): 5, or 4 where some FAST cell of the level spans more than 64 depth-5 buckets (the small
+        // levels, whose depth-5 buckets are ~3 px: their candidates were bucketed one by one inside the quadtree kernel, 14-18 us of
+        // those workgroups, which ended the launch).  A quota of ~200 nodes over 4 roots splits down to depth 3-4; nodes deeper than
+        // the level's bucket depth take the kernel's slow path as before.
+        auto build_tabs = [&](const LevelInfo &L, int depth, std::vector<uint32_t> &X, std::vector<uint32_t> &Y) {
+            const int region_w = (L.w - p.edge_threshold + 3) - c.min_border, region_h = (L.h - p.edge_threshold + 3) - c.min_border;
+            X.clear(); Y.clear();
+            for (int x = 0; x < region_w; x++) {
+                int b = (int)((float)x / L.hx);
+                b = b < 0 ? 0 : (b >= L.n_ini ? L.n_ini - 1 : b);
+                int x0 = (int)(L.hx * (float)b), x1 = (int)(L.hx * (float)(b + 1));
+                unsigned col = 0;
+                for (int d = 0; d < depth; d++) {
+                    const int mx = x0 + ((x1 - x0 + 1) >> 1);
+                    const int cx = x < mx ? 0 : 1;
+                    col = (col << 1) | (unsigned)cx;
+                    if (cx) x0 = mx; else x1 = mx;
+                }
+                X.push_back(((unsigned)b << (2 * depth)) | spread5(col) | ((((unsigned)b << depth) + col) << 16));
+            }
+            for (int y = 0; y < region_h; y++) {
+                int y0 = 0, y1 = region_h;
+                unsigned row = 0;
+                for (int d = 0; d < depth; d++) {
+                    const int my = y0 + ((y1 - y0 + 1) >> 1);
+                    const int cy = y < my ? 0 : 1;
+                    row = (row << 1) | (unsigned)cy;
+                    if (cy) y0 = my; else y1 = my;
+                }
+                Y.push_back((spread5(row) << 1) | (row << 16));
+            }
+        };
+        auto max_cell_buckets = [&](const LevelInfo &L, const std::vector<uint32_t> &X, const std::vector<uint32_t> &Y) {
+            int worst = 0;
+            for (int k = 0; k < L.n_cells; k++) {
+                const uint32_t *e = &ci[(size_t)(L.cell_off + k) * 4];
+                if (!(e[0] & 0x100u)) continue;
+                const int cx0 = (int)(e[1] & 0xffffu) - c.min_border, cy0 = (int)(e[1] >> 16) - c.min_border;
+                const int iw = (int)(e[2] & 0xffu) - 6, ih = (int)((e[2] >> 8) & 0xffu) - 6;
+                const int nb = ((int)(X[3 + cx0 + iw - 1] >> 16) - (int)(X[3 + cx0] >> 16) + 1) * ((int)(Y[3 + cy0 + ih - 1] >> 16) - (int)(Y[3 + cy0] >> 16) + 1);
+                worst = std::max(worst, nb);
+            }
+            return worst;
+        };
+        {
+            const char *bd = getenv("ORBFE_BK_DEPTH5"); // test knob: 1 = depth 5 on every level (round 3's layout: small levels bucket their candidates in the quadtree kernel)
+            std::vector<uint32_t> X, Y;
+            for (int l = 0; l < p.nlevels; l++) {
+                LevelInfo &L = ctx->cfg.lv[l];
+                L.bk_depth = ORBFE_BK_DEPTH;
+                build_tabs(L, ORBFE_BK_DEPTH, X, Y);
+                if (!(bd && bd[0] == '1') && max_cell_buckets(L, X, Y) > 64) {
+                    std::vector<uint32_t> X4, Y4;
+                    build_tabs(L, ORBFE_BK_DEPTH - 1, X4, Y4);
+                    if (max_cell_buckets(L, X4, Y4) <= 64) { L.bk_depth = ORBFE_BK_DEPTH - 1; X.swap(X4); Y.swap(Y4); }
+                }
+                L.bk_xoff = (int)bk_tab_host.size(); bk_tab_host.insert(bk_tab_host.end(), X.begin(), X.end());
+                L.bk_yoff = (int)bk_tab_host.size(); bk_tab_host.insert(bk_tab_host.end(), Y.begin(), Y.end());
+                if (getenv("ORBFE_HOST_TRACE")) fprintf(stderr, "orbfe: level %d quadtree bucket depth %d\n", l, L.bk_depth);
+            }
+            if (bk_tab_host.empty()) bk_tab_host.resize(4, 0);
+            uint32_t *d_tab = nullptr;
+            A(d_tab, bk_tab_host.size());
+            if (hipMemcpy(d_tab, bk_tab_host.data(), bk_tab_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+                orbfe_destroy(ctx);
+                return fail(nullptr, ORBFE_ERR_HIP, "bucket table upload failed");
+            }
+            b.bk_tab = d_tab;
+        }
         for (int l = 0; l < p.nlevels; l++) {
             LevelInfo &L = ctx->cfg.lv[l];
             L.bk_part_off = (int)emap.size();
@@ -820,7 +850,8 @@ try {
                 if (nb > 64) { off[L.cell_off + k] = ~0u; L.bk_points = 1; continue; }
                 for (int j = 0; j < nb; j++) {
                     const unsigned gx = (unsigned)(gx0 + j % ncols), by = (unsigned)(by0 + j / ncols);
-                    emap.push_back(((gx >> 5) << 10) | spread5(gx & 31u) | (spread5(by) << 1) | ((uint32_t)k << 16));
+                    const int dp = L.bk_depth;
+                    emap.push_back(((gx >> dp) << (2 * dp)) | spread5(gx & ((1u << dp) - 1u)) | (spread5(by) << 1) | ((uint32_t)k << 16));
                 }
             }
             L.bk_part_n = (int)emap.size() - L.bk_part_off;

@@ -61,6 +61,7 @@ struct LevelInfo {
     int pp_ok, pp_ntx, pp_nty, pp_tw, pp_tr, pp_xoff, pp_yoff;
     int bk_xoff, bk_yoff;          // quadtree bucket tables of this level in DeviceBuffers::bk_tab (orbfe_octree3.hip)
     int bk_part_off, bk_part_n;    // this level's per-cell bucket partials in DeviceBuffers::bk_part / bk_emap
+    int bk_depth;                  // quadtree bucket depth of this level: 5, or 4 where a FAST cell would span more than 64 depth-5 buckets
     int bk_points;                 // some cell of the level spans > 64 buckets: the quadtree kernel buckets its candidates itself
 };
 

@@ -200,19 +200,18 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     __shared__ int s_w[4 * OT3_WAVES];
     __shared__ int s_scal[8];
-    // The first blur_rows rows of the grid are not quadtree workgroups: their eight waves blur tiles [blur_t0, blur_t1) of the image
-    // (the levels no pyramid launch has blurred; describe_kernel is the first reader).  The quadtree workgroups are latency-bound and
-    // leave the chip mostly idle, so those memory-bound waves cost next to nothing here -- their own launch cost 9 us (level 7 of a
-    // 64-pair batch) to 21 us.
-    if ((int)blockIdx.y < blur_rows) {
-        const int u = blur_t0 + (int)blockIdx.y * OT3_WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // The LAST blur_rows rows of the grid are not quadtree workgroups: their waves blur tiles [blur_t0, blur_t1) of the image (the
+    // levels no pyramid launch has blurred; describe_kernel is the first reader).  The quadtree workgroups are latency-bound and leave
+    // the chip mostly idle, so those memory-bound waves cost little here -- their own launch cost 9 us (level 7 of a 64-pair batch) to
+    // 21 us.  Last, because every workgroup of this launch holds one of a CU's four LDS slots (the dynamic LDS size is per launch): at
+    // the head of the grid the blur kept a quarter of the quadtree workgroups waiting for ~9 us (round 4: launch 41.5 -> 38 us).
+    if ((int)blockIdx.y >= cfg.nlevels) {
+        const int u = blur_t0 + ((int)blockIdx.y - cfg.nlevels) * OT3_WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         if (u < blur_t1) blur_wave(cfg, buf, blockIdx.x, u);
         return;
     }
-    // longest first: the workgroups of level 0 (largest quota, most split passes) are dispatched before those of level 1, ...; with
-    // one or two LDS-filling workgroups per CU the launch then ends about (total work / CUs) after the last level-0 group, instead of
-    // every round of (image, all levels) groups waiting for its level-0 member
-    const int img = blockIdx.x, level = (int)blockIdx.y - blur_rows;
+    // longest first: the workgroups of level 0 (largest quota, most split passes) are dispatched before those of level 1, ...
+    const int img = blockIdx.x, level = (int)blockIdx.y;
     const LevelInfo &L = cfg.lv[level];
     const int tid = threadIdx.x;
 #ifdef ORBFE_PROFILE_CUTS // tools/octree3_timeline.py (`make cuts` build only): start / end of the first 2048 workgroups and the phase
@@ -271,6 +270,7 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
     const int region_h = (L.h - cfg.edge_threshold + 3) - cfg.min_border;
     const int n_ini = L.n_ini, quota = L.quota;
     const float hx = L.hx;
+    const int db = L.bk_depth; // this level's bucket depth: 5, or 4 (small levels: orbfe_create picks it so that every FAST cell has bucket partials)
 
     // ---- 1. buckets: the per-cell partial (count, best key) entries of fast_cell_kernel<.., true> (phase E), summed / maximised
     //      per bucket in LDS; bk_emap (host-built) names the bucket of every entry.  The candidates of cells without entries
@@ -278,8 +278,8 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
     {
         // depth-5 counts: 16 bit each, summed with 32-bit LDS atomics on the word that holds the pair (a bucket's total stays below
         // 2^16, so nothing carries into the neighbour)
-        unsigned *cnt5w = (unsigned *)(s_c16 + (ot3_off(OT3_DB) - OT3_HI));
-        unsigned *best5 = s_best + ot3_off(OT3_DB);
+        unsigned *cnt5w = (unsigned *)(s_c16 + (ot3_off(db) - OT3_HI)); // (names from the depth-5 case)
+        unsigned *best5 = s_best + ot3_off(db);
         auto cnt5_add = [&](int b, int v) { atomicAdd(&cnt5w[b >> 1], (unsigned)v << (16 * (b & 1))); };
         // ten entries per thread in flight (one batch covers level 0 of a 752 x 480 frame); the first batch is issued before the LDS arrays are cleared
         const uint32_t *part = buf.bk_part + ib * cfg.bk_part_total + L.bk_part_off;
@@ -305,8 +305,9 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
         };
         load(0);
         const uint4 zero = {0u, 0u, 0u, 0u};
-        for (int i = tid; i < OT3_BUCKETS / 4; i += OT3_THREADS) ((uint4 *)best5)[i] = zero;
-        for (int i = tid; i < OT3_BUCKETS / 8; i += OT3_THREADS) ((uint4 *)cnt5w)[i] = zero;
+        const int n_bk = OT3_ROOTS << (2 * db); // 4096 or 1024 buckets
+        for (int i = tid; i < n_bk / 4; i += OT3_THREADS) ((uint4 *)best5)[i] = zero;
+        for (int i = tid; i < n_bk / 8; i += OT3_THREADS) ((uint4 *)cnt5w)[i] = zero;
         __syncthreads();
         apply();
         for (int e0 = U * OT3_THREADS; e0 < n_part; e0 += U * OT3_THREADS) { load(e0); apply(); }
@@ -321,8 +322,8 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
             const uint32_t *bk_off = buf.bk_off + L.cell_off;
             auto put = [&](uint32_t xy, unsigned sc, int c, int k) {
                 int root;
-                const unsigned path = ot3_path((int)(xy & 0xffffu), (int)(xy >> 16), OT3_DB, hx, n_ini, region_h, root);
-                const int b = (root << (2 * OT3_DB)) + (int)path;
+                const unsigned path = ot3_path((int)(xy & 0xffffu), (int)(xy >> 16), db, hx, n_ini, region_h, root);
+                const int b = (root << (2 * db)) + (int)path;
                 cnt5_add(b, 1);
                 atomicMax(&best5[b], OT3_KEY(sc, c, k));
             };
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
     __syncthreads();
     OT3_PHASE();
     // ---- 2. pyramid ----
-    for (int d = OT3_DB - 1; d >= 0; d--) {
+    for (int d = db - 1; d >= 0; d--) {
         const int n_e = OT3_ROOTS << (2 * d);
         const int o = ot3_off(d), oc = ot3_off(d + 1);
         for (int e = tid; e < n_e; e += OT3_THREADS) {
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
     // child counts of a node deeper than the buckets: replay the paths of its bucket's points
     auto deep_children = [&](int dr, unsigned path, int c[4]) {
         const int d = dr & 15, root = dr >> 4;
-        const int b = (root << (2 * OT3_DB)) + (int)(path >> (2 * (d - OT3_DB)));
+        const int b = (root << (2 * db)) + (int)(path >> (2 * (d - db)));
         c[0] = c[1] = c[2] = c[3] = 0;
         for (int j = s_bend[b]; j < s_bend[b + 1]; j++) {
             const uint32_t xy = deep_xy[j];
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
             const int multi = cur.cnt[i] > 1;
             if (multi) {
                 const int dr = cur.dr[i], d = dr & 15, root = dr >> 4;
-                if (d < OT3_DB) {
+                if (d < db) {
                     const int c = ot3_off(d + 1) + 4 * ((root << (2 * d)) + (int)cur.path[i]);
                     c0 = cnt_at(c); c1 = cnt_at(c + 1); c2 = cnt_at(c + 2); c3 = cnt_at(c + 3);
                 } else {
@@ -430,15 +431,16 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
         if (*s_deep) {
             if (!deep_ready && deep_ok) {
                 // counting sort of the candidates by bucket: s_bend[1 + b] runs from the bucket's start to its end
-                const uint16_t *cnt5 = s_c16 + (ot3_off(OT3_DB) - OT3_HI);
-                for (int b = tid; b < OT3_BUCKETS; b += OT3_THREADS) s_bend[1 + b] = (int)cnt5[b];
+                const uint16_t *cnt5 = s_c16 + (ot3_off(db) - OT3_HI);
+                const int n_bk = OT3_ROOTS << (2 * db);
+                for (int b = tid; b < n_bk; b += OT3_THREADS) s_bend[1 + b] = (int)cnt5[b];
                 if (tid == 0) s_bend[0] = 0;
                 __syncthreads();
-                ot3_scan_array(s_bend + 1, OT3_BUCKETS, s_w);
+                ot3_scan_array(s_bend + 1, n_bk, s_w);
                 ot3_for_each_point(cell_cnt, cell_xy, cell_sc, L.n_cells, cfg.cell_cap, [&](uint32_t xy, unsigned sc, int cell, int slot) {
                     int root;
-                    const unsigned path = ot3_path((int)(xy & 0xffffu), (int)(xy >> 16), OT3_DB, hx, n_ini, region_h, root);
-                    const int b = (root << (2 * OT3_DB)) + (int)path;
+                    const unsigned path = ot3_path((int)(xy & 0xffffu), (int)(xy >> 16), db, hx, n_ini, region_h, root);
+                    const int b = (root << (2 * db)) + (int)path;
                     const int pos = atomicAdd(&s_bend[1 + b], 1);
                     deep_xy[pos] = xy;
                     deep_key[pos] = OT3_KEY(sc, cell, slot);
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
             }
             for (int i = tid; i < n; i += OT3_THREADS) {
                 const int dr = cur.dr[i];
-                if (cur.cnt[i] > 1 && (dr & 15) >= OT3_DB) {
+                if (cur.cnt[i] > 1 && (dr & 15) >= db) {
                     int c[4] = {0, 0, 0, 0};
                     if (deep_ready && (dr & 15) < 15) deep_children(dr, cur.path[i], c);
                     else { c[0] = cur.cnt[i]; } // cannot be refined (capacity guards only): keep the node whole
@@ -646,10 +648,10 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
         const int dr = cur.dr[i], d = dr & 15, root = dr >> 4;
         const unsigned path = cur.path[i];
         unsigned key = 0u;
-        if (d <= OT3_DB) {
+        if (d <= db) {
             key = g_best[ot3_off(d) + (root << (2 * d)) + (int)path];
         } else { // only reachable through deep_children, i.e. with the sorted arrays built
-            const int b = (root << (2 * OT3_DB)) + (int)(path >> (2 * (d - OT3_DB)));
+            const int b = (root << (2 * db)) + (int)(path >> (2 * (d - db)));
             for (int j = s_bend[b]; j < s_bend[b + 1]; j++) {
                 const uint32_t xy = deep_xy[j];
                 int r;
