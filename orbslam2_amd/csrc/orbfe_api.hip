@@ -836,6 +836,7 @@ try {
         }
         for (int l = 0; l < p.nlevels; l++) {
             LevelInfo &L = ctx->cfg.lv[l];
+            while (emap.size() % 4) emap.push_back(0); // octree3_kernel reads a level's entries as 128-bit quads: 16-byte aligned start, padded end (the padding's bk_part words stay zero: no cell owns them)
             L.bk_part_off = (int)emap.size();
             L.bk_points = 0;
             for (int k = 0; k < L.n_cells; k++) {
@@ -854,6 +855,7 @@ try {
                     emap.push_back(((gx >> dp) << (2 * dp)) | spread5(gx & ((1u << dp) - 1u)) | (spread5(by) << 1) | ((uint32_t)k << 16));
                 }
             }
+            while (emap.size() % 4) emap.push_back(0);
             L.bk_part_n = (int)emap.size() - L.bk_part_off;
         }
         ctx->cfg.bk_part_total = (int)emap.size();

@@ -281,27 +281,32 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
         unsigned *cnt5w = (unsigned *)(s_c16 + (ot3_off(db) - OT3_HI)); // (names from the depth-5 case)
         unsigned *best5 = s_best + ot3_off(db);
         auto cnt5_add = [&](int b, int v) { atomicAdd(&cnt5w[b >> 1], (unsigned)v << (16 * (b & 1))); };
-        // ten entries per thread in flight (one batch covers level 0 of a 752 x 480 frame); the first batch is issued before the LDS arrays are cleared
+        // 24 entries per thread in flight as six 128-bit loads of each array (one batch = 6144 entries covers level 0 of a KITTI frame;
+        // with ten dword loads per array and 256 threads that level was three dependent load rounds: 7 us of the launch's critical
+        // path); orbfe_create starts every level's entries on a 16-byte boundary (padding entries are zero and never written); the
+        // first batch is issued before the LDS arrays are cleared
         const uint32_t *part = buf.bk_part + ib * cfg.bk_part_total + L.bk_part_off;
         const uint32_t *emap = buf.bk_emap + L.bk_part_off;
         const int n_part = L.bk_part_n;
-        constexpr int U = 10;
-        uint32_t pe[U], be[U];
+        constexpr int U = 6;
+        uint4 pe[U], be[U];
         auto load = [&](int e0) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int e = e0 + u * OT3_THREADS + tid;
-                pe[u] = 0u; be[u] = 0u;
-                if (e < n_part) { pe[u] = part[e]; be[u] = emap[e]; }
+                const int e = e0 + 4 * (u * OT3_THREADS + tid);
+                pe[u] = make_uint4(0u, 0u, 0u, 0u); be[u] = pe[u];
+                if (e < n_part) { pe[u] = *(const uint4 *)(part + e); be[u] = *(const uint4 *)(emap + e); } // whole quads exist: the level's range is padded to a multiple of 4
+            }
+        };
+        auto apply1 = [&](uint32_t p1, uint32_t b1) {
+            if (p1 & 0xfffu) {
+                cnt5_add((int)(b1 & 0xffffu), (int)(p1 & 0xfffu));
+                atomicMax(&best5[b1 & 0xffffu], ORBFE_BK_PART_KEY(p1, b1 >> 16));
             }
         };
         auto apply = [&]() {
 #pragma unroll
-            for (int u = 0; u < U; u++)
-                if (pe[u] & 0xfffu) {
-                    cnt5_add((int)(be[u] & 0xffffu), (int)(pe[u] & 0xfffu));
-                    atomicMax(&best5[be[u] & 0xffffu], ORBFE_BK_PART_KEY(pe[u], be[u] >> 16));
-                }
+            for (int u = 0; u < U; u++) { apply1(pe[u].x, be[u].x); apply1(pe[u].y, be[u].y); apply1(pe[u].z, be[u].z); apply1(pe[u].w, be[u].w); }
         };
         load(0);
         const uint4 zero = {0u, 0u, 0u, 0u};
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
         for (int i = tid; i < n_bk / 8; i += OT3_THREADS) ((uint4 *)cnt5w)[i] = zero;
         __syncthreads();
         apply();
-        for (int e0 = U * OT3_THREADS; e0 < n_part; e0 += U * OT3_THREADS) { load(e0); apply(); }
+        for (int e0 = 4 * U * OT3_THREADS; e0 < n_part; e0 += 4 * U * OT3_THREADS) { load(e0); apply(); }
         OT3_PHASE();
         if (L.bk_points) {
             // sixteen lanes per cell (these levels have a handful of candidates per cell), everything a lane needs first loaded
