@@ -789,7 +789,7 @@ def main():
     # at every stage boundary costs ~6 us of idle GPU each, i.e. ~6 % of a step.  The full per-stage table comes from a separate,
     # untimed single-chain pass after the timed region.
     DOM = "fast"
-    EVERY = 4  # events on every 4th step of a chain: the two events of a step cost ~4 % of it
+    EVERY = 10  # events on every 10th step of a chain (two recorded steps per 20-step repeat): the two events of a step cost ~2 % of it
     for c in ctxs[:C]:
         c.set_profiling(2 + api.STAGE_NAMES.index(DOM))
         c.set_profiling_interval(EVERY)
