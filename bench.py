@@ -888,7 +888,7 @@ def main():
                 "whole_pipeline": {"alg_bytes_per_pair": B_PAIR, "achieved": B_PAIR * value / world / 1e9,
                                    "frac": B_PAIR * value / world / 1e9 / HBM_PEAK_GBS},
                 "stage_ms_per_step_summed_over_groups": per_launch_ms,
-                "stage_ms_note": "per-stage table from a separate untimed single-chain pass with events at every stage boundary; launch_ms from the timed region; 'pyramid' includes the blur of the levels that are blurred inside the resize launches (0..6 for a 64-pair batch), 'blur' holds no launch any more: the remaining levels are blurred inside the quadtree launch ('octree'); ORBFE_NO_FUSE=1 separates them all"}
+                "stage_ms_note": "per-stage table from a separate untimed single-chain pass with events at every stage boundary; launch_ms from the timed region; 'ingest' holds no launch any more (level 0 is the caller's image, read in place: what is left is the gap between two events); 'pyramid' includes the blur of the levels that are blurred inside the resize launches (0..6 for a 64-pair batch), 'blur' holds no launch any more: the remaining levels are blurred inside the quadtree launch ('octree'); ORBFE_NO_FUSE=1 separates them all"}
         if roof["traffic"]:
             roof["traffic_ratio"] = roof["traffic"] / roof["alg_bytes_per_launch"]  # counter bytes / algorithmic bytes of the dominant kernel
         wt, wsrc = whole_step_traffic_per_pair()
