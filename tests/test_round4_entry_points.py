@@ -175,3 +175,30 @@ def test_level0_in_place_never_reads_past_the_callers_buffer():
     k, d = O.Extractor(nfeatures=NF).extract(img)
     assert got["kps"].tobytes() == k.astype(api.KP_DTYPE).tobytes() and np.array_equal(got["desc"], d)
     ctx.close()
+
+
+def test_packed_block_stored_directly_into_pinned_host_memory(batch):
+    """ORBFE_PACK_DIRECT: the gather kernel writes the block into pinned host memory itself (no copy queued); same bytes as the copied
+    block; ordinary (pageable) memory is refused, not written to."""
+    api, torch = batch["api"], batch["torch"]
+    ctx = api.Context(max_images=10, **CFG)
+    st = torch.cuda.Stream()
+    ctx.enqueue_stereo(batch["dev"].data_ptr(), 5, st.cuda_stream)
+    flags = api.PACK_STEREO
+    lay = ctx.packed_layout(10, flags)
+    copied = torch.zeros(lay.bytes, dtype=torch.uint8).pin_memory()
+    direct = torch.zeros(lay.bytes, dtype=torch.uint8).pin_memory()
+    ctx.fetch_batch_packed(10, flags, copied.data_ptr(), lay.bytes, st.cuda_stream)
+    ctx.fetch_batch_packed(10, flags | api.PACK_DIRECT, direct.data_ptr(), lay.bytes, st.cuda_stream)
+    st.synchronize()
+    a, b = copied.numpy(), direct.numpy()
+    for o in range(10):
+        ga, gb = ctx.expand_packed(a, lay, o), ctx.expand_packed(b, lay, o)
+        assert ga["kps"].tobytes() == gb["kps"].tobytes() and np.array_equal(ga["desc"], gb["desc"])
+        if o % 2 == 0:
+            assert ga["u_right"].tobytes() == gb["u_right"].tobytes() and ga["depth"].tobytes() == gb["depth"].tobytes()
+    pageable = np.zeros(lay.bytes, np.uint8)
+    with pytest.raises(api.OrbfeError):
+        ctx.fetch_batch_packed(10, flags | api.PACK_DIRECT, pageable.ctypes.data, lay.bytes, st.cuda_stream)
+    assert not pageable.any()
+    ctx.close()
