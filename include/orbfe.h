@@ -28,8 +28,18 @@
  *   ORBFE_NO_FUSE=1    blur every level in one launch after the pyramid instead of blurring
  *                      level l - 1 inside the launch that resizes it into level l and the
  *                      remaining levels inside the quadtree launch;
+ *   ORBFE_NO_INPLACE=1 copy packed grey input into the library's pitched level 0 (ingest16_kernel)
+ *                      instead of reading the caller's images in place as pyramid level 0;
+ *   ORBFE_NO_PAIR=1|0  never / always compute two pyramid levels per launch (pyr_pair_kernel;
+ *                      default: for batches of fewer than 64 images);
+ *   ORBFE_RS_LOOKUP=1|0 cv::resize word bases from the host table / from the formula (default:
+ *                      the table for batches of 64 images and more);
+ *   ORBFE_BK_DEPTH5=1  quadtree buckets at depth 5 on every level (default: depth 4 on levels
+ *                      where a FAST cell would span more than 64 depth-5 buckets);
  *   ORBFE_HOST_TRACE=1 print the context's geometry, kernel choices and LDS sizes to
  *                      stderr at create time.
+ * Every alternative plan gives bit-identical results (tools/r04_fullsuite.sh runs the
+ * frame-path tests under each).
  *
  * No C++ exception leaves the library: a host-side failure (out of memory, ...) is
  * returned as ORBFE_ERR_HIP with its message in orbfe_last_error().
