@@ -569,7 +569,14 @@ def launch_ranks(n: int) -> int:
     t.start()
     rcs = [None] * n
     failed = None
+    deadline = time.time() + float(os.environ.get("ORBFE_BENCH_LAUNCH_TIMEOUT_S", "3000"))  # a rank that hangs must not hang the launcher for ever
     while any(rc is None for rc in rcs):
+        if time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            print("bench: the %d-rank run did not finish within ORBFE_BENCH_LAUNCH_TIMEOUT_S; killed" % n, file=sys.stderr)
+            return 1
         for r, p in enumerate(procs):
             if rcs[r] is None:
                 rcs[r] = p.poll()

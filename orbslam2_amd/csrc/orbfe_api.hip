@@ -35,7 +35,6 @@ struct orbfe_context {
     uint8_t *h_in = nullptr;      // [min(max_images,2)][w*h]
     float *h_depth_in = nullptr;  // [w*h]
     uint8_t *h_out = nullptr;     // see HostOut
-    const void *pack_direct_ok = nullptr; // last host block verified for ORBFE_PACK_DIRECT
     uint8_t *d_pack = nullptr;    // device staging of orbfe_fetch_batch_packed (lazily allocated for max_images)
     size_t d_pack_bytes = 0;
     uint8_t *d_ham = nullptr;     // scratch for orbfe_hamming_matrix
@@ -1247,6 +1246,7 @@ static int resize_input_staging(orbfe_context *ctx, size_t image_bytes)
     for (void *&q : ctx->allocs)
         if (q == ctx->d_in) q = nd;
     (void)hipFree(ctx->d_in);
+    if (ctx->last_src == ctx->d_in) ctx->last_src = nullptr; // the latest call's level 0 lived there (orbfe_fetch_pyramid)
     ctx->d_in = nd;
     if (ctx->h_in) { (void)hipHostFree(ctx->h_in); ctx->h_in = nullptr; }
     ctx->cfg.in_image_bytes = image_bytes;
@@ -1464,14 +1464,13 @@ try {
         // the caller's block is pinned host memory mapped into this device's address space: the gather kernel stores into it
         // across the link itself (posted writes), so no copy engine is involved -- on the measured link an upload and a download
         // queued on the copy engines take the SUM of their times, while a kernel's stores run beside an upload
-        if (host_block != ctx->pack_direct_ok) {
+        {   // checked on every call (a microsecond): the block a caller passes today may not be the pinned one it passed yesterday at the same address
             hipPointerAttribute_t at;
             void *dp = nullptr;
             if (hipPointerGetAttributes(&at, host_block) != hipSuccess || at.type != hipMemoryTypeHost || hipHostGetDevicePointer(&dp, host_block, 0) != hipSuccess || dp != host_block) {
                 (void)hipGetLastError();
                 return fail(ctx, ORBFE_ERR_INVALID, "ORBFE_PACK_DIRECT needs pinned host memory that the device addresses at the same pointer (hipHostMalloc / hipHostRegister)");
             }
-            ctx->pack_direct_ok = host_block;
         }
         orbfe_launch_pack_results(ctx->cfg, ctx->buf, (uint8_t *)host_block, po, lay.n_images_out, (flags & ORBFE_PACK_LEFT_ONLY) ? 2 : 1, (flags & ORBFE_PACK_STEREO) != 0, pick_stream(ctx, stream));
         HIP_TRY(ctx, hipGetLastError());
