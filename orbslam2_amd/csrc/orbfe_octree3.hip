@@ -415,6 +415,67 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
     for (int iter = 0; iter < 100000; iter++) { // n grows every pass, so this ends at n >= quota at the latest
         const int n = *s_n;
         OT3_PHASE();
+        // child k of node i as new node q
+        auto emit = [&](int q, int i, int k, int cnt) {
+            nxt.cnt[q] = cnt;
+            nxt.path[q] = (cur.path[i] << 2) | (unsigned)k;
+            nxt.dr[q] = (cur.dr[i] & 15) < 15 ? cur.dr[i] + 1 : cur.dr[i]; // depth 15 = 1-px boxes: never multi-point
+        };
+        auto copy_node = [&](int q, int i) { nxt.cnt[q] = cur.cnt[i]; nxt.path[q] = cur.path[i]; nxt.dr[q] = cur.dr[i]; };
+        if (!sorted_phase && n <= OT3_THREADS) {
+            // Express full pass (round 4): every multi-point node is split and thread i owns node i, so the child counts stay in
+            // registers, one 4-value block scan yields the ranks and the pass totals, every thread knows the stop rule's inputs, and the
+            // pass needs ONE barrier after the scan's two instead of six (the first passes -- 4, 16, 64 nodes -- are nothing but
+            // barriers and LDS round trips: 2.6 us each on the launch's critical path).  A node deeper than the bucket pyramid
+            // (counted in the scan's spare bits) sends the pass down the general path below.
+            int v4[4] = {0, 0, 0, 0}, c0 = 0, c1 = 0, c2 = 0, c3 = 0, k = 0, multi = 0;
+            if (tid < n) {
+                multi = cur.cnt[tid] > 1;
+                if (multi) {
+                    const int dr = cur.dr[tid], d = dr & 15, root = dr >> 4;
+                    if (d < db) {
+                        const int c = ot3_off(d + 1) + 4 * ((root << (2 * d)) + (int)cur.path[tid]);
+                        c0 = cnt_at(c); c1 = cnt_at(c + 1); c2 = cnt_at(c + 2); c3 = cnt_at(c + 3);
+                        k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+                        v4[0] = 1; v4[1] = k; v4[3] = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
+                    } else {
+                        v4[0] = 1 << 16; // deep
+                    }
+                } else {
+                    v4[2] = 1;
+                }
+            }
+            int tot[4];
+            ot3_block_scan4(v4, tot, s_w); // exclusive prefixes in list order
+            if ((tot[0] >> 16) == 0) {
+                const int total_k = tot[1], n_new = total_k + tot[2];
+                if (n_new > MAXN) {
+                    if (tid == 0) { *status = 2; *sel_cnt = 0; }
+                    return;
+                }
+                if (tid < n) {
+                    const int i = tid;
+                    if (!multi) {
+                        copy_node(total_k + v4[2], i);
+                    } else {
+                        int q = total_k - (v4[1] + k); // blocks of later-processed parents sit nearer the front; children n4..n1
+                        if (c3 > 0) emit(q++, i, 3, c3);
+                        if (c2 > 0) emit(q++, i, 2, c2);
+                        if (c1 > 0) emit(q++, i, 1, c1);
+                        if (c0 > 0) emit(q++, i, 0, c0);
+                    }
+                }
+                // stop logic (src/ORBextractor.cc:661-731): uniform values, written for the general path's readers
+                const bool done = n_new >= quota || n_new == n;
+                const int mode = n_new + 3 * tot[3] > quota ? 1 : 0;
+                if (tid == 0) { *s_n = n_new; *s_deep = 0; *s_done = done ? 1 : 0; *s_mode = mode; }
+                __syncthreads();
+                { Ot3Nodes t = cur; cur = nxt; nxt = t; }
+                if (done) break;
+                sorted_phase = mode;
+                continue;
+            }
+        }
         // child counts
         for (int i = tid; i < n; i += OT3_THREADS) {
             int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
@@ -464,14 +525,6 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
             }
             __syncthreads();
         }
-
-        // child k of node i as new node q
-        auto emit = [&](int q, int i, int k, int cnt) {
-            nxt.cnt[q] = cnt;
-            nxt.path[q] = (cur.path[i] << 2) | (unsigned)k;
-            nxt.dr[q] = (cur.dr[i] & 15) < 15 ? cur.dr[i] + 1 : cur.dr[i]; // depth 15 = 1-px boxes: never multi-point
-        };
-        auto copy_node = [&](int q, int i) { nxt.cnt[q] = cur.cnt[i]; nxt.path[q] = cur.path[i]; nxt.dr[q] = cur.dr[i]; };
 
         int n_new, nexpand_fast = -1;
         if (!sorted_phase && n <= OT3_THREADS) {
