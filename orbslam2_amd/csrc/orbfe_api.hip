@@ -47,6 +47,7 @@ struct orbfe_context {
     unsigned slot_cnt_epoch = ~0u;
     bool use_octree2 = false; // point-parallel quadtree (all levels have <= 4 roots and the LDS budget fits)
     bool fuse_blur = true;    // blur level l - 1 in the launch that resizes it into level l (ORBFE_NO_FUSE=1: separate launches)
+    bool blur_in_fast = true; // the levels the pyramid launches leave unblurred ride in FAST's launch (ORBFE_BLUR_IN_FAST=0: in the quadtree launch)
     // Level 0 read in place from the caller's packed CV_8UC1 images (no ingest launch, no copy): possible when level 1 is resized
     // by the LDS-free kernel and nothing stages level 0 through pyr_tail_kernel; ORBFE_NO_INPLACE=1 keeps the copy (A/B, tests).
     // Colour / rectified input always goes through ingest (it computes level 0).
@@ -400,7 +401,8 @@ try {
     // the XCD-aware block maps divide jb = blockIdx.x / 8 through a float reciprocal that is exact for jb < 2^21 (small_div,
     // orbfe_common.hpp), i.e. below 2^24 workgroups per launch; xcd_grid may round a launch up to twice blocks x images, so
     // the limit on blocks x images is 2^23
-    if (((size_t)ctx->cfg.cells_total / 4 + 1) * (size_t)p.max_images >= ((size_t)1 << 23) ||
+    if (((size_t)ctx->cfg.cells_total / 4 + 1 + (size_t)ctx->cfg.blur_tiles_total / 4 + 1) * (size_t)p.max_images >= ((size_t)1 << 23) || // FAST's launch may carry blur tiles too
+
         ((size_t)ctx->cfg.sel_total / 4 + 1) * (size_t)p.max_images >= ((size_t)1 << 23)) {
         delete ctx;
         return fail(nullptr, ORBFE_ERR_CAPACITY, "max_images %d: more than 2^23 workgroups per launch", p.max_images);
@@ -570,6 +572,7 @@ try {
             c2.tail_first = 0; c2.tail_n = 0; c2.tail_strips = 0; c2.tail_lds_bytes = 0;
             const int nst = p.nlevels >= 4 ? 3 : (p.nlevels == 3 ? 2 : 0);
             { const char *nf = getenv("ORBFE_NO_FUSE"); ctx->fuse_blur = !(nf && nf[0] == '1'); }
+            { const char *bf = getenv("ORBFE_BLUR_IN_FAST"); ctx->blur_in_fast = !(bf && bf[0] == '0'); }
             const char *env = getenv("ORBFE_NO_TAIL");
             c2.tail_max_images = env && env[0] == '0' ? INT_MAX : 63; // ORBFE_NO_TAIL=0: the tail at every batch size (A/B)
             if (nst >= 2 && !(env && env[0] == '1')) {
@@ -1139,17 +1142,27 @@ static void run_chain(orbfe_context *ctx, const uint8_t *d_images, int img0, int
     prof_mark(ctx, group, 1, s);
     const int blurred = orbfe_launch_pyramid(cfg, buf, n_images, ctx->fuse_blur, s);
     prof_mark(ctx, group, 2, s);
-    // the levels still unblurred after the pyramid ride in the quadtree launch, whose workgroups mostly wait (at the head of FAST's
-    // launch instead they cost FAST 10 us for 3 us saved there, and the three extra kernel arguments alone cost FAST 8 us: it sits at
-    // its scalar-register limit; tools/experiments); ORBFE_NO_FUSE=1: a launch of their own
-    const bool blur_in_quadtree = ctx->use_octree3 && ctx->fuse_blur;
-    if (!blur_in_quadtree) orbfe_launch_blur(cfg, buf, n_images, blurred, s);
+    // the levels still unblurred after the pyramid (level nlevels - 1 for a 64-pair batch, more for small ones) ride in FAST's launch as
+    // the last workgroups of each image's block list: FAST is bound by instruction issue, these waves by memory latency (+ 1 us there).
+    // Until round 4 they rode in the quadtree launch, behind its workgroups (every workgroup of that launch holds one of a CU's
+    // four LDS slots, so they started when the first quadtree workgroups ended, 27 us in, and ended the launch 4 us late);
+    // ORBFE_BLUR_IN_FAST=0 keeps that plan, ORBFE_NO_FUSE=1 gives every blur a launch of its own
+    const bool blur_in_fast = ctx->fuse_blur && ctx->blur_in_fast;
+    const bool blur_in_quadtree = ctx->fuse_blur && !blur_in_fast && ctx->use_octree3;
+    if (!blur_in_fast && !blur_in_quadtree) orbfe_launch_blur(cfg, buf, n_images, blurred, s);
     prof_mark(ctx, group, 3, s);
-    orbfe_launch_fast(cfg, buf, n_images, ctx->use_octree3, s);
+    orbfe_launch_fast(cfg, buf, n_images, ctx->use_octree3, s, blur_in_fast ? blurred : cfg.nlevels);
     prof_mark(ctx, group, 4, s);
     if (ctx->use_octree3) orbfe_launch_octree3(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot3_lds, ctx->ot3_nodes_in_hbm, s, blur_in_quadtree ? blurred : cfg.nlevels);
     else if (ctx->use_octree2) orbfe_launch_octree2(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot2_lds_pts, ctx->ot2_lds, s);
     else orbfe_launch_octree_generic(cfg, buf, n_images, s);
+#ifdef ORBFE_PROFILE_CUTS
+    { // EXPERIMENT: see dbg_sort_sel_kernel (orbfe_describe.hip)
+        extern void orbfe_launch_dbg_sort_sel(const DeviceConfig &, const DeviceBuffers &, int, int, hipStream_t);
+        static const int dbg_sort = getenv("ORBFE_DBG_SORT_SEL") ? atoi(getenv("ORBFE_DBG_SORT_SEL")) : 0;
+        if (dbg_sort) orbfe_launch_dbg_sort_sel(cfg, buf, n_images, dbg_sort, s);
+    }
+#endif
     prof_mark(ctx, group, 5, s);
     orbfe_launch_describe(cfg, buf, n_images, n_pairs > 0, s);
     prof_mark(ctx, group, 6, s);

@@ -197,3 +197,14 @@ __device__ __forceinline__ uint4 load16_unaligned(const uint8_t *p)
 
 // 12 bytes from any address: one global_load_dwordx3
 struct __attribute__((packed, aligned(4))) orbfe_u3_unaligned { uint32_t x, y, z; };
+
+// Wave-uniform reads of host-built tables (never written by a kernel) through the constant address space: only so does the compiler
+// keep them scalar loads whatever global stores the kernel holds elsewhere (a blur branch beside FAST's cells turned the cell table's
+// s_load into a vector load + v_readfirstlane: + 7 us on the launch).
+typedef uint32_t orbfe_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t const_load_u32(const uint32_t *p) { return *(const __attribute__((address_space(4))) uint32_t *)(uintptr_t)p; }
+__device__ __forceinline__ uint4 const_load_u32x4(const uint4 *p)
+{
+    const orbfe_u32x4 v = *(const __attribute__((address_space(4))) orbfe_u32x4 *)(uintptr_t)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}

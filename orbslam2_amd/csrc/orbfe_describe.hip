@@ -507,3 +507,48 @@ void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, in
     const size_t lds = ((cfg.patch_n * 2 + 15) & ~15) + 256 * 4 + 4 * (raw_bytes + DS_BLR_ROWS * DS_PATCH_W);
     hipLaunchKernelGGL(describe_generic_kernel, grid, dim3(256), lds, s, cfg, buf, n_images, stereo ? 1 : 0 ORBFE_CUT_ARG("ORBFE_DESC_DBG"));
 }
+
+#ifdef ORBFE_PROFILE_CUTS
+// EXPERIMENT (cut-point build only, ORBFE_DBG_SORT_SEL=1|2): re-order every (image, level)'s selected keypoints spatially before
+// describe_kernel runs, to measure what the kernel would gain from keypoints that share cache lines being processed together.
+// The OUTPUT ORDER is then not the reference's: timing only.  1: 32-px-tile rows, then x; 2: Morton order of 16-px cells.
+__global__ __launch_bounds__(256) void dbg_sort_sel_kernel(DeviceConfig cfg, DeviceBuffers buf, int mode)
+{
+    __shared__ uint32_t s_key[1024], s_xy[1024];
+    __shared__ uint8_t s_sc[1024];
+    const int img = blockIdx.x, level = blockIdx.y, tid = threadIdx.x;
+    const LevelInfo &L = cfg.lv[level];
+    int n = buf.sel_cnt[(size_t)img * cfg.nlevels + level];
+    n = n > 1024 ? 0 : n;
+    uint32_t *xy = buf.sel_xy + (size_t)img * cfg.sel_total + L.sel_off;
+    uint8_t *sc = buf.sel_sc + (size_t)img * cfg.sel_total + L.sel_off;
+    for (int i = tid; i < n; i += 256) {
+        const uint32_t v = xy[i];
+        const unsigned x = v & 0xffffu, y = v >> 16;
+        uint32_t key;
+        if (mode == 1) key = ((y >> 5) << 20) | (x << 8) | (y & 31u);
+        else if (mode == 3) key = ((y >> 5) << 20) | (unsigned)i;              // tile row only, list order inside (a stable 12-bin sort)
+        else if (mode == 4) key = ((y >> 4) << 20) | (x << 8) | (y & 15u);
+        else if (mode == 5) key = ((y >> 6) << 20) | (x << 8) | (y & 63u);
+        else if (mode == 6) key = ((x >> 5) << 20) | (y << 8) | (x & 31u);
+        else if (mode == 7) key = ((y >> 5) << 20) | ((x >> 6) << 12) | (unsigned)i; // 32 x 64 px cells in row-major order, list order inside
+        else {
+            unsigned m = 0;
+            for (int b = 0; b < 8; b++) m |= (((x >> (4 + b)) & 1u) << (2 * b)) | (((y >> (4 + b)) & 1u) << (2 * b + 1));
+            key = (m << 12) | ((y & 15u) << 4) | (x & 15u);
+        }
+        s_key[i] = key; s_xy[i] = v; s_sc[i] = sc[i];
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const uint32_t k = s_key[i];
+        int r = 0;
+        for (int j = 0; j < n; j++) r += (s_key[j] < k || (s_key[j] == k && j < i)) ? 1 : 0;
+        xy[r] = s_xy[i]; sc[r] = s_sc[i];
+    }
+}
+void orbfe_launch_dbg_sort_sel(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int mode, hipStream_t s)
+{
+    hipLaunchKernelGGL(dbg_sort_sel_kernel, dim3(n_images, cfg.nlevels), dim3(256), 0, s, cfg, buf, mode);
+}
+#endif

@@ -76,6 +76,7 @@ struct DeviceConfig {
     int cand_total;        // per image
     int sel_total;         // per image == keypoint capacity
     int blur_tiles_total;
+    int fast_blur_t0;      // blur tiles [fast_blur_t0, blur_tiles_total) ride in the FAST launch (set per launch; blur_tiles_total: none)
     int max_nodes;         // quadtree node capacity (LDS)
     int bk_part_total;     // per image: entries of DeviceBuffers::bk_part
     int row_cap;           // entries per image row in DeviceBuffers::row_ent
@@ -194,7 +195,7 @@ void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, cons
 int orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool fuse_blur, hipStream_t s); // returns the number of levels (from 0) whose blur it launched too
 int orbfe_resize_word_base_host(int xw, int dst_w, double scale, int src_w); // pyr_resize_direct_kernel's first-source-byte formula, for orbfe_create's check
 void orbfe_launch_blur(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int first_level, hipStream_t s);
-void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool buckets, hipStream_t s);
+void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool buckets, hipStream_t s, int blur_first_level);
 void orbfe_launch_octree_generic(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
 void orbfe_launch_octree2(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, int lds_pts, size_t lds, hipStream_t s);
 size_t orbfe_octree2_lds_bytes(int max_nodes, int sort_cap, int lds_pts);

@@ -1,5 +1,6 @@
 // orbfe_fast.hip -- cell-wise cv::FAST with two thresholds (src/ORBextractor.cc:783-823) + quadtree bucket accumulation.
 #include "orbfe_common.hpp"
+#include "orbfe_blur_wave.hpp"
 
 // ---------------------------------------------------------------------------
 // FAST-9/16 per cell: score map + 3x3 NMS inside the cell + two-threshold select
@@ -117,16 +118,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     // uses ~44 B of each line) are served by that XCD's L2 instead of being re-fetched from HBM by 8 XCDs.
     // A workgroup is four independent waves = four consecutive cells (no workgroup barriers: FAST_WAVE_SYNC): horizontally
     // adjacent cells share the 128-B lines of their tile rows, and on one CU those lines are fetched from L2 once.
-    const int bpi = (cfg.cells_total + 3) >> 2;
+    const int bpi_cells = (cfg.cells_total + 3) >> 2;
+    const int bpi = bpi_cells + ((cfg.blur_tiles_total - cfg.fast_blur_t0 + 3) >> 2);
     int img, blk;
     if (!xcd_map(bpi, n_images, img, blk)) return;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (__builtin_expect(blk >= bpi_cells, 0)) { // the image's last workgroups: blur tiles riding in this launch
+        const int u = cfg.fast_blur_t0 + (blk - bpi_cells) * 4 + wave;
+        if (u < cfg.blur_tiles_total) blur_wave(cfg, buf, img, u);
+        return;
+    }
     const int cell = blk * 4 + wave;
     if (cell >= cfg.cells_total) return;
     uint8_t *s_mem = s_mem_all + wave * lds_per_wave;
     // the cell's level, position and clipped tile size from the host-built table (one scalar load instead of the level search,
     // a division and the clipping of src/ORBextractor.cc:783-800 behind a chain of dependent scalar loads)
-    const uint4 cinfo = buf.cell_info[cell];
+    const uint4 cinfo = const_load_u32x4(buf.cell_info + cell);
     const int level = (int)(cinfo.x & 0xffu);
     const LevelInfo &L = cfg.lv[level];
     const int ci = (int)cinfo.w;
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     // bucket tables of this cell's columns / rows (BK): issued now, consumed in phase E
     unsigned tabx = 0u, taby = 0u, bk_off = ~0u;
     if (BK) {
-        bk_off = buf.bk_off[cell];
+        bk_off = const_load_u32(buf.bk_off + cell);
         const uint32_t *bx_tab = buf.bk_tab + L.bk_xoff + 3 + cell_x0; // survivor x = c + 3 + j * wCell
         const uint32_t *by_tab = buf.bk_tab + L.bk_yoff + 3 + cell_y0;
         tabx = bx_tab[lane < iw ? lane : iw - 1];
@@ -484,8 +491,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 static inline int max_cell_w(const DeviceConfig &cfg) { int m = 0; for (int l = 0; l < cfg.nlevels; l++) m = cfg.lv[l].w_cell > m ? cfg.lv[l].w_cell : m; return m; }
 static inline int max_cell_h(const DeviceConfig &cfg) { int m = 0; for (int l = 0; l < cfg.nlevels; l++) m = cfg.lv[l].h_cell > m ? cfg.lv[l].h_cell : m; return m; }
 
-void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool buckets, hipStream_t s)
+void orbfe_launch_fast(const DeviceConfig &cfg_in, const DeviceBuffers &buf, int n_images, bool buckets, hipStream_t s, int blur_first_level)
 {
+    DeviceConfig cfg = cfg_in;
+    cfg.fast_blur_t0 = blur_first_level < cfg.nlevels ? cfg.lv[blur_first_level].blur_tile_off : cfg.blur_tiles_total;
     const int mw = max_cell_w(cfg), mh = max_cell_h(cfg);
     const int tile_pitch = (mw + 6 + 15) & ~15; // whole 16-byte chunks (the staging stores 128 bits at a time)
     const int tile_rows = mh + 6;
@@ -497,7 +506,7 @@ void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_
     const int tile_region = tile_bytes > mw * mh ? tile_bytes : ((mw * mh + 15) & ~15);
     const int lds_per_wave = tile_region + sc_bytes + q_bytes + 512;
     const size_t lds = (size_t)4 * lds_per_wave;
-    dim3 grid(xcd_grid((cfg.cells_total + 3) / 4, n_images));
+    dim3 grid(xcd_grid((cfg.cells_total + 3) / 4 + (cfg.blur_tiles_total - cfg.fast_blur_t0 + 3) / 4, n_images));
 #define FAST_LAUNCH(TP)                                                                                                                   \
     do {                                                                                                                              \
         if (buckets) hipLaunchKernelGGL((fast_cell_kernel<TP, true>), grid, dim3(256), lds, s, cfg, buf, n_images, tile_pitch, tile_region, sc_bytes, q_bytes, lds_per_wave ORBFE_CUT_ARG("ORBFE_FAST_DBG")); \

@@ -207,7 +207,14 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
     // the head of the grid the blur kept a quarter of the quadtree workgroups waiting for ~9 us (round 4: launch 41.5 -> 38 us).
     if ((int)blockIdx.y >= cfg.nlevels) {
         const int u = blur_t0 + ((int)blockIdx.y - cfg.nlevels) * OT3_WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#ifdef ORBFE_PROFILE_CUTS
+        const int bi = (int)blockIdx.x * blur_rows + ((int)blockIdx.y - cfg.nlevels);
+        if (threadIdx.x == 0 && bi < 768) buf.dbg_ts[2560 + 2 * bi] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
         if (u < blur_t1) blur_wave(cfg, buf, blockIdx.x, u);
+#ifdef ORBFE_PROFILE_CUTS
+        if (threadIdx.x == 0 && bi < 768) buf.dbg_ts[2560 + 2 * bi + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
         return;
     }
     // longest first: the workgroups of level 0 (largest quota, most split passes) are dispatched before those of level 1, ...

@@ -25,6 +25,10 @@ print("launch span %.1f us (first start to last end)" % (t[:, :, 1].max() - t0))
 for l in range(8):
     s, e = t[:, l, 0] - t0, t[:, l, 1] - t0
     print("level %d: start %5.1f .. %5.1f  duration mean %5.1f max %5.1f  end max %5.1f" % (l, s.min(), s.max(), (e - s).mean(), (e - s).max(), e.max()))
+bl = ts[2560:4096].reshape(768, 2).astype(np.float64) / 100.0
+bl = bl[bl[:, 0] > 0]
+if len(bl):
+    print("blur workgroups riding in the launch: %d, start %5.1f .. %5.1f, duration mean %4.1f max %4.1f, end max %5.1f" % (len(bl), bl[:, 0].min() - t0, bl[:, 0].max() - t0, (bl[:, 1] - bl[:, 0]).mean(), (bl[:, 1] - bl[:, 0]).max(), bl[:, 1].max() - t0))
 ph = ts[2048:2048 + 512].reshape(8, 64).astype(np.float64) / 100.0
 for l in range(8):
     v = ph[l][ph[l] > 0]
