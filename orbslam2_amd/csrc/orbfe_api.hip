@@ -440,6 +440,10 @@ try {
     A(b.sel_cnt, B * c.nlevels);
     A(b.sel_xy, B * c.sel_total + 4); // + 4: stereo_rowlist_kernel reads whole quads of slots
     A(b.sel_sc, B * c.sel_total);
+    A(b.proc_xy, B * c.sel_total);
+    A(b.proc_meta, B * c.sel_total);
+    Z(b.proc_xy, B * c.sel_total * sizeof(uint32_t));
+    Z(b.proc_meta, B * c.sel_total * sizeof(uint32_t));
     A(kps, B * c.sel_total);
     b.kps = kps;
     A(b.desc, B * c.sel_total * 32);
@@ -903,6 +907,18 @@ try {
         }
         b.slot_level = d_sl;
     }
+    {   // describe_kernel's processing order (orbfe_octree3.hip step 4a): a node's bin = row bits | root | column bits of its quadrant path,
+        // rows ~40 px tall (a patch is 31 - 40 rows), the remaining bits of the 256 bins for columns
+        const char *np = getenv("ORBFE_NO_PROC_ORDER");
+        ctx->cfg.proc_order = !(np && np[0] == '1') && ctx->use_octree3 && !ctx->ot3_nodes_in_hbm;
+        for (int l = 0; l < p.nlevels; l++) {
+            LevelInfo &L = ctx->cfg.lv[l];
+            const int region_h = (L.h - p.edge_threshold + 3) - c.min_border;
+            int rb = 0;
+            while (rb < 3 && (region_h >> (rb + 1)) >= 28) rb++; // rows of 28 - 55 px (measured: 20 / 40-px minima cost describe_kernel 1 us, 14 / 112 px 3 - 5 us)
+            L.po_rb = rb; L.po_cb = 6 - rb;
+        }
+    }
     {   // circular patch of IC_Angle (src/ORBextractor.cc:79-96): |v| <= hp, |u| <= umax[|v|]
         std::vector<int16_t> uv;
         const int hp = p.half_patch_size;
@@ -1119,7 +1135,7 @@ static DeviceBuffers shift_buffers(const DeviceBuffers &b, const DeviceConfig &c
     o.bk_part += i * c.bk_part_total; o.bk_end += i * c.nlevels * 4097;
     if (o.ot3_scratch) o.ot3_scratch += i * c.nlevels * orbfe_octree3_node_bytes(c.max_nodes, ot_sort_cap_of(c));
     if (o.bk_best) o.bk_best += i * c.nlevels * ORBFE_BK_PYR;
-    o.sel_xy += i * c.sel_total; o.sel_sc += i * c.sel_total;
+    o.sel_xy += i * c.sel_total; o.sel_sc += i * c.sel_total; o.proc_xy += i * c.sel_total; o.proc_meta += i * c.sel_total;
     o.kps = (KeyPointPOD *)o.kps + i * c.sel_total; o.desc += i * c.sel_total * 32;
     o.kp_cnt += i; o.status += i;
     o.u_right += i * c.sel_total; o.depth += i * c.sel_total; o.sad += i * c.sel_total;

@@ -331,8 +331,21 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
     const int my_slot = slot0 + (lane < DS_KPW ? lane : 0);
     const bool my_in = lane < DS_KPW && my_slot < cfg.sel_total;
     const int level_l = my_in ? buf.slot_level[my_slot] : 0;
-    const uint32_t xy_l = my_in ? buf.sel_xy[(size_t)img * cfg.sel_total + my_slot] : 0u;
-    const int score_l = my_in ? buf.sel_sc[(size_t)img * cfg.sel_total + my_slot] : 0;
+    // DeviceConfig::proc_order: position -> keypoint through octree3_kernel's spatially ordered copy (proc_xy, proc_meta = slot | score << 24),
+    // so that the keypoints of a workgroup share cache lines; otherwise the keypoint of the slot itself.  Positions beyond the level's
+    // count are never used.
+    uint32_t xy_l = 0u;
+    int score_l = 0, pslot_l = my_slot;
+    if (my_in) {
+        if (cfg.proc_order) {
+            xy_l = buf.proc_xy[(size_t)img * cfg.sel_total + my_slot];
+            const uint32_t m = buf.proc_meta[(size_t)img * cfg.sel_total + my_slot];
+            pslot_l = (int)(m & 0xffffffu); score_l = (int)(m >> 24);
+        } else {
+            xy_l = buf.sel_xy[(size_t)img * cfg.sel_total + my_slot];
+            score_l = buf.sel_sc[(size_t)img * cfg.sel_total + my_slot];
+        }
+    }
     const int c_l = lane < cfg.nlevels ? sel_cnt[lane] : 0;
     // per-lane moment weights (host-built, orbfe_api.hip): 4 words (u + 16 inside the circle, else 0), 4 words (1 / 0), v
     const uint4 *mt = (const uint4 *)buf.mom_tab + 3 * lane;
@@ -360,7 +373,7 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
             const int k = slot0 + i - cfg.lv[level].sel_off;
             if (k < __builtin_amdgcn_readlane(c_l, level)) { // readlane (not a shuffle): the result is a scalar
                 hv[i] = true; lvv[i] = level;
-                outv[i] = k + __builtin_amdgcn_readlane(excl, level);
+                outv[i] = __builtin_amdgcn_readlane(pslot_l, i) - cfg.lv[level].sel_off + __builtin_amdgcn_readlane(excl, level);
                 cxv[i] = (int)(xy & 0xffffu) + cfg.min_border;
                 cyv[i] = (int)(xy >> 16) + cfg.min_border;
             }

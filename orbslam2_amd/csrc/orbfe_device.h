@@ -62,6 +62,7 @@ struct LevelInfo {
     int bk_xoff, bk_yoff;          // quadtree bucket tables of this level in DeviceBuffers::bk_tab (orbfe_octree3.hip)
     int bk_part_off, bk_part_n;    // this level's per-cell bucket partials in DeviceBuffers::bk_part / bk_emap
     int bk_depth;                  // quadtree bucket depth of this level: 5, or 4 where a FAST cell would span more than 64 depth-5 buckets
+    int po_rb, po_cb;              // processing order: row / column bits of a node's bin (orbfe_octree3.hip step 4a)
     int bk_points;                 // some cell of the level spans > 64 buckets: the quadtree kernel buckets its candidates itself
 };
 
@@ -76,6 +77,7 @@ struct DeviceConfig {
     int cand_total;        // per image
     int sel_total;         // per image == keypoint capacity
     int blur_tiles_total;
+    int proc_order;        // octree3_kernel also writes proc_xy / proc_meta and describe_kernel walks those (0: describe_kernel walks sel_xy; ORBFE_NO_PROC_ORDER=1, other quadtree kernels)
     int fast_blur_t0;      // blur tiles [fast_blur_t0, blur_tiles_total) ride in the FAST launch (set per launch; blur_tiles_total: none)
     int max_nodes;         // quadtree node capacity (LDS)
     int bk_part_total;     // per image: entries of DeviceBuffers::bk_part
@@ -143,6 +145,8 @@ struct DeviceBuffers {
     int *sel_cnt;        // [img][nlevels]
     uint32_t *sel_xy;    // [img][sel_total]
     uint8_t *sel_sc;     // [img][sel_total]
+    uint32_t *proc_xy;   // [img][sel_total] describe_kernel's processing order (DeviceConfig::proc_order): the keypoints of a level in a spatial order, ...
+    uint32_t *proc_meta; // ... and their slot | score << 24 (octree3_kernel writes both beside sel_xy / sel_sc, which stay in the reference's order)
     void *kps;           // [img][sel_total] orbfe_keypoint
     uint8_t *desc;       // [img][sel_total][32]
     int *kp_cnt;         // [img]

@@ -200,6 +200,7 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     __shared__ int s_w[4 * OT3_WAVES];
     __shared__ int s_scal[8];
+    __shared__ __attribute__((aligned(16))) int s_bin[256]; // step 4a (processing order for describe_kernel): zeroed here, used at the end
     // The LAST blur_rows rows of the grid are not quadtree workgroups: their waves blur tiles [blur_t0, blur_t1) of the image (the
     // levels no pyramid launch has blurred; describe_kernel is the first reader).  The quadtree workgroups are latency-bound and leave
     // the chip mostly idle, so those memory-bound waves cost little here -- their own launch cost 9 us (level 7 of a 64-pair batch) to
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
     }
     // longest first: the workgroups of level 0 (largest quota, most split passes) are dispatched before those of level 1, ...
     const int img = blockIdx.x, level = (int)blockIdx.y;
+    for (int i = threadIdx.x; i < 256; i += OT3_THREADS) s_bin[i] = 0;
     const LevelInfo &L = cfg.lv[level];
     const int tid = threadIdx.x;
 #ifdef ORBFE_PROFILE_CUTS // tools/octree3_timeline.py (`make cuts` build only): start / end of the first 2048 workgroups and the phase
@@ -709,12 +711,47 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
     const int n = *s_n;
     const int n_out = n < L.sel_cap ? n : L.sel_cap;
     if (n > L.sel_cap && tid == 0) *status = 3;
+    // ---- 4a. describe_kernel's processing order: the level's kept nodes counting-sorted into row-major order of coarse boxes --
+    //      bin = (top po_rb row bits of the node's quadrant path, root, top po_cb column bits): rows ~40 px tall, columns as fine as 256
+    //      bins allow; order inside a bin as the atomics fall (the order of PROCESSING changes no result: every keypoint is written
+    //      to its own slot).  Keypoints that share cache lines then run in the same describe_kernel workgroups, which is bound by
+    //      its L1 fills.  One barrier: every wave scans all 256 bins for itself (same values from every wave). ----
+    const bool ordered = !NODES_IN_HBM && cfg.proc_order;
+    unsigned key_pre = 0u; // the best key of the thread's first node: requested now, so that the ordering step runs under this load's latency
+    if (tid < n_out) {
+        const int dr = cur.dr[tid], d = dr & 15;
+        if (d <= db) key_pre = g_best[ot3_off(d) + ((dr >> 4) << (2 * d)) + (int)cur.path[tid]];
+    }
+    if (ordered) {
+        const int rb = L.po_rb, cb = L.po_cb;
+        int *s_base = s_chi; // the count pyramid is dead (16-byte aligned: the start of the dynamic LDS)
+        for (int i = tid; i < n_out; i += OT3_THREADS) {
+            const int dr = cur.dr[i], d = dr & 15, root = dr >> 4;
+            unsigned path = cur.path[i]; // x bits even, y bits odd, the first split highest
+            path = d >= 6 ? path >> (2 * (d - 6)) : path << (2 * (6 - d)); // six levels of it
+            const unsigned x6 = ((path >> 5) & 32u) | ((path >> 4) & 16u) | ((path >> 3) & 8u) | ((path >> 2) & 4u) | ((path >> 1) & 2u) | (path & 1u);
+            const unsigned y6 = ((path >> 6) & 32u) | ((path >> 5) & 16u) | ((path >> 4) & 8u) | ((path >> 3) & 4u) | ((path >> 2) & 2u) | ((path >> 1) & 1u);
+            const int bin = (int)((((y6 >> (6 - rb)) * OT3_ROOTS + (unsigned)root) << cb) | (x6 >> (6 - cb))); // (alternating the direction from row to row: no difference)
+            s_rank[i] = bin | (atomicAdd(&s_bin[bin], 1) << 8);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // LDS only: not the wait for key_pre that __syncthreads() would add
+        { // exclusive scan of the 256 bins by every wave: lane l owns bins 4 l .. 4 l + 3
+            const int lane = tid & 63;
+            const int4 v = ((const int4 *)s_bin)[lane];
+            const int sum = v.x + v.y + v.z + v.w;
+            const int ex = ot3_wave_incl_scan(sum, lane) - sum;
+            ((int4 *)s_base)[lane] = make_int4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z); // every wave stores the same values
+            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the wave's own stores
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    uint32_t *proc_xy = buf.proc_xy + ib * cfg.sel_total + L.sel_off, *proc_meta = buf.proc_meta + ib * cfg.sel_total + L.sel_off;
     for (int i = tid; i < n_out; i += OT3_THREADS) {
         const int dr = cur.dr[i], d = dr & 15, root = dr >> 4;
         const unsigned path = cur.path[i];
         unsigned key = 0u;
         if (d <= db) {
-            key = g_best[ot3_off(d) + (root << (2 * d)) + (int)path];
+            key = i == tid ? key_pre : g_best[ot3_off(d) + (root << (2 * d)) + (int)path];
         } else { // only reachable through deep_children, i.e. with the sorted arrays built
             const int b = (root << (2 * db)) + (int)(path >> (2 * (d - db)));
             for (int j = s_bend[b]; j < s_bend[b + 1]; j++) {
@@ -726,8 +763,15 @@ __global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))
             }
         }
         const unsigned ref = OT3_REF_MASK - (key & OT3_REF_MASK);
-        sel_xy[i] = cell_xy[(size_t)(ref >> 12) * cfg.cell_cap + (ref & 4095u)];
+        const uint32_t xy = cell_xy[(size_t)(ref >> 12) * cfg.cell_cap + (ref & 4095u)];
+        sel_xy[i] = xy;
         sel_sc[i] = (uint8_t)(key >> 24);
+        if (cfg.proc_order) {
+            int pos = i;
+            if (ordered) { const int r = s_rank[i]; pos = s_chi[r & 255] + (r >> 8); }
+            proc_xy[pos] = xy;
+            proc_meta[pos] = (uint32_t)(L.sel_off + i) | (key & 0xff000000u);
+        }
     }
     if (tid == 0) *sel_cnt = n_out;
     OT3_PHASE();
