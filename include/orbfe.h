@@ -27,7 +27,12 @@
  *                      above ~2) instead of the direct one;
  *   ORBFE_NO_FUSE=1    blur every level in one launch after the pyramid instead of blurring
  *                      level l - 1 inside the launch that resizes it into level l and the
- *                      remaining levels inside the quadtree launch;
+ *                      remaining levels inside FAST's launch;
+ *   ORBFE_BLUR_IN_FAST=0 those remaining levels inside the quadtree launch instead (the plan
+ *                      until round 4);
+ *   ORBFE_NO_PROC_ORDER=1 describe_kernel walks the keypoints in slot order instead of the
+ *                      spatial order the quadtree kernel writes beside its selection
+ *                      (results are the same either way: only the order of processing differs);
  *   ORBFE_NO_INPLACE=1 copy packed grey input into the library's pitched level 0 (ingest16_kernel)
  *                      instead of reading the caller's images in place as pyramid level 0;
  *   ORBFE_NO_PAIR=1|0  never / always compute two pyramid levels per launch (pyr_pair_kernel;

@@ -202,3 +202,35 @@ def test_packed_block_stored_directly_into_pinned_host_memory(batch):
         ctx.fetch_batch_packed(10, flags | api.PACK_DIRECT, pageable.ctypes.data, lay.bytes, st.cuda_stream)
     assert not pageable.any()
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knob,off", [("ORBFE_NO_PROC_ORDER", "1"), ("ORBFE_BLUR_IN_FAST", "0")])
+@pytest.mark.parametrize("w,h,nf,n_pairs", [(1241, 376, 2000, 3), (640, 480, 1000, 1), (403, 202, 300, 2)])
+def test_launch_plan_knobs_change_no_result(knob, off, w, h, nf, n_pairs, monkeypatch):
+    """describe_kernel walking the quadtree kernel's spatial processing order (default) or the slots (ORBFE_NO_PROC_ORDER=1), and the
+    unblurred levels riding in FAST's launch (default) or the quadtree's (ORBFE_BLUR_IN_FAST=0): the same bytes out, also for the
+    blurred pyramid of every level (which the second knob moves between launches) and for batches small enough that several levels ride."""
+    import torch
+    from orbslam2_amd import api
+    cfg = dict(width=w, height=h, nfeatures=nf, fx=350.0, fy=350.0, cx=w / 2, cy=h / 2, bf=140.0, max_images=2 * n_pairs)
+    pairs = [synth.stereo_pair(w, h, seed=90 + i) for i in range(n_pairs)]
+    host = np.stack([im for p in pairs for im in p])
+    dev = torch.from_numpy(host).cuda()
+    res = {}
+    for mode in ("default", "off"):
+        if mode == "off":
+            monkeypatch.setenv(knob, off)
+        ctx = api.Context(**cfg)
+        ctx.enqueue_stereo(dev.data_ptr(), n_pairs, 0)
+        ctx.synchronize()
+        res[mode] = [ctx.fetch_image(i, stereo=i % 2 == 0) for i in range(2 * n_pairs)]
+        res[mode + "b"] = [ctx.fetch_pyramid(2 * n_pairs - 1, l, blurred=True) for l in range(8)]
+        ctx.close()
+    for a, b in zip(res["default"], res["off"]):
+        assert a["kps"].tobytes() == b["kps"].tobytes() and np.array_equal(a["desc"], b["desc"])
+        if "u_right" in a:
+            assert a["u_right"].tobytes() == b["u_right"].tobytes() and a["depth"].tobytes() == b["depth"].tobytes()
+    for a, b in zip(res["defaultb"], res["offb"]):
+        assert np.array_equal(a, b)
+    assert len(res["default"][0]["kps"]) > 100

@@ -4,6 +4,7 @@ bash tools/collect_profiles.sh > /dev/null 2>&1 || { echo "collect_profiles fail
 out=gpurun_out/final
 bash tools/step_trace.sh r04 > $out/step_trace.txt 2>/dev/null
 timeout -k 10 300 python3 tools/pcie_rate2.py > $out/pcie.json 2>/dev/null
+[ -f tools/ab/cuts.so ] && bash tools/octree3_timeline.sh 2>/dev/null | grep -v amdgpu.ids > $out/octree3_timeline.txt
 ORBFE_BENCH_ONE_GPU=1 timeout -k 10 300 python3 bench.py --gpus 2 --backend gloo --cpu-pairs 0 --host-fed 0 --natural 0 --small-batch 0 --secondary 0 --pipelined 0 > $out/bench_2rank_gloo_one_gpu.json 2> $out/bench_2rank.err; echo "2-rank self-launch rc=$?"
 python3 - <<'PY'
 import json
