@@ -337,6 +337,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             const unsigned dq23 = u((A23 + tp) - v23), bq23 = u((v23 + tp) - B23);
             const unsigned o01 = (dq01 | bq01) & vm01, o23 = (dq23 | bq23) & vm23;
             const unsigned long long m0 = neg_lo16(o01), m1 = neg_hi16(o01), m2 = neg_lo16(o23), m3 = neg_hi16(o23);
+            if ((m0 | m1 | m2 | m3) == 0ull) continue; // no pixel of the band passes (a scalar test): nothing to queue -- the flat regions of real images
             // bright flag straight from bq's sign bits
             const unsigned q01 = (bq01 & 0x80008000u) | e01, q23 = (bq23 & 0x80008000u) | (e01 + 0x20002u);
             const int pos0 = n2 + (int)mbcnt64(m3, mbcnt64(m2, mbcnt64(m1, mbcnt64(m0, 0u))));
