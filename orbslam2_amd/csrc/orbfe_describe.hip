@@ -524,7 +524,8 @@ void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, in
 #ifdef ORBFE_PROFILE_CUTS
 // EXPERIMENT (cut-point build only, ORBFE_DBG_SORT_SEL=1|2): re-order every (image, level)'s selected keypoints spatially before
 // describe_kernel runs, to measure what the kernel would gain from keypoints that share cache lines being processed together.
-// The OUTPUT ORDER is then not the reference's: timing only.  1: 32-px-tile rows, then x; 2: Morton order of 16-px cells.
+// The OUTPUT ORDER is then not the reference's: timing only.  (It led to DeviceConfig::proc_order; with that on, describe_kernel walks proc_xy
+// and this kernel changes nothing for it: combine with ORBFE_NO_PROC_ORDER=1.)  1: 32-px-tile rows, then x; 2: Morton order of 16-px cells.
 __global__ __launch_bounds__(256) void dbg_sort_sel_kernel(DeviceConfig cfg, DeviceBuffers buf, int mode)
 {
     __shared__ uint32_t s_key[1024], s_xy[1024];
