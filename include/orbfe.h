@@ -62,7 +62,7 @@
 extern "C" {
 #endif
 
-#define ORBFE_ABI_VERSION 5 /* 2: orbfe_frame_view.device_slot_plus1; 3: .keyframe; 4: orbfe_get_camera, orbfe_assign_features_to_grid, orbfe_stereo_batch, orbfe_device_count, orbfe_set_profiling_interval; 5: orbfe_get_packed_layout, orbfe_fetch_batch_packed, orbfe_expand_packed, orbfe_stereo_batch_packed, orbfe_enqueue_rgbd */
+#define ORBFE_ABI_VERSION 6 /* 2: orbfe_frame_view.device_slot_plus1; 3: .keyframe; 4: orbfe_get_camera, orbfe_assign_features_to_grid, orbfe_stereo_batch, orbfe_device_count, orbfe_set_profiling_interval; 5: orbfe_get_packed_layout, orbfe_fetch_batch_packed, orbfe_expand_packed, orbfe_stereo_batch_packed, orbfe_enqueue_rgbd; 6: orbfe_build_id, orbfe_set_pattern, orbfe_get_pattern (additive: no struct changed) */
 
 enum {
     ORBFE_OK = 0,
@@ -105,11 +105,25 @@ typedef struct orbfe_params {
 typedef struct orbfe_context orbfe_context;
 
 int orbfe_abi_version(void);
+/* sha256 (64 hex digits) over the library's sources and compile flags, fixed at build time (orbslam2_amd/csrc/Makefile): measurement
+ * files under profiles/ carry the id of the build they were taken on, and bench.py replays a counter only when it matches the
+ * library it ran.  No counterpart in the reference. */
+const char *orbfe_build_id(void);
 const char *orbfe_last_error(const orbfe_context *ctx);
 
 /* Replaces `new ORBextractor(...)` (src/Tracking.cc:125-131, src/ORBextractor.cc:405-464). */
 int orbfe_create(const orbfe_params *params, orbfe_context **out);
 void orbfe_destroy(orbfe_context *ctx);
+
+/* The extractor's copy of the rBRIEF test table: ORBextractor::ORBextractor copies the 512 points of bit_pattern_31_ into its
+ * member `pattern` (src/ORBextractor.cc:442-444, include/ORBextractor.h:93), computeOrbDescriptor reads it (:103-142).  A new
+ * context holds the compiled-in table (orbslam2_amd/csrc/orb_pattern_31.inc); orbfe_set_pattern replaces it for every call
+ * enqueued afterwards -- what a multi-GPU deployment does with the table rank 0 broadcasts (orbslam2_amd/dist.py:
+ * broadcast_pattern).  pattern = 256 tests x (x0, y0, x1, y1), i.e. the reference's `int bit_pattern_31_[256 * 4]` layout; a
+ * point with x^2 + y^2 > 342 (it could rotate to more than 18 px from the keypoint) is refused with ORBFE_ERR_UNSUPPORTED: the
+ * descriptor stage reads +-18 px, which edge_threshold >= 19 keeps inside the level; the reference's table reaches x^2 + y^2 = 338. */
+int orbfe_set_pattern(orbfe_context *ctx, const int32_t *pattern);
+int orbfe_get_pattern(const orbfe_context *ctx, int32_t *pattern);
 
 /* Getters of include/ORBextractor.h:61-82 (GetLevels/GetScaleFactors/...), plus
  * mnFeaturesPerLevel and umax for tests.  Arrays hold nlevels entries (umax: half_patch+1). */

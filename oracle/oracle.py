@@ -85,6 +85,8 @@ def lib(target: str = "liborb_oracle.so"):
     L.orc_ic_angle.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.orc_orb_descriptor.restype = None
     L.orc_orb_descriptor.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_void_p]
+    L.orc_extractor_set_pattern.restype = None; L.orc_extractor_set_pattern.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_extractor_pattern.restype = i32p; L.orc_extractor_pattern.argtypes = [C.c_void_p]
     L.orc_stereo_matches.restype = C.c_int
     L.orc_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                      C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -327,6 +329,15 @@ class Extractor:
     def umax(self):
         p = self.L.orc_extractor_umax(self.h)
         return np.array([p[i] for i in range(self.params.half_patch_size + 1)], dtype=np.int32)
+
+    def set_pattern(self, pattern):
+        """Replace the extractor's copy of the 256 x (x0, y0, x1, y1) rBRIEF tests (src/ORBextractor.cc:442-444)."""
+        pat = np.ascontiguousarray(np.asarray(pattern, dtype=np.int32).reshape(1024))
+        self.L.orc_extractor_set_pattern(self.h, _ptr(pat))
+
+    def pattern(self):
+        p = self.L.orc_extractor_pattern(self.h)
+        return np.array([p[i] for i in range(1024)], dtype=np.int32).reshape(256, 4)
 
     def level_size(self, w, h, level):
         lw, lh = C.c_int(), C.c_int()

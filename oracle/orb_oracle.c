@@ -645,7 +645,7 @@ float orc_ic_angle(const uint8_t *img, size_t stride, int cx, int cy, const int3
 
 /* computeOrbDescriptor, reference src/ORBextractor.cc:103-142.  cos/sin via the
  * contract routine (Q4); products and sums individually rounded. */
-void orc_orb_descriptor(const uint8_t *img, size_t stride, int cx, int cy, float angle_deg, uint8_t *desc32)
+void orc_orb_descriptor_pat(const uint8_t *img, size_t stride, int cx, int cy, float angle_deg, const int32_t *pat, uint8_t *desc32)
 {
     const float factor_pi = (float)(3.14159265358979323846 / (double)180.f);
     float angle = angle_deg * factor_pi;
@@ -653,7 +653,7 @@ void orc_orb_descriptor(const uint8_t *img, size_t stride, int cx, int cy, float
     orc_sincos_det(angle, &b, &a); /* a = cos, b = sin */
     const uint8_t *center = img + (size_t)cy * stride + cx;
     const ptrdiff_t step = (ptrdiff_t)stride;
-    const int32_t *pat = g_bit_pattern_31;
+    if (!pat) pat = g_bit_pattern_31;
     for (int i = 0; i < 32; i++) {
         int val = 0;
         for (int bit = 0; bit < 8; bit++, pat += 4) {
@@ -668,6 +668,12 @@ void orc_orb_descriptor(const uint8_t *img, size_t stride, int cx, int cy, float
     }
 }
 
+/* the compiled bit_pattern_31_ (src/ORBextractor.cc:145-403) */
+void orc_orb_descriptor(const uint8_t *img, size_t stride, int cx, int cy, float angle_deg, uint8_t *desc32)
+{
+    orc_orb_descriptor_pat(img, stride, cx, cy, angle_deg, g_bit_pattern_31, desc32);
+}
+
 /* ------------------------------------------------------------------ */
 /* extractor object                                                    */
 /* ------------------------------------------------------------------ */
@@ -680,6 +686,7 @@ struct orc_extractor {
     float scale[ORC_MAX_LEVELS], inv_scale[ORC_MAX_LEVELS], sigma2[ORC_MAX_LEVELS], inv_sigma2[ORC_MAX_LEVELS];
     int32_t feats[ORC_MAX_LEVELS];
     int32_t umax[64];
+    int32_t pattern[256 * 4]; /* std::vector<cv::Point> pattern: the extractor's own copy of the 512 points (src/ORBextractor.cc:442-444) */
     /* state of the latest call */
     uint8_t *pyr[ORC_MAX_LEVELS];
     int lw[ORC_MAX_LEVELS], lh[ORC_MAX_LEVELS];
@@ -694,6 +701,7 @@ orc_extractor *orc_extractor_create(const orc_params *p)
         return NULL;
     orc_extractor *ex = (orc_extractor *)calloc(1, sizeof(*ex));
     ex->p = *p;
+    memcpy(ex->pattern, g_bit_pattern_31, sizeof(ex->pattern)); /* std::copy(pattern0, pattern0 + npoints, ...) :442-444 */
     ex->scale_factor_d = (double)p->scale_factor;
     ex->scale[0] = 1.0f; ex->sigma2[0] = 1.0f;
     for (int i = 1; i < p->nlevels; i++) {
@@ -745,6 +753,10 @@ void orc_extractor_destroy(orc_extractor *ex)
 }
 
 int orc_extractor_nlevels(const orc_extractor *ex) { return ex->p.nlevels; }
+/* The reference's extractor owns a copy of the test pattern (member `pattern`, include/ORBextractor.h:93); a deployment that
+ * distributes another table (BASELINE north_star: "broadcast of the ORB pattern") replaces it here: 256 tests x (x0, y0, x1, y1). */
+void orc_extractor_set_pattern(orc_extractor *ex, const int32_t *pat1024) { memcpy(ex->pattern, pat1024, sizeof(ex->pattern)); }
+const int32_t *orc_extractor_pattern(const orc_extractor *ex) { return ex->pattern; }
 const float *orc_extractor_scale_factors(const orc_extractor *ex) { return ex->scale; }
 const float *orc_extractor_inv_scale_factors(const orc_extractor *ex) { return ex->inv_scale; }
 const float *orc_extractor_sigma2(const orc_extractor *ex) { return ex->sigma2; }
@@ -893,7 +905,7 @@ int orc_extract(orc_extractor *ex, const uint8_t *img, int w, int h, size_t stri
                 float ang = orc_ic_angle(ex->pyr[level], (size_t)lw, icx, icy, ex->umax, ex->p.half_patch_size);
                 if (total < cap) {
                     orc_keypoint *kp = &kps[total];
-                    orc_orb_descriptor(blur, (size_t)lw, icx, icy, ang, desc + (size_t)total * 32);
+                    orc_orb_descriptor_pat(blur, (size_t)lw, icx, icy, ang, ex->pattern, desc + (size_t)total * 32);
                     kp->x = px; kp->y = py;
                     if (level != 0) { kp->x = px * scale; kp->y = py * scale; }
                     kp->size = (float)scaled_patch;

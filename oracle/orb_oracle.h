@@ -116,6 +116,11 @@ int orc_distribute_octtree(const int32_t *xs, const int32_t *ys, const int32_t *
 
 float orc_ic_angle(const uint8_t *img, size_t stride, int cx, int cy, const int32_t *umax, int half_patch);
 void orc_orb_descriptor(const uint8_t *img, size_t stride, int cx, int cy, float angle_deg, uint8_t *desc32);
+/* the same with an explicit test table (256 x (x0, y0, x1, y1)); NULL = the compiled bit_pattern_31_ */
+void orc_orb_descriptor_pat(const uint8_t *img, size_t stride, int cx, int cy, float angle_deg, const int32_t *pat, uint8_t *desc32);
+/* the extractor's own copy of the pattern (src/ORBextractor.cc:442-444) */
+void orc_extractor_set_pattern(orc_extractor *ex, const int32_t *pat1024);
+const int32_t *orc_extractor_pattern(const orc_extractor *ex);
 
 /* ---- Frame::ComputeStereoMatches ---- */
 /* Uses the pyramids held by exL/exR (latest orc_extract calls).  mb := bf/fx (Q1). */

@@ -21,6 +21,7 @@ assert KP_DTYPE.itemsize == 28
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 
 EXPORTS = [
+    "orbfe_build_id", "orbfe_set_pattern", "orbfe_get_pattern",
     "orbfe_abi_version", "orbfe_last_error", "orbfe_create", "orbfe_destroy", "orbfe_levels",
     "orbfe_keypoint_capacity", "orbfe_get_tables", "orbfe_level_size", "orbfe_extract",
     "orbfe_stereo_frame", "orbfe_rgbd_frame", "orbfe_rgbd_frame_u16", "orbfe_fetch_pyramid", "orbfe_enqueue_extract",
@@ -76,6 +77,11 @@ class OrbfeError(RuntimeError):
 _lib = None
 
 
+def build_id() -> str:
+    """orbfe_build_id(): sha256 over the sources and flags liborbfe.so was built from."""
+    return load().orbfe_build_id().decode()
+
+
 def load():
     """Load liborbfe.so; raises if it has not been built (no fallback)."""
     global _lib
@@ -93,6 +99,9 @@ def load():
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.orbfe_abi_version.restype = C.c_int
+    L.orbfe_build_id.restype = C.c_char_p
+    L.orbfe_set_pattern.restype = C.c_int; L.orbfe_set_pattern.argtypes = [vp, vp]
+    L.orbfe_get_pattern.restype = C.c_int; L.orbfe_get_pattern.argtypes = [vp, vp]
     L.orbfe_last_error.restype = C.c_char_p; L.orbfe_last_error.argtypes = [vp]
     L.orbfe_create.restype = C.c_int; L.orbfe_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
     L.orbfe_destroy.restype = None; L.orbfe_destroy.argtypes = [vp]
@@ -234,6 +243,16 @@ class Context:
         w, h = C.c_int(), C.c_int()
         self._check(self.L.orbfe_level_size(self.h, level, C.byref(w), C.byref(h)))
         return w.value, h.value
+
+    def set_pattern(self, pattern):
+        """Replace the context's copy of the 256 x (x0, y0, x1, y1) rBRIEF tests (ORBextractor::pattern, src/ORBextractor.cc:442-444)."""
+        pat = np.ascontiguousarray(np.asarray(pattern, dtype=np.int32).reshape(1024))
+        self._check(self.L.orbfe_set_pattern(self.h, _p(pat)))
+
+    def pattern(self):
+        pat = np.zeros(1024, np.int32)
+        self._check(self.L.orbfe_get_pattern(self.h, _p(pat)))
+        return pat.reshape(256, 4)
 
     # ---- host-image entry points ----
     @staticmethod

@@ -21,6 +21,10 @@
 #include <vector>
 
 size_t orbfe_octree_lds_bytes(const DeviceConfig &cfg);
+// bit_pattern_31_ (src/ORBextractor.cc:145-403, re-emitted by tools/extract_pattern.py): the default of every context's pattern copy
+static const int8_t k_bit_pattern_31[1024] = {
+#include "orb_pattern_31.inc"
+};
 #define ORBFE_MAX_GROUPS 8
 
 struct orbfe_context {
@@ -81,6 +85,7 @@ struct orbfe_context {
     hipEvent_t ev_fork = nullptr, ev_join[ORBFE_MAX_GROUPS] = {};
     float scale[ORBFE_MAX_LEVELS], inv_scale[ORBFE_MAX_LEVELS], sigma2[ORBFE_MAX_LEVELS], inv_sigma2[ORBFE_MAX_LEVELS];
     int32_t feats[ORBFE_MAX_LEVELS];
+    int8_t pattern[1024];     // host copy of DeviceBuffers::pattern
     std::vector<void *> allocs;
     orbfe_match_state *match = nullptr;
     orbfe_bow_state *bow = nullptr;
@@ -166,6 +171,12 @@ orbfe_bow_state *orbfe_ctx_bow_state(orbfe_context *ctx)
     } while (0)
 
 extern "C" int orbfe_abi_version(void) { return ORBFE_ABI_VERSION; }
+#include "build/orbfe_build_id.h" // generated by the Makefile: sha256 over the library's sources and compile flags
+#ifdef ORBFE_PROFILE_CUTS
+extern "C" const char *orbfe_build_id(void) { return ORBFE_BUILD_ID "+cuts"; }
+#else
+extern "C" const char *orbfe_build_id(void) { return ORBFE_BUILD_ID; }
+#endif
 extern "C" const char *orbfe_last_error(const orbfe_context *ctx) { return ctx ? ctx->err : g_err; }
 
 static int cv_round_f(float v) { return (int)lrintf(v); }
@@ -963,6 +974,16 @@ try {
         }
         b.mom_tab = d_mt;
     }
+    {   // the context's copy of the 256 rBRIEF tests (ORBextractor's member `pattern`, src/ORBextractor.cc:442-444)
+        uint32_t *d_pat = nullptr;
+        A(d_pat, 256);
+        if (hipMemcpy(d_pat, k_bit_pattern_31, 1024, hipMemcpyHostToDevice) != hipSuccess) {
+            orbfe_destroy(ctx);
+            return fail(nullptr, ORBFE_ERR_HIP, "pattern upload failed");
+        }
+        b.pattern = d_pat;
+        memcpy(ctx->pattern, k_bit_pattern_31, 1024);
+    }
     {
         const char *ni = getenv("ORBFE_NO_INPLACE");
         const DeviceConfig &cc = ctx->cfg;
@@ -1010,6 +1031,37 @@ extern "C" int orbfe_get_camera(const orbfe_context *ctx, float *cam)
 try {
     if (!ctx || !cam) return ORBFE_ERR_INVALID;
     cam[0] = ctx->params.fx; cam[1] = ctx->params.fy; cam[2] = ctx->params.cx; cam[3] = ctx->params.cy; cam[4] = ctx->params.bf;
+    return ORBFE_OK;
+} ORBFE_CATCH(nullptr)
+
+static int wait_latest(orbfe_context *ctx);
+// ORBextractor copies bit_pattern_31_ into its member `pattern` (src/ORBextractor.cc:442-444); a deployment that distributes the
+// table (one broadcast from rank 0: orbslam2_amd/dist.py) hands it to every context here.  Takes effect for calls enqueued afterwards.
+extern "C" int orbfe_set_pattern(orbfe_context *ctx, const int32_t *pattern)
+try {
+    ORBFE_ENTRY(ctx);
+    if (!ctx || !pattern) return fail(ctx, ORBFE_ERR_INVALID, "null argument");
+    int8_t pk[1024];
+    for (int i = 0; i < 512; i++) {
+        const int x = pattern[2 * i], y = pattern[2 * i + 1];
+        // describe_kernel stages +-18 px around a keypoint (what edge_threshold >= 19 guarantees inside the level): a rotated
+        // test point lands cvRound(r * cos / sin) <= cvRound(r) px away, r^2 = x^2 + y^2; r^2 <= 342 <=> r <= 18.493 rounds to 18
+        // (bit_pattern_31_ itself reaches r^2 = 338: the point (13, 13))
+        if (x < -18 || x > 18 || y < -18 || y > 18 || x * x + y * y > 342)
+            return fail(ctx, ORBFE_ERR_UNSUPPORTED, "pattern point %d = (%d, %d) can rotate to more than 18 px from the keypoint", i, x, y);
+        pk[2 * i] = (int8_t)x; pk[2 * i + 1] = (int8_t)y;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->params.device));
+    { const int rcw = wait_latest(ctx); if (rcw != ORBFE_OK) return rcw; } // calls already enqueued keep the table they were enqueued with
+    HIP_TRY(ctx, hipMemcpy((void *)ctx->buf.pattern, pk, 1024, hipMemcpyHostToDevice));
+    memcpy(ctx->pattern, pk, 1024);
+    return ORBFE_OK;
+} ORBFE_CATCH(ctx)
+
+extern "C" int orbfe_get_pattern(const orbfe_context *ctx, int32_t *pattern)
+try {
+    if (!ctx || !pattern) return ORBFE_ERR_INVALID;
+    for (int i = 0; i < 1024; i++) pattern[i] = ctx->pattern[i];
     return ORBFE_OK;
 } ORBFE_CATCH(nullptr)
 

@@ -2,9 +2,7 @@
 #include "orbfe_common.hpp"
 #include "orbfe_rowlist.hpp"
 
-__device__ __attribute__((aligned(16))) const int8_t g_pattern[1024] = {
-#include "orb_pattern_31.inc"
-};
+// the 256 tests come from DeviceBuffers::pattern (the context's own copy, as ORBextractor keeps one: src/ORBextractor.cc:442-444)
 
 // ---------------------------------------------------------------------------
 // orientation + descriptor + final keypoint record: one wave per keypoint slot
@@ -55,7 +53,7 @@ __global__ __launch_bounds__(256, 8) void describe_generic_kernel(DeviceConfig c
     uint8_t *s_blr = s_raw + raw_bytes;
     if (cfg.half_patch != 15) // the offset list is only read by the generic moment loop
         for (int i = tid; i < cfg.patch_n / 2; i += 256) ((int *)s_uv)[i] = ((const int *)buf.patch_uv)[i];
-    s_pat[tid] = ((const int *)g_pattern)[tid];
+    s_pat[tid] = (int)buf.pattern[tid];
     // per-wave slot data, one slot per lane (lanes < DS_KPW), issued before the barrier
     const int my_slot = slot0 + (lane < DS_KPW ? lane : 0);
     const bool my_in = lane < DS_KPW && my_slot < cfg.sel_total;
@@ -325,7 +323,7 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
     float4 *s_patf = (float4 *)s_dm;
     uint8_t *s_blr = s_dm + 256 * sizeof(float4) + wave * (DS_BLR_ROWS * DS_PATCH_W);
     {
-        const int pw = ((const int *)g_pattern)[tid];
+        const int pw = (int)buf.pattern[tid];
         s_patf[tid] = make_float4((float)(int)(int8_t)(pw & 0xff), (float)(int)(int8_t)((pw >> 8) & 0xff), (float)(int)(int8_t)((pw >> 16) & 0xff), (float)(pw >> 24));
     }
     const int my_slot = slot0 + (lane < DS_KPW ? lane : 0);

@@ -169,6 +169,8 @@ struct DeviceBuffers {
     const uint8_t *slot_level; // [sel_total] level of every keypoint slot
     const int16_t *patch_uv; // IC_Angle patch offsets: (u & 0xff) | (v << 8), padded with (0,0)
     const uint32_t *mom_tab; // [64 lanes][12] byte-dot-product weights of the same patch (hp == 15), see orbfe_api.hip
+    const uint32_t *pattern; // [256] the extractor's copy of the rBRIEF tests (src/ORBextractor.cc:442-444): x0 | y0 << 8 | x1 << 16 | y1 << 24 as int8;
+                             // the compiled bit_pattern_31_ unless orbfe_set_pattern replaced it
 };
 
 // Quadtree buckets (orbfe_octree3.hip).  A candidate's bucket = its root and quadrant path down to depth 5; the

@@ -1,9 +1,11 @@
 """Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" == RCCL over xGMI).
 
 Frame pairs are independent units: ranks shard them round-robin and never exchange
-pixels, keypoints or matches.  The only collective on the path is a ONE-TIME broadcast of the extractor
-parameters and the rBRIEF pattern checksum from rank 0 (every rank checks it runs the same front-end),
-plus a MAX all-reduce of the elapsed time for reporting.  CPU tests run the same code over gloo.
+pixels, keypoints or matches.  The only collectives on the path are ONE-TIME broadcasts from rank 0 -- the
+extractor parameters, the rBRIEF pattern table itself (4 KiB as int32, `broadcast_pattern`; every rank hands
+it to its context with `orbfe_set_pattern`, as ORBextractor copies the table per object,
+src/ORBextractor.cc:442-444) and the vocabulary -- plus a MAX all-reduce of the elapsed time for reporting.
+CPU tests run the same code over gloo.
 """
 from __future__ import annotations
 
@@ -56,6 +58,40 @@ def broadcast_params(blob: bytes, device) -> bytes:
         if not torch.equal(mine[n:], t[n:]):
             raise RuntimeError("rank %d: rBRIEF pattern differs from rank 0" % dist.get_rank())
     return bytes(t.cpu().numpy().tobytes())
+
+
+def compiled_pattern():
+    """bit_pattern_31_ as the library was compiled with it (orb_pattern_31.inc): int32 [256][4] = x0 y0 x1 y1 per test."""
+    import re
+    import numpy as np
+    text = re.sub(r"/\*.*?\*/", "", open(PATTERN_PATH).read(), flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    v = np.array([int(t) for t in re.findall(r"-?\d+", text)], dtype=np.int32)
+    if v.size != 1024:
+        raise RuntimeError("orb_pattern_31.inc: expected 1024 integers, found %d" % v.size)
+    return v.reshape(256, 4)
+
+
+def broadcast_pattern(pattern, device):
+    """The rBRIEF test table of rank 0 on every rank (BASELINE north_star: "RCCL broadcast of the ORB pattern"): 1024 int32
+    + their sha256 in one collective; `pattern` is ignored on the other ranks (None allowed).  Returns int32 [256][4]; the
+    caller passes it to Context.set_pattern.  Without a process group it is a checked copy."""
+    import numpy as np
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if rank == 0:
+        if pattern is None:
+            raise ValueError("broadcast_pattern: rank 0 must supply the table")
+        body = np.ascontiguousarray(np.asarray(pattern, dtype="<i4").reshape(1024)).tobytes()
+        payload = body + hashlib.sha256(body).digest()
+        t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
+    else:
+        t = torch.empty(4096 + 32, dtype=torch.uint8, device=device)
+    if dist.is_initialized():
+        dist.broadcast(t, src=0)
+    raw = t.cpu().numpy().tobytes()
+    if hashlib.sha256(raw[:4096]).digest() != raw[4096:]:
+        raise RuntimeError("rank %d: pattern table corrupted in the broadcast" % rank)
+    return np.frombuffer(raw[:4096], dtype="<i4").reshape(256, 4).copy()
 
 
 def broadcast_blob(blob, device) -> bytes:

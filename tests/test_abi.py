@@ -24,7 +24,9 @@ def test_every_declared_symbol_is_exported():
     for n in names:
         assert hasattr(lib, n), "liborbfe.so does not export %s" % n
     assert sorted(api.EXPORTS) == names, "api.EXPORTS out of sync with include/orbfe.h"
-    assert lib.orbfe_abi_version() == 5  # 2: orbfe_frame_view.device_slot_plus1; 3: .keyframe; 4: orbfe_get_camera, orbfe_assign_features_to_grid; 5: packed fetch, orbfe_enqueue_rgbd
+    assert lib.orbfe_abi_version() == 6  # 2: orbfe_frame_view.device_slot_plus1; 3: .keyframe; 4: orbfe_get_camera, orbfe_assign_features_to_grid; 5: packed fetch, orbfe_enqueue_rgbd; 6: orbfe_build_id, orbfe_set_pattern, orbfe_get_pattern
+    bid = lib.orbfe_build_id().decode()
+    assert len(bid) == 64 and all(c in "0123456789abcdef" for c in bid), bid
 
 
 def test_struct_layouts():

@@ -408,3 +408,20 @@ def test_descriptor_against_numpy_reimplementation(small_pair):
         bits = (samp(pat[:, 0], pat[:, 1]) < samp(pat[:, 2], pat[:, 3])).astype(np.uint8)
         ref = np.packbits(bits.reshape(32, 8)[:, ::-1], axis=1).ravel()                      # bit k of byte j = test 8j + k
         assert np.array_equal(ref, d[i]), i
+
+
+def test_descriptor_follows_the_extractors_own_pattern_copy():
+    """ORBextractor keeps its own copy of the 512 test points (src/ORBextractor.cc:442-444) and computeOrbDescriptor reads bit i
+    from points 2 i, 2 i + 1 (:116-136): permuting the 256 tests permutes the descriptor's bits and changes nothing else."""
+    from orbslam2_amd import dist as D, synth
+    img = synth.stereo_pair(240, 180, seed=5)[0]
+    pat = D.compiled_pattern()
+    perm = np.random.default_rng(2).permutation(256)
+    ex0, ex1 = O.Extractor(nfeatures=300), O.Extractor(nfeatures=300)
+    assert np.array_equal(ex0.pattern(), pat)
+    ex1.set_pattern(pat[perm])
+    (k0, d0), (k1, d1) = ex0.extract(img), ex1.extract(img)
+    assert len(k0) > 100 and np.array_equal(k0, k1)
+    b0 = np.unpackbits(d0, axis=1, bitorder="little")
+    b1 = np.unpackbits(d1, axis=1, bitorder="little")
+    assert np.array_equal(b1, b0[:, perm])

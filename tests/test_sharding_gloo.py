@@ -58,6 +58,28 @@ def _worker(rank, world, port, q):
     hv = OL.orc_vocab_from_blob(buf.ctypes.data_as(C.c_void_p), len(buf))
     assert hv
     OL.orc_vocab_destroy(hv)
+    # the rBRIEF test table itself travels (north_star: "broadcast of the ORB pattern"): rank 0 owns a PERMUTED table, the other
+    # ranks start from nothing; every rank must end up with rank 0's 1024 integers, and an extractor given them must differ from
+    # the compiled table's descriptors in the same way on every rank
+    pat0 = None
+    if rank == 0:
+        pat0 = D.compiled_pattern()[np.random.default_rng(11).permutation(256)]
+    pat = D.broadcast_pattern(pat0, dev)
+    pd = [None] * world
+    dist.all_gather_object(pd, hashlib.sha256(pat.tobytes()).hexdigest())
+    assert len(set(pd)) == 1, pd
+    assert pat.shape == (256, 4) and not np.array_equal(pat, D.compiled_pattern())
+    assert sorted(map(tuple, pat.tolist())) == sorted(map(tuple, D.compiled_pattern().tolist()))
+    from orbslam2_amd import synth
+    img = synth.stereo_pair(W, H, seed=900)[0]
+    ex_def, ex_pat = O.Extractor(nfeatures=NF), O.Extractor(nfeatures=NF)
+    ex_pat.set_pattern(pat)
+    assert np.array_equal(ex_pat.pattern(), pat)
+    (k0, d0), (k1, d1) = ex_def.extract(img), ex_pat.extract(img)
+    assert np.array_equal(k0, k1) and not np.array_equal(d0, d1) # the table only enters the descriptors
+    dd = [None] * world
+    dist.all_gather_object(dd, hashlib.sha256(d1.tobytes()).hexdigest())
+    assert len(set(dd)) == 1, dd
     my_pairs = D.shard_pairs(TOTAL_PAIRS, rank, world)
     res = {i: _pair_result(i) for i in my_pairs}
     gathered = [None] * world
