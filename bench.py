@@ -73,14 +73,46 @@ def stage_alg_bytes_per_pair(n_cand_per_image: float):
     }
 
 
-def traffic_bytes(stage: str, pairs: int, launches: int):
-    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (profiles/r02_traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate passes of this same command, gfx950 correction 2 x FETCH_SIZE as
-    MI355X_MICROARCH.md prescribes), scaled from the profiled batch to this run's batch; None if not profiled."""
-    # (profiles/r03_traffic.json when this round's passes are committed, else the latest earlier round)
+PROFILE_ROUND = "r05"
+_STALE = []  # profile files whose build id is not the id of the library that ran (reported as roofline.stale_profiles)
+
+
+def lib_build_id():
     try:
-        path = next(q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")) if os.path.exists(q))
-        t = json.load(open(path))["kernels"][stage]
+        from orbslam2_amd import api
+        return api.build_id()
+    except Exception:
+        return None
+
+
+def _profile_path(name):
+    """profiles/<round>_<name> -- ONLY this round's file, and only when it carries the build id of the liborbfe.so this process
+    has loaded (tools/collect_profiles.sh stamps every counter file with orbfe_build_id() of the build it profiled).  Counters of
+    another build are not replayed: the field they would feed is null and the file is listed under roofline.stale_profiles."""
+    path = os.path.join(ROOT, "profiles", "%s_%s" % (PROFILE_ROUND, name))
+    if not os.path.exists(path):
+        return None
+    try:
+        if path.endswith(".json"):
+            have = json.load(open(path)).get("build_id")
+        else:
+            first = open(path).readline()
+            have = first.split("build_id:")[1].strip() if "build_id:" in first else None
+    except Exception:
+        have = None
+    if have is None or have != lib_build_id():
+        if os.path.basename(path) not in _STALE:
+            _STALE.append(os.path.basename(path))
+        return None
+    return path
+
+
+def traffic_bytes(stage: str, pairs: int, launches: int):
+    """HBM bytes per launch of the stage's kernel REPLAYED from this round's committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate passes of this same command, gfx950 correction 2 x FETCH_SIZE as MI355X_MICROARCH.md
+    prescribes), scaled from the profiled batch to this run's batch; None if not profiled or profiled on another build."""
+    try:
+        t = json.load(open(_profile_path("traffic.json")))["kernels"][stage]
         per_pair = (2.0 * t["fetch_kb_per_pair"] + t["write_kb_per_pair"]) * 1024.0
         return per_pair * pairs / launches
     except Exception:
@@ -88,11 +120,11 @@ def traffic_bytes(stage: str, pairs: int, launches: int):
 
 
 def whole_step_traffic_per_pair():
-    """Counter bytes (2 * FETCH_SIZE + WRITE_SIZE) * 1024 of every kernel of a step, per pair, from the same committed passes (decimal
-    bytes, to be set against SURVEY's 19 567 078 algorithmic bytes); None if not profiled.  The stereo matcher's descriptor gathers are
-    counted by FETCH_SIZE as whole 64-byte sectors (tools/ubench/fetch_calib.hip), so its share is an upper bound."""
+    """Counter bytes (2 * FETCH_SIZE + WRITE_SIZE) * 1024 of every kernel of a step, per pair, from the same passes (decimal
+    bytes, to be set against SURVEY's 19 567 078 algorithmic bytes); None if not profiled on this build.  The stereo matcher's
+    descriptor gathers are counted by FETCH_SIZE as whole 64-byte sectors (tools/ubench/fetch_calib.hip), so its share is an upper bound."""
     try:
-        path = next(q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json")) if os.path.exists(q))
+        path = _profile_path("traffic.json")
         ks = json.load(open(path))["kernels"]
         return sum((2.0 * t["fetch_kb_per_pair"] + t["write_kb_per_pair"]) * 1024.0 for t in ks.values()), os.path.basename(path)
     except Exception:
@@ -100,32 +132,28 @@ def whole_step_traffic_per_pair():
 
 
 def _sq_valu_per_pair():
-    """SQ_INSTS_VALU per stereo pair of every kernel of the step, from the committed rocprofv3 counter pass (launches of 64 pairs;
-    the pyramid's resize kernel -- with the blur of the level it reads fused in -- runs once per level; the counts file says how often): {kernel name fragment: wave-instructions per pair}."""
-    for name in ("r04_pmc_sq.txt", "r03_pmc_sq.txt", "r02_pmc_sq.txt", "r01_pmc_sq.txt"):
-        path = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(path):
+    """SQ_INSTS_VALU per stereo pair of every kernel of the step, from this round's rocprofv3 counter pass on this build (launches
+    of 64 pairs; the counts file says how often a kernel ran per step): {kernel name fragment: wave-instructions per pair}."""
+    path = _profile_path("pmc_sq.txt")
+    if path is None:
+        return None, None
+    rows = []
+    for line in open(path):
+        if "SQ_INSTS_VALU" not in line or "{" not in line:
             continue
-        rows = []
-        for line in open(path):
-            if "SQ_INSTS_VALU" not in line or "{" not in line:
-                continue
-            d = eval(line[line.index("{"):line.rindex("}") + 1], {"__builtins__": {}})
-            kern = line[:line.index("{")].strip()
-            tail = line[line.rindex("}"):]
-            n = int(tail[tail.index("n=") + 2:]) if "n=" in tail else 1
-            if "rocclr" in kern or "candidates_gather" in kern:  # runtime copies; the parity tap of the post-run check
-                continue
-            rows.append((kern, d["SQ_INSTS_VALU"], n))
-        # launches per step of a kernel = its dispatch count / fast_cell_kernel's (one per step): the resize kernel runs once per
-        # level (4 with the fused tail, 7 without)
-        steps = max([n for k, _, n in rows if "fast_cell_kernel" in k] or [1])
-        out = {}
-        for kern, v, n in rows:
-            out[kern] = out.get(kern, 0.0) + v * (n / steps) / 64.0
-        if out:
-            return out, name
-    return None, None
+        d = eval(line[line.index("{"):line.rindex("}") + 1], {"__builtins__": {}})
+        kern = line[:line.index("{")].strip()
+        tail = line[line.rindex("}"):]
+        n = int(tail[tail.index("n=") + 2:]) if "n=" in tail else 1
+        if "rocclr" in kern or "candidates_gather" in kern:  # runtime copies; the parity tap of the post-run check
+            continue
+        rows.append((kern, d["SQ_INSTS_VALU"], n))
+    # launches per step of a kernel = its dispatch count / fast_cell_kernel's (one per step)
+    steps = max([n for k, _, n in rows if "fast_cell_kernel" in k] or [1])
+    out = {}
+    for kern, v, n in rows:
+        out[kern] = out.get(kern, 0.0) + v * (n / steps) / 64.0
+    return (out, os.path.basename(path)) if out else (None, None)
 
 
 def valu_issue(pairs: int, launches: int, launch_ms: float, step_ms: float):
@@ -149,8 +177,8 @@ def valu_issue(pairs: int, launches: int, launch_ms: float, step_ms: float):
                               "full-rate class (v_add_u32 ...) %.0f G/s" % (ops["v_pk_max_i16"]["8"]["cycles_per_wave_inst_per_simd"], full_rate / 1e9)}
         total = sum(per_pair.values()) * pairs
         whole = {"wave_insts_per_step": total, "frac": total / (step_ms * 1e-3) / half_rate}
-        mix_path = os.path.join(ROOT, "profiles", "r03_isa_mix.json")
-        if os.path.exists(mix_path):
+        mix_path = _profile_path("isa_mix.json")
+        if mix_path:
             mix = json.load(open(mix_path))["kernels"]
             simd_cycles_per_s = half_rate * ops["v_pk_max_i16"]["8"]["cycles_per_wave_inst_per_simd"]  # 1024 SIMDs x the clock the chip held
             def seconds(n, kern):  # n wave-instructions of kernel `kern` priced with its measured opcode mix
@@ -161,9 +189,10 @@ def valu_issue(pairs: int, launches: int, launch_ms: float, step_ms: float):
             out["frac_mix"] = seconds(insts, "fast_cell_kernel") / (launch_ms * 1e-3)
             out["mean_cycles_per_valu"] = mf["mean_cycles_per_valu"]
             out["full_rate_share"] = mf["full_rate_share"]
-            out["mix_source"] = "profiles/r03_isa_mix.json (tools/isa_mix.py: opcode histogram of the disassembly per phase x measured cycles per opcode, phases weighted by SQ_INSTS_VALU)"
+            out["mix_source"] = "profiles/" + os.path.basename(mix_path) + " (tools/isa_mix.py: opcode histogram of the disassembly per phase x measured cycles per opcode, phases weighted by SQ_INSTS_VALU)"
             whole["frac_mix"] = sum(seconds(n * pairs, k) for k, n in per_pair.items()) / (step_ms * 1e-3)
         out["whole_step"] = whole
+        out["source"] = "replayed"
         return out
     except Exception:
         pass
@@ -543,6 +572,40 @@ def cpu_baseline(n_pairs: int):
     return out
 
 
+def strong_pass(args, D, torch, make_ctx, d_images, share, P_total, world, cdev):
+    """BASELINE config 4 as worded on N ranks: P_total pairs per step in total, `share` of them on this rank (the first `share`
+    pairs of its resident batch), timed with the headline protocol (barrier + synchronize around EXACTLY --steps steps, MAX over
+    ranks, median of 3) with 1 and with --strong-chains step chains in flight.  Every step is enqueued exactly once, on context
+    k % chains (dist.chain_schedule); every rank runs all steps of its own share, so a step covers every pair exactly once."""
+    SC = max(1, min(args.strong_chains, 8))
+    ctxs = [make_ctx(share) for _ in range(SC)]
+    streams = [torch.cuda.Stream() for _ in range(SC)]
+    ptr = d_images.data_ptr()
+
+    def run(chains):
+        for k, c in D.chain_schedule(args.steps, chains):
+            ctxs[c].enqueue_stereo(ptr, share, streams[c].cuda_stream)
+
+    def timed(chains):
+        D.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(chains)
+        D.barrier(); torch.cuda.synchronize()
+        return D.max_over_ranks(time.perf_counter() - t0, cdev)
+
+    out = {"pairs_per_step_total": P_total, "pairs_per_step_per_gpu": [len(D.shard_pairs(P_total, r, world)) for r in range(world)]}
+    for chains in sorted({1, SC}):
+        run(chains)  # warm-up: every context once
+        dt = sorted(timed(chains) for _ in range(3))[1]
+        out["one_chain" if chains == 1 else "chains_%d" % chains] = {"chains_in_flight": chains, "value": P_total * args.steps / dt, "ms_per_step": dt / args.steps * 1e3}
+    best = out.get("chains_%d" % SC, out["one_chain"])
+    out.update({"value": best["value"], "ms_per_step": best["ms_per_step"], "chains_in_flight": best["chains_in_flight"],
+                "note": "same timing protocol (median of 3); `value` = the %d-chain figure (the product mode for small per-GPU batches), one_chain beside it" % best["chains_in_flight"]})
+    for c in ctxs:
+        c.close()
+    return out
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` with N > 1 and no launcher environment (the way the driver starts the N = 1 run): this process starts
     the N ranks itself -- one child per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, exactly what torch.distributed.run
@@ -630,9 +693,23 @@ def launcher_selftest(args, D, rank, world, real_stdout):
     voc = D.broadcast_blob(bytes(range(256)) * 16 if rank == 0 else None, cdev)
     t = D.max_over_ranks(1.0 + rank, cdev)
     assert t == float(world), t
+    # the strong-scaling pass with chains in flight (strong_pass): every (step, pair) is enqueued exactly once over all ranks and chains
+    pat = D.broadcast_pattern(D.compiled_pattern() if rank == 0 else None, cdev)
+    assert pat.shape == (256, 4)
+    SC = max(1, min(args.strong_chains, 8))
+    mine = D.shard_pairs(args.pairs, rank, world)
+    cover = [(k, c, p) for k, c in D.chain_schedule(args.steps, SC) for p in mine]
+    allc = [None] * world
+    dist.all_gather_object(allc, cover)
+    seen = {}
+    for r, cv in enumerate(allc):
+        for k, c, p in cv:
+            seen.setdefault((k, p), []).append((r, c))
+    strong_ok = (sorted(seen) == [(k, p) for k in range(args.steps) for p in range(args.pairs)] and all(len(v) == 1 for v in seen.values())
+                 and all(c == k % SC for cv in allc for k, c, _ in cv))
     D.barrier()
     if rank == 0:
-        out = {"selftest": "launcher", "n_gpus": joined, "value": None,
+        out = {"selftest": "launcher", "n_gpus": joined, "value": None, "strong_cover_exactly_once": bool(strong_ok), "strong_chains": SC,
                "config": {"rccl": {"ranks": joined, "backend": "gloo", "broadcast_bytes": len(params_blob) + len(voc) + 8 + 32,
                                    "self_launched": os.environ.get("ORBFE_BENCH_SELF_LAUNCHED") == "1"}}}
         sys.stdout.flush()
@@ -649,9 +726,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU (in flight in HBM; BASELINE.json config 4 batches 64 pairs)")
-    ap.add_argument("--chains", type=int, default=1, help="step chains in flight per GPU in the HEADLINE region: step k runs on context k %% chains and its stream (1 = one chain at a time)")
+    ap.add_argument("--chains", type=int, default=0, help="0 = 1 in --mode weak, --strong-chains in --mode strong; step chains in flight per GPU in the HEADLINE region: step k runs on context k %% chains and its stream (1 = one chain at a time)")
     ap.add_argument("--pipelined", type=int, default=3, help="after the headline region, time the same steps with this many chains in flight -> config.pipelined (0 / 1 = skip)")
     ap.add_argument("--repeat", type=int, default=5, help="the timed region (--steps steps) is repeated this often; value = median, config.repeat = min / max")
+    ap.add_argument("--min-region-ms", type=float, default=100.0, help="keep repeating the timed region until the regions add up to this much timed GPU work (at most 64 regions)")
+    ap.add_argument("--strong-chains", type=int, default=4, help="step chains in flight in the strong-scaling regime (8 pairs per GPU per step at N = 8 are launch-latency-bound with one): --mode strong runs its headline with this many, the strong pass beside a weak run reports 1 and this many")
     ap.add_argument("--streams", type=int, default=1, help="stream groups the batch is cut into inside the library (1 keeps per-kernel times clean)")
     ap.add_argument("--cpu-pairs", type=int, default=300, help="pairs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -735,6 +814,8 @@ def main():
     P = args.pairs if args.mode == "weak" else len(mine)
     if P < 1:
         raise SystemExit("bench: --mode strong needs --pairs >= number of GPUs")
+    if args.chains <= 0:
+        args.chains = 1 if args.mode == "weak" else args.strong_chains
     C = max(1, min(args.chains, 8))
     CP = max(C, min(args.pipelined, 8)) if args.pipelined > 1 else C  # contexts needed in all
     G = max(1, min(args.streams, P, 8))
@@ -802,11 +883,15 @@ def main():
         c.set_profiling_interval(EVERY)
     R = max(1, args.repeat)
     dts, dom_ms_sum, dom_calls = [], 0.0, 0
-    for _ in range(R):
+    # the region of EXACTLY --steps steps (barrier + synchronize on both sides) is repeated at least --repeat times and until the
+    # regions add up to --min-region-ms of timed GPU work (20 steps are ~13 ms: too short for a stable median on a fresh box);
+    # value = the median region, config.repeat = n / min / max
+    while len(dts) < R or (sum(dts) * 1e3 < args.min_region_ms and len(dts) < 64):
         dts.append(timed(args.steps))
         for c in ctxs[:C]:
             ms, calls = c.stage_times(reset=True)
             dom_ms_sum += ms[DOM]; dom_calls += calls
+    R = len(dts)
     dt = sorted(dts)[len(dts) // 2]
     # the dominant kernel alone on the chip (one chain at a time): what the co-scheduled figure of the timed region stretches
     for c in ctxs:
@@ -838,17 +923,12 @@ def main():
     for c in ctxs:
         c.set_profiling(0)
 
-    # strong-scaling pass beside a weak run on several GPUs: P_total pairs in total, this rank's share per step
+    # strong-scaling pass beside a weak run on several GPUs: P_total pairs in total, this rank's share per step -- with ONE step
+    # chain and with --strong-chains chains in flight (contexts sized for the share, step k on context k % chains: the product mode
+    # of config.small_batch; 8 pairs per GPU per step are launch-latency-bound with one chain, which says nothing about xGMI)
     strong = None
     if args.mode == "weak" and world > 1 and len(mine) >= 1:
-        n_step[0] = len(mine)
-        for _ in range(max(args.warmup, C)):
-            step()
-        dts_s = sorted(timed(args.steps) for _ in range(3))[1]
-        strong = {"pairs_per_step_total": P_total, "pairs_per_step_per_gpu": [len(D.shard_pairs(P_total, r, world)) for r in range(world)],
-                  "value": P_total * args.steps / dts_s, "ms_per_step": dts_s / args.steps * 1e3, "chains_in_flight": C,
-                  "note": "same timing protocol (median of 3); every rank runs the first len(shard) pairs of its resident batch"}
-        n_step[0] = P
+        strong = strong_pass(args, D, torch, make_ctx, d_images, len(mine), P_total, world, cdev)
     k_step[0] = 0
     step(1)  # leave the full batch's results in context 0 for the checks below
     barrier()
@@ -883,7 +963,7 @@ def main():
         # FAST's launch also carries the blur of the levels the pyramid launches leave unblurred: level NLEVELS - 1 for batches of
         # 64 images and more per launch (smaller batches carry more levels: not counted, i.e. understated); its algorithmic bytes
         # (one read, one write of the level, SURVEY's blur row) belong to the launch that does the work
-        riding = [NLEVELS - 1] if (dom == "fast" and 2 * P // launches >= 64 and os.environ.get("ORBFE_BLUR_IN_FAST", "1") != "0" and os.environ.get("ORBFE_NO_FUSE", "0") != "1") else []
+        riding = list(range(ctx.blur_ride_from(2 * P // launches), NLEVELS)) if dom == "fast" else []  # orbfe_blur_ride_from: the plan the library actually runs
         dom_alg = alg[dom] + sum(2 * 2 * LEVEL_PX[l] for l in riding)
         achieved = dom_alg * P / launches / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         metric = "frames/sec ORB extract+match, KITTI 1241x376 stereo, 2000 feats"
@@ -901,11 +981,16 @@ def main():
                                    "frac": B_PAIR * value / world / 1e9 / HBM_PEAK_GBS},
                 "stage_ms_per_step_summed_over_groups": per_launch_ms,
                 "stage_ms_note": "per-stage table from a separate untimed single-chain pass with events at every stage boundary; launch_ms from the timed region; 'ingest' holds no launch any more (level 0 is the caller's image, read in place: what is left is the gap between two events); 'pyramid' includes the blur of the levels that are blurred inside the resize launches (0..6 for a 64-pair batch), 'blur' holds no launch any more: the remaining levels (level 7 for a 64-pair batch) are blurred by workgroups that ride in FAST's launch ('fast'; ORBFE_BLUR_IN_FAST=0: in the quadtree launch); roofline.alg_bytes_per_launch = FAST's bytes + that level's blur (blur_levels_riding_in_launch); ORBFE_NO_FUSE=1 separates them all"}
+        roof["build_id"] = lib_build_id()
+        roof["traffic_source"] = ("replayed from profiles/%s_traffic.json (rocprofv3 --pmc passes of this build: build ids match)" % PROFILE_ROUND) if roof["traffic"] else None
         if roof["traffic"]:
             roof["traffic_ratio"] = roof["traffic"] / roof["alg_bytes_per_launch"]  # counter bytes / algorithmic bytes of the dominant kernel
         wt, wsrc = whole_step_traffic_per_pair()
         if wt:
             roof["whole_pipeline"].update({"traffic_bytes_per_pair": wt, "traffic_ratio": wt / B_PAIR, "traffic_source": "profiles/" + wsrc})
+        if _STALE:  # counter files of this round that were taken on another build: not replayed (their fields are null / absent)
+            roof["stale_profile"] = True
+            roof["stale_profiles"] = sorted(_STALE)
         if dom_alone is not None:
             roof["launch_ms_one_chain"] = dom_alone
             roof["frac_one_chain"] = alg[dom] * P / launches / (dom_alone * 1e-3) / 1e9 / HBM_PEAK_GBS

@@ -26,10 +26,11 @@
  *   ORBFE_PYR_LDS=1    keep cv::resize on the LDS-staged kernel (the path of scale factors
  *                      above ~2) instead of the direct one;
  *   ORBFE_NO_FUSE=1    blur every level in one launch after the pyramid instead of blurring
- *                      level l - 1 inside the launch that resizes it into level l and the
- *                      remaining levels inside FAST's launch;
- *   ORBFE_BLUR_IN_FAST=0 those remaining levels inside the quadtree launch instead (the plan
- *                      until round 4);
+ *                      levels inside the pyramid's and FAST's launches;
+ *   ORBFE_BLUR_RIDE_FROM=l for every batch size, blur levels >= l in FAST's launch and the lower ones beside the resize
+ *                      that reads them (default: every level rides for batches of 64 images and more -- the blur is
+ *                      memory-bound, FAST issue-bound -- and smaller batches blur beside the resize launches, FAST's
+ *                      launch taking what they leave);
  *   ORBFE_NO_PROC_ORDER=1 describe_kernel walks the keypoints in slot order instead of the
  *                      spatial order the quadtree kernel writes beside its selection
  *                      (results are the same either way: only the order of processing differs);
@@ -62,7 +63,7 @@
 extern "C" {
 #endif
 
-#define ORBFE_ABI_VERSION 6 /* 2: orbfe_frame_view.device_slot_plus1; 3: .keyframe; 4: orbfe_get_camera, orbfe_assign_features_to_grid, orbfe_stereo_batch, orbfe_device_count, orbfe_set_profiling_interval; 5: orbfe_get_packed_layout, orbfe_fetch_batch_packed, orbfe_expand_packed, orbfe_stereo_batch_packed, orbfe_enqueue_rgbd; 6: orbfe_build_id, orbfe_set_pattern, orbfe_get_pattern (additive: no struct changed) */
+#define ORBFE_ABI_VERSION 6 /* 2: orbfe_frame_view.device_slot_plus1; 3: .keyframe; 4: orbfe_get_camera, orbfe_assign_features_to_grid, orbfe_stereo_batch, orbfe_device_count, orbfe_set_profiling_interval; 5: orbfe_get_packed_layout, orbfe_fetch_batch_packed, orbfe_expand_packed, orbfe_stereo_batch_packed, orbfe_enqueue_rgbd; 6: orbfe_build_id, orbfe_set_pattern, orbfe_get_pattern, orbfe_blur_ride_from (additive: no struct changed) */
 
 enum {
     ORBFE_OK = 0,
@@ -122,6 +123,10 @@ void orbfe_destroy(orbfe_context *ctx);
  * broadcast_pattern).  pattern = 256 tests x (x0, y0, x1, y1), i.e. the reference's `int bit_pattern_31_[256 * 4]` layout; a
  * point with x^2 + y^2 > 342 (it could rotate to more than 18 px from the keypoint) is refused with ORBFE_ERR_UNSUPPORTED: the
  * descriptor stage reads +-18 px, which edge_threshold >= 19 keeps inside the level; the reference's table reaches x^2 + y^2 = 338. */
+/* Launch-plan query for measurement tools: the first pyramid level whose Gaussian blur (src/ORBextractor.cc:899-900) is computed by
+ * workgroups riding in the cell-FAST launch for a batch of n_images images (orbfe_levels(): none).  bench.py prices the
+ * dominant kernel's launch with it. */
+int orbfe_blur_ride_from(const orbfe_context *ctx, int n_images);
 int orbfe_set_pattern(orbfe_context *ctx, const int32_t *pattern);
 int orbfe_get_pattern(const orbfe_context *ctx, int32_t *pattern);
 

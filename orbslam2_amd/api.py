@@ -21,7 +21,7 @@ assert KP_DTYPE.itemsize == 28
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 
 EXPORTS = [
-    "orbfe_build_id", "orbfe_set_pattern", "orbfe_get_pattern",
+    "orbfe_build_id", "orbfe_set_pattern", "orbfe_get_pattern", "orbfe_blur_ride_from",
     "orbfe_abi_version", "orbfe_last_error", "orbfe_create", "orbfe_destroy", "orbfe_levels",
     "orbfe_keypoint_capacity", "orbfe_get_tables", "orbfe_level_size", "orbfe_extract",
     "orbfe_stereo_frame", "orbfe_rgbd_frame", "orbfe_rgbd_frame_u16", "orbfe_fetch_pyramid", "orbfe_enqueue_extract",
@@ -102,6 +102,7 @@ def load():
     L.orbfe_build_id.restype = C.c_char_p
     L.orbfe_set_pattern.restype = C.c_int; L.orbfe_set_pattern.argtypes = [vp, vp]
     L.orbfe_get_pattern.restype = C.c_int; L.orbfe_get_pattern.argtypes = [vp, vp]
+    L.orbfe_blur_ride_from.restype = C.c_int; L.orbfe_blur_ride_from.argtypes = [vp, C.c_int]
     L.orbfe_last_error.restype = C.c_char_p; L.orbfe_last_error.argtypes = [vp]
     L.orbfe_create.restype = C.c_int; L.orbfe_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
     L.orbfe_destroy.restype = None; L.orbfe_destroy.argtypes = [vp]
@@ -243,6 +244,13 @@ class Context:
         w, h = C.c_int(), C.c_int()
         self._check(self.L.orbfe_level_size(self.h, level, C.byref(w), C.byref(h)))
         return w.value, h.value
+
+    def blur_ride_from(self, n_images):
+        """First pyramid level whose blur rides in FAST's launch for a batch of n_images (nlevels: none)."""
+        r = self.L.orbfe_blur_ride_from(self.h, n_images)
+        if r < 0:
+            raise OrbfeError(r, "orbfe_blur_ride_from")
+        return r
 
     def set_pattern(self, pattern):
         """Replace the context's copy of the 256 x (x0, y0, x1, y1) rBRIEF tests (ORBextractor::pattern, src/ORBextractor.cc:442-444)."""

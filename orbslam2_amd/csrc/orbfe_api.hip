@@ -51,7 +51,11 @@ struct orbfe_context {
     unsigned slot_cnt_epoch = ~0u;
     bool use_octree2 = false; // point-parallel quadtree (all levels have <= 4 roots and the LDS budget fits)
     bool fuse_blur = true;    // blur level l - 1 in the launch that resizes it into level l (ORBFE_NO_FUSE=1: separate launches)
-    bool blur_in_fast = true; // the levels the pyramid launches leave unblurred ride in FAST's launch (ORBFE_BLUR_IN_FAST=0: in the quadtree launch)
+    // The blur of level l only needs level l, is memory-bound and is first read by describe_kernel: levels >= blur_ride_from are
+    // blurred by workgroups that ride in FAST's launch (issue-bound) instead of beside the resize that reads the level, for
+    // batches of at least blur_ride_min_images images (smaller batches: whatever the pyramid launches leave unblurred rides).
+    // Round 5, 64 pairs: every level riding (0) takes the pyramid's launches from 167 to 99 us and FAST's from 266 to 320 (+ 2 %).
+    int blur_ride_from = 0, blur_ride_min_images = 64;
     // Level 0 read in place from the caller's packed CV_8UC1 images (no ingest launch, no copy): possible when level 1 is resized
     // by the LDS-free kernel and nothing stages level 0 through pyr_tail_kernel; ORBFE_NO_INPLACE=1 keeps the copy (A/B, tests).
     // Colour / rectified input always goes through ingest (it computes level 0).
@@ -587,7 +591,7 @@ try {
             c2.tail_first = 0; c2.tail_n = 0; c2.tail_strips = 0; c2.tail_lds_bytes = 0;
             const int nst = p.nlevels >= 4 ? 3 : (p.nlevels == 3 ? 2 : 0);
             { const char *nf = getenv("ORBFE_NO_FUSE"); ctx->fuse_blur = !(nf && nf[0] == '1'); }
-            { const char *bf = getenv("ORBFE_BLUR_IN_FAST"); ctx->blur_in_fast = !(bf && bf[0] == '0'); }
+            { const char *bf = getenv("ORBFE_BLUR_RIDE_FROM"); if (bf && bf[0] >= '0' && bf[0] <= '9') { ctx->blur_ride_from = atoi(bf); ctx->blur_ride_min_images = 1; } } // given explicitly: for every batch size
             const char *env = getenv("ORBFE_NO_TAIL");
             c2.tail_max_images = env && env[0] == '0' ? INT_MAX : 63; // ORBFE_NO_TAIL=0: the tail at every batch size (A/B)
             if (nst >= 2 && !(env && env[0] == '1')) {
@@ -1195,6 +1199,22 @@ static DeviceBuffers shift_buffers(const DeviceBuffers &b, const DeviceConfig &c
     return o;
 }
 
+static int blur_ride_from_of(const orbfe_context *ctx, int n_images)
+{
+    if (!ctx->fuse_blur) return ctx->cfg.nlevels;
+    return n_images >= ctx->blur_ride_min_images ? (ctx->blur_ride_from < ctx->cfg.nlevels ? ctx->blur_ride_from : ctx->cfg.nlevels) : ORBFE_MAX_LEVELS;
+}
+
+// First pyramid level whose Gaussian blur rides in FAST's launch for a batch of n_images images (nlevels: none rides; the value is
+// an upper bound for batches below the threshold, whose pyramid launches blur as many levels as they reach): what bench.py
+// attributes to the dominant kernel's launch.
+extern "C" int orbfe_blur_ride_from(const orbfe_context *ctx, int n_images)
+try {
+    if (!ctx) return ORBFE_ERR_INVALID;
+    const int r = blur_ride_from_of(ctx, n_images);
+    return r < ctx->cfg.nlevels ? r : (ctx->fuse_blur && n_images < ctx->blur_ride_min_images ? ctx->cfg.nlevels - 1 : ctx->cfg.nlevels);
+} ORBFE_CATCH(nullptr)
+
 // One chain of stages over images [img0, img0 + n_images) on stream s; stereo stages if n_pairs > 0.
 static void run_chain(orbfe_context *ctx, const uint8_t *d_images, int img0, int n_images, int n_pairs, hipStream_t s, int group)
 {
@@ -1208,20 +1228,18 @@ static void run_chain(orbfe_context *ctx, const uint8_t *d_images, int img0, int
         orbfe_launch_ingest(cfg, buf, src, n_images, s);
     }
     prof_mark(ctx, group, 1, s);
-    const int blurred = orbfe_launch_pyramid(cfg, buf, n_images, ctx->fuse_blur, s);
+    // levels >= ride_from are left to FAST's launch (orbfe_context::blur_ride_from); the lower ones are blurred beside the resize
+    // that reads them, as far as the pyramid's launches reach
+    const int ride_from = blur_ride_from_of(ctx, n_images);
+    const int blurred = orbfe_launch_pyramid(cfg, buf, n_images, ctx->fuse_blur, s, ride_from);
     prof_mark(ctx, group, 2, s);
-    // the levels still unblurred after the pyramid (level nlevels - 1 for a 64-pair batch, more for small ones) ride in FAST's launch as
-    // the last workgroups of each image's block list: FAST is bound by instruction issue, these waves by memory latency (+ 1 us there).
-    // Until round 4 they rode in the quadtree launch, behind its workgroups (every workgroup of that launch holds one of a CU's
-    // four LDS slots, so they started when the first quadtree workgroups ended, 27 us in, and ended the launch 4 us late);
-    // ORBFE_BLUR_IN_FAST=0 keeps that plan, ORBFE_NO_FUSE=1 gives every blur a launch of its own
-    const bool blur_in_fast = ctx->fuse_blur && ctx->blur_in_fast;
-    const bool blur_in_quadtree = ctx->fuse_blur && !blur_in_fast && ctx->use_octree3;
-    if (!blur_in_fast && !blur_in_quadtree) orbfe_launch_blur(cfg, buf, n_images, blurred, s);
+    // the levels still unblurred ride in FAST's launch as the last workgroups of each image's block list: FAST is bound by
+    // instruction issue, these waves by memory latency.  ORBFE_NO_FUSE=1 gives every blur a launch of its own
+    if (!ctx->fuse_blur) orbfe_launch_blur(cfg, buf, n_images, blurred, s);
     prof_mark(ctx, group, 3, s);
-    orbfe_launch_fast(cfg, buf, n_images, ctx->use_octree3, s, blur_in_fast ? blurred : cfg.nlevels);
+    orbfe_launch_fast(cfg, buf, n_images, ctx->use_octree3, s, ctx->fuse_blur ? blurred : cfg.nlevels);
     prof_mark(ctx, group, 4, s);
-    if (ctx->use_octree3) orbfe_launch_octree3(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot3_lds, ctx->ot3_nodes_in_hbm, s, blur_in_quadtree ? blurred : cfg.nlevels);
+    if (ctx->use_octree3) orbfe_launch_octree3(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot3_lds, ctx->ot3_nodes_in_hbm, s);
     else if (ctx->use_octree2) orbfe_launch_octree2(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot2_lds_pts, ctx->ot2_lds, s);
     else orbfe_launch_octree_generic(cfg, buf, n_images, s);
 #ifdef ORBFE_PROFILE_CUTS

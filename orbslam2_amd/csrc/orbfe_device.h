@@ -198,7 +198,7 @@ static_assert(sizeof(KeyPointPOD) == 28, "keypoint must match cv::KeyPoint");
 // launchers (orbfe_pyramid.hip, orbfe_fast.hip, orbfe_octree*.hip, orbfe_describe.hip, orbfe_stereo.hip)
 void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, const uint8_t *d_images,
                          int n_images, hipStream_t s);
-int orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool fuse_blur, hipStream_t s); // returns the number of levels (from 0) whose blur it launched too
+int orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool fuse_blur, hipStream_t s, int ride_from = ORBFE_MAX_LEVELS); // returns the number of levels (from 0) whose blur it launched too
 int orbfe_resize_word_base_host(int xw, int dst_w, double scale, int src_w); // pyr_resize_direct_kernel's first-source-byte formula, for orbfe_create's check
 void orbfe_launch_blur(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int first_level, hipStream_t s);
 void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool buckets, hipStream_t s, int blur_first_level);
@@ -207,7 +207,7 @@ void orbfe_launch_octree2(const DeviceConfig &cfg, const DeviceBuffers &buf, int
 size_t orbfe_octree2_lds_bytes(int max_nodes, int sort_cap, int lds_pts);
 int orbfe_octree2_prepare(size_t lds);
 // orbfe_octree3.hip
-void orbfe_launch_octree3(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, size_t lds, bool nodes_in_hbm, hipStream_t s, int blur_first_level); // also blurs levels blur_first_level .. nlevels - 1 (pass nlevels for none)
+void orbfe_launch_octree3(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, size_t lds, bool nodes_in_hbm, hipStream_t s);
 void orbfe_launch_candidates_gather(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
 size_t orbfe_octree3_node_bytes(int max_nodes, int sort_cap);
 size_t orbfe_octree3_lds_bytes(int max_nodes, int sort_cap, bool nodes_in_hbm);

@@ -24,7 +24,6 @@
 // Candidates are never gathered into emission order on this path; orbfe_fetch_candidates runs
 // candidates_gather_kernel on demand (parity tap).
 #include "orbfe_common.hpp"
-#include "orbfe_blur_wave.hpp"
 #include <cstdlib>
 
 // Round 4: 256 threads and <= 40 KB of LDS per workgroup, so that all 1024 workgroups of a 64-pair step are resident at once
@@ -195,29 +194,12 @@ __device__ __forceinline__ void ot3_for_each_point(const int *cell_cnt, const ui
 }
 
 template <bool NODES_IN_HBM>
-__global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void octree3_kernel(DeviceConfig cfg, DeviceBuffers buf, int sort_cap, size_t node_bytes, int blur_rows, int blur_t0, int blur_t1)
+__global__ __launch_bounds__(OT3_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void octree3_kernel(DeviceConfig cfg, DeviceBuffers buf, int sort_cap, size_t node_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
     __shared__ int s_w[4 * OT3_WAVES];
     __shared__ int s_scal[8];
     __shared__ __attribute__((aligned(16))) int s_bin[256]; // step 4a (processing order for describe_kernel): zeroed here, used at the end
-    // The LAST blur_rows rows of the grid are not quadtree workgroups: their waves blur tiles [blur_t0, blur_t1) of the image (the
-    // levels no pyramid launch has blurred; describe_kernel is the first reader).  The quadtree workgroups are latency-bound and leave
-    // the chip mostly idle, so those memory-bound waves cost little here -- their own launch cost 9 us (level 7 of a 64-pair batch) to
-    // 21 us.  Last, because every workgroup of this launch holds one of a CU's four LDS slots (the dynamic LDS size is per launch): at
-    // the head of the grid the blur kept a quarter of the quadtree workgroups waiting for ~9 us (round 4: launch 41.5 -> 38 us).
-    if ((int)blockIdx.y >= cfg.nlevels) {
-        const int u = blur_t0 + ((int)blockIdx.y - cfg.nlevels) * OT3_WAVES + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#ifdef ORBFE_PROFILE_CUTS
-        const int bi = (int)blockIdx.x * blur_rows + ((int)blockIdx.y - cfg.nlevels);
-        if (threadIdx.x == 0 && bi < 768) buf.dbg_ts[2560 + 2 * bi] = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
-        if (u < blur_t1) blur_wave(cfg, buf, blockIdx.x, u);
-#ifdef ORBFE_PROFILE_CUTS
-        if (threadIdx.x == 0 && bi < 768) buf.dbg_ts[2560 + 2 * bi + 1] = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
-        return;
-    }
     // longest first: the workgroups of level 0 (largest quota, most split passes) are dispatched before those of level 1, ...
     const int img = blockIdx.x, level = (int)blockIdx.y;
     for (int i = threadIdx.x; i < 256; i += OT3_THREADS) s_bin[i] = 0;
@@ -825,15 +807,12 @@ __global__ __launch_bounds__(OT3_THREADS) void candidates_gather_kernel(DeviceCo
     }
 }
 
-void orbfe_launch_octree3(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, size_t lds, bool nodes_in_hbm, hipStream_t s, int blur_first_level)
+void orbfe_launch_octree3(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, size_t lds, bool nodes_in_hbm, hipStream_t s)
 {
-    // blur of levels blur_first_level .. nlevels - 1 beside the quadtree (nlevels: none)
-    const int t0 = blur_first_level < cfg.nlevels ? cfg.lv[blur_first_level].blur_tile_off : cfg.blur_tiles_total, t1 = cfg.blur_tiles_total;
-    const int blur_rows = (t1 - t0 + OT3_WAVES - 1) / OT3_WAVES;
-    dim3 grid(n_images, blur_rows + cfg.nlevels);
+    dim3 grid(n_images, cfg.nlevels);
     const size_t node_bytes = orbfe_octree3_node_bytes(cfg.max_nodes, sort_cap);
-    if (nodes_in_hbm) hipLaunchKernelGGL(octree3_kernel<true>, grid, dim3(OT3_THREADS), lds, s, cfg, buf, sort_cap, node_bytes, blur_rows, t0, t1);
-    else hipLaunchKernelGGL(octree3_kernel<false>, grid, dim3(OT3_THREADS), lds, s, cfg, buf, sort_cap, node_bytes, blur_rows, t0, t1);
+    if (nodes_in_hbm) hipLaunchKernelGGL(octree3_kernel<true>, grid, dim3(OT3_THREADS), lds, s, cfg, buf, sort_cap, node_bytes);
+    else hipLaunchKernelGGL(octree3_kernel<false>, grid, dim3(OT3_THREADS), lds, s, cfg, buf, sort_cap, node_bytes);
 }
 
 void orbfe_launch_candidates_gather(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s)

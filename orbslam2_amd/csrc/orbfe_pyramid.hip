@@ -751,8 +751,10 @@ void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, cons
     else hipLaunchKernelGGL(ingest_kernel<1>, grid, dim3(256), 0, s, cfg, buf, d_images);
 }
 
-int orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool fuse_blur, hipStream_t s)
+int orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool fuse_blur, hipStream_t s, int ride_from)
 {
+    // ride_from: the blur of levels >= ride_from is left to the caller (FAST's launch carries it: orbfe_launch_fast); the lower
+    // levels are blurred beside the resize that reads them, as far as the launches reach
     // Fused tail or one launch per level for the last levels: the tail is one launch instead of three (small batches are bound by
     // the chain's latency: 8 pairs per step 46.9 k pairs/s against 45.4 k), three direct launches carry the blur of the level below
     // and leave the last blur launch one level instead of four (64 pairs: 86.4 k -> 87.0 k, three chains in flight 96.2 -> 96.9 k)
@@ -771,13 +773,15 @@ int orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int 
         // waits for: a single stereo pair's five pyramid launches 48 us -> three 34 us, 8 pairs per step +6 %); at 128 images every
         // per-level launch is throughput-bound and the pair kernel's ~15 % recomputed pixels and its barrier make the pyramid 15 us
         // SLOWER (170 -> 185 us), so large batches keep one launch per level.  ORBFE_NO_PAIR=0 forces pairs, =1 forbids them.
-        if (cfg.lv[l].pp_ok && l + 1 <= last_single && n_images <= cfg.pp_max_images) { // this level and the next in one launch; the blur of every finished level rides along
-            const int t0 = fuse_blur ? cfg.lv[blurred].blur_tile_off : 0, t1 = fuse_blur ? cfg.lv[l - 1].blur_tile_off + cfg.lv[l - 1].blur_tiles_x * cfg.lv[l - 1].blur_tiles_y : 0;
+        if (cfg.lv[l].pp_ok && l + 1 <= last_single && n_images <= cfg.pp_max_images) { // this level and the next in one launch; the blur of every finished level below ride_from rides along
+            const bool ride = fuse_blur && blurred <= l - 1 && blurred < ride_from;
+            const int lb = l - 1 < ride_from - 1 ? l - 1 : ride_from - 1; // last level blurred here
+            const int t0 = ride ? cfg.lv[blurred].blur_tile_off : 0, t1 = ride ? cfg.lv[lb].blur_tile_off + cfg.lv[lb].blur_tiles_x * cfg.lv[lb].blur_tiles_y : 0;
             const int n_pair = cfg.lv[l].pp_ntx * cfg.lv[l].pp_nty;
             dim3 grid(n_images, n_pair + (t1 - t0 + 3) / 4);
             if (l == 1 && buf.lv0_packed) hipLaunchKernelGGL(pyr_pair_kernel<true>, grid, dim3(256), 0, s, cfg, buf, l, n_pair, t0, t1);
             else hipLaunchKernelGGL(pyr_pair_kernel<false>, grid, dim3(256), 0, s, cfg, buf, l, n_pair, t0, t1);
-            if (fuse_blur) blurred = l;
+            if (ride) blurred = lb + 1;
             l++; // level l + 1 is done too
             continue;
         }
@@ -785,8 +789,8 @@ int orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int 
             const int nwords = cfg.lv[l].rs_xtab_n >> 2;
             constexpr int rb = ORBFE_PYR_RB > 0 ? ORBFE_PYR_RB : 8;
             const int strips = (nwords + 63) / 64, groups = (total_rows + 4 * rb - 1) / (4 * rb);
-            if (fuse_blur && blurred <= l - 1) { // every level finished by the earlier launches and not blurred yet
-                const LevelInfo &P = cfg.lv[l - 1];
+            if (fuse_blur && blurred <= l - 1 && blurred < ride_from) { // every level finished by the earlier launches and not blurred yet
+                const LevelInfo &P = cfg.lv[l - 1 < ride_from - 1 ? l - 1 : ride_from - 1];
                 const int t0 = cfg.lv[blurred].blur_tile_off, t1 = P.blur_tile_off + P.blur_tiles_x * P.blur_tiles_y;
                 dim3 grid(n_images, strips * groups + (t1 - t0 + 3) / 4);
                 const bool packed = l == 1 && buf.lv0_packed;
@@ -794,7 +798,7 @@ int orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int 
                 else if (packed) hipLaunchKernelGGL((pyr_resize_blur_kernel<rb, true, false>), grid, dim3(256), 0, s, cfg, buf, l, strips, strips * groups, t0, t1);
                 else if (lookup) hipLaunchKernelGGL((pyr_resize_blur_kernel<rb, false, true>), grid, dim3(256), 0, s, cfg, buf, l, strips, strips * groups, t0, t1);
                 else hipLaunchKernelGGL((pyr_resize_blur_kernel<rb, false, false>), grid, dim3(256), 0, s, cfg, buf, l, strips, strips * groups, t0, t1);
-                blurred = l;
+                blurred = l < ride_from ? l : ride_from;
             } else {
                 dim3 grid(strips, groups, n_images);
                 const bool packed = l == 1 && buf.lv0_packed;

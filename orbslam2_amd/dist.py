@@ -127,6 +127,12 @@ def shard_pairs(total_pairs: int, rank: int, world: int):
     return list(range(rank, total_pairs, world))
 
 
+def chain_schedule(steps: int, chains: int):
+    """Steps 0 .. steps - 1 with `chains` step chains in flight: step k is enqueued on context / stream k % chains, once."""
+    chains = max(1, int(chains))
+    return [(k, k % chains) for k in range(int(steps))]
+
+
 def max_over_ranks(value: float, device) -> float:
     if dist.is_initialized():
         t = torch.tensor([value], dtype=torch.float64, device=device)

@@ -30,6 +30,23 @@ def test_self_launch_two_ranks_prints_one_line_with_n_gpus_2():
     assert out["n_gpus"] == 2
     assert out["config"]["rccl"]["ranks"] == 2 and out["config"]["rccl"]["self_launched"] is True
     assert out["config"]["rccl"]["broadcast_bytes"] > 4096  # parameters + pattern checksum + the vocabulary blob
+    # the strong-scaling pass with step chains in flight: every (step, pair) enqueued exactly once over both ranks, step k on chain k % C
+    assert out["strong_cover_exactly_once"] is True and out["strong_chains"] == 4
+
+
+def test_strong_pass_with_chains_in_flight_covers_every_pair_exactly_once():
+    """bench.py's strong_pass: P pairs per step in total, dealt by dist.shard_pairs; steps dealt to C chains by dist.chain_schedule."""
+    sys.path.insert(0, ROOT)
+    from orbslam2_amd import dist as D
+    for world in (1, 2, 4, 8):
+        for chains in (1, 3, 4):
+            seen = {}
+            for rank in range(world):
+                for k, c in D.chain_schedule(20, chains):
+                    assert c == k % chains
+                    for p in D.shard_pairs(64, rank, world):
+                        seen[(k, p)] = seen.get((k, p), 0) + 1
+            assert len(seen) == 20 * 64 and set(seen.values()) == {1}
 
 
 def test_launcher_environment_with_fewer_ranks_than_gpus_is_an_error():

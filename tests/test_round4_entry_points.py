@@ -205,12 +205,12 @@ def test_packed_block_stored_directly_into_pinned_host_memory(batch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("knob,off", [("ORBFE_NO_PROC_ORDER", "1"), ("ORBFE_BLUR_IN_FAST", "0")])
+@pytest.mark.parametrize("knob,off", [("ORBFE_NO_PROC_ORDER", "1"), ("ORBFE_BLUR_RIDE_FROM", "0"), ("ORBFE_BLUR_RIDE_FROM", "3")])
 @pytest.mark.parametrize("w,h,nf,n_pairs", [(1241, 376, 2000, 3), (640, 480, 1000, 1), (403, 202, 300, 2)])
 def test_launch_plan_knobs_change_no_result(knob, off, w, h, nf, n_pairs, monkeypatch):
     """describe_kernel walking the quadtree kernel's spatial processing order (default) or the slots (ORBFE_NO_PROC_ORDER=1), and the
-    unblurred levels riding in FAST's launch (default) or the quadtree's (ORBFE_BLUR_IN_FAST=0): the same bytes out, also for the
-    blurred pyramid of every level (which the second knob moves between launches) and for batches small enough that several levels ride."""
+    blur of every level / of levels 3.. riding in FAST's launch (ORBFE_BLUR_RIDE_FROM: the default of 64-image batches, forced here on small
+    ones) instead of beside the resize launches: the same bytes out, also for the blurred pyramid of every level (which the knob moves between launches)."""
     import torch
     from orbslam2_amd import api
     cfg = dict(width=w, height=h, nfeatures=nf, fx=350.0, fy=350.0, cx=w / 2, cy=h / 2, bf=140.0, max_images=2 * n_pairs)
