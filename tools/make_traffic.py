@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """pmc_FETCH_SIZE.txt + pmc_WRITE_SIZE.txt (tools/pmc_summary.py output) -> traffic json read by bench.py.
 
-usage: make_traffic.py <dir with pmc_FETCH_SIZE.txt, pmc_WRITE_SIZE.txt> <pairs per launch> <out.json>
+usage: make_traffic.py <dir with pmc_FETCH_SIZE.txt, pmc_WRITE_SIZE.txt> <pairs per launch> <out.json> [build id]
 Counter values are KB per launch (mean over launches); a stage's launches per step (the pyramid has several) are summed:
 launches per step = the kernel's dispatch count / fast_cell_kernel's (one per step).
 """
@@ -36,6 +36,7 @@ def read(path, counter):
 d, pairs, dst = sys.argv[1], float(sys.argv[2]), sys.argv[3]
 f, w = read(d + "/pmc_FETCH_SIZE.txt", "FETCH_SIZE"), read(d + "/pmc_WRITE_SIZE.txt", "WRITE_SIZE")
 json.dump({
+    "build_id": sys.argv[4] if len(sys.argv) > 4 else None,
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --cpu-pairs 0 "
               "--no-check; KB per launch averaged over launches, %g pairs per launch" % pairs,
     "correction": "gfx950: hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, HBM section); narrow access widths are uncalibrated",

@@ -2,6 +2,8 @@
 """Summarise a rocprofv3 --pmc csv run: mean counter value per kernel name."""
 import csv, glob, sys, collections
 d = sys.argv[1]
+if len(sys.argv) > 2:  # build id of the liborbfe.so the pass ran on (orbfe_build_id): bench.py replays the file only for that build
+    print("# build_id:", sys.argv[2])
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
