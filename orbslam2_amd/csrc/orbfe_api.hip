@@ -56,10 +56,6 @@ struct orbfe_context {
     // batches of at least blur_ride_min_images images (smaller batches: whatever the pyramid launches leave unblurred rides).
     // Round 5, 64 pairs: every level riding (0) takes the pyramid's launches from 167 to 99 us and FAST's from 266 to 320 (+ 2 %).
     int blur_ride_from = 0, blur_ride_min_images = 64;
-    // Pyramid levels >= ride_from are resized INSIDE FAST's launch behind ready counters (orbfe_fast.hip) for batches of at least
-    // ride_min_images images; cfg.nlevels: none (the plan of every smaller batch).  ride_ahead = rounds of 8 images the chain of a
-    // riding image is spread over ahead of its cells.
-    int ride_from = ORBFE_MAX_LEVELS, ride_min_images = 64, ride_ahead = 3;
     // Level 0 read in place from the caller's packed CV_8UC1 images (no ingest launch, no copy): possible when level 1 is resized
     // by the LDS-free kernel and nothing stages level 0 through pyr_tail_kernel; ORBFE_NO_INPLACE=1 keeps the copy (A/B, tests).
     // Colour / rectified input always goes through ingest (it computes level 0).
@@ -982,54 +978,6 @@ try {
         }
         b.mom_tab = d_mt;
     }
-    {   // riding pyramid levels (orbfe_fast.hip): the resize workgroups of levels ride_from .. nlevels - 1 in the order they take in an
-        // image's block list, each with the number of rounds it runs ahead of its image's cells.  Stage s = level - ride_from of S stages is
-        // placed floor-wise on a time line of ride_ahead rounds: rounds ahead = ride_ahead - floor(s * ride_ahead / S), and inside a list
-        // the stages come in the order of their fractional position, so two dependent stages of one image are ride_ahead / S rounds apart.
-        DeviceConfig &rcf = ctx->cfg;
-        const char *rf = getenv("ORBFE_RIDE_FROM"); // levels >= this are resized inside FAST's launch (batches of >= 64 images); >= nlevels: none
-        if (rf && rf[0] >= '0' && rf[0] <= '9') ctx->ride_from = atoi(rf);
-        const char *ra = getenv("ORBFE_RIDE_AHEAD");
-        if (ra && ra[0] >= '1' && ra[0] <= '9') ctx->ride_ahead = atoi(ra) > 15 ? 15 : atoi(ra);
-        if (ctx->ride_from < 2) ctx->ride_from = 2; // level 1 reads the caller's image: its launch also clears the status words
-        bool ok = ctx->ride_from < p.nlevels && ctx->fuse_blur;
-        for (int l = ctx->ride_from; ok && l < p.nlevels; l++) ok = rcf.lv[l].rs_direct != 0;
-        rcf.ride_from = p.nlevels; rcf.ride_n = 0; rcf.ride_q = 0; rcf.ride_mix = (rcf.cells_total + 3) / 4; rcf.ride_pro = 0; rcf.ride_rounds = 0;
-        for (int l = 0; l < ORBFE_MAX_LEVELS; l++) rcf.ride_cnt[l] = 0;
-        std::vector<uint32_t> tab;
-        if (ok) {
-            const int K = ctx->ride_from, S = p.nlevels - K, D = ctx->ride_ahead;
-            struct Item { int frac, stage; };
-            std::vector<Item> order;
-            for (int st = 0; st < S; st++) order.push_back({(st * D) % S, st});
-            std::stable_sort(order.begin(), order.end(), [](const Item &a, const Item &b) { return a.frac < b.frac; });
-            for (const Item &it : order) {
-                const int l = K + it.stage, ahead = D - (it.stage * D) / S;
-                const int nwords = rcf.lv[l].rs_xtab_n >> 2, strips = (nwords + 63) / 64, groups = (rcf.lv[l].h + 2 * 3 + 15) / 16;
-                if (strips > 16 || groups > 256) { ok = false; break; }
-                rcf.ride_cnt[l] = strips * groups;
-                for (int g = 0; g < groups; g++)
-                    for (int st = 0; st < strips; st++) tab.push_back((uint32_t)l | ((uint32_t)st << 4) | ((uint32_t)g << 8) | ((uint32_t)ahead << 16));
-            }
-            if (ok) {
-                rcf.ride_from = K; rcf.ride_n = (int)tab.size(); rcf.ride_mix = rcf.ride_n + (rcf.cells_total + 3) / 4; rcf.ride_pro = D;
-                rcf.ride_q = (int)(((long long)rcf.ride_n * 65536 + rcf.ride_mix - 1) / rcf.ride_mix);
-                if (rcf.ride_mix >= 65536 || (((long long)rcf.ride_mix * rcf.ride_q) >> 16) != rcf.ride_n) ok = false;
-            }
-        }
-        if (!ok) { rcf.ride_from = p.nlevels; rcf.ride_n = 0; tab.clear(); }
-        ctx->ride_from = rcf.ride_from;
-        if (getenv("ORBFE_HOST_TRACE")) fprintf(stderr, "orbfe: pyramid levels riding in FAST's launch: %s (from level %d, %d resize workgroups per image, %d rounds ahead)\n", rcf.ride_n ? "yes" : "no", rcf.ride_from, rcf.ride_n, rcf.ride_pro);
-        uint32_t *d_rt = nullptr; unsigned *d_rd = nullptr;
-        A(d_rt, tab.size() + 1);
-        if (!tab.empty() && hipMemcpy(d_rt, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
-            orbfe_destroy(ctx);
-            return fail(nullptr, ORBFE_ERR_HIP, "ride table upload failed");
-        }
-        A(d_rd, B * ORBFE_MAX_LEVELS);
-        Z(d_rd, sizeof(unsigned) * B * ORBFE_MAX_LEVELS);
-        b.ride_tab = d_rt; b.ride_done = d_rd;
-    }
     {   // the context's copy of the 256 rBRIEF tests (ORBextractor's member `pattern`, src/ORBextractor.cc:442-444)
         uint32_t *d_pat = nullptr;
         A(d_pat, 256);
@@ -1245,7 +1193,7 @@ static DeviceBuffers shift_buffers(const DeviceBuffers &b, const DeviceConfig &c
     if (o.bk_best) o.bk_best += i * c.nlevels * ORBFE_BK_PYR;
     o.sel_xy += i * c.sel_total; o.sel_sc += i * c.sel_total; o.proc_xy += i * c.sel_total; o.proc_meta += i * c.sel_total;
     o.kps = (KeyPointPOD *)o.kps + i * c.sel_total; o.desc += i * c.sel_total * 32;
-    o.kp_cnt += i; o.status += i; o.ride_done += i * ORBFE_MAX_LEVELS;
+    o.kp_cnt += i; o.status += i;
     o.u_right += i * c.sel_total; o.depth += i * c.sel_total; o.sad += i * c.sel_total;
     o.row_cnt += (i / 2) * (size_t)c.height; o.row_ent += (i / 2) * (size_t)c.height * c.row_cap;
     return o;
@@ -1283,14 +1231,13 @@ static void run_chain(orbfe_context *ctx, const uint8_t *d_images, int img0, int
     // levels >= ride_from are left to FAST's launch (orbfe_context::blur_ride_from); the lower ones are blurred beside the resize
     // that reads them, as far as the pyramid's launches reach
     const int ride_from = blur_ride_from_of(ctx, n_images);
-    const bool ride = cfg.ride_n > 0 && n_images >= ctx->ride_min_images; // pyramid levels >= cfg.ride_from are resized inside FAST's launch
-    const int blurred = orbfe_launch_pyramid(cfg, buf, n_images, ctx->fuse_blur, s, ride_from, ride ? cfg.ride_from - 1 : ORBFE_MAX_LEVELS);
+    const int blurred = orbfe_launch_pyramid(cfg, buf, n_images, ctx->fuse_blur, s, ride_from);
     prof_mark(ctx, group, 2, s);
     // the levels still unblurred ride in FAST's launch as the last workgroups of each image's block list: FAST is bound by
     // instruction issue, these waves by memory latency.  ORBFE_NO_FUSE=1 gives every blur a launch of its own
     if (!ctx->fuse_blur) orbfe_launch_blur(cfg, buf, n_images, blurred, s);
     prof_mark(ctx, group, 3, s);
-    orbfe_launch_fast(cfg, buf, n_images, ctx->use_octree3, s, ctx->fuse_blur ? blurred : cfg.nlevels, ride);
+    orbfe_launch_fast(cfg, buf, n_images, ctx->use_octree3, s, ctx->fuse_blur ? blurred : cfg.nlevels);
     prof_mark(ctx, group, 4, s);
     if (ctx->use_octree3) orbfe_launch_octree3(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot3_lds, ctx->ot3_nodes_in_hbm, s);
     else if (ctx->use_octree2) orbfe_launch_octree2(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot2_lds_pts, ctx->ot2_lds, s);

@@ -43,9 +43,6 @@ __global__ __launch_bounds__(256, 8) void describe_generic_kernel(DeviceConfig c
         int tot = 0;
         for (int l = 0; l < cfg.nlevels; l++) tot += sel_cnt[l];
         buf.kp_cnt[img] = tot;
-        // the image's ready counters of the pyramid levels that ride in FAST's launch (orbfe_fast.hip): this launch follows that one
-        // in the chain's stream and precedes the next chain's, so they are zero whenever a FAST launch starts
-        for (int l = 0; l < cfg.nlevels; l++) buf.ride_done[(size_t)img * ORBFE_MAX_LEVELS + l] = 0u;
     }
     // block-shared tables: patch offsets (patch_n shorts) | pattern (256 words)
     int16_t *s_uv = (int16_t *)s_dm;
@@ -321,9 +318,6 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
         int tot = 0;
         for (int l = 0; l < cfg.nlevels; l++) tot += sel_cnt[l];
         buf.kp_cnt[img] = tot;
-        // the image's ready counters of the pyramid levels that ride in FAST's launch (orbfe_fast.hip): this launch follows that one
-        // in the chain's stream and precedes the next chain's, so they are zero whenever a FAST launch starts
-        for (int l = 0; l < cfg.nlevels; l++) buf.ride_done[(size_t)img * ORBFE_MAX_LEVELS + l] = 0u;
     }
     // block-shared: the 256 tests as (x0, y0, x1, y1) floats; per wave: the blurred patch (40 rows x 40 bytes)
     float4 *s_patf = (float4 *)s_dm;

@@ -79,13 +79,6 @@ struct DeviceConfig {
     int blur_tiles_total;
     int proc_order;        // octree3_kernel also writes proc_xy / proc_meta and describe_kernel walks those (0: describe_kernel walks sel_xy; ORBFE_NO_PROC_ORDER=1, other quadtree kernels)
     int fast_blur_t0;      // blur tiles [fast_blur_t0, blur_tiles_total) ride in the FAST launch (set per launch; blur_tiles_total: none)
-    // Pyramid levels ride_from .. nlevels - 1 are computed INSIDE FAST's launch (round 5; set per launch, ride_from = nlevels: none):
-    // every image's block list mixes ride_n resize workgroups (host-built order and look-ahead: DeviceBuffers::ride_tab) evenly
-    // among its cell workgroups; a level's readers wait for DeviceBuffers::ride_done[image][level] to reach ride_cnt[level]
-    int ride_from, ride_n, ride_q, ride_mix; // ride_q = ceil(ride_n * 65536 / ride_mix): block b of the mixed region is ride block (b * ride_q) >> 16 iff that value steps at b + 1
-    int ride_dbg;                            // EXPERIMENT bits: 1 no acquire fence, 2 plain stores, 4 no wait at all
-    int ride_pro, ride_rounds;               // prologue rounds (no cells: only the look-ahead resize blocks), rounds of 8 images
-    int ride_cnt[ORBFE_MAX_LEVELS];          // resize workgroups per image of a riding level
     int max_nodes;         // quadtree node capacity (LDS)
     int bk_part_total;     // per image: entries of DeviceBuffers::bk_part
     int row_cap;           // entries per image row in DeviceBuffers::row_ent
@@ -176,8 +169,6 @@ struct DeviceBuffers {
     const uint8_t *slot_level; // [sel_total] level of every keypoint slot
     const int16_t *patch_uv; // IC_Angle patch offsets: (u & 0xff) | (v << 8), padded with (0,0)
     const uint32_t *mom_tab; // [64 lanes][12] byte-dot-product weights of the same patch (hp == 15), see orbfe_api.hip
-    const uint32_t *ride_tab; // [ride_n] riding resize workgroups of an image's block list in dispatch order: level | strip << 4 | row group << 8 | rounds ahead << 16
-    unsigned *ride_done;      // [img][ORBFE_MAX_LEVELS] finished resize workgroups of a riding level; zeroed by the describe launch of the same chain
     const uint32_t *pattern; // [256] the extractor's copy of the rBRIEF tests (src/ORBextractor.cc:442-444): x0 | y0 << 8 | x1 << 16 | y1 << 24 as int8;
                              // the compiled bit_pattern_31_ unless orbfe_set_pattern replaced it
 };
@@ -207,10 +198,10 @@ static_assert(sizeof(KeyPointPOD) == 28, "keypoint must match cv::KeyPoint");
 // launchers (orbfe_pyramid.hip, orbfe_fast.hip, orbfe_octree*.hip, orbfe_describe.hip, orbfe_stereo.hip)
 void orbfe_launch_ingest(const DeviceConfig &cfg, const DeviceBuffers &buf, const uint8_t *d_images,
                          int n_images, hipStream_t s);
-int orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool fuse_blur, hipStream_t s, int ride_from = ORBFE_MAX_LEVELS, int last_level = ORBFE_MAX_LEVELS); // returns the number of levels (from 0) whose blur it launched too
+int orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool fuse_blur, hipStream_t s, int ride_from = ORBFE_MAX_LEVELS); // returns the number of levels (from 0) whose blur it launched too
 int orbfe_resize_word_base_host(int xw, int dst_w, double scale, int src_w); // pyr_resize_direct_kernel's first-source-byte formula, for orbfe_create's check
 void orbfe_launch_blur(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int first_level, hipStream_t s);
-void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool buckets, hipStream_t s, int blur_first_level, bool ride = false); // ride: cfg.ride_* are set (levels ride_from.. are resized inside this launch)
+void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool buckets, hipStream_t s, int blur_first_level);
 void orbfe_launch_octree_generic(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
 void orbfe_launch_octree2(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, int lds_pts, size_t lds, hipStream_t s);
 size_t orbfe_octree2_lds_bytes(int max_nodes, int sort_cap, int lds_pts);

@@ -1,45 +1,6 @@
 // orbfe_fast.hip -- cell-wise cv::FAST with two thresholds (src/ORBextractor.cc:783-823) + quadtree bucket accumulation.
 #include "orbfe_common.hpp"
 #include "orbfe_blur_wave.hpp"
-#include "orbfe_resize_wave.hpp"
-
-// ---------------------------------------------------------------------------
-// Pyramid levels riding in this launch (round 5).  The resize of level l only needs level l - 1, FAST's cells of level l only
-// level l: as launches of their own the last levels are chains of short latency-bound grids in front of the issue-bound FAST.
-// Here their workgroups (the wave body of pyr_resize_direct_kernel, orbfe_resize_wave.hpp) are dealt evenly among FAST's cell
-// workgroups, ROUNDS AHEAD of the cells that read them (DeviceBuffers::ride_tab: the resize of level l for the images of a later
-// round sits in this round's block lists), and every reader of a riding level waits for the level's counter
-// (DeviceBuffers::ride_done[image][level] == DeviceConfig::ride_cnt[level]).  Hand-off as MI355X_MICROARCH.md prescribes for
-// write-through payloads: every byte of a riding level is stored with sc1 (ResizeStoreGlobalWT), every storing wave drains its
-// stores (s_waitcnt vmcnt(0)), workgroup barrier, one lane: relaxed agent-scope add; reader: relaxed polls, ONE agent-scope
-// acquire fence, then its loads.  (The plain-store form -- an agent-scope release fence before the add -- writes the XCD's whole L2
-// back once per resize workgroup: measured, it took FAST's launch from 0.32 to 0.60 ms with three riding levels.)  Forward progress: a
-// waiter's producers always sit at lower block indices (earlier in dispatch order) and wait only on producers of that kind; the
-// first riding level waits for nothing.  A wait that outlasts RIDE_SPIN_LIMIT polls (~0.3 s; never in practice) flags the image
-// (status 16) and goes on, so a launch always drains.
-// ---------------------------------------------------------------------------
-#define RIDE_SPIN_LIMIT (1 << 14)
-__device__ __forceinline__ void ride_wait(const unsigned *cnt, unsigned target, int *status, int dbg = 0)
-{
-    if (dbg & 4) return;
-    unsigned v = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (__builtin_expect(v < target, 0)) {
-        int spins = 0;
-        do {
-            __builtin_amdgcn_s_sleep(32);
-            if (++spins > RIDE_SPIN_LIMIT) { if ((threadIdx.x & 63) == 0) atomicOr(status, 16); break; }
-            v = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } while (v < target);
-    }
-    if (!(dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-// a resize workgroup's four waves have stored their rows of `level`: count the workgroup
-__device__ __forceinline__ void ride_signal(unsigned *cnt)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // ---------------------------------------------------------------------------
 // FAST-9/16 per cell: score map + 3x3 NMS inside the cell + two-threshold select
@@ -158,42 +119,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     // A workgroup is four independent waves = four consecutive cells (no workgroup barriers: FAST_WAVE_SYNC): horizontally
     // adjacent cells share the 128-B lines of their tile rows, and on one CU those lines are fetched from L2 once.
     const int bpi_cells = (cfg.cells_total + 3) >> 2;
+    const int bpi = bpi_cells + ((cfg.blur_tiles_total - cfg.fast_blur_t0 + 3) >> 2);
     int img, blk;
+    if (!xcd_map(bpi, n_images, img, blk)) return;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (cfg.ride_from < cfg.nlevels) {
-        // riding plan: rounds of 8 images (one per XCD), ride_pro prologue rounds ahead of round 0; an image's block list =
-        // [ride_mix blocks: resize workgroups dealt evenly among the cell workgroups][blur workgroups]
-        const int bpi = cfg.ride_mix + ((cfg.blur_tiles_total - cfg.fast_blur_t0 + 3) >> 2);
-        const int xcd = (int)blockIdx.x & 7, jb = (int)blockIdx.x >> 3;
-        const int vri = __builtin_amdgcn_readfirstlane(small_div(jb, bpi));
-        const int b = jb - vri * bpi, vr = vri - cfg.ride_pro;
-        const int rb0 = (b * cfg.ride_q) >> 16, rb1 = ((b + 1) * cfg.ride_q) >> 16;
-        if (b < cfg.ride_mix && rb1 > rb0) { // resize workgroup rb0 of the list
-            const uint32_t e = const_load_u32(buf.ride_tab + rb0);
-            const int level = (int)(e & 15u), q = vr + (int)(e >> 16);
-            const int rimg = q * 8 + xcd;
-            if (q < 0 || rimg >= n_images) return;
-            if (level > cfg.ride_from) ride_wait(buf.ride_done + (size_t)rimg * ORBFE_MAX_LEVELS + (level - 1), (unsigned)cfg.ride_cnt[level - 1], buf.status + rimg, cfg.ride_dbg);
-            if (cfg.ride_dbg & 2) resize_direct_wave<4, false, true, ResizeStoreGlobal>(cfg, buf, level, rimg, (int)((e >> 4) & 15u), (int)((e >> 8) & 255u) * 4 + wave);
-            else
-            resize_direct_wave<4, false, true, ResizeStoreGlobalWT>(cfg, buf, level, rimg, (int)((e >> 4) & 15u), (int)((e >> 8) & 255u) * 4 + wave);
-            ride_signal(buf.ride_done + (size_t)rimg * ORBFE_MAX_LEVELS + level);
-            return;
-        }
-        img = vr * 8 + xcd;
-        if (vr < 0 || img >= n_images) return;
-        blk = b < cfg.ride_mix ? b - rb1 : bpi_cells + (b - cfg.ride_mix);
-    } else {
-        const int bpi = bpi_cells + ((cfg.blur_tiles_total - cfg.fast_blur_t0 + 3) >> 2);
-        if (!xcd_map(bpi, n_images, img, blk)) return;
-    }
     if (__builtin_expect(blk >= bpi_cells, 0)) { // the image's last workgroups: blur tiles riding in this launch
         const int u = cfg.fast_blur_t0 + (blk - bpi_cells) * 4 + wave;
-        if (u < cfg.blur_tiles_total) {
-            const int bl = (int)(buf.blur_tile_info[u] & 0xffu);
-            if (bl >= cfg.ride_from) ride_wait(buf.ride_done + (size_t)img * ORBFE_MAX_LEVELS + bl, (unsigned)cfg.ride_cnt[bl], buf.status + img, cfg.ride_dbg);
-            blur_wave(cfg, buf, img, u);
-        }
+        if (u < cfg.blur_tiles_total) blur_wave(cfg, buf, img, u);
         return;
     }
     const int cell = blk * 4 + wave;
@@ -211,7 +143,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         if (lane == 0) *cnt_out = 0;
         return;
     }
-    if (level >= cfg.ride_from) ride_wait(buf.ride_done + (size_t)img * ORBFE_MAX_LEVELS + level, (unsigned)cfg.ride_cnt[level], buf.status + img, cfg.ride_dbg); // the level is resized inside this launch
     const int ini_x = (int)(cinfo.y & 0xffffu), ini_y = (int)(cinfo.y >> 16);
     const int max_x = ini_x + (int)(cinfo.z & 0xffu);
     const int tw = (int)(cinfo.z & 0xffu), th = (int)((cinfo.z >> 8) & 0xffu);
@@ -561,13 +492,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 static inline int max_cell_w(const DeviceConfig &cfg) { int m = 0; for (int l = 0; l < cfg.nlevels; l++) m = cfg.lv[l].w_cell > m ? cfg.lv[l].w_cell : m; return m; }
 static inline int max_cell_h(const DeviceConfig &cfg) { int m = 0; for (int l = 0; l < cfg.nlevels; l++) m = cfg.lv[l].h_cell > m ? cfg.lv[l].h_cell : m; return m; }
 
-void orbfe_launch_fast(const DeviceConfig &cfg_in, const DeviceBuffers &buf, int n_images, bool buckets, hipStream_t s, int blur_first_level, bool ride)
+void orbfe_launch_fast(const DeviceConfig &cfg_in, const DeviceBuffers &buf, int n_images, bool buckets, hipStream_t s, int blur_first_level)
 {
     DeviceConfig cfg = cfg_in;
     cfg.fast_blur_t0 = blur_first_level < cfg.nlevels ? cfg.lv[blur_first_level].blur_tile_off : cfg.blur_tiles_total;
-    if (!ride) { cfg.ride_from = cfg.nlevels; cfg.ride_n = 0; }
-    cfg.ride_rounds = (n_images + 7) / 8;
-    { static const int dbg = getenv("ORBFE_RIDE_DBG") ? atoi(getenv("ORBFE_RIDE_DBG")) : 0; cfg.ride_dbg = dbg; }
     const int mw = max_cell_w(cfg), mh = max_cell_h(cfg);
     const int tile_pitch = (mw + 6 + 15) & ~15; // whole 16-byte chunks (the staging stores 128 bits at a time)
     const int tile_rows = mh + 6;
@@ -580,7 +508,6 @@ void orbfe_launch_fast(const DeviceConfig &cfg_in, const DeviceBuffers &buf, int
     const int lds_per_wave = tile_region + sc_bytes + q_bytes + 512;
     const size_t lds = (size_t)4 * lds_per_wave;
     dim3 grid(xcd_grid((cfg.cells_total + 3) / 4 + (cfg.blur_tiles_total - cfg.fast_blur_t0 + 3) / 4, n_images));
-    if (ride) grid = dim3((unsigned)((cfg.ride_pro + cfg.ride_rounds) * (cfg.ride_mix + (cfg.blur_tiles_total - cfg.fast_blur_t0 + 3) / 4) * 8));
 #define FAST_LAUNCH(TP)                                                                                                                   \
     do {                                                                                                                              \
         if (buckets) hipLaunchKernelGGL((fast_cell_kernel<TP, true>), grid, dim3(256), lds, s, cfg, buf, n_images, tile_pitch, tile_region, sc_bytes, q_bytes, lds_per_wave ORBFE_CUT_ARG("ORBFE_FAST_DBG")); \
