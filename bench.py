@@ -614,6 +614,17 @@ def launch_ranks(n: int) -> int:
     (they would otherwise wait in the rendezvous)."""
     import socket
     import subprocess
+    # The rendezvous port is found by binding to port 0 and closing the socket: another process can take it before rank 0 listens
+    # there (rank 0 then dies with "address already in use").  That, and only that, is retried with a fresh port.
+    for attempt in range(3):
+        rc = _launch_once(n, socket, subprocess)
+        if rc != "port-taken":
+            return rc
+        print("bench: rendezvous port was taken before rank 0 could bind it; retrying with another (%d)" % (attempt + 1), file=sys.stderr)
+    return 1
+
+
+def _launch_once(n, socket, subprocess):
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
@@ -623,13 +634,20 @@ def launch_ranks(n: int) -> int:
                    ORBFE_BENCH_SELF_LAUNCHED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
-    line = {}
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=subprocess.PIPE if r == 0 else sys.stderr))
+    line = {"err": b""}
 
     def read0():
         line["out"] = procs[0].stdout.read()
+
+    def tee0():  # rank 0's stderr goes through to ours, and its tail is kept: the one message the launcher reacts to is a bind failure
+        for chunk in iter(lambda: procs[0].stderr.read1(4096), b""):
+            sys.stderr.buffer.write(chunk); sys.stderr.flush()
+            line["err"] = (line["err"] + chunk)[-8192:]
     t = threading.Thread(target=read0, daemon=True)
     t.start()
+    t2 = threading.Thread(target=tee0, daemon=True)
+    t2.start()
     rcs = [None] * n
     failed = None
     deadline = time.time() + float(os.environ.get("ORBFE_BENCH_LAUNCH_TIMEOUT_S", "3000"))  # a rank that hangs must not hang the launcher for ever
@@ -638,6 +656,12 @@ def launch_ranks(n: int) -> int:
             for p in procs:
                 if p.poll() is None:
                     p.kill()
+            for p in procs:  # reap them, and let the reader threads see end-of-file before their output is dropped
+                try:
+                    p.wait(15)
+                except subprocess.TimeoutExpired:
+                    pass
+            t.join(15); t2.join(15)
             print("bench: the %d-rank run did not finish within ORBFE_BENCH_LAUNCH_TIMEOUT_S; killed" % n, file=sys.stderr)
             return 1
         for r, p in enumerate(procs):
@@ -657,9 +681,13 @@ def launch_ranks(n: int) -> int:
                 p.wait(15)
             except subprocess.TimeoutExpired:
                 p.kill()
+        t.join(15); t2.join(15)
+        err = line["err"].decode("utf-8", "replace").lower()
+        if failed == 0 and ("address already in use" in err or "eaddrinuse" in err):
+            return "port-taken"
         print("bench: rank %d exited with code %d; %d-rank run aborted" % (failed, rcs[failed], n), file=sys.stderr)
         return rcs[failed] if 0 < rcs[failed] < 256 else 1
-    t.join(30)
+    t.join(30); t2.join(30)
     text = (line.get("out") or b"").decode("utf-8", "replace")
     rows = [ln for ln in text.splitlines() if ln.strip().startswith("{")]
     if len(rows) != 1:

@@ -17,8 +17,8 @@
  * on one context must order those pairs themselves.
  *
  * Environment (read once, by orbfe_create; meant for tests and A/B measurements):
- *   ORBFE_OCTREE=2|1   force the point-parallel (2) or the generic node-parallel (1)
- *                      DistributeOctTree kernel instead of the bucket-pyramid one
+ *   ORBFE_OCTREE=1     force the generic node-parallel DistributeOctTree kernel (the fallback beyond the
+ *                      bucket-pyramid kernel's limits) instead of the bucket-pyramid one
  *                      (orbfe_quadtree_kernel() reports the choice);
  *   ORBFE_NO_TAIL=1|0  never / always run the last three pyramid levels in the fused tail
  *                      kernel (default: for batches of fewer than 64 images; larger
@@ -38,14 +38,12 @@
  *                      instead of reading the caller's images in place as pyramid level 0;
  *   ORBFE_NO_PAIR=1|0  never / always compute two pyramid levels per launch (pyr_pair_kernel;
  *                      default: for batches of fewer than 64 images);
- *   ORBFE_RS_LOOKUP=1|0 cv::resize word bases from the host table / from the formula (default:
- *                      the table for batches of 64 images and more);
- *   ORBFE_BK_DEPTH5=1  quadtree buckets at depth 5 on every level (default: depth 4 on levels
- *                      where a FAST cell would span more than 64 depth-5 buckets);
  *   ORBFE_HOST_TRACE=1 print the context's geometry, kernel choices and LDS sizes to
  *                      stderr at create time.
- * Every alternative plan gives bit-identical results (tools/r04_fullsuite.sh runs the
- * frame-path tests under each).
+ * Every alternative plan gives bit-identical results (tools/r05_fullsuite.sh runs the
+ * frame-path tests under each).  Round 5 removed the plans that lost at every measured batch size (the blur in the quadtree
+ * launch, depth-5 buckets everywhere, the resize table / formula switch) and the point-parallel quadtree kernel (the generic
+ * kernel covers its geometries).
  *
  * No C++ exception leaves the library: a host-side failure (out of memory, ...) is
  * returned as ORBFE_ERR_HIP with its message in orbfe_last_error().
@@ -63,7 +61,7 @@
 extern "C" {
 #endif
 
-#define ORBFE_ABI_VERSION 6 /* 2: orbfe_frame_view.device_slot_plus1; 3: .keyframe; 4: orbfe_get_camera, orbfe_assign_features_to_grid, orbfe_stereo_batch, orbfe_device_count, orbfe_set_profiling_interval; 5: orbfe_get_packed_layout, orbfe_fetch_batch_packed, orbfe_expand_packed, orbfe_stereo_batch_packed, orbfe_enqueue_rgbd; 6: orbfe_build_id, orbfe_set_pattern, orbfe_get_pattern, orbfe_blur_ride_from (additive: no struct changed) */
+#define ORBFE_ABI_VERSION 6 /* 2: orbfe_frame_view.device_slot_plus1; 3: .keyframe; 4: orbfe_get_camera, orbfe_assign_features_to_grid, orbfe_stereo_batch, orbfe_device_count, orbfe_set_profiling_interval; 5: orbfe_get_packed_layout, orbfe_fetch_batch_packed, orbfe_expand_packed, orbfe_stereo_batch_packed, orbfe_enqueue_rgbd; 6: orbfe_build_id, orbfe_set_pattern, orbfe_get_pattern, orbfe_blur_ride_from, orbfe_set_input_retained (additive: no struct changed; orbfe_fetch_pyramid(level 0) of an in-place batched call now needs the latter) */
 
 enum {
     ORBFE_OK = 0,
@@ -123,6 +121,9 @@ void orbfe_destroy(orbfe_context *ctx);
  * broadcast_pattern).  pattern = 256 tests x (x0, y0, x1, y1), i.e. the reference's `int bit_pattern_31_[256 * 4]` layout; a
  * point with x^2 + y^2 > 342 (it could rotate to more than 18 px from the keypoint) is refused with ORBFE_ERR_UNSUPPORTED: the
  * descriptor stage reads +-18 px, which edge_threshold >= 19 keeps inside the level; the reference's table reaches x^2 + y^2 = 338. */
+/* Lifetime promise for the images of orbfe_enqueue_* (see orbfe_fetch_pyramid): retained != 0 = they stay valid and unchanged until
+ * this context's next enqueue call.  Default 0: valid until the call's work on the stream has finished (stream order suffices). */
+int orbfe_set_input_retained(orbfe_context *ctx, int retained);
 /* Launch-plan query for measurement tools: the first pyramid level whose Gaussian blur (src/ORBextractor.cc:899-900) is computed by
  * workgroups riding in the cell-FAST launch for a batch of n_images images (orbfe_levels(): none).  bench.py prices the
  * dominant kernel's launch with it. */
@@ -217,7 +218,11 @@ int orbfe_rgbd_frame_u16(orbfe_context *ctx, const uint8_t *gray, const uint16_t
 
 /* mvImagePyramid[level] of image slot `image` of the latest call (include/ORBextractor.h:84;
  * read by src/Frame.cc:471,565,577,582).  blurred!=0 returns the Gaussian-blurred
- * working copy (src/ORBextractor.cc:899-900).  Copies w*h bytes into dst (row stride dst_stride). */
+ * working copy (src/ORBextractor.cc:899-900).  Copies w*h bytes into dst (row stride dst_stride).
+ * Level 0 (unblurred) of a device-resident call on packed grey images IS the caller's buffer (read in place, never copied): the
+ * library follows that pointer only after orbfe_set_input_retained(ctx, 1) and returns ORBFE_ERR_UNSUPPORTED otherwise -- the
+ * caller may legally have freed or reused the buffer once the call's work was done.  The host entry points (orbfe_extract,
+ * orbfe_stereo_frame, ...) stage their images inside the library and are not affected. */
 int orbfe_fetch_pyramid(orbfe_context *ctx, int image, int level, int blurred,
                         uint8_t *dst, size_t dst_stride);
 

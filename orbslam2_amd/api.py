@@ -21,7 +21,7 @@ assert KP_DTYPE.itemsize == 28
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 
 EXPORTS = [
-    "orbfe_build_id", "orbfe_set_pattern", "orbfe_get_pattern", "orbfe_blur_ride_from",
+    "orbfe_build_id", "orbfe_set_pattern", "orbfe_get_pattern", "orbfe_blur_ride_from", "orbfe_set_input_retained",
     "orbfe_abi_version", "orbfe_last_error", "orbfe_create", "orbfe_destroy", "orbfe_levels",
     "orbfe_keypoint_capacity", "orbfe_get_tables", "orbfe_level_size", "orbfe_extract",
     "orbfe_stereo_frame", "orbfe_rgbd_frame", "orbfe_rgbd_frame_u16", "orbfe_fetch_pyramid", "orbfe_enqueue_extract",
@@ -103,6 +103,7 @@ def load():
     L.orbfe_set_pattern.restype = C.c_int; L.orbfe_set_pattern.argtypes = [vp, vp]
     L.orbfe_get_pattern.restype = C.c_int; L.orbfe_get_pattern.argtypes = [vp, vp]
     L.orbfe_blur_ride_from.restype = C.c_int; L.orbfe_blur_ride_from.argtypes = [vp, C.c_int]
+    L.orbfe_set_input_retained.restype = C.c_int; L.orbfe_set_input_retained.argtypes = [vp, C.c_int]
     L.orbfe_last_error.restype = C.c_char_p; L.orbfe_last_error.argtypes = [vp]
     L.orbfe_create.restype = C.c_int; L.orbfe_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
     L.orbfe_destroy.restype = None; L.orbfe_destroy.argtypes = [vp]
@@ -251,6 +252,10 @@ class Context:
         if r < 0:
             raise OrbfeError(r, "orbfe_blur_ride_from")
         return r
+
+    def set_input_retained(self, retained=True):
+        """Promise that the images of an enqueue_* call stay valid until the next one (orbfe_fetch_pyramid's level 0 then reads them in place)."""
+        self._check(self.L.orbfe_set_input_retained(self.h, int(bool(retained))))
 
     def set_pattern(self, pattern):
         """Replace the context's copy of the 256 x (x0, y0, x1, y1) rBRIEF tests (ORBextractor::pattern, src/ORBextractor.cc:442-444)."""

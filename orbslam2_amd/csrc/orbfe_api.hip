@@ -41,6 +41,8 @@ struct orbfe_context {
     uint8_t *h_out = nullptr;     // see HostOut
     uint8_t *d_pack = nullptr;    // device staging of orbfe_fetch_batch_packed (lazily allocated for max_images)
     size_t d_pack_bytes = 0;
+    hipEvent_t ev_pack = nullptr; // recorded behind the staging's device-to-host copy: the next packed fetch (whatever its stream) waits for it before it refills d_pack
+    bool ev_pack_set = false;
     uint8_t *d_ham = nullptr;     // scratch for orbfe_hamming_matrix
     void *d_und = nullptr;        // scratch for the undistortion entry points
     size_t d_und_bytes = 0;
@@ -49,7 +51,6 @@ struct orbfe_context {
     unsigned epoch = 0;       // extraction calls enqueued so far (device-resident frame caches key on it)
     std::vector<int> slot_cnt;    // keypoint counts of the slots of call `slot_cnt_epoch` (host copy, filled by the first fetch)
     unsigned slot_cnt_epoch = ~0u;
-    bool use_octree2 = false; // point-parallel quadtree (all levels have <= 4 roots and the LDS budget fits)
     bool fuse_blur = true;    // blur level l - 1 in the launch that resizes it into level l (ORBFE_NO_FUSE=1: separate launches)
     // The blur of level l only needs level l, is memory-bound and is first read by describe_kernel: levels >= blur_ride_from are
     // blurred by workgroups that ride in FAST's launch (issue-bound) instead of beside the resize that reads the level, for
@@ -61,12 +62,12 @@ struct orbfe_context {
     // Colour / rectified input always goes through ingest (it computes level 0).
     bool inplace_ok = false;
     const uint8_t *last_src = nullptr; // images of the latest enqueue when it ran in place (orbfe_fetch_pyramid's level 0), else null
+    bool last_src_owned = false;       // ... and they live in the library's own staging (d_in: the host entry points), which outlives the call
+    bool input_retained = false;       // orbfe_set_input_retained: the caller keeps the images of an enqueue call valid until its next call
     bool use_octree3 = false; // bucket-pyramid quadtree (orbfe_octree3.hip); preferred when its limits hold
     size_t ot3_lds = 0;
     bool ot3_nodes_in_hbm = false; // node tables of the bucket-pyramid quadtree in HBM scratch (large per-level quotas)
-    int ot2_sort_cap = 0;
-    int ot2_lds_pts = 0;      // candidates per level the quadtree keeps in LDS
-    size_t ot2_lds = 0;
+    int ot_sort_cap = 0;      // power of two >= max_nodes: the quadtree kernels' sort buffer
     // stage timing: ring of PROF_RING calls x (ORBFE_NUM_STAGES + 1) events
     bool profiling = false;
     int prof_every = 1;      // record events on every prof_every-th enqueue call only (orbfe_set_profiling_interval)
@@ -364,14 +365,7 @@ static int build_config(orbfe_context *ctx)
         for (int l = 0; l < p.nlevels; l++) roots_ok = roots_ok && c.lv[l].n_ini <= 4;
         int max_cand = 0;
         for (int l = 0; l < p.nlevels; l++) { roots_ok = roots_ok && c.lv[l].cand_cap <= (1 << 20); max_cand = c.lv[l].cand_cap > max_cand ? c.lv[l].cand_cap : max_cand; }
-        ctx->ot2_sort_cap = sc;
-        // LDS-resident point arrays for levels of up to 8192 candidates (9 B each) if the budget allows
-        int pts = max_cand < 8192 ? ((max_cand + 63) & ~63) : 8192;
-        while (pts > 0 && orbfe_octree2_lds_bytes(c.max_nodes, sc, pts) > 150 * 1024) pts -= 1024;
-        if (pts < 0) pts = 0;
-        ctx->ot2_lds_pts = pts;
-        ctx->ot2_lds = orbfe_octree2_lds_bytes(c.max_nodes, sc, pts);
-        ctx->use_octree2 = roots_ok && c.max_nodes <= 4096 && ctx->ot2_lds <= 150 * 1024;
+        ctx->ot_sort_cap = sc;
         {
             bool ok3 = roots_ok && c.cell_cap <= 4095; // key fields: 12-bit cell, 12-bit slot; bucket partials: 12-bit count
             for (int l = 0; l < p.nlevels; l++) ok3 = ok3 && c.lv[l].n_cells <= 4096 && c.lv[l].w_cell <= 64 && c.lv[l].h_cell <= 64; // one lane per cell column / row
@@ -383,11 +377,10 @@ static int build_config(orbfe_context *ctx)
             }
             ctx->ot3_nodes_in_hbm = orbfe_octree3_lds_bytes(c.max_nodes, sc, false) > 150 * 1024;
             ctx->ot3_lds = orbfe_octree3_lds_bytes(c.max_nodes, sc, ctx->ot3_nodes_in_hbm);
-            const char *force = getenv("ORBFE_OCTREE"); // test knob: 2 = point-parallel kernel, 1 = generic kernel
-            ctx->use_octree3 = ok3 && ctx->ot3_lds <= 150 * 1024 && !(force && (atoi(force) == 2 || atoi(force) == 1));
-            if (force && atoi(force) == 1) ctx->use_octree2 = false;
+            const char *force = getenv("ORBFE_OCTREE"); // test knob: 1 = the generic node-parallel kernel (the fallback beyond the bucket-pyramid kernel's limits)
+            ctx->use_octree3 = ok3 && ctx->ot3_lds <= 150 * 1024 && !(force && atoi(force) == 1);
         }
-        if (!ctx->use_octree3 && !ctx->use_octree2 && orbfe_octree_lds_bytes(c) > 150 * 1024)
+        if (!ctx->use_octree3 && orbfe_octree_lds_bytes(c) > 150 * 1024)
             return fail(ctx, ORBFE_ERR_UNSUPPORTED, "nfeatures too large for the quadtree LDS budget");
     }
     return ORBFE_OK;
@@ -425,7 +418,6 @@ try {
     if (hipSetDevice(p.device) != hipSuccess) { delete ctx; return fail(nullptr, ORBFE_ERR_NO_DEVICE, "hipSetDevice failed"); }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return fail(nullptr, ORBFE_ERR_NO_DEVICE, "hipStreamCreate failed"); }
     if (hipEventCreateWithFlags(&ctx->ev_latest, hipEventDisableTiming) != hipSuccess) { orbfe_destroy(ctx); return fail(nullptr, ORBFE_ERR_NO_DEVICE, "hipEventCreate failed"); }
-    if (ctx->use_octree2 && orbfe_octree2_prepare(ctx->ot2_lds) != 0) ctx->use_octree2 = false;
     if (ctx->use_octree3 && orbfe_octree3_prepare(ctx->ot3_lds, ctx->ot3_nodes_in_hbm) != 0) ctx->use_octree3 = false;
     const DeviceConfig &c = ctx->cfg;
     const size_t B = (size_t)p.max_images;
@@ -441,16 +433,14 @@ try {
     A(b.cell_base, B * c.cells_total);
     A(b.cand_xy, B * c.cand_total);
     A(b.cand_sc, B * c.cand_total);
-    A(b.cand_sc2, B * c.cand_total);
     A(b.ot_xy2, B * c.cand_total);
-    A(b.ot_sc3, B * c.cand_total);
     A(b.idx0, B * c.cand_total);
     A(b.idx1, B * c.cand_total);
     A(b.bk_end, B * c.nlevels * 4097);
     b.bk_best = nullptr;
     if (ctx->use_octree3) A(b.bk_best, B * c.nlevels * ORBFE_BK_PYR);
     b.ot3_scratch = nullptr;
-    if (ctx->use_octree3 && ctx->ot3_nodes_in_hbm) A(b.ot3_scratch, B * c.nlevels * orbfe_octree3_node_bytes(c.max_nodes, ctx->ot2_sort_cap));
+    if (ctx->use_octree3 && ctx->ot3_nodes_in_hbm) A(b.ot3_scratch, B * c.nlevels * orbfe_octree3_node_bytes(c.max_nodes, ctx->ot_sort_cap));
     A(b.lvl_ncand, B * c.nlevels);
     A(b.sel_cnt, B * c.nlevels);
     A(b.sel_xy, B * c.sel_total + 4); // + 4: stereo_rowlist_kernel reads whole quads of slots
@@ -670,7 +660,6 @@ try {
             const char *np = getenv("ORBFE_NO_PAIR");
             const bool want = !(np && np[0] == '1');
             ctx->cfg.pp_max_images = np && np[0] == '0' ? INT_MAX : 63; // ORBFE_NO_PAIR=0: pairs at every batch size (A/B)
-            { const char *rl = getenv("ORBFE_RS_LOOKUP"); ctx->cfg.rs_lookup = rl && (rl[0] == '0' || rl[0] == '1') ? rl[0] - '0' : -1; }
             for (int l = 1; l + 1 < p.nlevels; l++) {
                 LevelInfo &D1 = ctx->cfg.lv[l];
                 const LevelInfo &D2 = ctx->cfg.lv[l + 1];
@@ -831,13 +820,12 @@ try {
             return worst;
         };
         {
-            const char *bd = getenv("ORBFE_BK_DEPTH5"); // test knob: 1 = depth 5 on every level (round 3's layout: small levels bucket their candidates in the quadtree kernel)
             std::vector<uint32_t> X, Y;
             for (int l = 0; l < p.nlevels; l++) {
                 LevelInfo &L = ctx->cfg.lv[l];
                 L.bk_depth = ORBFE_BK_DEPTH;
                 build_tabs(L, ORBFE_BK_DEPTH, X, Y);
-                if (!(bd && bd[0] == '1') && max_cell_buckets(L, X, Y) > 64) {
+                if (max_cell_buckets(L, X, Y) > 64) { // depth 4 where a FAST cell would span more than 64 depth-5 buckets (else the quadtree kernel buckets that level's candidates one by one)
                     std::vector<uint32_t> X4, Y4;
                     build_tabs(L, ORBFE_BK_DEPTH - 1, X4, Y4);
                     if (max_cell_buckets(L, X4, Y4) <= 64) { L.bk_depth = ORBFE_BK_DEPTH - 1; X.swap(X4); Y.swap(Y4); }
@@ -1016,6 +1004,7 @@ extern "C" void orbfe_destroy(orbfe_context *ctx)
     }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_latest) hipEventDestroy(ctx->ev_latest);
+    if (ctx->ev_pack) { if (ctx->ev_pack_set) hipEventSynchronize(ctx->ev_pack); hipEventDestroy(ctx->ev_pack); }
     if (ctx->match) orbfe_match_state_destroy(ctx->match);
     if (ctx->bow) orbfe_bow_state_destroy(ctx->bow);
     if (ctx->pose) orbfe_pose_state_destroy(ctx->pose);
@@ -1185,8 +1174,8 @@ static DeviceBuffers shift_buffers(const DeviceBuffers &b, const DeviceConfig &c
     o.lv0 = o.pyr + c.lv[0].pyr_off; o.lv0_stride = c.pyr_bytes; o.lv0_pitch = c.lv[0].pitch; o.lv0_packed = 0;
     o.cell_cnt += i * c.cells_total; o.cell_base += i * c.cells_total;
     o.cell_xy += i * c.cells_total * c.cell_cap; o.cell_sc += i * c.cells_total * c.cell_cap;
-    o.cand_xy += i * c.cand_total; o.cand_sc += i * c.cand_total; o.cand_sc2 += i * c.cand_total;
-    o.idx0 += i * c.cand_total; o.idx1 += i * c.cand_total; o.ot_xy2 += i * c.cand_total; o.ot_sc3 += i * c.cand_total;
+    o.cand_xy += i * c.cand_total; o.cand_sc += i * c.cand_total;
+    o.idx0 += i * c.cand_total; o.idx1 += i * c.cand_total; o.ot_xy2 += i * c.cand_total;
     o.lvl_ncand += i * c.nlevels; o.sel_cnt += i * c.nlevels;
     o.bk_part += i * c.bk_part_total; o.bk_end += i * c.nlevels * 4097;
     if (o.ot3_scratch) o.ot3_scratch += i * c.nlevels * orbfe_octree3_node_bytes(c.max_nodes, ot_sort_cap_of(c));
@@ -1239,8 +1228,7 @@ static void run_chain(orbfe_context *ctx, const uint8_t *d_images, int img0, int
     prof_mark(ctx, group, 3, s);
     orbfe_launch_fast(cfg, buf, n_images, ctx->use_octree3, s, ctx->fuse_blur ? blurred : cfg.nlevels);
     prof_mark(ctx, group, 4, s);
-    if (ctx->use_octree3) orbfe_launch_octree3(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot3_lds, ctx->ot3_nodes_in_hbm, s);
-    else if (ctx->use_octree2) orbfe_launch_octree2(cfg, buf, n_images, ctx->ot2_sort_cap, ctx->ot2_lds_pts, ctx->ot2_lds, s);
+    if (ctx->use_octree3) orbfe_launch_octree3(cfg, buf, n_images, ctx->ot_sort_cap, ctx->ot3_lds, ctx->ot3_nodes_in_hbm, s);
     else orbfe_launch_octree_generic(cfg, buf, n_images, s);
 #ifdef ORBFE_PROFILE_CUTS
     { // EXPERIMENT: see dbg_sort_sel_kernel (orbfe_describe.hip)
@@ -1289,6 +1277,7 @@ static int enqueue_batch(orbfe_context *ctx, const uint8_t *d_images, int n_unit
     }
     HIP_TRY(ctx, hipGetLastError());
     ctx->last_src = (ctx->inplace_ok && ctx->cfg.in_cn == 1 && !ctx->cfg.rm_on) ? d_images : nullptr;
+    ctx->last_src_owned = ctx->last_src && ctx->last_src == ctx->d_in;
     ctx->last_images = n_images;
     ctx->epoch++;
     ctx->prof_groups = G;
@@ -1301,7 +1290,7 @@ static int enqueue_batch(orbfe_context *ctx, const uint8_t *d_images, int n_unit
 extern "C" int orbfe_quadtree_kernel(const orbfe_context *ctx)
 try {
     if (!ctx) return 0;
-    return ctx->use_octree3 ? 3 : (ctx->use_octree2 ? 2 : 1);
+    return ctx->use_octree3 ? 3 : 1;
 } ORBFE_CATCH(nullptr)
 
 extern "C" int orbfe_set_streams(orbfe_context *ctx, int groups)
@@ -1316,6 +1305,17 @@ try {
         if (!ctx->ev_join[g]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join[g], hipEventDisableTiming));
     }
     ctx->groups = groups;
+    return ORBFE_OK;
+} ORBFE_CATCH(ctx)
+
+// Level 0 of a batched call on packed grey images is the caller's buffer itself (round 4: no ingest copy).  The kernels need it until
+// the call's work has finished; orbfe_fetch_pyramid(level 0) would need it AFTER that, which the library cannot know: it follows the
+// pointer only for callers that state here that the images of an enqueue call stay valid (and unchanged) until their next call.
+extern "C" int orbfe_set_input_retained(orbfe_context *ctx, int retained)
+try {
+    ORBFE_ENTRY(ctx);
+    if (!ctx) return ORBFE_ERR_INVALID;
+    ctx->input_retained = retained != 0;
     return ORBFE_OK;
 } ORBFE_CATCH(ctx)
 
@@ -1570,6 +1570,15 @@ try {
                 (void)hipGetLastError();
                 return fail(ctx, ORBFE_ERR_INVALID, "ORBFE_PACK_DIRECT needs pinned host memory that the device addresses at the same pointer (hipHostMalloc / hipHostRegister)");
             }
+            // ... and the pinned range must hold the whole block: the gather kernel stores lay.bytes from the pointer on
+            hipDeviceptr_t base = nullptr;
+            size_t range = 0;
+            if (hipMemGetAddressRange(&base, &range, (hipDeviceptr_t)host_block) == hipSuccess) {
+                if ((const uint8_t *)host_block + lay.bytes > (const uint8_t *)base + range)
+                    return fail(ctx, ORBFE_ERR_CAPACITY, "ORBFE_PACK_DIRECT: the pinned range ends %zu bytes after the pointer, the block needs %zu", (size_t)((const uint8_t *)base + range - (const uint8_t *)host_block), lay.bytes);
+            } else {
+                (void)hipGetLastError(); // the runtime cannot tell (registered memory on some versions): the caller's host_bytes stands
+            }
         }
         orbfe_launch_pack_results(ctx->cfg, ctx->buf, (uint8_t *)host_block, po, lay.n_images_out, (flags & ORBFE_PACK_LEFT_ONLY) ? 2 : 1, (flags & ORBFE_PACK_STEREO) != 0, pick_stream(ctx, stream));
         HIP_TRY(ctx, hipGetLastError());
@@ -1580,15 +1589,21 @@ try {
         packed_layout(ctx, ctx->params.max_images, 0, &mx); // every image slot, plus uRight / depth of half of them
         const size_t want = mx.bytes + 2 * (((size_t)4 * ((size_t)ctx->params.max_images / 2 + 1) * (size_t)ctx->cfg.sel_total + 63) & ~(size_t)63);
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->ev_pack_set) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_pack)); // a copy out of the old staging may be in flight on a caller's stream
         if (ctx->d_pack) (void)hipFree(ctx->d_pack);
         ctx->d_pack = nullptr; ctx->d_pack_bytes = 0;
         HIP_TRY(ctx, hipMalloc((void **)&ctx->d_pack, want));
         ctx->d_pack_bytes = want;
     }
     hipStream_t s = pick_stream(ctx, stream);
+    // ONE staging buffer per context: a fetch queued on another stream while the previous copy is still in flight must not refill it
+    if (!ctx->ev_pack) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_pack, hipEventDisableTiming));
+    if (ctx->ev_pack_set) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_pack, 0));
     orbfe_launch_pack_results(ctx->cfg, ctx->buf, ctx->d_pack, po, lay.n_images_out, (flags & ORBFE_PACK_LEFT_ONLY) ? 2 : 1, (flags & ORBFE_PACK_STEREO) != 0, s);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(host_block, ctx->d_pack, lay.bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_pack, s));
+    ctx->ev_pack_set = true;
     return ORBFE_OK;
 } ORBFE_CATCH(ctx)
 
@@ -1950,7 +1965,12 @@ try {
             }
         return ORBFE_OK;
     }
-    if (level == 0 && !blurred && ctx->last_src) { // read in place by the latest call: level 0 IS the caller's image (which must still be there)
+    if (level == 0 && !blurred && ctx->last_src) { // read in place by the latest call: level 0 IS the caller's image
+        // ... which the library does not own: a caller may have freed or reused it once the call's work was done (legal since ABI 1), so
+        // the raw pointer is only followed when it is the library's own staging or the caller has promised to keep its images
+        if (!ctx->last_src_owned && !ctx->input_retained)
+            return fail(ctx, ORBFE_ERR_UNSUPPORTED, "level 0 of the latest call is the caller's own image buffer (read in place, never copied): "
+                                                    "call orbfe_set_input_retained(ctx, 1) if that buffer is still valid, or read the images there");
         HIP_TRY(ctx, hipMemcpy2D(dst, dst_stride, ctx->last_src + (size_t)image * ctx->cfg.in_image_bytes, (size_t)L.w, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost));
         return ORBFE_OK;
     }

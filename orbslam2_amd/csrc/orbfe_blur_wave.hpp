@@ -127,7 +127,7 @@ __device__ __forceinline__ void blur_wave(const DeviceConfig &cfg, const DeviceB
             const unsigned xo = lane0 ? 0u : (unsigned)(x0 - 4);
             blur_wave_rows(cfg, L, r0, dst, [&](int y, unsigned &w0, unsigned &w1, unsigned &w2) {
                 const unsigned ro = row_off(y), sh = ro & 3u;
-                const uint4 q = *(const uint4 *)(sbase + (ro & ~3u) + xo);
+                const uint4 q = load16_unaligned(sbase + (ro & ~3u) + xo); // 4-byte aligned, not 16
                 w0 = __builtin_amdgcn_alignbyte(q.y, q.x, sh); w1 = __builtin_amdgcn_alignbyte(q.z, q.y, sh); w2 = __builtin_amdgcn_alignbyte(q.w, q.z, sh);
                 if (strip == 0) { // uniform
                     const unsigned t = __builtin_amdgcn_perm(w1, w0, 0x01020304u);
@@ -158,7 +158,7 @@ __device__ __forceinline__ void blur_wave(const DeviceConfig &cfg, const DeviceB
             unsigned ld = want & ~3u;
             ld = ld > end16 ? end16 : ld;
             unsigned sh = want - ld; // 0 .. 4
-            uint4 q = *(const uint4 *)(sbase + ld);
+            uint4 q = load16_any(sbase + ld); // the clamped window may start at any byte
             if (sh >= 4u) { q.x = q.y; q.y = q.z; q.z = q.w; sh -= 4u; }
             const unsigned A0 = __builtin_amdgcn_alignbyte(q.y, q.x, sh), A1 = __builtin_amdgcn_alignbyte(q.z, q.y, sh), A2 = __builtin_amdgcn_alignbyte(q.w, q.z, sh);
             w0 = __builtin_amdgcn_perm(A1, A0, selA[0]) | __builtin_amdgcn_perm(0u, A2, selB[0]);

@@ -195,6 +195,14 @@ __device__ __forceinline__ uint4 load16_unaligned(const uint8_t *p)
     return make_uint4(t.x, t.y, t.z, t.w);
 }
 
+// 16 bytes from ANY byte address (still one global_load_dwordx4: the target runs in unaligned access mode)
+struct __attribute__((packed, aligned(1))) orbfe_u4_any { uint32_t x, y, z, w; };
+__device__ __forceinline__ uint4 load16_any(const uint8_t *p)
+{
+    const orbfe_u4_any t = *(const orbfe_u4_any *)p;
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+
 // 12 bytes from any address: one global_load_dwordx3
 struct __attribute__((packed, aligned(4))) orbfe_u3_unaligned { uint32_t x, y, z; };
 

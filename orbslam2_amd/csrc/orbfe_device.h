@@ -85,7 +85,6 @@ struct DeviceConfig {
     int patch_n;           // entries in DeviceBuffers::patch_uv (multiple of 64)
     // fused pyramid tail (pyr_tail_kernel): the last tail_n levels (2 or 3) in one launch, 0 = not used
     int tail_first, tail_n, tail_strips;
-    int rs_lookup;                     // pyr_resize_direct: first source byte of a word from the table (1), from the formula (0), by batch size (-1)
     int pp_max_images;                 // pyr_pair_kernel (two levels per launch) serves batches of up to this many images
     int tail_max_images;               // the fused tail serves batches of up to this many images; larger ones run levels tail_first.. as single launches
     int tail_src_words;                // staged words per row of level tail_first - 1 (widest strip)
@@ -131,9 +130,7 @@ struct DeviceBuffers {
     int *cell_base;      // [img][cells_total] scratch (exclusive scan)
     uint32_t *cand_xy;   // [img][cand_total]
     uint8_t *cand_sc;    // [img][cand_total]
-    uint8_t *cand_sc2;   // [img][cand_total] quadtree ping-pong (with idx0)
     uint32_t *ot_xy2;    // [img][cand_total] quadtree ping-pong partner
-    uint8_t *ot_sc3;     // [img][cand_total]
     uint32_t *idx0, *idx1; // [img][cand_total] ping-pong permutation
     uint32_t *bk_part;   // [img][bk_part_total] count | best slot << 12 | best score << 24 (ORBFE_BK_PART) of every bucket a FAST cell's
                          // survivors can fall into, cell after cell; rewritten by fast_cell_kernel every frame, summed into the
@@ -203,9 +200,6 @@ int orbfe_resize_word_base_host(int xw, int dst_w, double scale, int src_w); // 
 void orbfe_launch_blur(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int first_level, hipStream_t s);
 void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool buckets, hipStream_t s, int blur_first_level);
 void orbfe_launch_octree_generic(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
-void orbfe_launch_octree2(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, int lds_pts, size_t lds, hipStream_t s);
-size_t orbfe_octree2_lds_bytes(int max_nodes, int sort_cap, int lds_pts);
-int orbfe_octree2_prepare(size_t lds);
 // orbfe_octree3.hip
 void orbfe_launch_octree3(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, size_t lds, bool nodes_in_hbm, hipStream_t s);
 void orbfe_launch_candidates_gather(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);

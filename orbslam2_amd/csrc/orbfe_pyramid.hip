@@ -759,7 +759,7 @@ int orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int 
     // the chain's latency: 8 pairs per step 46.9 k pairs/s against 45.4 k), three direct launches carry the blur of the level below
     // and leave the last blur launch one level instead of four (64 pairs: 86.4 k -> 87.0 k, three chains in flight 96.2 -> 96.9 k)
     const bool tail = cfg.tail_first && n_images <= cfg.tail_max_images;
-    const bool lookup = cfg.rs_lookup == 1 || (cfg.rs_lookup < 0 && n_images >= 64); // ORBFE_RS_LOOKUP=1 | 0 forces; default: large batches
+    const bool lookup = n_images >= 64; // large batches are issue-bound (table), small ones latency-bound (formula: one dependent load less)
     const int last_single = tail ? cfg.tail_first - 1 : cfg.nlevels - 1;
     int blurred = 0; // levels 0 .. blurred - 1 have had their blur launched (beside the resize that reads them)
     for (int l = 1; l <= last_single; l++) {

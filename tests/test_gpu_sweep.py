@@ -1,5 +1,7 @@
 """Wider GPU parity sweep: odd geometries, feature budgets that stress every quadtree path (few / many nodes, the
 "largest first" phase, levels without cells), several scenes.  Everything is compared bit-exactly with the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -22,7 +24,14 @@ def test_stereo_frame_bit_exact(w, h, nf, seed):
     from orbslam2_amd import api
     left, right = synth.stereo_pair(w, h, seed=seed)
     fx, bf = 0.6 * w, 0.25 * w
-    ctx = api.Context(width=w, height=h, nfeatures=nf, fx=fx, fy=fx, cx=w / 2, cy=h / 2, bf=bf)
+    try:
+        ctx = api.Context(width=w, height=h, nfeatures=nf, fx=fx, fy=fx, cx=w / 2, cy=h / 2, bf=bf)
+    except api.OrbfeError as e:
+        # the forced fallback quadtree kernel (tools/r05_fullsuite.sh: ORBFE_OCTREE=1) keeps its node tables in LDS and refuses
+        # quotas beyond that budget (15000 features) loudly; by default such a geometry runs on the bucket-pyramid kernel
+        if os.environ.get("ORBFE_OCTREE") == "1" and e.code == api.ERR_UNSUPPORTED:
+            pytest.skip(str(e))
+        raise
     out = ctx.stereo_frame(left, right)
     exl, exr = O.Extractor(nfeatures=nf), O.Extractor(nfeatures=nf)
     kl, dl = exl.extract(left); kr, dr = exr.extract(right)
@@ -143,16 +152,13 @@ def test_clustered_candidates_deep_quadtree(patch, nf):
     ctx.close()
 
 
-def test_point_parallel_quadtree_kernel_still_matches(monkeypatch):
-    """ORBFE_OCTREE=2 routes the quadtree to the point-parallel kernel (the fallback beyond the pyramid kernel's limits)."""
+def test_generic_quadtree_kernel_still_matches(monkeypatch):
+    """ORBFE_OCTREE=1 routes the quadtree to the generic node-parallel kernel (the fallback beyond the bucket-pyramid kernel's limits)."""
     from orbslam2_amd import api
     left = synth.mono_image(640, 480, seed=5)
+    monkeypatch.delenv("ORBFE_OCTREE", raising=False)  # tools/r05_fullsuite.sh may have forced it for the whole run
     ctx = api.Context(width=640, height=480, nfeatures=1200)
     assert ctx.quadtree_kernel() == 3  # the default
-    ctx.close()
-    monkeypatch.setenv("ORBFE_OCTREE", "2")
-    ctx = api.Context(width=640, height=480, nfeatures=1200)
-    assert ctx.quadtree_kernel() == 2
     k, d = ctx.extract(left)
     ctx.close()
     monkeypatch.setenv("ORBFE_OCTREE", "1")
@@ -433,7 +439,14 @@ def test_fast_threshold_fallback_cells(kind):
         s = (((xx // 5) & 1) * 50 + ((yy // 7) & 1) * 25 + 80).astype(np.uint8)
         left, right = s, np.roll(s, -10, axis=1)
     fx, bf = 0.6 * w, 0.25 * w
-    ctx = api.Context(width=w, height=h, nfeatures=nf, fx=fx, fy=fx, cx=w / 2, cy=h / 2, bf=bf)
+    try:
+        ctx = api.Context(width=w, height=h, nfeatures=nf, fx=fx, fy=fx, cx=w / 2, cy=h / 2, bf=bf)
+    except api.OrbfeError as e:
+        # the forced fallback quadtree kernel (tools/r05_fullsuite.sh: ORBFE_OCTREE=1) keeps its node tables in LDS and refuses
+        # quotas beyond that budget (15000 features) loudly; by default such a geometry runs on the bucket-pyramid kernel
+        if os.environ.get("ORBFE_OCTREE") == "1" and e.code == api.ERR_UNSUPPORTED:
+            pytest.skip(str(e))
+        raise
     out = ctx.stereo_frame(left, right)
     exl, exr = O.Extractor(nfeatures=nf), O.Extractor(nfeatures=nf)
     kl, dl = exl.extract(left); kr, dr = exr.extract(right)

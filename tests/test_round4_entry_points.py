@@ -141,6 +141,15 @@ def test_level0_in_place_equals_the_ingest_copy_at_every_row_alignment(w, h, mon
             ctx.enqueue_stereo(dev.data_ptr(), 2, 0)
             ctx.synchronize()
             res[mode] = [ctx.fetch_image(i, stereo=i % 2 == 0) for i in range(4)]
+            # read in place, level 0 is the caller's buffer: the library only follows that pointer for callers that keep it valid
+            # (round-4 advisor finding); the copy plans (ORBFE_NO_INPLACE=1, or ORBFE_PYR_LDS=1 whose level 1 cannot read in place) own level 0
+            in_place = mode == "0" and os.environ.get("ORBFE_PYR_LDS") != "1"
+            try:
+                ctx.fetch_pyramid(1, 0)
+                assert not in_place
+            except api.OrbfeError as e:
+                assert in_place and e.code == -5 and "orbfe_set_input_retained" in str(e)
+                ctx.set_input_retained(True)
             lv0 = ctx.fetch_pyramid(1, 0)
             assert np.array_equal(lv0, host[1])
             blur = [ctx.fetch_pyramid(3, l, blurred=True) for l in range(2)]
