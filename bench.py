@@ -826,6 +826,9 @@ def main():
     params_blob = D.pack_params(NFEAT, 1.2, NLEVELS, 20, 7, 31, 15, 19, FX, FY, CX, CY, BF)
     blob = D.broadcast_params(params_blob, cdev)
     nf, sf, nl, ini, mn, ps, hps, et, fx, fy, cx, cy, bf = D.unpack_params(blob)
+    # ... and of the rBRIEF test table itself (north_star: "RCCL broadcast of the ORB pattern"): rank 0's 256 x 4 integers travel, every
+    # rank hands them to its contexts (orbfe_set_pattern), as ORBextractor copies the table per object (src/ORBextractor.cc:442-444)
+    pattern = D.broadcast_pattern(D.compiled_pattern() if rank == 0 else None, cdev)
 
     # one-time RCCL broadcast of the vocabulary (fbow file format) from rank 0 into every rank's HBM: the only other
     # xGMI traffic north_star allows.  Synthetic k = 10 / L = 3 tree here (no vocabulary file ships with the repo).
@@ -852,6 +855,7 @@ def main():
         c = api.Context(width=W, height=H, nfeatures=nf, scale_factor=sf, nlevels=nl, ini_th_fast=ini, min_th_fast=mn,
                         patch_size=ps, half_patch_size=hps, edge_threshold=et, fx=fx, fy=fy, cx=cx, cy=cy, bf=bf,
                         device=gpu_index, max_images=2 * pairs)
+        c.set_pattern(pattern)  # the broadcast table, not the compiled-in one (equal here; a deployment may distribute its own)
         return c
 
     ctxs = [make_ctx() for _ in range(CP)]
@@ -1055,7 +1059,8 @@ def main():
             out["config"]["vocabulary_broadcast_bytes"] = len(voc_blob)
         # what the collectives themselves saw: ranks = SUM all-reduce of 1 over the group (1 and "none" when no group exists)
         out["config"]["rccl"] = {"ranks": ranks_joined, "backend": args.backend if dist.is_initialized() else "none (single rank, no process group)",
-                                 "broadcast_bytes": (len(params_blob) + (len(voc_blob) + 8 + 32 if voc_blob is not None else 0)) if dist.is_initialized() else 0,
+                                 "broadcast_bytes": (len(params_blob) + 4096 + 32 + (len(voc_blob) + 8 + 32 if voc_blob is not None else 0)) if dist.is_initialized() else 0,
+                                 "broadcasts": ["extractor parameters", "rBRIEF pattern (256 x 4 int32 + sha256)"] + (["vocabulary blob"] if voc_blob is not None else []),
                                  "self_launched": os.environ.get("ORBFE_BENCH_SELF_LAUNCHED") == "1"}
     for c in ctxs[1:]:
         c.close()

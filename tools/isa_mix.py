@@ -39,12 +39,13 @@ UNITS = {  # translation unit -> [(kernel name fragment, report name)]
 CUTS = {"orbfe_fast.hip", "orbfe_describe.hip"}
 PHASE_NAMES = {"fast_cell_kernel<48, true>": {1: "prologue + tile staging", 3: "A: necessary test + queues", 4: "C: exact score", 5: "D / E: NMS, compaction, buckets", 0: "D / E: NMS, compaction, bucket partials"},
                "describe_kernel": {1: "prologue", 2: "slot data + raw patch loads", 3: "moments, angle, first patch staging", 0: "descriptors + records + row lists"}}
-DYN_FILES = {"fast_cell_kernel<48, true>": "r03_fast_insts.txt", "describe_kernel": "r03_desc_insts.txt"}
+ROUND = os.environ.get("ORBFE_PROFILE_ROUND", "r05")  # the per-phase instruction counts of THIS round's kernels (tools/fast_insts.sh, tools/desc_insts.sh on the cuts build)
+DYN_FILES = {"fast_cell_kernel<48, true>": ROUND + "_fast_insts.txt", "describe_kernel": ROUND + "_desc_insts.txt"}
 
 
 def measured_cycles():
     cyc = {}
-    for name in ("r02_valu_peak.json", "r03_valu_peak.json"):
+    for name in ("r02_valu_peak.json", "r03_valu_peak.json", "r05_valu_peak_sdwa.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             for op, v in json.load(open(p))["ops"].items():
@@ -170,7 +171,8 @@ def dynamic_counts(path):
 def main():
     cyc = measured_cycles()
     half = 4.13
-    res = {"method": " ".join(__doc__.split("\n\n")[1].split()), "opcodes_measured": len(cyc), "kernels": {}}
+    res = {"build_id": sys.argv[1] if len(sys.argv) > 1 else None,  # orbfe_build_id() of the sources disassembled here: bench.py replays the mix only for that build
+           "method": " ".join(__doc__.split("\n\n")[1].split()), "opcodes_measured": len(cyc), "kernels": {}}
     for unit, kernels in UNITS.items():
         path = asm_of(unit, unit in CUTS)
         for frag, name in kernels:

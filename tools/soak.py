@@ -54,8 +54,11 @@ for i in range(n):
     except (ValueError, api.OrbfeError):
         skipped = globals().get("skipped", 0) + 1
         continue
-    out = ctx.stereo_frame(left, right)
     exl, exr = O.Extractor(**kw), O.Extractor(**kw)
+    if i % 5 == 4:  # round 5: the context's own copy of the rBRIEF table (orbfe_set_pattern), here a random one inside the supported reach
+        pat = rng.integers(-13, 14, (256, 4)).astype(np.int32)
+        ctx.set_pattern(pat); exl.set_pattern(pat); exr.set_pattern(pat)
+    out = ctx.stereo_frame(left, right)
     kl, dl = exl.extract(left); kr, dr = exr.extract(right)
     ur, dp, _ = O.stereo_matches(exl, exr, kl, dl, kr, dr, bf, fx)
     ok = (np.array_equal(out["kps_left"], kl.astype(api.KP_DTYPE)) and np.array_equal(out["kps_right"], kr.astype(api.KP_DTYPE)) and
@@ -67,6 +70,8 @@ for i in range(n):
     ok = ok and (pl["kps"].tobytes() == out["kps_left"].tobytes() and pr["kps"].tobytes() == out["kps_right"].tobytes() and
                  np.array_equal(pl["desc"], out["desc_left"]) and np.array_equal(pr["desc"], out["desc_right"]) and
                  pl["u_right"].tobytes() == out["u_right"].tobytes() and pl["depth"].tobytes() == out["depth"].tobytes())
+    if i % 100 == 99:
+        print("soak: %d cases done, %d mismatches" % (i + 1, bad), flush=True)
     if not ok:
         bad += 1
         print("MISMATCH case", i, w, h, kw)
