@@ -1012,7 +1012,7 @@ def main():
                 "whole_pipeline": {"alg_bytes_per_pair": B_PAIR, "achieved": B_PAIR * value / world / 1e9,
                                    "frac": B_PAIR * value / world / 1e9 / HBM_PEAK_GBS},
                 "stage_ms_per_step_summed_over_groups": per_launch_ms,
-                "stage_ms_note": "per-stage table from a separate untimed single-chain pass with events at every stage boundary; launch_ms from the timed region; 'ingest' holds no launch any more (level 0 is the caller's image, read in place: what is left is the gap between two events); 'pyramid' includes the blur of the levels that are blurred inside the resize launches (0..6 for a 64-pair batch), 'blur' holds no launch any more: the remaining levels (level 7 for a 64-pair batch) are blurred by workgroups that ride in FAST's launch ('fast'; ORBFE_BLUR_IN_FAST=0: in the quadtree launch); roofline.alg_bytes_per_launch = FAST's bytes + that level's blur (blur_levels_riding_in_launch); ORBFE_NO_FUSE=1 separates them all"}
+                "stage_ms_note": "per-stage table from a separate untimed single-chain pass with events at every stage boundary; launch_ms from the timed region; 'ingest' holds no launch (level 0 is the caller's image, read in place: what is left is the gap between two events); 'pyramid' = the resize launches alone for batches of 64 images and more (round 5: the blur of every level rides in FAST's launch, blur_levels_riding_in_launch; smaller batches blur beside the resize launches), 'blur' holds no launch; roofline.alg_bytes_per_launch = FAST's bytes + the riding levels' blur; ORBFE_NO_FUSE=1 separates them all"}
         roof["build_id"] = lib_build_id()
         roof["traffic_source"] = ("replayed from profiles/%s_traffic.json (rocprofv3 --pmc passes of this build: build ids match)" % PROFILE_ROUND) if roof["traffic"] else None
         if roof["traffic"]:
