@@ -254,3 +254,48 @@ def test_the_checkers_themselves_on_oracle_made_stand_in_pins():
     bad = dict(pr); bad["atan2_out"] = pr["atan2_out"].copy(); bad["atan2_out"][3] = np.nextafter(bad["atan2_out"][3], np.float32(400))
     with pytest.raises(AssertionError, match="fastAtan2"):
         _check_primitives(bad)
+
+
+def test_kit_end_to_end_with_oracle_made_containers(tmp_path):
+    """export_inputs -> (a Python stand-in for the `pin` binary that writes the SAME record names from the oracle) -> import_pins ->
+    the pin checker: proves the plumbing (file names, record names, dtypes, the 28-byte keypoint records, the params vector), so the first
+    real run of the kit does not die on it.  Also: every record name the checkers read is a name pin.cpp writes."""
+    import export_inputs as EX
+    import import_pins as IP
+    from oracle import oracle as O
+    src = open(os.path.join(KIT, "pin.cpp")).read()
+    written = set(re.findall(r'w\.put(?:_mat_u8|_f32|_i32|_keys)?\("([a-z0-9_]+)"', src))
+    for prefix in ("pyr", "blur", "resize", "fast", "undist", "resize_any_"):  # names completed with std::to_string at run time
+        assert ('"%s" + std::to_string' % prefix) in src or ('"%s' % prefix) in src, prefix
+    need_case = {"params", "kl", "kr", "dl", "dr", "u_right", "depth", "scale", "inv_scale", "sigma2", "inv_sigma2"}
+    need_prim = {"cvround_f_in", "cvround_f_out", "cvround_d_in", "cvround_d_out", "atan2_y", "atan2_x", "atan2_out", "resize_any_src", "cvt_rgb_in", "cvt_rgba_in",
+                 "cvt_rgb2gray", "cvt_bgr2gray", "cvt_rgba2gray", "cvt_bgra2gray", "remap_src", "remap_mx", "remap_my", "remap_out"}
+    assert need_case <= written and need_prim <= written, (need_case - written, need_prim - written)
+
+    in_dir, pin_dir, out_dir = tmp_path / "in", tmp_path / "pins", tmp_path / "npz"
+    EX.main(str(in_dir)); os.makedirs(pin_dir)
+    row = next(r.split() for r in open(in_dir / "cases.txt").read().splitlines() if r.startswith("stereo_400x160_f300 "))
+    name, lf, rf, nf, fx, bf, scale, levels, ini, mn = row[0], row[1], row[2], int(row[3]), float(row[4]), float(row[5]), float(row[6]), int(row[7]), int(row[8]), int(row[9])
+    left, right = IP.read_pgm(str(in_dir / lf)), IP.read_pgm(str(in_dir / rf))
+    exl, exr = O.Extractor(nfeatures=nf), O.Extractor(nfeatures=nf)
+    kl, dl = exl.extract(left); kr, dr = exr.extract(right)
+    ur, dp, _ = O.stereo_matches(exl, exr, kl, dl, kr, dr, bf, fx)
+    code = {np.dtype(np.uint8): 0, np.dtype(np.int32): 1, np.dtype(np.float32): 2, np.dtype(np.float64): 3}
+
+    def rec(f, k, v):
+        v = np.ascontiguousarray(v)
+        f.write(struct.pack("<I", len(k)) + k.encode() + struct.pack("<II", code[v.dtype], v.ndim) + struct.pack("<%dI" % v.ndim, *v.shape) + v.tobytes())
+    with open(pin_dir / (name + ".pin"), "wb") as f:
+        f.write(b"ORBPIN01")
+        rec(f, "params", np.array([left.shape[1], left.shape[0], nf, fx, bf, scale, levels, ini, mn], np.float64))
+        rec(f, "kl", np.frombuffer(kl.tobytes(), np.uint8).reshape(len(kl), 28)); rec(f, "kr", np.frombuffer(kr.tobytes(), np.uint8).reshape(len(kr), 28))
+        rec(f, "dl", dl); rec(f, "dr", dr); rec(f, "u_right", ur); rec(f, "depth", dp); rec(f, "sad", np.zeros(len(kl), np.int32))
+        for l in range(levels):
+            rec(f, "pyr%d" % l, exl.pyramid_level(l)); rec(f, "blur%d" % l, O.gaussian7(exl.pyramid_level(l)))
+        for k, v in (("scale", exl.scale_factors()), ("inv_scale", exl.inv_scale_factors()), ("sigma2", exl.sigma2()), ("inv_sigma2", exl.inv_sigma2())):
+            rec(f, k, v)
+    open(pin_dir / "opencv_version.txt", "w").write("stand-in\n")
+    IP.main(str(in_dir), str(pin_dir), str(out_dir))
+    g = np.load(out_dir / ("case_" + name + ".npz"))
+    assert g["kl"].dtype == IP.KP_DTYPE and np.array_equal(g["left"], left)
+    _check_case(g)
