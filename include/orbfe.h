@@ -241,7 +241,8 @@ int orbfe_synchronize(orbfe_context *ctx, void *stream);
  * streams forked from / joined to the caller's stream (overlaps barrier-bound and ALU-bound stages). */
 int orbfe_set_streams(orbfe_context *ctx, int groups);
 /* Which DistributeOctTree kernel this context uses (src/ORBextractor.cc:533-757): 3 = bucket pyramid,
- * 2 = point-parallel, 1 = generic node-parallel (chosen at create time from the geometry / LDS limits). */
+ * 1 = generic node-parallel (chosen at create time from the geometry / LDS limits; 2 was the point-parallel
+ * kernel, removed in round 5). */
 int orbfe_quadtree_kernel(const orbfe_context *ctx);
 /* Copy the results of image slot `image` to host.  u_right/depth may be NULL.  The blocking fetch functions
  * (orbfe_fetch_image / _counts / _keys_un / _pyramid / _candidates) first wait for the stream of the latest

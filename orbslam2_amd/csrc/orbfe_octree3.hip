@@ -14,9 +14,9 @@
 //   2. counts and best keys are summed / maximised up the quadrant pyramid (depths 4..0);
 //   3. the split passes work on the node list alone (<= max_nodes entries in LDS): a node is
 //      (box, depth, path), its child counts are pyramid look-ups, and the list-order bookkeeping, the
-//      "largest node first" phase and the stop rules are those of the point-parallel kernel
-//      (orbfe_octree.hip), which tests/octree_model.py validates against the literal std::list
-//      restatement.  No pass touches the points again;
+//      "largest node first" phase and the stop rules are those of tests/octree_model.py, which is
+//      validated against the literal std::list restatement (and were the point-parallel kernel's, which
+//      round 5 removed).  No pass touches the points again;
 //   4. the surviving point of a node is a best-key look-up.
 // Nodes deeper than the bucket depth (clustered candidates with a generous quota) take a slow path:
 // the candidates are counting-sorted by bucket once (HBM scratch), and a deep node classifies the few

@@ -1,10 +1,10 @@
-// orbfe_octree_generic.hip -- DistributeOctTree (src/ORBextractor.cc:533-757), generic node-parallel kernel: last fallback of orbfe_octree3.hip / orbfe_octree.hip.
+// orbfe_octree_generic.hip -- DistributeOctTree (src/ORBextractor.cc:533-757), generic node-parallel kernel: the fallback of orbfe_octree3.hip (geometries beyond the bucket-pyramid kernel's limits).
 #include "orbfe_common.hpp"
 
 #define OT_THREADS 512
 
 // ---------------------------------------------------------------------------
-// DistributeOctTree, generic node-parallel kernel (any n_ini; fallback of orbfe_octree.hip): one workgroup per (image, level)
+// DistributeOctTree, generic node-parallel kernel (any n_ini; fallback of orbfe_octree3.hip): one workgroup per (image, level)
 // ---------------------------------------------------------------------------
 // Array formulation validated on the CPU by tests/octree_model.py:
 //  * nodes live in an array kept in std::list order (front -> back);
