@@ -18,7 +18,7 @@
 // tile u of the flattened (level, row band, 256-column strip) list, by one wave.  `fetch(y, w0, w1, w2)` delivers the three
 // words of input row y around the lane's four columns (bytes x0 - 4 .. x0 + 7, reflect-101 outside the image).
 template <class Fetch>
-__device__ __forceinline__ void blur_wave_rows(const DeviceConfig &cfg, const LevelInfo &L, int r0, uint8_t *dst, Fetch fetch)
+__device__ __forceinline__ void blur_wave_rows(const DeviceConfig &cfg, const LevelInfo &L, int r0, __amdgpu_buffer_rsrc_t dst, unsigned dst_off, Fetch fetch)
 {
     const unsigned tile_row_bytes = (unsigned)L.blur_tx << 7;
     unsigned tw[4][3]; // tw[j][q]: taps against the bytes of word q for pixel j; byte 4 q + b meets tap 4 q + b - 1 - j
@@ -40,6 +40,7 @@ __device__ __forceinline__ void blur_wave_rows(const DeviceConfig &cfg, const Le
     // 0 k0 | k1 k2 | k3 k4 | k5 k6 against the same four pairs: four v_dot2_u32_u16 per pixel either way, and only one pair is
     // formed per two rows (pairs at every row start, which the three-dot2-plus-mad form needs, cost twice the packing ops).
     typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned bw_v4 __attribute__((ext_vector_type(4)));
     const unsigned short k0 = (unsigned short)cfg.taps[0], k1 = (unsigned short)cfg.taps[1], k2 = (unsigned short)cfg.taps[2], k3 = (unsigned short)cfg.taps[3];
     const unsigned short k4 = (unsigned short)cfg.taps[4], k5 = (unsigned short)cfg.taps[5], k6 = (unsigned short)cfg.taps[6];
     const u16x2 te[4] = {{k0, k1}, {k2, k3}, {k4, k5}, {k6, 0}}, to[4] = {{0, k0}, {k1, k2}, {k3, k4}, {k5, k6}};
@@ -89,7 +90,7 @@ __device__ __forceinline__ void blur_wave_rows(const DeviceConfig &cfg, const Le
         if (!(a & 1)) { og.x = o2[0]; og.y = o2[1]; continue; }
         og.z = o2[0]; og.w = o2[1];
         // rows 2a - 2 .. 2a + 1 = one row of tiles; rows past the level in the last one are allocated and never read
-        if (r0 + 2 * a - 2 < L.h) *(uint4 *)(dst + (unsigned)(a >> 1) * tile_row_bytes) = og;
+        if (r0 + 2 * a - 2 < L.h) __builtin_amdgcn_raw_buffer_store_b128((bw_v4){og.x, og.y, og.z, og.w}, dst, dst_off, (unsigned)(a >> 1) * tile_row_bytes, 0);
     }
 }
 
@@ -107,7 +108,11 @@ __device__ __forceinline__ void blur_wave(const DeviceConfig &cfg, const DeviceB
     // being eight 4 x 4 px blocks of 16 B: the lane's four columns of four rows are ONE 16-byte store and a wave's store
     // instruction fills eight whole lines (one dword per row in row-major tiles meant 32-B pieces of eight lines per store:
     // 0.097 -> 0.084 ms)
-    uint8_t *dst = buf.blur + (size_t)img * cfg.blur_bytes + L.blur_off + (((unsigned)(r0 >> 2) * L.blur_tx + (x0 >> 5)) << 7) + ((x0 & 31) << 2);
+    // Buffer addressing (round 5): descriptor (wave-uniform base) + scalar row offset + the lane's 32-bit offset: no 64-bit vector add per
+    // row load / tile store (these waves ride in FAST's launch, where every vector instruction is paid for at FAST's issue rate).
+    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(buf.blur + (size_t)img * cfg.blur_bytes + L.blur_off + (((unsigned)(r0 >> 2) * L.blur_tx) << 7), 0,
+                                                                       (BL_ROWS / 4) * (L.blur_tx << 7), ORBFE_RSRC_FLAGS);
+    const unsigned dst_off = ((unsigned)(x0 >> 5) << 7) + (((unsigned)x0 & 31u) << 2);
     if (level == 0 && buf.lv0_packed) {
         // Level 0 read in place from the caller's packed image (round 4): rows at any alignment and no margin.  A lane's 12 bytes
         // come from ONE 128-bit load at the 4-byte boundary below them (byte-aligned loads cost the texture addresser about twice
@@ -125,9 +130,11 @@ __device__ __forceinline__ void blur_wave(const DeviceConfig &cfg, const DeviceB
         if (!last) {
             const bool lane0 = strip == 0 && lane == 0; // columns -4 .. -1 are columns 4 .. 1
             const unsigned xo = lane0 ? 0u : (unsigned)(x0 - 4);
-            blur_wave_rows(cfg, L, r0, dst, [&](int y, unsigned &w0, unsigned &w1, unsigned &w2) {
+            typedef unsigned bw_v4 __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t src0 = __builtin_amdgcn_make_buffer_rsrc((void *)sbase, 0, (unsigned)__mul24(h, pitch) + a0, ORBFE_RSRC_FLAGS); // every window of these strips ends inside its row
+            blur_wave_rows(cfg, L, r0, dst, dst_off, [&](int y, unsigned &w0, unsigned &w1, unsigned &w2) {
                 const unsigned ro = row_off(y), sh = ro & 3u;
-                const uint4 q = load16_unaligned(sbase + (ro & ~3u) + xo); // 4-byte aligned, not 16
+                const bw_v4 q = __builtin_amdgcn_raw_buffer_load_b128(src0, xo, ro & ~3u, 0); // 4-byte aligned, not 16
                 w0 = __builtin_amdgcn_alignbyte(q.y, q.x, sh); w1 = __builtin_amdgcn_alignbyte(q.z, q.y, sh); w2 = __builtin_amdgcn_alignbyte(q.w, q.z, sh);
                 if (strip == 0) { // uniform
                     const unsigned t = __builtin_amdgcn_perm(w1, w0, 0x01020304u);
@@ -153,7 +160,7 @@ __device__ __forceinline__ void blur_wave(const DeviceConfig &cfg, const DeviceB
             selA[q] = sa; selB[q] = sb;
         }
         const unsigned end16 = (unsigned)__mul24(h, pitch) + a0 - 16u; // last 16-byte load that stays inside the image
-        blur_wave_rows(cfg, L, r0, dst, [&](int y, unsigned &w0, unsigned &w1, unsigned &w2) {
+        blur_wave_rows(cfg, L, r0, dst, dst_off, [&](int y, unsigned &w0, unsigned &w1, unsigned &w2) {
             const unsigned want = row_off(y) + (unsigned)xs; // first byte of the window
             unsigned ld = want & ~3u;
             ld = ld > end16 ? end16 : ld;
@@ -167,10 +174,13 @@ __device__ __forceinline__ void blur_wave(const DeviceConfig &cfg, const DeviceB
         });
         return;
     }
-    const uint8_t *src = buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off + x0;
+    // extended row 0, extended column 0 of the level (rows - PYR_MY .. h + PYR_MY - 1 are materialised; y >= -3 here)
     const int pitch = L.pitch;
-    blur_wave_rows(cfg, L, r0, dst, [&](int y, unsigned &w0, unsigned &w1, unsigned &w2) {
-        const uint32_t *row = (const uint32_t *)(src + __mul24(y, pitch));
-        w0 = row[-1]; w1 = row[0]; w2 = row[1];
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(buf.pyr + (size_t)img * cfg.pyr_bytes + L.pyr_off - (PYR_MY * pitch + PYR_MX), 0,
+                                                                       (L.h + 2 * PYR_MY) * pitch, ORBFE_RSRC_FLAGS);
+    typedef unsigned bw_v3 __attribute__((ext_vector_type(3)));
+    blur_wave_rows(cfg, L, r0, dst, dst_off, [&](int y, unsigned &w0, unsigned &w1, unsigned &w2) {
+        const bw_v3 v = __builtin_amdgcn_raw_buffer_load_b96(src, (unsigned)x0, (unsigned)__mul24(y + PYR_MY, pitch), 0); // bytes x0 - 4 .. x0 + 7 of row y
+        w0 = v.x; w1 = v.y; w2 = v.z;
     });
 }

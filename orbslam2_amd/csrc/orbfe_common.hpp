@@ -10,6 +10,7 @@
 typedef short pk16 __attribute__((ext_vector_type(2))); // two int16 lanes in one VGPR (v_pk_* ops)
 #define PYR_MX 4 // reflect-101 margin of every pyramid level: pixels left of column 0 ...
 #define PYR_MY 3 // ... and rows above row 0 / below the last row
+#define ORBFE_RSRC_FLAGS 0x00020000 // word 3 of a gfx9 raw buffer descriptor (__builtin_amdgcn_make_buffer_rsrc): 32-bit data format, no swizzle, no stride
 
 // ---------------------------------------------------------------------------
 // small helpers

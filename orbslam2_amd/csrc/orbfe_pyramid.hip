@@ -305,9 +305,11 @@ int orbfe_resize_word_base_host(int xw, int dst_w, double scale, int src_w) { re
 // alignment, so the 96-bit window is loaded at the row's own 4-byte boundary and the byte shift is per row; the one window that
 // could reach past the image's last byte (last source row, last words) is loaded 12 bytes before the image's end instead and
 // shifted into place.  The first workgroup of every image also clears the image's status word (ingest's job in copy mode).
+// Buffer addressing (round 5): descriptor (wave-uniform base) + scalar row offset + the lane's own 32-bit offset, so a row's address costs
+// no vector instruction (flat addressing made every load / store a 64-bit vector add, the stores a v_mad_i64_i32 as well).
 struct ResizeStoreGlobal { // the word of extended row y goes to the level's row in HBM
-    uint8_t *dst; int pitch;
-    __device__ __forceinline__ void operator()(int y, uint32_t out) const { *(uint32_t *)(dst + (ptrdiff_t)(y - PYR_MY) * pitch) = out; }
+    __amdgpu_buffer_rsrc_t dst; unsigned off, pitch; // dst = extended row 0 of the lane's image and level, off = the lane's word in a row
+    __device__ __forceinline__ void operator()(int y, uint32_t out) const { __builtin_amdgcn_raw_buffer_store_b32(out, dst, off, (unsigned)y * pitch, 0); }
 };
 // word xw of the extended rows y0 .. min(y0 + RB, y_end) - 1 of `level`; store(y, word) receives the results
 // LOOKUP: the word's first source byte from the host table instead of the double-precision formula: 45 fewer VALU instructions per
@@ -323,7 +325,8 @@ __device__ __forceinline__ void resize_direct_wave(const DeviceConfig &cfg, cons
     const int lane = threadIdx.x & 63;
     if (PACKED0 && strip == 0 && band == 0 && lane == 0) buf.status[img] = 0;
     const int xw = strip * 64 + lane;
-    const ResizeStoreGlobal st = {buf.pyr + (size_t)img * cfg.pyr_bytes + D.pyr_off + (xw * 4 - PYR_MX), D.pitch};
+    uint8_t *drow0 = buf.pyr + (size_t)img * cfg.pyr_bytes + D.pyr_off - (PYR_MY * D.pitch + PYR_MX); // extended row 0, extended column 0
+    const ResizeStoreGlobal st = {__builtin_amdgcn_make_buffer_rsrc(drow0, 0, D.rs_ytab_n * D.pitch, ORBFE_RSRC_FLAGS), (unsigned)xw * 4u, (unsigned)D.pitch};
     resize_direct_rows<RB, PACKED0, ResizeStoreGlobal, LOOKUP>(cfg, buf, level, img, xw, band * RB, D.rs_ytab_n, st);
 }
 
@@ -346,16 +349,16 @@ __device__ __forceinline__ void resize_direct_rows(const DeviceConfig &cfg, cons
     // three words in ONE global_load_dwordx3 (a struct of three fields is split into two overlapping 64-bit loads as soon as its
     // fields are selected between, as the clamped-window fix-up below does)
     typedef uint32_t win_v __attribute__((ext_vector_type(3)));
-    typedef win_v win_ld __attribute__((aligned(4)));
     struct win_t { uint32_t x, y, z; };
-    auto ld_win = [](const uint8_t *p) { const win_v v = *(const win_ld *)p; win_t w; w.x = v.x; w.y = v.y; w.z = v.z; return w; };
+    auto ld_win = [](__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) { const win_v v = __builtin_amdgcn_raw_buffer_load_b96(r, voff, soff, 0); win_t w; w.x = v.x; w.y = v.y; w.z = v.z; return w; };
     const unsigned spitch = PACKED0 ? (unsigned)buf.lv0_pitch : (unsigned)S.pitch;
     const uint8_t *simg = PACKED0 ? buf.lv0 + (size_t)img * buf.lv0_stride : buf.pyr + (size_t)img * cfg.pyr_bytes + S.pyr_off;
     // copy mode: pixel (0,0) and the pitch are 4-byte aligned, the window's shift is the lane's own constant.  In place: offsets from
     // the 4-byte boundary at or below the image's first byte; a window's shift depends on its row
     const unsigned a0 = PACKED0 ? (unsigned)((uintptr_t)simg & 3u) : 0u;
-    const uint8_t *sp = PACKED0 ? simg - a0 : simg + (base & ~3);
-    const unsigned sh_fixed = (unsigned)base & 3u;
+    // source descriptor: the image's level from the 4-byte boundary at or below its first byte, to the end of its last row
+    const __amdgpu_buffer_rsrc_t sp = __builtin_amdgcn_make_buffer_rsrc((void *)(PACKED0 ? simg - a0 : simg), 0, (unsigned)S.h * spitch + (PACKED0 ? a0 : 64u), ORBFE_RSRC_FLAGS); // copy mode: a last-row window may run into the bottom margin
+    const unsigned voff_fixed = (unsigned)base & ~3u, sh_fixed = (unsigned)base & 3u;
     const unsigned lim = (unsigned)S.h * spitch + a0 - 12u; // PACKED0: the last window that ends inside the image
     uint32_t ye[RB], yb[RB];
 #pragma unroll
@@ -367,12 +370,12 @@ __device__ __forceinline__ void resize_direct_rows(const DeviceConfig &cfg, cons
     // offset in them.  No branch here: every load of the band is issued before anything waits (a uniform "last row" branch
     // around the load made the compiler serialise them: level 1 took 44 us instead of 28).
     auto load_win = [&](unsigned row, win_t &w, unsigned &sh) {
-        if (!PACKED0) { w = ld_win(sp + __umul24(row, spitch)); sh = sh_fixed; return; }
+        if (!PACKED0) { w = ld_win(sp, voff_fixed, __umul24(row, spitch)); sh = sh_fixed; return; }
         const unsigned off = __umul24(row, spitch) + ((unsigned)base + a0);
         unsigned ld = off & ~3u;
         ld = ld > lim ? lim : ld; // only in the image's last row, last words: never read past the image (the caller's buffer may end there)
         sh = off - ld;            // 0 .. 3, or up to 11 for a clamped window (whose bytes end at the row's last pixel)
-        w = ld_win(sp + ld);
+        w = ld_win(sp, ld, 0u);
     };
     const uint4 SEL = *(const uint4 *)(dt + 4 * xw);
     const uint4 WT = *(const uint4 *)(xt + nx + 4 * xw);
@@ -394,7 +397,7 @@ __device__ __forceinline__ void resize_direct_rows(const DeviceConfig &cfg, cons
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const unsigned pp = __builtin_amdgcn_perm(hi, lo, sel[j]); // S[sx] | S[sx1] << 16
-            h[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pp), __builtin_bit_cast(u16x2, wt[j]), 0u, false) & ~15u;
+            h[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pp), __builtin_bit_cast(u16x2, wt[j]), 0u, false) & ~15u; // < 2^20
         }
     };
     unsigned hA[4], hB[4];
@@ -408,15 +411,16 @@ __device__ __forceinline__ void resize_direct_rows(const DeviceConfig &cfg, cons
             hpass(wa[k], sa[k], (ye[k] & 0xffffu) + 1u == (unsigned)S.h, hA);
         }
         hpass(wb[k], sb[k], (ye[k] >> 16) + 1u == (unsigned)S.h, hB);
-        const unsigned b0 = (yb[k] & 0xffffu) << 12, b1 = (yb[k] >> 16) << 12; // <= 2^23
-        uint32_t out = 0;
+        const unsigned b0 = (yb[k] & 0xffffu) << 12, b1 = (yb[k] >> 16) << 12; // <= 2^23, wave-uniform
+        // (b * (h >> 4)) >> 16 = the high word of the 24 x 24-bit product (b << 12) * (h & ~15), stated as the instruction so that the
+        // operands' masks (which the values already satisfy) are not re-applied after every select between hA and hB
+        auto mulhi24 = [](unsigned b, unsigned h) { unsigned r; asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "s"(b), "v"(h)); return r; };
+        unsigned t[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const unsigned v0 = (unsigned)(((unsigned long long)(b0 & 0xffffffu) * (unsigned long long)(hA[j] & 0xffffffu)) >> 32);
-            const unsigned v1 = (unsigned)(((unsigned long long)(b1 & 0xffffffu) * (unsigned long long)(hB[j] & 0xffffffu)) >> 32);
-            out |= ((v0 + v1 + 2u) >> 2) << (8 * j);
-        }
-        store(y0 + k, out);
+        for (int j = 0; j < 4; j++) t[j] = mulhi24(b0, hA[j]) + mulhi24(b1, hB[j]) + 2u; // <= 1022
+        // bytes (t >> 2) of the four pixels: pixels 0 | 2 and 1 | 3 share a register 16 bits apart, one shift each, one byte pick
+        const unsigned e = (t[0] + (t[2] << 16)) >> 2, o = (t[1] + (t[3] << 16)) >> 2;
+        store(y0 + k, __builtin_amdgcn_perm(o, e, 0x06020400u));
     }
 }
 
@@ -707,7 +711,7 @@ __global__ __launch_bounds__(256) void pyr_pair_kernel(DeviceConfig cfg, DeviceB
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const unsigned pp = __builtin_amdgcn_perm(hi, lo, sel[j]);
-            h[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pp), __builtin_bit_cast(u16x2, wt[j]), 0u, false) & ~15u;
+            h[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pp), __builtin_bit_cast(u16x2, wt[j]), 0u, false) & ~15u; // < 2^20
         }
     };
     uint8_t *dst = buf.pyr + (size_t)img * cfg.pyr_bytes + D2.pyr_off + (xw2 * 4 - PYR_MX);
