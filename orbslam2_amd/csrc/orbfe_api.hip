@@ -736,7 +736,9 @@ try {
     std::vector<uint32_t> bk_tab_host;
     {   // FAST cell table: what fast_cell_kernel's prologue would otherwise derive per wave from a chain of dependent scalar loads
         // (level search over lv[].cell_off, a division by n_cols, the clipping of src/ORBextractor.cc:783-800)
-        std::vector<uint32_t> ci((size_t)c.cells_total * 4, 0u);
+        std::vector<uint32_t> ci((size_t)c.cells_total * 4, 0u), ca((size_t)c.cells_total * 2, 0u);
+        std::vector<uint32_t> shapes, lane_tab; // tile w | h << 8 of every distinct cell shape; [shape][64][8]
+        const int pw = orbfe_fast_tile_pitch(c) >> 2;
         for (int l = 0; l < p.nlevels; l++) {
             const LevelInfo &L = c.lv[l];
             const int max_bx = L.w - c.edge_threshold + 3, max_by = L.h - c.edge_threshold + 3;
@@ -754,8 +756,44 @@ try {
                 e[0] |= 1u << 8;
                 e[1] = (uint32_t)ini_x | ((uint32_t)ini_y << 16);
                 e[2] = (uint32_t)tw | ((uint32_t)th << 8);
+                // the divisions of fast_cell_kernel's lane maps (its prologue: tile staging by 16-byte chunks, phase A by 4-pixel groups)
+                const int iw = tw - 6, ih = th - 6;
+                const int ng = (iw + 3) >> 2, dr = 64 / ng, r0_last = ((ih - 1) / dr) * dr;
+                const int cpr = ((((tw + 3) >> 2)) + 3) >> 2, rpi = 64 / cpr;
+                uint32_t *a = &ca[(size_t)(L.cell_off + k) * 2];
+                size_t shape = 0;
+                while (shape < shapes.size() && shapes[shape] != e[2]) shape++;
+                if (shape == shapes.size()) { // phase A's per-lane constants for this tile size (fast_cell_kernel documents them)
+                    shapes.push_back(e[2]);
+                    for (int lane = 0; lane < 64; lane++) {
+                        const int rl = lane / ng, jg = lane - rl * ng, c0 = 4 * jg;
+                        const bool act = rl < dr, in_last = r0_last + rl < ih;
+                        const uint32_t vm01 = (act ? 0x8000u : 0u) | (act && c0 + 1 < iw ? 0x80000000u : 0u);
+                        const uint32_t vm23 = (act && c0 + 2 < iw ? 0x8000u : 0u) | (act && c0 + 3 < iw ? 0x80000000u : 0u);
+                        const uint32_t row[8] = {vm01, vm23, in_last ? vm01 : 0u, in_last ? vm23 : 0u,
+                                                 (uint32_t)(((rl + 1) << 8) + c0) * 0x10001u + 0x10000u, (uint32_t)(rl * pw + jg), 0u, 0u};
+                        lane_tab.insert(lane_tab.end(), row, row + 8);
+                    }
+                }
+                a[0] = (uint32_t)shape | ((uint32_t)dr << 17) | ((uint32_t)r0_last << 24);
+                a[1] = (uint32_t)((65536 + cpr - 1) / cpr) | ((uint32_t)rpi << 17);
             }
         }
+        uint32_t *d_ca = nullptr;
+        A(d_ca, ca.size());
+        if (hipMemcpy(d_ca, ca.data(), ca.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            orbfe_destroy(ctx);
+            return fail(nullptr, ORBFE_ERR_HIP, "cell table upload failed");
+        }
+        b.cell_aux = (const uint2 *)d_ca;
+        if (lane_tab.empty()) lane_tab.resize(512, 0u);
+        uint32_t *d_lt = nullptr;
+        A(d_lt, lane_tab.size());
+        if (hipMemcpy(d_lt, lane_tab.data(), lane_tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            orbfe_destroy(ctx);
+            return fail(nullptr, ORBFE_ERR_HIP, "cell table upload failed");
+        }
+        b.fast_lane_tab = d_lt;
         uint32_t *d_ci = nullptr;
         A(d_ci, ci.size());
         if (hipMemcpy(d_ci, ci.data(), ci.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {

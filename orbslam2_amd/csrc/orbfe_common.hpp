@@ -70,6 +70,28 @@ __device__ __forceinline__ bool xcd_map_of(int bid, int blocks_per_unit, int n_u
     return unit < n_units && blk < blocks_per_unit;
 }
 
+// The same map with the division done in SCALAR arithmetic: magic = ceil(2^32 / per_xcd) from the host (xcd_map_magic_host; 0 = no magic:
+// per_xcd == 1 or (grid / 8) * per_xcd >= 2^32), so round = (jb * magic) >> 32 exactly.  small_div costs every wave seven vector
+// instructions, a quarter-rate v_rcp_f32 among them, and a v_readfirstlane; fast_cell_kernel's 180 k waves per launch pay for them at its issue rate.
+__host__ __forceinline__ uint32_t xcd_map_magic_host(int blocks_per_unit, int n_units)
+{
+    const int lg = xcd_split_log2(n_units), per_xcd = (blocks_per_unit + (1 << lg) - 1) >> lg, side = 8 >> lg;
+    const unsigned long long rounds = (unsigned long long)((n_units + side - 1) / side); // jb < per_xcd * rounds
+    if (per_xcd <= 1 || (unsigned long long)per_xcd * rounds * (unsigned long long)per_xcd >= (1ull << 32)) return 0u;
+    return (uint32_t)(((1ull << 32) + (unsigned long long)per_xcd - 1ull) / (unsigned long long)per_xcd);
+}
+__device__ __forceinline__ bool xcd_map_magic(int blocks_per_unit, int n_units, uint32_t magic, int &unit, int &blk)
+{
+    if (magic == 0u) return xcd_map(blocks_per_unit, n_units, unit, blk);
+    const int bid = (int)blockIdx.x;
+    const int lg = xcd_split_log2(n_units), xcd = bid & 7, jb = bid >> 3;
+    const int per_xcd = (blocks_per_unit + (1 << lg) - 1) >> lg;
+    const int round = (int)__builtin_amdgcn_readfirstlane((int)(((unsigned long long)(unsigned)jb * (unsigned long long)magic) >> 32)); // uniform: s_mul_hi_u32
+    unit = round * (8 >> lg) + (xcd >> lg);
+    blk = ((jb - round * per_xcd) << lg) + (xcd & ((1 << lg) - 1));
+    return unit < n_units && blk < blocks_per_unit;
+}
+
 __device__ __forceinline__ int reflect101(int p, int len)
 {
     if (len == 1) return 0;

@@ -79,6 +79,7 @@ struct DeviceConfig {
     int blur_tiles_total;
     int proc_order;        // octree3_kernel also writes proc_xy / proc_meta and describe_kernel walks those (0: describe_kernel walks sel_xy; ORBFE_NO_PROC_ORDER=1, other quadtree kernels)
     int fast_blur_t0;      // blur tiles [fast_blur_t0, blur_tiles_total) ride in the FAST launch (set per launch; blur_tiles_total: none)
+    uint32_t fast_xcd_magic; // ceil(2^32 / workgroups per XCD and image round) of the FAST launch's block map (set per launch; 0: divide in the kernel)
     int max_nodes;         // quadtree node capacity (LDS)
     int bk_part_total;     // per image: entries of DeviceBuffers::bk_part
     int row_cap;           // entries per image row in DeviceBuffers::row_ent
@@ -158,6 +159,10 @@ struct DeviceBuffers {
     const uint32_t *bk_off;  // [cells_total] first bk_part entry of the cell; ~0u: the cell spans > 64 buckets (no partials)
     const uint32_t *rs_tab; // cv::resize offset/weight tables of every level (see pyr_resize_kernel)
     const uint4 *cell_info; // [cells_total] FAST cells: level | valid << 8, ini_x | ini_y << 16, tile w | h << 8, index inside the level (fast_cell_kernel)
+    const uint2 *cell_aux;  // [cells_total] the lane maps of the cell's shape, divided on the host: x = shape index (fast_lane_tab) | (64 / ng) << 17 | last band's first row << 24
+                            // (ng = 4-pixel groups per interior row), y = ceil(2^16 / cpr) | (64 / cpr) << 17 (cpr = 16-byte chunks per tile row)
+    const uint32_t *fast_lane_tab; // [shapes][64 lanes][8]: phase A's per-lane constants of a cell shape (tile w x h): pixel masks of the pairs 0 1 / 2 3, the same in
+                                   // the cell's last band, entry word of pixels 0 1, word offset of the lane's window in the LDS tile, 2 spare
     const uint32_t *blur_tile_info; // [blur_tiles_total] level | column strip << 8 | first row << 16 (blur_kernel)
     const uint32_t *rs_blk; // per (level, block of 4 * rs_rw output rows): first source row | source rows << 16 (pyr_resize_kernel)
     const int *pair_plan;   // pyr_pair_kernel: per tile column / row of a level pair {first word (row) of the LDS tile, words (rows), first, end word (row) this workgroup stores}
@@ -199,6 +204,7 @@ int orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int 
 int orbfe_resize_word_base_host(int xw, int dst_w, double scale, int src_w); // pyr_resize_direct_kernel's first-source-byte formula, for orbfe_create's check
 void orbfe_launch_blur(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int first_level, hipStream_t s);
 void orbfe_launch_fast(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool buckets, hipStream_t s, int blur_first_level);
+int orbfe_fast_tile_pitch(const DeviceConfig &cfg); // bytes per row of fast_cell_kernel's LDS tile (orbfe_create builds fast_lane_tab with it)
 void orbfe_launch_octree_generic(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, hipStream_t s);
 // orbfe_octree3.hip
 void orbfe_launch_octree3(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, int sort_cap, size_t lds, bool nodes_in_hbm, hipStream_t s);

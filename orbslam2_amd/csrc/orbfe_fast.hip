@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     const int bpi_cells = (cfg.cells_total + 3) >> 2;
     const int bpi = bpi_cells + ((cfg.blur_tiles_total - cfg.fast_blur_t0 + 3) >> 2);
     int img, blk;
-    if (!xcd_map(bpi, n_images, img, blk)) return;
+    if (!xcd_map_magic(bpi, n_images, cfg.fast_xcd_magic, img, blk)) return;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (__builtin_expect(blk >= bpi_cells, 0)) { // the image's last workgroups: blur tiles riding in this launch
         const int u = cfg.fast_blur_t0 + (blk - bpi_cells) * 4 + wave;
@@ -134,6 +134,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     // the cell's level, position and clipped tile size from the host-built table (one scalar load instead of the level search,
     // a division and the clipping of src/ORBextractor.cc:783-800 behind a chain of dependent scalar loads)
     const uint4 cinfo = const_load_u32x4(buf.cell_info + cell);
+    const uint32_t aux_g = const_load_u32((const uint32_t *)buf.cell_aux + 2 * cell), aux_c = const_load_u32((const uint32_t *)buf.cell_aux + 2 * cell + 1); // host-divided lane maps
+    // phase A's per-lane constants of this cell's shape, built on the host (35 vector instructions per wave otherwise): issued now, used after the staging
+    const uint32_t *lane_tab = buf.fast_lane_tab + ((aux_g & 0x1ffffu) << 9); // uniform
+    const uint4 lt_a = *(const uint4 *)(lane_tab + ((threadIdx.x & 63) << 3));
+    const uint2 lt_b = *(const uint2 *)(lane_tab + ((threadIdx.x & 63) << 3) + 4);
     const int level = (int)(cinfo.x & 0xffu);
     const LevelInfo &L = cfg.lv[level];
     const int ci = (int)cinfo.w;
@@ -193,8 +198,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         // to 15 bytes past the tile (inside the pyramid row's margin, or -- level 0 read in place -- the first bytes of the next row: a
         // tile ends >= 10 rows above the image's last row) into LDS bytes no pixel test uses.
         const int cpr = (wpr + 3) >> 2;
-        const int rpi = small_div(64, cpr);
-        int rl0 = small_div(lane, cpr);
+        const int rpi = (int)((aux_c >> 17) & 0x7fu);                       // 64 / cpr
+        int rl0 = (int)(__umul24((unsigned)lane, aux_c & 0x1ffffu) >> 16);  // lane / cpr
         rl0 = rl0 < rpi ? rl0 : rpi - 1;
         const int ch16 = (lane - rl0 * cpr < cpr ? lane - rl0 * cpr : 0) << 4;
         for (int rb = 0; rb < th; rb += 2 * rpi) { // two loads in flight per lane
@@ -284,26 +289,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         // because FAST cells are < 60 px wide, src/ORBextractor.cc:766-775; 8-10 for every level of the usual cameras, so 94-100 %
         // of the lanes work), which makes the column range checks, the entry's column part and the LDS column offset loop
         // invariants and leaves one add each for the address and the entries per iteration
-        const int ng = (iw + ox + 3) >> 2;       // groups per interior row; group j covers c = 4j - ox .. 4j - ox + 3
-        const int dr = 64 / ng;
-        const int rl = small_div(lane, ng), jg = lane - rl * ng;
+        const int dr = (int)((aux_g >> 17) & 0x7fu); // 64 / ng, ng = (iw + 3) >> 2 groups per interior row; group j covers c = 4 j .. 4 j + 3
         const int pw = tile_pitch >> 2;
         const pk16 tp = {(short)t, (short)t};
-        const int c0 = 4 * jg - ox;
-        const bool act = rl < dr;
-        const bool b0 = act & (c0 >= 0), b1 = act & ((unsigned)(c0 + 1) < (unsigned)iw);
-        const bool b2 = act & ((unsigned)(c0 + 2) < (unsigned)iw), b3 = act & (c0 + 3 < iw);
-        // which of the lane's four pixels exist, as sign bits of the halves (a ballot of `value & mask != 0` is one compare; a
-        // ballot of a boolean expression is a select plus a compare); the last band may be cut by the cell's bottom
-        unsigned vm01 = (b0 ? 0x8000u : 0u) | (b1 ? 0x80000000u : 0u), vm23 = (b2 ? 0x8000u : 0u) | (b3 ? 0x80000000u : 0u);
-        const int r0_last = ((ih - 1) / dr) * dr;
-        const bool in_last = r0_last + rl < ih;
-        const unsigned vl01 = in_last ? vm01 : 0u, vl23 = in_last ? vm23 : 0u;
-        // entries c | (r + 1) << 8 of the pixel pairs in the two halves (the row bias keeps the word positive when c0 < 0, which
-        // only happens for pixels that are never stored)
-        unsigned e01 = __umul24((unsigned)(((rl + 1) << 8) + c0), 0x10001u) + 0x10000u;
+        // From fast_lane_tab (orbfe_api.hip builds it with these formulas): rl = lane / ng, jg = lane - rl * ng, c0 = 4 jg; the lane works when rl < dr;
+        // vm01 / vm23: which of the lane's four pixels exist, as sign bits of the halves (a ballot of `value & mask != 0` is one compare; a
+        // ballot of a boolean expression is a select plus a compare); vl01 / vl23: the same in the last band, which the cell's bottom may cut;
+        // e01: entries c | (r + 1) << 8 of pixels 0 1 in the two halves (the row bias keeps the word positive)
+        unsigned vm01 = lt_a.x, vm23 = lt_a.y;
+        const unsigned vl01 = lt_a.z, vl23 = lt_a.w;
+        const int r0_last = (int)(aux_g >> 24); // ((ih - 1) / dr) * dr
+        unsigned e01 = lt_b.x;
         const unsigned e_step = (unsigned)(dr << 8) * 0x10001u;
-        const uint32_t *tw4 = (const uint32_t *)s_tile + (__mul24(rl, pw) + jg);
+        const uint32_t *tw4 = (const uint32_t *)s_tile + lt_b.y; // rl * pw + jg
         for (int r0 = 0; r0 < ih; r0 += dr, tw4 += dr * pw, e01 += e_step) {
             if (r0 == r0_last) { vm01 = vl01; vm23 = vl23; } // rows past the cell read LDS beyond the tile (still this wave's region)
             unsigned w0[3], w1[3], w3[3], w5[3], w6[3];
@@ -492,12 +490,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 static inline int max_cell_w(const DeviceConfig &cfg) { int m = 0; for (int l = 0; l < cfg.nlevels; l++) m = cfg.lv[l].w_cell > m ? cfg.lv[l].w_cell : m; return m; }
 static inline int max_cell_h(const DeviceConfig &cfg) { int m = 0; for (int l = 0; l < cfg.nlevels; l++) m = cfg.lv[l].h_cell > m ? cfg.lv[l].h_cell : m; return m; }
 
+int orbfe_fast_tile_pitch(const DeviceConfig &cfg) { return (max_cell_w(cfg) + 6 + 15) & ~15; } // whole 16-byte chunks (the staging stores 128 bits at a time)
+
 void orbfe_launch_fast(const DeviceConfig &cfg_in, const DeviceBuffers &buf, int n_images, bool buckets, hipStream_t s, int blur_first_level)
 {
     DeviceConfig cfg = cfg_in;
     cfg.fast_blur_t0 = blur_first_level < cfg.nlevels ? cfg.lv[blur_first_level].blur_tile_off : cfg.blur_tiles_total;
     const int mw = max_cell_w(cfg), mh = max_cell_h(cfg);
-    const int tile_pitch = (mw + 6 + 15) & ~15; // whole 16-byte chunks (the staging stores 128 bits at a time)
+    const int tile_pitch = orbfe_fast_tile_pitch(cfg);
     const int tile_rows = mh + 6;
     const int tile_bytes = (tile_pitch * tile_rows + 15) & ~15;
     const int sc_bytes = ((mw + 2) * (mh + 2) + 15) & ~15;
@@ -507,7 +507,9 @@ void orbfe_launch_fast(const DeviceConfig &cfg_in, const DeviceBuffers &buf, int
     const int tile_region = tile_bytes > mw * mh ? tile_bytes : ((mw * mh + 15) & ~15);
     const int lds_per_wave = tile_region + sc_bytes + q_bytes + 512;
     const size_t lds = (size_t)4 * lds_per_wave;
-    dim3 grid(xcd_grid((cfg.cells_total + 3) / 4 + (cfg.blur_tiles_total - cfg.fast_blur_t0 + 3) / 4, n_images));
+    const int bpi = (cfg.cells_total + 3) / 4 + (cfg.blur_tiles_total - cfg.fast_blur_t0 + 3) / 4;
+    cfg.fast_xcd_magic = xcd_map_magic_host(bpi, n_images);
+    dim3 grid(xcd_grid(bpi, n_images));
 #define FAST_LAUNCH(TP)                                                                                                                   \
     do {                                                                                                                              \
         if (buckets) hipLaunchKernelGGL((fast_cell_kernel<TP, true>), grid, dim3(256), lds, s, cfg, buf, n_images, tile_pitch, tile_region, sc_bytes, q_bytes, lds_per_wave ORBFE_CUT_ARG("ORBFE_FAST_DBG")); \
