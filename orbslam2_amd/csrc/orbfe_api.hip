@@ -237,6 +237,15 @@ static int build_config(orbfe_context *ctx)
     c.edge_threshold = p.edge_threshold;
     c.min_border = p.edge_threshold - 3;
     c.ini_th = p.ini_th_fast; c.min_th = p.min_th_fast;
+    {   // integers 0 .. 255 as IEEE half precision (exact): 0 -> 0, else exponent e = floor(log2 t) biased by 15, mantissa t's bits below the leading one
+        auto half_bits = [](int t) -> uint32_t {
+            if (t <= 0) return 0u;
+            int e = 0;
+            while ((t >> (e + 1)) != 0) e++;
+            return (uint32_t)(((e + 15) << 10) | (((t << (10 - e)) & 0x3ff)));
+        };
+        c.ini_th_h2 = half_bits(c.ini_th) * 0x10001u; c.min_th_h2 = half_bits(c.min_th) * 0x10001u;
+    }
     c.half_patch = p.half_patch_size;
     c.bf = p.bf; c.fx = p.fx;
     c.mb = p.fx != 0.f ? p.bf / p.fx : 0.f; // mb := mbf / fx

@@ -71,6 +71,7 @@ struct DeviceConfig {
     int width, height;
     int edge_threshold, min_border; // min_border = edge_threshold - 3
     int ini_th, min_th;
+    uint32_t ini_th_h2, min_th_h2; // the thresholds as half-precision numbers in both halves of a word (fast_cell_kernel's score clamp)
     int half_patch;
     int cell_cap;          // slots per FAST cell
     int cells_total;       // per image

@@ -159,8 +159,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         bk_off = const_load_u32(buf.bk_off + cell);
         const uint32_t *bx_tab = buf.bk_tab + L.bk_xoff + 3 + cell_x0; // survivor x = c + 3 + j * wCell
         const uint32_t *by_tab = buf.bk_tab + L.bk_yoff + 3 + cell_y0;
-        tabx = bx_tab[lane < iw ? lane : iw - 1];
-        taby = by_tab[lane < ih ? lane : ih - 1];
+        // (scalar base, 32-bit lane byte offset) addressing: no 64-bit vector add
+        tabx = *(const uint32_t *)((const uint8_t *)bx_tab + min((unsigned)lane << 2, (unsigned)(iw - 1) << 2));
+        taby = *(const uint32_t *)((const uint8_t *)by_tab + min((unsigned)lane << 2, (unsigned)(ih - 1) << 2));
     }
     // LDS layout (sizes fixed by the host from the largest cell): tile | scores | queue.  Queue 2 is
     // compacted in place over queue 1 (writes never pass the read cursor); the per-entry flags of
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     //      minima (v_pk_maximum3_f16 / v_pk_minimum3_f16, two queue entries per lane, one in each half) instead of 80 two-way
     //      ones.  Bright entries are negated (centre and ring), which maps their score onto the dark formula; both the negation
     //      and the byte -> f16 conversion are ONE xor.  Entries: c | (r + 1) << 8 | bright << 15. ----
-    const unsigned tt16 = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(float)t) * 0x10001u; // t in both halves
+    const unsigned tt16 = attempt == 0 ? cfg.ini_th_h2 : cfg.min_th_h2; // t as a half-precision number in both halves (from the host: a conversion and a quarter-rate multiply per wave otherwise)
     auto score_entries = [&](int count, auto fetch) {
         for (int q0 = 0; q0 < count; q0 += 128) {
             const int qa = q0 + lane, qb = q0 + 64 + lane;
