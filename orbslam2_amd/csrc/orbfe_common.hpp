@@ -80,10 +80,9 @@ __host__ __forceinline__ uint32_t xcd_map_magic_host(int blocks_per_unit, int n_
     if (per_xcd <= 1 || (unsigned long long)per_xcd * rounds * (unsigned long long)per_xcd >= (1ull << 32)) return 0u;
     return (uint32_t)(((1ull << 32) + (unsigned long long)per_xcd - 1ull) / (unsigned long long)per_xcd);
 }
-__device__ __forceinline__ bool xcd_map_magic(int blocks_per_unit, int n_units, uint32_t magic, int &unit, int &blk)
+__device__ __forceinline__ bool xcd_map_of_magic(int bid, int blocks_per_unit, int n_units, uint32_t magic, int &unit, int &blk)
 {
-    if (magic == 0u) return xcd_map(blocks_per_unit, n_units, unit, blk);
-    const int bid = (int)blockIdx.x;
+    if (magic == 0u) return xcd_map_of(bid, blocks_per_unit, n_units, unit, blk);
     const int lg = xcd_split_log2(n_units), xcd = bid & 7, jb = bid >> 3;
     const int per_xcd = (blocks_per_unit + (1 << lg) - 1) >> lg;
     const int round = (int)__builtin_amdgcn_readfirstlane((int)(((unsigned long long)(unsigned)jb * (unsigned long long)magic) >> 32)); // uniform: s_mul_hi_u32
@@ -91,6 +90,8 @@ __device__ __forceinline__ bool xcd_map_magic(int blocks_per_unit, int n_units, 
     blk = ((jb - round * per_xcd) << lg) + (xcd & ((1 << lg) - 1));
     return unit < n_units && blk < blocks_per_unit;
 }
+
+__device__ __forceinline__ bool xcd_map_magic(int blocks_per_unit, int n_units, uint32_t magic, int &unit, int &blk) { return xcd_map_of_magic((int)blockIdx.x, blocks_per_unit, n_units, magic, unit, blk); }
 
 __device__ __forceinline__ int reflect101(int p, int len)
 {

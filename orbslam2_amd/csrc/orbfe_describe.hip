@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256, 8) void describe_generic_kernel(DeviceConfig c
     // overlapping 31x31 / 37x37 patches are read, instead of every patch row coming from the MALL.
     const int bpi = (cfg.sel_total + 4 * DS_KPW - 1) / (4 * DS_KPW); // blocks per image
     int img, blk;
-    if (!xcd_map(bpi, n_images, img, blk)) return;
+    if (!xcd_map_magic(bpi, n_images, cfg.xcd_magic, img, blk)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform values must be provably so: they feed scalar addresses
     const int slot0 = blk * (4 * DS_KPW) + wave * DS_KPW;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
     }
     const int bpi = (cfg.sel_total + 4 * DS_KPW - 1) / (4 * DS_KPW); // blocks per image (XCD-aware map: see describe_generic_kernel)
     int img, blk;
-    if (!xcd_map_of(bid, bpi, n_images, img, blk)) return;
+    if (!xcd_map_of_magic(bid, bpi, n_images, cfg.xcd_magic, img, blk)) return;
     const int slot0 = blk * (4 * DS_KPW) + wave * DS_KPW;
     const int *sel_cnt = buf.sel_cnt + (size_t)img * cfg.nlevels;
     if (blk == 0 && tid == 0) {
@@ -500,8 +500,10 @@ __global__ __launch_bounds__(256, 8) void describe_kernel(DeviceConfig cfg, Devi
     }
 }
 
-void orbfe_launch_describe(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_images, bool stereo, hipStream_t s)
+void orbfe_launch_describe(const DeviceConfig &cfg_in, const DeviceBuffers &buf, int n_images, bool stereo, hipStream_t s)
 {
+    DeviceConfig cfg = cfg_in;
+    cfg.xcd_magic = xcd_map_magic_host((cfg.sel_total + 4 * DS_KPW - 1) / (4 * DS_KPW), n_images);
     dim3 grid(xcd_grid((cfg.sel_total + 4 * DS_KPW - 1) / (4 * DS_KPW), n_images));
     if (cfg.half_patch == 15) { // the reference's HALF_PATCH_SIZE
         size_t lds = 256 * sizeof(float4) + 4 * (DS_BLR_ROWS * DS_PATCH_W);

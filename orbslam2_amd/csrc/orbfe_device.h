@@ -80,7 +80,8 @@ struct DeviceConfig {
     int blur_tiles_total;
     int proc_order;        // octree3_kernel also writes proc_xy / proc_meta and describe_kernel walks those (0: describe_kernel walks sel_xy; ORBFE_NO_PROC_ORDER=1, other quadtree kernels)
     int fast_blur_t0;      // blur tiles [fast_blur_t0, blur_tiles_total) ride in the FAST launch (set per launch; blur_tiles_total: none)
-    uint32_t fast_xcd_magic; // ceil(2^32 / workgroups per XCD and image round) of the FAST launch's block map (set per launch; 0: divide in the kernel)
+    uint32_t xcd_magic;    // ceil(2^32 / workgroups per XCD and round of units) of the block map of the launch this copy is passed to (FAST, describe,
+                           // stereo match: set by the launcher, xcd_map_magic_host; 0: divide in the kernel)
     int max_nodes;         // quadtree node capacity (LDS)
     int bk_part_total;     // per image: entries of DeviceBuffers::bk_part
     int row_cap;           // entries per image row in DeviceBuffers::row_ent

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     const int bpi_cells = (cfg.cells_total + 3) >> 2;
     const int bpi = bpi_cells + ((cfg.blur_tiles_total - cfg.fast_blur_t0 + 3) >> 2);
     int img, blk;
-    if (!xcd_map_magic(bpi, n_images, cfg.fast_xcd_magic, img, blk)) return;
+    if (!xcd_map_magic(bpi, n_images, cfg.xcd_magic, img, blk)) return;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (__builtin_expect(blk >= bpi_cells, 0)) { // the image's last workgroups: blur tiles riding in this launch
         const int u = cfg.fast_blur_t0 + (blk - bpi_cells) * 4 + wave;
@@ -509,7 +509,7 @@ void orbfe_launch_fast(const DeviceConfig &cfg_in, const DeviceBuffers &buf, int
     const int lds_per_wave = tile_region + sc_bytes + q_bytes + 512;
     const size_t lds = (size_t)4 * lds_per_wave;
     const int bpi = (cfg.cells_total + 3) / 4 + (cfg.blur_tiles_total - cfg.fast_blur_t0 + 3) / 4;
-    cfg.fast_xcd_magic = xcd_map_magic_host(bpi, n_images);
+    cfg.xcd_magic = xcd_map_magic_host(bpi, n_images);
     dim3 grid(xcd_grid(bpi, n_images));
 #define FAST_LAUNCH(TP)                                                                                                                   \
     do {                                                                                                                              \

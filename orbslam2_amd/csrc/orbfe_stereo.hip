@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(DeviceConfig cfg, Dev
     const int kpb = 256 / SM_G;
     const int bpp = (cfg.sel_total + kpb - 1) / kpb;
     int pair, blk;
-    if (!xcd_map(bpp, n_pairs, pair, blk)) return;
+    if (!xcd_map_magic(bpp, n_pairs, cfg.xcd_magic, pair, blk)) return;
     const int imgL = 2 * pair, imgR = 2 * pair + 1;
     const int gl = threadIdx.x & (SM_G - 1);
     const int iL = blk * kpb + (threadIdx.x / SM_G);
@@ -424,9 +424,11 @@ void orbfe_launch_stereo_rowlists(const DeviceConfig &cfg, const DeviceBuffers &
     hipLaunchKernelGGL(stereo_rowlist_kernel, grid, dim3(256), 4 * RL_LDS_BYTES, s, cfg, buf);
 }
 
-void orbfe_launch_stereo_match(const DeviceConfig &cfg, const DeviceBuffers &buf, int n_pairs, hipStream_t s)
+void orbfe_launch_stereo_match(const DeviceConfig &cfg_in, const DeviceBuffers &buf, int n_pairs, hipStream_t s)
 {
     const int kpb = 256 / SM_G;
+    DeviceConfig cfg = cfg_in;
+    cfg.xcd_magic = xcd_map_magic_host((cfg.sel_total + kpb - 1) / kpb, n_pairs);
     dim3 grid(xcd_grid((cfg.sel_total + kpb - 1) / kpb, n_pairs));
     hipLaunchKernelGGL(stereo_match_kernel, grid, dim3(256), 0, s, cfg, buf, n_pairs);
 }
