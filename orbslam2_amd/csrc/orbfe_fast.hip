@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     }
     // LDS layout (sizes fixed by the host from the largest cell): tile | scores | queue.  Queue 2 is
     // compacted in place over queue 1 (writes never pass the read cursor); the per-entry flags of
-    // phase D reuse the tile, which is dead after phase C.  4.7 KB per wave keeps 32 waves per CU.
+    // phase D reuse the tile, which is dead after phase C.  5.2 KB per wave at KITTI's cell size: seven workgroups per CU, which is also what
+    // the kernel's 70 VGPRs allow (round 5; 72 VGPRs and six until the lane maps moved to host tables).
     uint8_t *s_tile = s_mem;                           // [th][tile_pitch], column 0 = pixel xa (4-aligned)
     uint8_t *s_sc = s_mem + tile_bytes;                // [(ih+2)][(iw+2)], zero border
     uint16_t *s_q1 = (uint16_t *)(s_sc + sc_bytes);    // packed (r << 8 | c), row-major ascending

@@ -313,8 +313,9 @@ struct ResizeStoreGlobal { // the word of extended row y goes to the level's row
 };
 // word xw of the extended rows y0 .. min(y0 + RB, y_end) - 1 of `level`; store(y, word) receives the results
 // LOOKUP: the word's first source byte from the host table instead of the double-precision formula: 45 fewer VALU instructions per
-// wave (a fifth of the kernel) for one more dependent load -- used for batches of 64 images and more, whose launches are bound by
-// instruction issue (0.3 VALU per output pixel), not by the latency of a wave's load chain (round 4: pyramid + blur 174 -> 168 us in the stage table, value + 0.9 %)
+// wave (a fifth of the kernel) for one more dependent load -- used for batches of 64 images and more (round 4: pyramid + blur 174 -> 168 us in
+// the stage table, value + 0.9 %; the blur still rode in these launches then and made them issue-bound.  Round 5: the blur rides in FAST's
+// launch and what is left here is bound by the memory path -- a third fewer instructions bought 3 % -- but the table still wins by ~1 us)
 template <int RB, bool PACKED0, class Store, bool LOOKUP = false>
 __device__ __forceinline__ void resize_direct_rows(const DeviceConfig &cfg, const DeviceBuffers &buf, int level, int img, int xw, int y0, int y_end, Store store);
 
@@ -763,7 +764,7 @@ int orbfe_launch_pyramid(const DeviceConfig &cfg, const DeviceBuffers &buf, int 
     // the chain's latency: 8 pairs per step 46.9 k pairs/s against 45.4 k), three direct launches carry the blur of the level below
     // and leave the last blur launch one level instead of four (64 pairs: 86.4 k -> 87.0 k, three chains in flight 96.2 -> 96.9 k)
     const bool tail = cfg.tail_first && n_images <= cfg.tail_max_images;
-    const bool lookup = n_images >= 64; // large batches are issue-bound (table), small ones latency-bound (formula: one dependent load less)
+    const bool lookup = n_images >= 64; // large batches: the table (fewer instructions); small ones are latency-bound: the formula (one dependent load less)
     const int last_single = tail ? cfg.tail_first - 1 : cfg.nlevels - 1;
     int blurred = 0; // levels 0 .. blurred - 1 have had their blur launched (beside the resize that reads them)
     for (int l = 1; l <= last_single; l++) {
