@@ -13,9 +13,10 @@ f = glob.glob("gpurun_out/st_%s/*/*kernel_trace.csv" % tag)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 rows = [r for r in rows if "rocclr" not in r["Kernel_Name"] and "candidates_gather" not in r["Kernel_Name"]]
 steps, cur = [], []
+last = "stereo_median" if any("stereo_median" in r["Kernel_Name"] for r in rows) else "stereo_match"  # the step's last launch (round 5: the median cut rides in the matcher's launch)
 for r in rows:
     cur.append(r)
-    if "stereo_median" in r["Kernel_Name"]:
+    if last in r["Kernel_Name"]:
         steps.append(cur); cur = []
 n = collections.Counter(len(s) for s in steps).most_common(1)[0][0]
 steps = [s for s in steps if len(s) == n][2:]
