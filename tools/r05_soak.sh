@@ -7,4 +7,4 @@ echo "build: $(python3 -c "import ctypes; l = ctypes.CDLL('orbslam2_amd/liborbfe
 SOAK_GEOM=1 SOAK_SEED=${SOAK_BASE:-710000} timeout -k 10 1000 python3 tools/soak.py ${1:-700}
 ORBFE_BLUR_RIDE_FROM=0 SOAK_GEOM=1 SOAK_SEED=$((${SOAK_BASE:-710000} + 10000)) timeout -k 10 900 python3 tools/soak.py ${2:-500}
 ORBFE_BLUR_RIDE_FROM=3 SOAK_PATCH=1 SOAK_SEED=$((${SOAK_BASE:-710000} + 20000)) timeout -k 10 600 python3 tools/soak.py ${3:-300}
-} 2>&1 | grep -v "amdgpu.ids" | tee gpurun_out/r05/soak.txt
+} 2>&1 | grep --line-buffered -v "amdgpu.ids" | tee gpurun_out/r05/soak.txt
